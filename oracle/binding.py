@@ -1,0 +1,253 @@
+"""ctypes binding of oracle/_build/liboracle.so (TEST INFRASTRUCTURE ONLY).
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg;
+never from zkvm_amd/.  `load()` builds the library with oracle/Makefile when the
+.so is missing or older than its sources.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence, Tuple
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "_build", "liboracle.so")
+_lib = None
+
+
+class Fe(C.Structure):
+    _fields_ = [("v", C.c_uint64 * 5)]
+
+
+class Sc(C.Structure):
+    _fields_ = [("v", C.c_uint64 * 4)]
+
+
+class Ge(C.Structure):
+    _fields_ = [("X", Fe), ("Y", Fe), ("Z", Fe), ("T", Fe)]
+
+
+class Transcript(C.Structure):
+    _fields_ = [("st", C.c_uint8 * 200), ("pos", C.c_uint8), ("pos_begin", C.c_uint8), ("cur_flags", C.c_uint8)]
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".c", ".h"))]
+    stale = force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", HERE], check=True, capture_output=True)
+    return SO
+
+
+def load():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(SO)
+        _lib.zko_msm.restype = C.c_int
+        _lib.zko_verify_batch.restype = C.c_int
+        _lib.zko_max_threads.restype = C.c_int
+    return _lib
+
+
+# ---- field ------------------------------------------------------------------
+def fe_from_int(x: int) -> Fe:
+    f = Fe()
+    load().fe_frombytes(C.byref(f), (x % (2**255)).to_bytes(32, "little"))
+    return f
+
+
+def fe_to_int(f: Fe) -> int:
+    out = C.create_string_buffer(32)
+    load().fe_tobytes(out, C.byref(f))
+    return int.from_bytes(out.raw, "little")
+
+
+def fe_binop(name: str, a: int, b: int) -> int:
+    fa, fb, r = fe_from_int(a), fe_from_int(b), Fe()
+    getattr(load(), name)(C.byref(r), C.byref(fa), C.byref(fb))
+    return fe_to_int(r)
+
+
+def fe_unop(name: str, a: int) -> int:
+    fa, r = fe_from_int(a), Fe()
+    getattr(load(), name)(C.byref(r), C.byref(fa))
+    return fe_to_int(r)
+
+
+def fe_sqrt_ratio_m1(u: int, v: int) -> Tuple[bool, int]:
+    fu, fv, r = fe_from_int(u), fe_from_int(v), Fe()
+    ok = load().fe_sqrt_ratio_m1(C.byref(r), C.byref(fu), C.byref(fv))
+    return bool(ok), fe_to_int(r)
+
+
+# ---- scalars ----------------------------------------------------------------
+def sc_from_int(x: int) -> Sc:
+    s = Sc()
+    load().sc_from_bytes_wide(C.byref(s), (x % (2**512)).to_bytes(64, "little"))
+    return s
+
+
+def sc_to_int(s: Sc) -> int:
+    out = C.create_string_buffer(32)
+    load().sc_to_bytes(out, C.byref(s))
+    return int.from_bytes(out.raw, "little")
+
+
+def sc_binop(name: str, a: int, b: int) -> int:
+    sa, sb, r = sc_from_int(a), sc_from_int(b), Sc()
+    getattr(load(), name)(C.byref(r), C.byref(sa), C.byref(sb))
+    return sc_to_int(r)
+
+
+def sc_invert(a: int) -> int:
+    sa, r = sc_from_int(a), Sc()
+    load().sc_invert(C.byref(r), C.byref(sa))
+    return sc_to_int(r)
+
+
+def sc_reduce_wide(b: bytes) -> int:
+    s = Sc()
+    load().sc_from_bytes_wide(C.byref(s), b)
+    return sc_to_int(s)
+
+
+# ---- group ------------------------------------------------------------------
+def decode(b: bytes) -> Optional[Ge]:
+    p = Ge()
+    return p if load().ristretto_decode(C.byref(p), b) else None
+
+
+def encode(p: Ge) -> bytes:
+    out = C.create_string_buffer(32)
+    load().ristretto_encode(out, C.byref(p))
+    return out.raw
+
+
+def from_uniform_bytes(b: bytes) -> bytes:
+    p = Ge()
+    load().ristretto_from_uniform_bytes(C.byref(p), b)
+    return encode(p)
+
+
+def basepoint() -> Ge:
+    p = Ge()
+    load().ge_basepoint(C.byref(p))
+    return p
+
+
+def scalarmult(k: int, p: Ge) -> Ge:
+    r, s = Ge(), sc_from_int(k)
+    load().ge_scalarmult(C.byref(r), C.byref(s), C.byref(p))
+    return r
+
+
+def add(p: Ge, q: Ge) -> Ge:
+    r = Ge()
+    load().ge_add(C.byref(r), C.byref(p), C.byref(q))
+    return r
+
+
+def double(p: Ge) -> Ge:
+    r = Ge()
+    load().ge_double(C.byref(r), C.byref(p))
+    return r
+
+
+def msm_points(kind: str, scalars: Sequence[int], points: Sequence[Ge]) -> Ge:
+    n = len(scalars)
+    sa = (Sc * max(n, 1))(*[sc_from_int(k) for k in scalars])
+    pa = (Ge * max(n, 1))(*points)
+    r = Ge()
+    getattr(load(), "ge_msm_" + kind)(C.byref(r), sa, pa, C.c_size_t(n))
+    return r
+
+
+# ---- byte-level entry points (the shapes of include/zkgpu.h) ------------------
+def msm(scalars: bytes, points: bytes) -> Tuple[int, bytes, int]:
+    """-> (rc, 32-byte encoding, bad_index)"""
+    n = len(scalars) // 32
+    assert len(scalars) == 32 * n and len(points) == 32 * n
+    out = C.create_string_buffer(32)
+    bad = C.c_size_t(0)
+    rc = load().zko_msm(scalars, points, C.c_size_t(n), out, C.byref(bad))
+    return rc, out.raw, bad.value
+
+
+def verify_batch(scalars: bytes, points: bytes, offsets: Sequence[int], threads: int = 1) -> bytes:
+    b = len(offsets) - 1
+    off = (C.c_uint64 * (b + 1))(*offsets)
+    bitmap = C.create_string_buffer((b + 7) // 8 or 1)
+    rc = load().zko_verify_batch(scalars, points, off, C.c_size_t(b), bitmap, C.c_int(threads))
+    assert rc == 0
+    return bitmap.raw[: (b + 7) // 8]
+
+
+def decode_batch(points: bytes) -> bytes:
+    n = len(points) // 32
+    ok = C.create_string_buffer(max(n, 1))
+    load().zko_decode_batch(points, C.c_size_t(n), ok)
+    return ok.raw[:n]
+
+
+def max_threads() -> int:
+    return load().zko_max_threads()
+
+
+# ---- hashing / transcripts ---------------------------------------------------
+def sha3_512(data: bytes) -> bytes:
+    out = C.create_string_buffer(64)
+    load().sha3_512(out, data, C.c_size_t(len(data)))
+    return out.raw
+
+
+class Shake256Ctx(C.Structure):
+    _fields_ = [("st", C.c_uint64 * 25), ("pos", C.c_uint), ("squeezing", C.c_int)]
+
+
+def shake256(data: bytes, outlen: int) -> bytes:
+    c = Shake256Ctx()
+    lib = load()
+    lib.shake256_init(C.byref(c))
+    lib.shake256_absorb(C.byref(c), data, C.c_size_t(len(data)))
+    out = C.create_string_buffer(outlen)
+    # squeeze in two pieces to exercise the streaming path
+    h = outlen // 2
+    lib.shake256_squeeze(C.byref(c), out, C.c_size_t(h))
+    lib.shake256_squeeze(C.byref(c), C.byref(out, h), C.c_size_t(outlen - h))
+    return out.raw
+
+
+class MerlinTranscript:
+    def __init__(self, label: bytes):
+        self.t = Transcript()
+        load().merlin_init(C.byref(self.t), label, C.c_size_t(len(label)))
+
+    def append_message(self, label: bytes, msg: bytes) -> None:
+        load().merlin_append_message(C.byref(self.t), label, msg, C.c_size_t(len(msg)))
+
+    def append_u64(self, label: bytes, x: int) -> None:
+        load().merlin_append_u64(C.byref(self.t), label, C.c_uint64(x))
+
+    def challenge_bytes(self, label: bytes, n: int) -> bytes:
+        out = C.create_string_buffer(n)
+        load().merlin_challenge_bytes(C.byref(self.t), label, out, C.c_size_t(n))
+        return out.raw
+
+    def challenge_scalar(self, label: bytes) -> int:
+        s = Sc()
+        load().merlin_challenge_scalar(C.byref(self.t), label, C.byref(s))
+        return sc_to_int(s)
+
+
+def pedersen_gens() -> Tuple[bytes, bytes]:
+    b, bb = Ge(), Ge()
+    load().pedersen_gens(C.byref(b), C.byref(bb))
+    return encode(b), encode(bb)
+
+
+def bulletproof_gens(n: int, which: str, party: int = 0) -> List[bytes]:
+    arr = (Ge * n)()
+    load().bulletproof_gens_chain(arr, C.c_size_t(n), C.c_char(which.encode()), C.c_uint32(party))
+    return [encode(arr[i]) for i in range(n)]

@@ -1,0 +1,32 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "ristretto255.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import binding
+    binding.load()
+    return binding
+
+
+@pytest.fixture(scope="session")
+def pyref():
+    from oracle import pyref as R
+    return R
