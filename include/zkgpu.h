@@ -1,0 +1,127 @@
+/* zkgpu.h -- C ABI of libzkgpu.so, the MI355X (gfx950) back end for the
+ * multiscalar-multiplication tail of ZkVM / Bulletproofs-R1CS verification.
+ *
+ * What each entry point replaces in the reference (interstellar/zkvm ->
+ * slingshot/zkvm; /root/reference holds only README.md:1-7, so the items below
+ * are named by their upstream Rust paths):
+ *
+ *   zkgpu_msm*            RistrettoPoint::vartime_multiscalar_mul /
+ *                         optional_multiscalar_mul  (curve25519-dalek,
+ *                         traits::VartimeMultiscalarMul) followed by
+ *                         RistrettoPoint::compress
+ *   zkgpu_verify_batch*   the tail of bulletproofs::r1cs::Verifier::verify
+ *                         (`mega_check = optional_multiscalar_mul(..)`,
+ *                         `mega_check.is_identity()`) for a batch of
+ *                         independent proofs, one accept bit per proof
+ *   zkgpu_pointset_*      BulletproofGens / PedersenGens held decompressed on
+ *                         the device (the reference keeps them decompressed
+ *                         in host memory)
+ *
+ * Conventions
+ *   - plain pointers and sizes, no allocation handed across, no callbacks;
+ *   - scalars: 32 bytes little endian, bit 255 clear (dalek `Scalar` invariant);
+ *     points: 32-byte ristretto255 encodings (RFC 9496 sec 4.3.1);
+ *   - every call returns ZKGPU_OK (0) or a negative error code; on ANY error
+ *     the outputs are zeroed (fail-closed: an error is never an "accept");
+ *   - a context is bound to one GPU and one HIP stream, and serialises its own
+ *     calls; use one context per thread / per GPU (one process per GPU under
+ *     torch.distributed);
+ *   - `*_dev` variants take device pointers (inputs already resident in HBM) and
+ *     are what bench.py times; host-pointer variants add the PCIe copies.
+ */
+#ifndef ZKGPU_H
+#define ZKGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKGPU_OK 0
+#define ZKGPU_EINVAL (-1)          /* bad argument (null pointer, bad offsets, scalar bit 255 set) */
+#define ZKGPU_EINVALID_POINT (-2)  /* zkgpu_msm*: a point failed RFC 9496 DECODE */
+#define ZKGPU_EHIP (-3)            /* HIP runtime error; see zkgpu_last_error */
+#define ZKGPU_ENOMEM (-4)
+#define ZKGPU_ENODEVICE (-5)
+
+typedef struct zkgpu_ctx zkgpu_ctx;
+typedef struct zkgpu_pointset zkgpu_pointset;
+
+/* ABI version of this header (bumped on any signature change). */
+int zkgpu_abi_version(void);
+const char *zkgpu_strerror(int code);
+/* Human-readable detail of the last failing HIP call on this context. */
+const char *zkgpu_last_error(const zkgpu_ctx *ctx);
+
+/* Create a context on HIP device `device`. */
+int zkgpu_init(int device, zkgpu_ctx **out);
+void zkgpu_destroy(zkgpu_ctx *ctx);
+
+/* out = compress(sum_i scalars[i] * decompress(points[i])), n >= 0.
+ * An undecodable point gives ZKGPU_EINVALID_POINT and *bad_index = the lowest
+ * offending index (bad_index may be NULL). */
+int zkgpu_msm(zkgpu_ctx *ctx, const uint8_t *scalars, const uint8_t *points, size_t n,
+              uint8_t out[32], size_t *bad_index);
+int zkgpu_msm_dev(zkgpu_ctx *ctx, const void *d_scalars, const void *d_points, size_t n,
+                  uint8_t out[32], size_t *bad_index);
+
+/* Batch of `batch` independent checks  sum_j s_ij * P_ij == identity,  rows of a
+ * CSR layout: check i owns terms offsets[i] .. offsets[i+1]-1.  Bit i of
+ * accept_bitmap (byte i/8, bit i%8) is 1 iff every point of check i decodes and
+ * the sum is the identity.  accept_bitmap has ceil(batch/8) bytes (host memory
+ * in both variants). */
+int zkgpu_verify_batch(zkgpu_ctx *ctx, const uint8_t *scalars, const uint8_t *points,
+                       const uint64_t *offsets, size_t batch, uint8_t *accept_bitmap);
+int zkgpu_verify_batch_dev(zkgpu_ctx *ctx, const void *d_scalars, const void *d_points,
+                           const void *d_offsets, size_t batch, size_t n_terms,
+                           uint8_t *accept_bitmap);
+
+/* A set of points decompressed once and kept on the device (generators).
+ * Fails with ZKGPU_EINVALID_POINT if any encoding is invalid. */
+int zkgpu_pointset_create(zkgpu_ctx *ctx, const uint8_t *points, size_t n, zkgpu_pointset **out);
+void zkgpu_pointset_destroy(zkgpu_pointset *ps);
+size_t zkgpu_pointset_size(const zkgpu_pointset *ps);
+
+/* As zkgpu_verify_batch, with each check made of two CSR rows: "dynamic" terms
+ * carrying their own compressed points (proof points, commitments) and "static"
+ * terms that name a point of `ps` by index (generators).  static_index may be
+ * NULL, meaning the j-th static term of a check uses point j of the set.
+ * All pointers are host pointers; *_dev takes device pointers for everything
+ * except accept_bitmap. */
+int zkgpu_verify_batch_ps(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t batch,
+                          const uint8_t *dyn_scalars, const uint8_t *dyn_points,
+                          const uint64_t *dyn_offsets,
+                          const uint8_t *static_scalars, const uint32_t *static_index,
+                          const uint64_t *static_offsets, uint8_t *accept_bitmap);
+int zkgpu_verify_batch_ps_dev(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t batch,
+                              const void *d_dyn_scalars, const void *d_dyn_points,
+                              const void *d_dyn_offsets, size_t n_dyn,
+                              const void *d_static_scalars, const void *d_static_index,
+                              const void *d_static_offsets, size_t n_static,
+                              uint8_t *accept_bitmap);
+
+/* Decode-only helper (CompressedRistretto::decompress validity): ok[i] = 1/0. */
+int zkgpu_decode_check(zkgpu_ctx *ctx, const uint8_t *points, size_t n, uint8_t *ok);
+
+/* ---- measurement hooks (used by bench.py; not part of the reference API) ---- */
+/* When enabled, every kernel launch of this context is bracketed by HIP events
+ * on the context's own stream. */
+int zkgpu_profile_enable(zkgpu_ctx *ctx, int on);
+void zkgpu_profile_reset(zkgpu_ctx *ctx);
+/* Number of distinct kernels seen since the last reset. */
+int zkgpu_profile_count(zkgpu_ctx *ctx);
+/* i-th kernel: name (static storage), launches, total milliseconds. */
+int zkgpu_profile_get(zkgpu_ctx *ctx, int i, const char **name, uint64_t *launches, double *total_ms);
+/* Pippenger window width (bits) chosen by the last call, and the number of
+ * point additions its bucket-accumulation kernel performed. */
+int zkgpu_last_window_bits(const zkgpu_ctx *ctx);
+uint64_t zkgpu_last_bucket_adds(const zkgpu_ctx *ctx);
+/* Override the window width (0 = automatic). */
+int zkgpu_set_window_bits(zkgpu_ctx *ctx, int w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

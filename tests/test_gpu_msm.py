@@ -1,0 +1,207 @@
+"""GPU parity: libzkgpu (HIP, through the C ABI) vs the CPU oracle and the libsodium golden
+vectors.  Bit-exact on the 32-byte canonical encodings / accept bitmaps.
+Reference rows: SURVEY.md sec 8(a) a4-a7, a9 (tail)."""
+import random
+
+import pytest
+
+from gpu_util import BAD_POINT, L, bits, points, scalars
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from zkvm_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def test_decode_check_golden(ctx, golden):
+    encs = [bytes.fromhex(v["enc"]) for v in golden["valid_encoding"] + golden["noncanonical"]]
+    want = [v["valid"] for v in golden["valid_encoding"] + golden["noncanonical"]]
+    encs += [bytes.fromhex(h) for h in golden["rfc_only_reject"]]
+    want += [0] * len(golden["rfc_only_reject"])
+    assert list(ctx.decode_check(b"".join(encs))) == want
+
+
+def test_msm_golden_libsodium(ctx, golden):
+    for v in golden["msm"]:
+        out = ctx.msm(bytes.fromhex(v["scalars"]), bytes.fromhex(v["points"]))
+        assert out.hex() == v["result"]
+    # scalar multiplication vectors as 1-term MSMs
+    for v in golden["scalarmult"]:
+        k = int(v["k"], 16).to_bytes(32, "little")
+        assert ctx.msm(k, bytes.fromhex(v["P"])).hex() == v["kP"]
+    # from_uniform_bytes outputs decode and re-encode (1 * P)
+    one = (1).to_bytes(32, "little")
+    for v in golden["from_uniform_bytes"][:8]:
+        assert ctx.msm(one, bytes.fromhex(v["out"])).hex() == v["out"]
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 63, 64, 65, 255, 1000, 4097])
+def test_msm_vs_oracle_sizes(ctx, oracle, n):
+    sc, pt = scalars("sz%d" % n, n), points(oracle, "sz%d" % n, n, distinct=min(n, 50))
+    rc, want, _ = oracle.msm(sc, pt)
+    assert rc == 0
+    assert ctx.msm(sc, pt) == want
+
+
+@pytest.mark.parametrize("w", [4, 5, 7, 8, 11, 13, 15, 16])
+def test_msm_every_window_width(ctx, oracle, w):
+    n = 700
+    sc, pt = scalars("w%d" % w, n), points(oracle, "w", n, distinct=40)
+    rc, want, _ = oracle.msm(sc, pt)
+    ctx.set_window_bits(w)
+    try:
+        assert ctx.msm(sc, pt) == want
+        assert ctx.last_window_bits() == w
+    finally:
+        ctx.set_window_bits(0)
+
+
+def test_msm_structured_scalars(ctx, oracle):
+    n = 600
+    pt = points(oracle, "structured", n, distinct=30)
+    same = pt[:32] * n
+    for name, k in [("zero", 0), ("one", 1), ("lm1", L - 1), ("2^252", 2**252), ("2^254", 2**254), ("top", 2**255 - 1)]:
+        sc = k.to_bytes(32, "little") * n
+        for p in (pt, same):
+            rc, want, _ = oracle.msm(sc, p)
+            assert ctx.msm(sc, p) == want, name
+    # everything cancels -> identity (all-zero encoding)
+    half = scalars("cancel", n // 2)
+    neg = b"".join(((L - int.from_bytes(half[32 * i: 32 * i + 32], "little")) % L).to_bytes(32, "little")
+                   for i in range(n // 2))
+    assert ctx.msm(half + neg, pt[: 16 * n] + pt[: 16 * n]) == bytes(32)
+
+
+def test_msm_invalid_point_and_scalar(ctx, oracle):
+    from zkvm_amd import ZkGpuError
+    n = 300
+    sc, pt = scalars("inv", n), bytearray(points(oracle, "inv", n, distinct=20))
+    pt[32 * 123: 32 * 124] = BAD_POINT
+    pt[32 * 250: 32 * 251] = BAD_POINT
+    with pytest.raises(ZkGpuError) as e:
+        ctx.msm(sc, bytes(pt))
+    assert e.value.code == -2 and e.value.index == 123
+    # scalar with bit 255 set violates the `Scalar` invariant -> EINVAL
+    bad_sc = bytearray(sc)
+    bad_sc[31] |= 0x80
+    with pytest.raises(ZkGpuError) as e:
+        ctx.msm(bytes(bad_sc), points(oracle, "inv", n, distinct=20))
+    assert e.value.code == -1
+
+
+def test_msm_large_vs_oracle(ctx, oracle):
+    n = 1 << 16
+    sc, pt = scalars("large", n), points(oracle, "large", n, distinct=257)
+    rc, want, _ = oracle.msm(sc, pt)
+    assert ctx.msm(sc, pt) == want
+    assert ctx.last_window_bits() >= 11
+
+
+def test_msm_full_size_properties(ctx, oracle):
+    """BASELINE config 3 size (2^20 terms): linearity and a closed form instead of the oracle.
+    sum_i k_i P  = (sum k_i) P ;  MSM(a) + MSM(b) == MSM(a + b)."""
+    n = 1 << 20
+    p = points(oracle, "full", 1)
+    a, b = scalars("fulla", n), scalars("fullb", n)
+    ia = [int.from_bytes(a[32 * i: 32 * i + 32], "little") for i in range(n)]
+    ib = [int.from_bytes(b[32 * i: 32 * i + 32], "little") for i in range(n)]
+    same = p * n
+    ra, rb = ctx.msm(a, same), ctx.msm(b, same)
+    assert ra == ctx.msm((sum(ia) % L).to_bytes(32, "little"), p)
+    assert rb == ctx.msm((sum(ib) % L).to_bytes(32, "little"), p)
+    ab = b"".join(((x + y) % L).to_bytes(32, "little") for x, y in zip(ia, ib))
+    rab = ctx.msm(ab, same)
+    one = (1).to_bytes(32, "little")
+    assert ctx.msm(one + one, ra + rb) == rab
+    # distinct points: split the sum in two halves, recombine
+    pts = points(oracle, "fullp", n, distinct=4099)
+    whole = ctx.msm(a, pts)
+    h = n // 2
+    lo, hi = ctx.msm(a[: 32 * h], pts[: 32 * h]), ctx.msm(a[32 * h:], pts[32 * h:])
+    assert ctx.msm(one + one, lo + hi) == whole
+
+
+def _make_batch(oracle, rng, sizes, corrupt):
+    base = oracle.basepoint()
+    sc, pt, offs, want = b"", b"", [0], []
+    for i, n in enumerate(sizes):
+        terms = []
+        for _ in range(n // 2):
+            k = rng.randrange(1, L)
+            p = oracle.encode(oracle.scalarmult(rng.randrange(1, L), base))
+            terms += [(k, p), (L - k, p)]
+        good = True
+        kind = corrupt.get(i)
+        if kind == "scalar" and terms:
+            terms[0] = ((terms[0][0] + 1) % L, terms[0][1]); good = False
+        if kind == "point" and terms:
+            terms[-1] = (terms[-1][0], BAD_POINT); good = False
+        rng.shuffle(terms)
+        sc += b"".join(k.to_bytes(32, "little") for k, _ in terms)
+        pt += b"".join(p for _, p in terms)
+        offs.append(offs[-1] + len(terms))
+        want.append(int(good))
+    return sc, pt, offs, want
+
+
+def test_verify_batch_ragged_vs_oracle(ctx, oracle):
+    rng = random.Random(21)
+    sizes = [rng.choice([0, 2, 4, 10, 64, 200, 550]) for _ in range(97)]
+    corrupt = {i: ("scalar" if i % 7 == 3 else "point") for i in range(97) if i % 7 in (3, 5)}
+    sc, pt, offs, want = _make_batch(oracle, rng, sizes, corrupt)
+    want = [w if s else 1 for w, s in zip(want, sizes)]      # empty MSM == identity
+    bm = ctx.verify_batch(sc, pt, offs)
+    assert bits(bm, len(sizes)) == want
+    assert bm == oracle.verify_batch(sc, pt, offs)
+    assert ctx.verify_batch(b"", b"", [0]) == b""
+    assert ctx.verify_batch(b"", b"", [0, 0, 0]) == b"\x03"
+
+
+def test_verify_batch_with_pointset_vs_generic(ctx, oracle):
+    """static (generator) terms by index + dynamic terms == the same checks through the generic CSR path."""
+    from zkvm_amd import PointSet
+    rng = random.Random(22)
+    n_gen = 64
+    gens = points(oracle, "gens", n_gen)
+    ps = PointSet(ctx, gens)
+    assert len(ps) == n_gen
+    dyn_sc, dyn_pt, dyn_off = b"", b"", [0]
+    st_sc, st_idx, st_off = b"", [], [0]
+    gen_sc, gen_pt, gen_off = b"", b"", [0]
+    for i in range(40):
+        # static part: random scalars on a random subset of generators
+        idx = rng.sample(range(n_gen), rng.choice([1, 8, 64]))
+        ks = [rng.randrange(L) for _ in idx]
+        # dynamic part: points whose combination cancels the static part  ->  -(sum k_j G_j) as one extra point
+        pts = [oracle.decode(gens[32 * j: 32 * j + 32]) for j in idx]
+        tot = oracle.msm_points("vartime", ks, pts)
+        t_enc = oracle.encode(tot)
+        extra_k = (L - 1) if i % 5 else (L - 2)      # every 5th check is wrong
+        st_sc += b"".join(k.to_bytes(32, "little") for k in ks)
+        st_idx += idx
+        st_off.append(st_off[-1] + len(idx))
+        dyn_sc += extra_k.to_bytes(32, "little")
+        dyn_pt += t_enc
+        dyn_off.append(dyn_off[-1] + 1)
+        gen_sc += b"".join(k.to_bytes(32, "little") for k in ks) + extra_k.to_bytes(32, "little")
+        gen_pt += b"".join(gens[32 * j: 32 * j + 32] for j in idx) + t_enc
+        gen_off.append(gen_off[-1] + len(idx) + 1)
+    want = oracle.verify_batch(gen_sc, gen_pt, gen_off)
+    assert bits(want, 40) == [1 if i % 5 else 0 for i in range(40)]
+    assert ctx.verify_batch(gen_sc, gen_pt, gen_off) == want
+    assert ctx.verify_batch_ps(ps, dyn_sc, dyn_pt, dyn_off, st_sc, st_off, static_index=st_idx) == want
+    ps.close()
+    from zkvm_amd import ZkGpuError
+    with pytest.raises(ZkGpuError):
+        PointSet(ctx, gens[:64] + BAD_POINT)
+
+
+def test_determinism_two_runs(ctx, oracle):
+    n = 5000
+    sc, pt = scalars("det", n), points(oracle, "det", n, distinct=100)
+    assert ctx.msm(sc, pt) == ctx.msm(sc, pt)

@@ -1,0 +1,11 @@
+"""zkvm_amd -- MI355X (gfx950) back end for the multiscalar-multiplication tail of
+ZkVM / Bulletproofs-R1CS verification.
+
+The product is `lib/libzkgpu.so` (hand-written HIP, C ABI in include/zkgpu.h);
+this package is the thin host-side mirror used by tests and bench.py.  There is
+no CPU fallback: importing works anywhere, but creating a `Context` without the
+built library or without a GPU raises.
+"""
+from .native import Context, PointSet, ZkGpuError, lib_path, load_library  # noqa: F401
+
+__all__ = ["Context", "PointSet", "ZkGpuError", "lib_path", "load_library"]

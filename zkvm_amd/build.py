@@ -1,0 +1,35 @@
+"""Build lib/libzkgpu.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "zkgpu.hip")
+OUT = os.path.join(HERE, "lib", "libzkgpu.so")
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("zkgpu.hip", "kernels.hpp", "curve.hpp", "field.hpp", "constants.inc")]
+DEPS.append(os.path.join(HERE, "..", "include", "zkgpu.h"))
+
+
+def stale() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not (force or stale()):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,429 @@
+// kernels.hpp -- the HIP kernels of the MSM pipeline (gfx950).
+//
+// Pipeline (one HIP stream, no host round trips until the end):
+//
+//   k_decompress        32-byte ristretto encodings -> 128-byte affine-Niels rows
+//   k_digits_count      scalars -> signed radix-2^w digits; histogram of
+//                       (msm, window, |digit|) bins            (L2 atomics)
+//   k_scan_*            exclusive prefix sum of the histogram
+//   k_digits_scatter    write (sign | point-row) entries into their bins
+//   k_bucket_accumulate one lane per bin: sum its points with mixed additions
+//                       (the dominant kernel: 7 field multiplications per term
+//                       and window)
+//   k_bucket_reduce     sum_b (b+1) * bucket[b] per (msm, window[, chunk]) by
+//                       running sums
+//   k_window_partials   fold the chunk partials of one window (wave shuffles)
+//   k_msm_finish        Horner over windows + ristretto identity test, one lane
+//                       per MSM (batch mode); single MSMs are finished on the host
+//
+// Data layout in HBM
+//   scalars   n x 32 B little endian (as given)
+//   niels row 32 x u32: ypx[10] ymx[10] xy2d[10] valid pad   (128 B, 16 B aligned)
+//   ext row   40 x u32: X[10] Y[10] Z[10] T[10]              (160 B)
+//   entries   u32: bit 31 = subtract, bit 30 = row lives in the per-call
+//             ("dynamic") table, bits 0..29 = row index
+#pragma once
+#include "curve.hpp"
+
+namespace zk {
+
+constexpr uint32_t ENTRY_NEG = 1u << 31;
+constexpr uint32_t ENTRY_DYN = 1u << 30;
+constexpr uint32_t ENTRY_IDX = (1u << 30) - 1;
+constexpr int NIELS_WORDS = 32;
+constexpr int EXT_WORDS = 40;
+constexpr int REDUCE_CHUNK = 64;   // buckets per lane in k_bucket_reduce
+
+struct JobDesc {
+  // dynamic terms (own compressed points)
+  const uint32_t* dyn_scalars;   // n_dyn x 8 words
+  const uint64_t* dyn_offsets;   // n_msm + 1   (nullptr when n_msm == 1)
+  uint64_t n_dyn;
+  // static terms (points of a resident set)
+  const uint32_t* st_scalars;    // n_static x 8 words
+  const uint32_t* st_index;      // n_static, or nullptr = position within the row
+  const uint64_t* st_offsets;    // n_msm + 1
+  uint64_t n_static;
+  uint32_t n_msm;
+  int w;                         // window bits
+  int n_windows;                 // 255 / w + 1
+  uint32_t n_buckets;            // 2^(w-1)
+};
+
+// ---- small helpers ---------------------------------------------------------
+
+__device__ __forceinline__ void load_niels(ge_niels& q, const uint32_t* row) {
+  const uint4* r4 = reinterpret_cast<const uint4*>(row);
+  uint32_t w[32];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint4 v = r4[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { q.ypx.v[i] = w[i]; q.ymx.v[i] = w[10 + i]; q.xy2d.v[i] = w[20 + i]; }
+}
+
+__device__ __forceinline__ void store_niels(uint32_t* row, const ge_niels& q, uint32_t valid) {
+  uint32_t w[32];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { w[i] = q.ypx.v[i]; w[10 + i] = q.ymx.v[i]; w[20 + i] = q.xy2d.v[i]; }
+  w[30] = valid; w[31] = 0;
+  uint4* r4 = reinterpret_cast<uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+__device__ __forceinline__ void load_ext(ge& p, const uint32_t* row) {
+  const uint4* r4 = reinterpret_cast<const uint4*>(row);
+  uint32_t w[40];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    uint4 v = r4[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { p.X.v[i] = w[i]; p.Y.v[i] = w[10 + i]; p.Z.v[i] = w[20 + i]; p.T.v[i] = w[30 + i]; }
+}
+
+__device__ __forceinline__ void store_ext(uint32_t* row, const ge& p) {
+  uint32_t w[40];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { w[i] = p.X.v[i]; w[10 + i] = p.Y.v[i]; w[20 + i] = p.Z.v[i]; w[30 + i] = p.T.v[i]; }
+  uint4* r4 = reinterpret_cast<uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) r4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// largest m with offsets[m] <= g  (offsets has n_msm + 1 entries, non-decreasing)
+__device__ __forceinline__ uint32_t find_row(const uint64_t* __restrict__ offsets, uint32_t n_msm, uint64_t g) {
+  uint32_t lo = 0, hi = n_msm;   // invariant: offsets[lo] <= g < offsets[hi]
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (offsets[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// ---- k_decompress ----------------------------------------------------------
+// status[0] |= 1 when any point is invalid; status[1] = min bad index (atomicMin)
+__global__ void __launch_bounds__(256)
+k_decompress(const uint32_t* __restrict__ pts, uint32_t* __restrict__ rows, uint64_t n,
+             const uint64_t* __restrict__ offsets, uint32_t n_msm, uint32_t* __restrict__ msm_fail,
+             unsigned long long* __restrict__ bad_index, uint8_t* __restrict__ ok_out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* p4 = reinterpret_cast<const uint4*>(pts + 8 * i);
+  uint4 a = p4[0], b = p4[1];
+  uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  fe x, y;
+  bool ok = ristretto_decode_affine(x, y, w);
+  ge_niels q;
+  niels_from_affine(q, x, y);
+  if (!ok) niels_identity(q);
+  if (rows) store_niels(rows + NIELS_WORDS * i, q, ok ? 1u : 0u);
+  if (ok_out) ok_out[i] = ok ? 1 : 0;
+  if (!ok) {
+    if (bad_index) atomicMin(bad_index, (unsigned long long)i);
+    if (msm_fail) {
+      uint32_t m = (n_msm > 1 && offsets) ? find_row(offsets, n_msm, i) : 0;
+      atomicOr(&msm_fail[m], 1u);
+    }
+  }
+}
+
+// ---- digits ----------------------------------------------------------------
+// Signed radix-2^w recoding, digits in (-2^(w-1), 2^(w-1)], least significant
+// window first.  `f(t, d)` is called for every non-zero digit.
+template <typename F>
+__device__ __forceinline__ void for_each_digit(const uint32_t* __restrict__ sc, int w, int n_windows, F f) {
+  uint32_t s[8];
+  const uint4* s4 = reinterpret_cast<const uint4*>(sc);
+  uint4 a = s4[0], b = s4[1];
+  s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  const uint32_t mask = (1u << w) - 1, half = 1u << (w - 1);
+  uint32_t carry = 0;
+  for (int t = 0; t < n_windows; ++t) {
+    const int pos = t * w;
+    uint32_t bits = 0;
+    if (pos < 256) {
+      const int idx = pos >> 5, sh = pos & 31;
+      // select words idx, idx+1 without dynamic register indexing
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { lo = (k == idx) ? s[k] : lo; hi = (k == idx + 1) ? s[k] : hi; }
+      uint64_t two = (uint64_t)lo | ((uint64_t)hi << 32);
+      bits = (uint32_t)(two >> sh) & mask;
+    }
+    uint32_t v = bits + carry;
+    int d;
+    if (v > half) { d = (int)v - (int)(mask + 1); carry = 1; }
+    else { d = (int)v; carry = 0; }
+    if (d != 0) f(t, d);
+  }
+}
+
+__device__ __forceinline__ void term_lookup(const JobDesc& j, uint64_t g, const uint32_t*& sc, uint32_t& m,
+                                            uint32_t& entry) {
+  if (g < j.n_dyn) {
+    sc = j.dyn_scalars + 8 * g;
+    m = (j.n_msm > 1) ? find_row(j.dyn_offsets, j.n_msm, g) : 0;
+    entry = ENTRY_DYN | (uint32_t)g;
+  } else {
+    const uint64_t k = g - j.n_dyn;
+    sc = j.st_scalars + 8 * k;
+    m = (j.n_msm > 1) ? find_row(j.st_offsets, j.n_msm, k) : 0;
+    entry = j.st_index ? j.st_index[k] : (uint32_t)(k - (j.n_msm > 1 ? j.st_offsets[m] : 0));
+  }
+}
+
+// status[0] bit 1: a scalar had bit 255 set
+__global__ void __launch_bounds__(256)
+k_digits_count(JobDesc j, uint32_t* __restrict__ hist, uint32_t* __restrict__ status) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= j.n_dyn + j.n_static) return;
+  const uint32_t* sc; uint32_t m, entry;
+  term_lookup(j, g, sc, m, entry);
+  if (sc[7] >> 31) atomicOr(&status[0], 2u);
+  const uint64_t base = (uint64_t)m * j.n_windows;
+  for_each_digit(sc, j.w, j.n_windows, [&](int t, int d) {
+    const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+    atomicAdd(&hist[(base + t) * j.n_buckets + b], 1u);
+  });
+}
+
+__global__ void __launch_bounds__(256)
+k_digits_scatter(JobDesc j, uint32_t* __restrict__ cursor, uint32_t* __restrict__ entries) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= j.n_dyn + j.n_static) return;
+  const uint32_t* sc; uint32_t m, entry;
+  term_lookup(j, g, sc, m, entry);
+  const uint64_t base = (uint64_t)m * j.n_windows;
+  for_each_digit(sc, j.w, j.n_windows, [&](int t, int d) {
+    const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+    const uint32_t pos = atomicAdd(&cursor[(base + t) * j.n_buckets + b], 1u);
+    entries[pos] = entry | (d < 0 ? ENTRY_NEG : 0u);
+  });
+}
+
+// ---- exclusive scan over u32 (three launches) --------------------------------
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t& total) {
+  __shared__ uint32_t wave_tot[SCAN_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t y = __shfl_up(x, o);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wave_tot[wid] = x;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_BLOCK / 64; ++k) {
+    uint32_t wt = wave_tot[k];
+    if (k < wid) base += wt;
+    tot += wt;
+  }
+  __syncthreads();
+  total = tot;
+  return base + x - v;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK)
+k_scan_reduce(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ block_sums) {
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n) s += in[base + k];
+  uint32_t total;
+  (void)block_exclusive_scan(s, total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK)
+k_scan_blocksums(uint32_t* __restrict__ block_sums, uint32_t n_blocks) {
+  uint32_t carry = 0;
+  for (uint32_t start = 0; start < n_blocks; start += SCAN_BLOCK) {
+    const uint32_t i = start + threadIdx.x;
+    uint32_t v = i < n_blocks ? block_sums[i] : 0;
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(v, total);
+    if (i < n_blocks) block_sums[i] = carry + ex;
+    carry += total;
+  }
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK)
+k_scan_apply(uint32_t* __restrict__ data, uint64_t n, const uint32_t* __restrict__ block_sums) {
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < n) ? data[base + k] : 0; s += v[k]; }
+  uint32_t total;
+  uint32_t ex = block_exclusive_scan(s, total) + block_sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < n) data[base + k] = ex; ex += v[k]; }
+}
+
+// ---- k_bucket_accumulate ------------------------------------------------------
+// After the scatter, cursor[bin] is the END offset of bin; its start is the end
+// of the previous bin.  One lane per bin.
+__global__ void __launch_bounds__(256)
+k_bucket_accumulate(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ entries,
+                    const uint32_t* __restrict__ static_rows, const uint32_t* __restrict__ dyn_rows,
+                    uint32_t* __restrict__ buckets, uint64_t n_bins) {
+  const uint64_t bin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (bin >= n_bins) return;
+  const uint32_t start = bin ? cursor[bin - 1] : 0u, end = cursor[bin];
+  if (start == end) return;
+  ge acc;
+  ge_identity(acc);
+  for (uint32_t k = start; k < end; ++k) {
+    const uint32_t e = entries[k];
+    const uint32_t* row = ((e & ENTRY_DYN) ? dyn_rows : static_rows) + (uint64_t)(e & ENTRY_IDX) * NIELS_WORDS;
+    ge_niels q;
+    load_niels(q, row);
+    ge_madd(acc, acc, q, (e & ENTRY_NEG) != 0);
+  }
+  store_ext(buckets + bin * EXT_WORDS, acc);
+}
+
+// ---- k_bucket_reduce ------------------------------------------------------------
+// One lane per (msm, window, chunk of REDUCE_CHUNK buckets):
+//   out = sum_{b in chunk} (b + 1) * bucket[b]
+//       = sum (b - lo + 1) * bucket[b]  +  lo * sum bucket[b]
+// via the running-sum recurrence; empty buckets are skipped.
+__global__ void __launch_bounds__(256)
+k_bucket_reduce(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ buckets,
+                uint32_t* __restrict__ partials, uint32_t* __restrict__ partial_nonempty,
+                uint64_t n_tasks, uint32_t n_buckets, uint32_t chunks_per_window) {
+  const uint64_t task = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (task >= n_tasks) return;
+  const uint64_t win = task / chunks_per_window;           // msm * n_windows + t
+  const uint32_t chunk = (uint32_t)(task % chunks_per_window);
+  const uint32_t lo = chunk * REDUCE_CHUNK;
+  const uint32_t hi = min(lo + (uint32_t)REDUCE_CHUNK, n_buckets);
+  const uint64_t bin0 = win * n_buckets;
+  ge run, sum;
+  bool run_set = false, sum_set = false;
+  for (uint32_t b = hi; b-- > lo;) {
+    const uint64_t bin = bin0 + b;
+    const uint32_t s = bin ? cursor[bin - 1] : 0u, e = cursor[bin];
+    if (s != e) {
+      ge p;
+      load_ext(p, buckets + bin * EXT_WORDS);
+      if (run_set) ge_add(run, run, p); else { run = p; run_set = true; }
+    }
+    if (run_set) {
+      if (sum_set) ge_add(sum, sum, run); else { sum = run; sum_set = true; }
+    }
+  }
+  if (sum_set && lo != 0) {
+    // sum += lo * run   (lo < 2^15, double-and-add from the top bit)
+    ge acc = run;
+    const int top = 31 - __clz(lo);
+    for (int bit = top - 1; bit >= 0; --bit) {
+      ge_double(acc, acc);
+      if ((lo >> bit) & 1) ge_add(acc, acc, run);
+    }
+    ge_add(sum, sum, acc);
+  }
+  partial_nonempty[task] = sum_set ? 1u : 0u;
+  if (sum_set) store_ext(partials + task * EXT_WORDS, sum);
+}
+
+// ---- k_window_partials ------------------------------------------------------------
+// One wave per window: fold `chunks_per_window` partials into the window sum.
+// Each lane adds its strided share, then the 64 lane sums are combined with
+// wavefront shuffles (40 dwords per point per step).
+__device__ __forceinline__ void shfl_down_ge(ge& out, const ge& in, int delta) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    out.X.v[i] = __shfl_down(in.X.v[i], delta);
+    out.Y.v[i] = __shfl_down(in.Y.v[i], delta);
+    out.Z.v[i] = __shfl_down(in.Z.v[i], delta);
+    out.T.v[i] = __shfl_down(in.T.v[i], delta);
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_window_partials(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ partial_nonempty,
+                  uint32_t* __restrict__ window_sums, uint32_t* __restrict__ window_nonempty,
+                  uint32_t chunks_per_window) {
+  const uint64_t win = blockIdx.x;
+  const int lane = threadIdx.x;
+  ge acc;
+  ge_identity(acc);
+  int have = 0;
+  for (uint32_t c = lane; c < chunks_per_window; c += 64) {
+    const uint64_t task = win * chunks_per_window + c;
+    if (partial_nonempty[task]) {
+      ge p;
+      load_ext(p, partials + task * EXT_WORDS);
+      if (have) ge_add(acc, acc, p); else { acc = p; have = 1; }
+    }
+  }
+#pragma unroll 1
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    ge other;
+    shfl_down_ge(other, acc, delta);
+    const int other_have = __shfl_down(have, delta);
+    if (lane < delta) {
+      if (other_have) {
+        if (have) ge_add(acc, acc, other); else { acc = other; have = 1; }
+      }
+    }
+  }
+  if (lane == 0) {
+    window_nonempty[win] = (uint32_t)have;
+    if (have) store_ext(window_sums + win * EXT_WORDS, acc);
+  }
+}
+
+// ---- k_msm_finish ----------------------------------------------------------------
+// Batch mode: one lane per MSM.  result = sum_t 2^(w t) W_t by Horner from the
+// top window; accept = identity test & no undecodable point.
+__global__ void __launch_bounds__(64)
+k_msm_finish(const uint32_t* __restrict__ window_sums, const uint32_t* __restrict__ window_nonempty,
+             const uint32_t* __restrict__ msm_fail, uint8_t* __restrict__ accept, uint32_t n_msm, int w,
+             int n_windows) {
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_msm) return;
+  ge acc;
+  bool have = false;
+  for (int t = n_windows - 1; t >= 0; --t) {
+    if (have) {
+      for (int k = 0; k < w - 1; ++k) ge_double<false>(acc, acc);
+      ge_double<true>(acc, acc);
+    }
+    const uint64_t win = (uint64_t)m * n_windows + t;
+    if (window_nonempty[win]) {
+      ge p;
+      load_ext(p, window_sums + win * EXT_WORDS);
+      if (have) ge_add(acc, acc, p); else { acc = p; have = true; }
+    }
+  }
+  const bool ident = have ? ge_is_identity(acc) : true;
+  accept[m] = (ident && !(msm_fail && msm_fail[m])) ? 1 : 0;
+}
+
+// pack accept bytes into a bitmap (byte i/8, bit i%8)
+__global__ void __launch_bounds__(256)
+k_pack_bitmap(const uint8_t* __restrict__ accept, uint8_t* __restrict__ bitmap, uint32_t n_msm) {
+  const uint32_t byte = blockIdx.x * blockDim.x + threadIdx.x;
+  if (byte >= (n_msm + 7) / 8) return;
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t i = byte * 8 + k;
+    if (i < n_msm && accept[i]) v |= 1u << k;
+  }
+  bitmap[byte] = (uint8_t)v;
+}
+
+}  // namespace zk

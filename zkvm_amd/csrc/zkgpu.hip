@@ -1,0 +1,631 @@
+// zkgpu.hip -- context, workspace, launch sequence and the C ABI (include/zkgpu.h).
+//
+// There is deliberately no CPU fallback in this file: every entry point needs a
+// HIP device, and fails with ZKGPU_ENODEVICE / ZKGPU_EHIP otherwise.  The only
+// arithmetic done on the host is the 255-doubling Horner tail of a *single*
+// MSM (a strictly serial chain that one lane of a GPU runs ~10x slower than a
+// host core) and the final RFC 9496 ENCODE of its result.
+#include "../../include/zkgpu.h"
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace zk;
+
+namespace {
+
+struct ProfEntry {
+  const char* name;
+  uint64_t launches;
+  double ms;
+};
+
+struct Buffer {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct zkgpu_pointset {
+  zkgpu_ctx* ctx;
+  uint32_t* rows;   // n x 32 words, device
+  size_t n;
+};
+
+struct zkgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::recursive_mutex mu;
+  std::string last_error;
+  // workspace (grown on demand, never shrunk; no allocation in steady state)
+  Buffer in_scalars, in_points, in_offsets, in_st_scalars, in_st_index, in_st_offsets;
+  Buffer dyn_rows, bins, block_sums, entries, buckets, partials, partial_flags, window_sums, window_flags;
+  Buffer msm_fail, status, accept, bitmap, ok_bytes;
+  void* pinned = nullptr;   // host staging for results
+  size_t pinned_cap = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<ProfEntry> prof;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  std::vector<std::pair<int, int>> ev_used;   // (prof index, pool index)
+  size_t ev_next = 0;
+  int forced_w = 0;
+  int last_w = 0;
+  uint64_t last_adds = 0;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      char buf__[256];                                                                      \
+      snprintf(buf__, sizeof buf__, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+               __FILE__, __LINE__);                                                         \
+      (ctx)->last_error = buf__;                                                            \
+      return ZKGPU_EHIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+int ensure(zkgpu_ctx* c, Buffer& b, size_t bytes) {
+  if (bytes <= b.cap) return ZKGPU_OK;
+  if (b.p) HIP_TRY(c, hipFree(b.p));
+  b.p = nullptr; b.cap = 0;
+  size_t want = bytes + bytes / 8 + 256;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) { c->last_error = std::string("hipMalloc: ") + hipGetErrorString(e); b.p = nullptr; return ZKGPU_ENOMEM; }
+  b.cap = want;
+  return ZKGPU_OK;
+}
+
+int ensure_pinned(zkgpu_ctx* c, size_t bytes) {
+  if (bytes <= c->pinned_cap) return ZKGPU_OK;
+  if (c->pinned) HIP_TRY(c, hipHostFree(c->pinned));
+  c->pinned = nullptr; c->pinned_cap = 0;
+  HIP_TRY(c, hipHostMalloc(&c->pinned, bytes + 4096, hipHostMallocDefault));
+  c->pinned_cap = bytes + 4096;
+  return ZKGPU_OK;
+}
+
+#define TRY(expr) do { int rc__ = (expr); if (rc__ != ZKGPU_OK) return rc__; } while (0)
+
+int prof_index(zkgpu_ctx* c, const char* name) {
+  for (size_t i = 0; i < c->prof.size(); ++i) if (strcmp(c->prof[i].name, name) == 0) return (int)i;
+  c->prof.push_back({name, 0, 0.0});
+  return (int)c->prof.size() - 1;
+}
+
+struct Launch {
+  zkgpu_ctx* c;
+  int pool = -1;
+  Launch(zkgpu_ctx* ctx, const char* name) : c(ctx) {
+    if (!c->profiling) return;
+    if (c->ev_next == c->ev_pool.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      c->ev_pool.push_back({a, b});
+    }
+    pool = (int)c->ev_next++;
+    c->ev_used.push_back({prof_index(c, name), pool});
+    (void)hipEventRecord(c->ev_pool[pool].first, c->stream);
+  }
+  ~Launch() {
+    if (pool >= 0) (void)hipEventRecord(c->ev_pool[pool].second, c->stream);
+  }
+};
+
+void prof_collect(zkgpu_ctx* c) {
+  for (auto& u : c->ev_used) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev_pool[u.second].first, c->ev_pool[u.second].second) == hipSuccess) {
+      c->prof[u.first].launches += 1;
+      c->prof[u.first].ms += ms;
+    }
+  }
+  c->ev_used.clear();
+  c->ev_next = 0;
+}
+
+inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+// window width minimising  W * (terms + 2 * 2^(w-1) * msms)  point additions
+int choose_window(uint64_t n_terms, uint32_t n_msm) {
+  double per = (double)n_terms / (n_msm ? n_msm : 1);
+  int best = 4; double best_cost = 1e300;
+  for (int w = 4; w <= 16; ++w) {
+    double W = 255 / w + 1;
+    double reduce = 2.0 * (double)(1u << (w - 1));
+    if ((1u << (w - 1)) > (unsigned)REDUCE_CHUNK) reduce *= 1.3;  // chunk fix-up work
+    double cost = W * (per + reduce);
+    if (cost < best_cost) { best_cost = cost; best = w; }
+  }
+  return best;
+}
+
+struct Job {
+  // device pointers
+  const uint32_t* d_dyn_scalars = nullptr;
+  const uint32_t* d_dyn_points = nullptr;
+  const uint64_t* d_dyn_offsets = nullptr;
+  uint64_t n_dyn = 0;
+  const uint32_t* d_st_scalars = nullptr;
+  const uint32_t* d_st_index = nullptr;
+  const uint64_t* d_st_offsets = nullptr;
+  uint64_t n_static = 0;
+  const uint32_t* d_static_rows = nullptr;
+  uint32_t n_msm = 1;
+};
+
+// Runs decompress .. window sums.  On return (stream not yet synchronised):
+//   c->window_sums / c->window_flags hold n_msm * n_windows extended points
+//   c->msm_fail[m] != 0 when MSM m had an undecodable point
+//   c->status: [0] flags (bit 1: scalar >= 2^255), [2..3] u64 min bad point index
+int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd) {
+  const uint64_t n_terms = job.n_dyn + job.n_static;
+  int w = c->forced_w ? c->forced_w : choose_window(n_terms, job.n_msm);
+  w = std::max(2, std::min(16, w));
+  jd.dyn_scalars = job.d_dyn_scalars;
+  jd.dyn_offsets = job.d_dyn_offsets;
+  jd.n_dyn = job.n_dyn;
+  jd.st_scalars = job.d_st_scalars;
+  jd.st_index = job.d_st_index;
+  jd.st_offsets = job.d_st_offsets;
+  jd.n_static = job.n_static;
+  jd.n_msm = job.n_msm;
+  jd.w = w;
+  jd.n_windows = 255 / w + 1;
+  jd.n_buckets = 1u << (w - 1);
+  c->last_w = w;
+
+  const uint64_t n_wins = (uint64_t)job.n_msm * jd.n_windows;
+  const uint64_t n_bins = n_wins * jd.n_buckets;
+  const uint32_t chunks = (jd.n_buckets + REDUCE_CHUNK - 1) / REDUCE_CHUNK;
+  const uint64_t n_tasks = n_wins * chunks;
+  const uint64_t max_entries = n_terms * jd.n_windows;
+  if (max_entries >= (1ull << 32) || n_bins >= (1ull << 32) || job.n_dyn >= (1ull << 30) ||
+      job.n_static >= (1ull << 32)) {
+    c->last_error = "job too large for 32-bit entry indices; split the batch";
+    return ZKGPU_EINVAL;
+  }
+  const unsigned scan_blocks = blocks_for(n_bins, SCAN_TILE);
+
+  TRY(ensure(c, c->dyn_rows, std::max<uint64_t>(job.n_dyn, 1) * NIELS_WORDS * 4));
+  TRY(ensure(c, c->bins, (n_bins + 1) * 4));
+  TRY(ensure(c, c->block_sums, ((size_t)scan_blocks + 1) * 4));
+  TRY(ensure(c, c->entries, std::max<uint64_t>(max_entries, 1) * 4));
+  TRY(ensure(c, c->buckets, n_bins * EXT_WORDS * 4));
+  TRY(ensure(c, c->partials, n_tasks * EXT_WORDS * 4));
+  TRY(ensure(c, c->partial_flags, n_tasks * 4));
+  TRY(ensure(c, c->window_sums, n_wins * EXT_WORDS * 4));
+  TRY(ensure(c, c->window_flags, n_wins * 4));
+  TRY(ensure(c, c->msm_fail, (size_t)job.n_msm * 4));
+  TRY(ensure(c, c->status, 64));
+
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipMemsetAsync(c->bins.p, 0, (n_bins + 1) * 4, s));
+  HIP_TRY(c, hipMemsetAsync(c->msm_fail.p, 0, (size_t)job.n_msm * 4, s));
+  HIP_TRY(c, hipMemsetAsync(c->status.p, 0, 8, s));
+  HIP_TRY(c, hipMemsetAsync((char*)c->status.p + 8, 0xff, 8, s));
+  uint32_t* status = (uint32_t*)c->status.p;
+  unsigned long long* bad_index = (unsigned long long*)((char*)c->status.p + 8);
+
+  if (job.n_dyn) {
+    Launch l(c, "k_decompress");
+    hipLaunchKernelGGL(k_decompress, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, s, job.d_dyn_points,
+                       (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, job.n_msm,
+                       (uint32_t*)c->msm_fail.p, bad_index, (uint8_t*)nullptr);
+  }
+  if (n_terms) {
+    Launch l(c, "k_digits_count");
+    hipLaunchKernelGGL(k_digits_count, dim3(blocks_for(n_terms, 256)), dim3(256), 0, s, jd, (uint32_t*)c->bins.p,
+                       status);
+  }
+  {
+    Launch l(c, "k_scan");
+    hipLaunchKernelGGL(k_scan_reduce, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, (const uint32_t*)c->bins.p, n_bins,
+                       (uint32_t*)c->block_sums.p);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, s, (uint32_t*)c->block_sums.p, scan_blocks);
+    hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, (uint32_t*)c->bins.p, n_bins,
+                       (const uint32_t*)c->block_sums.p);
+  }
+  if (n_terms) {
+    Launch l(c, "k_digits_scatter");
+    hipLaunchKernelGGL(k_digits_scatter, dim3(blocks_for(n_terms, 256)), dim3(256), 0, s, jd, (uint32_t*)c->bins.p,
+                       (uint32_t*)c->entries.p);
+  }
+  {
+    Launch l(c, "k_bucket_accumulate");
+    hipLaunchKernelGGL(k_bucket_accumulate, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s,
+                       (const uint32_t*)c->bins.p, (const uint32_t*)c->entries.p, job.d_static_rows,
+                       (const uint32_t*)c->dyn_rows.p, (uint32_t*)c->buckets.p, n_bins);
+  }
+  uint32_t* partials = chunks == 1 ? (uint32_t*)c->window_sums.p : (uint32_t*)c->partials.p;
+  uint32_t* pflags = chunks == 1 ? (uint32_t*)c->window_flags.p : (uint32_t*)c->partial_flags.p;
+  {
+    Launch l(c, "k_bucket_reduce");
+    hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_for(n_tasks, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p,
+                       (const uint32_t*)c->buckets.p, partials, pflags, n_tasks, jd.n_buckets, chunks);
+  }
+  if (chunks > 1) {
+    Launch l(c, "k_window_partials");
+    hipLaunchKernelGGL(k_window_partials, dim3((unsigned)n_wins), dim3(64), 0, s, (const uint32_t*)c->partials.p,
+                       (const uint32_t*)c->partial_flags.p, (uint32_t*)c->window_sums.p,
+                       (uint32_t*)c->window_flags.p, chunks);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return ZKGPU_OK;
+}
+
+// ---- single MSM ----------------------------------------------------------------
+int msm_device(zkgpu_ctx* c, const void* d_scalars, const void* d_points, size_t n, uint8_t out[32],
+               size_t* bad_index) {
+  memset(out, 0, 32);
+  if (bad_index) *bad_index = (size_t)-1;
+  if (n == 0) return ZKGPU_OK;   // empty sum = identity = all-zero encoding
+  Job job;
+  job.d_dyn_scalars = (const uint32_t*)d_scalars;
+  job.d_dyn_points = (const uint32_t*)d_points;
+  job.n_dyn = n;
+  job.n_msm = 1;
+  JobDesc jd;
+  TRY(run_to_windows(c, job, jd));
+  const size_t W = (size_t)jd.n_windows;
+  const size_t bytes = W * EXT_WORDS * 4 + W * 4 + 64;
+  TRY(ensure_pinned(c, bytes));
+  char* h = (char*)c->pinned;
+  HIP_TRY(c, hipMemcpyAsync(h, c->window_sums.p, W * EXT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(h + W * EXT_WORDS * 4, c->window_flags.p, W * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(h + W * EXT_WORDS * 4 + W * 4, c->status.p, 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->profiling) prof_collect(c);
+  const uint32_t* hs = (const uint32_t*)(h + W * EXT_WORDS * 4 + W * 4);
+  unsigned long long bad;
+  memcpy(&bad, hs + 2, 8);
+  if (bad != ~0ull) {
+    if (bad_index) *bad_index = (size_t)bad;
+    return ZKGPU_EINVALID_POINT;
+  }
+  if (hs[0] & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
+  // Horner over the windows on the host (serial tail, see file header)
+  const uint32_t* sums = (const uint32_t*)h;
+  const uint32_t* flags = (const uint32_t*)(h + W * EXT_WORDS * 4);
+  ge acc;
+  bool have = false;
+  for (int t = (int)W - 1; t >= 0; --t) {
+    if (have) {
+      for (int k = 0; k < jd.w - 1; ++k) ge_double<false>(acc, acc);
+      ge_double<true>(acc, acc);
+    }
+    if (flags[t]) {
+      ge p;
+      const uint32_t* r = sums + (size_t)t * EXT_WORDS;
+      for (int i = 0; i < 10; ++i) { p.X.v[i] = r[i]; p.Y.v[i] = r[10 + i]; p.Z.v[i] = r[20 + i]; p.T.v[i] = r[30 + i]; }
+      if (have) ge_add(acc, acc, p); else { acc = p; have = true; }
+    }
+  }
+  if (!have) return ZKGPU_OK;
+  uint32_t enc[8];
+  ristretto_encode(enc, acc);
+  memcpy(out, enc, 32);
+  return ZKGPU_OK;
+}
+
+// ---- batch ------------------------------------------------------------------------
+int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap) {
+  const size_t B = job.n_msm;
+  const size_t nbytes = (B + 7) / 8;
+  memset(accept_bitmap, 0, nbytes);
+  if (B == 0) return ZKGPU_OK;
+  JobDesc jd;
+  TRY(run_to_windows(c, job, jd));
+  TRY(ensure(c, c->accept, B));
+  TRY(ensure(c, c->bitmap, nbytes));
+  TRY(ensure_pinned(c, nbytes + 64));
+  {
+    Launch l(c, "k_msm_finish");
+    hipLaunchKernelGGL(k_msm_finish, dim3(blocks_for(B, 64)), dim3(64), 0, c->stream,
+                       (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p,
+                       (const uint32_t*)c->msm_fail.p, (uint8_t*)c->accept.p, (uint32_t)B, jd.w, jd.n_windows);
+  }
+  {
+    Launch l(c, "k_pack_bitmap");
+    hipLaunchKernelGGL(k_pack_bitmap, dim3(blocks_for(nbytes, 256)), dim3(256), 0, c->stream,
+                       (const uint8_t*)c->accept.p, (uint8_t*)c->bitmap.p, (uint32_t)B);
+  }
+  HIP_TRY(c, hipGetLastError());
+  char* h = (char*)c->pinned;
+  HIP_TRY(c, hipMemcpyAsync(h, c->bitmap.p, nbytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(h + nbytes, c->status.p, 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->profiling) prof_collect(c);
+  const uint32_t* hs = (const uint32_t*)(h + nbytes);
+  uint32_t st;
+  memcpy(&st, hs, 4);
+  if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
+  memcpy(accept_bitmap, h, nbytes);
+  return ZKGPU_OK;
+}
+
+int upload(zkgpu_ctx* c, Buffer& b, const void* src, size_t bytes) {
+  TRY(ensure(c, b, std::max<size_t>(bytes, 16)));
+  if (bytes) HIP_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+  return ZKGPU_OK;
+}
+
+bool offsets_ok(const uint64_t* off, size_t batch, uint64_t* total) {
+  if (off[0] != 0) return false;
+  for (size_t i = 0; i < batch; ++i) if (off[i + 1] < off[i]) return false;
+  *total = off[batch];
+  return true;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace
+
+// =============================== C ABI =========================================
+extern "C" {
+
+int zkgpu_abi_version(void) { return 1; }
+
+const char* zkgpu_strerror(int code) {
+  switch (code) {
+    case ZKGPU_OK: return "ok";
+    case ZKGPU_EINVAL: return "invalid argument";
+    case ZKGPU_EINVALID_POINT: return "invalid ristretto255 encoding";
+    case ZKGPU_EHIP: return "HIP runtime error";
+    case ZKGPU_ENOMEM: return "out of device memory";
+    case ZKGPU_ENODEVICE: return "no usable HIP device";
+    default: return "unknown error";
+  }
+}
+
+const char* zkgpu_last_error(const zkgpu_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int zkgpu_init(int device, zkgpu_ctx** out) {
+  if (!out) return ZKGPU_EINVAL;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ZKGPU_ENODEVICE;
+  if (hipSetDevice(device) != hipSuccess) return ZKGPU_ENODEVICE;
+  zkgpu_ctx* c = new zkgpu_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZKGPU_EHIP; }
+  *out = c;
+  return ZKGPU_OK;
+}
+
+void zkgpu_destroy(zkgpu_ctx* c) {
+  if (!c) return;
+  DeviceGuard g(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  Buffer* bufs[] = {&c->in_scalars, &c->in_points, &c->in_offsets, &c->in_st_scalars, &c->in_st_index,
+                    &c->in_st_offsets, &c->dyn_rows, &c->bins, &c->block_sums, &c->entries, &c->buckets,
+                    &c->partials, &c->partial_flags, &c->window_sums, &c->window_flags, &c->msm_fail,
+                    &c->status, &c->accept, &c->bitmap, &c->ok_bytes};
+  for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int zkgpu_msm_dev(zkgpu_ctx* c, const void* d_scalars, const void* d_points, size_t n, uint8_t out[32],
+                  size_t* bad_index) {
+  if (!c || !out || (n && (!d_scalars || !d_points))) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  int rc = msm_device(c, d_scalars, d_points, n, out, bad_index);
+  if (rc != ZKGPU_OK) memset(out, 0, 32);
+  return rc;
+}
+
+int zkgpu_msm(zkgpu_ctx* c, const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t out[32],
+              size_t* bad_index) {
+  if (!c || !out || (n && (!scalars || !points))) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  memset(out, 0, 32);
+  TRY(upload(c, c->in_scalars, scalars, n * 32));
+  TRY(upload(c, c->in_points, points, n * 32));
+  int rc = msm_device(c, c->in_scalars.p, c->in_points.p, n, out, bad_index);
+  if (rc != ZKGPU_OK) memset(out, 0, 32);
+  return rc;
+}
+
+int zkgpu_verify_batch_dev(zkgpu_ctx* c, const void* d_scalars, const void* d_points, const void* d_offsets,
+                           size_t batch, size_t n_terms, uint8_t* accept_bitmap) {
+  if (!c || !accept_bitmap || (batch && !d_offsets) || (n_terms && (!d_scalars || !d_points))) return ZKGPU_EINVAL;
+  if (batch >= (1ull << 31)) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  Job job;
+  job.d_dyn_scalars = (const uint32_t*)d_scalars;
+  job.d_dyn_points = (const uint32_t*)d_points;
+  job.d_dyn_offsets = (const uint64_t*)d_offsets;
+  job.n_dyn = n_terms;
+  job.n_msm = (uint32_t)batch;
+  int rc = batch_device(c, job, accept_bitmap);
+  if (rc != ZKGPU_OK) memset(accept_bitmap, 0, (batch + 7) / 8);
+  return rc;
+}
+
+int zkgpu_verify_batch(zkgpu_ctx* c, const uint8_t* scalars, const uint8_t* points, const uint64_t* offsets,
+                       size_t batch, uint8_t* accept_bitmap) {
+  if (!c || !accept_bitmap || !offsets) return ZKGPU_EINVAL;
+  memset(accept_bitmap, 0, (batch + 7) / 8);
+  uint64_t n = 0;
+  if (!offsets_ok(offsets, batch, &n) || (n && (!scalars || !points)) || batch >= (1ull << 31)) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  TRY(upload(c, c->in_scalars, scalars, n * 32));
+  TRY(upload(c, c->in_points, points, n * 32));
+  TRY(upload(c, c->in_offsets, offsets, (batch + 1) * 8));
+  Job job;
+  job.d_dyn_scalars = (const uint32_t*)c->in_scalars.p;
+  job.d_dyn_points = (const uint32_t*)c->in_points.p;
+  job.d_dyn_offsets = (const uint64_t*)c->in_offsets.p;
+  job.n_dyn = n;
+  job.n_msm = (uint32_t)batch;
+  int rc = batch_device(c, job, accept_bitmap);
+  if (rc != ZKGPU_OK) memset(accept_bitmap, 0, (batch + 7) / 8);
+  return rc;
+}
+
+int zkgpu_pointset_create(zkgpu_ctx* c, const uint8_t* points, size_t n, zkgpu_pointset** out) {
+  if (!c || !out || (n && !points) || n >= (1ull << 30)) return ZKGPU_EINVAL;
+  *out = nullptr;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  TRY(upload(c, c->in_points, points, n * 32));
+  TRY(ensure(c, c->status, 64));
+  uint32_t* rows = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&rows, std::max<size_t>(n, 1) * NIELS_WORDS * 4));
+  HIP_TRY(c, hipMemsetAsync(c->status.p, 0xff, 16, c->stream));
+  unsigned long long* bad_index = (unsigned long long*)((char*)c->status.p + 8);
+  if (n) {
+    Launch l(c, "k_decompress");
+    hipLaunchKernelGGL(k_decompress, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream,
+                       (const uint32_t*)c->in_points.p, rows, (uint64_t)n, (const uint64_t*)nullptr, 1u,
+                       (uint32_t*)nullptr, bad_index, (uint8_t*)nullptr);
+  }
+  unsigned long long bad = ~0ull;
+  hipError_t e = hipMemcpyAsync(&bad, bad_index, 8, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (c->profiling) prof_collect(c);
+  if (e != hipSuccess) { (void)hipFree(rows); c->last_error = hipGetErrorString(e); return ZKGPU_EHIP; }
+  if (bad != ~0ull) { (void)hipFree(rows); return ZKGPU_EINVALID_POINT; }
+  zkgpu_pointset* ps = new zkgpu_pointset{c, rows, n};
+  *out = ps;
+  return ZKGPU_OK;
+}
+
+void zkgpu_pointset_destroy(zkgpu_pointset* ps) {
+  if (!ps) return;
+  DeviceGuard g(ps->ctx->device);
+  (void)hipFree(ps->rows);
+  delete ps;
+}
+
+size_t zkgpu_pointset_size(const zkgpu_pointset* ps) { return ps ? ps->n : 0; }
+
+int zkgpu_verify_batch_ps_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, const void* d_dyn_scalars,
+                              const void* d_dyn_points, const void* d_dyn_offsets, size_t n_dyn,
+                              const void* d_static_scalars, const void* d_static_index,
+                              const void* d_static_offsets, size_t n_static, uint8_t* accept_bitmap) {
+  if (!c || !ps || ps->ctx != c || !accept_bitmap || batch >= (1ull << 31)) return ZKGPU_EINVAL;
+  if (batch && (!d_dyn_offsets || !d_static_offsets)) return ZKGPU_EINVAL;
+  if ((n_dyn && (!d_dyn_scalars || !d_dyn_points)) || (n_static && !d_static_scalars)) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  Job job;
+  job.d_dyn_scalars = (const uint32_t*)d_dyn_scalars;
+  job.d_dyn_points = (const uint32_t*)d_dyn_points;
+  job.d_dyn_offsets = (const uint64_t*)d_dyn_offsets;
+  job.n_dyn = n_dyn;
+  job.d_st_scalars = (const uint32_t*)d_static_scalars;
+  job.d_st_index = (const uint32_t*)d_static_index;
+  job.d_st_offsets = (const uint64_t*)d_static_offsets;
+  job.n_static = n_static;
+  job.d_static_rows = ps->rows;
+  job.n_msm = (uint32_t)batch;
+  int rc = batch_device(c, job, accept_bitmap);
+  if (rc != ZKGPU_OK) memset(accept_bitmap, 0, (batch + 7) / 8);
+  return rc;
+}
+
+int zkgpu_verify_batch_ps(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, const uint8_t* dyn_scalars,
+                          const uint8_t* dyn_points, const uint64_t* dyn_offsets, const uint8_t* static_scalars,
+                          const uint32_t* static_index, const uint64_t* static_offsets, uint8_t* accept_bitmap) {
+  if (!c || !ps || ps->ctx != c || !accept_bitmap || !dyn_offsets || !static_offsets) return ZKGPU_EINVAL;
+  memset(accept_bitmap, 0, (batch + 7) / 8);
+  uint64_t nd = 0, ns = 0;
+  if (!offsets_ok(dyn_offsets, batch, &nd) || !offsets_ok(static_offsets, batch, &ns)) return ZKGPU_EINVAL;
+  if ((nd && (!dyn_scalars || !dyn_points)) || (ns && !static_scalars)) return ZKGPU_EINVAL;
+  // static indices must name points of the set
+  if (static_index) {
+    for (uint64_t k = 0; k < ns; ++k) if (static_index[k] >= ps->n) return ZKGPU_EINVAL;
+  } else {
+    for (size_t i = 0; i < batch; ++i) if (static_offsets[i + 1] - static_offsets[i] > ps->n) return ZKGPU_EINVAL;
+  }
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  {
+    DeviceGuard g(c->device);
+    TRY(upload(c, c->in_scalars, dyn_scalars, nd * 32));
+    TRY(upload(c, c->in_points, dyn_points, nd * 32));
+    TRY(upload(c, c->in_offsets, dyn_offsets, (batch + 1) * 8));
+    TRY(upload(c, c->in_st_scalars, static_scalars, ns * 32));
+    if (static_index) TRY(upload(c, c->in_st_index, static_index, ns * 4));
+    TRY(upload(c, c->in_st_offsets, static_offsets, (batch + 1) * 8));
+  }
+  return zkgpu_verify_batch_ps_dev(c, ps, batch, c->in_scalars.p, c->in_points.p, c->in_offsets.p, nd,
+                                   c->in_st_scalars.p, static_index ? c->in_st_index.p : nullptr,
+                                   c->in_st_offsets.p, ns, accept_bitmap);
+}
+
+int zkgpu_decode_check(zkgpu_ctx* c, const uint8_t* points, size_t n, uint8_t* ok) {
+  if (!c || (n && (!points || !ok))) return ZKGPU_EINVAL;
+  if (n == 0) return ZKGPU_OK;
+  memset(ok, 0, n);
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  TRY(upload(c, c->in_points, points, n * 32));
+  TRY(ensure(c, c->ok_bytes, n));
+  {
+    Launch l(c, "k_decompress");
+    hipLaunchKernelGGL(k_decompress, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream,
+                       (const uint32_t*)c->in_points.p, (uint32_t*)nullptr, (uint64_t)n, (const uint64_t*)nullptr,
+                       1u, (uint32_t*)nullptr, (unsigned long long*)nullptr, (uint8_t*)c->ok_bytes.p);
+  }
+  HIP_TRY(c, hipMemcpyAsync(ok, c->ok_bytes.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->profiling) prof_collect(c);
+  return ZKGPU_OK;
+}
+
+int zkgpu_profile_enable(zkgpu_ctx* c, int on) {
+  if (!c) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->profiling = on != 0;
+  return ZKGPU_OK;
+}
+
+void zkgpu_profile_reset(zkgpu_ctx* c) {
+  if (!c) return;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->prof.clear();
+}
+
+int zkgpu_profile_count(zkgpu_ctx* c) { return c ? (int)c->prof.size() : 0; }
+
+int zkgpu_profile_get(zkgpu_ctx* c, int i, const char** name, uint64_t* launches, double* total_ms) {
+  if (!c || i < 0 || i >= (int)c->prof.size()) return ZKGPU_EINVAL;
+  if (name) *name = c->prof[i].name;
+  if (launches) *launches = c->prof[i].launches;
+  if (total_ms) *total_ms = c->prof[i].ms;
+  return ZKGPU_OK;
+}
+
+int zkgpu_last_window_bits(const zkgpu_ctx* c) { return c ? c->last_w : 0; }
+uint64_t zkgpu_last_bucket_adds(const zkgpu_ctx* c) { return c ? c->last_adds : 0; }
+
+int zkgpu_set_window_bits(zkgpu_ctx* c, int w) {
+  if (!c || w < 0 || w > 16 || w == 1) return ZKGPU_EINVAL;
+  c->forced_w = w;
+  return ZKGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+"""ctypes binding of libzkgpu.so (include/zkgpu.h).
+
+Mirrors, on the host side, the two reference call sites this library replaces
+(upstream Rust names; /root/reference holds no source):
+
+  Context.msm(scalars, points)           ~ RistrettoPoint::vartime_multiscalar_mul(..).compress()
+  Context.verify_batch(scalars, points,  ~ for each proof: optional_multiscalar_mul(..)
+                       offsets)             .map(|p| p.is_identity())  (tail of r1cs::Verifier::verify)
+
+Errors follow the reference's "Result, never panic on malformed input":
+an undecodable point raises ZkGpuError(EINVALID_POINT, index) from `msm` and
+clears the accept bit in `verify_batch`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence, Tuple
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+OK, EINVAL, EINVALID_POINT, EHIP, ENOMEM, ENODEVICE = 0, -1, -2, -3, -4, -5
+
+
+class ZkGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str, index: Optional[int] = None):
+        super().__init__(f"zkgpu error {code}: {msg}" + (f" (index {index})" if index is not None else ""))
+        self.code = code
+        self.index = index
+
+
+def lib_path() -> str:
+    return os.path.join(HERE, "lib", "libzkgpu.so")
+
+
+def load_library():
+    """Load libzkgpu.so.  Fails loudly when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ZkGpuError(ENODEVICE, f"{path} is missing: run `python -m zkvm_amd.build` (there is no CPU fallback)")
+    lib = C.CDLL(path)
+    vp, sz, u8p = C.c_void_p, C.c_size_t, C.c_char_p
+    lib.zkgpu_abi_version.restype = C.c_int
+    lib.zkgpu_strerror.restype = C.c_char_p
+    lib.zkgpu_strerror.argtypes = [C.c_int]
+    lib.zkgpu_last_error.restype = C.c_char_p
+    lib.zkgpu_last_error.argtypes = [vp]
+    lib.zkgpu_init.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.zkgpu_destroy.argtypes = [vp]
+    lib.zkgpu_destroy.restype = None
+    lib.zkgpu_msm.argtypes = [vp, u8p, u8p, sz, u8p, C.POINTER(sz)]
+    lib.zkgpu_msm_dev.argtypes = [vp, vp, vp, sz, u8p, C.POINTER(sz)]
+    lib.zkgpu_verify_batch.argtypes = [vp, u8p, u8p, C.POINTER(C.c_uint64), sz, u8p]
+    lib.zkgpu_verify_batch_dev.argtypes = [vp, vp, vp, vp, sz, sz, u8p]
+    lib.zkgpu_pointset_create.argtypes = [vp, u8p, sz, C.POINTER(vp)]
+    lib.zkgpu_pointset_destroy.argtypes = [vp]
+    lib.zkgpu_pointset_destroy.restype = None
+    lib.zkgpu_pointset_size.argtypes = [vp]
+    lib.zkgpu_pointset_size.restype = sz
+    lib.zkgpu_verify_batch_ps.argtypes = [vp, vp, sz, u8p, u8p, C.POINTER(C.c_uint64), u8p, C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_uint64), u8p]
+    lib.zkgpu_verify_batch_ps_dev.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, sz, u8p]
+    lib.zkgpu_decode_check.argtypes = [vp, u8p, sz, u8p]
+    lib.zkgpu_profile_enable.argtypes = [vp, C.c_int]
+    lib.zkgpu_profile_reset.argtypes = [vp]
+    lib.zkgpu_profile_reset.restype = None
+    lib.zkgpu_profile_count.argtypes = [vp]
+    lib.zkgpu_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    lib.zkgpu_last_window_bits.argtypes = [vp]
+    lib.zkgpu_last_bucket_adds.argtypes = [vp]
+    lib.zkgpu_last_bucket_adds.restype = C.c_uint64
+    lib.zkgpu_set_window_bits.argtypes = [vp, C.c_int]
+    _LIB = lib
+    return lib
+
+
+def _ptr(x) -> int:
+    """Device pointer of a torch tensor (or a raw int)."""
+    return x if isinstance(x, int) else x.data_ptr()
+
+
+def _u64arr(xs: Sequence[int]):
+    return (C.c_uint64 * len(xs))(*xs)
+
+
+class PointSet:
+    """A set of points decompressed once and resident on the device (generators)."""
+
+    def __init__(self, ctx: "Context", points: bytes):
+        assert len(points) % 32 == 0
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        rc = ctx.lib.zkgpu_pointset_create(ctx.h, points, len(points) // 32, C.byref(self.h))
+        ctx._check(rc)
+
+    def __len__(self) -> int:
+        return int(self.ctx.lib.zkgpu_pointset_size(self.h))
+
+    def close(self) -> None:
+        if self.h:
+            self.ctx.lib.zkgpu_pointset_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU, one HIP stream.  Use one Context per process / per GPU."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.zkgpu_init(device, C.byref(self.h))
+        if rc != OK:
+            raise ZkGpuError(rc, self.lib.zkgpu_strerror(rc).decode() + " (libzkgpu needs a HIP device; no CPU fallback)")
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.zkgpu_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, index: Optional[int] = None) -> None:
+        if rc != OK:
+            detail = self.lib.zkgpu_last_error(self.h).decode() if rc in (EHIP, ENOMEM, EINVAL) else ""
+            raise ZkGpuError(rc, self.lib.zkgpu_strerror(rc).decode() + (": " + detail if detail else ""), index)
+
+    # ---- single MSM ---------------------------------------------------------
+    def msm(self, scalars: bytes, points: bytes) -> bytes:
+        n = len(scalars) // 32
+        assert len(scalars) == 32 * n and len(points) == 32 * n
+        out = C.create_string_buffer(32)
+        bad = C.c_size_t(0)
+        rc = self.lib.zkgpu_msm(self.h, scalars, points, n, out, C.byref(bad))
+        self._check(rc, bad.value if rc == EINVALID_POINT else None)
+        return out.raw
+
+    def msm_dev(self, d_scalars, d_points, n: int) -> bytes:
+        out = C.create_string_buffer(32)
+        bad = C.c_size_t(0)
+        rc = self.lib.zkgpu_msm_dev(self.h, _ptr(d_scalars), _ptr(d_points), n, out, C.byref(bad))
+        self._check(rc, bad.value if rc == EINVALID_POINT else None)
+        return out.raw
+
+    # ---- batch of MSM == identity checks ---------------------------------------
+    def verify_batch(self, scalars: bytes, points: bytes, offsets: Sequence[int]) -> bytes:
+        batch = len(offsets) - 1
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        rc = self.lib.zkgpu_verify_batch(self.h, scalars, points, _u64arr(offsets), batch, bm)
+        self._check(rc)
+        return bm.raw[: (batch + 7) // 8]
+
+    def verify_batch_dev(self, d_scalars, d_points, d_offsets, batch: int, n_terms: int) -> bytes:
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        rc = self.lib.zkgpu_verify_batch_dev(self.h, _ptr(d_scalars), _ptr(d_points), _ptr(d_offsets), batch, n_terms, bm)
+        self._check(rc)
+        return bm.raw[: (batch + 7) // 8]
+
+    def verify_batch_ps(self, ps: PointSet, dyn_scalars: bytes, dyn_points: bytes, dyn_offsets: Sequence[int],
+                        static_scalars: bytes, static_offsets: Sequence[int],
+                        static_index: Optional[Sequence[int]] = None) -> bytes:
+        batch = len(dyn_offsets) - 1
+        assert len(static_offsets) == batch + 1
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        idx = (C.c_uint32 * len(static_index))(*static_index) if static_index is not None else None
+        rc = self.lib.zkgpu_verify_batch_ps(self.h, ps.h, batch, dyn_scalars, dyn_points, _u64arr(dyn_offsets),
+                                            static_scalars, idx, _u64arr(static_offsets), bm)
+        self._check(rc)
+        return bm.raw[: (batch + 7) // 8]
+
+    def verify_batch_ps_dev(self, ps: PointSet, batch: int, d_dyn_scalars, d_dyn_points, d_dyn_offsets, n_dyn: int,
+                            d_static_scalars, d_static_index, d_static_offsets, n_static: int) -> bytes:
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        rc = self.lib.zkgpu_verify_batch_ps_dev(self.h, ps.h, batch, _ptr(d_dyn_scalars), _ptr(d_dyn_points),
+                                                _ptr(d_dyn_offsets), n_dyn, _ptr(d_static_scalars),
+                                                _ptr(d_static_index) if d_static_index is not None else None,
+                                                _ptr(d_static_offsets), n_static, bm)
+        self._check(rc)
+        return bm.raw[: (batch + 7) // 8]
+
+    def decode_check(self, points: bytes) -> bytes:
+        n = len(points) // 32
+        ok = C.create_string_buffer(max(n, 1))
+        self._check(self.lib.zkgpu_decode_check(self.h, points, n, ok))
+        return ok.raw[:n]
+
+    # ---- measurement hooks -------------------------------------------------------
+    def profile(self, on: bool) -> None:
+        self.lib.zkgpu_profile_enable(self.h, 1 if on else 0)
+
+    def profile_reset(self) -> None:
+        self.lib.zkgpu_profile_reset(self.h)
+
+    def profile_read(self) -> Dict[str, Tuple[int, float]]:
+        out = {}
+        for i in range(self.lib.zkgpu_profile_count(self.h)):
+            name, n, ms = C.c_char_p(), C.c_uint64(), C.c_double()
+            self.lib.zkgpu_profile_get(self.h, i, C.byref(name), C.byref(n), C.byref(ms))
+            out[name.value.decode()] = (int(n.value), float(ms.value))
+        return out
+
+    def last_window_bits(self) -> int:
+        return int(self.lib.zkgpu_last_window_bits(self.h))
+
+    def set_window_bits(self, w: int) -> None:
+        self._check(self.lib.zkgpu_set_window_bits(self.h, w))
