@@ -102,6 +102,21 @@ int zkgpu_verify_batch_ps_dev(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t b
                               const void *d_static_offsets, size_t n_static,
                               uint8_t *accept_bitmap);
 
+/* Values instead of identity tests: out[32*i] = compress(sum of row i), or 32
+ * zero bytes with bit i of ok_bitmap cleared when a point of row i is invalid
+ * (RistrettoPoint::optional_multiscalar_mul returning None). Host pointers. */
+int zkgpu_msm_batch(zkgpu_ctx *ctx, const uint8_t *scalars, const uint8_t *points,
+                    const uint64_t *offsets, size_t batch, uint8_t *out, uint8_t *ok_bitmap);
+
+/* RistrettoPoint::from_uniform_bytes for n 64-byte inputs (RFC 9496 sec 4.3.4),
+ * out = n compressed points. */
+int zkgpu_hash_to_points(zkgpu_ctx *ctx, const uint8_t *uniform, size_t n, uint8_t *out);
+
+/* bulletproofs::PedersenGens::default() and BulletproofGens::new(capacity, ..).share(party),
+ * as compressed points (feed them to zkgpu_pointset_create). */
+int zkgpu_pedersen_gens(zkgpu_ctx *ctx, uint8_t B[32], uint8_t B_blinding[32]);
+int zkgpu_bulletproof_gens(zkgpu_ctx *ctx, size_t capacity, uint32_t party, uint8_t *G, uint8_t *H);
+
 /* Decode-only helper (CompressedRistretto::decompress validity): ok[i] = 1/0. */
 int zkgpu_decode_check(zkgpu_ctx *ctx, const uint8_t *points, size_t n, uint8_t *ok);
 

@@ -205,3 +205,37 @@ def test_determinism_two_runs(ctx, oracle):
     n = 5000
     sc, pt = scalars("det", n), points(oracle, "det", n, distinct=100)
     assert ctx.msm(sc, pt) == ctx.msm(sc, pt)
+
+
+def test_generators_and_hash_to_point_vs_oracle(ctx, oracle, golden):
+    """Product-side generator derivation vs the oracle and dalek's published constant."""
+    b, bb = ctx.pedersen_gens()
+    assert (b, bb) == oracle.pedersen_gens()
+    assert bb.hex() == "8c9240b456a9e6dc65c377a1048d745f94a08cdb7f44cbcd7b46f34048871134"
+    g, h = ctx.bulletproof_gens(40)
+    assert [g[32 * i: 32 * i + 32] for i in range(40)] == oracle.bulletproof_gens(40, "G")
+    assert [h[32 * i: 32 * i + 32] for i in range(40)] == oracle.bulletproof_gens(40, "H")
+    g1, _ = ctx.bulletproof_gens(3, party=1)
+    assert [g1[32 * i: 32 * i + 32] for i in range(3)] == oracle.bulletproof_gens(3, "G", party=1)
+    ins = b"".join(bytes.fromhex(v["in"]) for v in golden["from_uniform_bytes"])
+    outs = b"".join(bytes.fromhex(v["out"]) for v in golden["from_uniform_bytes"])
+    assert ctx.hash_to_points(ins) == outs          # libsodium-generated vectors
+
+
+def test_msm_batch_values_vs_oracle(ctx, oracle):
+    rng = random.Random(31)
+    sizes = [0, 1, 2, 5, 33, 190, 549]
+    sc, pt, offs = b"", b"", [0]
+    want = []
+    for i, n in enumerate(sizes):
+        s, p = scalars("mb%d" % i, n), bytearray(points(oracle, "mb%d" % i, n, distinct=min(n, 20) or 1)[: 32 * n])
+        if i == 3:
+            p[32:64] = BAD_POINT
+        rc, enc, _ = oracle.msm(s, bytes(p))
+        want.append(enc if rc == 0 else bytes(32))
+        sc += s
+        pt += bytes(p)
+        offs.append(offs[-1] + n)
+    out, ok = ctx.msm_batch(sc, pt, offs)
+    assert [out[32 * i: 32 * i + 32] for i in range(len(sizes))] == want
+    assert bits(ok, len(sizes)) == [1, 1, 1, 0, 1, 1, 1]

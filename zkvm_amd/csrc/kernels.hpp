@@ -390,8 +390,8 @@ k_window_partials(const uint32_t* __restrict__ partials, const uint32_t* __restr
 // top window; accept = identity test & no undecodable point.
 __global__ void __launch_bounds__(64)
 k_msm_finish(const uint32_t* __restrict__ window_sums, const uint32_t* __restrict__ window_nonempty,
-             const uint32_t* __restrict__ msm_fail, uint8_t* __restrict__ accept, uint32_t n_msm, int w,
-             int n_windows) {
+             const uint32_t* __restrict__ msm_fail, uint8_t* __restrict__ accept, uint32_t* __restrict__ out_enc,
+             uint32_t n_msm, int w, int n_windows) {
   const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n_msm) return;
   ge acc;
@@ -408,8 +408,38 @@ k_msm_finish(const uint32_t* __restrict__ window_sums, const uint32_t* __restric
       if (have) ge_add(acc, acc, p); else { acc = p; have = true; }
     }
   }
+  const bool failed = msm_fail && msm_fail[m];
+  if (out_enc) {
+    // value mode: accept[m] = "every point decoded", out = canonical encoding (zeros on failure)
+    uint32_t enc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (have && !failed) ristretto_encode(enc, acc);
+    uint4* o = reinterpret_cast<uint4*>(out_enc + 8 * (uint64_t)m);
+    o[0] = make_uint4(enc[0], enc[1], enc[2], enc[3]);
+    o[1] = make_uint4(enc[4], enc[5], enc[6], enc[7]);
+    accept[m] = failed ? 0 : 1;
+    return;
+  }
   const bool ident = have ? ge_is_identity(acc) : true;
-  accept[m] = (ident && !(msm_fail && msm_fail[m])) ? 1 : 0;
+  accept[m] = (ident && !failed) ? 1 : 0;
+}
+
+// ---- k_from_uniform ------------------------------------------------------------
+// RFC 9496 sec 4.3.4 element derivation: 64 uniform bytes -> encoding of the point
+__global__ void __launch_bounds__(64)
+k_from_uniform(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[16];
+  const uint4* i4 = reinterpret_cast<const uint4*>(in + 16 * i);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { uint4 v = i4[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+  ge p;
+  ristretto_from_uniform_words(p, w);
+  uint32_t enc[8];
+  ristretto_encode(enc, p);
+  uint4* o = reinterpret_cast<uint4*>(out + 8 * i);
+  o[0] = make_uint4(enc[0], enc[1], enc[2], enc[3]);
+  o[1] = make_uint4(enc[4], enc[5], enc[6], enc[7]);
 }
 
 // pack accept bytes into a bitmap (byte i/8, bit i%8)

@@ -7,6 +7,7 @@
 // host core) and the final RFC 9496 ENCODE of its result.
 #include "../../include/zkgpu.h"
 #include "kernels.hpp"
+#include "keccak.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -48,7 +49,7 @@ struct zkgpu_ctx {
   // workspace (grown on demand, never shrunk; no allocation in steady state)
   Buffer in_scalars, in_points, in_offsets, in_st_scalars, in_st_index, in_st_offsets;
   Buffer dyn_rows, bins, block_sums, entries, buckets, partials, partial_flags, window_sums, window_flags;
-  Buffer msm_fail, status, accept, bitmap, ok_bytes;
+  Buffer msm_fail, status, accept, bitmap, ok_bytes, values, uniform;
   void* pinned = nullptr;   // host staging for results
   size_t pinned_cap = 0;
   // profiling
@@ -320,21 +321,26 @@ int msm_device(zkgpu_ctx* c, const void* d_scalars, const void* d_points, size_t
 }
 
 // ---- batch ------------------------------------------------------------------------
-int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap) {
+// values != nullptr: "value mode" -- write the 32-byte encoding of every MSM to
+// values[32 * i] (host) and make bit i mean "all points of MSM i decoded".
+int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap, uint8_t* values = nullptr) {
   const size_t B = job.n_msm;
   const size_t nbytes = (B + 7) / 8;
   memset(accept_bitmap, 0, nbytes);
+  if (values) memset(values, 0, 32 * B);
   if (B == 0) return ZKGPU_OK;
   JobDesc jd;
   TRY(run_to_windows(c, job, jd));
   TRY(ensure(c, c->accept, B));
   TRY(ensure(c, c->bitmap, nbytes));
-  TRY(ensure_pinned(c, nbytes + 64));
+  TRY(ensure_pinned(c, nbytes + 64 + (values ? 32 * B : 0)));
+  if (values) TRY(ensure(c, c->values, 32 * B));
   {
     Launch l(c, "k_msm_finish");
     hipLaunchKernelGGL(k_msm_finish, dim3(blocks_for(B, 64)), dim3(64), 0, c->stream,
                        (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p,
-                       (const uint32_t*)c->msm_fail.p, (uint8_t*)c->accept.p, (uint32_t)B, jd.w, jd.n_windows);
+                       (const uint32_t*)c->msm_fail.p, (uint8_t*)c->accept.p,
+                       values ? (uint32_t*)c->values.p : (uint32_t*)nullptr, (uint32_t)B, jd.w, jd.n_windows);
   }
   {
     Launch l(c, "k_pack_bitmap");
@@ -345,6 +351,7 @@ int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap) {
   char* h = (char*)c->pinned;
   HIP_TRY(c, hipMemcpyAsync(h, c->bitmap.p, nbytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(h + nbytes, c->status.p, 16, hipMemcpyDeviceToHost, c->stream));
+  if (values) HIP_TRY(c, hipMemcpyAsync(h + nbytes + 64, c->values.p, 32 * B, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->profiling) prof_collect(c);
   const uint32_t* hs = (const uint32_t*)(h + nbytes);
@@ -352,6 +359,7 @@ int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap) {
   memcpy(&st, hs, 4);
   if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
   memcpy(accept_bitmap, h, nbytes);
+  if (values) memcpy(values, h + nbytes + 64, 32 * B);
   return ZKGPU_OK;
 }
 
@@ -415,7 +423,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
   Buffer* bufs[] = {&c->in_scalars, &c->in_points, &c->in_offsets, &c->in_st_scalars, &c->in_st_index,
                     &c->in_st_offsets, &c->dyn_rows, &c->bins, &c->block_sums, &c->entries, &c->buckets,
                     &c->partials, &c->partial_flags, &c->window_sums, &c->window_flags, &c->msm_fail,
-                    &c->status, &c->accept, &c->bitmap, &c->ok_bytes};
+                    &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform};
   for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -593,6 +601,80 @@ int zkgpu_decode_check(zkgpu_ctx* c, const uint8_t* points, size_t n, uint8_t* o
   HIP_TRY(c, hipMemcpyAsync(ok, c->ok_bytes.p, n, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->profiling) prof_collect(c);
+  return ZKGPU_OK;
+}
+
+int zkgpu_msm_batch(zkgpu_ctx* c, const uint8_t* scalars, const uint8_t* points, const uint64_t* offsets,
+                    size_t batch, uint8_t* out, uint8_t* ok_bitmap) {
+  if (!c || !out || !ok_bitmap || !offsets) return ZKGPU_EINVAL;
+  memset(out, 0, 32 * batch);
+  memset(ok_bitmap, 0, (batch + 7) / 8);
+  uint64_t n = 0;
+  if (!offsets_ok(offsets, batch, &n) || (n && (!scalars || !points)) || batch >= (1ull << 31)) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  TRY(upload(c, c->in_scalars, scalars, n * 32));
+  TRY(upload(c, c->in_points, points, n * 32));
+  TRY(upload(c, c->in_offsets, offsets, (batch + 1) * 8));
+  Job job;
+  job.d_dyn_scalars = (const uint32_t*)c->in_scalars.p;
+  job.d_dyn_points = (const uint32_t*)c->in_points.p;
+  job.d_dyn_offsets = (const uint64_t*)c->in_offsets.p;
+  job.n_dyn = n;
+  job.n_msm = (uint32_t)batch;
+  int rc = batch_device(c, job, ok_bitmap, out);
+  if (rc != ZKGPU_OK) { memset(out, 0, 32 * batch); memset(ok_bitmap, 0, (batch + 7) / 8); }
+  return rc;
+}
+
+int zkgpu_hash_to_points(zkgpu_ctx* c, const uint8_t* uniform, size_t n, uint8_t* out) {
+  if (!c || (n && (!uniform || !out))) return ZKGPU_EINVAL;
+  if (n == 0) return ZKGPU_OK;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  TRY(upload(c, c->uniform, uniform, 64 * n));
+  TRY(ensure(c, c->values, 32 * n));
+  {
+    Launch l(c, "k_from_uniform");
+    hipLaunchKernelGGL(k_from_uniform, dim3(blocks_for(n, 64)), dim3(64), 0, c->stream,
+                       (const uint32_t*)c->uniform.p, (uint32_t*)c->values.p, (uint64_t)n);
+  }
+  HIP_TRY(c, hipMemcpyAsync(out, c->values.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->profiling) prof_collect(c);
+  return ZKGPU_OK;
+}
+
+// PedersenGens::default(): B = ristretto basepoint; B_blinding =
+// from_uniform_bytes(SHA3-512(compress(B))).
+int zkgpu_pedersen_gens(zkgpu_ctx* c, uint8_t B[32], uint8_t B_blinding[32]) {
+  if (!c || !B || !B_blinding) return ZKGPU_EINVAL;
+  ge base;
+  base.X = fe_BASE_X(); base.Y = fe_BASE_Y(); base.Z = fe_one(); base.T = fe_BASE_T();
+  uint32_t enc[8];
+  ristretto_encode(enc, base);
+  memcpy(B, enc, 32);
+  uint8_t h[64];
+  Sponge sp = sha3_512_sponge();
+  sp.absorb(B, 32);
+  sp.squeeze(h, 64);
+  return zkgpu_hash_to_points(c, h, 1, B_blinding);
+}
+
+// BulletproofGens share `party`: G_i / H_i = from_uniform_bytes of consecutive
+// 64-byte blocks of SHAKE256("GeneratorsChain" || 'G'/'H' || LE32(party)).
+int zkgpu_bulletproof_gens(zkgpu_ctx* c, size_t capacity, uint32_t party, uint8_t* G, uint8_t* H) {
+  if (!c || (capacity && (!G || !H))) return ZKGPU_EINVAL;
+  std::vector<uint8_t> stream(64 * capacity);
+  for (int side = 0; side < 2; ++side) {
+    Sponge sp = shake256_sponge();
+    const uint8_t label[5] = {(uint8_t)(side ? 'H' : 'G'), (uint8_t)party, (uint8_t)(party >> 8),
+                              (uint8_t)(party >> 16), (uint8_t)(party >> 24)};
+    sp.absorb((const uint8_t*)"GeneratorsChain", 15);
+    sp.absorb(label, 5);
+    sp.squeeze(stream.data(), stream.size());
+    TRY(zkgpu_hash_to_points(c, stream.data(), capacity, side ? H : G));
+  }
   return ZKGPU_OK;
 }
 

@@ -65,6 +65,10 @@ def load_library():
                                           C.POINTER(C.c_uint64), u8p]
     lib.zkgpu_verify_batch_ps_dev.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, sz, u8p]
     lib.zkgpu_decode_check.argtypes = [vp, u8p, sz, u8p]
+    lib.zkgpu_msm_batch.argtypes = [vp, u8p, u8p, C.POINTER(C.c_uint64), sz, u8p, u8p]
+    lib.zkgpu_hash_to_points.argtypes = [vp, u8p, sz, u8p]
+    lib.zkgpu_pedersen_gens.argtypes = [vp, u8p, u8p]
+    lib.zkgpu_bulletproof_gens.argtypes = [vp, sz, C.c_uint32, u8p, u8p]
     lib.zkgpu_profile_enable.argtypes = [vp, C.c_int]
     lib.zkgpu_profile_reset.argtypes = [vp]
     lib.zkgpu_profile_reset.restype = None
@@ -190,6 +194,30 @@ class Context:
                                                 _ptr(d_static_offsets), n_static, bm)
         self._check(rc)
         return bm.raw[: (batch + 7) // 8]
+
+    def msm_batch(self, scalars: bytes, points: bytes, offsets: Sequence[int]) -> Tuple[bytes, bytes]:
+        """-> (batch x 32-byte encodings, ok bitmap)"""
+        batch = len(offsets) - 1
+        out = C.create_string_buffer(max(32 * batch, 1))
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        self._check(self.lib.zkgpu_msm_batch(self.h, scalars, points, _u64arr(offsets), batch, out, bm))
+        return out.raw[: 32 * batch], bm.raw[: (batch + 7) // 8]
+
+    def hash_to_points(self, uniform: bytes) -> bytes:
+        n = len(uniform) // 64
+        out = C.create_string_buffer(max(32 * n, 1))
+        self._check(self.lib.zkgpu_hash_to_points(self.h, uniform, n, out))
+        return out.raw[: 32 * n]
+
+    def pedersen_gens(self) -> Tuple[bytes, bytes]:
+        b, bb = C.create_string_buffer(32), C.create_string_buffer(32)
+        self._check(self.lib.zkgpu_pedersen_gens(self.h, b, bb))
+        return b.raw, bb.raw
+
+    def bulletproof_gens(self, capacity: int, party: int = 0) -> Tuple[bytes, bytes]:
+        g, h = C.create_string_buffer(max(32 * capacity, 1)), C.create_string_buffer(max(32 * capacity, 1))
+        self._check(self.lib.zkgpu_bulletproof_gens(self.h, capacity, party, g, h))
+        return g.raw[: 32 * capacity], h.raw[: 32 * capacity]
 
     def decode_check(self, points: bytes) -> bytes:
         n = len(points) // 32
