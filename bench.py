@@ -134,12 +134,24 @@ def flatten_rows(w, rows):
     return b"".join(sc), b"".join(pt), offs
 
 
+def usable_cores(omp_threads: int) -> int:
+    """Threads the process may really run: min(OpenMP default, affinity mask, cgroup CPU quota)."""
+    n = min(omp_threads, len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(w, gpu_bitmap: bytes, batch: int):
     """Time the CPU oracle (kind "port": same radix-2^51 field and Straus/Pippenger split as the
     reference's dalek back end; the Rust reference itself is not mounted) on this box's cores,
     and check its accept bits against the GPU's on the sampled transactions."""
     from oracle import binding as oracle
-    cores = oracle.max_threads()
+    cores = usable_cores(oracle.max_threads())
     one = list(range(0, min(batch, 24)))
     sc, pt, offs = flatten_rows(w, one)
     t0 = time.perf_counter()
@@ -159,7 +171,7 @@ def cpu_baseline(w, gpu_bitmap: bytes, batch: int):
     assert all(((bm1[i // 8] >> (i % 8)) & 1) == ((gpu_bitmap[i // 8] >> (i % 8)) & 1) for i in one)
     return {"value": round(batch * reps / tall, 1), "unit": "tx/s", "cores": cores, "kind": "port",
             "value_1core": round(len(one) / t1, 2),
-            "sample": "%d x the full %d-tx batch on %d OpenMP threads (%.1f s); 1-core figure on %d tx (%.1f s); "
+            "sample": "%d x the full %d-tx batch on %d OpenMP threads = this box's cgroup CPU quota (%.1f s); 1-core figure on %d tx (%.1f s); "
                       "accept bits compared with the GPU's" % (reps, batch, cores, tall, len(one), t1)}
 
 
