@@ -239,3 +239,51 @@ def test_msm_batch_values_vs_oracle(ctx, oracle):
     out, ok = ctx.msm_batch(sc, pt, offs)
     assert [out[32 * i: 32 * i + 32] for i in range(len(sizes))] == want
     assert bits(ok, len(sizes)) == [1, 1, 1, 0, 1, 1, 1]
+
+
+@pytest.mark.parametrize("w", [4, 7, 9])
+def test_fixed_base_tables_equal_generic_path(ctx, oracle, w):
+    """Generator terms summed out of the fixed-base window tables must give the same accept bits as the
+    Pippenger path and as the oracle -- ragged rows, index lists, zero / edge scalars, bad dynamic points."""
+    from zkvm_amd import PointSet
+    rng = random.Random(40 + w)
+    n_gen = 37
+    gens = points(oracle, "tblgens", n_gen)
+    ps = PointSet(ctx, gens)
+    dyn_sc, dyn_pt, dyn_off = b"", b"", [0]
+    st_sc, st_idx, st_off = b"", [], [0]
+    gen_sc, gen_pt, gen_off = b"", b"", [0]
+    B = 61
+    for i in range(B):
+        cnt = rng.choice([0, 1, 5, n_gen])
+        idx = rng.sample(range(n_gen), cnt)
+        ks = [rng.choice([0, 1, L - 1, 2**252 - 1, rng.randrange(L), rng.randrange(L)]) for _ in idx]
+        pts = [oracle.decode(gens[32 * j: 32 * j + 32]) for j in idx]
+        tot = oracle.encode(oracle.msm_points("vartime", ks, pts)) if cnt else bytes(32)
+        kind = i % 6
+        extra_k = (L - 1) if kind != 2 else (L - 3)          # kind 2: wrong
+        extra_p = tot if kind != 4 else BAD_POINT            # kind 4: undecodable dynamic point
+        n_extra = 1 if (cnt or kind in (2, 4)) else 0
+        st_sc += b"".join(k.to_bytes(32, "little") for k in ks)
+        st_idx += idx
+        st_off.append(st_off[-1] + cnt)
+        dyn_sc += extra_k.to_bytes(32, "little") * n_extra
+        dyn_pt += extra_p * n_extra
+        dyn_off.append(dyn_off[-1] + n_extra)
+        gen_sc += b"".join(k.to_bytes(32, "little") for k in ks) + extra_k.to_bytes(32, "little") * n_extra
+        gen_pt += b"".join(gens[32 * j: 32 * j + 32] for j in idx) + extra_p * n_extra
+        gen_off.append(gen_off[-1] + cnt + n_extra)
+    want = oracle.verify_batch(gen_sc, gen_pt, gen_off)
+    plain = ctx.verify_batch_ps(ps, dyn_sc, dyn_pt, dyn_off, st_sc, st_off, static_index=st_idx)
+    assert plain == want
+    nbytes = ps.build_tables(w)
+    assert nbytes == (255 // w + 1) * n_gen * (1 << (w - 1)) * 128
+    for parts in (0, 1, 3):
+        ctx.set_static_parts(parts)
+        assert ctx.verify_batch_ps(ps, dyn_sc, dyn_pt, dyn_off, st_sc, st_off, static_index=st_idx) == want
+    ctx.set_static_parts(0)
+    # static terms only (no dynamic rows at all): sum k_j G_j - k_j G_j
+    k = rng.randrange(L)
+    sc2 = k.to_bytes(32, "little") + (L - k).to_bytes(32, "little")
+    assert ctx.verify_batch_ps(ps, b"", b"", [0, 0, 0], sc2 + sc2, [0, 2, 4], static_index=[3, 3, 5, 6]) == b"\x01"
+    ps.close()

@@ -24,6 +24,7 @@
 //             ("dynamic") table, bits 0..29 = row index
 #pragma once
 #include "curve.hpp"
+#include "quad.hpp"
 
 namespace zk {
 
@@ -391,7 +392,7 @@ k_window_partials(const uint32_t* __restrict__ partials, const uint32_t* __restr
 __global__ void __launch_bounds__(64)
 k_msm_finish(const uint32_t* __restrict__ window_sums, const uint32_t* __restrict__ window_nonempty,
              const uint32_t* __restrict__ msm_fail, uint8_t* __restrict__ accept, uint32_t* __restrict__ out_enc,
-             uint32_t n_msm, int w, int n_windows) {
+             uint32_t* __restrict__ out_ext, uint32_t n_msm, int w, int n_windows) {
   const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n_msm) return;
   ge acc;
@@ -409,8 +410,61 @@ k_msm_finish(const uint32_t* __restrict__ window_sums, const uint32_t* __restric
     }
   }
   const bool failed = msm_fail && msm_fail[m];
+  if (out_ext) {
+    // point mode: hand the (extended) sum to k_static_combine; identity when empty
+    if (!have) ge_identity(acc);
+    store_ext(out_ext + (uint64_t)m * EXT_WORDS, acc);
+    accept[m] = failed ? 0 : 1;
+    return;
+  }
   if (out_enc) {
     // value mode: accept[m] = "every point decoded", out = canonical encoding (zeros on failure)
+    uint32_t enc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (have && !failed) ristretto_encode(enc, acc);
+    uint4* o = reinterpret_cast<uint4*>(out_enc + 8 * (uint64_t)m);
+    o[0] = make_uint4(enc[0], enc[1], enc[2], enc[3]);
+    o[1] = make_uint4(enc[4], enc[5], enc[6], enc[7]);
+    accept[m] = failed ? 0 : 1;
+    return;
+  }
+  const bool ident = have ? ge_is_identity(acc) : true;
+  accept[m] = (ident && !failed) ? 1 : 0;
+}
+
+// ---- k_msm_finish_quad -----------------------------------------------------------
+// Same contract as k_msm_finish, four lanes per MSM (quad.hpp): the Horner chain
+// of ~255 doublings is the latency floor of a batch, and a quad walks it ~3x faster.
+__global__ void __launch_bounds__(256)
+k_msm_finish_quad(const uint32_t* __restrict__ window_sums, const uint32_t* __restrict__ window_nonempty,
+                  const uint32_t* __restrict__ msm_fail, uint8_t* __restrict__ accept,
+                  uint32_t* __restrict__ out_enc, uint32_t* __restrict__ out_ext, uint32_t n_msm, int w,
+                  int n_windows) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = g & 3;
+  const bool live = (g >> 2) < n_msm;
+  const uint32_t m = live ? (g >> 2) : (n_msm - 1);   // keep whole quads active for DPP
+  ge acc;
+  ge_identity(acc);
+  bool have = false;
+  for (int t = n_windows - 1; t >= 0; --t) {
+    if (have) {
+      for (int k = 0; k < w; ++k) quad_double(acc, r);
+    }
+    const uint64_t win = (uint64_t)m * n_windows + t;
+    if (window_nonempty[win]) {
+      ge p;
+      load_ext(p, window_sums + win * EXT_WORDS);
+      if (have) quad_add(acc, p, r); else { acc = p; have = true; }
+    }
+  }
+  if (!live || r != 0) return;
+  const bool failed = msm_fail && msm_fail[m];
+  if (out_ext) {
+    store_ext(out_ext + (uint64_t)m * EXT_WORDS, acc);
+    accept[m] = failed ? 0 : 1;
+    return;
+  }
+  if (out_enc) {
     uint32_t enc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (have && !failed) ristretto_encode(enc, acc);
     uint4* o = reinterpret_cast<uint4*>(out_enc + 8 * (uint64_t)m);
@@ -454,6 +508,162 @@ k_pack_bitmap(const uint8_t* __restrict__ accept, uint8_t* __restrict__ bitmap, 
     if (i < n_msm && accept[i]) v |= 1u << k;
   }
   bitmap[byte] = (uint8_t)v;
+}
+
+// =============================================================================
+// Fixed-base path for the resident generators (BulletproofGens / PedersenGens)
+// =============================================================================
+// The generators never change, so the device keeps, for every window position t
+// and every generator j, the affine-Niels rows of d * 2^(w t) * G_j for
+// d = 1 .. 2^(w-1):
+//     table[((t * n_set + j) * H + (d - 1)) * 32 words],  H = 2^(w-1)
+// A generator term s * G_j then costs one mixed addition per window with NO
+// doublings, no sorting and no bucket reduction, and every lane of the kernel
+// does the same number of additions.  Memory is what MI355X has plenty of:
+// w = 12 -> 22 * 514 * 2048 rows * 128 B = 2.96 GB for the 2-in/2-out generators.
+
+// lane j: base[t][j] = 2^(w t) * G_j for t = 0 .. W-1 (extended, 160 B rows)
+__global__ void __launch_bounds__(64)
+k_tbl_base(const uint32_t* __restrict__ rows /*niels, n_set*/, uint32_t* __restrict__ base, uint32_t n_set, int w, int W) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_set) return;
+  ge_niels q;
+  load_niels(q, rows + (uint64_t)j * NIELS_WORDS);
+  ge p;
+  ge_identity(p);
+  ge_madd(p, p, q, false);
+  for (int t = 0; t < W; ++t) {
+    store_ext(base + ((uint64_t)t * n_set + j) * EXT_WORDS, p);
+    if (t + 1 < W) {
+      for (int k = 0; k < w - 1; ++k) ge_double<false>(p, p);
+      ge_double<true>(p, p);
+    }
+  }
+}
+
+// lane (t, j): multiples d * base[t][j], d = 1..H, normalised to affine with one
+// inversion per lane (Montgomery's trick), written as Niels rows.
+// tmp: H x 40 words per lane: X, Y, Z of d*P and the running product of the Z's.
+__global__ void __launch_bounds__(64)
+k_tbl_multiples(const uint32_t* __restrict__ base, uint32_t* __restrict__ tmp, uint32_t* __restrict__ table,
+                uint64_t n_lanes, uint32_t H) {
+  const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= n_lanes) return;
+  ge p, q;
+  load_ext(p, base + lane * EXT_WORDS);
+  q = p;
+  fe prod = fe_one();
+  uint32_t* mytmp = tmp + lane * (uint64_t)H * EXT_WORDS;
+  for (uint32_t d = 0; d < H; ++d) {
+    if (d) ge_add(q, q, p);
+    fe_mul(prod, prod, q.Z);
+    ge rec;                       // reuse the ext row layout: X, Y, Z, running product
+    rec.X = q.X; rec.Y = q.Y; rec.Z = q.Z; rec.T = prod;
+    store_ext(mytmp + (uint64_t)d * EXT_WORDS, rec);
+  }
+  fe inv;
+  fe_invert(inv, prod);           // 1 / (Z_1 ... Z_H)
+  uint32_t* myrows = table + lane * (uint64_t)H * NIELS_WORDS;
+  for (uint32_t d = H; d-- > 0;) {
+    ge rec;
+    load_ext(rec, mytmp + (uint64_t)d * EXT_WORDS);
+    fe prev = fe_one();
+    if (d) {
+      ge r2;
+      load_ext(r2, mytmp + (uint64_t)(d - 1) * EXT_WORDS);
+      prev = r2.T;
+    }
+    fe zinv, x, y;
+    fe_mul(zinv, inv, prev);      // 1 / Z_d
+    fe_mul(inv, inv, rec.Z);      // 1 / (Z_1 ... Z_{d-1})
+    fe_mul(x, rec.X, zinv);
+    fe_mul(y, rec.Y, zinv);
+    ge_niels nq;
+    niels_from_affine(nq, x, y);
+    store_niels(myrows + (uint64_t)d * NIELS_WORDS, nq, 1u);
+  }
+}
+
+// lane k (one static term): all W signed digits of its scalar -> digits[t * n_static + k]
+__global__ void __launch_bounds__(256)
+k_static_digits(const uint32_t* __restrict__ st_scalars, int16_t* __restrict__ digits, uint64_t n_static, int w,
+                int W, uint32_t* __restrict__ status) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_static) return;
+  const uint32_t* sc = st_scalars + 8 * k;
+  if (sc[7] >> 31) atomicOr(&status[0], 2u);
+  for (int t = 0; t < W; ++t) digits[(uint64_t)t * n_static + k] = 0;
+  for_each_digit(sc, w, W, [&](int t, int d) { digits[(uint64_t)t * n_static + k] = (int16_t)d; });
+}
+
+// lane (tx, t, part): sum over its share of the tx's static terms of
+// sign(d) * table[t][idx][|d|-1]; the next row is fetched while the current
+// addition runs.  partials[((tx * W + t) * P + part)] (extended).
+__global__ void __launch_bounds__(256)
+k_static_accumulate(const int16_t* __restrict__ digits, const uint64_t* __restrict__ st_offsets,
+                    const uint32_t* __restrict__ st_index, const uint32_t* __restrict__ table, uint32_t n_set,
+                    uint32_t H, int W, int P, uint32_t n_msm, uint64_t n_static, uint32_t* __restrict__ partials) {
+  const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= (uint64_t)n_msm * W * P) return;
+  // window-major lane order: the chip sweeps the table one window slice at a time
+  const uint32_t part = (uint32_t)(lane % P);
+  const uint32_t tx = (uint32_t)((lane / P) % n_msm);
+  const uint32_t t = (uint32_t)(lane / ((uint64_t)P * n_msm));
+  const uint64_t k0 = st_offsets[tx], k1 = st_offsets[tx + 1];
+  const int16_t* dig = digits + (uint64_t)t * n_static;
+  const uint64_t tbase = (uint64_t)t * n_set;
+  ge acc;
+  ge_identity(acc);
+  auto fetch = [&](uint64_t k, ge_niels& q, bool& neg) {
+    const int d = dig[k];
+    const uint32_t idx = st_index ? st_index[k] : (uint32_t)(k - k0);
+    const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+    const uint32_t* row = table + ((tbase + idx) * H + (mag ? mag - 1 : 0)) * NIELS_WORDS;
+    load_niels(q, row);
+    if (d == 0) niels_identity(q);
+    neg = d < 0;
+  };
+  uint64_t k = k0 + part;
+  ge_niels cur, nxt;
+  bool cur_neg = false, nxt_neg = false;
+  if (k < k1) fetch(k, cur, cur_neg);
+  while (k < k1) {
+    const uint64_t kn = k + P;
+    if (kn < k1) fetch(kn, nxt, nxt_neg);
+    ge_madd(acc, acc, cur, cur_neg);
+    cur = nxt; cur_neg = nxt_neg;
+    k = kn;
+  }
+  store_ext(partials + (((uint64_t)tx * W + t) * P + part) * EXT_WORDS, acc);
+}
+
+// one wave per tx: sum the W*P static partials and the dynamic-term sum, then
+// the ristretto identity test.  Lane sums are folded with wavefront shuffles.
+__global__ void __launch_bounds__(64)
+k_static_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
+                 const uint8_t* __restrict__ dyn_ok, const uint32_t* __restrict__ status_unused,
+                 uint8_t* __restrict__ accept) {
+  const uint32_t tx = blockIdx.x;
+  const int lane = threadIdx.x;
+  ge acc;
+  ge_identity(acc);
+  for (uint32_t c = lane; c < n_partials; c += 64) {
+    ge p;
+    load_ext(p, partials + ((uint64_t)tx * n_partials + c) * EXT_WORDS);
+    ge_add(acc, acc, p);
+  }
+  if (lane == 0 && dyn_sum) {
+    ge p;
+    load_ext(p, dyn_sum + (uint64_t)tx * EXT_WORDS);
+    ge_add(acc, acc, p);
+  }
+#pragma unroll 1
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    ge other;
+    shfl_down_ge(other, acc, delta);
+    if (lane < delta) ge_add(acc, acc, other);
+  }
+  if (lane == 0) accept[tx] = (ge_is_identity(acc) && (!dyn_ok || dyn_ok[tx])) ? 1 : 0;
 }
 
 }  // namespace zk

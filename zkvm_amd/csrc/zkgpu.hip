@@ -39,17 +39,25 @@ struct zkgpu_pointset {
   zkgpu_ctx* ctx;
   uint32_t* rows;   // n x 32 words, device
   size_t n;
+  // optional fixed-base window tables (see kernels.hpp "Fixed-base path")
+  uint32_t* table = nullptr;   // W x n x H niels rows
+  int tbl_w = 0, tbl_W = 0;
+  uint32_t tbl_H = 0;
 };
 
 struct zkgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;        // generator (fixed-base) work runs beside the proof-point pipeline
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::recursive_mutex mu;
   std::string last_error;
   // workspace (grown on demand, never shrunk; no allocation in steady state)
   Buffer in_scalars, in_points, in_offsets, in_st_scalars, in_st_index, in_st_offsets;
   Buffer dyn_rows, bins, block_sums, entries, buckets, partials, partial_flags, window_sums, window_flags;
   Buffer msm_fail, status, accept, bitmap, ok_bytes, values, uniform;
+  Buffer digits, st_partials, dynsum, accept2;
+  int forced_parts = 0;
   void* pinned = nullptr;   // host staging for results
   size_t pinned_cap = 0;
   // profiling
@@ -107,8 +115,9 @@ int prof_index(zkgpu_ctx* c, const char* name) {
 
 struct Launch {
   zkgpu_ctx* c;
+  hipStream_t st;
   int pool = -1;
-  Launch(zkgpu_ctx* ctx, const char* name) : c(ctx) {
+  Launch(zkgpu_ctx* ctx, const char* name, hipStream_t stream = nullptr) : c(ctx), st(stream ? stream : ctx->stream) {
     if (!c->profiling) return;
     if (c->ev_next == c->ev_pool.size()) {
       hipEvent_t a, b;
@@ -117,10 +126,10 @@ struct Launch {
     }
     pool = (int)c->ev_next++;
     c->ev_used.push_back({prof_index(c, name), pool});
-    (void)hipEventRecord(c->ev_pool[pool].first, c->stream);
+    (void)hipEventRecord(c->ev_pool[pool].first, st);
   }
   ~Launch() {
-    if (pool >= 0) (void)hipEventRecord(c->ev_pool[pool].second, c->stream);
+    if (pool >= 0) (void)hipEventRecord(c->ev_pool[pool].second, st);
   }
 };
 
@@ -170,7 +179,7 @@ struct Job {
 //   c->window_sums / c->window_flags hold n_msm * n_windows extended points
 //   c->msm_fail[m] != 0 when MSM m had an undecodable point
 //   c->status: [0] flags (bit 1: scalar >= 2^255), [2..3] u64 min bad point index
-int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd) {
+int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status = true) {
   const uint64_t n_terms = job.n_dyn + job.n_static;
   int w = c->forced_w ? c->forced_w : choose_window(n_terms, job.n_msm);
   w = std::max(2, std::min(16, w));
@@ -214,8 +223,10 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd) {
   hipStream_t s = c->stream;
   HIP_TRY(c, hipMemsetAsync(c->bins.p, 0, (n_bins + 1) * 4, s));
   HIP_TRY(c, hipMemsetAsync(c->msm_fail.p, 0, (size_t)job.n_msm * 4, s));
-  HIP_TRY(c, hipMemsetAsync(c->status.p, 0, 8, s));
-  HIP_TRY(c, hipMemsetAsync((char*)c->status.p + 8, 0xff, 8, s));
+  if (reset_status) {
+    HIP_TRY(c, hipMemsetAsync(c->status.p, 0, 8, s));
+    HIP_TRY(c, hipMemsetAsync((char*)c->status.p + 8, 0xff, 8, s));
+  }
   uint32_t* status = (uint32_t*)c->status.p;
   unsigned long long* bad_index = (unsigned long long*)((char*)c->status.p + 8);
 
@@ -337,10 +348,11 @@ int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap, uint8_t* 
   if (values) TRY(ensure(c, c->values, 32 * B));
   {
     Launch l(c, "k_msm_finish");
-    hipLaunchKernelGGL(k_msm_finish, dim3(blocks_for(B, 64)), dim3(64), 0, c->stream,
+    hipLaunchKernelGGL(k_msm_finish_quad, dim3(blocks_for(4 * B, 256)), dim3(256), 0, c->stream,
                        (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p,
                        (const uint32_t*)c->msm_fail.p, (uint8_t*)c->accept.p,
-                       values ? (uint32_t*)c->values.p : (uint32_t*)nullptr, (uint32_t)B, jd.w, jd.n_windows);
+                       values ? (uint32_t*)c->values.p : (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)B, jd.w,
+                       jd.n_windows);
   }
   {
     Launch l(c, "k_pack_bitmap");
@@ -360,6 +372,86 @@ int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap, uint8_t* 
   if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
   memcpy(accept_bitmap, h, nbytes);
   if (values) memcpy(values, h + nbytes + 64, 32 * B);
+  return ZKGPU_OK;
+}
+
+// Batch path when the point set carries fixed-base tables: generator terms are
+// summed straight out of the tables (no sort, no buckets, no doublings); only
+// the proof-specific terms go through the Pippenger pipeline.
+int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, uint8_t* accept_bitmap) {
+  const size_t B = job.n_msm;
+  const size_t nbytes = (B + 7) / 8;
+  memset(accept_bitmap, 0, nbytes);
+  if (B == 0) return ZKGPU_OK;
+  hipStream_t s = c->stream, s2 = c->stream2;
+  const bool has_dyn = job.n_dyn > 0;
+  const int W = ps->tbl_W;
+  int P = c->forced_parts;
+  if (P <= 0) {
+    P = (int)((131072 + B * W - 1) / (B * W));
+    P = std::max(1, std::min(16, P));
+  }
+  const uint64_t n_lanes = (uint64_t)B * W * P;
+  TRY(ensure(c, c->accept, B));
+  TRY(ensure(c, c->accept2, B));
+  TRY(ensure(c, c->bitmap, nbytes));
+  TRY(ensure_pinned(c, nbytes + 64));
+  TRY(ensure(c, c->status, 64));
+  TRY(ensure(c, c->digits, std::max<uint64_t>(job.n_static, 1) * W * 2));
+  TRY(ensure(c, c->st_partials, n_lanes * EXT_WORDS * 4));
+  TRY(ensure(c, c->dynsum, B * EXT_WORDS * 4));
+  HIP_TRY(c, hipMemsetAsync(c->status.p, 0, 8, s));
+  HIP_TRY(c, hipMemsetAsync((char*)c->status.p + 8, 0xff, 8, s));
+  // fork: generator terms on stream2 (fills the chip), proof-point pipeline on the main stream
+  // (its tail is a latency-bound Horner chain that occupies a few dozen wavefronts)
+  HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+  HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
+  if (has_dyn) {
+    Job dj = job;
+    dj.d_st_scalars = nullptr; dj.d_st_index = nullptr; dj.d_st_offsets = nullptr; dj.n_static = 0;
+    JobDesc jd;
+    TRY(run_to_windows(c, dj, jd, /*reset_status=*/false));
+    Launch l(c, "k_msm_finish");
+    hipLaunchKernelGGL(k_msm_finish_quad, dim3(blocks_for(4 * B, 256)), dim3(256), 0, s,
+                       (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p,
+                       (const uint32_t*)c->msm_fail.p, (uint8_t*)c->accept.p, (uint32_t*)nullptr,
+                       (uint32_t*)c->dynsum.p, (uint32_t)B, jd.w, jd.n_windows);
+  }
+  if (job.n_static) {
+    Launch l(c, "k_static_digits", s2);
+    hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, s2, job.d_st_scalars,
+                       (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p);
+  }
+  {
+    Launch l(c, "k_static_accumulate", s2);
+    hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s2,
+                       (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
+                       (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)B, job.n_static, (uint32_t*)c->st_partials.p);
+  }
+  HIP_TRY(c, hipEventRecord(c->ev_join, s2));
+  HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+  {
+    Launch l(c, "k_static_combine");
+    hipLaunchKernelGGL(k_static_combine, dim3((unsigned)B), dim3(64), 0, s, (const uint32_t*)c->st_partials.p,
+                       (uint32_t)(W * P), has_dyn ? (const uint32_t*)c->dynsum.p : (const uint32_t*)nullptr,
+                       has_dyn ? (const uint8_t*)c->accept.p : (const uint8_t*)nullptr, (const uint32_t*)nullptr,
+                       (uint8_t*)c->accept2.p);
+  }
+  {
+    Launch l(c, "k_pack_bitmap");
+    hipLaunchKernelGGL(k_pack_bitmap, dim3(blocks_for(nbytes, 256)), dim3(256), 0, s, (const uint8_t*)c->accept2.p,
+                       (uint8_t*)c->bitmap.p, (uint32_t)B);
+  }
+  HIP_TRY(c, hipGetLastError());
+  char* h = (char*)c->pinned;
+  HIP_TRY(c, hipMemcpyAsync(h, c->bitmap.p, nbytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(h + nbytes, c->status.p, 16, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (c->profiling) prof_collect(c);
+  uint32_t st;
+  memcpy(&st, h + nbytes, 4);
+  if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
+  memcpy(accept_bitmap, h, nbytes);
   return ZKGPU_OK;
 }
 
@@ -411,7 +503,14 @@ int zkgpu_init(int device, zkgpu_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return ZKGPU_ENODEVICE;
   zkgpu_ctx* c = new zkgpu_ctx();
   c->device = device;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZKGPU_EHIP; }
+  // main stream: the proof-point pipeline and its latency-bound tail, high priority;
+  // stream2: the chip-filling generator kernel, low priority
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return ZKGPU_EHIP; }
   *out = c;
   return ZKGPU_OK;
 }
@@ -423,11 +522,15 @@ void zkgpu_destroy(zkgpu_ctx* c) {
   Buffer* bufs[] = {&c->in_scalars, &c->in_points, &c->in_offsets, &c->in_st_scalars, &c->in_st_index,
                     &c->in_st_offsets, &c->dyn_rows, &c->bins, &c->block_sums, &c->entries, &c->buckets,
                     &c->partials, &c->partial_flags, &c->window_sums, &c->window_flags, &c->msm_fail,
-                    &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform};
+                    &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform,
+                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2};
   for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   delete c;
 }
 
@@ -525,16 +628,68 @@ void zkgpu_pointset_destroy(zkgpu_pointset* ps) {
   if (!ps) return;
   DeviceGuard g(ps->ctx->device);
   (void)hipFree(ps->rows);
+  if (ps->table) (void)hipFree(ps->table);
   delete ps;
 }
 
 size_t zkgpu_pointset_size(const zkgpu_pointset* ps) { return ps ? ps->n : 0; }
 
+int zkgpu_pointset_build_tables(zkgpu_ctx* c, zkgpu_pointset* ps, int window_bits) {
+  if (!c || !ps || ps->ctx != c || window_bits < 2 || window_bits > 15 || ps->n == 0) return ZKGPU_EINVAL;  // digits are int16
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  if (ps->table) { HIP_TRY(c, hipFree(ps->table)); ps->table = nullptr; }
+  const int w = window_bits, W = 255 / w + 1;
+  const uint32_t H = 1u << (w - 1);
+  const uint64_t n_lanes = (uint64_t)W * ps->n;
+  const uint64_t n_rows = n_lanes * H;
+  uint32_t *base = nullptr, *tmp = nullptr, *table = nullptr;
+  hipError_t e = hipMalloc((void**)&table, n_rows * NIELS_WORDS * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&base, n_lanes * EXT_WORDS * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&tmp, n_rows * EXT_WORDS * 4);
+  if (e != hipSuccess) {
+    if (table) (void)hipFree(table);
+    if (base) (void)hipFree(base);
+    if (tmp) (void)hipFree(tmp);
+    c->last_error = std::string("table allocation: ") + hipGetErrorString(e);
+    return ZKGPU_ENOMEM;
+  }
+  {
+    Launch l(c, "k_tbl_base");
+    hipLaunchKernelGGL(k_tbl_base, dim3(blocks_for(ps->n, 64)), dim3(64), 0, c->stream, (const uint32_t*)ps->rows, base,
+                       (uint32_t)ps->n, w, W);
+  }
+  {
+    Launch l(c, "k_tbl_multiples");
+    hipLaunchKernelGGL(k_tbl_multiples, dim3(blocks_for(n_lanes, 64)), dim3(64), 0, c->stream, (const uint32_t*)base,
+                       tmp, table, n_lanes, H);
+  }
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (c->profiling) prof_collect(c);
+  (void)hipFree(base);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) { (void)hipFree(table); c->last_error = hipGetErrorString(e); return ZKGPU_EHIP; }
+  ps->table = table; ps->tbl_w = w; ps->tbl_W = W; ps->tbl_H = H;
+  return ZKGPU_OK;
+}
+
+size_t zkgpu_pointset_table_bytes(const zkgpu_pointset* ps) {
+  return (ps && ps->table) ? (size_t)ps->tbl_W * ps->n * ps->tbl_H * NIELS_WORDS * 4 : 0;
+}
+
+int zkgpu_set_static_parts(zkgpu_ctx* c, int parts) {
+  if (!c || parts < 0 || parts > 64) return ZKGPU_EINVAL;
+  c->forced_parts = parts;
+  return ZKGPU_OK;
+}
+
 int zkgpu_verify_batch_ps_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, const void* d_dyn_scalars,
                               const void* d_dyn_points, const void* d_dyn_offsets, size_t n_dyn,
                               const void* d_static_scalars, const void* d_static_index,
                               const void* d_static_offsets, size_t n_static, uint8_t* accept_bitmap) {
-  if (!c || !ps || ps->ctx != c || !accept_bitmap || batch >= (1ull << 31)) return ZKGPU_EINVAL;
+  // a point set may be used from any context of the same device (its rows and tables are read-only)
+  if (!c || !ps || ps->ctx->device != c->device || !accept_bitmap || batch >= (1ull << 31)) return ZKGPU_EINVAL;
   if (batch && (!d_dyn_offsets || !d_static_offsets)) return ZKGPU_EINVAL;
   if ((n_dyn && (!d_dyn_scalars || !d_dyn_points)) || (n_static && !d_static_scalars)) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
@@ -550,7 +705,7 @@ int zkgpu_verify_batch_ps_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t bat
   job.n_static = n_static;
   job.d_static_rows = ps->rows;
   job.n_msm = (uint32_t)batch;
-  int rc = batch_device(c, job, accept_bitmap);
+  int rc = (ps->table && n_static) ? batch_device_tables(c, job, ps, accept_bitmap) : batch_device(c, job, accept_bitmap);
   if (rc != ZKGPU_OK) memset(accept_bitmap, 0, (batch + 7) / 8);
   return rc;
 }
@@ -558,7 +713,7 @@ int zkgpu_verify_batch_ps_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t bat
 int zkgpu_verify_batch_ps(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, const uint8_t* dyn_scalars,
                           const uint8_t* dyn_points, const uint64_t* dyn_offsets, const uint8_t* static_scalars,
                           const uint32_t* static_index, const uint64_t* static_offsets, uint8_t* accept_bitmap) {
-  if (!c || !ps || ps->ctx != c || !accept_bitmap || !dyn_offsets || !static_offsets) return ZKGPU_EINVAL;
+  if (!c || !ps || ps->ctx->device != c->device || !accept_bitmap || !dyn_offsets || !static_offsets) return ZKGPU_EINVAL;
   memset(accept_bitmap, 0, (batch + 7) / 8);
   uint64_t nd = 0, ns = 0;
   if (!offsets_ok(dyn_offsets, batch, &nd) || !offsets_ok(static_offsets, batch, &ns)) return ZKGPU_EINVAL;

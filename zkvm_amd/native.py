@@ -64,6 +64,10 @@ def load_library():
     lib.zkgpu_verify_batch_ps.argtypes = [vp, vp, sz, u8p, u8p, C.POINTER(C.c_uint64), u8p, C.POINTER(C.c_uint32),
                                           C.POINTER(C.c_uint64), u8p]
     lib.zkgpu_verify_batch_ps_dev.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, sz, u8p]
+    lib.zkgpu_pointset_build_tables.argtypes = [vp, vp, C.c_int]
+    lib.zkgpu_pointset_table_bytes.argtypes = [vp]
+    lib.zkgpu_pointset_table_bytes.restype = sz
+    lib.zkgpu_set_static_parts.argtypes = [vp, C.c_int]
     lib.zkgpu_decode_check.argtypes = [vp, u8p, sz, u8p]
     lib.zkgpu_msm_batch.argtypes = [vp, u8p, u8p, C.POINTER(C.c_uint64), sz, u8p, u8p]
     lib.zkgpu_hash_to_points.argtypes = [vp, u8p, sz, u8p]
@@ -103,6 +107,11 @@ class PointSet:
 
     def __len__(self) -> int:
         return int(self.ctx.lib.zkgpu_pointset_size(self.h))
+
+    def build_tables(self, window_bits: int) -> int:
+        """Fixed-base window tables (one-time); returns their size in bytes."""
+        self.ctx._check(self.ctx.lib.zkgpu_pointset_build_tables(self.ctx.h, self.h, window_bits))
+        return int(self.ctx.lib.zkgpu_pointset_table_bytes(self.h))
 
     def close(self) -> None:
         if self.h:
@@ -242,6 +251,9 @@ class Context:
 
     def last_window_bits(self) -> int:
         return int(self.lib.zkgpu_last_window_bits(self.h))
+
+    def set_static_parts(self, parts: int) -> None:
+        self._check(self.lib.zkgpu_set_static_parts(self.h, parts))
 
     def set_window_bits(self, w: int) -> None:
         self._check(self.lib.zkgpu_set_window_bits(self.h, w))
