@@ -111,6 +111,24 @@ int zkgpu_verify_batch_ps_dev(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t b
                               const void *d_static_offsets, size_t n_static,
                               uint8_t *accept_bitmap);
 
+/* Proof bytes in, accept bits out: the whole of bulletproofs::r1cs::Verifier::verify for
+ * a batch of ZkVM `cloak` statements (what Tx::verify spends its time in once the VM has
+ * run).  Statement i: n_in[i] inputs and n_out[i] outputs, each value a pair of Pedersen
+ * commitments (quantity, flavor) -- commitments holds 64 * (n_in[i] + n_out[i]) bytes per
+ * statement, back to back; proofs / proof_offsets are a CSR of R1CSProof encodings.
+ * The transcript replay, constraint flattening and verification scalars run on
+ * `host_threads` host threads (0 = all), the multiscalar multiplications in ONE device
+ * call.  `ps` must hold [B, B_blinding, G_0..G_{cap-1}, H_0..H_{cap-1}] (zkgpu_pedersen_gens
+ * + zkgpu_bulletproof_gens with gens_capacity = cap).  r_bytes: 64 uniform bytes per
+ * statement for the verifier's random weight r, or NULL to draw them from the OS.
+ * A malformed proof (wrong length, non-canonical scalar, identity where the reference's
+ * validate_and_append_point forbids it, more multipliers than generators) clears its bit,
+ * exactly where the reference returns Err. */
+int zkgpu_cloak_verify_batch(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t gens_capacity, size_t batch,
+                             const uint32_t *n_in, const uint32_t *n_out, const uint8_t *commitments,
+                             const uint8_t *proofs, const uint64_t *proof_offsets, const uint8_t *r_bytes,
+                             uint8_t *accept_bitmap, int host_threads);
+
 /* Values instead of identity tests: out[32*i] = compress(sum of row i), or 32
  * zero bytes with bit i of ok_bitmap cleared when a point of row i is invalid
  * (RistrettoPoint::optional_multiscalar_mul returning None). Host pointers. */

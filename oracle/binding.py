@@ -251,3 +251,64 @@ def bulletproof_gens(n: int, which: str, party: int = 0) -> List[bytes]:
     arr = (Ge * n)()
     load().bulletproof_gens_chain(arr, C.c_size_t(n), C.c_char(which.encode()), C.c_uint32(party))
     return [encode(arr[i]) for i in range(n)]
+
+
+# ---- R1CS / cloak (oracle/r1cs.c, oracle/cloak.c) ------------------------------------
+class R1csMsm(C.Structure):
+    _fields_ = [("dyn_scalars", C.POINTER(C.c_uint8)), ("dyn_points", C.POINTER(C.c_uint8)),
+                ("static_scalars", C.POINTER(C.c_uint8)), ("n_dyn", C.c_size_t), ("n_static", C.c_size_t),
+                ("padded_n", C.c_size_t)]
+
+
+def cloak_proof_size(padded_n: int) -> int:
+    lib = load()
+    lib.r1cs_proof_size.restype = C.c_size_t
+    return int(lib.r1cs_proof_size(C.c_size_t(padded_n)))
+
+
+def cloak_prove(q: Sequence[int], flavors: Sequence[bytes], n_in: int, n_out: int, seed: bytes):
+    """-> (rc, commitments[64 * (n_in + n_out)], proof bytes, multipliers)"""
+    nv = n_in + n_out
+    assert len(q) == nv and len(flavors) == nv and len(seed) == 32
+    qa = (C.c_uint64 * nv)(*q)
+    com = C.create_string_buffer(64 * nv)
+    cap = 1 + 32 * (14 + 2 * 16 + 2)
+    proof = C.create_string_buffer(cap)
+    plen, nm = C.c_size_t(0), C.c_size_t(0)
+    rc = load().zko_cloak_prove(qa, b"".join(flavors), C.c_size_t(n_in), C.c_size_t(n_out), seed, com, proof,
+                                C.c_size_t(cap), C.byref(plen), C.byref(nm))
+    return rc, com.raw, proof.raw[: plen.value], nm.value
+
+
+def cloak_prove_batch(count: int, n_in: int, n_out: int, seed: bytes, threads: int = 1):
+    """-> (commitments: count x 64*(n_in+n_out) bytes, proofs: list of bytes)"""
+    nv = n_in + n_out
+    stride = 1 + 32 * (14 + 2 * 16 + 2)
+    com = C.create_string_buffer(64 * nv * count)
+    proofs = C.create_string_buffer(stride * count)
+    plen = C.c_size_t(0)
+    rc = load().zko_cloak_prove_batch(C.c_size_t(count), C.c_size_t(n_in), C.c_size_t(n_out), seed, com, proofs,
+                                      C.c_size_t(stride), C.byref(plen), C.c_int(threads))
+    assert rc == 0, "oracle prover failed"
+    n = plen.value
+    return com.raw, [proofs.raw[i * stride: i * stride + n] for i in range(count)]
+
+
+def cloak_verify(commitments: bytes, n_in: int, n_out: int, proof: bytes, r_bytes: bytes) -> bool:
+    assert len(r_bytes) == 64
+    return bool(load().zko_cloak_verify(commitments, C.c_size_t(n_in), C.c_size_t(n_out), proof,
+                                        C.c_size_t(len(proof)), r_bytes))
+
+
+def cloak_verify_prepare(commitments: bytes, n_in: int, n_out: int, proof: bytes, r_bytes: bytes):
+    """-> None when the proof is malformed, else (dyn_scalars, dyn_points, static_scalars, padded_n)"""
+    m = R1csMsm()
+    lib = load()
+    rc = lib.zko_cloak_verify_prepare(commitments, C.c_size_t(n_in), C.c_size_t(n_out), proof, C.c_size_t(len(proof)),
+                                      r_bytes, C.byref(m))
+    if rc != 0:
+        return None
+    out = (C.string_at(m.dyn_scalars, 32 * m.n_dyn), C.string_at(m.dyn_points, 32 * m.n_dyn),
+           C.string_at(m.static_scalars, 32 * m.n_static), int(m.padded_n))
+    lib.r1cs_msm_free(C.byref(m))
+    return out

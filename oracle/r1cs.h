@@ -1,0 +1,75 @@
+/* r1cs.h -- constraint-system API of the CPU oracle (TEST INFRASTRUCTURE, see oracle.h). */
+#ifndef ZK_ORACLE_R1CS_H
+#define ZK_ORACLE_R1CS_H
+#include "oracle.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VAR_COMMITTED = 0, VAR_MUL_LEFT, VAR_MUL_RIGHT, VAR_MUL_OUT, VAR_ONE };
+typedef struct { int kind; uint32_t idx; } r1cs_var;
+typedef struct { r1cs_var v; sc c; } r1cs_term;
+typedef struct { r1cs_term *t; size_t n, cap; } r1cs_lc;
+typedef struct r1cs_cs r1cs_cs;
+typedef int (*r1cs_rand_fn)(r1cs_cs *cs, void *ud);
+
+void lc_init(r1cs_lc *l);
+void lc_free(r1cs_lc *l);
+void lc_push(r1cs_lc *l, r1cs_var v, const sc *c);
+void lc_push_u64(r1cs_lc *l, r1cs_var v, uint64_t c);
+void lc_push_neg_u64(r1cs_lc *l, r1cs_var v, uint64_t c);
+void lc_add_scaled(r1cs_lc *dst, const r1cs_lc *src, const sc *scale);
+void lc_clone(r1cs_lc *dst, const r1cs_lc *src);
+r1cs_var var_one(void);
+
+r1cs_cs *r1cs_prover_new(const uint8_t *label, size_t len);
+r1cs_cs *r1cs_verifier_new(const uint8_t *label, size_t len);
+void r1cs_free(r1cs_cs *cs);
+r1cs_var r1cs_prover_commit(r1cs_cs *cs, const sc *v, const sc *v_blinding, uint8_t out[32]);
+r1cs_var r1cs_verifier_commit(r1cs_cs *cs, const uint8_t commitment[32]);
+void r1cs_constrain(r1cs_cs *cs, r1cs_lc *l);                              /* consumes l */
+void r1cs_multiply(r1cs_cs *cs, r1cs_lc *left, r1cs_lc *right, r1cs_var out[3]); /* consumes both */
+r1cs_var r1cs_allocate(r1cs_cs *cs, const sc *assignment);                 /* NULL for a verifier */
+void r1cs_allocate_multiplier(r1cs_cs *cs, const sc *l, const sc *r, r1cs_var out[3]);
+int r1cs_specify_randomized_constraints(r1cs_cs *cs, r1cs_rand_fn fn, void *ud);
+void r1cs_challenge_scalar(r1cs_cs *cs, const char *label, sc *out);       /* second phase only */
+int r1cs_is_prover(const r1cs_cs *cs);
+size_t r1cs_num_multipliers(const r1cs_cs *cs);
+size_t r1cs_num_constraints(const r1cs_cs *cs);
+size_t r1cs_num_commitments(const r1cs_cs *cs);
+
+size_t r1cs_proof_size(size_t padded_n);
+int r1cs_prove(r1cs_cs *cs, const uint8_t rng_seed[32], uint8_t *proof, size_t proof_cap, size_t *proof_len);
+
+typedef struct {
+  uint8_t *dyn_scalars, *dyn_points;   /* n_dyn x 32 */
+  uint8_t *static_scalars;             /* n_static x 32: B, B_blinding, G_0.., H_0.. */
+  size_t n_dyn, n_static, padded_n;
+} r1cs_msm;
+int r1cs_verify_prepare(r1cs_cs *cs, const uint8_t *proof, size_t proof_len, const uint8_t r_bytes[64], r1cs_msm *out);
+void r1cs_msm_free(r1cs_msm *m);
+int r1cs_verify(r1cs_cs *cs, const uint8_t *proof, size_t proof_len, const uint8_t r_bytes[64]); /* 1 accept */
+
+/* ---- spacesuit "cloak" gadget and a whole-transaction-shaped statement -------- */
+typedef struct { r1cs_var q, f; uint64_t q_val; sc f_val; int has_assignment; } cloak_value;
+int cloak_gadget(r1cs_cs *cs, const cloak_value *inputs, size_t n_in, const cloak_value *outputs, size_t n_out);
+
+/* Prove / verify "n_in inputs -> n_out outputs balance per flavor, outputs in [0, 2^64)".
+ * quantities q[i], flavors f[i] (32-byte scalars) listed inputs first.
+ * commitments: 2 * (n_in + n_out) compressed Pedersen commitments (q, f per value). */
+int zko_cloak_prove(const uint64_t *q, const uint8_t *flavors, size_t n_in, size_t n_out, const uint8_t seed[32],
+                    uint8_t *commitments, uint8_t *proof, size_t proof_cap, size_t *proof_len,
+                    size_t *n_multipliers);
+int zko_cloak_verify(const uint8_t *commitments, size_t n_in, size_t n_out, const uint8_t *proof, size_t proof_len,
+                     const uint8_t r_bytes[64]);
+int zko_cloak_verify_prepare(const uint8_t *commitments, size_t n_in, size_t n_out, const uint8_t *proof,
+                             size_t proof_len, const uint8_t r_bytes[64], r1cs_msm *out);
+/* batch helper: many proofs of the same shape, OpenMP over proofs */
+int zko_cloak_prove_batch(size_t count, size_t n_in, size_t n_out, const uint8_t seed[32], uint8_t *commitments,
+                          uint8_t *proofs, size_t proof_stride, size_t *proof_len, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

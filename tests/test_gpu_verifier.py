@@ -1,0 +1,66 @@
+"""GPU parity for the proof-bytes boundary: zkgpu_cloak_verify_batch (host transcript replay in C++
++ device MSMs) vs the oracle's Verifier on the same proof bytes; and the product's MSM terms vs the
+oracle's."""
+import hashlib
+
+import pytest
+
+from gpu_util import bits
+
+pytestmark = pytest.mark.gpu
+L = 2**252 + 27742317777372353535851937790883648493
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from zkvm_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _txs(oracle, count, n_in, n_out, seed):
+    from zkvm_amd.verifier import CloakTx
+    com, proofs = oracle.cloak_prove_batch(count, n_in, n_out, seed, threads=8)
+    w = 64 * (n_in + n_out)
+    return [CloakTx(n_in, n_out, com[w * i: w * (i + 1)], proofs[i]) for i in range(count)]
+
+
+@pytest.mark.parametrize("table_bits", [0, 9])
+def test_cloak_verify_batch_vs_oracle(ctx, oracle, table_bits):
+    from zkvm_amd.verifier import BulletproofGens, CloakTx, InvalidR1CSProof, Verifier
+    gens = BulletproofGens(ctx, 256, table_bits=table_bits)
+    txs = _txs(oracle, 24, 2, 2, b"\x01" * 32) + _txs(oracle, 6, 1, 2, b"\x02" * 32) + _txs(oracle, 6, 3, 3, b"\x03" * 32)
+    # corruptions: proof byte, commitment byte, truncated proof, identity T_1, non-canonical t_x, wrong shape
+    def mut(tx, **kw):
+        return CloakTx(kw.get("n_in", tx.n_in), kw.get("n_out", tx.n_out), kw.get("commitments", tx.commitments),
+                       kw.get("proof", tx.proof))
+    p = bytearray(txs[3].proof); p[1 + 32 * 12 + 3] ^= 0x10; txs[3] = mut(txs[3], proof=bytes(p))
+    cm = bytearray(txs[5].commitments); cm[70] ^= 1; txs[5] = mut(txs[5], commitments=bytes(cm))
+    txs[7] = mut(txs[7], proof=txs[7].proof[:-32])
+    p = bytearray(txs[9].proof); p[1 + 32 * 6: 1 + 32 * 7] = bytes(32); txs[9] = mut(txs[9], proof=bytes(p))
+    p = bytearray(txs[11].proof); p[1 + 32 * 11: 1 + 32 * 12] = L.to_bytes(32, "little"); txs[11] = mut(txs[11], proof=bytes(p))
+    txs[13] = mut(txs[13], proof=txs[14].proof)                       # someone else's proof
+    p = bytearray(txs[15].proof); p[1 + 32 * 2: 1 + 32 * 3] = bytes.fromhex("01" + "00" * 31); txs[15] = mut(txs[15], proof=bytes(p))
+    r = hashlib.shake_256(b"verifier r").digest(64 * len(txs))
+    want = [int(oracle.cloak_verify(t.commitments, t.n_in, t.n_out, t.proof, r[64 * i: 64 * i + 64]))
+            for i, t in enumerate(txs)]
+    assert want.count(0) == 7 and want.count(1) == len(txs) - 7
+    v = Verifier(ctx, gens, host_threads=4)
+    bm = v.verify_bitmap(txs, r)
+    assert bits(bm, len(txs)) == want
+    res = v.verify_cloak_txs(txs, r)
+    assert [x is None for x in res] == [bool(b) for b in want]
+    assert all(isinstance(x, InvalidR1CSProof) for x in res if x is not None)
+    # OS randomness for r: same verdicts
+    assert bits(v.verify_bitmap(txs), len(txs)) == want
+    assert v.verify_bitmap([]) == b""
+    gens.close()
+
+
+def test_generators_capacity_too_small_rejects(ctx, oracle):
+    from zkvm_amd.verifier import BulletproofGens, Verifier
+    gens = BulletproofGens(ctx, 128)           # 2-in/2-out needs 256
+    txs = _txs(oracle, 2, 2, 2, b"\x04" * 32)
+    assert Verifier(ctx, gens).verify_bitmap(txs) == b"\x00"   # InvalidGeneratorsLength in the reference
+    gens.close()

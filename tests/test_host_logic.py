@@ -1,0 +1,107 @@
+"""Product host logic on CPU (no GPU): scalar field, Merlin transcript and the R1CS verifier's scalar
+preparation (zkvm_amd/csrc/{scalar,merlin,r1cs_verifier}.hpp via libzkhost.so) vs the oracle.
+The MSM terms must agree byte for byte: same challenges, same flattened constraints, same s vector."""
+import ctypes as C
+import hashlib
+import os
+import random
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L = 2**252 + 27742317777372353535851937790883648493
+
+
+@pytest.fixture(scope="module")
+def host():
+    from zkvm_amd import build
+    build.build()
+    return C.CDLL(os.path.join(ROOT, "zkvm_amd", "lib", "libzkhost.so"))
+
+
+def _op(host, op, a, b=0):
+    out = C.create_string_buffer(32)
+    assert host.zkhost_scalar_op(op, a.to_bytes(64, "little"), b.to_bytes(64, "little"), out) == 0
+    return int.from_bytes(out.raw, "little")
+
+
+def test_scalar_field_vs_bigint(host):
+    rng = random.Random(9)
+    edge = [0, 1, L - 1, L, L + 1, 2**252, 2**256 - 1, 2**512 - 1, L * L, 2**511 + 7]
+    xs = edge + [rng.getrandbits(512) for _ in range(150)]
+    for a in xs:
+        assert _op(host, 5, a) == a % L
+        assert _op(host, 3, a) == (-a) % L
+        for b in rng.sample(xs, 4):
+            assert _op(host, 0, a, b) == (a + b) % L
+            assert _op(host, 1, a, b) == (a - b) % L
+            assert _op(host, 2, a, b) == (a * b) % L
+    for a in xs[:6] + xs[10:14]:
+        if a % L:
+            assert _op(host, 4, a) == pow(a, -1, L)
+    assert host.zkhost_scalar_is_canonical((L - 1).to_bytes(32, "little")) == 1
+    assert host.zkhost_scalar_is_canonical(L.to_bytes(32, "little")) == 0
+    assert host.zkhost_scalar_is_canonical((2**256 - 1).to_bytes(32, "little")) == 0
+
+
+def _merlin(host, label, msgs, ch_label, n):
+    k = len(msgs)
+    labels = (C.c_char_p * k)(*[m[0] for m in msgs])
+    bufs = [C.create_string_buffer(m[1], len(m[1])) for m in msgs]
+    ptrs = (C.c_void_p * k)(*[C.addressof(b) for b in bufs])
+    lens = (C.c_size_t * k)(*[len(m[1]) for m in msgs])
+    out = C.create_string_buffer(n)
+    host.zkhost_merlin(label, k, labels, ptrs, lens, ch_label, out, C.c_size_t(n))
+    return out.raw
+
+
+def test_merlin_known_answer_and_vs_oracle(host, oracle):
+    got = _merlin(host, b"test protocol", [(b"some label", b"some data")], b"challenge", 32)
+    assert got.hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    rng = random.Random(10)
+    msgs = [(b"l%d" % i, bytes(rng.getrandbits(8) for _ in range(rng.choice([0, 1, 32, 165, 166, 167, 500])))) for i in range(12)]
+    t = oracle.MerlinTranscript(b"ZkVM.r1cs")
+    for lab, m in msgs:
+        t.append_message(lab, m)
+    assert _merlin(host, b"ZkVM.r1cs", msgs, b"c", 200) == t.challenge_bytes(b"c", 200)
+
+
+def _prepare(host, com, n_in, n_out, proof, r, cap):
+    ds, dp = C.create_string_buffer(32 * 128), C.create_string_buffer(32 * 128)
+    ss, si = C.create_string_buffer(32 * (2 + 2 * cap)), (C.c_uint32 * (2 + 2 * cap))()
+    nd, ns, pn = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    rc = host.zkhost_cloak_prepare(com, C.c_size_t(n_in), C.c_size_t(n_out), proof, C.c_size_t(len(proof)), r,
+                                   C.c_size_t(cap), ds, dp, C.byref(nd), ss, si, C.byref(ns), C.byref(pn))
+    if rc:
+        return None
+    return ds.raw[: 32 * nd.value], dp.raw[: 32 * nd.value], ss.raw[: 32 * ns.value], list(si[: ns.value]), pn.value
+
+
+@pytest.mark.parametrize("n_in,n_out", [(1, 1), (2, 2), (1, 2), (3, 3)])
+def test_verifier_msm_terms_equal_oracle(host, oracle, n_in, n_out):
+    com, proofs = oracle.cloak_prove_batch(3, n_in, n_out, bytes([n_in * 16 + n_out] * 32), threads=2)
+    w = 64 * (n_in + n_out)
+    for i, proof in enumerate(proofs):
+        r = hashlib.shake_256(b"r%d" % i).digest(64)
+        want = oracle.cloak_verify_prepare(com[w * i: w * (i + 1)], n_in, n_out, proof, r)
+        cap = 256
+        got = _prepare(host, com[w * i: w * (i + 1)], n_in, n_out, proof, r, cap)
+        assert got is not None and want is not None
+        assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2] and got[4] == want[3]
+        pn = got[4]
+        assert got[3] == [0, 1] + [2 + j for j in range(pn)] + [2 + cap + j for j in range(pn)]
+
+
+def test_verifier_prepare_rejects_malformed(host, oracle):
+    com, proofs = oracle.cloak_prove_batch(1, 2, 2, b"\x09" * 32)
+    r = bytes(64)
+    proof = proofs[0]
+    assert _prepare(host, com, 2, 2, proof, r, 256) is not None
+    assert _prepare(host, com, 2, 2, proof, r, 128) is None                        # not enough generators
+    assert _prepare(host, com, 2, 2, proof[:-32], r, 256) is None
+    assert _prepare(host, com, 2, 2, b"\x00" + proof[1:], r, 256) is None          # wrong version tag
+    bad = bytearray(proof); bad[1 + 32 * 7: 1 + 32 * 8] = bytes(32)
+    assert _prepare(host, com, 2, 2, bytes(bad), r, 256) is None                   # T_3 = identity
+    bad = bytearray(proof); bad[-32:] = L.to_bytes(32, "little")
+    assert _prepare(host, com, 2, 2, bytes(bad), r, 256) is None                   # b not canonical
+    assert _prepare(host, com, 1, 1, proof, r, 256) is None                        # k does not match the statement

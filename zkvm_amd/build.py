@@ -8,12 +8,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "zkgpu.hip")
 OUT = os.path.join(HERE, "lib", "libzkgpu.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("zkgpu.hip", "kernels.hpp", "curve.hpp", "field.hpp", "constants.inc")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("zkgpu.hip", "kernels.hpp", "quad.hpp", "curve.hpp", "field.hpp", "constants.inc",
+                                                  "keccak.hpp", "scalar.hpp", "merlin.hpp", "r1cs_verifier.hpp", "hostlib.cpp")]
+HOST_SRC = os.path.join(HERE, "csrc", "hostlib.cpp")
+HOST_OUT = os.path.join(HERE, "lib", "libzkhost.so")
 DEPS.append(os.path.join(HERE, "..", "include", "zkgpu.h"))
 
 
 def stale() -> bool:
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(HOST_OUT):
         return True
     t = os.path.getmtime(OUT)
     return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
@@ -28,6 +31,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    # host-only logic (scalars, Merlin, R1CS verifier preparation) for the CPU test tier
+    cxx = os.environ.get("CXX", "g++")
+    subprocess.run([cxx, "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-o", HOST_OUT, HOST_SRC], check=True)
     return OUT
 
 

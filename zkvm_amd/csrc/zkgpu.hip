@@ -16,7 +16,11 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <random>
+#include <thread>
 #include <vector>
+
+#include "r1cs_verifier.hpp"
 
 using namespace zk;
 
@@ -756,6 +760,70 @@ int zkgpu_decode_check(zkgpu_ctx* c, const uint8_t* points, size_t n, uint8_t* o
   HIP_TRY(c, hipMemcpyAsync(ok, c->ok_bytes.p, n, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->profiling) prof_collect(c);
+  return ZKGPU_OK;
+}
+
+// ---- proof bytes in, accept bits out -------------------------------------------------
+// Host side of r1cs::Verifier::verify for ZkVM `cloak` statements (r1cs_verifier.hpp),
+// spread over `host_threads` threads, then ONE device call for the whole batch.
+int zkgpu_cloak_verify_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_capacity, size_t batch,
+                             const uint32_t* n_in, const uint32_t* n_out, const uint8_t* commitments,
+                             const uint8_t* proofs, const uint64_t* proof_offsets, const uint8_t* r_bytes,
+                             uint8_t* accept_bitmap, int host_threads) {
+  if (!c || !ps || !accept_bitmap || (batch && (!n_in || !n_out || !commitments || !proofs || !proof_offsets)))
+    return ZKGPU_EINVAL;
+  memset(accept_bitmap, 0, (batch + 7) / 8);
+  if (ps->n < 2 + 2 * gens_capacity) return ZKGPU_EINVAL;
+  if (batch == 0) return ZKGPU_OK;
+  std::vector<uint64_t> com_off(batch + 1, 0);
+  for (size_t i = 0; i < batch; ++i) com_off[i + 1] = com_off[i] + 64ull * ((uint64_t)n_in[i] + n_out[i]);
+  std::vector<VerifierMsm> prep(batch);
+  std::vector<uint8_t> wellformed(batch, 0);
+  // verifier randomness r: caller-provided (reproducible) or from the OS
+  std::vector<uint8_t> rnd;
+  if (!r_bytes) {
+    rnd.resize(64 * batch);
+    std::random_device rd;
+    for (size_t i = 0; i < rnd.size(); i += 4) { uint32_t v = rd(); memcpy(&rnd[i], &v, 4); }
+    r_bytes = rnd.data();
+  }
+  const int nt = std::max(1, std::min<int>(host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency(), 256));
+  auto work = [&](int tid) {
+    for (size_t i = (size_t)tid; i < batch; i += (size_t)nt) {
+      if (proof_offsets[i + 1] < proof_offsets[i]) continue;
+      const Scalar r = Scalar::from_wide(r_bytes + 64 * i);
+      wellformed[i] = cloak::prepare_tx(commitments + com_off[i], n_in[i], n_out[i], proofs + proof_offsets[i],
+                                        (size_t)(proof_offsets[i + 1] - proof_offsets[i]), r, gens_capacity, prep[i])
+                          ? 1 : 0;
+    }
+  };
+  if (nt == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto& t : th) t.join();
+  }
+  // CSR over the well-formed proofs (malformed ones keep an empty row and are masked out below)
+  std::vector<uint64_t> dyn_off(batch + 1, 0), st_off(batch + 1, 0);
+  for (size_t i = 0; i < batch; ++i) {
+    dyn_off[i + 1] = dyn_off[i] + (wellformed[i] ? prep[i].dyn_scalars.size() / 32 : 0);
+    st_off[i + 1] = st_off[i] + (wellformed[i] ? prep[i].static_scalars.size() / 32 : 0);
+  }
+  std::vector<uint8_t> dyn_sc(32 * dyn_off[batch]), dyn_pt(32 * dyn_off[batch]), st_sc(32 * st_off[batch]);
+  std::vector<uint32_t> st_idx(st_off[batch]);
+  for (size_t i = 0; i < batch; ++i) {
+    if (!wellformed[i]) continue;
+    memcpy(&dyn_sc[32 * dyn_off[i]], prep[i].dyn_scalars.data(), prep[i].dyn_scalars.size());
+    memcpy(&dyn_pt[32 * dyn_off[i]], prep[i].dyn_points.data(), prep[i].dyn_points.size());
+    memcpy(&st_sc[32 * st_off[i]], prep[i].static_scalars.data(), prep[i].static_scalars.size());
+    memcpy(&st_idx[st_off[i]], prep[i].static_index.data(), prep[i].static_index.size() * 4);
+  }
+  int rc = zkgpu_verify_batch_ps(c, ps, batch, dyn_sc.data(), dyn_pt.data(), dyn_off.data(), st_sc.data(),
+                                 st_idx.data(), st_off.data(), accept_bitmap);
+  if (rc != ZKGPU_OK) { memset(accept_bitmap, 0, (batch + 7) / 8); return rc; }
+  for (size_t i = 0; i < batch; ++i)
+    if (!wellformed[i]) accept_bitmap[i / 8] &= (uint8_t)~(1u << (i % 8));
   return ZKGPU_OK;
 }
 

@@ -1,0 +1,91 @@
+"""Host-side mirror of the reference's verification API for the path this repo accelerates.
+
+Upstream (slingshot/zkvm, Rust; not mounted under /root/reference -- SURVEY.md sec 8(b)):
+
+    Tx::verify(&self, bp_gens: &BulletproofGens) -> Result<VerifiedTx, VMError>
+    Verifier::verify_tx(tx: &Tx, bp_gens: &BulletproofGens) -> Result<VerifiedTx, VMError>
+
+Both run the VM over the program (out of scope here: SURVEY.md sec 2) and then spend their
+time in `r1cs::Verifier::verify(proof, pc_gens, bp_gens)`.  `Verifier.verify_cloak_txs` below
+is that second half for a batch: same inputs a `cloak` instruction leaves behind (value
+commitments + R1CSProof bytes), same per-transaction Ok / Err outcome, one GPU call.
+
+`BulletproofGens(gens_capacity)` mirrors `BulletproofGens::new(gens_capacity, 1)`: it owns the
+device-resident generator set (and its fixed-base tables) instead of a Vec<RistrettoPoint>.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+from .native import Context, PointSet, ZkGpuError
+
+
+class VMError(Exception):
+    """Mirror of zkvm::VMError for the variants this path can produce."""
+
+
+class InvalidR1CSProof(VMError):
+    pass
+
+
+@dataclass
+class CloakTx:
+    """What a ZkVM `cloak` leaves for the proof system: (quantity, flavor) commitments of the
+    inputs then the outputs (64 bytes per value) and the R1CSProof encoding."""
+    n_in: int
+    n_out: int
+    commitments: bytes
+    proof: bytes
+
+
+class BulletproofGens:
+    def __init__(self, ctx: Context, gens_capacity: int, table_bits: int = 0):
+        self.ctx = ctx
+        self.gens_capacity = gens_capacity
+        b, bb = ctx.pedersen_gens()
+        g, h = ctx.bulletproof_gens(gens_capacity)
+        self.points = PointSet(ctx, b + bb + g + h)
+        if table_bits:
+            self.points.build_tables(table_bits)
+
+    def close(self) -> None:
+        self.points.close()
+
+
+class Verifier:
+    """Batch verifier; `verify_cloak_txs` returns one Optional[VMError] per transaction
+    (None = Ok), the shape of `txs.iter().map(|tx| tx.verify(bp_gens))`."""
+
+    def __init__(self, ctx: Context, bp_gens: BulletproofGens, host_threads: int = 0):
+        self.ctx = ctx
+        self.bp_gens = bp_gens
+        self.host_threads = host_threads
+
+    def verify_bitmap(self, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None) -> bytes:
+        batch = len(txs)
+        n_in = (C.c_uint32 * max(batch, 1))(*[t.n_in for t in txs])
+        n_out = (C.c_uint32 * max(batch, 1))(*[t.n_out for t in txs])
+        offs = [0]
+        for t in txs:
+            if len(t.commitments) != 64 * (t.n_in + t.n_out):
+                raise ValueError("commitments must hold 64 bytes per value")
+            offs.append(offs[-1] + len(t.proof))
+        po = (C.c_uint64 * (batch + 1))(*offs)
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        if r_bytes is not None and len(r_bytes) != 64 * batch:
+            raise ValueError("r_bytes must hold 64 bytes per transaction")
+        rc = self.ctx.lib.zkgpu_cloak_verify_batch(
+            self.ctx.h, self.bp_gens.points.h, self.bp_gens.gens_capacity, batch, n_in, n_out,
+            b"".join(t.commitments for t in txs), b"".join(t.proof for t in txs), po, r_bytes, bm, self.host_threads)
+        self.ctx._check(rc)
+        return bm.raw[: (batch + 7) // 8]
+
+    def verify_cloak_txs(self, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None) -> List[Optional[VMError]]:
+        try:
+            bm = self.verify_bitmap(txs, r_bytes)
+        except ZkGpuError as e:   # fail closed: a device error is never an accept
+            return [VMError(str(e)) for _ in txs]
+        return [None if (bm[i // 8] >> (i % 8)) & 1 else InvalidR1CSProof("R1CS proof did not verify")
+                for i in range(len(txs))]
