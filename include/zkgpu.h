@@ -129,6 +129,18 @@ int zkgpu_cloak_verify_batch(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t ge
                              const uint8_t *proofs, const uint64_t *proof_offsets, const uint8_t *r_bytes,
                              uint8_t *accept_bitmap, int host_threads);
 
+/* The host half of zkgpu_cloak_verify_batch alone: proof bytes -> the CSR of multiscalar
+ * multiplication terms that zkgpu_verify_batch_ps* consumes (no device involved).
+ * Statement i needs 11 + 2 (n_in+n_out) + 2k dynamic and 2 + 2 * 2^k static terms (k = lg of
+ * its padded multiplier count); *_capacity are in terms.  wellformed[i] = 0 marks a proof
+ * the reference would reject before the multiplication (its rows are left empty). */
+int zkgpu_cloak_prepare_batch(size_t gens_capacity, size_t batch, const uint32_t *n_in, const uint32_t *n_out,
+                              const uint8_t *commitments, const uint8_t *proofs, const uint64_t *proof_offsets,
+                              const uint8_t *r_bytes, int host_threads, uint8_t *dyn_scalars, uint8_t *dyn_points,
+                              uint64_t *dyn_offsets, size_t dyn_capacity, uint8_t *static_scalars,
+                              uint32_t *static_index, uint64_t *static_offsets, size_t static_capacity,
+                              uint8_t *wellformed);
+
 /* Values instead of identity tests: out[32*i] = compress(sum of row i), or 32
  * zero bytes with bit i of ok_bitmap cleared when a point of row i is invalid
  * (RistrettoPoint::optional_multiscalar_mul returning None). Host pointers. */

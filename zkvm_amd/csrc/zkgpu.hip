@@ -766,19 +766,20 @@ int zkgpu_decode_check(zkgpu_ctx* c, const uint8_t* points, size_t n, uint8_t* o
 // ---- proof bytes in, accept bits out -------------------------------------------------
 // Host side of r1cs::Verifier::verify for ZkVM `cloak` statements (r1cs_verifier.hpp),
 // spread over `host_threads` threads, then ONE device call for the whole batch.
-int zkgpu_cloak_verify_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_capacity, size_t batch,
-                             const uint32_t* n_in, const uint32_t* n_out, const uint8_t* commitments,
-                             const uint8_t* proofs, const uint64_t* proof_offsets, const uint8_t* r_bytes,
-                             uint8_t* accept_bitmap, int host_threads) {
-  if (!c || !ps || !accept_bitmap || (batch && (!n_in || !n_out || !commitments || !proofs || !proof_offsets)))
-    return ZKGPU_EINVAL;
-  memset(accept_bitmap, 0, (batch + 7) / 8);
-  if (ps->n < 2 + 2 * gens_capacity) return ZKGPU_EINVAL;
-  if (batch == 0) return ZKGPU_OK;
+namespace {
+struct CloakBatch {
+  std::vector<uint64_t> dyn_off, st_off;
+  std::vector<uint8_t> dyn_sc, dyn_pt, st_sc, wellformed;
+  std::vector<uint32_t> st_idx;
+};
+
+int prepare_cloak_batch(size_t gens_capacity, size_t batch, const uint32_t* n_in, const uint32_t* n_out,
+                        const uint8_t* commitments, const uint8_t* proofs, const uint64_t* proof_offsets,
+                        const uint8_t* r_bytes, int host_threads, CloakBatch& out) {
   std::vector<uint64_t> com_off(batch + 1, 0);
   for (size_t i = 0; i < batch; ++i) com_off[i + 1] = com_off[i] + 64ull * ((uint64_t)n_in[i] + n_out[i]);
   std::vector<VerifierMsm> prep(batch);
-  std::vector<uint8_t> wellformed(batch, 0);
+  out.wellformed.assign(batch, 0);
   // verifier randomness r: caller-provided (reproducible) or from the OS
   std::vector<uint8_t> rnd;
   if (!r_bytes) {
@@ -792,9 +793,9 @@ int zkgpu_cloak_verify_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens
     for (size_t i = (size_t)tid; i < batch; i += (size_t)nt) {
       if (proof_offsets[i + 1] < proof_offsets[i]) continue;
       const Scalar r = Scalar::from_wide(r_bytes + 64 * i);
-      wellformed[i] = cloak::prepare_tx(commitments + com_off[i], n_in[i], n_out[i], proofs + proof_offsets[i],
-                                        (size_t)(proof_offsets[i + 1] - proof_offsets[i]), r, gens_capacity, prep[i])
-                          ? 1 : 0;
+      out.wellformed[i] = cloak::prepare_tx(commitments + com_off[i], n_in[i], n_out[i], proofs + proof_offsets[i],
+                                            (size_t)(proof_offsets[i + 1] - proof_offsets[i]), r, gens_capacity,
+                                            prep[i]) ? 1 : 0;
     }
   };
   if (nt == 1) {
@@ -804,26 +805,65 @@ int zkgpu_cloak_verify_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens
     for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
     for (auto& t : th) t.join();
   }
-  // CSR over the well-formed proofs (malformed ones keep an empty row and are masked out below)
-  std::vector<uint64_t> dyn_off(batch + 1, 0), st_off(batch + 1, 0);
+  // CSR over the well-formed proofs (malformed ones keep an empty row and are masked out by the caller)
+  out.dyn_off.assign(batch + 1, 0);
+  out.st_off.assign(batch + 1, 0);
   for (size_t i = 0; i < batch; ++i) {
-    dyn_off[i + 1] = dyn_off[i] + (wellformed[i] ? prep[i].dyn_scalars.size() / 32 : 0);
-    st_off[i + 1] = st_off[i] + (wellformed[i] ? prep[i].static_scalars.size() / 32 : 0);
+    out.dyn_off[i + 1] = out.dyn_off[i] + (out.wellformed[i] ? prep[i].dyn_scalars.size() / 32 : 0);
+    out.st_off[i + 1] = out.st_off[i] + (out.wellformed[i] ? prep[i].static_scalars.size() / 32 : 0);
   }
-  std::vector<uint8_t> dyn_sc(32 * dyn_off[batch]), dyn_pt(32 * dyn_off[batch]), st_sc(32 * st_off[batch]);
-  std::vector<uint32_t> st_idx(st_off[batch]);
+  out.dyn_sc.resize(32 * out.dyn_off[batch]);
+  out.dyn_pt.resize(32 * out.dyn_off[batch]);
+  out.st_sc.resize(32 * out.st_off[batch]);
+  out.st_idx.resize(out.st_off[batch]);
   for (size_t i = 0; i < batch; ++i) {
-    if (!wellformed[i]) continue;
-    memcpy(&dyn_sc[32 * dyn_off[i]], prep[i].dyn_scalars.data(), prep[i].dyn_scalars.size());
-    memcpy(&dyn_pt[32 * dyn_off[i]], prep[i].dyn_points.data(), prep[i].dyn_points.size());
-    memcpy(&st_sc[32 * st_off[i]], prep[i].static_scalars.data(), prep[i].static_scalars.size());
-    memcpy(&st_idx[st_off[i]], prep[i].static_index.data(), prep[i].static_index.size() * 4);
+    if (!out.wellformed[i]) continue;
+    memcpy(&out.dyn_sc[32 * out.dyn_off[i]], prep[i].dyn_scalars.data(), prep[i].dyn_scalars.size());
+    memcpy(&out.dyn_pt[32 * out.dyn_off[i]], prep[i].dyn_points.data(), prep[i].dyn_points.size());
+    memcpy(&out.st_sc[32 * out.st_off[i]], prep[i].static_scalars.data(), prep[i].static_scalars.size());
+    memcpy(&out.st_idx[out.st_off[i]], prep[i].static_index.data(), prep[i].static_index.size() * 4);
   }
-  int rc = zkgpu_verify_batch_ps(c, ps, batch, dyn_sc.data(), dyn_pt.data(), dyn_off.data(), st_sc.data(),
-                                 st_idx.data(), st_off.data(), accept_bitmap);
+  return ZKGPU_OK;
+}
+}  // namespace
+
+int zkgpu_cloak_prepare_batch(size_t gens_capacity, size_t batch, const uint32_t* n_in, const uint32_t* n_out,
+                              const uint8_t* commitments, const uint8_t* proofs, const uint64_t* proof_offsets,
+                              const uint8_t* r_bytes, int host_threads, uint8_t* dyn_scalars, uint8_t* dyn_points,
+                              uint64_t* dyn_offsets, size_t dyn_capacity, uint8_t* static_scalars,
+                              uint32_t* static_index, uint64_t* static_offsets, size_t static_capacity,
+                              uint8_t* wellformed) {
+  if (batch && (!n_in || !n_out || !commitments || !proofs || !proof_offsets)) return ZKGPU_EINVAL;
+  if (!dyn_offsets || !static_offsets || !wellformed) return ZKGPU_EINVAL;
+  CloakBatch cb;
+  TRY(prepare_cloak_batch(gens_capacity, batch, n_in, n_out, commitments, proofs, proof_offsets, r_bytes,
+                          host_threads, cb));
+  if (cb.dyn_off[batch] > dyn_capacity || cb.st_off[batch] > static_capacity) return ZKGPU_EINVAL;
+  memcpy(dyn_offsets, cb.dyn_off.data(), (batch + 1) * 8);
+  memcpy(static_offsets, cb.st_off.data(), (batch + 1) * 8);
+  memcpy(wellformed, cb.wellformed.data(), batch);
+  if (!cb.dyn_sc.empty()) { memcpy(dyn_scalars, cb.dyn_sc.data(), cb.dyn_sc.size()); memcpy(dyn_points, cb.dyn_pt.data(), cb.dyn_pt.size()); }
+  if (!cb.st_sc.empty()) { memcpy(static_scalars, cb.st_sc.data(), cb.st_sc.size()); memcpy(static_index, cb.st_idx.data(), cb.st_idx.size() * 4); }
+  return ZKGPU_OK;
+}
+
+int zkgpu_cloak_verify_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_capacity, size_t batch,
+                             const uint32_t* n_in, const uint32_t* n_out, const uint8_t* commitments,
+                             const uint8_t* proofs, const uint64_t* proof_offsets, const uint8_t* r_bytes,
+                             uint8_t* accept_bitmap, int host_threads) {
+  if (!c || !ps || !accept_bitmap || (batch && (!n_in || !n_out || !commitments || !proofs || !proof_offsets)))
+    return ZKGPU_EINVAL;
+  memset(accept_bitmap, 0, (batch + 7) / 8);
+  if (ps->n < 2 + 2 * gens_capacity) return ZKGPU_EINVAL;
+  if (batch == 0) return ZKGPU_OK;
+  CloakBatch cb;
+  TRY(prepare_cloak_batch(gens_capacity, batch, n_in, n_out, commitments, proofs, proof_offsets, r_bytes,
+                          host_threads, cb));
+  int rc = zkgpu_verify_batch_ps(c, ps, batch, cb.dyn_sc.data(), cb.dyn_pt.data(), cb.dyn_off.data(), cb.st_sc.data(),
+                                 cb.st_idx.data(), cb.st_off.data(), accept_bitmap);
   if (rc != ZKGPU_OK) { memset(accept_bitmap, 0, (batch + 7) / 8); return rc; }
   for (size_t i = 0; i < batch; ++i)
-    if (!wellformed[i]) accept_bitmap[i / 8] &= (uint8_t)~(1u << (i % 8));
+    if (!cb.wellformed[i]) accept_bitmap[i / 8] &= (uint8_t)~(1u << (i % 8));
   return ZKGPU_OK;
 }
 

@@ -71,6 +71,9 @@ def load_library():
     lib.zkgpu_decode_check.argtypes = [vp, u8p, sz, u8p]
     lib.zkgpu_cloak_verify_batch.argtypes = [vp, vp, sz, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p, u8p,
                                              C.POINTER(C.c_uint64), u8p, u8p, C.c_int]
+    lib.zkgpu_cloak_prepare_batch.argtypes = [sz, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p, u8p,
+                                              C.POINTER(C.c_uint64), u8p, C.c_int, u8p, u8p, C.POINTER(C.c_uint64), sz,
+                                              u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), sz, u8p]
     lib.zkgpu_msm_batch.argtypes = [vp, u8p, u8p, C.POINTER(C.c_uint64), sz, u8p, u8p]
     lib.zkgpu_hash_to_points.argtypes = [vp, u8p, sz, u8p]
     lib.zkgpu_pedersen_gens.argtypes = [vp, u8p, u8p]

@@ -82,6 +82,32 @@ class Verifier:
         self.ctx._check(rc)
         return bm.raw[: (batch + 7) // 8]
 
+    def prepare(self, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None):
+        """Host half only: proof bytes -> MSM terms (CSR) for Context.verify_batch_ps*.
+        -> dict(dyn_sc, dyn_pt, dyn_off, st_sc, st_idx, st_off, wellformed)"""
+        batch = len(txs)
+        n_in = (C.c_uint32 * max(batch, 1))(*[t.n_in for t in txs])
+        n_out = (C.c_uint32 * max(batch, 1))(*[t.n_out for t in txs])
+        offs = [0]
+        dyn_cap = st_cap = 0
+        for t in txs:
+            offs.append(offs[-1] + len(t.proof))
+            k = max(0, ((len(t.proof) - 1) // 32 - 16) // 2)
+            dyn_cap += 11 + 2 * (t.n_in + t.n_out) + 2 * k
+            st_cap += 2 + 2 * (1 << min(k, 20))
+        po = (C.c_uint64 * (batch + 1))(*offs)
+        ds, dp = C.create_string_buffer(max(32 * dyn_cap, 1)), C.create_string_buffer(max(32 * dyn_cap, 1))
+        ss, si = C.create_string_buffer(max(32 * st_cap, 1)), (C.c_uint32 * max(st_cap, 1))()
+        do, so = (C.c_uint64 * (batch + 1))(), (C.c_uint64 * (batch + 1))()
+        wf = C.create_string_buffer(max(batch, 1))
+        rc = self.ctx.lib.zkgpu_cloak_prepare_batch(
+            self.bp_gens.gens_capacity, batch, n_in, n_out, b"".join(t.commitments for t in txs),
+            b"".join(t.proof for t in txs), po, r_bytes, self.host_threads, ds, dp, do, dyn_cap, ss, si, so, st_cap, wf)
+        self.ctx._check(rc)
+        nd, ns = do[batch], so[batch]
+        return {"dyn_sc": ds.raw[: 32 * nd], "dyn_pt": dp.raw[: 32 * nd], "dyn_off": list(do),
+                "st_sc": ss.raw[: 32 * ns], "st_idx": list(si[:ns]), "st_off": list(so), "wellformed": wf.raw[:batch]}
+
     def verify_cloak_txs(self, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None) -> List[Optional[VMError]]:
         try:
             bm = self.verify_bitmap(txs, r_bytes)
