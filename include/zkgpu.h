@@ -129,6 +129,23 @@ int zkgpu_cloak_verify_batch(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t ge
                              const uint8_t *proofs, const uint64_t *proof_offsets, const uint8_t *r_bytes,
                              uint8_t *accept_bitmap, int host_threads);
 
+/* The same with the host half moved onto the device.  A plan compiles the constraint system
+ * of one statement shape (n_in, n_out) once; zkgpu_cloak_verify_batch_gpu then replays the
+ * Merlin transcripts (one lane per transaction), rebuilds every scalar of the verification
+ * equation (one workgroup per transaction) and evaluates it, all on the GPU: the only PCIe
+ * traffic is commitments + proof bytes + 64 bytes of verifier randomness per transaction.
+ * Every statement of the batch has the plan's shape and `proof_len` bytes of proof
+ * (fixed stride).  Verdicts are identical to zkgpu_cloak_verify_batch. */
+typedef struct zkgpu_cloak_plan zkgpu_cloak_plan;
+int zkgpu_cloak_plan_create(zkgpu_ctx *ctx, uint32_t n_in, uint32_t n_out, size_t gens_capacity,
+                            zkgpu_cloak_plan **out);
+void zkgpu_cloak_plan_destroy(zkgpu_cloak_plan *plan);
+int zkgpu_cloak_plan_info(const zkgpu_cloak_plan *plan, uint32_t *multipliers, uint32_t *padded_n,
+                          uint32_t *constraints, uint32_t *terms, uint32_t *proof_len);
+int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx *ctx, const zkgpu_pointset *ps, zkgpu_cloak_plan *plan, size_t batch,
+                                 const uint8_t *commitments, const uint8_t *proofs, size_t proof_len,
+                                 const uint8_t *r_bytes, uint8_t *accept_bitmap);
+
 /* The host half of zkgpu_cloak_verify_batch alone: proof bytes -> the CSR of multiscalar
  * multiplication terms that zkgpu_verify_batch_ps* consumes (no device involved).
  * Statement i needs 11 + 2 (n_in+n_out) + 2k dynamic and 2 + 2 * 2^k static terms (k = lg of

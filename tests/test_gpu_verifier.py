@@ -64,3 +64,39 @@ def test_generators_capacity_too_small_rejects(ctx, oracle):
     txs = _txs(oracle, 2, 2, 2, b"\x04" * 32)
     assert Verifier(ctx, gens).verify_bitmap(txs) == b"\x00"   # InvalidGeneratorsLength in the reference
     gens.close()
+
+
+@pytest.mark.parametrize("table_bits", [0, 9])
+def test_device_side_preparation_equals_host_and_oracle(ctx, oracle, table_bits):
+    """zkgpu_cloak_verify_batch_gpu (Merlin replay + scalar preparation on the device)
+    gives the verdicts of the host-prepared path and of the oracle on the same proof bytes."""
+    from zkvm_amd.verifier import BulletproofGens, CloakTx, Verifier
+    gens = BulletproofGens(ctx, 256, table_bits=table_bits)
+    txs = _txs(oracle, 70, 2, 2, b"\x11" * 32) + _txs(oracle, 5, 1, 1, b"\x12" * 32) + _txs(oracle, 5, 3, 3, b"\x13" * 32) \
+        + _txs(oracle, 4, 1, 2, b"\x14" * 32)
+
+    def mut(tx, **kw):
+        return CloakTx(kw.get("n_in", tx.n_in), kw.get("n_out", tx.n_out), kw.get("commitments", tx.commitments),
+                       kw.get("proof", tx.proof))
+    p = bytearray(txs[3].proof); p[1 + 32 * 12 + 3] ^= 0x10; txs[3] = mut(txs[3], proof=bytes(p))          # t_x_blinding bit
+    cm = bytearray(txs[5].commitments); cm[70] ^= 1; txs[5] = mut(txs[5], commitments=bytes(cm))
+    txs[7] = mut(txs[7], proof=txs[7].proof[:-32])                                                          # wrong length
+    p = bytearray(txs[9].proof); p[1 + 32 * 6: 1 + 32 * 7] = bytes(32); txs[9] = mut(txs[9], proof=bytes(p))  # T_1 identity
+    p = bytearray(txs[11].proof); p[1 + 32 * 11: 1 + 32 * 12] = L.to_bytes(32, "little"); txs[11] = mut(txs[11], proof=bytes(p))
+    txs[13] = mut(txs[13], proof=txs[14].proof)
+    p = bytearray(txs[15].proof); p[0] = 0; txs[15] = mut(txs[15], proof=bytes(p))                          # version byte
+    p = bytearray(txs[17].proof); p[1 + 32 * 14 + 32 * 5: 1 + 32 * 14 + 32 * 6] = bytes(32); txs[17] = mut(txs[17], proof=bytes(p))  # an IPA point = identity
+    p = bytearray(txs[19].proof); p[-1] |= 0x80; txs[19] = mut(txs[19], proof=bytes(p))                     # b not canonical
+    p = bytearray(txs[72].proof); p[40] ^= 4; txs[72] = mut(txs[72], proof=bytes(p))                        # in the 1x1 group
+    r = hashlib.shake_256(b"verifier r 2").digest(64 * len(txs))
+    want = [int(oracle.cloak_verify(t.commitments, t.n_in, t.n_out, t.proof, r[64 * i: 64 * i + 64]))
+            for i, t in enumerate(txs)]
+    assert want.count(0) == 10
+    v = Verifier(ctx, gens, host_threads=4)
+    assert bits(v.verify_bitmap(txs, r), len(txs)) == want
+    assert bits(v.verify_bitmap_gpu(txs, r), len(txs)) == want
+    assert bits(v.verify_bitmap_gpu(txs), len(txs)) == want          # OS randomness
+    info = v.plan_info(2, 2)
+    assert info["multipliers"] == 150 and info["padded_n"] == 256 and info["proof_len"] == 1025
+    v.close()
+    gens.close()

@@ -25,6 +25,12 @@ class Strobe128 {
   }
   void meta_ad(const uint8_t* d, size_t n, bool more) { begin_op(kM | kA, more); absorb(d, n); }
   void ad(const uint8_t* d, size_t n, bool more) { begin_op(kA, more); absorb(d, n); }
+  // 50 state words + position + begin marker (seed of the device-side replay, merlin_dev.hpp)
+  void export_state(uint32_t out[52]) const {
+    for (int i = 0; i < 25; ++i) { out[2 * i] = (uint32_t)st_[i]; out[2 * i + 1] = (uint32_t)(st_[i] >> 32); }
+    out[50] = pos_;
+    out[51] = pos_begin_;
+  }
   void prf(uint8_t* out, size_t n) {
     begin_op(kI | kA | kC, false);
     for (size_t i = 0; i < n; ++i) {
@@ -92,6 +98,7 @@ class Transcript {
     s_.meta_ad(len, 4, true);
     s_.prf(out, n);
   }
+  void export_state(uint32_t out[52]) const { s_.export_state(out); }
   Scalar challenge_scalar(const char* label) {
     uint8_t b[64];
     challenge_bytes(label, b, 64);

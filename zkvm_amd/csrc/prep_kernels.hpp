@@ -1,0 +1,341 @@
+// prep_kernels.hpp -- the host half of r1cs::Verifier::verify, on the device
+// (SURVEY.md sec 8 row f-2): proof bytes -> the scalars of the verification
+// multiscalar multiplication, for a batch of cloak statements of ONE shape.
+//
+//   k_proof_unpack   byte-aligned proofs -> word-aligned rows, version check
+//   k_transcript     one lane per transaction: Merlin replay, challenges,
+//                    canonicity / identity checks, the one field inversion
+//   k_prepare        one workgroup per transaction: monomials, z powers,
+//                    constraint flattening (plan replay), s vector, y^-i,
+//                    delta, g_i / h_i and the proof-point scalars
+//
+// Challenge slots of a transaction (scm, Montgomery form):
+//   0 y  1 z  2 u  3 x  4 w  5 1/y  6 prod 1/u_j  7 r  8 t_x  9 t_x_blinding
+//   10 e_blinding  11 a  12 b  | 13.. second-phase challenges | u_j | 1/u_j
+#pragma once
+#include "merlin_dev.hpp"
+#include "sc_dev.hpp"
+
+namespace zk {
+
+constexpr int CH_FIXED = 13;
+
+struct PrepShape {
+  uint32_t m, n1, n, pn, k, n_cons, n_chal2, n_mono, n_targets, n_terms;
+  uint32_t proof_words;     // (16 + 2k) * 8
+  uint32_t n_ch;            // CH_FIXED + n_chal2 + 2k
+  uint32_t n_dyn, n_static; // 11 + m + 2k, 2 + 2 pn
+};
+
+__device__ __forceinline__ void ld_scm(scm& s, const uint32_t* p) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s.v[i] = p[i];
+}
+__device__ __forceinline__ void st_scm(uint32_t* p, const scm& s) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = s.v[i];
+}
+
+__device__ inline scm scm_pow_u32(const scm& base, uint32_t e) {
+  scm acc = scm_one();
+  if (e == 0) return acc;
+  const int top = 31 - __clz(e);
+  for (int i = top; i >= 0; --i) {
+    acc = scm_sq(acc);
+    if ((e >> i) & 1) acc = scm_mul(acc, base);
+  }
+  return acc;
+}
+
+// ---- k_proof_unpack -------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_proof_unpack(const uint8_t* __restrict__ proofs, uint64_t proof_stride, uint32_t* __restrict__ pw,
+               uint32_t proof_words, uint32_t batch, uint32_t* __restrict__ wellformed) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)batch * proof_words) return;
+  const uint32_t tx = (uint32_t)(g / proof_words), j = (uint32_t)(g % proof_words);
+  const uint8_t* p = proofs + (uint64_t)tx * proof_stride;
+  const uint8_t* b = p + 1 + 4 * (uint64_t)j;
+  pw[g] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+  if (j == 0 && p[0] != 1) atomicAnd(&wellformed[tx], 0u);   // wrong wire-format version
+}
+
+// ---- k_transcript -----------------------------------------------------------------------
+__device__ __forceinline__ bool words_are_zero(const uint32_t* w) {
+  uint32_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc |= w[i];
+  return acc == 0;
+}
+
+// init: the STROBE state after Transcript::new("ZkVM.r1cs") + r1cs_domain_sep (same for every tx)
+__global__ void __launch_bounds__(64)
+k_transcript(PrepShape sh, const uint32_t* __restrict__ init_state /*50 words + pos + pos_begin*/,
+             const uint8_t* __restrict__ chal_label, const uint32_t* __restrict__ com /*[B][m][8]*/,
+             const uint32_t* __restrict__ pw /*[B][proof_words]*/, const uint32_t* __restrict__ rbytes /*[B][16]*/,
+             uint32_t batch, uint32_t* __restrict__ ch /*[B][n_ch][8]*/, uint32_t* __restrict__ wellformed) {
+  __shared__ uint32_t lds[52 * 64];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t tx_raw = blockIdx.x * 64 + lane;
+  const bool live = tx_raw < batch;
+  const uint32_t tx = live ? tx_raw : batch - 1;
+  StrobeDev s;
+  s.st = lds + lane;
+  s.stride = 64;
+  for (int i = 0; i < 50; ++i) s.st[i * 64] = init_state[i];
+  s.pos = init_state[50];
+  s.pos_begin = init_state[51];
+  const uint32_t* c = com + (uint64_t)tx * sh.m * 8;
+  const uint32_t* p = pw + (uint64_t)tx * sh.proof_words;
+  uint32_t* out = ch + (uint64_t)tx * sh.n_ch * 8;
+  bool ok = true;
+
+  for (uint32_t i = 0; i < sh.m; ++i) s.append_message_words("V", 1, c + 8 * i, 8);
+  s.append_u64("m", 1, sh.m);
+  ok &= !words_are_zero(p) & !words_are_zero(p + 8) & !words_are_zero(p + 16);
+  s.append_message_words("A_I1", 4, p, 8);
+  s.append_message_words("A_O1", 4, p + 8, 8);
+  s.append_message_words("S1", 2, p + 16, 8);
+  uint32_t wide[16];
+  if (sh.n_chal2 == 0) {
+    s.append_message_const("dom-sep", 7, "r1cs-1phase", 11);
+  } else {
+    s.append_message_const("dom-sep", 7, "r1cs-2phase", 11);
+    for (uint32_t j = 0; j < sh.n_chal2; ++j) {
+      const uint32_t id = chal_label[j];
+      if (id == 0) s.challenge_wide("mix challenge", 13, wide);
+      else if (id == 1) s.challenge_wide("k-value shuffle challenge", 25, wide);
+      else s.challenge_wide("shuffle challenge", 17, wide);
+      st_scm(out + (CH_FIXED + j) * 8, scm_from_wide(wide));
+    }
+  }
+  s.append_message_words("A_I2", 4, p + 24, 8);
+  s.append_message_words("A_O2", 4, p + 32, 8);
+  s.append_message_words("S2", 2, p + 40, 8);
+  s.challenge_wide("y", 1, wide);
+  const scm y = scm_from_wide(wide);
+  s.challenge_wide("z", 1, wide);
+  st_scm(out + 1 * 8, scm_from_wide(wide));
+  for (int i = 6; i < 11; ++i) ok &= !words_are_zero(p + 8 * i);
+  s.append_message_words("T_1", 3, p + 48, 8);
+  s.append_message_words("T_3", 3, p + 56, 8);
+  s.append_message_words("T_4", 3, p + 64, 8);
+  s.append_message_words("T_5", 3, p + 72, 8);
+  s.append_message_words("T_6", 3, p + 80, 8);
+  s.challenge_wide("u", 1, wide);
+  st_scm(out + 2 * 8, scm_from_wide(wide));
+  s.challenge_wide("x", 1, wide);
+  st_scm(out + 3 * 8, scm_from_wide(wide));
+  const uint32_t* sc3 = p + 88;               // t_x, t_x_blinding, e_blinding
+  const uint32_t* lr = p + 112;               // L_0 R_0 L_1 R_1 ...
+  const uint32_t* ab = lr + 16 * sh.k;        // a, b
+  ok &= scm_is_canonical(sc3) & scm_is_canonical(sc3 + 8) & scm_is_canonical(sc3 + 16) & scm_is_canonical(ab) &
+        scm_is_canonical(ab + 8);
+  s.append_message_words("t_x", 3, sc3, 8);
+  s.append_message_words("t_x_blinding", 12, sc3 + 8, 8);
+  s.append_message_words("e_blinding", 10, sc3 + 16, 8);
+  s.challenge_wide("w", 1, wide);
+  st_scm(out + 4 * 8, scm_from_wide(wide));
+  st_scm(out + 8 * 8, scm_from_words(sc3));
+  st_scm(out + 9 * 8, scm_from_words(sc3 + 8));
+  st_scm(out + 10 * 8, scm_from_words(sc3 + 16));
+  st_scm(out + 11 * 8, scm_from_words(ab));
+  st_scm(out + 12 * 8, scm_from_words(ab + 8));
+  st_scm(out + 7 * 8, scm_from_wide(rbytes + (uint64_t)tx * 16));
+  // inner-product argument
+  s.append_message_const("dom-sep", 7, "ipp v1", 6);
+  s.append_u64("n", 1, sh.pn);
+  uint32_t* uj = out + (CH_FIXED + sh.n_chal2) * 8;
+  uint32_t* ujinv = uj + 8 * sh.k;
+  scm prod = y;                               // running product y * u_0 * ... (prefixes parked in the 1/u_j slots)
+  for (uint32_t j = 0; j < sh.k; ++j) {
+    ok &= !words_are_zero(lr + 16 * j) & !words_are_zero(lr + 16 * j + 8);
+    s.append_message_words("L", 1, lr + 16 * j, 8);
+    s.append_message_words("R", 1, lr + 16 * j + 8, 8);
+    s.challenge_wide("u", 1, wide);
+    const scm u = scm_from_wide(wide);
+    st_scm(uj + 8 * j, u);
+    st_scm(ujinv + 8 * j, prod);              // prefix product BEFORE u_j
+    prod = scm_mul(prod, u);
+  }
+  // one inversion for y and every u_j (Montgomery's trick)
+  scm inv = scm_invert(prod);
+  for (uint32_t j = sh.k; j-- > 0;) {
+    scm pre, u;
+    ld_scm(pre, ujinv + 8 * j);
+    ld_scm(u, uj + 8 * j);
+    st_scm(ujinv + 8 * j, scm_mul(inv, pre));  // 1 / u_j
+    inv = scm_mul(inv, u);
+  }
+  // inv = 1 / y now; prod 1/u_j = (1 / (y prod u_j)) * y
+  st_scm(out + 0 * 8, y);
+  st_scm(out + 5 * 8, inv);
+  scm allinv = scm_one();
+  for (uint32_t j = 0; j < sh.k; ++j) { scm t; ld_scm(t, ujinv + 8 * j); allinv = scm_mul(allinv, t); }
+  st_scm(out + 6 * 8, allinv);
+  if (live && !ok) atomicAnd(&wellformed[tx], 0u);
+}
+
+// ---- k_prepare ------------------------------------------------------------------------------
+// LDS (words): chs[n_ch*8] | sym[n_mono*8] | zpow[n_cons*8] | tv[n_terms*8] | wv[n_targets*8] | yip[pn*8] | sv[pn*8] | red[256*8]
+__global__ void __launch_bounds__(256)
+k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* __restrict__ mono_pow,
+          const uint32_t* __restrict__ tgt_off, const uint32_t* __restrict__ term_q,
+          const uint32_t* __restrict__ term_mono, const uint32_t* __restrict__ term_coef,
+          const uint32_t* __restrict__ ch, const uint32_t* __restrict__ com, const uint32_t* __restrict__ pw,
+          uint32_t* __restrict__ dyn_scalars, uint32_t* __restrict__ dyn_points, uint32_t* __restrict__ static_scalars) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint32_t* chs = lds;
+  uint32_t* sym = chs + sh.n_ch * 8;
+  uint32_t* zpow = sym + sh.n_mono * 8;
+  uint32_t* tv = zpow + sh.n_cons * 8;
+  uint32_t* wv = tv + sh.n_terms * 8;
+  uint32_t* yip = wv + sh.n_targets * 8;
+  uint32_t* sv = yip + sh.pn * 8;
+  uint32_t* red = sv + sh.pn * 8;
+  const uint32_t tx = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+
+  for (uint32_t i = t; i < sh.n_ch * 8; i += nt) chs[i] = ch[(uint64_t)tx * sh.n_ch * 8 + i];
+  __syncthreads();
+  scm z, y_inv;
+  ld_scm(z, chs + 1 * 8);
+  ld_scm(y_inv, chs + 5 * 8);
+  // monomials: challenge^power
+  for (uint32_t j = t; j < sh.n_mono; j += nt) {
+    scm v = scm_one();
+    if (mono_chal[j] != 0xffffffffu) {
+      scm c;
+      ld_scm(c, chs + (CH_FIXED + mono_chal[j]) * 8);
+      v = scm_pow_u32(c, mono_pow[j]);
+    }
+    st_scm(sym + 8 * j, v);
+  }
+  // z^(q+1), y^-i, s_i
+  {
+    const scm zt = scm_pow_u32(z, t + 1);
+    if (t < sh.n_cons) st_scm(zpow + 8 * t, zt);
+    if (sh.n_cons > nt) {
+      const scm zstep = scm_pow_u32(z, nt);
+      scm cur = zt;
+      for (uint32_t q = t + nt; q < sh.n_cons; q += nt) { cur = scm_mul(cur, zstep); st_scm(zpow + 8 * q, cur); }
+    }
+  }
+  for (uint32_t i = t; i < sh.pn; i += nt) {
+    st_scm(yip + 8 * i, scm_pow_u32(y_inv, i));
+    // s_i = prod_j (bit (k-1-j) of i ? u_j : 1/u_j): the first challenge pairs with the top bit
+    scm s = scm_one();
+    for (uint32_t j = 0; j < sh.k; ++j) {
+      scm f;
+      const bool bit = (i >> (sh.k - 1 - j)) & 1;
+      ld_scm(f, chs + (CH_FIXED + sh.n_chal2 + (bit ? j : sh.k + j)) * 8);
+      s = scm_mul(s, f);
+    }
+    st_scm(sv + 8 * i, s);
+  }
+  __syncthreads();
+  // plan replay: one product per term, then one sum per target
+  for (uint32_t e = t; e < sh.n_terms; e += nt) {
+    scm c, m, zq;
+    ld_scm(c, term_coef + 8 * (uint64_t)e);
+    ld_scm(m, sym + 8 * term_mono[e]);
+    ld_scm(zq, zpow + 8 * term_q[e]);
+    st_scm(tv + 8 * e, scm_mul(scm_mul(c, m), zq));
+  }
+  __syncthreads();
+  for (uint32_t g = t; g < sh.n_targets; g += nt) {
+    scm acc = scm_zero();
+    for (uint32_t e = tgt_off[g]; e < tgt_off[g + 1]; ++e) { scm v; ld_scm(v, tv + 8 * e); acc = scm_add(acc, v); }
+    st_scm(wv + 8 * g, acc);
+  }
+  __syncthreads();
+  const uint32_t* wL = wv;
+  const uint32_t* wR = wv + sh.n * 8;
+  const uint32_t* wO = wv + 2 * sh.n * 8;
+  const uint32_t* wV = wv + 3 * sh.n * 8;
+  const uint32_t* wc = wV + sh.m * 8;
+  // delta = sum_{i<n} y^-i wR_i wL_i  (block reduction in LDS)
+  {
+    scm part = scm_zero();
+    for (uint32_t i = t; i < sh.n; i += nt) {
+      scm a, b, c;
+      ld_scm(a, yip + 8 * i); ld_scm(b, wR + 8 * i); ld_scm(c, wL + 8 * i);
+      part = scm_add(part, scm_mul(scm_mul(a, b), c));
+    }
+    st_scm(red + 8 * t, part);
+    __syncthreads();
+    for (uint32_t s2 = nt >> 1; s2 > 0; s2 >>= 1) {
+      if (t < s2) { scm a, b; ld_scm(a, red + 8 * t); ld_scm(b, red + 8 * (t + s2)); st_scm(red + 8 * t, scm_add(a, b)); }
+      __syncthreads();
+    }
+  }
+  scm delta, x, u, r, a_, b_, w_, t_x, t_x_bl, e_bl;
+  ld_scm(delta, red);
+  ld_scm(u, chs + 2 * 8); ld_scm(x, chs + 3 * 8); ld_scm(w_, chs + 4 * 8); ld_scm(r, chs + 7 * 8);
+  ld_scm(t_x, chs + 8 * 8); ld_scm(t_x_bl, chs + 9 * 8); ld_scm(e_bl, chs + 10 * 8);
+  ld_scm(a_, chs + 11 * 8); ld_scm(b_, chs + 12 * 8);
+  const scm xx = scm_sq(x), xxx = scm_mul(xx, x), rxx = scm_mul(r, xx);
+  uint32_t* ds = dyn_scalars + (uint64_t)tx * sh.n_dyn * 8;
+  uint32_t* dp = dyn_points + (uint64_t)tx * sh.n_dyn * 8;
+  uint32_t* ss = static_scalars + (uint64_t)tx * sh.n_static * 8;
+  const uint32_t* p = pw + (uint64_t)tx * sh.proof_words;
+  const uint32_t* c = com + (uint64_t)tx * sh.m * 8;
+  const uint32_t* lr = p + 112;
+  // generator scalars
+  for (uint32_t i = t; i < sh.pn; i += nt) {
+    scm yi, si, sr, g, h, wl = scm_zero(), wr = scm_zero(), wo = scm_zero();
+    ld_scm(yi, yip + 8 * i); ld_scm(si, sv + 8 * i); ld_scm(sr, sv + 8 * (sh.pn - 1 - i));
+    if (i < sh.n) { ld_scm(wl, wL + 8 * i); ld_scm(wr, wR + 8 * i); ld_scm(wo, wO + 8 * i); }
+    g = scm_sub(scm_mul(x, scm_mul(wr, yi)), scm_mul(a_, si));
+    h = scm_sub(scm_mul(yi, scm_sub(scm_add(scm_mul(x, wl), wo), scm_mul(b_, sr))), scm_one());
+    if (i >= sh.n1) { g = scm_mul(g, u); h = scm_mul(h, u); }
+    uint32_t o[8];
+    scm_to_words(o, g);
+    for (int q = 0; q < 8; ++q) ss[(2 + i) * 8 + q] = o[q];
+    scm_to_words(o, h);
+    for (int q = 0; q < 8; ++q) ss[(2 + sh.pn + i) * 8 + q] = o[q];
+  }
+  // proof-point scalars (and B, B_blinding), one lane each
+  if (t < sh.n_dyn + 2) {
+    scm v;
+    const uint32_t* pt = nullptr;
+    const uint32_t j = t;
+    if (j < 6) {
+      const scm base = (j % 3 == 0) ? x : (j % 3 == 1 ? xx : xxx);
+      v = j < 3 ? base : scm_mul(u, base);
+      pt = p + 8 * j;
+    } else if (j < 6 + sh.m) {
+      scm wvj; ld_scm(wvj, wV + 8 * (j - 6));
+      v = scm_mul(wvj, rxx);
+      pt = c + 8 * (j - 6);
+    } else if (j < 6 + sh.m + 5) {
+      const uint32_t q = j - 6 - sh.m;      // T_1 T_3 T_4 T_5 T_6 -> r x, r x^3, r x^4, r x^5, r x^6
+      const scm rx = scm_mul(r, x);
+      v = rx;
+      const uint32_t reps = q == 0 ? 0 : q + 1;
+      for (uint32_t e = 0; e < reps; ++e) v = scm_mul(v, x);
+      pt = p + 8 * (6 + q);
+    } else if (j < sh.n_dyn) {
+      const uint32_t q = j - 6 - sh.m - 5;  // u_j^2 for L_j, then u_j^-2 for R_j
+      scm f;
+      if (q < sh.k) { ld_scm(f, chs + (CH_FIXED + sh.n_chal2 + q) * 8); pt = lr + 16 * q; }
+      else { ld_scm(f, chs + (CH_FIXED + sh.n_chal2 + sh.k + (q - sh.k)) * 8); pt = lr + 16 * (q - sh.k) + 8; }
+      v = scm_sq(f);
+    } else if (j == sh.n_dyn) {             // B: w (t_x - a b) + r (xx (wc + delta) - t_x)
+      scm wcv; ld_scm(wcv, wc);
+      const scm t1 = scm_mul(w_, scm_sub(t_x, scm_mul(a_, b_)));
+      const scm t2 = scm_mul(r, scm_sub(scm_mul(xx, scm_add(wcv, delta)), t_x));
+      v = scm_add(t1, t2);
+    } else {                                // B_blinding: -(e_blinding + r t_x_blinding)
+      v = scm_neg(scm_add(e_bl, scm_mul(r, t_x_bl)));
+    }
+    uint32_t o[8];
+    scm_to_words(o, v);
+    if (j < sh.n_dyn) {
+      for (int q = 0; q < 8; ++q) { ds[j * 8 + q] = o[q]; dp[j * 8 + q] = pt[q]; }
+    } else {
+      for (int q = 0; q < 8; ++q) ss[(j - sh.n_dyn) * 8 + q] = o[q];
+    }
+  }
+}
+
+}  // namespace zk

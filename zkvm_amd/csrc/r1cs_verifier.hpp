@@ -7,6 +7,11 @@
 // instruction -- none of whose Rust sources are mounted; written from Bunz et
 // al. 2018 sec 3/5 and the crates' published protocol notes).
 //
+// The constraint system is generic in its scalar type S: with S = Scalar it is
+// the numeric verifier (R1csVerifier); with S = SymScalar (cloak_plan.hpp) the
+// same gadget code records a symbolic "tape" that the device-side preparation
+// kernels replay per transaction.
+//
 // The output layout is the argument list of dalek's `mega_check`:
 //   dynamic terms  [A_I1 A_O1 S1 A_I2 A_O2 S2 | V_0..V_{m-1} | T_1 T_3 T_4 T_5 T_6 | L_0.. | R_0..]
 //   static terms   [B, B_blinding, G_0..G_{n-1}, H_0..H_{n-1}]   (indices into the generator set)
@@ -27,16 +32,62 @@ struct Var {
 };
 inline Var var_one() { return Var{VarKind::One, 0}; }
 
-struct LC {
-  std::vector<std::pair<Var, Scalar>> terms;
-  LC() = default;
-  LC(Var v) { terms.emplace_back(v, Scalar::one()); }   // NOLINT: implicit on purpose
-  LC& add(Var v, const Scalar& c) { terms.emplace_back(v, c); return *this; }
-  LC& sub(Var v, const Scalar& c) { terms.emplace_back(v, -c); return *this; }
+template <class S>
+struct LCt {
+  std::vector<std::pair<Var, S>> terms;
+  LCt() = default;
+  LCt(Var v) { terms.emplace_back(v, S::one()); }   // NOLINT: implicit on purpose
+  LCt& add(Var v, const S& c) { terms.emplace_back(v, c); return *this; }
+  LCt& sub(Var v, const S& c) { terms.emplace_back(v, -c); return *this; }
 };
 
 struct Value {   // spacesuit AllocatedValue: quantity and flavor variables
   Var q, f;
+};
+
+// Constraint collection shared by the numeric verifier and the plan builder.
+template <class S>
+class ConstraintSystemT {
+ public:
+  using Scalar_t = S;
+  using LC = LCt<S>;
+  using Deferred = std::function<void(ConstraintSystemT&)>;
+  virtual ~ConstraintSystemT() = default;
+
+  void constrain(LC lc) { cons_.push_back(std::move(lc)); }
+  // (left, right, out) of a fresh multiplier constrained to the two combinations
+  void multiply(LC left, LC right, Var out[3]) {
+    allocate_multiplier(out);
+    left.sub(out[0], S::one());
+    right.sub(out[1], S::one());
+    constrain(std::move(left));
+    constrain(std::move(right));
+  }
+  void allocate_multiplier(Var out[3]) {
+    const uint32_t i = num_vars_++;
+    out[0] = Var{VarKind::MulLeft, i}; out[1] = Var{VarKind::MulRight, i}; out[2] = Var{VarKind::MulOut, i};
+  }
+  void specify_randomized_constraints(Deferred f) {
+    if (phase2_) f(*this); else deferred_.push_back(std::move(f));
+  }
+  virtual S challenge_scalar(const char* label) = 0;   // second phase only
+  size_t num_multipliers() const { return num_vars_; }
+  size_t num_constraints() const { return cons_.size(); }
+
+ protected:
+  std::vector<LC> cons_;
+  std::vector<Deferred> deferred_;
+  uint32_t num_vars_ = 0;
+  bool phase2_ = false;
+  // returns the number of first-phase multipliers; leaves the system in phase 2
+  size_t run_second_phase() {
+    const size_t n1 = num_vars_;
+    phase2_ = true;
+    for (size_t i = 0; i < deferred_.size(); ++i) deferred_[i](*this);
+    deferred_.clear();
+    return n1;
+  }
+  bool has_deferred() const { return !deferred_.empty(); }
 };
 
 struct VerifierMsm {
@@ -45,7 +96,7 @@ struct VerifierMsm {
   size_t padded_n = 0;
 };
 
-class R1csVerifier {
+class R1csVerifier : public ConstraintSystemT<Scalar> {
  public:
   explicit R1csVerifier(const char* label) : tr_(label) { tr_.append_message("dom-sep", (const uint8_t*)"r1cs v1", 7); }
 
@@ -54,26 +105,7 @@ class R1csVerifier {
     tr_.append_point("V", commitment);
     return Var{VarKind::Committed, (uint32_t)(V_.size() / 32 - 1)};
   }
-  void constrain(LC lc) { cons_.push_back(std::move(lc)); }
-  // (left, right, out) of a fresh multiplier constrained to the two combinations
-  void multiply(LC left, LC right, Var out[3]) {
-    const uint32_t i = num_vars_++;
-    out[0] = Var{VarKind::MulLeft, i}; out[1] = Var{VarKind::MulRight, i}; out[2] = Var{VarKind::MulOut, i};
-    left.sub(out[0], Scalar::one());
-    right.sub(out[1], Scalar::one());
-    constrain(std::move(left));
-    constrain(std::move(right));
-  }
-  void allocate_multiplier(Var out[3]) {
-    const uint32_t i = num_vars_++;
-    out[0] = Var{VarKind::MulLeft, i}; out[1] = Var{VarKind::MulRight, i}; out[2] = Var{VarKind::MulOut, i};
-  }
-  using Deferred = std::function<void(R1csVerifier&)>;
-  void specify_randomized_constraints(Deferred f) {
-    if (phase2_) f(*this); else deferred_.push_back(std::move(f));
-  }
-  Scalar challenge_scalar(const char* label) { return tr_.challenge_scalar(label); }
-  size_t num_multipliers() const { return num_vars_; }
+  Scalar challenge_scalar(const char* label) override { return tr_.challenge_scalar(label); }
 
   // Replays the transcript over `proof` and fills `out`.  gens_capacity = number of (G, H)
   // pairs in the generator set (static index of H_i is 2 + gens_capacity + i).
@@ -95,19 +127,17 @@ class R1csVerifier {
       return false;
     const size_t m = V_.size() / 32;
     tr_.append_u64("m", m);
-    const size_t n1 = num_vars_;
     // validate_and_append_point: the identity is rejected
     if (is_identity(pt) || is_identity(pt + 32) || is_identity(pt + 64)) return false;
     tr_.append_point("A_I1", pt);
     tr_.append_point("A_O1", pt + 32);
     tr_.append_point("S1", pt + 64);
-    if (deferred_.empty()) {
+    size_t n1 = num_vars_;
+    if (!has_deferred()) {
       tr_.append_message("dom-sep", (const uint8_t*)"r1cs-1phase", 11);
     } else {
       tr_.append_message("dom-sep", (const uint8_t*)"r1cs-2phase", 11);
-      phase2_ = true;
-      for (size_t i = 0; i < deferred_.size(); ++i) deferred_[i](*this);
-      deferred_.clear();
+      n1 = run_second_phase();
     }
     const size_t n = num_vars_;
     size_t pn = 1;
@@ -224,10 +254,6 @@ class R1csVerifier {
  private:
   Transcript tr_;
   std::vector<uint8_t> V_;
-  std::vector<LC> cons_;
-  std::vector<Deferred> deferred_;
-  uint32_t num_vars_ = 0;
-  bool phase2_ = false;
 
   static bool is_identity(const uint8_t p[32]) {
     uint8_t acc = 0;
@@ -236,16 +262,19 @@ class R1csVerifier {
   }
 };
 
-// ---- spacesuit::cloak, verifier side ---------------------------------------------------
+// ---- spacesuit::cloak, verifier side (generic in the constraint system) ------------------
 namespace cloak {
 
-inline Value allocate_value(R1csVerifier& cs) {
+template <class CS>
+Value allocate_value(CS& cs) {
   Var o[3];
   cs.allocate_multiplier(o);
   return Value{o[0], o[1]};
 }
 
-inline Var product_minus_z(R1csVerifier& cs, const std::vector<Var>& x, const Scalar& z) {
+template <class CS>
+Var product_minus_z(CS& cs, const std::vector<Var>& x, const typename CS::Scalar_t& z) {
+  using LC = typename CS::LC;
   const size_t k = x.size();
   Var o[3];
   cs.multiply(LC(x[k - 1]).sub(var_one(), z), LC(x[k - 2]).sub(var_one(), z), o);
@@ -253,28 +282,34 @@ inline Var product_minus_z(R1csVerifier& cs, const std::vector<Var>& x, const Sc
   return o[2];
 }
 
-inline void scalar_shuffle(R1csVerifier& cs, std::vector<Var> x, std::vector<Var> y) {
+template <class CS>
+void scalar_shuffle(CS& cs, std::vector<Var> x, std::vector<Var> y) {
+  using S = typename CS::Scalar_t;
+  using LC = typename CS::LC;
   const size_t k = x.size();
   if (k == 0) return;
-  if (k == 1) { cs.constrain(LC(y[0]).sub(x[0], Scalar::one())); return; }
-  cs.specify_randomized_constraints([x, y](R1csVerifier& c) {
-    const Scalar z = c.challenge_scalar("shuffle challenge");
+  if (k == 1) { cs.constrain(LC(y[0]).sub(x[0], S::one())); return; }
+  cs.specify_randomized_constraints([x, y](ConstraintSystemT<S>& c) {
+    const S z = c.challenge_scalar("shuffle challenge");
     const Var px = product_minus_z(c, x, z);
     const Var py = product_minus_z(c, y, z);
-    c.constrain(LC(px).sub(py, Scalar::one()));
+    c.constrain(LC(px).sub(py, S::one()));
   });
 }
 
-inline void value_shuffle(R1csVerifier& cs, std::vector<Value> x, std::vector<Value> y) {
+template <class CS>
+void value_shuffle(CS& cs, std::vector<Value> x, std::vector<Value> y) {
+  using S = typename CS::Scalar_t;
+  using LC = typename CS::LC;
   const size_t k = x.size();
   if (k == 0) return;
   if (k == 1) {
-    cs.constrain(LC(x[0].q).sub(y[0].q, Scalar::one()));
-    cs.constrain(LC(x[0].f).sub(y[0].f, Scalar::one()));
+    cs.constrain(LC(x[0].q).sub(y[0].q, S::one()));
+    cs.constrain(LC(x[0].f).sub(y[0].f, S::one()));
     return;
   }
-  cs.specify_randomized_constraints([x, y](R1csVerifier& c) {
-    const Scalar w = c.challenge_scalar("k-value shuffle challenge");
+  cs.specify_randomized_constraints([x, y](ConstraintSystemT<S>& c) {
+    const S w = c.challenge_scalar("k-value shuffle challenge");
     std::vector<Var> xs, ys;
     for (size_t i = 0; i < x.size(); ++i) {
       Var o[3];
@@ -286,17 +321,21 @@ inline void value_shuffle(R1csVerifier& cs, std::vector<Value> x, std::vector<Va
   });
 }
 
-inline void padded_shuffle(R1csVerifier& cs, std::vector<Value> x, std::vector<Value> y) {
+template <class CS>
+void padded_shuffle(CS& cs, std::vector<Value> x, std::vector<Value> y) {
   const size_t k = x.size() > y.size() ? x.size() : y.size();
   while (x.size() < k) x.push_back(allocate_value(cs));
   while (y.size() < k) y.push_back(allocate_value(cs));
   value_shuffle(cs, x, y);
 }
 
-inline void mix(R1csVerifier& cs, Value A, Value B, Value C, Value D) {
-  cs.specify_randomized_constraints([A, B, C, D](R1csVerifier& c) {
-    const Scalar w = c.challenge_scalar("mix challenge");
-    const Scalar w2 = w * w, w3 = w2 * w, w4 = w3 * w, one = Scalar::one();
+template <class CS>
+void mix(CS& cs, Value A, Value B, Value C, Value D) {
+  using S = typename CS::Scalar_t;
+  using LC = typename CS::LC;
+  cs.specify_randomized_constraints([A, B, C, D](ConstraintSystemT<S>& c) {
+    const S w = c.challenge_scalar("mix challenge");
+    const S w2 = w * w, w3 = w2 * w, w4 = w3 * w, one = S::one();
     LC l, r;
     l.add(A.q, one).sub(C.q, one).add(A.f, w).sub(C.f, w).add(B.q, w2).sub(D.q, w2).add(B.f, w3).sub(D.f, w3);
     r.add(C.q, one).add(A.f, w4).sub(B.f, w4).add(D.q, w2).sub(A.q, w2).sub(B.q, w2).add(D.f, w3).sub(A.f, w3);
@@ -307,8 +346,8 @@ inline void mix(R1csVerifier& cs, Value A, Value B, Value C, Value D) {
 }
 
 // (grouped, merged) of a k-mix over `vals`
-inline void k_mix(R1csVerifier& cs, const std::vector<Value>& vals, std::vector<Value>& grouped,
-                  std::vector<Value>& merged) {
+template <class CS>
+void k_mix(CS& cs, const std::vector<Value>& vals, std::vector<Value>& grouped, std::vector<Value>& merged) {
   const size_t k = vals.size();
   grouped.clear();
   merged.clear();
@@ -321,21 +360,25 @@ inline void k_mix(R1csVerifier& cs, const std::vector<Value>& vals, std::vector<
     mix(cs, i == 0 ? grouped[0] : mid[i - 1], grouped[i + 1], merged[i], (i + 2 == k) ? merged[k - 1] : mid[i]);
 }
 
-inline void range_proof(R1csVerifier& cs, Var v, int nbits) {
+template <class CS>
+void range_proof(CS& cs, Var v, int nbits) {
+  using S = typename CS::Scalar_t;
+  using LC = typename CS::LC;
   LC acc(v);
-  Scalar exp2 = Scalar::one();
+  S exp2 = S::one();
   for (int i = 0; i < nbits; ++i) {
     Var o[3];
     cs.allocate_multiplier(o);
     cs.constrain(LC(o[2]));
-    cs.constrain(LC(o[0]).add(o[1], Scalar::one()).sub(var_one(), Scalar::one()));
+    cs.constrain(LC(o[0]).add(o[1], S::one()).sub(var_one(), S::one()));
     acc.sub(o[1], exp2);
     exp2 = exp2 + exp2;
   }
   cs.constrain(std::move(acc));
 }
 
-inline void gadget(R1csVerifier& cs, const std::vector<Value>& in, const std::vector<Value>& out) {
+template <class CS>
+void gadget(CS& cs, const std::vector<Value>& in, const std::vector<Value>& out) {
   std::vector<Value> merge_in, merge_out, split_out, split_in;
   k_mix(cs, in, merge_in, merge_out);
   k_mix(cs, out, split_out, split_in);
@@ -343,6 +386,14 @@ inline void gadget(R1csVerifier& cs, const std::vector<Value>& in, const std::ve
   padded_shuffle(cs, merge_out, split_in);
   value_shuffle(cs, split_out, out);
   for (const Value& o : out) range_proof(cs, o.q, 64);
+}
+
+// committed values of a ZkVM `cloak`: variable 2i = quantity, 2i + 1 = flavor of value i
+inline std::vector<Value> committed_values(size_t n) {
+  std::vector<Value> v;
+  for (size_t i = 0; i < n; ++i)
+    v.push_back(Value{Var{VarKind::Committed, (uint32_t)(2 * i)}, Var{VarKind::Committed, (uint32_t)(2 * i + 1)}});
+  return v;
 }
 
 // The statement of a ZkVM `cloak` over committed values: commitments = (q, f) per value, inputs first.

@@ -21,6 +21,8 @@
 #include <vector>
 
 #include "r1cs_verifier.hpp"
+#include "cloak_plan.hpp"
+#include "prep_kernels.hpp"
 
 using namespace zk;
 
@@ -61,6 +63,7 @@ struct zkgpu_ctx {
   Buffer dyn_rows, bins, block_sums, entries, buckets, partials, partial_flags, window_sums, window_flags;
   Buffer msm_fail, status, accept, bitmap, ok_bytes, values, uniform;
   Buffer digits, st_partials, dynsum, accept2;
+  Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
   int forced_parts = 0;
   void* pinned = nullptr;   // host staging for results
   size_t pinned_cap = 0;
@@ -527,7 +530,8 @@ void zkgpu_destroy(zkgpu_ctx* c) {
                     &c->in_st_offsets, &c->dyn_rows, &c->bins, &c->block_sums, &c->entries, &c->buckets,
                     &c->partials, &c->partial_flags, &c->window_sums, &c->window_flags, &c->msm_fail,
                     &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform,
-                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2};
+                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->prep_com, &c->prep_proofs, &c->prep_r,
+                    &c->prep_pw, &c->prep_ch, &c->prep_wf, &c->prep_dyn_sc, &c->prep_dyn_pt, &c->prep_st_sc};
   for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -844,6 +848,190 @@ int zkgpu_cloak_prepare_batch(size_t gens_capacity, size_t batch, const uint32_t
   memcpy(wellformed, cb.wellformed.data(), batch);
   if (!cb.dyn_sc.empty()) { memcpy(dyn_scalars, cb.dyn_sc.data(), cb.dyn_sc.size()); memcpy(dyn_points, cb.dyn_pt.data(), cb.dyn_pt.size()); }
   if (!cb.st_sc.empty()) { memcpy(static_scalars, cb.st_sc.data(), cb.st_sc.size()); memcpy(static_index, cb.st_idx.data(), cb.st_idx.size() * 4); }
+  return ZKGPU_OK;
+}
+
+// ---- the same, with the host half moved onto the device (plan replay) -------------------
+struct zkgpu_cloak_plan {
+  zkgpu_ctx* ctx;
+  CloakPlan host;
+  PrepShape shape;
+  size_t gens_capacity;
+  uint32_t *d_init = nullptr, *d_mono_chal = nullptr, *d_mono_pow = nullptr, *d_tgt_off = nullptr, *d_term_q = nullptr,
+           *d_term_mono = nullptr, *d_term_coef = nullptr;
+  uint8_t* d_chal_label = nullptr;
+  // per-batch-size cached CSR scaffolding
+  size_t cached_batch = 0;
+  uint64_t *d_dyn_off = nullptr, *d_st_off = nullptr;
+  uint32_t* d_st_index = nullptr;
+  size_t lds_bytes = 0;
+};
+
+namespace {
+int plan_upload_bytes(zkgpu_ctx* c, void** dst, const void* src, size_t bytes) {
+  HIP_TRY(c, hipMalloc(dst, std::max<size_t>(bytes, 16)));
+  if (bytes) HIP_TRY(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return ZKGPU_OK;
+}
+#define plan_upload(c, dst, vec) plan_upload_bytes((c), (void**)(dst), (vec).data(), (vec).size() * sizeof((vec)[0]))
+}  // namespace
+
+int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t gens_capacity, zkgpu_cloak_plan** out) {
+  if (!c || !out || n_in + n_out == 0 || n_in > 64 || n_out > 64) return ZKGPU_EINVAL;
+  *out = nullptr;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  zkgpu_cloak_plan* p = new zkgpu_cloak_plan();
+  p->ctx = c;
+  p->gens_capacity = gens_capacity;
+  try {
+    p->host = PlanBuilder::build(n_in, n_out);
+  } catch (const std::exception& e) {
+    c->last_error = e.what();
+    delete p;
+    return ZKGPU_EINVAL;
+  }
+  const CloakPlan& h = p->host;
+  if (h.pn > gens_capacity || h.k > 16) { delete p; c->last_error = "statement needs more generators than the set holds"; return ZKGPU_EINVAL; }
+  PrepShape& s = p->shape;
+  s.m = h.m; s.n1 = h.n1; s.n = h.n; s.pn = h.pn; s.k = h.k; s.n_cons = h.n_cons;
+  s.n_chal2 = (uint32_t)h.chal_label.size();
+  s.n_mono = (uint32_t)h.mono_chal.size();
+  s.n_targets = h.n_targets();
+  s.n_terms = (uint32_t)h.term_q.size();
+  s.proof_words = (16 + 2 * h.k) * 8;
+  s.n_ch = CH_FIXED + s.n_chal2 + 2 * h.k;
+  s.n_dyn = 11 + h.m + 2 * h.k;
+  s.n_static = 2 + 2 * h.pn;
+  p->lds_bytes = (size_t)(s.n_ch + s.n_mono + s.n_cons + s.n_terms + s.n_targets + 2 * s.pn + 256) * 32;
+  if (p->lds_bytes > 160 * 1024) { delete p; c->last_error = "plan does not fit the 160 KiB LDS of a CU"; return ZKGPU_EINVAL; }
+  // STROBE state after Transcript::new("ZkVM.r1cs") + r1cs_domain_sep()
+  Transcript tr("ZkVM.r1cs");
+  tr.append_message("dom-sep", (const uint8_t*)"r1cs v1", 7);
+  std::vector<uint32_t> init(52);
+  tr.export_state(init.data());
+  TRY(plan_upload(c, &p->d_init, init));
+  TRY(plan_upload(c, &p->d_chal_label, h.chal_label));
+  TRY(plan_upload(c, &p->d_mono_chal, h.mono_chal));
+  TRY(plan_upload(c, &p->d_mono_pow, h.mono_pow));
+  TRY(plan_upload(c, &p->d_tgt_off, h.tgt_off));
+  TRY(plan_upload(c, &p->d_term_q, h.term_q));
+  TRY(plan_upload(c, &p->d_term_mono, h.term_mono));
+  TRY(plan_upload(c, &p->d_term_coef, h.term_coef));
+  HIP_TRY(c, hipFuncSetAttribute((const void*)k_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+  *out = p;
+  return ZKGPU_OK;
+}
+
+void zkgpu_cloak_plan_destroy(zkgpu_cloak_plan* p) {
+  if (!p) return;
+  DeviceGuard g(p->ctx->device);
+  void* ptrs[] = {p->d_init, p->d_chal_label, p->d_mono_chal, p->d_mono_pow, p->d_tgt_off, p->d_term_q, p->d_term_mono,
+                  p->d_term_coef, p->d_dyn_off, p->d_st_off, p->d_st_index};
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  delete p;
+}
+
+int zkgpu_cloak_plan_info(const zkgpu_cloak_plan* p, uint32_t* multipliers, uint32_t* padded_n, uint32_t* constraints,
+                          uint32_t* terms, uint32_t* proof_len) {
+  if (!p) return ZKGPU_EINVAL;
+  if (multipliers) *multipliers = p->host.n;
+  if (padded_n) *padded_n = p->host.pn;
+  if (constraints) *constraints = p->host.n_cons;
+  if (terms) *terms = (uint32_t)p->host.term_q.size();
+  if (proof_len) *proof_len = 1 + 32 * (16 + 2 * p->host.k);
+  return ZKGPU_OK;
+}
+
+// Proof bytes in, accept bits out, everything after the PCIe copy on the device: transcript
+// replay (one lane per transaction), scalar preparation (one workgroup per transaction),
+// then the multiscalar multiplications.  All `batch` statements have the plan's shape.
+int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
+                                 const uint8_t* commitments, const uint8_t* proofs, size_t proof_len,
+                                 const uint8_t* r_bytes, uint8_t* accept_bitmap) {
+  if (!c || !ps || !plan || plan->ctx != c || ps->ctx->device != c->device || !accept_bitmap) return ZKGPU_EINVAL;
+  memset(accept_bitmap, 0, (batch + 7) / 8);
+  if (batch == 0) return ZKGPU_OK;
+  if (!commitments || !proofs || batch >= (1ull << 24)) return ZKGPU_EINVAL;
+  if (ps->n < 2 + 2 * plan->gens_capacity) return ZKGPU_EINVAL;
+  const PrepShape& sh = plan->shape;
+  if (proof_len != 1 + 4ull * sh.proof_words) return ZKGPU_OK;   // wrong length for this statement: every proof is Err
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  hipStream_t s = c->stream;
+  std::vector<uint8_t> rnd;
+  if (!r_bytes) {
+    rnd.resize(64 * batch);
+    std::random_device rd;
+    for (size_t i = 0; i < rnd.size(); i += 4) { uint32_t v = rd(); memcpy(&rnd[i], &v, 4); }
+    r_bytes = rnd.data();
+  }
+  const uint32_t B = (uint32_t)batch;
+  TRY(upload(c, c->prep_com, commitments, (size_t)B * sh.m * 32));
+  TRY(upload(c, c->prep_proofs, proofs, (size_t)B * proof_len));
+  TRY(upload(c, c->prep_r, r_bytes, (size_t)B * 64));
+  TRY(ensure(c, c->prep_pw, (size_t)B * sh.proof_words * 4));
+  TRY(ensure(c, c->prep_ch, (size_t)B * sh.n_ch * 32));
+  TRY(ensure(c, c->prep_wf, (size_t)B * 4));
+  TRY(ensure(c, c->prep_dyn_sc, (size_t)B * sh.n_dyn * 32));
+  TRY(ensure(c, c->prep_dyn_pt, (size_t)B * sh.n_dyn * 32));
+  TRY(ensure(c, c->prep_st_sc, (size_t)B * sh.n_static * 32));
+  if (plan->cached_batch != batch) {   // CSR scaffolding of a uniform batch: offsets and the generator index template
+    if (plan->d_dyn_off) { (void)hipFree(plan->d_dyn_off); (void)hipFree(plan->d_st_off); (void)hipFree(plan->d_st_index); }
+    plan->d_dyn_off = nullptr; plan->d_st_off = nullptr; plan->d_st_index = nullptr;
+    std::vector<uint64_t> doff(batch + 1), soff(batch + 1);
+    for (size_t i = 0; i <= batch; ++i) { doff[i] = i * sh.n_dyn; soff[i] = i * sh.n_static; }
+    std::vector<uint32_t> idx((size_t)batch * sh.n_static);
+    for (size_t i = 0; i < batch; ++i) {
+      uint32_t* row = &idx[i * sh.n_static];
+      row[0] = 0; row[1] = 1;
+      for (uint32_t j = 0; j < sh.pn; ++j) { row[2 + j] = 2 + j; row[2 + sh.pn + j] = (uint32_t)(2 + plan->gens_capacity + j); }
+    }
+    TRY(plan_upload(c, &plan->d_dyn_off, doff));
+    TRY(plan_upload(c, &plan->d_st_off, soff));
+    TRY(plan_upload(c, &plan->d_st_index, idx));
+    plan->cached_batch = batch;
+  }
+  HIP_TRY(c, hipMemsetAsync(c->prep_wf.p, 0xff, (size_t)B * 4, s));
+  {
+    Launch l(c, "k_proof_unpack");
+    hipLaunchKernelGGL(k_proof_unpack, dim3(blocks_for((uint64_t)B * sh.proof_words, 256)), dim3(256), 0, s,
+                       (const uint8_t*)c->prep_proofs.p, (uint64_t)proof_len, (uint32_t*)c->prep_pw.p, sh.proof_words, B,
+                       (uint32_t*)c->prep_wf.p);
+  }
+  {
+    Launch l(c, "k_transcript");
+    hipLaunchKernelGGL(k_transcript, dim3(blocks_for(B, 64)), dim3(64), 0, s, sh, (const uint32_t*)plan->d_init,
+                       (const uint8_t*)plan->d_chal_label, (const uint32_t*)c->prep_com.p, (const uint32_t*)c->prep_pw.p,
+                       (const uint32_t*)c->prep_r.p, B, (uint32_t*)c->prep_ch.p, (uint32_t*)c->prep_wf.p);
+  }
+  {
+    Launch l(c, "k_prepare");
+    hipLaunchKernelGGL(k_prepare, dim3(B), dim3(256), plan->lds_bytes, s, sh, (const uint32_t*)plan->d_mono_chal,
+                       (const uint32_t*)plan->d_mono_pow, (const uint32_t*)plan->d_tgt_off, (const uint32_t*)plan->d_term_q,
+                       (const uint32_t*)plan->d_term_mono, (const uint32_t*)plan->d_term_coef, (const uint32_t*)c->prep_ch.p,
+                       (const uint32_t*)c->prep_com.p, (const uint32_t*)c->prep_pw.p, (uint32_t*)c->prep_dyn_sc.p,
+                       (uint32_t*)c->prep_dyn_pt.p, (uint32_t*)c->prep_st_sc.p);
+  }
+  HIP_TRY(c, hipGetLastError());
+  Job job;
+  job.d_dyn_scalars = (const uint32_t*)c->prep_dyn_sc.p;
+  job.d_dyn_points = (const uint32_t*)c->prep_dyn_pt.p;
+  job.d_dyn_offsets = plan->d_dyn_off;
+  job.n_dyn = (uint64_t)B * sh.n_dyn;
+  job.d_st_scalars = (const uint32_t*)c->prep_st_sc.p;
+  job.d_st_index = plan->d_st_index;
+  job.d_st_offsets = plan->d_st_off;
+  job.n_static = (uint64_t)B * sh.n_static;
+  job.d_static_rows = ps->rows;
+  job.n_msm = B;
+  int rc = ps->table ? batch_device_tables(c, job, ps, accept_bitmap) : batch_device(c, job, accept_bitmap);
+  if (rc != ZKGPU_OK) { memset(accept_bitmap, 0, (batch + 7) / 8); return rc; }
+  std::vector<uint32_t> wf(batch);
+  hipError_t e = hipMemcpy(wf.data(), c->prep_wf.p, batch * 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { memset(accept_bitmap, 0, (batch + 7) / 8); c->last_error = hipGetErrorString(e); return ZKGPU_EHIP; }
+  for (size_t i = 0; i < batch; ++i)
+    if (!wf[i]) accept_bitmap[i / 8] &= (uint8_t)~(1u << (i % 8));
   return ZKGPU_OK;
 }
 

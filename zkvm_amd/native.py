@@ -71,6 +71,11 @@ def load_library():
     lib.zkgpu_decode_check.argtypes = [vp, u8p, sz, u8p]
     lib.zkgpu_cloak_verify_batch.argtypes = [vp, vp, sz, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p, u8p,
                                              C.POINTER(C.c_uint64), u8p, u8p, C.c_int]
+    lib.zkgpu_cloak_plan_create.argtypes = [vp, C.c_uint32, C.c_uint32, sz, C.POINTER(vp)]
+    lib.zkgpu_cloak_plan_destroy.argtypes = [vp]
+    lib.zkgpu_cloak_plan_destroy.restype = None
+    lib.zkgpu_cloak_plan_info.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 5
+    lib.zkgpu_cloak_verify_batch_gpu.argtypes = [vp, vp, vp, sz, u8p, u8p, sz, u8p, u8p]
     lib.zkgpu_cloak_prepare_batch.argtypes = [sz, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p, u8p,
                                               C.POINTER(C.c_uint64), u8p, C.c_int, u8p, u8p, C.POINTER(C.c_uint64), sz,
                                               u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), sz, u8p]

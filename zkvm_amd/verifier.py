@@ -82,6 +82,49 @@ class Verifier:
         self.ctx._check(rc)
         return bm.raw[: (batch + 7) // 8]
 
+    # ---- host half on the device (plan replay) ---------------------------------------------
+    def _plan(self, n_in: int, n_out: int):
+        plans = self.__dict__.setdefault("_plans", {})
+        key = (n_in, n_out)
+        if key not in plans:
+            h = C.c_void_p()
+            self.ctx._check(self.ctx.lib.zkgpu_cloak_plan_create(self.ctx.h, n_in, n_out, self.bp_gens.gens_capacity,
+                                                                 C.byref(h)))
+            plans[key] = h
+        return plans[key]
+
+    def plan_info(self, n_in: int, n_out: int) -> dict:
+        vals = [C.c_uint32() for _ in range(5)]
+        self.ctx._check(self.ctx.lib.zkgpu_cloak_plan_info(self._plan(n_in, n_out), *[C.byref(v) for v in vals]))
+        return dict(zip(("multipliers", "padded_n", "constraints", "terms", "proof_len"), [v.value for v in vals]))
+
+    def verify_bitmap_gpu(self, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None) -> bytes:
+        """As verify_bitmap, with the transcript replay and the scalar preparation on the GPU.
+        Transactions are grouped by shape (one device plan per shape); a proof whose length does
+        not fit its shape is rejected, as in the reference."""
+        batch = len(txs)
+        out = bytearray((batch + 7) // 8)
+        groups = {}
+        for i, t in enumerate(txs):
+            groups.setdefault((t.n_in, t.n_out, len(t.proof)), []).append(i)
+        for (n_in, n_out, plen), idx in groups.items():
+            sub = [txs[i] for i in idx]
+            rb = b"".join(r_bytes[64 * i: 64 * i + 64] for i in idx) if r_bytes is not None else None
+            bm = C.create_string_buffer(max((len(sub) + 7) // 8, 1))
+            rc = self.ctx.lib.zkgpu_cloak_verify_batch_gpu(
+                self.ctx.h, self.bp_gens.points.h, self._plan(n_in, n_out), len(sub),
+                b"".join(t.commitments for t in sub), b"".join(t.proof for t in sub), plen, rb, bm)
+            self.ctx._check(rc)
+            for j, i in enumerate(idx):
+                if (bm.raw[j // 8] >> (j % 8)) & 1:
+                    out[i // 8] |= 1 << (i % 8)
+        return bytes(out)
+
+    def close(self) -> None:
+        for h in self.__dict__.get("_plans", {}).values():
+            self.ctx.lib.zkgpu_cloak_plan_destroy(h)
+        self.__dict__["_plans"] = {}
+
     def prepare(self, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None):
         """Host half only: proof bytes -> MSM terms (CSR) for Context.verify_batch_ps*.
         -> dict(dyn_sc, dyn_pt, dyn_off, st_sc, st_idx, st_off, wellformed)"""
