@@ -277,7 +277,7 @@ def test_fixed_base_tables_equal_generic_path(ctx, oracle, w):
     plain = ctx.verify_batch_ps(ps, dyn_sc, dyn_pt, dyn_off, st_sc, st_off, static_index=st_idx)
     assert plain == want
     nbytes = ps.build_tables(w)
-    assert nbytes == (255 // w + 1) * n_gen * (1 << (w - 1)) * 128
+    assert nbytes == (255 // w + 1) * n_gen * (1 << (w - 1)) * 96
     for parts in (0, 1, 3):
         ctx.set_static_parts(parts)
         assert ctx.verify_batch_ps(ps, dyn_sc, dyn_pt, dyn_off, st_sc, st_off, static_index=st_idx) == want

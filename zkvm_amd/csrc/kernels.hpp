@@ -34,6 +34,7 @@ constexpr uint32_t ENTRY_IDX = (1u << 30) - 1;
 constexpr int NIELS_WORDS = 32;
 constexpr int EXT_WORDS = 40;
 constexpr int REDUCE_CHUNK = 64;   // buckets per lane in k_bucket_reduce
+constexpr int TABLE_WORDS = 24;    // fixed-base table row: three canonical 255-bit values, 96 B
 
 struct JobDesc {
   // dynamic terms (own compressed points)
@@ -94,6 +95,30 @@ __device__ __forceinline__ void store_ext(uint32_t* row, const ge& p) {
   uint4* r4 = reinterpret_cast<uint4*>(row);
 #pragma unroll
   for (int i = 0; i < 10; ++i) r4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// fixed-base table rows are packed (3 x 32 B) to cut the gather traffic by a quarter
+__device__ __forceinline__ void load_table_row(ge_niels& q, const uint32_t* row) {
+  const uint4* r4 = reinterpret_cast<const uint4*>(row);
+  uint32_t w[24];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    uint4 v = r4[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  fe_from_words(q.ypx, w);
+  fe_from_words(q.ymx, w + 8);
+  fe_from_words(q.xy2d, w + 16);
+}
+
+__device__ __forceinline__ void store_table_row(uint32_t* row, const ge_niels& q) {
+  uint32_t w[24];
+  fe_to_words(w, q.ypx);
+  fe_to_words(w + 8, q.ymx);
+  fe_to_words(w + 16, q.xy2d);
+  uint4* r4 = reinterpret_cast<uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 
 // largest m with offsets[m] <= g  (offsets has n_msm + 1 entries, non-decreasing)
@@ -431,6 +456,101 @@ k_msm_finish(const uint32_t* __restrict__ window_sums, const uint32_t* __restric
   accept[m] = (ident && !failed) ? 1 : 0;
 }
 
+// ---- k_small_msm_windows ------------------------------------------------------------
+// Window sums of a SMALL multiscalar multiplication (the few dozen proof-specific
+// points of one transaction) without the global sort: one wavefront per MSM, window
+// width 4, so the 64 lanes ARE the 64 windows.
+//   phase 1  lane i: the 64 signed digits of scalar i (LDS, one byte each) and the
+//            multiples P_i, 2P_i .. 8P_i in "cached" form (Y+X, Y-X, 2Z, 2dT), 160 B each, in LDS
+//   phase 2  lane t: W_t = sum_i sign(d_it) * (|d_it| P_i): one 8M addition per point,
+//            every lane busy, no buckets, no atomics, no HBM intermediates
+// More than `chunk` points per MSM are handled chunk at a time (window sums add up).
+struct ge_cached { fe YpX, YmX, Z2, T2d; };
+
+__device__ __forceinline__ void ge_add_cached(ge& r, const ge& p, const ge_cached& q, bool negate) {
+  fe a, b, c, d, e, f, g, h, t0, t1, qa = q.YmX, qb = q.YpX;
+  fe_cswap(qa, qb, negate);
+  fe_sub(t0, p.Y, p.X);
+  fe_add(t1, p.Y, p.X);
+  fe_mul(a, t0, qa);
+  fe_mul(b, t1, qb);
+  fe_mul(c, p.T, q.T2d);
+  fe_mul(d, p.Z, q.Z2);
+  fe_sub(e, b, a);
+  fe_add(h, b, a);
+  fe_sub(f, d, c);
+  fe_add(g, d, c);
+  fe_cswap(f, g, negate);
+  fe_mul(r.X, e, f);
+  fe_mul(r.Y, g, h);
+  fe_mul(r.Z, f, g);
+  fe_mul(r.T, e, h);
+}
+
+constexpr int SMALL_TBL = 8;   // multiples per point (signed 4-bit digits)
+
+__global__ void __launch_bounds__(64)
+k_small_msm_windows(const uint32_t* __restrict__ dyn_scalars, const uint64_t* __restrict__ dyn_offsets,
+                    const uint32_t* __restrict__ dyn_rows, uint32_t n_msm, uint32_t* __restrict__ window_sums,
+                    uint32_t* __restrict__ window_nonempty, uint32_t* __restrict__ status, int chunk) {
+  // LDS is what limits how many of these waves a CU holds, so the host sizes it for `chunk`
+  // points (<= 64, about the typical point count of one MSM): chunk * (8 * 160 + 64) bytes
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* tbl = smem;                                               // [chunk points][8][40 words]
+  int8_t* digits = reinterpret_cast<int8_t*>(smem + chunk * SMALL_TBL * EXT_WORDS);   // [chunk points][64 windows]
+  const uint32_t m = blockIdx.x;
+  const int t = threadIdx.x;
+  const uint64_t k0 = dyn_offsets[m], k1 = dyn_offsets[m + 1];
+  ge total;
+  bool total_set = false;
+  for (uint64_t base = k0; base < k1; base += chunk) {
+    const int n = (int)min((uint64_t)chunk, k1 - base);
+    __syncthreads();
+    if (t < n) {
+      const uint32_t* sc = dyn_scalars + 8 * (base + t);
+      if (sc[7] >> 31) atomicOr(&status[0], 2u);
+      for (int q = 0; q < 64; ++q) digits[t * 64 + q] = 0;
+      for_each_digit(sc, 4, 64, [&](int win, int d) { digits[t * 64 + win] = (int8_t)d; });
+      // multiples of point t
+      ge_niels nq;
+      load_niels(nq, dyn_rows + (base + t) * NIELS_WORDS);
+      ge p1, cur;
+      ge_identity(p1);
+      ge_madd(p1, p1, nq, false);
+      cur = p1;
+#pragma unroll 1
+      for (int e = 0; e < SMALL_TBL; ++e) {
+        if (e == 1) ge_double(cur, p1);
+        else if (e > 1) ge_add(cur, cur, p1);
+        ge c4;   // cached form packed in an ext row: YpX, YmX, 2Z, 2dT
+        fe_add_c(c4.X, cur.Y, cur.X);
+        fe_sub_c(c4.Y, cur.Y, cur.X);
+        fe_add_c(c4.Z, cur.Z, cur.Z);
+        fe_mul(c4.T, cur.T, fe_D2());
+        uint32_t* row = tbl + ((uint32_t)t * SMALL_TBL + e) * EXT_WORDS;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) { row[q] = c4.X.v[q]; row[10 + q] = c4.Y.v[q]; row[20 + q] = c4.Z.v[q]; row[30 + q] = c4.T.v[q]; }
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+      const int d = digits[i * 64 + t];
+      if (d != 0) {
+        const uint32_t* row = tbl + ((uint32_t)i * SMALL_TBL + (uint32_t)((d < 0 ? -d : d) - 1)) * EXT_WORDS;
+        ge_cached c;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) { c.YpX.v[q] = row[q]; c.YmX.v[q] = row[10 + q]; c.Z2.v[q] = row[20 + q]; c.T2d.v[q] = row[30 + q]; }
+        if (!total_set) { ge_identity(total); total_set = true; }
+        ge_add_cached(total, total, c, d < 0);
+      }
+    }
+  }
+  const uint64_t win = (uint64_t)m * 64 + t;
+  window_nonempty[win] = total_set ? 1u : 0u;
+  if (total_set) store_ext(window_sums + win * EXT_WORDS, total);
+}
+
 // ---- k_msm_finish_quad -----------------------------------------------------------
 // Same contract as k_msm_finish, four lanes per MSM (quad.hpp): the Horner chain
 // of ~255 doublings is the latency floor of a batch, and a quad walks it ~3x faster.
@@ -516,7 +636,7 @@ k_pack_bitmap(const uint8_t* __restrict__ accept, uint8_t* __restrict__ bitmap, 
 // The generators never change, so the device keeps, for every window position t
 // and every generator j, the affine-Niels rows of d * 2^(w t) * G_j for
 // d = 1 .. 2^(w-1):
-//     table[((t * n_set + j) * H + (d - 1)) * 32 words],  H = 2^(w-1)
+//     table[((t * n_set + j) * H + (d - 1)) * 24 words],  H = 2^(w-1)   (96-byte packed rows)
 // A generator term s * G_j then costs one mixed addition per window with NO
 // doublings, no sorting and no bucket reduction, and every lane of the kernel
 // does the same number of additions.  Memory is what MI355X has plenty of:
@@ -563,7 +683,7 @@ k_tbl_multiples(const uint32_t* __restrict__ base, uint32_t* __restrict__ tmp, u
   }
   fe inv;
   fe_invert(inv, prod);           // 1 / (Z_1 ... Z_H)
-  uint32_t* myrows = table + lane * (uint64_t)H * NIELS_WORDS;
+  uint32_t* myrows = table + lane * (uint64_t)H * TABLE_WORDS;
   for (uint32_t d = H; d-- > 0;) {
     ge rec;
     load_ext(rec, mytmp + (uint64_t)d * EXT_WORDS);
@@ -580,7 +700,7 @@ k_tbl_multiples(const uint32_t* __restrict__ base, uint32_t* __restrict__ tmp, u
     fe_mul(y, rec.Y, zinv);
     ge_niels nq;
     niels_from_affine(nq, x, y);
-    store_niels(myrows + (uint64_t)d * NIELS_WORDS, nq, 1u);
+    store_table_row(myrows + (uint64_t)d * TABLE_WORDS, nq);
   }
 }
 
@@ -618,8 +738,8 @@ k_static_accumulate(const int16_t* __restrict__ digits, const uint64_t* __restri
     const int d = dig[k];
     const uint32_t idx = st_index ? st_index[k] : (uint32_t)(k - k0);
     const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-    const uint32_t* row = table + ((tbase + idx) * H + (mag ? mag - 1 : 0)) * NIELS_WORDS;
-    load_niels(q, row);
+    const uint32_t* row = table + ((tbase + idx) * H + (mag ? mag - 1 : 0)) * TABLE_WORDS;
+    load_table_row(q, row);
     if (d == 0) niels_identity(q);
     neg = d < 0;
   };

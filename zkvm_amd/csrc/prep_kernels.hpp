@@ -25,6 +25,8 @@ struct PrepShape {
   uint32_t proof_words;     // (16 + 2k) * 8
   uint32_t n_ch;            // CH_FIXED + n_chal2 + 2k
   uint32_t n_dyn, n_static; // 11 + m + 2k, 2 + 2 pn
+  uint32_t n_heavy;         // targets with many terms (e.g. wc) are summed by the whole workgroup
+  uint32_t heavy[8];
 };
 
 __device__ __forceinline__ void ld_scm(scm& s, const uint32_t* p) {
@@ -177,7 +179,8 @@ k_transcript(PrepShape sh, const uint32_t* __restrict__ init_state /*50 words + 
 }
 
 // ---- k_prepare ------------------------------------------------------------------------------
-// LDS (words): chs[n_ch*8] | sym[n_mono*8] | zpow[n_cons*8] | tv[n_terms*8] | wv[n_targets*8] | yip[pn*8] | sv[pn*8] | red[256*8]
+// LDS (words): chs[n_ch*8] | sym[n_mono*8] | wv[n_targets*8] | A: zpow[n_cons*8] tv[n_terms*8]
+// and, once the flattening is done, the same region A again as yip[pn*8] sv[pn*8] red[256*8]
 __global__ void __launch_bounds__(256)
 k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* __restrict__ mono_pow,
           const uint32_t* __restrict__ tgt_off, const uint32_t* __restrict__ term_q,
@@ -187,10 +190,10 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* chs = lds;
   uint32_t* sym = chs + sh.n_ch * 8;
-  uint32_t* zpow = sym + sh.n_mono * 8;
+  uint32_t* wv = sym + sh.n_mono * 8;
+  uint32_t* zpow = wv + sh.n_targets * 8;      // region A, first life
   uint32_t* tv = zpow + sh.n_cons * 8;
-  uint32_t* wv = tv + sh.n_terms * 8;
-  uint32_t* yip = wv + sh.n_targets * 8;
+  uint32_t* yip = zpow;                          // region A, second life
   uint32_t* sv = yip + sh.pn * 8;
   uint32_t* red = sv + sh.pn * 8;
   const uint32_t tx = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
@@ -220,18 +223,6 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
       for (uint32_t q = t + nt; q < sh.n_cons; q += nt) { cur = scm_mul(cur, zstep); st_scm(zpow + 8 * q, cur); }
     }
   }
-  for (uint32_t i = t; i < sh.pn; i += nt) {
-    st_scm(yip + 8 * i, scm_pow_u32(y_inv, i));
-    // s_i = prod_j (bit (k-1-j) of i ? u_j : 1/u_j): the first challenge pairs with the top bit
-    scm s = scm_one();
-    for (uint32_t j = 0; j < sh.k; ++j) {
-      scm f;
-      const bool bit = (i >> (sh.k - 1 - j)) & 1;
-      ld_scm(f, chs + (CH_FIXED + sh.n_chal2 + (bit ? j : sh.k + j)) * 8);
-      s = scm_mul(s, f);
-    }
-    st_scm(sv + 8 * i, s);
-  }
   __syncthreads();
   // plan replay: one product per term, then one sum per target
   for (uint32_t e = t; e < sh.n_terms; e += nt) {
@@ -243,9 +234,48 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   }
   __syncthreads();
   for (uint32_t g = t; g < sh.n_targets; g += nt) {
+    bool heavy = false;
+    for (uint32_t hI = 0; hI < sh.n_heavy; ++hI) heavy |= (sh.heavy[hI] == g);
+    if (heavy) continue;
     scm acc = scm_zero();
     for (uint32_t e = tgt_off[g]; e < tgt_off[g + 1]; ++e) { scm v; ld_scm(v, tv + 8 * e); acc = scm_add(acc, v); }
     st_scm(wv + 8 * g, acc);
+  }
+  // heavy targets: every lane sums a strided share, wavefront shuffles fold the lanes, lane 0 of
+  // each wave parks its sum in wv-adjacent scratch (the tail of tv is free: use 4 slots after n_terms)
+  for (uint32_t hI = 0; hI < sh.n_heavy; ++hI) {
+    const uint32_t g = sh.heavy[hI];
+    scm acc = scm_zero();
+    for (uint32_t e = tgt_off[g] + t; e < tgt_off[g + 1]; e += nt) { scm v; ld_scm(v, tv + 8 * e); acc = scm_add(acc, v); }
+#pragma unroll 1
+    for (int delta = 32; delta >= 1; delta >>= 1) {
+      scm o;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o.v[q] = __shfl_down(acc.v[q], delta);
+      acc = scm_add(acc, o);
+    }
+    uint32_t* wave_sums = tv + (sh.n_terms + 4 * hI) * 8;
+    if ((t & 63) == 0) st_scm(wave_sums + 8 * (t >> 6), acc);
+    __syncthreads();
+    if (t == 0) {
+      scm tot = scm_zero();
+      for (uint32_t wI = 0; wI < (nt >> 6); ++wI) { scm v; ld_scm(v, wave_sums + 8 * wI); tot = scm_add(tot, v); }
+      st_scm(wv + 8 * g, tot);
+    }
+  }
+  __syncthreads();
+  // region A is dead now: y^-i and s_i take its place
+  for (uint32_t i = t; i < sh.pn; i += nt) {
+    st_scm(yip + 8 * i, scm_pow_u32(y_inv, i));
+    // s_i = prod_j (bit (k-1-j) of i ? u_j : 1/u_j): the first challenge pairs with the top bit
+    scm s = scm_one();
+    for (uint32_t j = 0; j < sh.k; ++j) {
+      scm f;
+      const bool bit = (i >> (sh.k - 1 - j)) & 1;
+      ld_scm(f, chs + (CH_FIXED + sh.n_chal2 + (bit ? j : sh.k + j)) * 8);
+      s = scm_mul(s, f);
+    }
+    st_scm(sv + 8 * i, s);
   }
   __syncthreads();
   const uint32_t* wL = wv;

@@ -417,7 +417,32 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
     Job dj = job;
     dj.d_st_scalars = nullptr; dj.d_st_index = nullptr; dj.d_st_offsets = nullptr; dj.n_static = 0;
     JobDesc jd;
-    TRY(run_to_windows(c, dj, jd, /*reset_status=*/false));
+    if (!c->forced_w && job.n_dyn <= 128ull * B) {
+      // few proof-specific points per transaction: one wavefront per transaction, no global sort
+      jd.w = 4; jd.n_windows = 64;
+      c->last_w = 4;
+      TRY(ensure(c, c->dyn_rows, std::max<uint64_t>(job.n_dyn, 1) * NIELS_WORDS * 4));
+      TRY(ensure(c, c->window_sums, (size_t)B * 64 * EXT_WORDS * 4));
+      TRY(ensure(c, c->window_flags, (size_t)B * 64 * 4));
+      TRY(ensure(c, c->msm_fail, (size_t)B * 4));
+      HIP_TRY(c, hipMemsetAsync(c->msm_fail.p, 0, (size_t)B * 4, s));
+      {
+        Launch l(c, "k_decompress");
+        hipLaunchKernelGGL(k_decompress, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, s, job.d_dyn_points,
+                           (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, (uint32_t)B,
+                           (uint32_t*)c->msm_fail.p, (unsigned long long*)((char*)c->status.p + 8), (uint8_t*)nullptr);
+      }
+      {
+        Launch l(c, "k_small_msm_windows");
+        const int chunk = (int)std::min<uint64_t>(64, std::max<uint64_t>(8, ((job.n_dyn + B - 1) / B + 3) / 4 * 4));
+        hipLaunchKernelGGL(k_small_msm_windows, dim3((unsigned)B), dim3(64),
+                           (size_t)chunk * (SMALL_TBL * EXT_WORDS * 4 + 64), s, job.d_dyn_scalars, job.d_dyn_offsets,
+                           (const uint32_t*)c->dyn_rows.p, (uint32_t)B, (uint32_t*)c->window_sums.p,
+                           (uint32_t*)c->window_flags.p, (uint32_t*)c->status.p, chunk);
+      }
+    } else {
+      TRY(run_to_windows(c, dj, jd, /*reset_status=*/false));
+    }
     Launch l(c, "k_msm_finish");
     hipLaunchKernelGGL(k_msm_finish_quad, dim3(blocks_for(4 * B, 256)), dim3(256), 0, s,
                        (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p,
@@ -518,6 +543,8 @@ int zkgpu_init(int device, zkgpu_ctx** out) {
       hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return ZKGPU_EHIP; }
+  (void)hipFuncSetAttribute((const void*)k_small_msm_windows, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            64 * SMALL_TBL * EXT_WORDS * 4 + 64 * 64);
   *out = c;
   return ZKGPU_OK;
 }
@@ -652,7 +679,7 @@ int zkgpu_pointset_build_tables(zkgpu_ctx* c, zkgpu_pointset* ps, int window_bit
   const uint64_t n_lanes = (uint64_t)W * ps->n;
   const uint64_t n_rows = n_lanes * H;
   uint32_t *base = nullptr, *tmp = nullptr, *table = nullptr;
-  hipError_t e = hipMalloc((void**)&table, n_rows * NIELS_WORDS * 4);
+  hipError_t e = hipMalloc((void**)&table, n_rows * TABLE_WORDS * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&base, n_lanes * EXT_WORDS * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&tmp, n_rows * EXT_WORDS * 4);
   if (e != hipSuccess) {
@@ -683,7 +710,7 @@ int zkgpu_pointset_build_tables(zkgpu_ctx* c, zkgpu_pointset* ps, int window_bit
 }
 
 size_t zkgpu_pointset_table_bytes(const zkgpu_pointset* ps) {
-  return (ps && ps->table) ? (size_t)ps->tbl_W * ps->n * ps->tbl_H * NIELS_WORDS * 4 : 0;
+  return (ps && ps->table) ? (size_t)ps->tbl_W * ps->n * ps->tbl_H * TABLE_WORDS * 4 : 0;
 }
 
 int zkgpu_set_static_parts(zkgpu_ctx* c, int parts) {
@@ -903,7 +930,11 @@ int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t 
   s.n_ch = CH_FIXED + s.n_chal2 + 2 * h.k;
   s.n_dyn = 11 + h.m + 2 * h.k;
   s.n_static = 2 + 2 * h.pn;
-  p->lds_bytes = (size_t)(s.n_ch + s.n_mono + s.n_cons + s.n_terms + s.n_targets + 2 * s.pn + 256) * 32;
+  s.n_heavy = 0;
+  for (uint32_t t = 0; t < s.n_targets && s.n_heavy < 8; ++t)
+    if (h.tgt_off[t + 1] - h.tgt_off[t] > 24) s.heavy[s.n_heavy++] = t;
+  const size_t region_a = std::max<size_t>((size_t)s.n_cons + s.n_terms + 4 * 8, (size_t)2 * s.pn + 256);
+  p->lds_bytes = ((size_t)s.n_ch + s.n_mono + s.n_targets + region_a) * 32;
   if (p->lds_bytes > 160 * 1024) { delete p; c->last_error = "plan does not fit the 160 KiB LDS of a CU"; return ZKGPU_EINVAL; }
   // STROBE state after Transcript::new("ZkVM.r1cs") + r1cs_domain_sep()
   Transcript tr("ZkVM.r1cs");

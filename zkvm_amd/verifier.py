@@ -120,6 +120,15 @@ class Verifier:
                     out[i // 8] |= 1 << (i % 8)
         return bytes(out)
 
+    def verify_packed_gpu(self, n_in: int, n_out: int, batch: int, commitments: bytes, proofs: bytes, proof_len: int,
+                          r_bytes: Optional[bytes] = None) -> bytes:
+        """zkgpu_cloak_verify_batch_gpu on already-contiguous buffers (what a Rust caller would hand over)."""
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        rc = self.ctx.lib.zkgpu_cloak_verify_batch_gpu(self.ctx.h, self.bp_gens.points.h, self._plan(n_in, n_out), batch,
+                                                       commitments, proofs, proof_len, r_bytes, bm)
+        self.ctx._check(rc)
+        return bm.raw[: (batch + 7) // 8]
+
     def close(self) -> None:
         for h in self.__dict__.get("_plans", {}).values():
             self.ctx.lib.zkgpu_cloak_plan_destroy(h)
