@@ -25,7 +25,7 @@
 #include <hip/hip_runtime.h>
 #define ZK_HD __host__ __device__ __forceinline__
 #define ZK_UNROLL _Pragma("unroll")
-#define ZK_NOUNROLL _Pragma("unroll 1")
+#define ZK_NOUNROLL _Pragma("clang loop unroll(disable)")
 #else
 #define ZK_HD inline
 #define ZK_UNROLL
@@ -156,7 +156,14 @@ ZK_HD void fe_sq(fe& h, const fe& f) {
 
 ZK_HD void fe_sqn(fe& h, const fe& f, int n) {
   fe_sq(h, f);
-  ZK_NOUNROLL for (int i = 1; i < n; ++i) fe_sq(h, h);
+  ZK_NOUNROLL for (int i = 1; i < n; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keep every iteration a self-contained squaring: without this fence the optimiser
+    // rotates / interleaves the chain and the register allocation triples
+    ZK_UNROLL for (int k = 0; k < 10; ++k) asm volatile("" : "+v"(h.v[k]));
+#endif
+    fe_sq(h, h);
+  }
 }
 
 // fully reduced limbs (the unique representative in [0, p))

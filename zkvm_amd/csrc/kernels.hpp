@@ -33,7 +33,8 @@ constexpr uint32_t ENTRY_DYN = 1u << 30;
 constexpr uint32_t ENTRY_IDX = (1u << 30) - 1;
 constexpr int NIELS_WORDS = 32;
 constexpr int EXT_WORDS = 40;
-constexpr int REDUCE_CHUNK = 64;   // buckets per lane in k_bucket_reduce
+constexpr int REDUCE_CHUNK = 64;   // buckets per lane in k_bucket_reduce when a window has at most this many
+constexpr int REDUCE_CHUNK_BIG = 16;  // ... and when it has more (more lanes, shorter serial chains)
 constexpr int TABLE_WORDS = 24;    // fixed-base table row: three canonical 255-bit values, 96 B
 
 struct JobDesc {
@@ -149,6 +150,124 @@ k_decompress(const uint32_t* __restrict__ pts, uint32_t* __restrict__ rows, uint
   if (!ok) niels_identity(q);
   if (rows) store_niels(rows + NIELS_WORDS * i, q, ok ? 1u : 0u);
   if (ok_out) ok_out[i] = ok ? 1 : 0;
+  if (!ok) {
+    if (bad_index) atomicMin(bad_index, (unsigned long long)i);
+    if (msm_fail) {
+      uint32_t m = (n_msm > 1 && offsets) ? find_row(offsets, n_msm, i) : 0;
+      atomicOr(&msm_fail[m], 1u);
+    }
+  }
+}
+
+// ---- split decompression (large point counts) ----------------------------------
+// DECODE is one 250-squaring chain wrapped in a dozen multiplications.  Fused, the chain
+// shares its registers with everything live around it and the kernel runs one wave per
+// SIMD; split in three, the chain runs alone in a ~100-register kernel at full occupancy
+// and the ends trade 280 B/point of scratch traffic for it.
+//   scratch row (72 words): s[10] u1[10] u2[10] v[10] w[10] r[10] flags pad  (w = v * u2^2, r = w^((p-5)/8))
+constexpr int DEC_WORDS = 64;
+
+__global__ void __launch_bounds__(256)
+k_decompress_pre(const uint32_t* __restrict__ pts, uint32_t* __restrict__ scratch, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* p4 = reinterpret_cast<const uint4*>(pts + 8 * i);
+  uint4 a = p4[0], b = p4[1];
+  uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  fe s, ss, u1, u2, u2_sqr, v, t;
+  fe_from_words(s, w);
+  uint32_t chk[8];
+  fe_to_words(chk, s);
+  bool canonical = true;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) canonical &= (chk[k] == w[k]);
+  const bool pre_ok = canonical && !(w[0] & 1);
+  fe_sq(ss, s);
+  fe_sub(u1, fe_one(), ss);
+  fe_add(u2, fe_one(), ss);
+  fe_carry(u1);
+  fe_carry(u2);
+  fe_sq(u2_sqr, u2);
+  fe_sq(t, u1);
+  fe_mul(t, t, fe_D());
+  fe_add(t, t, u2_sqr);
+  fe_sub_c(v, fe_zero(), t);
+  fe_mul(t, v, u2_sqr);               // w: the argument of SQRT_RATIO_M1(1, w)
+  // (1 * w^7)^((p-5)/8) is what the chain computes: hand it w^7 and keep w^3 for afterwards
+  fe w2, w3, w7;
+  fe_sq(w2, t);
+  fe_mul(w3, w2, t);
+  fe_sq(w7, w3);
+  fe_mul(w7, w7, t);
+  uint32_t* row = scratch + i * DEC_WORDS;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { row[k] = s.v[k]; row[10 + k] = u1.v[k]; row[20 + k] = u2.v[k]; row[30 + k] = v.v[k]; row[40 + k] = t.v[k]; row[50 + k] = w7.v[k]; }
+  row[60] = pre_ok ? 1u : 0u;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) row[61 + k] = 0;
+  (void)w3;
+}
+
+// row[50..59] <- row[50..59]^((p-5)/8)
+__global__ void __launch_bounds__(256, 4)
+k_pow22523(uint32_t* __restrict__ scratch, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t* row = scratch + i * DEC_WORDS + 50;
+  fe x, r;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) x.v[k] = row[k];
+  fe_pow22523(r, x);
+#pragma unroll
+  for (int k = 0; k < 10; ++k) row[k] = r.v[k];
+}
+
+__global__ void __launch_bounds__(256)
+k_decompress_post(const uint32_t* __restrict__ scratch, uint32_t* __restrict__ rows, uint64_t n,
+                  const uint64_t* __restrict__ offsets, uint32_t n_msm, uint32_t* __restrict__ msm_fail,
+                  unsigned long long* __restrict__ bad_index) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* row = scratch + i * DEC_WORDS;
+  fe s, u1, u2, v, w, pw;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { s.v[k] = row[k]; u1.v[k] = row[10 + k]; u2.v[k] = row[20 + k]; v.v[k] = row[30 + k]; w.v[k] = row[40 + k]; pw.v[k] = row[50 + k]; }
+  const bool pre_ok = row[60] != 0;
+  // SQRT_RATIO_M1(1, w): r = w^3 * (w^7)^((p-5)/8); check = w r^2
+  fe w3, r, t, check, r_prime, neg_r;
+  fe_sq(t, w);
+  fe_mul(w3, t, w);
+  fe_mul(r, pw, w3);
+  fe_sq(t, r);
+  fe_mul(check, t, w);
+  const fe one = fe_one();
+  fe neg_one, neg_i;
+  fe_neg(neg_one, one);
+  fe_mul(neg_i, neg_one, fe_SQRT_M1());
+  const bool correct_sign = fe_eq(check, one);
+  const bool flipped_sign = fe_eq(check, neg_one);
+  const bool flipped_sign_i = fe_eq(check, neg_i);
+  fe_mul(r_prime, r, fe_SQRT_M1());
+  fe_cmov(r, r_prime, flipped_sign | flipped_sign_i);
+  fe_neg(neg_r, r);
+  fe_cmov(r, neg_r, fe_is_negative(r));
+  const bool was_square = correct_sign | flipped_sign;
+  fe den_x, den_y, x, y, nx;
+  fe_mul(den_x, r, u2);
+  fe_mul(den_y, r, den_x);
+  fe_mul(den_y, den_y, v);
+  fe_mul(x, s, den_x);
+  fe_add(x, x, x);
+  fe_carry(x);
+  fe_neg(nx, x);
+  fe_cmov(x, nx, fe_is_negative(x));
+  fe_mul(y, u1, den_y);
+  fe_mul(t, x, y);
+  const bool ok = pre_ok & was_square & !fe_is_negative(t) & !fe_is_zero(y);
+  ge_niels q;
+  niels_from_affine(q, x, y);
+  if (!ok) niels_identity(q);
+  store_niels(rows + NIELS_WORDS * i, q, ok ? 1u : 0u);
   if (!ok) {
     if (bad_index) atomicMin(bad_index, (unsigned long long)i);
     if (msm_fail) {
@@ -296,44 +415,186 @@ k_scan_apply(uint32_t* __restrict__ data, uint64_t n, const uint32_t* __restrict
   for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < n) data[base + k] = ex; ex += v[k]; }
 }
 
+// ---- partition sort (single large MSM) ------------------------------------------------
+// The (window, bucket) sort of a 2^20-term MSM is 16.7 M keys over 524 288 bins.  Doing
+// it with one global atomic per key runs at the chip's random-atomic rate (~20 G/s,
+// MI355X_MICROARCH.md "Global float atomics": they execute at the memory side) and
+// cost more than the point additions.  Here every atomic is an LDS atomic:
+//   k_part_hist     tile of PART_TILE terms -> LDS histogram over partitions
+//                   p = (window, high bucket bits); counts out partition-major
+//   k_scan_*        exclusive scan of the (partition, tile) counts
+//   k_part_scatter  same tile: rank inside (partition, tile) by LDS atomic, entries
+//                   land in 128-byte runs per partition
+//   k_part_sort     one workgroup per partition: histogram of the low bucket bits
+//                   (LDS), scan, then place every entry at its final position and
+//                   emit the bin end offsets the accumulate kernel reads
+constexpr int PART_TILE = 2048;      // terms per tile
+constexpr int PART_LO_BITS = 8;      // low bucket bits sorted inside a partition
+
+struct PartShape {
+  uint32_t n_part, n_tiles, hi_bits, lo_bits;
+};
+
+__global__ void __launch_bounds__(256)
+k_part_hist(JobDesc j, PartShape ps, uint32_t* __restrict__ hist, uint32_t* __restrict__ status) {
+  extern __shared__ uint32_t cnt[];
+  for (uint32_t p = threadIdx.x; p < ps.n_part; p += 256) cnt[p] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * PART_TILE;
+  for (int r = 0; r < PART_TILE / 256; ++r) {
+    const uint64_t g = base + r * 256 + threadIdx.x;
+    if (g < j.n_dyn) {
+      const uint32_t* sc = j.dyn_scalars + 8 * g;
+      if (sc[7] >> 31) atomicOr(&status[0], 2u);
+      for_each_digit(sc, j.w, j.n_windows, [&](int t, int d) {
+        const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+        atomicAdd(&cnt[((uint32_t)t << ps.hi_bits) | (b >> ps.lo_bits)], 1u);
+      });
+    }
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < ps.n_part; p += 256) hist[(uint64_t)p * ps.n_tiles + blockIdx.x] = cnt[p];
+}
+
+__global__ void __launch_bounds__(256)
+k_part_scatter(JobDesc j, PartShape ps, const uint32_t* __restrict__ offs, uint32_t* __restrict__ pe,
+               uint8_t* __restrict__ plo) {
+  extern __shared__ uint32_t cur[];
+  for (uint32_t p = threadIdx.x; p < ps.n_part; p += 256) cur[p] = offs[(uint64_t)p * ps.n_tiles + blockIdx.x];
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * PART_TILE;
+  const uint32_t lo_mask = (1u << ps.lo_bits) - 1;
+  for (int r = 0; r < PART_TILE / 256; ++r) {
+    const uint64_t g = base + r * 256 + threadIdx.x;
+    if (g < j.n_dyn) {
+      const uint32_t* sc = j.dyn_scalars + 8 * g;
+      for_each_digit(sc, j.w, j.n_windows, [&](int t, int d) {
+        const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+        const uint32_t pos = atomicAdd(&cur[((uint32_t)t << ps.hi_bits) | (b >> ps.lo_bits)], 1u);
+        pe[pos] = ENTRY_DYN | (uint32_t)g | (d < 0 ? ENTRY_NEG : 0u);
+        plo[pos] = (uint8_t)(b & lo_mask);
+      });
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_part_sort(PartShape ps, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ pe,
+            const uint8_t* __restrict__ plo, uint32_t* __restrict__ entries, uint32_t* __restrict__ cursor) {
+  __shared__ uint32_t c[256], cur[256];
+  const uint32_t p = blockIdx.x, t = threadIdx.x;
+  const uint32_t start = offs[(uint64_t)p * ps.n_tiles];
+  const uint32_t end = offs[(uint64_t)(p + 1) * ps.n_tiles];   // one extra element holds the grand total
+  c[t] = 0;
+  __syncthreads();
+  for (uint32_t e = start + t; e < end; e += 256) atomicAdd(&c[plo[e]], 1u);
+  __syncthreads();
+  uint32_t total;
+  const uint32_t mine = c[t];
+  const uint32_t ex = block_exclusive_scan(mine, total);
+  cur[t] = start + ex;
+  const uint32_t n_lo = 1u << ps.lo_bits;
+  if (t < n_lo) cursor[(uint64_t)p * n_lo + t] = start + ex + mine;   // END offset of bin (p, lo = t)
+  __syncthreads();
+  for (uint32_t e = start + t; e < end; e += 256) {
+    const uint32_t pos = atomicAdd(&cur[plo[e]], 1u);
+    entries[pos] = pe[e];
+  }
+}
+
+// ---- bin ordering ---------------------------------------------------------------
+// One lane sums one bin, so a wavefront takes as long as its fullest bin.  Bins are
+// therefore handed to lanes in order of decreasing size (256 size classes, counting
+// sort): the lanes of a wavefront get bins of (nearly) equal size, and the fullest
+// bins -- e.g. the top window, whose few significant bits concentrate the terms in a
+// handful of buckets -- start first instead of forming a tail.
+constexpr int SIZE_CLASSES = 256;
+__device__ __forceinline__ uint32_t bin_size_class(const uint32_t* __restrict__ cursor, uint64_t bin) {
+  const uint32_t cnt = cursor[bin] - (bin ? cursor[bin - 1] : 0u);
+  return (SIZE_CLASSES - 1) - min(cnt, (uint32_t)(SIZE_CLASSES - 1));   // class 0 = fullest
+}
+
+__global__ void __launch_bounds__(256)
+k_bin_classes(const uint32_t* __restrict__ cursor, uint64_t n_bins, uint32_t* __restrict__ class_count) {
+  __shared__ uint32_t h[SIZE_CLASSES];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t bin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (bin < n_bins) atomicAdd(&h[bin_size_class(cursor, bin)], 1u);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&class_count[threadIdx.x], h[threadIdx.x]);
+}
+
+// class_count[256] -> exclusive offsets in class_cursor[256]
+__global__ void __launch_bounds__(256)
+k_class_scan(const uint32_t* __restrict__ class_count, uint32_t* __restrict__ class_cursor) {
+  uint32_t total;
+  const uint32_t ex = block_exclusive_scan(class_count[threadIdx.x], total);
+  class_cursor[threadIdx.x] = ex;
+}
+
+__global__ void __launch_bounds__(256)
+k_bin_order(const uint32_t* __restrict__ cursor, uint64_t n_bins, uint32_t* __restrict__ class_cursor,
+            uint32_t* __restrict__ order) {
+  __shared__ uint32_t h[SIZE_CLASSES], base[SIZE_CLASSES];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t bin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t cls = 0, rank = 0;
+  if (bin < n_bins) { cls = bin_size_class(cursor, bin); rank = atomicAdd(&h[cls], 1u); }
+  __syncthreads();
+  if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&class_cursor[threadIdx.x], h[threadIdx.x]);
+  __syncthreads();
+  if (bin < n_bins) order[base[cls] + rank] = (uint32_t)bin;
+}
+
 // ---- k_bucket_accumulate ------------------------------------------------------
 // After the scatter, cursor[bin] is the END offset of bin; its start is the end
-// of the previous bin.  One lane per bin.
+// of the previous bin.  One lane per bin, bins taken in `order` (fullest first);
+// the row of the next entry is fetched while the current addition runs.
 __global__ void __launch_bounds__(256)
 k_bucket_accumulate(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ entries,
                     const uint32_t* __restrict__ static_rows, const uint32_t* __restrict__ dyn_rows,
-                    uint32_t* __restrict__ buckets, uint64_t n_bins) {
-  const uint64_t bin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (bin >= n_bins) return;
+                    uint32_t* __restrict__ buckets, uint64_t n_bins, const uint32_t* __restrict__ order) {
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_bins) return;
+  const uint64_t bin = order ? order[gid] : gid;
   const uint32_t start = bin ? cursor[bin - 1] : 0u, end = cursor[bin];
   if (start == end) return;
   ge acc;
   ge_identity(acc);
-  for (uint32_t k = start; k < end; ++k) {
+  auto fetch = [&](uint32_t k, ge_niels& q, bool& neg) {
     const uint32_t e = entries[k];
     const uint32_t* row = ((e & ENTRY_DYN) ? dyn_rows : static_rows) + (uint64_t)(e & ENTRY_IDX) * NIELS_WORDS;
-    ge_niels q;
     load_niels(q, row);
-    ge_madd(acc, acc, q, (e & ENTRY_NEG) != 0);
+    neg = (e & ENTRY_NEG) != 0;
+  };
+  ge_niels cur, nxt;
+  bool cur_neg = false, nxt_neg = false;
+  fetch(start, cur, cur_neg);
+  for (uint32_t k = start; k < end; ++k) {
+    if (k + 1 < end) fetch(k + 1, nxt, nxt_neg);
+    ge_madd(acc, acc, cur, cur_neg);
+    cur = nxt; cur_neg = nxt_neg;
   }
   store_ext(buckets + bin * EXT_WORDS, acc);
 }
 
 // ---- k_bucket_reduce ------------------------------------------------------------
-// One lane per (msm, window, chunk of REDUCE_CHUNK buckets):
+// One lane per (msm, window, chunk of chunk_size buckets):
 //   out = sum_{b in chunk} (b + 1) * bucket[b]
 //       = sum (b - lo + 1) * bucket[b]  +  lo * sum bucket[b]
 // via the running-sum recurrence; empty buckets are skipped.
 __global__ void __launch_bounds__(256)
 k_bucket_reduce(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ buckets,
                 uint32_t* __restrict__ partials, uint32_t* __restrict__ partial_nonempty,
-                uint64_t n_tasks, uint32_t n_buckets, uint32_t chunks_per_window) {
+                uint64_t n_tasks, uint32_t n_buckets, uint32_t chunks_per_window, uint32_t chunk_size) {
   const uint64_t task = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (task >= n_tasks) return;
   const uint64_t win = task / chunks_per_window;           // msm * n_windows + t
   const uint32_t chunk = (uint32_t)(task % chunks_per_window);
-  const uint32_t lo = chunk * REDUCE_CHUNK;
-  const uint32_t hi = min(lo + (uint32_t)REDUCE_CHUNK, n_buckets);
+  const uint32_t lo = chunk * chunk_size;
+  const uint32_t hi = min(lo + chunk_size, n_buckets);
   const uint64_t bin0 = win * n_buckets;
   ge run, sum;
   bool run_set = false, sum_set = false;

@@ -62,7 +62,7 @@ struct zkgpu_ctx {
   Buffer in_scalars, in_points, in_offsets, in_st_scalars, in_st_index, in_st_offsets;
   Buffer dyn_rows, bins, block_sums, entries, buckets, partials, partial_flags, window_sums, window_flags;
   Buffer msm_fail, status, accept, bitmap, ok_bytes, values, uniform;
-  Buffer digits, st_partials, dynsum, accept2;
+  Buffer digits, st_partials, dynsum, accept2, bin_order, class_count, part_hist, part_entries, part_lo, dec_scratch;
   Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
   int forced_parts = 0;
   void* pinned = nullptr;   // host staging for results
@@ -205,7 +205,8 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
 
   const uint64_t n_wins = (uint64_t)job.n_msm * jd.n_windows;
   const uint64_t n_bins = n_wins * jd.n_buckets;
-  const uint32_t chunks = (jd.n_buckets + REDUCE_CHUNK - 1) / REDUCE_CHUNK;
+  const uint32_t chunk_size = jd.n_buckets <= (uint32_t)REDUCE_CHUNK ? jd.n_buckets : (uint32_t)REDUCE_CHUNK_BIG;
+  const uint32_t chunks = (jd.n_buckets + chunk_size - 1) / chunk_size;
   const uint64_t n_tasks = n_wins * chunks;
   const uint64_t max_entries = n_terms * jd.n_windows;
   if (max_entries >= (1ull << 32) || n_bins >= (1ull << 32) || job.n_dyn >= (1ull << 30) ||
@@ -237,42 +238,108 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
   uint32_t* status = (uint32_t*)c->status.p;
   unsigned long long* bad_index = (unsigned long long*)((char*)c->status.p + 8);
 
-  if (job.n_dyn) {
+  if (job.n_dyn >= 131072) {
+    // many points: run the squaring chain in its own lean kernel (kernels.hpp "split decompression")
+    TRY(ensure(c, c->dec_scratch, job.n_dyn * DEC_WORDS * 4));
+    Launch l(c, "k_decompress");
+    hipLaunchKernelGGL(k_decompress_pre, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, s, job.d_dyn_points,
+                       (uint32_t*)c->dec_scratch.p, job.n_dyn);
+    hipLaunchKernelGGL(k_pow22523, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, s, (uint32_t*)c->dec_scratch.p,
+                       job.n_dyn);
+    hipLaunchKernelGGL(k_decompress_post, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, s,
+                       (const uint32_t*)c->dec_scratch.p, (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets,
+                       job.n_msm, (uint32_t*)c->msm_fail.p, bad_index);
+  } else if (job.n_dyn) {
     Launch l(c, "k_decompress");
     hipLaunchKernelGGL(k_decompress, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, s, job.d_dyn_points,
                        (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, job.n_msm,
                        (uint32_t*)c->msm_fail.p, bad_index, (uint8_t*)nullptr);
   }
-  if (n_terms) {
-    Launch l(c, "k_digits_count");
-    hipLaunchKernelGGL(k_digits_count, dim3(blocks_for(n_terms, 256)), dim3(256), 0, s, jd, (uint32_t*)c->bins.p,
-                       status);
+  const bool part_sort = job.n_msm == 1 && job.n_static == 0 && w - 1 >= PART_LO_BITS && n_terms >= 32768;
+  if (part_sort) {
+    // single large MSM: two-level sort with LDS atomics only
+    PartShape ps;
+    ps.lo_bits = PART_LO_BITS;
+    ps.hi_bits = (uint32_t)(w - 1 - PART_LO_BITS);
+    ps.n_part = (uint32_t)jd.n_windows << ps.hi_bits;
+    ps.n_tiles = (uint32_t)blocks_for(n_terms, PART_TILE);
+    const uint64_t n_cells = (uint64_t)ps.n_part * ps.n_tiles + 1;     // + grand total
+    const unsigned cell_blocks = blocks_for(n_cells, SCAN_TILE);
+    TRY(ensure(c, c->part_hist, n_cells * 4));
+    TRY(ensure(c, c->block_sums, ((size_t)cell_blocks + 1) * 4));
+    TRY(ensure(c, c->part_entries, std::max<uint64_t>(max_entries, 1) * 4));
+    TRY(ensure(c, c->part_lo, std::max<uint64_t>(max_entries, 1)));
+    HIP_TRY(c, hipMemsetAsync((uint32_t*)c->part_hist.p + (n_cells - 1), 0, 4, s));
+    {
+      Launch l(c, "k_part_hist");
+      hipLaunchKernelGGL(k_part_hist, dim3(ps.n_tiles), dim3(256), ps.n_part * 4, s, jd, ps, (uint32_t*)c->part_hist.p,
+                         status);
+    }
+    {
+      Launch l(c, "k_scan");
+      hipLaunchKernelGGL(k_scan_reduce, dim3(cell_blocks), dim3(SCAN_BLOCK), 0, s, (const uint32_t*)c->part_hist.p,
+                         n_cells, (uint32_t*)c->block_sums.p);
+      hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, s, (uint32_t*)c->block_sums.p, cell_blocks);
+      hipLaunchKernelGGL(k_scan_apply, dim3(cell_blocks), dim3(SCAN_BLOCK), 0, s, (uint32_t*)c->part_hist.p, n_cells,
+                         (const uint32_t*)c->block_sums.p);
+    }
+    {
+      Launch l(c, "k_part_scatter");
+      hipLaunchKernelGGL(k_part_scatter, dim3(ps.n_tiles), dim3(256), ps.n_part * 4, s, jd, ps,
+                         (const uint32_t*)c->part_hist.p, (uint32_t*)c->part_entries.p, (uint8_t*)c->part_lo.p);
+    }
+    {
+      Launch l(c, "k_part_sort");
+      hipLaunchKernelGGL(k_part_sort, dim3(ps.n_part), dim3(256), 0, s, ps, (const uint32_t*)c->part_hist.p,
+                         (const uint32_t*)c->part_entries.p, (const uint8_t*)c->part_lo.p, (uint32_t*)c->entries.p,
+                         (uint32_t*)c->bins.p);
+    }
+  } else {
+    if (n_terms) {
+      Launch l(c, "k_digits_count");
+      hipLaunchKernelGGL(k_digits_count, dim3(blocks_for(n_terms, 256)), dim3(256), 0, s, jd, (uint32_t*)c->bins.p,
+                         status);
+    }
+    {
+      Launch l(c, "k_scan");
+      hipLaunchKernelGGL(k_scan_reduce, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, (const uint32_t*)c->bins.p, n_bins,
+                         (uint32_t*)c->block_sums.p);
+      hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, s, (uint32_t*)c->block_sums.p, scan_blocks);
+      hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, (uint32_t*)c->bins.p, n_bins,
+                         (const uint32_t*)c->block_sums.p);
+    }
+    if (n_terms) {
+      Launch l(c, "k_digits_scatter");
+      hipLaunchKernelGGL(k_digits_scatter, dim3(blocks_for(n_terms, 256)), dim3(256), 0, s, jd, (uint32_t*)c->bins.p,
+                         (uint32_t*)c->entries.p);
+    }
   }
+  TRY(ensure(c, c->bin_order, n_bins * 4));
+  TRY(ensure(c, c->class_count, 2 * SIZE_CLASSES * 4));
+  uint32_t* class_count = (uint32_t*)c->class_count.p;
+  uint32_t* class_cursor = class_count + SIZE_CLASSES;
+  HIP_TRY(c, hipMemsetAsync(class_count, 0, SIZE_CLASSES * 4, s));
   {
-    Launch l(c, "k_scan");
-    hipLaunchKernelGGL(k_scan_reduce, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, (const uint32_t*)c->bins.p, n_bins,
-                       (uint32_t*)c->block_sums.p);
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, s, (uint32_t*)c->block_sums.p, scan_blocks);
-    hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, (uint32_t*)c->bins.p, n_bins,
-                       (const uint32_t*)c->block_sums.p);
-  }
-  if (n_terms) {
-    Launch l(c, "k_digits_scatter");
-    hipLaunchKernelGGL(k_digits_scatter, dim3(blocks_for(n_terms, 256)), dim3(256), 0, s, jd, (uint32_t*)c->bins.p,
-                       (uint32_t*)c->entries.p);
+    Launch l(c, "k_bin_order");
+    hipLaunchKernelGGL(k_bin_classes, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p, n_bins,
+                       class_count);
+    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(256), 0, s, (const uint32_t*)class_count, class_cursor);
+    hipLaunchKernelGGL(k_bin_order, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p, n_bins,
+                       class_cursor, (uint32_t*)c->bin_order.p);
   }
   {
     Launch l(c, "k_bucket_accumulate");
     hipLaunchKernelGGL(k_bucket_accumulate, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s,
                        (const uint32_t*)c->bins.p, (const uint32_t*)c->entries.p, job.d_static_rows,
-                       (const uint32_t*)c->dyn_rows.p, (uint32_t*)c->buckets.p, n_bins);
+                       (const uint32_t*)c->dyn_rows.p, (uint32_t*)c->buckets.p, n_bins,
+                       (const uint32_t*)c->bin_order.p);
   }
   uint32_t* partials = chunks == 1 ? (uint32_t*)c->window_sums.p : (uint32_t*)c->partials.p;
   uint32_t* pflags = chunks == 1 ? (uint32_t*)c->window_flags.p : (uint32_t*)c->partial_flags.p;
   {
     Launch l(c, "k_bucket_reduce");
     hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_for(n_tasks, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p,
-                       (const uint32_t*)c->buckets.p, partials, pflags, n_tasks, jd.n_buckets, chunks);
+                       (const uint32_t*)c->buckets.p, partials, pflags, n_tasks, jd.n_buckets, chunks, chunk_size);
   }
   if (chunks > 1) {
     Launch l(c, "k_window_partials");
@@ -557,7 +624,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
                     &c->in_st_offsets, &c->dyn_rows, &c->bins, &c->block_sums, &c->entries, &c->buckets,
                     &c->partials, &c->partial_flags, &c->window_sums, &c->window_flags, &c->msm_fail,
                     &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform,
-                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->prep_com, &c->prep_proofs, &c->prep_r,
+                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->prep_com, &c->prep_proofs, &c->prep_r,
                     &c->prep_pw, &c->prep_ch, &c->prep_wf, &c->prep_dyn_sc, &c->prep_dyn_pt, &c->prep_st_sc};
   for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
