@@ -287,3 +287,26 @@ def test_fixed_base_tables_equal_generic_path(ctx, oracle, w):
     sc2 = k.to_bytes(32, "little") + (L - k).to_bytes(32, "little")
     assert ctx.verify_batch_ps(ps, b"", b"", [0, 0, 0], sc2 + sc2, [0, 2, 4], static_index=[3, 3, 5, 6]) == b"\x01"
     ps.close()
+
+
+def test_msm_adversarial_bin_loads(ctx, oracle):
+    """All terms in one bucket per window (equal scalars), tiny scalars (everything in window 0) and a
+    half/half mix: the heavy-bin path must give the oracle's answer and must not take seconds."""
+    import time
+    n = 1 << 17
+    pts = points(oracle, "adv", n, distinct=331)
+    one_pt = pts[:32]
+    k = 0x1f3e5d7c9b0a1122334455667788990011223344556677889900aabbccddeeff % L
+    for name, sc in [("equal", k.to_bytes(32, "little") * n),
+                     ("tiny", b"".join((i % 7 + 1).to_bytes(32, "little") for i in range(n))),
+                     ("mix", k.to_bytes(32, "little") * (n // 2) + scalars("advmix", n // 2))]:
+        t0 = time.perf_counter()
+        got = ctx.msm(sc, pts)
+        dt = time.perf_counter() - t0
+        rc, want, _ = oracle.msm(sc, pts)
+        assert rc == 0 and got == want, name
+        assert dt < 2.0, (name, dt)
+    # 2^20 equal scalars on one point: closed form (n * k) P
+    n = 1 << 20
+    got = ctx.msm(k.to_bytes(32, "little") * n, one_pt * n)
+    assert got == ctx.msm(((n * k) % L).to_bytes(32, "little"), one_pt)

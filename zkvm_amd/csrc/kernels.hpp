@@ -502,6 +502,16 @@ k_part_sort(PartShape ps, const uint32_t* __restrict__ offs, const uint32_t* __r
   }
 }
 
+__device__ __forceinline__ void shfl_down_ge(ge& out, const ge& in, int delta) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    out.X.v[i] = __shfl_down(in.X.v[i], delta);
+    out.Y.v[i] = __shfl_down(in.Y.v[i], delta);
+    out.Z.v[i] = __shfl_down(in.Z.v[i], delta);
+    out.T.v[i] = __shfl_down(in.T.v[i], delta);
+  }
+}
+
 // ---- bin ordering ---------------------------------------------------------------
 // One lane sums one bin, so a wavefront takes as long as its fullest bin.  Bins are
 // therefore handed to lanes in order of decreasing size (256 size classes, counting
@@ -533,15 +543,28 @@ k_class_scan(const uint32_t* __restrict__ class_count, uint32_t* __restrict__ cl
   class_cursor[threadIdx.x] = ex;
 }
 
+// Bins above HEAVY_BIN entries (all terms sharing one digit: equal scalars, tiny scalars,
+// a top window with one significant bit) would pin one lane for milliseconds to seconds;
+// they are listed in heavy[1..] (heavy[0] = count) and summed by a whole workgroup each.
+constexpr uint32_t HEAVY_BIN = 2048;
+constexpr uint32_t HEAVY_MAX = 65536;
+
 __global__ void __launch_bounds__(256)
 k_bin_order(const uint32_t* __restrict__ cursor, uint64_t n_bins, uint32_t* __restrict__ class_cursor,
-            uint32_t* __restrict__ order) {
+            uint32_t* __restrict__ order, uint32_t* __restrict__ heavy) {
   __shared__ uint32_t h[SIZE_CLASSES], base[SIZE_CLASSES];
   h[threadIdx.x] = 0;
   __syncthreads();
   const uint64_t bin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t cls = 0, rank = 0;
-  if (bin < n_bins) { cls = bin_size_class(cursor, bin); rank = atomicAdd(&h[cls], 1u); }
+  if (bin < n_bins) {
+    cls = bin_size_class(cursor, bin);
+    rank = atomicAdd(&h[cls], 1u);
+    if (cls == 0 && cursor[bin] - (bin ? cursor[bin - 1] : 0u) > HEAVY_BIN) {
+      const uint32_t slot = atomicAdd(&heavy[0], 1u);
+      if (slot < HEAVY_MAX) heavy[1 + slot] = (uint32_t)bin;
+    }
+  }
   __syncthreads();
   if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&class_cursor[threadIdx.x], h[threadIdx.x]);
   __syncthreads();
@@ -560,7 +583,7 @@ k_bucket_accumulate(const uint32_t* __restrict__ cursor, const uint32_t* __restr
   if (gid >= n_bins) return;
   const uint64_t bin = order ? order[gid] : gid;
   const uint32_t start = bin ? cursor[bin - 1] : 0u, end = cursor[bin];
-  if (start == end) return;
+  if (start == end || end - start > HEAVY_BIN) return;   // heavy bins: k_bucket_heavy
   ge acc;
   ge_identity(acc);
   auto fetch = [&](uint32_t k, ge_niels& q, bool& neg) {
@@ -578,6 +601,51 @@ k_bucket_accumulate(const uint32_t* __restrict__ cursor, const uint32_t* __restr
     cur = nxt; cur_neg = nxt_neg;
   }
   store_ext(buckets + bin * EXT_WORDS, acc);
+}
+
+// One workgroup per heavy bin: 256 strided partial sums, folded by wavefront shuffles and
+// one pass through LDS.  The grid is fixed; workgroups walk the heavy list.
+__global__ void __launch_bounds__(256)
+k_bucket_heavy(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ entries,
+               const uint32_t* __restrict__ static_rows, const uint32_t* __restrict__ dyn_rows,
+               uint32_t* __restrict__ buckets, const uint32_t* __restrict__ heavy) {
+  __shared__ uint32_t wave_pts[4 * EXT_WORDS];
+  const uint32_t n_heavy = min(heavy[0], HEAVY_MAX);
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  for (uint32_t hI = blockIdx.x; hI < n_heavy; hI += gridDim.x) {
+    const uint64_t bin = heavy[1 + hI];
+    const uint32_t start = bin ? cursor[bin - 1] : 0u, end = cursor[bin];
+    ge acc;
+    ge_identity(acc);
+    for (uint32_t k = start + t; k < end; k += 256) {
+      const uint32_t e = entries[k];
+      const uint32_t* row = ((e & ENTRY_DYN) ? dyn_rows : static_rows) + (uint64_t)(e & ENTRY_IDX) * NIELS_WORDS;
+      ge_niels q;
+      load_niels(q, row);
+      ge_madd(acc, acc, q, (e & ENTRY_NEG) != 0);
+    }
+#pragma unroll 1
+    for (int delta = 32; delta >= 1; delta >>= 1) {
+      ge other;
+      shfl_down_ge(other, acc, delta);
+      if (lane < delta) ge_add(acc, acc, other);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      uint32_t* w = wave_pts + wid * EXT_WORDS;
+      for (int q = 0; q < 10; ++q) { w[q] = acc.X.v[q]; w[10 + q] = acc.Y.v[q]; w[20 + q] = acc.Z.v[q]; w[30 + q] = acc.T.v[q]; }
+    }
+    __syncthreads();
+    if (t == 0) {
+      for (int wv = 1; wv < 4; ++wv) {
+        ge o;
+        const uint32_t* w = wave_pts + wv * EXT_WORDS;
+        for (int q = 0; q < 10; ++q) { o.X.v[q] = w[q]; o.Y.v[q] = w[10 + q]; o.Z.v[q] = w[20 + q]; o.T.v[q] = w[30 + q]; }
+        ge_add(acc, acc, o);
+      }
+      store_ext(buckets + bin * EXT_WORDS, acc);
+    }
+  }
 }
 
 // ---- k_bucket_reduce ------------------------------------------------------------
@@ -628,15 +696,6 @@ k_bucket_reduce(const uint32_t* __restrict__ cursor, const uint32_t* __restrict_
 // One wave per window: fold `chunks_per_window` partials into the window sum.
 // Each lane adds its strided share, then the 64 lane sums are combined with
 // wavefront shuffles (40 dwords per point per step).
-__device__ __forceinline__ void shfl_down_ge(ge& out, const ge& in, int delta) {
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    out.X.v[i] = __shfl_down(in.X.v[i], delta);
-    out.Y.v[i] = __shfl_down(in.Y.v[i], delta);
-    out.Z.v[i] = __shfl_down(in.Z.v[i], delta);
-    out.T.v[i] = __shfl_down(in.T.v[i], delta);
-  }
-}
 
 __global__ void __launch_bounds__(64)
 k_window_partials(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ partial_nonempty,

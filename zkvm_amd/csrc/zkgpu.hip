@@ -62,7 +62,7 @@ struct zkgpu_ctx {
   Buffer in_scalars, in_points, in_offsets, in_st_scalars, in_st_index, in_st_offsets;
   Buffer dyn_rows, bins, block_sums, entries, buckets, partials, partial_flags, window_sums, window_flags;
   Buffer msm_fail, status, accept, bitmap, ok_bytes, values, uniform;
-  Buffer digits, st_partials, dynsum, accept2, bin_order, class_count, part_hist, part_entries, part_lo, dec_scratch;
+  Buffer digits, st_partials, dynsum, accept2, bin_order, class_count, part_hist, part_entries, part_lo, dec_scratch, heavy;
   Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
   int forced_parts = 0;
   void* pinned = nullptr;   // host staging for results
@@ -319,13 +319,15 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
   uint32_t* class_count = (uint32_t*)c->class_count.p;
   uint32_t* class_cursor = class_count + SIZE_CLASSES;
   HIP_TRY(c, hipMemsetAsync(class_count, 0, SIZE_CLASSES * 4, s));
+  TRY(ensure(c, c->heavy, (HEAVY_MAX + 1) * 4));
+  HIP_TRY(c, hipMemsetAsync(c->heavy.p, 0, 4, s));
   {
     Launch l(c, "k_bin_order");
     hipLaunchKernelGGL(k_bin_classes, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p, n_bins,
                        class_count);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(256), 0, s, (const uint32_t*)class_count, class_cursor);
     hipLaunchKernelGGL(k_bin_order, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p, n_bins,
-                       class_cursor, (uint32_t*)c->bin_order.p);
+                       class_cursor, (uint32_t*)c->bin_order.p, (uint32_t*)c->heavy.p);
   }
   {
     Launch l(c, "k_bucket_accumulate");
@@ -333,6 +335,12 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
                        (const uint32_t*)c->bins.p, (const uint32_t*)c->entries.p, job.d_static_rows,
                        (const uint32_t*)c->dyn_rows.p, (uint32_t*)c->buckets.p, n_bins,
                        (const uint32_t*)c->bin_order.p);
+  }
+  {
+    Launch l(c, "k_bucket_heavy");
+    hipLaunchKernelGGL(k_bucket_heavy, dim3(512), dim3(256), 0, s, (const uint32_t*)c->bins.p,
+                       (const uint32_t*)c->entries.p, job.d_static_rows, (const uint32_t*)c->dyn_rows.p,
+                       (uint32_t*)c->buckets.p, (const uint32_t*)c->heavy.p);
   }
   uint32_t* partials = chunks == 1 ? (uint32_t*)c->window_sums.p : (uint32_t*)c->partials.p;
   uint32_t* pflags = chunks == 1 ? (uint32_t*)c->window_flags.p : (uint32_t*)c->partial_flags.p;
@@ -624,7 +632,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
                     &c->in_st_offsets, &c->dyn_rows, &c->bins, &c->block_sums, &c->entries, &c->buckets,
                     &c->partials, &c->partial_flags, &c->window_sums, &c->window_flags, &c->msm_fail,
                     &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform,
-                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->prep_com, &c->prep_proofs, &c->prep_r,
+                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->prep_com, &c->prep_proofs, &c->prep_r,
                     &c->prep_pw, &c->prep_ch, &c->prep_wf, &c->prep_dyn_sc, &c->prep_dyn_pt, &c->prep_st_sc};
   for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
