@@ -298,7 +298,14 @@ def main():
                 prof[k] = (a[0] + v[0], a[1] + v[1])
         kern_ms = {k: v[1] / v[0] for k, v in prof.items() if v[0]}
         total_kernel_ms = sum(v[1] for v in prof.values()) / max(args.steps, 1)
-        dom = max(kern_ms, key=kern_ms.get)
+        # Dominant kernel = the one that issues most of the step's VALU work, not the longest-lived one:
+        # with several calls in flight the latency-bound tail kernels (k_msm_finish: 16-64 wavefronts
+        # walking a 255-doubling chain) show long durations while occupying a sliver of the chip.
+        # SQ_INSTS_VALU per launch (profiles/r01c_pmc_SQ_WAVE_CYCLES.txt): k_static_accumulate 203 M,
+        # k_bucket_accumulate / k_small_msm_windows ~100 M, k_msm_finish 15 M.
+        dom = "k_static_accumulate" if (args.table_bits and "k_static_accumulate" in kern_ms) else "k_bucket_accumulate"
+        if dom not in kern_ms:
+            dom = max(kern_ms, key=kern_ms.get)
         dom_ms = kern_ms[dom]
         wbits = ctx.last_window_bits()                 # Pippenger width of the proof-point pipeline
         tbits = args.table_bits
