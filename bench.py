@@ -1,19 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- batch verification throughput of ZkVM cloak transactions on MI355X.
 
-One "step" = one pass of the hot path (zkgpu_verify_batch_ps_dev: decompress the proof
-points, multiscalar multiplication per transaction, ristretto identity test, accept bitmap)
-over one batch whose inputs are already resident in HBM.  Workload = BASELINE.json
-configs[1]: 1024 2-in/2-out cloak transactions per GPU.  The proofs are REAL Bulletproofs
-R1CS proofs of the cloak statement (tests/golden/cloak_2x2_proofs.bin: 64 proofs from the
-oracle prover, committed as data); transaction i verifies proof i mod 64 under its own
-verifier randomness r_i, so all 1024 verification equations differ.  The host half of
-`r1cs::Verifier::verify` (Merlin replay, constraint flattening, IPA scalars -- product code,
-zkgpu_cloak_prepare_batch) runs once, outside the timed region; its output is the
-argument list of the reference's `mega_check` multiscalar multiplication: per transaction
-549 terms = 35 proof-specific points + 514 shared generators (n = 256, k = 8, m = 8).
-~1.5 % of the transactions are corrupted (undecodable commitment, wrong IPA scalar, someone
-else's proof) so the accept bitmap is not trivial.
+One "step" = one complete `r1cs::Verifier::verify` of every transaction of one batch, on the
+device, from inputs resident in HBM (zkgpu_cloak_verify_batch_gpu_dev): Merlin transcript
+replay, verification scalars (inner-product-argument s vector, constraint flattening, g_i /
+h_i), decompression of the proof points, the 549-term multiscalar multiplication per
+transaction and the ristretto identity test -> accept bitmap (copied to the host).
+Workload = BASELINE.json configs[1]: 1024 2-in/2-out cloak transactions per GPU.  The proofs
+are REAL Bulletproofs R1CS proofs of the cloak statement (tests/golden/cloak_2x2_proofs.bin:
+64 proofs from the oracle prover, committed as data); transaction i verifies proof
+i mod 64 under its own verifier randomness r_i, so all 1024 verification equations differ
+(n = 256 multipliers, k = 8, m = 8 commitments: 35 proof-specific points + 514 shared
+generators per transaction).  ~1.5 % of the transactions are corrupted (undecodable
+commitment, wrong IPA scalar, someone else's proof) so the accept bitmap is not trivial.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -22,9 +21,10 @@ collective is the RCCL all-gather of the per-shard accept bitmaps.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel vs the HBM
 roofline the north-star names, plus the integer-ALU figure that actually binds),
-"cpu_baseline" (the CPU oracle -- a port of the reference's algorithm; the reference itself
-is not mounted -- on this box's host cores, same MSM boundary), "end_to_end" (proof bytes ->
-accept bits including the host half), "msm_2p20" (BASELINE configs[2] microbench).
+"cpu_baseline" (the CPU oracle's full verifier -- a port of the reference's algorithm; the
+reference itself is not mounted -- on this box's host cores), "msm_boundary" (the
+multiscalar-multiplication tail alone), "host_memory" (the same calls fed from host memory),
+"msm_2p20" (BASELINE configs[2] microbench).
 """
 from __future__ import annotations
 
@@ -119,49 +119,38 @@ def usable_cores(omp_threads: int) -> int:
 
 
 def cpu_baseline(ctx, w, gpu_bitmap: bytes, batch: int):
-    """Time the CPU oracle (kind "port": same radix-2^51 field, same Straus/Pippenger split as the
-    reference's dalek back end; the Rust reference itself is not mounted) on the SAME multiscalar
-    multiplications the GPU step evaluates, and compare accept bits."""
+    """Time the CPU oracle's full verifier (kind "port": transcript replay + scalars + MSM with the same
+    radix-2^51 field and Straus/Pippenger split as the reference's dalek back end; the Rust reference
+    itself is not mounted) on the same proof bytes, and compare every accept bit with the GPU's."""
     from oracle import binding as oracle
     cores = usable_cores(oracle.max_threads())
-    b, bb = ctx.pedersen_gens()
-    g, h = ctx.bulletproof_gens(N_MULT)
-    static_points = b + bb + g + h
-    sp = [static_points[32 * j: 32 * j + 32] for j in range(len(static_points) // 32)]
-    sc, pt, offs = [], [], [0]
-    for i in range(batch):
-        d0, d1 = w["dyn_off"][i], w["dyn_off"][i + 1]
-        s0, s1 = w["st_off"][i], w["st_off"][i + 1]
-        sc.append(w["dyn_sc"][32 * d0: 32 * d1] + w["st_sc"][32 * s0: 32 * s1])
-        pt.append(w["dyn_pt"][32 * d0: 32 * d1] + b"".join(sp[j] for j in w["st_idx"][s0:s1]))
-        offs.append(offs[-1] + (d1 - d0) + (s1 - s0))
-    one = 24
+    tx0 = w["txs"][0]
+    plen = len(tx0.proof)
+    com = b"".join(t.commitments for t in w["txs"])
+    proofs = b"".join(t.proof for t in w["txs"])
+    wcom = 64 * (tx0.n_in + tx0.n_out)
+    one = 32
     t0 = time.perf_counter()
-    bm1 = oracle.verify_batch(b"".join(sc[:one]), b"".join(pt[:one]), offs[: one + 1], threads=1)
+    acc1 = oracle.cloak_verify_batch(com[: wcom * one], tx0.n_in, tx0.n_out, proofs[: plen * one], plen,
+                                     w["r_bytes"][: 64 * one], threads=1)
     t1 = time.perf_counter() - t0
-    scb, ptb = b"".join(sc), b"".join(pt)
     reps = 0
     t0 = time.perf_counter()
     while True:
-        bm = oracle.verify_batch(scb, ptb, offs, threads=cores)
+        acc = oracle.cloak_verify_batch(com, tx0.n_in, tx0.n_out, proofs, plen, w["r_bytes"], threads=cores)
         reps += 1
-        if time.perf_counter() - t0 > 6.0 or reps >= 50:
+        if time.perf_counter() - t0 > 8.0 or reps >= 50:
             break
     tall = time.perf_counter() - t0
-    assert bm == gpu_bitmap, "GPU accept bitmap differs from the CPU oracle"
-    assert all(((bm1[i // 8] >> (i % 8)) & 1) == ((gpu_bitmap[i // 8] >> (i % 8)) & 1) for i in range(one))
-    # the oracle's own full verifier (transcript replay + MSM) on a few proofs: same verdicts
-    t0 = time.perf_counter()
-    full = [int(oracle.cloak_verify(t.commitments, t.n_in, t.n_out, t.proof, w["r_bytes"][64 * i: 64 * i + 64]))
-            for i, t in enumerate(w["txs"][:16])]
-    tfull = time.perf_counter() - t0
-    assert full == [(gpu_bitmap[i // 8] >> (i % 8)) & 1 for i in range(16)]
+    gpu_bits = [(gpu_bitmap[i // 8] >> (i % 8)) & 1 for i in range(batch)]
+    assert list(acc) == gpu_bits, "GPU accept bitmap differs from the CPU oracle"
+    assert list(acc1) == gpu_bits[:one]
     return {"value": round(batch * reps / tall, 1), "unit": "tx/s", "cores": cores, "kind": "port",
-            "value_1core": round(one / t1, 2), "full_verify_1core": round(16 / tfull, 2),
-            "sample": "%d x the full %d-tx batch (the same MSMs the GPU step evaluates) on %d OpenMP threads = this "
-                      "box's cgroup CPU quota (%.1f s); 1-core figure on %d tx (%.1f s); full_verify_1core = oracle "
-                      "Verifier (transcript + MSM) on 16 proofs; accept bits compared with the GPU's"
-                      % (reps, batch, cores, tall, one, t1)}
+            "value_1core": round(one / t1, 2),
+            "sample": "%d x the full %d-tx batch (oracle Verifier: transcript replay + scalars + 549-term MSM per tx, "
+                      "same proof bytes and verifier randomness as the GPU step) on %d OpenMP threads = this box's "
+                      "cgroup CPU quota (%.1f s); 1-core figure on %d tx (%.1f s); all %d accept bits compared "
+                      "with the GPU's" % (reps, batch, cores, tall, one, t1, batch)}
 
 
 def msm_microbench(ctx, torch, dev):
@@ -252,12 +241,29 @@ def main():
     ctxs = [ctx] + [Context(local) for _ in range(max(1, args.inflight) - 1)]
     lanes = [ThreadPoolExecutor(max_workers=1) for _ in ctxs]
 
+    # THE STEP: the complete r1cs::Verifier::verify of every transaction of the batch, on the device,
+    # from commitments + proof bytes + verifier randomness resident in HBM: Merlin transcript replay
+    # (k_transcript), verification scalars incl. the inner-product-argument s vector (k_prepare), point
+    # decompression, the multiscalar multiplications and the identity test -> accept bitmap.
+    from zkvm_amd.verifier import Verifier
+    tx0 = w["txs"][0]
+    proof_len = len(tx0.proof)
+    d_com = to_dev(b"".join(t.commitments for t in w["txs"]))
+    d_proofs = to_dev(b"".join(t.proof for t in w["txs"]))
+    d_r = to_dev(w["r_bytes"])
+    gvs = {id(c): Verifier(c, w["gens"]) for c in ctxs}
+    torch.cuda.synchronize()
+
     def verify_on(c):
+        return gvs[id(c)].verify_packed_gpu_dev(tx0.n_in, tx0.n_out, batch, d_com, d_proofs, proof_len, d_r)
+
+    def msm_only_on(c):   # the MSM boundary alone: scalars prepared beforehand (by the host verifier)
         return c.verify_batch_ps_dev(ps, batch, d_dyn_sc, d_dyn_pt, d_dyn_off, batch * N_DYN,
                                      d_st_sc, d_st_idx, d_st_off, batch * N_STATIC)
 
-    def run_steps(n):
-        futs = [lanes[i % len(ctxs)].submit(verify_on, ctxs[i % len(ctxs)]) for i in range(n)]
+    def run_steps(n, fn=None):
+        fn = fn or verify_on
+        futs = [lanes[i % len(ctxs)].submit(fn, ctxs[i % len(ctxs)]) for i in range(n)]
         bm = None
         for f in futs:
             bm = f.result()
@@ -342,32 +348,21 @@ def main():
         bm_e2e = v.verify_bitmap(w["txs"], w["r_bytes"])
         e2e_s = time.perf_counter() - t0
         assert bm_e2e == bm
-        # proof bytes -> accept bits with the host half on the GPU too (plan replay); `inflight`
-        # verifiers (one context each) so consecutive batches overlap, PCIe copies included
-        from zkvm_amd.verifier import Verifier
-        gvs = [Verifier(c, w["gens"]) for c in ctxs]
-        for gv in gvs:
-            assert gv.verify_bitmap_gpu(w["txs"], w["r_bytes"]) == bm     # warm-up + parity
-            gv.ctx.profile_reset()
-            gv.ctx.profile(True)
-        n_e2e = 8 * len(gvs)
-        t0tx = w["txs"][0]
+        # the same call with its inputs in HOST memory (PCIe copies + python marshalling included)
         packed_com = b"".join(t.commitments for t in w["txs"])
         packed_proofs = b"".join(t.proof for t in w["txs"])
+        n_e2e = 6 * len(ctxs)
         t0 = time.perf_counter()
-        futs = [lanes[i % len(gvs)].submit(gvs[i % len(gvs)].verify_packed_gpu, t0tx.n_in, t0tx.n_out, batch, packed_com,
-                                           packed_proofs, len(t0tx.proof), w["r_bytes"]) for i in range(n_e2e)]
+        futs = [lanes[i % len(ctxs)].submit(gvs[id(ctxs[i % len(ctxs)])].verify_packed_gpu, tx0.n_in, tx0.n_out, batch,
+                                            packed_com, packed_proofs, proof_len, w["r_bytes"]) for i in range(n_e2e)]
         outs = [f.result() for f in futs]
         e2e_gpu_s = (time.perf_counter() - t0) / n_e2e
         assert all(o == bm for o in outs)
-        prep_prof = {}
-        for gv in gvs:
-            gv.ctx.profile(False)
-            for k, x in gv.ctx.profile_read().items():
-                a = prep_prof.get(k, (0, 0.0))
-                prep_prof[k] = (a[0] + x[0], a[1] + x[1])
-            gv.close()
-        prep_ms = {k: round(x[1] / x[0], 4) for k, x in prep_prof.items() if x[0] and k in ("k_proof_unpack", "k_transcript", "k_prepare")}
+        # the multiscalar-multiplication boundary alone (scalars prepared beforehand by the host verifier)
+        assert run_steps(len(ctxs), msm_only_on) == bm
+        t0 = time.perf_counter()
+        run_steps(args.steps, msm_only_on)
+        msm_only_s = (time.perf_counter() - t0) / args.steps
         line = {
             "metric": "ZkVM tx verifications/sec (batch)",
             "value": round(batch * world * args.steps / elapsed, 1),
@@ -382,9 +377,11 @@ def main():
             "dtype": "u32 limb pairs of radix-2^51 (v_mad_u64_u32)",
             "data": "synthetic: 64 real R1CS proofs of the 2-in/2-out cloak statement (committed fixture), "
                     "each verified under per-transaction verifier randomness; ~1.5% corrupted",
-            "config": {"workload": "batch of %d 2-in/2-out cloak tx per GPU: the mega_check multiscalar multiplication "
-                                   "of r1cs::Verifier::verify (n=256, k=8, m=8: 549 terms, 514 on shared generators) "
-                                   "+ identity test, inputs resident in HBM" % batch,
+            "config": {"workload": "batch of %d 2-in/2-out cloak tx per GPU, complete r1cs::Verifier::verify on the device "
+                                   "from commitments + R1CSProof bytes + verifier randomness resident in HBM: Merlin "
+                                   "replay, verification scalars (IPA s vector, constraint flattening), decompression, "
+                                   "the 549-term mega_check MSM (n=256, k=8, m=8; 514 terms on shared generators), "
+                                   "identity test -> accept bitmap" % batch,
                        "tx_per_gpu": batch, "terms_per_tx": N_DYN + N_STATIC, "window_bits": wbits,
                        "generator_table_bits": tbits, "calls_in_flight": len(ctxs),
                        "parallelism": "tx-sharded x%d, RCCL all-gather of accept bitmaps" % world},
@@ -404,17 +401,16 @@ def main():
             "kernel_ms_per_step": {k: round(x, 4) for k, x in sorted(kern_ms.items())},
             "kernel_ms_solo": {k: round(x, 4) for k, x in sorted(solo.items())},
             "kernel_ms_total_per_step": round(total_kernel_ms, 4),
-            "end_to_end": {"gpu_resident_tx_per_s": round(batch / e2e_gpu_s, 1),
-                           "gpu_resident_ms_per_batch": round(e2e_gpu_s * 1e3, 3),
-                           "gpu_prepare_kernel_ms": prep_ms,
-                           "host_prepared_tx_per_s": round(batch / e2e_s, 1), "host_threads": host_threads,
-                           "host_prepare_ms_per_batch": round(w["prepare_s"] * 1e3, 2),
-                           "note": "proof bytes in host memory -> accept bits, PCIe copies included (python-side "
-                                   "marshalling of the byte strings too).  gpu_resident: zkgpu_cloak_verify_batch_gpu, "
-                                   "transcript replay + scalar preparation + MSMs all on the device, %d calls in "
-                                   "flight.  host_prepared: zkgpu_cloak_verify_batch, the same preparation on %d host "
-                                   "threads (host-bound).  Neither is the reported `value` (inputs resident in HBM)."
-                                   % (len(ctxs), host_threads)},
+            "msm_boundary": {"tx_per_s": round(batch / msm_only_s, 1), "ms_per_step": round(msm_only_s * 1e3, 4),
+                             "note": "zkgpu_verify_batch_ps_dev alone: decompress + MSM + identity test on scalars "
+                                     "prepared beforehand (the argument list of dalek's mega_check resident in HBM)"},
+            "host_memory": {"gpu_resident_tx_per_s": round(batch / e2e_gpu_s, 1),
+                            "host_prepared_tx_per_s": round(batch / e2e_s, 1), "host_threads": host_threads,
+                            "host_prepare_ms_per_batch": round(w["prepare_s"] * 1e3, 2),
+                            "note": "proof bytes in host memory -> accept bits, PCIe copies and python marshalling "
+                                    "included.  gpu_resident: zkgpu_cloak_verify_batch_gpu (everything after the copy on "
+                                    "the device).  host_prepared: zkgpu_cloak_verify_batch (transcript replay and scalar "
+                                    "preparation on %d host threads, host-bound).  Neither is `value`." % host_threads},
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(ctx, w, bm, batch)
@@ -426,6 +422,8 @@ def main():
         dist.destroy_process_group()
     for ex in lanes:
         ex.shutdown()
+    for gv in gvs.values():
+        gv.close()
     for c in ctxs[1:]:
         c.close()
     w["gens"].close()

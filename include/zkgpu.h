@@ -146,6 +146,12 @@ int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx *ctx, const zkgpu_pointset *ps, zkgpu
                                  const uint8_t *commitments, const uint8_t *proofs, size_t proof_len,
                                  const uint8_t *r_bytes, uint8_t *accept_bitmap);
 
+/* The same with commitments, proofs and verifier randomness already resident in HBM
+ * (device pointers; this is what bench.py times as one step). */
+int zkgpu_cloak_verify_batch_gpu_dev(zkgpu_ctx *ctx, const zkgpu_pointset *ps, zkgpu_cloak_plan *plan, size_t batch,
+                                     const void *d_commitments, const void *d_proofs, size_t proof_len,
+                                     const void *d_r, uint8_t *accept_bitmap);
+
 /* The host half of zkgpu_cloak_verify_batch alone: proof bytes -> the CSR of multiscalar
  * multiplication terms that zkgpu_verify_batch_ps* consumes (no device involved).
  * Statement i needs 11 + 2 (n_in+n_out) + 2k dynamic and 2 + 2 * 2^k static terms (k = lg of

@@ -312,3 +312,13 @@ def cloak_verify_prepare(commitments: bytes, n_in: int, n_out: int, proof: bytes
            C.string_at(m.static_scalars, 32 * m.n_static), int(m.padded_n))
     lib.r1cs_msm_free(C.byref(m))
     return out
+
+
+def cloak_verify_batch(commitments: bytes, n_in: int, n_out: int, proofs: bytes, proof_len: int, r_bytes: bytes,
+                       threads: int = 1) -> bytes:
+    """Full CPU verification (transcript replay + MSM) of count = len(proofs) / proof_len proofs; -> accept bytes"""
+    count = len(proofs) // proof_len
+    acc = C.create_string_buffer(max(count, 1))
+    load().zko_cloak_verify_batch(C.c_size_t(count), C.c_size_t(n_in), C.c_size_t(n_out), commitments, proofs,
+                                  C.c_size_t(proof_len), C.c_size_t(proof_len), r_bytes, acc, C.c_int(threads))
+    return acc.raw[:count]

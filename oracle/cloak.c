@@ -368,3 +368,18 @@ int zko_cloak_prove_batch(size_t count, size_t n_in, size_t n_out, const uint8_t
   if (proof_len) *proof_len = plen;
   return failed ? -1 : 0;
 }
+
+/* verify `count` proofs of one shape (OpenMP over proofs): accept[i] = 1 / 0 */
+int zko_cloak_verify_batch(size_t count, size_t n_in, size_t n_out, const uint8_t *commitments, const uint8_t *proofs,
+                           size_t proof_stride, size_t proof_len, const uint8_t *r_bytes, uint8_t *accept,
+                           int threads) {
+  size_t w = 64 * (n_in + n_out);
+  (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 1 ? threads : 1)
+#endif
+  for (long long i = 0; i < (long long)count; ++i)
+    accept[i] = (uint8_t)zko_cloak_verify(commitments + w * (size_t)i, n_in, n_out, proofs + proof_stride * (size_t)i,
+                                           proof_len, r_bytes + 64 * (size_t)i);
+  return 0;
+}

@@ -65,6 +65,9 @@ int zko_cloak_verify(const uint8_t *commitments, size_t n_in, size_t n_out, cons
                      const uint8_t r_bytes[64]);
 int zko_cloak_verify_prepare(const uint8_t *commitments, size_t n_in, size_t n_out, const uint8_t *proof,
                              size_t proof_len, const uint8_t r_bytes[64], r1cs_msm *out);
+int zko_cloak_verify_batch(size_t count, size_t n_in, size_t n_out, const uint8_t *commitments, const uint8_t *proofs,
+                           size_t proof_stride, size_t proof_len, const uint8_t *r_bytes, uint8_t *accept,
+                           int threads);
 /* batch helper: many proofs of the same shape, OpenMP over proofs */
 int zko_cloak_prove_batch(size_t count, size_t n_in, size_t n_out, const uint8_t seed[32], uint8_t *commitments,
                           uint8_t *proofs, size_t proof_stride, size_t *proof_len, int threads);

@@ -1052,6 +1052,13 @@ int zkgpu_cloak_plan_info(const zkgpu_cloak_plan* p, uint32_t* multipliers, uint
 // Proof bytes in, accept bits out, everything after the PCIe copy on the device: transcript
 // replay (one lane per transaction), scalar preparation (one workgroup per transaction),
 // then the multiscalar multiplications.  All `batch` statements have the plan's shape.
+namespace {
+// shared body: d_com / d_proofs / d_r are device pointers
+int cloak_verify_gpu_body(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
+                          const uint32_t* d_com, const uint8_t* d_proofs, const uint32_t* d_r, size_t proof_len,
+                          uint8_t* accept_bitmap);
+}  // namespace
+
 int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
                                  const uint8_t* commitments, const uint8_t* proofs, size_t proof_len,
                                  const uint8_t* r_bytes, uint8_t* accept_bitmap) {
@@ -1059,12 +1066,10 @@ int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_c
   memset(accept_bitmap, 0, (batch + 7) / 8);
   if (batch == 0) return ZKGPU_OK;
   if (!commitments || !proofs || batch >= (1ull << 24)) return ZKGPU_EINVAL;
-  if (ps->n < 2 + 2 * plan->gens_capacity) return ZKGPU_EINVAL;
   const PrepShape& sh = plan->shape;
   if (proof_len != 1 + 4ull * sh.proof_words) return ZKGPU_OK;   // wrong length for this statement: every proof is Err
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   DeviceGuard g(c->device);
-  hipStream_t s = c->stream;
   std::vector<uint8_t> rnd;
   if (!r_bytes) {
     rnd.resize(64 * batch);
@@ -1072,10 +1077,37 @@ int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_c
     for (size_t i = 0; i < rnd.size(); i += 4) { uint32_t v = rd(); memcpy(&rnd[i], &v, 4); }
     r_bytes = rnd.data();
   }
+  TRY(upload(c, c->prep_com, commitments, batch * sh.m * 32));
+  TRY(upload(c, c->prep_proofs, proofs, batch * proof_len));
+  TRY(upload(c, c->prep_r, r_bytes, batch * 64));
+  return cloak_verify_gpu_body(c, ps, plan, batch, (const uint32_t*)c->prep_com.p, (const uint8_t*)c->prep_proofs.p,
+                               (const uint32_t*)c->prep_r.p, proof_len, accept_bitmap);
+}
+
+// Inputs already resident in HBM (what bench.py times): d_commitments = batch x 64 (n_in + n_out)
+// bytes, d_proofs = batch x proof_len bytes, d_r = batch x 64 bytes of verifier randomness.
+int zkgpu_cloak_verify_batch_gpu_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
+                                     const void* d_commitments, const void* d_proofs, size_t proof_len,
+                                     const void* d_r, uint8_t* accept_bitmap) {
+  if (!c || !ps || !plan || plan->ctx != c || ps->ctx->device != c->device || !accept_bitmap) return ZKGPU_EINVAL;
+  memset(accept_bitmap, 0, (batch + 7) / 8);
+  if (batch == 0) return ZKGPU_OK;
+  if (!d_commitments || !d_proofs || !d_r || batch >= (1ull << 24)) return ZKGPU_EINVAL;
+  if (proof_len != 1 + 4ull * plan->shape.proof_words) return ZKGPU_OK;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  return cloak_verify_gpu_body(c, ps, plan, batch, (const uint32_t*)d_commitments, (const uint8_t*)d_proofs,
+                               (const uint32_t*)d_r, proof_len, accept_bitmap);
+}
+
+namespace {
+int cloak_verify_gpu_body(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
+                          const uint32_t* d_com, const uint8_t* d_proofs, const uint32_t* d_r, size_t proof_len,
+                          uint8_t* accept_bitmap) {
+  if (ps->n < 2 + 2 * plan->gens_capacity) return ZKGPU_EINVAL;
+  const PrepShape& sh = plan->shape;
+  hipStream_t s = c->stream;
   const uint32_t B = (uint32_t)batch;
-  TRY(upload(c, c->prep_com, commitments, (size_t)B * sh.m * 32));
-  TRY(upload(c, c->prep_proofs, proofs, (size_t)B * proof_len));
-  TRY(upload(c, c->prep_r, r_bytes, (size_t)B * 64));
   TRY(ensure(c, c->prep_pw, (size_t)B * sh.proof_words * 4));
   TRY(ensure(c, c->prep_ch, (size_t)B * sh.n_ch * 32));
   TRY(ensure(c, c->prep_wf, (size_t)B * 4));
@@ -1102,21 +1134,21 @@ int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_c
   {
     Launch l(c, "k_proof_unpack");
     hipLaunchKernelGGL(k_proof_unpack, dim3(blocks_for((uint64_t)B * sh.proof_words, 256)), dim3(256), 0, s,
-                       (const uint8_t*)c->prep_proofs.p, (uint64_t)proof_len, (uint32_t*)c->prep_pw.p, sh.proof_words, B,
+                       d_proofs, (uint64_t)proof_len, (uint32_t*)c->prep_pw.p, sh.proof_words, B,
                        (uint32_t*)c->prep_wf.p);
   }
   {
     Launch l(c, "k_transcript");
     hipLaunchKernelGGL(k_transcript, dim3(blocks_for(B, 64)), dim3(64), 0, s, sh, (const uint32_t*)plan->d_init,
-                       (const uint8_t*)plan->d_chal_label, (const uint32_t*)c->prep_com.p, (const uint32_t*)c->prep_pw.p,
-                       (const uint32_t*)c->prep_r.p, B, (uint32_t*)c->prep_ch.p, (uint32_t*)c->prep_wf.p);
+                       (const uint8_t*)plan->d_chal_label, d_com, (const uint32_t*)c->prep_pw.p,
+                       d_r, B, (uint32_t*)c->prep_ch.p, (uint32_t*)c->prep_wf.p);
   }
   {
     Launch l(c, "k_prepare");
     hipLaunchKernelGGL(k_prepare, dim3(B), dim3(256), plan->lds_bytes, s, sh, (const uint32_t*)plan->d_mono_chal,
                        (const uint32_t*)plan->d_mono_pow, (const uint32_t*)plan->d_tgt_off, (const uint32_t*)plan->d_term_q,
                        (const uint32_t*)plan->d_term_mono, (const uint32_t*)plan->d_term_coef, (const uint32_t*)c->prep_ch.p,
-                       (const uint32_t*)c->prep_com.p, (const uint32_t*)c->prep_pw.p, (uint32_t*)c->prep_dyn_sc.p,
+                       d_com, (const uint32_t*)c->prep_pw.p, (uint32_t*)c->prep_dyn_sc.p,
                        (uint32_t*)c->prep_dyn_pt.p, (uint32_t*)c->prep_st_sc.p);
   }
   HIP_TRY(c, hipGetLastError());
@@ -1140,6 +1172,7 @@ int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_c
     if (!wf[i]) accept_bitmap[i / 8] &= (uint8_t)~(1u << (i % 8));
   return ZKGPU_OK;
 }
+}  // namespace
 
 int zkgpu_cloak_verify_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_capacity, size_t batch,
                              const uint32_t* n_in, const uint32_t* n_out, const uint8_t* commitments,

@@ -76,6 +76,7 @@ def load_library():
     lib.zkgpu_cloak_plan_destroy.restype = None
     lib.zkgpu_cloak_plan_info.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 5
     lib.zkgpu_cloak_verify_batch_gpu.argtypes = [vp, vp, vp, sz, u8p, u8p, sz, u8p, u8p]
+    lib.zkgpu_cloak_verify_batch_gpu_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, u8p]
     lib.zkgpu_cloak_prepare_batch.argtypes = [sz, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p, u8p,
                                               C.POINTER(C.c_uint64), u8p, C.c_int, u8p, u8p, C.POINTER(C.c_uint64), sz,
                                               u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), sz, u8p]

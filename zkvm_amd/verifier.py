@@ -129,6 +129,17 @@ class Verifier:
         self.ctx._check(rc)
         return bm.raw[: (batch + 7) // 8]
 
+    def verify_packed_gpu_dev(self, n_in: int, n_out: int, batch: int, d_commitments, d_proofs, proof_len: int,
+                              d_r) -> bytes:
+        """zkgpu_cloak_verify_batch_gpu_dev: inputs are device buffers (torch tensors or raw pointers)."""
+        from .native import _ptr
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        rc = self.ctx.lib.zkgpu_cloak_verify_batch_gpu_dev(self.ctx.h, self.bp_gens.points.h, self._plan(n_in, n_out),
+                                                           batch, _ptr(d_commitments), _ptr(d_proofs), proof_len,
+                                                           _ptr(d_r), bm)
+        self.ctx._check(rc)
+        return bm.raw[: (batch + 7) // 8]
+
     def close(self) -> None:
         for h in self.__dict__.get("_plans", {}).values():
             self.ctx.lib.zkgpu_cloak_plan_destroy(h)
