@@ -233,12 +233,13 @@ def main():
     d_all = torch.zeros(nbytes * world, dtype=torch.uint8, device=dev) if world > 1 else None
     torch.cuda.synchronize()
 
-    # `--inflight M`: M contexts (own streams + workspaces, shared generator tables), one host thread
-    # each; consecutive steps go to alternating contexts so the latency-bound tail of one batch (the
-    # ~255-doubling Horner chain of its proof points) overlaps the chip-filling kernels of the next.
-    # Every step is still one complete, independent verify call; K steps are timed as a whole.
+    # `--inflight M`: M batches in flight.  Each has its own forked context (workspace + a light stream
+    # for its latency-bound kernels: the Merlin replay, the 255-doubling Horner tail); the chip-filling
+    # kernels of all of them go first-in first-out through the parent's two streams (zkgpu_ctx_fork).
+    # One host thread submits step i + M only after collecting step i.  Every step is still one
+    # complete, independent verification of the whole batch; K steps are timed as a whole.
     from concurrent.futures import ThreadPoolExecutor
-    ctxs = [ctx] + [Context(local) for _ in range(max(1, args.inflight) - 1)]
+    ctxs = [ctx] + [ctx.fork() for _ in range(max(1, args.inflight) - 1)]
     lanes = [ThreadPoolExecutor(max_workers=1) for _ in ctxs]
 
     # THE STEP: the complete r1cs::Verifier::verify of every transaction of the batch, on the device,
@@ -251,25 +252,34 @@ def main():
     d_com = to_dev(b"".join(t.commitments for t in w["txs"]))
     d_proofs = to_dev(b"".join(t.proof for t in w["txs"]))
     d_r = to_dev(w["r_bytes"])
-    gvs = {id(c): Verifier(c, w["gens"]) for c in ctxs}
+    gv = Verifier(ctx, w["gens"])
     torch.cuda.synchronize()
 
-    def verify_on(c):
-        return gvs[id(c)].verify_packed_gpu_dev(tx0.n_in, tx0.n_out, batch, d_com, d_proofs, proof_len, d_r)
+    def submit_verify(c):
+        gv.submit_packed_gpu_dev(tx0.n_in, tx0.n_out, batch, d_com, d_proofs, proof_len, d_r, ctx=c)
 
-    def msm_only_on(c):   # the MSM boundary alone: scalars prepared beforehand (by the host verifier)
-        return c.verify_batch_ps_dev(ps, batch, d_dyn_sc, d_dyn_pt, d_dyn_off, batch * N_DYN,
+    def submit_msm_only(c):   # the MSM boundary alone: scalars prepared beforehand (by the host verifier)
+        c.verify_batch_ps_submit_dev(ps, batch, d_dyn_sc, d_dyn_pt, d_dyn_off, batch * N_DYN,
                                      d_st_sc, d_st_idx, d_st_off, batch * N_STATIC)
 
-    def run_steps(n, fn=None):
-        fn = fn or verify_on
-        futs = [lanes[i % len(ctxs)].submit(fn, ctxs[i % len(ctxs)]) for i in range(n)]
+    def collect(c):
+        bm = c.verify_wait()
+        if world > 1:
+            d_bm.copy_(torch.frombuffer(bytearray(bm), dtype=torch.uint8))
+            dist.all_gather_into_tensor(d_all, d_bm)    # RCCL over xGMI: the per-shard accept bitmaps
+        return bm
+
+    def run_steps(n, submit=None):
+        submit = submit or submit_verify
+        depth = len(ctxs)
         bm = None
-        for f in futs:
-            bm = f.result()
-            if world > 1:
-                d_bm.copy_(torch.frombuffer(bytearray(bm), dtype=torch.uint8))
-                dist.all_gather_into_tensor(d_all, d_bm)    # RCCL over xGMI: the per-shard accept bitmaps
+        for i in range(n):
+            c = ctxs[i % depth]
+            if i >= depth:
+                bm = collect(c)
+            submit(c)
+        for i in range(max(n - depth, 0), n):
+            bm = collect(ctxs[i % depth])
         return bm
 
     bm = run_steps(max(args.warmup, len(ctxs)))
@@ -331,7 +341,8 @@ def main():
         ctx.profile_reset()
         ctx.profile(True)
         for _ in range(5):
-            verify_on(ctx)
+            submit_verify(ctx)
+            ctx.verify_wait()
         ctx.profile(False)
         solo = {k: v[1] / v[0] for k, v in ctx.profile_read().items() if v[0]}
         solo_ms = solo.get(dom, dom_ms)
@@ -353,15 +364,18 @@ def main():
         packed_proofs = b"".join(t.proof for t in w["txs"])
         n_e2e = 6 * len(ctxs)
         t0 = time.perf_counter()
-        futs = [lanes[i % len(ctxs)].submit(gvs[id(ctxs[i % len(ctxs)])].verify_packed_gpu, tx0.n_in, tx0.n_out, batch,
+        hvs = [Verifier(c, w["gens"]) for c in ctxs]
+        for hv in hvs:
+            hv.__dict__["_plans"] = gv.__dict__["_plans"]     # one device plan per shape, shared
+        futs = [lanes[i % len(ctxs)].submit(hvs[i % len(ctxs)].verify_packed_gpu, tx0.n_in, tx0.n_out, batch,
                                             packed_com, packed_proofs, proof_len, w["r_bytes"]) for i in range(n_e2e)]
         outs = [f.result() for f in futs]
         e2e_gpu_s = (time.perf_counter() - t0) / n_e2e
         assert all(o == bm for o in outs)
         # the multiscalar-multiplication boundary alone (scalars prepared beforehand by the host verifier)
-        assert run_steps(len(ctxs), msm_only_on) == bm
+        assert run_steps(len(ctxs), submit_msm_only) == bm
         t0 = time.perf_counter()
-        run_steps(args.steps, msm_only_on)
+        run_steps(args.steps, submit_msm_only)
         msm_only_s = (time.perf_counter() - t0) / args.steps
         line = {
             "metric": "ZkVM tx verifications/sec (batch)",
@@ -422,8 +436,7 @@ def main():
         dist.destroy_process_group()
     for ex in lanes:
         ex.shutdown()
-    for gv in gvs.values():
-        gv.close()
+    gv.close()
     for c in ctxs[1:]:
         c.close()
     w["gens"].close()

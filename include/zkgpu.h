@@ -152,6 +152,32 @@ int zkgpu_cloak_verify_batch_gpu_dev(zkgpu_ctx *ctx, const zkgpu_pointset *ps, z
                                      const void *d_commitments, const void *d_proofs, size_t proof_len,
                                      const void *d_r, uint8_t *accept_bitmap);
 
+/* ---- several batches in flight --------------------------------------------------------------
+ * zkgpu_ctx_fork: a context with its own workspace and its own stream for the latency-bound
+ * kernels (transcript replay, Horner tails) that SHARES the parent's two streams for the
+ * chip-filling kernels, so that those run first-in first-out across the batches in flight.  The
+ * parent must outlive its forks.  A fork is a full context: every entry point accepts it.
+ *
+ * zkgpu_cloak_verify_submit_dev / zkgpu_verify_batch_ps_submit_dev: as the *_dev calls of the same
+ * name without `submit`, but return once the work is queued; at most one batch may be pending per
+ * context.  zkgpu_verify_wait blocks until that batch is done and writes its accept bitmap
+ * ((batch + 7) / 8 bytes; zeroed on any error: fail-closed).
+ * (Replaces: a Rust caller running `Verifier::verify` for several blocks on a thread pool.) */
+int zkgpu_ctx_fork(zkgpu_ctx* parent, zkgpu_ctx** out);
+
+/* Plain device memory for callers without a HIP binding of their own: what the *_dev entry points
+ * take.  zkgpu_upload is a blocking host-to-device copy. */
+int zkgpu_malloc(zkgpu_ctx* ctx, size_t bytes, void** out);
+int zkgpu_free(zkgpu_ctx* ctx, void* d_ptr);
+int zkgpu_upload(zkgpu_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int zkgpu_cloak_verify_submit_dev(zkgpu_ctx* ctx, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
+                                  const void* d_commitments, const void* d_proofs, size_t proof_len, const void* d_r);
+int zkgpu_verify_batch_ps_submit_dev(zkgpu_ctx* ctx, const zkgpu_pointset* ps, size_t batch, const void* d_dyn_scalars,
+                                     const void* d_dyn_points, const void* d_dyn_offsets, size_t n_dyn,
+                                     const void* d_static_scalars, const void* d_static_index,
+                                     const void* d_static_offsets, size_t n_static);
+int zkgpu_verify_wait(zkgpu_ctx* ctx, uint8_t* accept_bitmap);
+
 /* The host half of zkgpu_cloak_verify_batch alone: proof bytes -> the CSR of multiscalar
  * multiplication terms that zkgpu_verify_batch_ps* consumes (no device involved).
  * Statement i needs 11 + 2 (n_in+n_out) + 2k dynamic and 2 + 2 * 2^k static terms (k = lg of

@@ -100,3 +100,45 @@ def test_device_side_preparation_equals_host_and_oracle(ctx, oracle, table_bits)
     assert info["multipliers"] == 150 and info["padded_n"] == 256 and info["proof_len"] == 1025
     v.close()
     gens.close()
+
+
+def test_batches_in_flight_equal_synchronous_calls(ctx, oracle):
+    """zkgpu_ctx_fork + zkgpu_cloak_verify_submit_dev / zkgpu_verify_wait: three batches in flight on
+    forked contexts (shared chip-filling streams) give, batch by batch, the verdicts of the oracle and
+    of the synchronous call; a second submit on a busy context is refused; the MSM-boundary submit too."""
+    from zkvm_amd import ZkGpuError
+    from zkvm_amd.verifier import BulletproofGens, Verifier
+    gens = BulletproofGens(ctx, 256, table_bits=9)
+    v = Verifier(ctx, gens)
+    forks = [ctx, ctx.fork(), ctx.fork()]
+    batches = []
+    for b, count in enumerate((40, 17, 64)):
+        txs = _txs(oracle, count, 2, 2, bytes([0x21 + b]) * 32)
+        proofs = [bytearray(t.proof) for t in txs]
+        coms = [bytearray(t.commitments) for t in txs]
+        proofs[b + 1][1 + 32 * 11 + 2] ^= 4            # t_x
+        coms[b + 3][5] ^= 1                             # a commitment
+        proofs[b + 5][0] = 2                            # wire-format version
+        r = hashlib.shake_256(b"in flight %d" % b).digest(64 * count)
+        want = [int(oracle.cloak_verify(bytes(coms[i]), 2, 2, bytes(proofs[i]), r[64 * i: 64 * i + 64])) for i in range(count)]
+        assert want.count(0) == 3
+        batches.append((count, ctx.to_device(b"".join(coms)), ctx.to_device(b"".join(proofs)), ctx.to_device(r), want,
+                        len(proofs[0])))
+    for rounds in range(3):
+        for c, (count, d_com, d_pr, d_r, want, plen) in zip(forks, batches):
+            v.submit_packed_gpu_dev(2, 2, count, d_com, d_pr, plen, d_r, ctx=c)
+        with pytest.raises(ZkGpuError):
+            v.submit_packed_gpu_dev(2, 2, batches[0][0], batches[0][1], batches[0][2], batches[0][5], batches[0][3], ctx=forks[0])
+        for c, (count, d_com, d_pr, d_r, want, plen) in zip(forks, batches):
+            assert bits(c.verify_wait(), count) == want
+    for c, (count, d_com, d_pr, d_r, want, plen) in zip(forks, batches):
+        assert bits(v.verify_packed_gpu_dev(2, 2, count, d_com, d_pr, plen, d_r), count) == want
+    with pytest.raises(ZkGpuError):
+        forks[1].verify_wait()                          # nothing pending
+    for (count, d_com, d_pr, d_r, want, plen) in batches:
+        for d in (d_com, d_pr, d_r):
+            ctx.free_device(d)
+    v.close()
+    for c in forks[1:]:
+        c.close()
+    gens.close()

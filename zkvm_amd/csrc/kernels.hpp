@@ -938,14 +938,15 @@ k_from_uniform(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint
 
 // pack accept bytes into a bitmap (byte i/8, bit i%8)
 __global__ void __launch_bounds__(256)
-k_pack_bitmap(const uint8_t* __restrict__ accept, uint8_t* __restrict__ bitmap, uint32_t n_msm) {
+k_pack_bitmap(const uint8_t* __restrict__ accept, const uint32_t* __restrict__ wellformed /*optional*/,
+              uint8_t* __restrict__ bitmap, uint32_t n_msm) {
   const uint32_t byte = blockIdx.x * blockDim.x + threadIdx.x;
   if (byte >= (n_msm + 7) / 8) return;
   uint32_t v = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const uint32_t i = byte * 8 + k;
-    if (i < n_msm && accept[i]) v |= 1u << k;
+    if (i < n_msm && accept[i] && (!wellformed || wellformed[i])) v |= 1u << k;
   }
   bitmap[byte] = (uint8_t)v;
 }

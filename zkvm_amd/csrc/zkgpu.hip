@@ -56,6 +56,17 @@ struct zkgpu_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;        // generator (fixed-base) work runs beside the proof-point pipeline
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // pipelined submit / wait (see pipe_enqueue): a light stream of this context's own for the
+  // latency-bound kernels; `stream` / `stream2` carry the chip-filling ones and may be SHARED with
+  // the contexts forked from this one (zkgpu_ctx_fork), so that those run first-in first-out
+  hipStream_t stream_l = nullptr;
+  bool owns_streams = true;
+  hipEvent_t ev_t = nullptr, ev_p = nullptr, ev_sm = nullptr, ev_sa = nullptr, ev_done = nullptr;
+  bool pending = false;            // a submitted batch has not been waited for yet
+  size_t pending_batch = 0;
+  std::vector<uint8_t> sync_result; // result of a submit that had to run synchronously
+  bool sync_result_valid = false;
+  int sync_rc = 0;
   std::recursive_mutex mu;
   std::string last_error;
   // workspace (grown on demand, never shrunk; no allocation in steady state)
@@ -180,6 +191,7 @@ struct Job {
   uint64_t n_static = 0;
   const uint32_t* d_static_rows = nullptr;
   uint32_t n_msm = 1;
+  const uint32_t* d_wellformed = nullptr;   // optional per-MSM flags ANDed into the accept bitmap
 };
 
 // Runs decompress .. window sums.  On return (stream not yet synchronised):
@@ -439,7 +451,7 @@ int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap, uint8_t* 
   {
     Launch l(c, "k_pack_bitmap");
     hipLaunchKernelGGL(k_pack_bitmap, dim3(blocks_for(nbytes, 256)), dim3(256), 0, c->stream,
-                       (const uint8_t*)c->accept.p, (uint8_t*)c->bitmap.p, (uint32_t)B);
+                       (const uint8_t*)c->accept.p, job.d_wellformed, (uint8_t*)c->bitmap.p, (uint32_t)B);
   }
   HIP_TRY(c, hipGetLastError());
   char* h = (char*)c->pinned;
@@ -547,7 +559,7 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
   {
     Launch l(c, "k_pack_bitmap");
     hipLaunchKernelGGL(k_pack_bitmap, dim3(blocks_for(nbytes, 256)), dim3(256), 0, s, (const uint8_t*)c->accept2.p,
-                       (uint8_t*)c->bitmap.p, (uint32_t)B);
+                       job.d_wellformed, (uint8_t*)c->bitmap.p, (uint32_t)B);
   }
   HIP_TRY(c, hipGetLastError());
   char* h = (char*)c->pinned;
@@ -562,9 +574,174 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
   return ZKGPU_OK;
 }
 
-int upload(zkgpu_ctx* c, Buffer& b, const void* src, size_t bytes) {
+// ---- pipelined submit / wait ---------------------------------------------------------------
+// The kernels of one batch form a small DAG:
+//     unpack -> transcript -> prepare -+-> decompress -> small_msm_windows -> finish -+-> combine -> pack
+//                                      +-> static_digits -> static_accumulate --------+
+// transcript and finish are latency-bound (a few dozen wavefronts walking long serial chains);
+// prepare, small_msm_windows and static_accumulate fill the chip.  With several batches in flight
+// the chip-filling kernels of ALL batches go through the two shared streams first-in first-out,
+// while each batch's latency-bound kernels sit on its context's own light stream and run beside
+// them.  (Letting whole batches share the chip on equal terms instead makes them finish together,
+// start their transcripts together, and leave the chip idle for the length of a transcript.)
+struct PrepLaunch {
+  PrepShape sh;
+  const uint32_t *d_init, *d_mono_chal, *d_mono_pow, *d_tgt_off, *d_term_q, *d_term_mono, *d_term_coef;
+  const uint8_t* d_chal_label;
+  size_t lds_bytes;
+  const uint32_t* d_com;
+  const uint8_t* d_proofs;
+  const uint32_t* d_r;
+  size_t proof_len;
+};
+
+bool pipe_eligible(const zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps) {
+  return ps && ps->table && job.n_static && job.n_dyn && !c->forced_w && job.n_dyn <= 128ull * job.n_msm;
+}
+
+int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const PrepLaunch* prep) {
+  const size_t B = job.n_msm;
+  const size_t nbytes = (B + 7) / 8;
+  hipStream_t L = c->stream_l, H1 = c->stream, H2 = c->stream2;
+  const int W = ps->tbl_W;
+  int P = c->forced_parts;
+  if (P <= 0) {
+    P = (int)((131072 + B * W - 1) / (B * W));
+    P = std::max(1, std::min(16, P));
+  }
+  const uint64_t n_lanes = (uint64_t)B * W * P;
+  TRY(ensure(c, c->accept, B));
+  TRY(ensure(c, c->accept2, B));
+  TRY(ensure(c, c->bitmap, nbytes));
+  TRY(ensure_pinned(c, nbytes + 64));
+  TRY(ensure(c, c->status, 64));
+  TRY(ensure(c, c->digits, std::max<uint64_t>(job.n_static, 1) * W * 2));
+  TRY(ensure(c, c->st_partials, n_lanes * EXT_WORDS * 4));
+  TRY(ensure(c, c->dynsum, B * EXT_WORDS * 4));
+  TRY(ensure(c, c->dyn_rows, std::max<uint64_t>(job.n_dyn, 1) * NIELS_WORDS * 4));
+  TRY(ensure(c, c->window_sums, (size_t)B * 64 * EXT_WORDS * 4));
+  TRY(ensure(c, c->window_flags, (size_t)B * 64 * 4));
+  TRY(ensure(c, c->msm_fail, (size_t)B * 4));
+  c->last_w = 4;
+  HIP_TRY(c, hipMemsetAsync(c->status.p, 0, 8, L));
+  HIP_TRY(c, hipMemsetAsync((char*)c->status.p + 8, 0xff, 8, L));
+  HIP_TRY(c, hipMemsetAsync(c->msm_fail.p, 0, (size_t)B * 4, L));
+  if (prep) {
+    const PrepShape& sh = prep->sh;
+    HIP_TRY(c, hipMemsetAsync(c->prep_wf.p, 0xff, (size_t)B * 4, L));
+    {
+      Launch l(c, "k_proof_unpack", L);
+      hipLaunchKernelGGL(k_proof_unpack, dim3(blocks_for((uint64_t)B * sh.proof_words, 256)), dim3(256), 0, L,
+                         prep->d_proofs, (uint64_t)prep->proof_len, (uint32_t*)c->prep_pw.p, sh.proof_words,
+                         (uint32_t)B, (uint32_t*)c->prep_wf.p);
+    }
+    {
+      Launch l(c, "k_transcript", L);
+      hipLaunchKernelGGL(k_transcript, dim3(blocks_for(B, 64)), dim3(64), 0, L, sh, prep->d_init, prep->d_chal_label,
+                         prep->d_com, (const uint32_t*)c->prep_pw.p, prep->d_r, (uint32_t)B, (uint32_t*)c->prep_ch.p,
+                         (uint32_t*)c->prep_wf.p);
+    }
+  }
+  HIP_TRY(c, hipEventRecord(c->ev_t, L));
+  HIP_TRY(c, hipStreamWaitEvent(H1, c->ev_t, 0));
+  if (prep) {
+    Launch l(c, "k_prepare", H1);
+    hipLaunchKernelGGL(k_prepare, dim3((unsigned)B), dim3(256), prep->lds_bytes, H1, prep->sh, prep->d_mono_chal,
+                       prep->d_mono_pow, prep->d_tgt_off, prep->d_term_q, prep->d_term_mono, prep->d_term_coef,
+                       (const uint32_t*)c->prep_ch.p, prep->d_com, (const uint32_t*)c->prep_pw.p,
+                       (uint32_t*)c->prep_dyn_sc.p, (uint32_t*)c->prep_dyn_pt.p, (uint32_t*)c->prep_st_sc.p);
+  }
+  HIP_TRY(c, hipEventRecord(c->ev_p, H1));
+  HIP_TRY(c, hipStreamWaitEvent(H2, c->ev_p, 0));
+  {
+    Launch l(c, "k_static_digits", H2);
+    hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, H2, job.d_st_scalars,
+                       (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p);
+  }
+  {
+    Launch l(c, "k_static_accumulate", H2);
+    hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, H2,
+                       (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
+                       (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)B, job.n_static, (uint32_t*)c->st_partials.p);
+  }
+  HIP_TRY(c, hipEventRecord(c->ev_sa, H2));
+  {
+    Launch l(c, "k_decompress", H1);
+    hipLaunchKernelGGL(k_decompress, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, H1, job.d_dyn_points,
+                       (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, (uint32_t)B, (uint32_t*)c->msm_fail.p,
+                       (unsigned long long*)((char*)c->status.p + 8), (uint8_t*)nullptr);
+  }
+  {
+    Launch l(c, "k_small_msm_windows", H1);
+    const int chunk = (int)std::min<uint64_t>(64, std::max<uint64_t>(8, ((job.n_dyn + B - 1) / B + 3) / 4 * 4));
+    hipLaunchKernelGGL(k_small_msm_windows, dim3((unsigned)B), dim3(64), (size_t)chunk * (SMALL_TBL * EXT_WORDS * 4 + 64),
+                       H1, job.d_dyn_scalars, job.d_dyn_offsets, (const uint32_t*)c->dyn_rows.p, (uint32_t)B,
+                       (uint32_t*)c->window_sums.p, (uint32_t*)c->window_flags.p, (uint32_t*)c->status.p, chunk);
+  }
+  HIP_TRY(c, hipEventRecord(c->ev_sm, H1));
+  HIP_TRY(c, hipStreamWaitEvent(L, c->ev_sm, 0));
+  {
+    Launch l(c, "k_msm_finish", L);
+    hipLaunchKernelGGL(k_msm_finish_quad, dim3(blocks_for(4 * B, 256)), dim3(256), 0, L,
+                       (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p,
+                       (const uint32_t*)c->msm_fail.p, (uint8_t*)c->accept.p, (uint32_t*)nullptr,
+                       (uint32_t*)c->dynsum.p, (uint32_t)B, 4, 64);
+  }
+  HIP_TRY(c, hipStreamWaitEvent(L, c->ev_sa, 0));
+  {
+    Launch l(c, "k_static_combine", L);
+    hipLaunchKernelGGL(k_static_combine, dim3((unsigned)B), dim3(64), 0, L, (const uint32_t*)c->st_partials.p,
+                       (uint32_t)(W * P), (const uint32_t*)c->dynsum.p, (const uint8_t*)c->accept.p,
+                       (const uint32_t*)nullptr, (uint8_t*)c->accept2.p);
+  }
+  {
+    Launch l(c, "k_pack_bitmap", L);
+    hipLaunchKernelGGL(k_pack_bitmap, dim3(blocks_for(nbytes, 256)), dim3(256), 0, L, (const uint8_t*)c->accept2.p,
+                       job.d_wellformed, (uint8_t*)c->bitmap.p, (uint32_t)B);
+  }
+  HIP_TRY(c, hipGetLastError());
+  char* h = (char*)c->pinned;
+  HIP_TRY(c, hipMemcpyAsync(h, c->bitmap.p, nbytes, hipMemcpyDeviceToHost, L));
+  HIP_TRY(c, hipMemcpyAsync(h + nbytes, c->status.p, 16, hipMemcpyDeviceToHost, L));
+  HIP_TRY(c, hipEventRecord(c->ev_done, L));
+  c->pending = true;
+  c->pending_batch = B;
+  c->sync_result_valid = false;
+  return ZKGPU_OK;
+}
+
+// a submit whose shape the pipeline does not cover has already run synchronously: park its result
+void park_sync_result(zkgpu_ctx* c, int rc, const uint8_t* bitmap, size_t batch) {
+  c->sync_result.assign(bitmap, bitmap + (batch + 7) / 8);
+  c->sync_rc = rc;
+  c->sync_result_valid = true;
+  c->pending = true;
+  c->pending_batch = batch;
+}
+
+int pipe_wait(zkgpu_ctx* c, uint8_t* accept_bitmap) {
+  if (!c->pending) return ZKGPU_EINVAL;
+  const size_t nbytes = (c->pending_batch + 7) / 8;
+  c->pending = false;
+  memset(accept_bitmap, 0, nbytes);
+  if (c->sync_result_valid) {
+    c->sync_result_valid = false;
+    if (c->sync_rc == ZKGPU_OK) memcpy(accept_bitmap, c->sync_result.data(), nbytes);
+    return c->sync_rc;
+  }
+  HIP_TRY(c, hipEventSynchronize(c->ev_done));
+  if (c->profiling) prof_collect(c);
+  const char* h = (const char*)c->pinned;
+  uint32_t st;
+  memcpy(&st, h + nbytes, 4);
+  if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
+  memcpy(accept_bitmap, h, nbytes);
+  return ZKGPU_OK;
+}
+
+int upload(zkgpu_ctx* c, Buffer& b, const void* src, size_t bytes, hipStream_t stream = nullptr) {
   TRY(ensure(c, b, std::max<size_t>(bytes, 16)));
-  if (bytes) HIP_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+  if (bytes) HIP_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, stream ? stream : c->stream));
   return ZKGPU_OK;
 }
 
@@ -602,32 +779,82 @@ const char* zkgpu_strerror(int code) {
 
 const char* zkgpu_last_error(const zkgpu_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
+namespace {
+int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
+  zkgpu_ctx* c = new zkgpu_ctx();
+  c->device = device;
+  // main stream: the proof-point pipeline, high priority; stream2: the chip-filling generator
+  // kernel, low priority; stream_l: latency-bound kernels (transcripts, Horner tails), high priority
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  bool ok = true;
+  if (parent) {
+    c->stream = parent->stream;
+    c->stream2 = parent->stream2;
+    c->owns_streams = false;
+  } else {
+    ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+         hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess;
+  }
+  ok = ok && hipStreamCreateWithPriority(&c->stream_l, hipStreamNonBlocking, prio_greatest) == hipSuccess;
+  hipEvent_t* evs[] = {&c->ev_fork, &c->ev_join, &c->ev_t, &c->ev_p, &c->ev_sm, &c->ev_sa, &c->ev_done};
+  for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { delete c; return ZKGPU_EHIP; }
+  (void)hipFuncSetAttribute((const void*)k_small_msm_windows, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            64 * SMALL_TBL * EXT_WORDS * 4 + 64 * 64);
+  *out = c;
+  return ZKGPU_OK;
+}
+}  // namespace
+
 int zkgpu_init(int device, zkgpu_ctx** out) {
   if (!out) return ZKGPU_EINVAL;
   *out = nullptr;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ZKGPU_ENODEVICE;
   if (hipSetDevice(device) != hipSuccess) return ZKGPU_ENODEVICE;
-  zkgpu_ctx* c = new zkgpu_ctx();
-  c->device = device;
-  // main stream: the proof-point pipeline and its latency-bound tail, high priority;
-  // stream2: the chip-filling generator kernel, low priority
-  int prio_least = 0, prio_greatest = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-  if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
-      hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return ZKGPU_EHIP; }
-  (void)hipFuncSetAttribute((const void*)k_small_msm_windows, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            64 * SMALL_TBL * EXT_WORDS * 4 + 64 * 64);
-  *out = c;
+  return ctx_create(device, nullptr, out);
+}
+
+// Plain device memory for callers that have no HIP binding of their own (the *_dev entry points
+// take what these return).
+int zkgpu_malloc(zkgpu_ctx* c, size_t bytes, void** out) {
+  if (!c || !out) return ZKGPU_EINVAL;
+  *out = nullptr;
+  DeviceGuard g(c->device);
+  hipError_t e = hipMalloc(out, std::max<size_t>(bytes, 16));
+  if (e != hipSuccess) { c->last_error = std::string("hipMalloc: ") + hipGetErrorString(e); *out = nullptr; return ZKGPU_ENOMEM; }
   return ZKGPU_OK;
+}
+
+int zkgpu_free(zkgpu_ctx* c, void* p) {
+  if (!c) return ZKGPU_EINVAL;
+  if (!p) return ZKGPU_OK;
+  DeviceGuard g(c->device);
+  HIP_TRY(c, hipFree(p));
+  return ZKGPU_OK;
+}
+
+int zkgpu_upload(zkgpu_ctx* c, void* d_dst, const void* src, size_t bytes) {
+  if (!c || (bytes && (!d_dst || !src))) return ZKGPU_EINVAL;
+  DeviceGuard g(c->device);
+  if (bytes) HIP_TRY(c, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+  return ZKGPU_OK;
+}
+
+int zkgpu_ctx_fork(zkgpu_ctx* parent, zkgpu_ctx** out) {
+  if (!parent || !out) return ZKGPU_EINVAL;
+  *out = nullptr;
+  DeviceGuard g(parent->device);
+  return ctx_create(parent->device, parent, out);
 }
 
 void zkgpu_destroy(zkgpu_ctx* c) {
   if (!c) return;
   DeviceGuard g(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  if (c->stream_l) (void)hipStreamSynchronize(c->stream_l);
   Buffer* bufs[] = {&c->in_scalars, &c->in_points, &c->in_offsets, &c->in_st_scalars, &c->in_st_index,
                     &c->in_st_offsets, &c->dyn_rows, &c->bins, &c->block_sums, &c->entries, &c->buckets,
                     &c->partials, &c->partial_flags, &c->window_sums, &c->window_flags, &c->msm_fail,
@@ -637,10 +864,13 @@ void zkgpu_destroy(zkgpu_ctx* c) {
   for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  (void)hipStreamDestroy(c->stream);
-  if (c->stream2) (void)hipStreamDestroy(c->stream2);
-  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->owns_streams) {
+    (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  }
+  if (c->stream_l) (void)hipStreamDestroy(c->stream_l);
+  hipEvent_t evs[] = {c->ev_fork, c->ev_join, c->ev_t, c->ev_p, c->ev_sm, c->ev_sa, c->ev_done};
+  for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -956,6 +1186,8 @@ int zkgpu_cloak_prepare_batch(size_t gens_capacity, size_t batch, const uint32_t
 // ---- the same, with the host half moved onto the device (plan replay) -------------------
 struct zkgpu_cloak_plan {
   zkgpu_ctx* ctx;
+  int device = 0;
+  std::mutex mu;       // guards the per-batch-size scaffolding below
   CloakPlan host;
   PrepShape shape;
   size_t gens_capacity;
@@ -985,6 +1217,7 @@ int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t 
   DeviceGuard g(c->device);
   zkgpu_cloak_plan* p = new zkgpu_cloak_plan();
   p->ctx = c;
+  p->device = c->device;
   p->gens_capacity = gens_capacity;
   try {
     p->host = PlanBuilder::build(n_in, n_out);
@@ -1062,7 +1295,7 @@ int cloak_verify_gpu_body(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_pl
 int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
                                  const uint8_t* commitments, const uint8_t* proofs, size_t proof_len,
                                  const uint8_t* r_bytes, uint8_t* accept_bitmap) {
-  if (!c || !ps || !plan || plan->ctx != c || ps->ctx->device != c->device || !accept_bitmap) return ZKGPU_EINVAL;
+  if (!c || !ps || !plan || plan->device != c->device || ps->ctx->device != c->device || !accept_bitmap) return ZKGPU_EINVAL;
   memset(accept_bitmap, 0, (batch + 7) / 8);
   if (batch == 0) return ZKGPU_OK;
   if (!commitments || !proofs || batch >= (1ull << 24)) return ZKGPU_EINVAL;
@@ -1077,9 +1310,10 @@ int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_c
     for (size_t i = 0; i < rnd.size(); i += 4) { uint32_t v = rd(); memcpy(&rnd[i], &v, 4); }
     r_bytes = rnd.data();
   }
-  TRY(upload(c, c->prep_com, commitments, batch * sh.m * 32));
-  TRY(upload(c, c->prep_proofs, proofs, batch * proof_len));
-  TRY(upload(c, c->prep_r, r_bytes, batch * 64));
+  TRY(upload(c, c->prep_com, commitments, batch * sh.m * 32, c->stream_l));
+  TRY(upload(c, c->prep_proofs, proofs, batch * proof_len, c->stream_l));
+  TRY(upload(c, c->prep_r, r_bytes, batch * 64, c->stream_l));
+  HIP_TRY(c, hipStreamSynchronize(c->stream_l));   // the sources are caller-owned (pageable) host memory
   return cloak_verify_gpu_body(c, ps, plan, batch, (const uint32_t*)c->prep_com.p, (const uint8_t*)c->prep_proofs.p,
                                (const uint32_t*)c->prep_r.p, proof_len, accept_bitmap);
 }
@@ -1089,7 +1323,7 @@ int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_c
 int zkgpu_cloak_verify_batch_gpu_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
                                      const void* d_commitments, const void* d_proofs, size_t proof_len,
                                      const void* d_r, uint8_t* accept_bitmap) {
-  if (!c || !ps || !plan || plan->ctx != c || ps->ctx->device != c->device || !accept_bitmap) return ZKGPU_EINVAL;
+  if (!c || !ps || !plan || plan->device != c->device || ps->ctx->device != c->device || !accept_bitmap) return ZKGPU_EINVAL;
   memset(accept_bitmap, 0, (batch + 7) / 8);
   if (batch == 0) return ZKGPU_OK;
   if (!d_commitments || !d_proofs || !d_r || batch >= (1ull << 24)) return ZKGPU_EINVAL;
@@ -1101,12 +1335,13 @@ int zkgpu_cloak_verify_batch_gpu_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, zkg
 }
 
 namespace {
-int cloak_verify_gpu_body(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
-                          const uint32_t* d_com, const uint8_t* d_proofs, const uint32_t* d_r, size_t proof_len,
-                          uint8_t* accept_bitmap) {
+// Enqueues (pipeline) or runs (shapes the pipeline does not cover) the verification of one batch;
+// the result is collected by pipe_wait.
+int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
+                             const uint32_t* d_com, const uint8_t* d_proofs, const uint32_t* d_r, size_t proof_len) {
   if (ps->n < 2 + 2 * plan->gens_capacity) return ZKGPU_EINVAL;
+  if (c->pending) { c->last_error = "a submitted batch is still waiting for zkgpu_verify_wait"; return ZKGPU_EINVAL; }
   const PrepShape& sh = plan->shape;
-  hipStream_t s = c->stream;
   const uint32_t B = (uint32_t)batch;
   TRY(ensure(c, c->prep_pw, (size_t)B * sh.proof_words * 4));
   TRY(ensure(c, c->prep_ch, (size_t)B * sh.n_ch * 32));
@@ -1114,22 +1349,53 @@ int cloak_verify_gpu_body(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_pl
   TRY(ensure(c, c->prep_dyn_sc, (size_t)B * sh.n_dyn * 32));
   TRY(ensure(c, c->prep_dyn_pt, (size_t)B * sh.n_dyn * 32));
   TRY(ensure(c, c->prep_st_sc, (size_t)B * sh.n_static * 32));
-  if (plan->cached_batch != batch) {   // CSR scaffolding of a uniform batch: offsets and the generator index template
-    if (plan->d_dyn_off) { (void)hipFree(plan->d_dyn_off); (void)hipFree(plan->d_st_off); (void)hipFree(plan->d_st_index); }
-    plan->d_dyn_off = nullptr; plan->d_st_off = nullptr; plan->d_st_index = nullptr;
-    std::vector<uint64_t> doff(batch + 1), soff(batch + 1);
-    for (size_t i = 0; i <= batch; ++i) { doff[i] = i * sh.n_dyn; soff[i] = i * sh.n_static; }
-    std::vector<uint32_t> idx((size_t)batch * sh.n_static);
-    for (size_t i = 0; i < batch; ++i) {
-      uint32_t* row = &idx[i * sh.n_static];
-      row[0] = 0; row[1] = 1;
-      for (uint32_t j = 0; j < sh.pn; ++j) { row[2 + j] = 2 + j; row[2 + sh.pn + j] = (uint32_t)(2 + plan->gens_capacity + j); }
+  {
+    std::lock_guard<std::mutex> plk(plan->mu);
+    if (plan->cached_batch < batch) {   // CSR scaffolding of a uniform batch: offsets and the generator index template
+      // (a prefix of a larger scaffolding serves every smaller batch; contexts in flight may still be
+      // reading the old one, so drain the device before it is replaced)
+      HIP_TRY(c, hipDeviceSynchronize());
+      if (plan->d_dyn_off) { (void)hipFree(plan->d_dyn_off); (void)hipFree(plan->d_st_off); (void)hipFree(plan->d_st_index); }
+      plan->d_dyn_off = nullptr; plan->d_st_off = nullptr; plan->d_st_index = nullptr;
+      plan->cached_batch = 0;
+      std::vector<uint64_t> doff(batch + 1), soff(batch + 1);
+      for (size_t i = 0; i <= batch; ++i) { doff[i] = i * sh.n_dyn; soff[i] = i * sh.n_static; }
+      std::vector<uint32_t> idx((size_t)batch * sh.n_static);
+      for (size_t i = 0; i < batch; ++i) {
+        uint32_t* row = &idx[i * sh.n_static];
+        row[0] = 0; row[1] = 1;
+        for (uint32_t j = 0; j < sh.pn; ++j) { row[2 + j] = 2 + j; row[2 + sh.pn + j] = (uint32_t)(2 + plan->gens_capacity + j); }
+      }
+      TRY(plan_upload(c, &plan->d_dyn_off, doff));
+      TRY(plan_upload(c, &plan->d_st_off, soff));
+      TRY(plan_upload(c, &plan->d_st_index, idx));
+      plan->cached_batch = batch;
     }
-    TRY(plan_upload(c, &plan->d_dyn_off, doff));
-    TRY(plan_upload(c, &plan->d_st_off, soff));
-    TRY(plan_upload(c, &plan->d_st_index, idx));
-    plan->cached_batch = batch;
   }
+  Job job;
+  job.d_dyn_scalars = (const uint32_t*)c->prep_dyn_sc.p;
+  job.d_dyn_points = (const uint32_t*)c->prep_dyn_pt.p;
+  job.d_dyn_offsets = plan->d_dyn_off;
+  job.n_dyn = (uint64_t)B * sh.n_dyn;
+  job.d_st_scalars = (const uint32_t*)c->prep_st_sc.p;
+  job.d_st_index = plan->d_st_index;
+  job.d_st_offsets = plan->d_st_off;
+  job.n_static = (uint64_t)B * sh.n_static;
+  job.d_static_rows = ps->rows;
+  job.n_msm = B;
+  job.d_wellformed = (const uint32_t*)c->prep_wf.p;   // folded into the accept bitmap on the device
+  if (pipe_eligible(c, job, ps)) {
+    PrepLaunch pl;
+    pl.sh = sh;
+    pl.d_init = plan->d_init; pl.d_mono_chal = plan->d_mono_chal; pl.d_mono_pow = plan->d_mono_pow;
+    pl.d_tgt_off = plan->d_tgt_off; pl.d_term_q = plan->d_term_q; pl.d_term_mono = plan->d_term_mono;
+    pl.d_term_coef = plan->d_term_coef; pl.d_chal_label = plan->d_chal_label; pl.lds_bytes = plan->lds_bytes;
+    pl.d_com = d_com; pl.d_proofs = d_proofs; pl.d_r = d_r; pl.proof_len = proof_len;
+    return pipe_enqueue(c, job, ps, &pl);
+  }
+  // general shapes (no generator tables, forced window width, many proof points): one stream, synchronous
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipStreamSynchronize(c->stream_l));      // uploads, if any, were queued on the light stream
   HIP_TRY(c, hipMemsetAsync(c->prep_wf.p, 0xff, (size_t)B * 4, s));
   {
     Launch l(c, "k_proof_unpack");
@@ -1152,27 +1418,78 @@ int cloak_verify_gpu_body(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_pl
                        (uint32_t*)c->prep_dyn_pt.p, (uint32_t*)c->prep_st_sc.p);
   }
   HIP_TRY(c, hipGetLastError());
-  Job job;
-  job.d_dyn_scalars = (const uint32_t*)c->prep_dyn_sc.p;
-  job.d_dyn_points = (const uint32_t*)c->prep_dyn_pt.p;
-  job.d_dyn_offsets = plan->d_dyn_off;
-  job.n_dyn = (uint64_t)B * sh.n_dyn;
-  job.d_st_scalars = (const uint32_t*)c->prep_st_sc.p;
-  job.d_st_index = plan->d_st_index;
-  job.d_st_offsets = plan->d_st_off;
-  job.n_static = (uint64_t)B * sh.n_static;
-  job.d_static_rows = ps->rows;
-  job.n_msm = B;
-  int rc = ps->table ? batch_device_tables(c, job, ps, accept_bitmap) : batch_device(c, job, accept_bitmap);
-  if (rc != ZKGPU_OK) { memset(accept_bitmap, 0, (batch + 7) / 8); return rc; }
-  std::vector<uint32_t> wf(batch);
-  hipError_t e = hipMemcpy(wf.data(), c->prep_wf.p, batch * 4, hipMemcpyDeviceToHost);
-  if (e != hipSuccess) { memset(accept_bitmap, 0, (batch + 7) / 8); c->last_error = hipGetErrorString(e); return ZKGPU_EHIP; }
-  for (size_t i = 0; i < batch; ++i)
-    if (!wf[i]) accept_bitmap[i / 8] &= (uint8_t)~(1u << (i % 8));
+  std::vector<uint8_t> bm((batch + 7) / 8, 0);
+  int rc = ps->table ? batch_device_tables(c, job, ps, bm.data()) : batch_device(c, job, bm.data());
+  park_sync_result(c, rc, bm.data(), batch);
   return ZKGPU_OK;
 }
+
+int cloak_verify_gpu_body(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
+                          const uint32_t* d_com, const uint8_t* d_proofs, const uint32_t* d_r, size_t proof_len,
+                          uint8_t* accept_bitmap) {
+  TRY(cloak_verify_gpu_enqueue(c, ps, plan, batch, d_com, d_proofs, d_r, proof_len));
+  int rc = pipe_wait(c, accept_bitmap);
+  if (rc != ZKGPU_OK) memset(accept_bitmap, 0, (batch + 7) / 8);
+  return rc;
+}
 }  // namespace
+
+// Asynchronous form: enqueue the verification of one batch (inputs resident in HBM, as for
+// zkgpu_cloak_verify_batch_gpu_dev) and return; zkgpu_verify_wait(ctx, bitmap) collects the result.
+// One batch may be pending per context; fork contexts (zkgpu_ctx_fork) to keep several in flight.
+int zkgpu_cloak_verify_submit_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
+                                  const void* d_commitments, const void* d_proofs, size_t proof_len, const void* d_r) {
+  if (!c || !ps || !plan || plan->device != c->device || ps->ctx->device != c->device) return ZKGPU_EINVAL;
+  if (batch == 0 || !d_commitments || !d_proofs || !d_r || batch >= (1ull << 24)) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  if (c->pending) return ZKGPU_EINVAL;
+  if (proof_len != 1 + 4ull * plan->shape.proof_words) {     // wrong length for this statement: every proof is Err
+    std::vector<uint8_t> z((batch + 7) / 8, 0);
+    park_sync_result(c, ZKGPU_OK, z.data(), batch);
+    return ZKGPU_OK;
+  }
+  DeviceGuard g(c->device);
+  return cloak_verify_gpu_enqueue(c, ps, plan, batch, (const uint32_t*)d_commitments, (const uint8_t*)d_proofs,
+                                  (const uint32_t*)d_r, proof_len);
+}
+
+int zkgpu_verify_batch_ps_submit_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, const void* d_dyn_scalars,
+                                     const void* d_dyn_points, const void* d_dyn_offsets, size_t n_dyn,
+                                     const void* d_static_scalars, const void* d_static_index,
+                                     const void* d_static_offsets, size_t n_static) {
+  if (!c || !ps || ps->ctx->device != c->device || batch == 0 || batch >= (1ull << 31)) return ZKGPU_EINVAL;
+  if (!d_dyn_offsets || !d_static_offsets) return ZKGPU_EINVAL;
+  if ((n_dyn && (!d_dyn_scalars || !d_dyn_points)) || (n_static && !d_static_scalars)) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  if (c->pending) return ZKGPU_EINVAL;
+  DeviceGuard g(c->device);
+  Job job;
+  job.d_dyn_scalars = (const uint32_t*)d_dyn_scalars;
+  job.d_dyn_points = (const uint32_t*)d_dyn_points;
+  job.d_dyn_offsets = (const uint64_t*)d_dyn_offsets;
+  job.n_dyn = n_dyn;
+  job.d_st_scalars = (const uint32_t*)d_static_scalars;
+  job.d_st_index = (const uint32_t*)d_static_index;
+  job.d_st_offsets = (const uint64_t*)d_static_offsets;
+  job.n_static = n_static;
+  job.d_static_rows = ps->rows;
+  job.n_msm = (uint32_t)batch;
+  if (pipe_eligible(c, job, ps)) return pipe_enqueue(c, job, ps, nullptr);
+  std::vector<uint8_t> bm((batch + 7) / 8, 0);
+  int rc = (ps->table && n_static) ? batch_device_tables(c, job, ps, bm.data()) : batch_device(c, job, bm.data());
+  park_sync_result(c, rc, bm.data(), batch);
+  return ZKGPU_OK;
+}
+
+int zkgpu_verify_wait(zkgpu_ctx* c, uint8_t* accept_bitmap) {
+  if (!c || !accept_bitmap) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  const size_t nbytes = (c->pending_batch + 7) / 8;
+  int rc = pipe_wait(c, accept_bitmap);
+  if (rc != ZKGPU_OK && c->pending_batch) memset(accept_bitmap, 0, nbytes);
+  return rc;
+}
 
 int zkgpu_cloak_verify_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_capacity, size_t batch,
                              const uint32_t* n_in, const uint32_t* n_out, const uint8_t* commitments,

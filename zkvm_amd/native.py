@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Dict, Optional, Sequence, Tuple
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -77,6 +78,13 @@ def load_library():
     lib.zkgpu_cloak_plan_info.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 5
     lib.zkgpu_cloak_verify_batch_gpu.argtypes = [vp, vp, vp, sz, u8p, u8p, sz, u8p, u8p]
     lib.zkgpu_cloak_verify_batch_gpu_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, u8p]
+    lib.zkgpu_ctx_fork.argtypes = [vp, C.POINTER(vp)]
+    lib.zkgpu_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.zkgpu_free.argtypes = [vp, vp]
+    lib.zkgpu_upload.argtypes = [vp, vp, u8p, sz]
+    lib.zkgpu_cloak_verify_submit_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp]
+    lib.zkgpu_verify_batch_ps_submit_dev.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, sz]
+    lib.zkgpu_verify_wait.argtypes = [vp, u8p]
     lib.zkgpu_cloak_prepare_batch.argtypes = [sz, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p, u8p,
                                               C.POINTER(C.c_uint64), u8p, C.c_int, u8p, u8p, C.POINTER(C.c_uint64), sz,
                                               u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), sz, u8p]
@@ -139,15 +147,54 @@ class PointSet:
 class Context:
     """One GPU, one HIP stream.  Use one Context per process / per GPU."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _parent: Optional["Context"] = None):
         self.lib = load_library()
         self.h = C.c_void_p()
-        rc = self.lib.zkgpu_init(device, C.byref(self.h))
+        self.parent = _parent          # a fork shares its parent's chip-filling streams: keep the parent alive
+        self._forks = weakref.WeakSet()
+        self._pending_batch = 0
+        if _parent is not None:
+            rc = self.lib.zkgpu_ctx_fork(_parent.h, C.byref(self.h))
+        else:
+            rc = self.lib.zkgpu_init(device, C.byref(self.h))
         if rc != OK:
             raise ZkGpuError(rc, self.lib.zkgpu_strerror(rc).decode() + " (libzkgpu needs a HIP device; no CPU fallback)")
 
+    def to_device(self, data: bytes) -> int:
+        """zkgpu_malloc + zkgpu_upload: a device buffer holding `data`; release with free_device."""
+        p = C.c_void_p()
+        self._check(self.lib.zkgpu_malloc(self.h, len(data), C.byref(p)))
+        self._check(self.lib.zkgpu_upload(self.h, p, data, len(data)))
+        return int(p.value)
+
+    def free_device(self, d_ptr: int) -> None:
+        self._check(self.lib.zkgpu_free(self.h, C.c_void_p(d_ptr)))
+
+    def fork(self) -> "Context":
+        """zkgpu_ctx_fork: own workspace + light stream, the parent's heavy streams (batches in flight)."""
+        f = Context(_parent=self)
+        self._forks.add(f)
+        return f
+
+    def verify_batch_ps_submit_dev(self, ps: "PointSet", batch: int, d_dyn_scalars, d_dyn_points, d_dyn_offsets,
+                                   n_dyn: int, d_static_scalars, d_static_index, d_static_offsets, n_static: int) -> None:
+        self._check(self.lib.zkgpu_verify_batch_ps_submit_dev(
+            self.h, ps.h, batch, _ptr(d_dyn_scalars), _ptr(d_dyn_points), _ptr(d_dyn_offsets), n_dyn,
+            _ptr(d_static_scalars), _ptr(d_static_index) if d_static_index is not None else None,
+            _ptr(d_static_offsets), n_static))
+        self._pending_batch = batch
+
+    def verify_wait(self) -> bytes:
+        """zkgpu_verify_wait: the accept bitmap of the batch submitted last on this context."""
+        n = (self._pending_batch + 7) // 8
+        bm = C.create_string_buffer(max(n, 1))
+        self._check(self.lib.zkgpu_verify_wait(self.h, bm))
+        return bm.raw[:n]
+
     def close(self) -> None:
         if self.h:
+            for f in list(self._forks):     # forks borrow this context's streams: they go first
+                f.close()
             self.lib.zkgpu_destroy(self.h)
             self.h = C.c_void_p()
 

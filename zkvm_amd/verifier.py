@@ -140,6 +140,17 @@ class Verifier:
         self.ctx._check(rc)
         return bm.raw[: (batch + 7) // 8]
 
+    def submit_packed_gpu_dev(self, n_in: int, n_out: int, batch: int, d_commitments, d_proofs, proof_len: int, d_r,
+                              ctx: Optional[Context] = None) -> Context:
+        """zkgpu_cloak_verify_submit_dev on `ctx` (this verifier's context or one of its forks): returns once the
+        batch is queued; `ctx.verify_wait()` yields the accept bitmap."""
+        from .native import _ptr
+        c = ctx or self.ctx
+        c._check(c.lib.zkgpu_cloak_verify_submit_dev(c.h, self.bp_gens.points.h, self._plan(n_in, n_out), batch,
+                                                     _ptr(d_commitments), _ptr(d_proofs), proof_len, _ptr(d_r)))
+        c._pending_batch = batch
+        return c
+
     def close(self) -> None:
         for h in self.__dict__.get("_plans", {}).values():
             self.ctx.lib.zkgpu_cloak_plan_destroy(h)
