@@ -28,6 +28,13 @@ multiscalar-multiplication tail alone), "host_memory" (the same calls fed from h
 """
 from __future__ import annotations
 
+import os
+
+# Each batch in flight has a stream of its own for its latency-bound kernels; the HIP runtime maps
+# streams onto 4 hardware queues by default, which would serialise those streams again.  Must be set
+# before the runtime initialises (i.e. before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import argparse
 import hashlib
 import json

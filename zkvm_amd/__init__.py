@@ -6,6 +6,12 @@ this package is the thin host-side mirror used by tests and bench.py.  There is
 no CPU fallback: importing works anywhere, but creating a `Context` without the
 built library or without a GPU raises.
 """
+import os as _os
+
+# batches in flight use one light stream each (zkgpu_ctx_fork): let the HIP runtime give them hardware
+# queues of their own (default 4).  Only effective when set before the runtime initialises.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 from .native import Context, PointSet, ZkGpuError, lib_path, load_library  # noqa: F401
 
 __all__ = ["Context", "PointSet", "ZkGpuError", "lib_path", "load_library"]

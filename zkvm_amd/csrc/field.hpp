@@ -24,10 +24,12 @@
 #if defined(__HIPCC__) || defined(__HIP__)
 #include <hip/hip_runtime.h>
 #define ZK_HD __host__ __device__ __forceinline__
+#define ZK_HD_NOINLINE __host__ __device__ inline __attribute__((noinline))
 #define ZK_UNROLL _Pragma("unroll")
 #define ZK_NOUNROLL _Pragma("clang loop unroll(disable)")
 #else
 #define ZK_HD inline
+#define ZK_HD_NOINLINE inline
 #define ZK_UNROLL
 #define ZK_NOUNROLL
 #endif

@@ -776,15 +776,18 @@ k_msm_finish(const uint32_t* __restrict__ window_sums, const uint32_t* __restric
   accept[m] = (ident && !failed) ? 1 : 0;
 }
 
-// ---- k_small_msm_windows ------------------------------------------------------------
+// ---- small multiscalar multiplications: k_small_tables + k_small_accumulate ------------
 // Window sums of a SMALL multiscalar multiplication (the few dozen proof-specific
-// points of one transaction) without the global sort: one wavefront per MSM, window
-// width 4, so the 64 lanes ARE the 64 windows.
-//   phase 1  lane i: the 64 signed digits of scalar i (LDS, one byte each) and the
-//            multiples P_i, 2P_i .. 8P_i in "cached" form (Y+X, Y-X, 2Z, 2dT), 160 B each, in LDS
-//   phase 2  lane t: W_t = sum_i sign(d_it) * (|d_it| P_i): one 8M addition per point,
-//            every lane busy, no buckets, no atomics, no HBM intermediates
-// More than `chunk` points per MSM are handled chunk at a time (window sums add up).
+// points of one transaction) without the global sort.  Window width 4, so one
+// wavefront's 64 lanes ARE the 64 windows of a 256-bit scalar.
+//   k_small_tables      per point: P, 2P .. 8P in "cached" form (Y+X, Y-X, 2Z, 2dT), 8 x 160 B
+//                       in HBM (L2-resident while in use), and the scalar recoded as
+//                       s' = s + 0x88..8 (digit t = nibble t of s' minus 8: no carry chain).
+//   k_small_accumulate  one workgroup of `parts` wavefronts per MSM; wavefront p takes the points
+//                       p, p + parts, ...; lane t: W_t += sign(d_it) * (|d_it| P_i), one 8M
+//                       addition per point, no buckets, no atomics; the parts meet in LDS.
+// A lone wavefront per SIMD issues a dependent multiply chain at a fraction of the pipe's
+// rate, so the point loop is split over `parts` wavefronts to keep 3-4 of them per SIMD.
 struct ge_cached { fe YpX, YmX, Z2, T2d; };
 
 __device__ __forceinline__ void ge_add_cached(ge& r, const ge& p, const ge_cached& q, bool negate) {
@@ -809,61 +812,93 @@ __device__ __forceinline__ void ge_add_cached(ge& r, const ge& p, const ge_cache
 
 constexpr int SMALL_TBL = 8;   // multiples per point (signed 4-bit digits)
 
+__device__ __forceinline__ void store_cached(uint32_t* row, const ge& p) {
+  ge c4;   // cached form packed in an ext row: YpX, YmX, 2Z, 2dT
+  fe_add_c(c4.X, p.Y, p.X);
+  fe_sub_c(c4.Y, p.Y, p.X);
+  fe_add_c(c4.Z, p.Z, p.Z);
+  fe_mul(c4.T, p.T, fe_D2());
+  store_ext(row, c4);
+}
+
 __global__ void __launch_bounds__(64)
-k_small_msm_windows(const uint32_t* __restrict__ dyn_scalars, const uint64_t* __restrict__ dyn_offsets,
-                    const uint32_t* __restrict__ dyn_rows, uint32_t n_msm, uint32_t* __restrict__ window_sums,
-                    uint32_t* __restrict__ window_nonempty, uint32_t* __restrict__ status, int chunk) {
-  // LDS is what limits how many of these waves a CU holds, so the host sizes it for `chunk`
-  // points (<= 64, about the typical point count of one MSM): chunk * (8 * 160 + 64) bytes
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t* tbl = smem;                                               // [chunk points][8][40 words]
-  int8_t* digits = reinterpret_cast<int8_t*>(smem + chunk * SMALL_TBL * EXT_WORDS);   // [chunk points][64 windows]
+k_small_tables(const uint32_t* __restrict__ dyn_scalars, const uint32_t* __restrict__ dyn_rows, uint64_t n,
+               uint32_t* __restrict__ tbl /*[n][8][40]*/, uint32_t* __restrict__ recoded /*[n][8]*/,
+               uint32_t* __restrict__ status) {
+  const uint64_t k = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (k >= n) return;
+  // s' = s + 0x8888...8 (mod 2^256; a wrap leaves top nibble 0, which k_small_accumulate reads as +8)
+  const uint32_t* sc = dyn_scalars + 8 * k;
+  if (sc[7] >> 31) atomicOr(&status[0], 2u);
+  uint32_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t v = (uint64_t)sc[i] + 0x88888888u + carry;
+    recoded[8 * k + i] = (uint32_t)v;
+    carry = (uint32_t)(v >> 32);
+  }
+  // one rolled loop (a mixed addition + the cached-form conversion): the body stays in the
+  // instruction cache, where a straight-line chain of different doublings / additions does not
+  ge_niels nq;
+  load_niels(nq, dyn_rows + k * NIELS_WORDS);
+  ge cur;
+  ge_identity(cur);
+  uint32_t* row = tbl + k * (SMALL_TBL * EXT_WORDS);
+#pragma unroll 1
+  for (int e = 0; e < SMALL_TBL; ++e) {
+    ge_madd(cur, cur, nq, false);
+    store_cached(row + e * EXT_WORDS, cur);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_small_accumulate(const uint32_t* __restrict__ recoded, const uint64_t* __restrict__ dyn_offsets,
+                   const uint32_t* __restrict__ tbl, uint32_t n_msm, uint32_t* __restrict__ window_sums,
+                   uint32_t* __restrict__ window_nonempty) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [parts - 1][41][64]
   const uint32_t m = blockIdx.x;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x & 63;
+  const int part = threadIdx.x >> 6, parts = blockDim.x >> 6;
   const uint64_t k0 = dyn_offsets[m], k1 = dyn_offsets[m + 1];
   ge total;
   bool total_set = false;
-  for (uint64_t base = k0; base < k1; base += chunk) {
-    const int n = (int)min((uint64_t)chunk, k1 - base);
-    __syncthreads();
-    if (t < n) {
-      const uint32_t* sc = dyn_scalars + 8 * (base + t);
-      if (sc[7] >> 31) atomicOr(&status[0], 2u);
-      for (int q = 0; q < 64; ++q) digits[t * 64 + q] = 0;
-      for_each_digit(sc, 4, 64, [&](int win, int d) { digits[t * 64 + win] = (int8_t)d; });
-      // multiples of point t
-      ge_niels nq;
-      load_niels(nq, dyn_rows + (base + t) * NIELS_WORDS);
-      ge p1, cur;
-      ge_identity(p1);
-      ge_madd(p1, p1, nq, false);
-      cur = p1;
 #pragma unroll 1
-      for (int e = 0; e < SMALL_TBL; ++e) {
-        if (e == 1) ge_double(cur, p1);
-        else if (e > 1) ge_add(cur, cur, p1);
-        ge c4;   // cached form packed in an ext row: YpX, YmX, 2Z, 2dT
-        fe_add_c(c4.X, cur.Y, cur.X);
-        fe_sub_c(c4.Y, cur.Y, cur.X);
-        fe_add_c(c4.Z, cur.Z, cur.Z);
-        fe_mul(c4.T, cur.T, fe_D2());
-        uint32_t* row = tbl + ((uint32_t)t * SMALL_TBL + e) * EXT_WORDS;
+  for (uint64_t k = k0 + part; k < k1; k += parts) {
+    const uint32_t n4 = (recoded[8 * k + (t >> 3)] >> (4 * (t & 7))) & 15u;
+    const int d = (t == 63 && n4 < 8u) ? (int)n4 + 8 : (int)n4 - 8;
+    if (d != 0) {
+      ge c4;
+      load_ext(c4, tbl + (k * SMALL_TBL + (uint64_t)((d < 0 ? -d : d) - 1)) * EXT_WORDS);
+      ge_cached c;
+      c.YpX = c4.X; c.YmX = c4.Y; c.Z2 = c4.Z; c.T2d = c4.T;
+      if (!total_set) { ge_identity(total); total_set = true; }
+      ge_add_cached(total, total, c, d < 0);
+    }
+  }
+  if (part > 0) {
+    uint32_t* slot = smem + (uint32_t)(part - 1) * 41 * 64;
+    slot[40 * 64 + t] = total_set ? 1u : 0u;
+    if (total_set) {
 #pragma unroll
-        for (int q = 0; q < 10; ++q) { row[q] = c4.X.v[q]; row[10 + q] = c4.Y.v[q]; row[20 + q] = c4.Z.v[q]; row[30 + q] = c4.T.v[q]; }
+      for (int q = 0; q < 10; ++q) {
+        slot[q * 64 + t] = total.X.v[q]; slot[(10 + q) * 64 + t] = total.Y.v[q];
+        slot[(20 + q) * 64 + t] = total.Z.v[q]; slot[(30 + q) * 64 + t] = total.T.v[q];
       }
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  if (part != 0) return;
 #pragma unroll 1
-    for (int i = 0; i < n; ++i) {
-      const int d = digits[i * 64 + t];
-      if (d != 0) {
-        const uint32_t* row = tbl + ((uint32_t)i * SMALL_TBL + (uint32_t)((d < 0 ? -d : d) - 1)) * EXT_WORDS;
-        ge_cached c;
+  for (int o = 1; o < parts; ++o) {
+    const uint32_t* slot = smem + (uint32_t)(o - 1) * 41 * 64;
+    if (slot[40 * 64 + t]) {
+      ge other;
 #pragma unroll
-        for (int q = 0; q < 10; ++q) { c.YpX.v[q] = row[q]; c.YmX.v[q] = row[10 + q]; c.Z2.v[q] = row[20 + q]; c.T2d.v[q] = row[30 + q]; }
-        if (!total_set) { ge_identity(total); total_set = true; }
-        ge_add_cached(total, total, c, d < 0);
+      for (int q = 0; q < 10; ++q) {
+        other.X.v[q] = slot[q * 64 + t]; other.Y.v[q] = slot[(10 + q) * 64 + t];
+        other.Z.v[q] = slot[(20 + q) * 64 + t]; other.T.v[q] = slot[(30 + q) * 64 + t];
       }
+      if (total_set) ge_add(total, total, other); else { total = other; total_set = true; }
     }
   }
   const uint64_t win = (uint64_t)m * 64 + t;

@@ -69,7 +69,11 @@ ZK_HD scm scm_sub(const scm& a, const scm& b) {
 ZK_HD scm scm_neg(const scm& a) { return scm_sub(scm_zero(), a); }
 
 // Montgomery product a * b / 2^256 mod l (CIOS).  a < 2^256, b < l  ->  result < l.
-ZK_HD scm scm_mul_raw(const uint32_t a[8], const uint32_t b[8]) {
+// (~400 instructions.  Measured: making this a real, non-inlined function is slower -- k_prepare
+// 0.30 -> 0.38 ms -- even though it shrinks that kernel from 150 KB to 19 KB of code.)
+ZK_HD scm scm_mul_core(const scm& av, const scm& bv) {
+  const uint32_t* a = av.v;
+  const uint32_t* b = bv.v;
   const uint32_t l[8] = ZK_SC_L;
   uint32_t t[10];
   ZK_UNROLL for (int i = 0; i < 10; ++i) t[i] = 0;
@@ -102,8 +106,13 @@ ZK_HD scm scm_mul_raw(const uint32_t a[8], const uint32_t b[8]) {
   return r;
 }
 
-ZK_HD scm scm_mul(const scm& a, const scm& b) { return scm_mul_raw(a.v, b.v); }
-ZK_HD scm scm_sq(const scm& a) { return scm_mul_raw(a.v, a.v); }
+ZK_HD scm scm_mul_raw(const uint32_t a[8], const uint32_t b[8]) {
+  scm x, y;
+  ZK_UNROLL for (int i = 0; i < 8; ++i) { x.v[i] = a[i]; y.v[i] = b[i]; }
+  return scm_mul_core(x, y);
+}
+ZK_HD scm scm_mul(const scm& a, const scm& b) { return scm_mul_core(a, b); }
+ZK_HD scm scm_sq(const scm& a) { return scm_mul_core(a, a); }
 
 // plain little-endian words (any value < 2^256) -> Montgomery form of (value mod l)
 ZK_HD scm scm_from_words(const uint32_t w[8]) {

@@ -60,6 +60,7 @@ struct zkgpu_ctx {
   // latency-bound kernels; `stream` / `stream2` carry the chip-filling ones and may be SHARED with
   // the contexts forked from this one (zkgpu_ctx_fork), so that those run first-in first-out
   hipStream_t stream_l = nullptr;
+  hipStream_t stream3 = nullptr;        // shared like stream/stream2: the scalar preparation (k_prepare)
   bool owns_streams = true;
   hipEvent_t ev_t = nullptr, ev_p = nullptr, ev_sm = nullptr, ev_sa = nullptr, ev_done = nullptr;
   bool pending = false;            // a submitted batch has not been waited for yet
@@ -74,6 +75,7 @@ struct zkgpu_ctx {
   Buffer dyn_rows, bins, block_sums, entries, buckets, partials, partial_flags, window_sums, window_flags;
   Buffer msm_fail, status, accept, bitmap, ok_bytes, values, uniform;
   Buffer digits, st_partials, dynsum, accept2, bin_order, class_count, part_hist, part_entries, part_lo, dec_scratch, heavy;
+  Buffer small_tbl, recoded;
   Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
   int forced_parts = 0;
   void* pinned = nullptr;   // host staging for results
@@ -161,6 +163,14 @@ void prof_collect(zkgpu_ctx* c) {
   }
   c->ev_used.clear();
   c->ev_next = 0;
+}
+
+// wavefronts per MSM in k_small_accumulate: about three per SIMD (1024 SIMDs) over the whole launch;
+// ZKGPU_SMALL_PARTS overrides for experiments
+inline int small_parts(uint64_t B) {
+  static const int forced = [] { const char* e = getenv("ZKGPU_SMALL_PARTS"); return e ? atoi(e) : 0; }();
+  if (forced >= 1 && forced <= 4) return forced;
+  return (int)std::max<uint64_t>(1, std::min<uint64_t>(4, (3072 + B / 2) / std::max<uint64_t>(B, 1)));
 }
 
 inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
@@ -469,6 +479,27 @@ int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap, uint8_t* 
   return ZKGPU_OK;
 }
 
+// window sums of many small MSMs (few proof-specific points each): see kernels.hpp, k_small_tables
+int small_msm_launch(zkgpu_ctx* c, const Job& job, hipStream_t st) {
+  const size_t B = job.n_msm;
+  TRY(ensure(c, c->small_tbl, std::max<uint64_t>(job.n_dyn, 1) * SMALL_TBL * EXT_WORDS * 4));
+  TRY(ensure(c, c->recoded, std::max<uint64_t>(job.n_dyn, 1) * 32));
+  {
+    Launch l(c, "k_small_tables", st);
+    hipLaunchKernelGGL(k_small_tables, dim3(blocks_for(job.n_dyn, 64)), dim3(64), 0, st, job.d_dyn_scalars,
+                       (const uint32_t*)c->dyn_rows.p, job.n_dyn, (uint32_t*)c->small_tbl.p, (uint32_t*)c->recoded.p,
+                       (uint32_t*)c->status.p);
+  }
+  {
+    Launch l(c, "k_small_accumulate", st);
+    const int parts = small_parts(B);
+    hipLaunchKernelGGL(k_small_accumulate, dim3((unsigned)B), dim3(64 * parts), (size_t)(parts - 1) * 41 * 64 * 4, st,
+                       (const uint32_t*)c->recoded.p, job.d_dyn_offsets, (const uint32_t*)c->small_tbl.p, (uint32_t)B,
+                       (uint32_t*)c->window_sums.p, (uint32_t*)c->window_flags.p);
+  }
+  return ZKGPU_OK;
+}
+
 // Batch path when the point set carries fixed-base tables: generator terms are
 // summed straight out of the tables (no sort, no buckets, no doublings); only
 // the proof-specific terms go through the Pippenger pipeline.
@@ -519,14 +550,7 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
                            (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, (uint32_t)B,
                            (uint32_t*)c->msm_fail.p, (unsigned long long*)((char*)c->status.p + 8), (uint8_t*)nullptr);
       }
-      {
-        Launch l(c, "k_small_msm_windows");
-        const int chunk = (int)std::min<uint64_t>(64, std::max<uint64_t>(8, ((job.n_dyn + B - 1) / B + 3) / 4 * 4));
-        hipLaunchKernelGGL(k_small_msm_windows, dim3((unsigned)B), dim3(64),
-                           (size_t)chunk * (SMALL_TBL * EXT_WORDS * 4 + 64), s, job.d_dyn_scalars, job.d_dyn_offsets,
-                           (const uint32_t*)c->dyn_rows.p, (uint32_t)B, (uint32_t*)c->window_sums.p,
-                           (uint32_t*)c->window_flags.p, (uint32_t*)c->status.p, chunk);
-      }
+      TRY(small_msm_launch(c, job, s));
     } else {
       TRY(run_to_windows(c, dj, jd, /*reset_status=*/false));
     }
@@ -643,15 +667,17 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     }
   }
   HIP_TRY(c, hipEventRecord(c->ev_t, L));
-  HIP_TRY(c, hipStreamWaitEvent(H1, c->ev_t, 0));
   if (prep) {
-    Launch l(c, "k_prepare", H1);
-    hipLaunchKernelGGL(k_prepare, dim3((unsigned)B), dim3(256), prep->lds_bytes, H1, prep->sh, prep->d_mono_chal,
+    hipStream_t H3 = c->stream3;
+    HIP_TRY(c, hipStreamWaitEvent(H3, c->ev_t, 0));
+    Launch l(c, "k_prepare", H3);
+    hipLaunchKernelGGL(k_prepare, dim3((unsigned)B), dim3(256), prep->lds_bytes, H3, prep->sh, prep->d_mono_chal,
                        prep->d_mono_pow, prep->d_tgt_off, prep->d_term_q, prep->d_term_mono, prep->d_term_coef,
                        (const uint32_t*)c->prep_ch.p, prep->d_com, (const uint32_t*)c->prep_pw.p,
                        (uint32_t*)c->prep_dyn_sc.p, (uint32_t*)c->prep_dyn_pt.p, (uint32_t*)c->prep_st_sc.p);
   }
-  HIP_TRY(c, hipEventRecord(c->ev_p, H1));
+  HIP_TRY(c, hipEventRecord(c->ev_p, prep ? c->stream3 : L));
+  HIP_TRY(c, hipStreamWaitEvent(H1, c->ev_p, 0));
   HIP_TRY(c, hipStreamWaitEvent(H2, c->ev_p, 0));
   {
     Launch l(c, "k_static_digits", H2);
@@ -671,13 +697,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
                        (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, (uint32_t)B, (uint32_t*)c->msm_fail.p,
                        (unsigned long long*)((char*)c->status.p + 8), (uint8_t*)nullptr);
   }
-  {
-    Launch l(c, "k_small_msm_windows", H1);
-    const int chunk = (int)std::min<uint64_t>(64, std::max<uint64_t>(8, ((job.n_dyn + B - 1) / B + 3) / 4 * 4));
-    hipLaunchKernelGGL(k_small_msm_windows, dim3((unsigned)B), dim3(64), (size_t)chunk * (SMALL_TBL * EXT_WORDS * 4 + 64),
-                       H1, job.d_dyn_scalars, job.d_dyn_offsets, (const uint32_t*)c->dyn_rows.p, (uint32_t)B,
-                       (uint32_t*)c->window_sums.p, (uint32_t*)c->window_flags.p, (uint32_t*)c->status.p, chunk);
-  }
+  TRY(small_msm_launch(c, job, H1));
   HIP_TRY(c, hipEventRecord(c->ev_sm, H1));
   HIP_TRY(c, hipStreamWaitEvent(L, c->ev_sm, 0));
   {
@@ -791,17 +811,17 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
   if (parent) {
     c->stream = parent->stream;
     c->stream2 = parent->stream2;
+    c->stream3 = parent->stream3;
     c->owns_streams = false;
   } else {
     ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
-         hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess;
+         hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
+         hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   }
   ok = ok && hipStreamCreateWithPriority(&c->stream_l, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   hipEvent_t* evs[] = {&c->ev_fork, &c->ev_join, &c->ev_t, &c->ev_p, &c->ev_sm, &c->ev_sa, &c->ev_done};
   for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   if (!ok) { delete c; return ZKGPU_EHIP; }
-  (void)hipFuncSetAttribute((const void*)k_small_msm_windows, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            64 * SMALL_TBL * EXT_WORDS * 4 + 64 * 64);
   *out = c;
   return ZKGPU_OK;
 }
@@ -854,12 +874,13 @@ void zkgpu_destroy(zkgpu_ctx* c) {
   DeviceGuard g(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->stream_l) (void)hipStreamSynchronize(c->stream_l);
   Buffer* bufs[] = {&c->in_scalars, &c->in_points, &c->in_offsets, &c->in_st_scalars, &c->in_st_index,
                     &c->in_st_offsets, &c->dyn_rows, &c->bins, &c->block_sums, &c->entries, &c->buckets,
                     &c->partials, &c->partial_flags, &c->window_sums, &c->window_flags, &c->msm_fail,
                     &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform,
-                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->prep_com, &c->prep_proofs, &c->prep_r,
+                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->small_tbl, &c->recoded, &c->prep_com, &c->prep_proofs, &c->prep_r,
                     &c->prep_pw, &c->prep_ch, &c->prep_wf, &c->prep_dyn_sc, &c->prep_dyn_pt, &c->prep_st_sc};
   for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -867,6 +888,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
   if (c->owns_streams) {
     (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
   }
   if (c->stream_l) (void)hipStreamDestroy(c->stream_l);
   hipEvent_t evs[] = {c->ev_fork, c->ev_join, c->ev_t, c->ev_p, c->ev_sm, c->ev_sa, c->ev_done};
