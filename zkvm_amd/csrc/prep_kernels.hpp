@@ -179,8 +179,20 @@ k_transcript(PrepShape sh, const uint32_t* __restrict__ init_state /*50 words + 
 }
 
 // ---- k_prepare ------------------------------------------------------------------------------
-// LDS (words): chs[n_ch*8] | sym[n_mono*8] | wv[n_targets*8] | A: zpow[n_cons*8] tv[n_terms*8]
-// and, once the flattening is done, the same region A again as yip[pn*8] sv[pn*8] red[256*8]
+// LDS (8-word slots): chs[n_ch] | sym[n_mono] | wv[n_targets] | strides[PREP_STRIDES] | zpow[n_cons] |
+// region A: tv[n_terms + 32], and once the flattening is done yip[pn] sv[pn] red[256] in its place.
+//
+// Power tables are built by doubling (entry q + 2^L = entry q * stride_L, one product per entry)
+// instead of one square-and-multiply per entry, and y^-i is kept in PLAIN form: a Montgomery
+// product with one plain operand yields a plain result, so the generator scalars come out as
+// canonical words without a conversion product of their own.
+constexpr uint32_t PREP_STRIDES = 64;   // z^(2^L) [0..15] | y^-(2^L) [16..31] | u_j^2 [32..47] | (spare)
+
+__host__ __device__ inline size_t prepare_lds_slots(const PrepShape& sh) {
+  const size_t tv = (size_t)sh.n_terms + 32, second = (size_t)2 * sh.pn + 256;
+  return (size_t)sh.n_ch + sh.n_mono + sh.n_targets + PREP_STRIDES + sh.n_cons + (tv > second ? tv : second);
+}
+
 __global__ void __launch_bounds__(256)
 k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* __restrict__ mono_pow,
           const uint32_t* __restrict__ tgt_off, const uint32_t* __restrict__ term_q,
@@ -191,48 +203,74 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   uint32_t* chs = lds;
   uint32_t* sym = chs + sh.n_ch * 8;
   uint32_t* wv = sym + sh.n_mono * 8;
-  uint32_t* zpow = wv + sh.n_targets * 8;      // region A, first life
-  uint32_t* tv = zpow + sh.n_cons * 8;
-  uint32_t* yip = zpow;                          // region A, second life
+  uint32_t* zs = wv + sh.n_targets * 8;         // z^(2^L)
+  uint32_t* ys = zs + 16 * 8;                    // y^-(2^L)
+  uint32_t* us2 = ys + 16 * 8;                   // u_j^2
+  uint32_t* zpow = zs + PREP_STRIDES * 8;
+  uint32_t* tv = zpow + sh.n_cons * 8;           // region A, first life
+  uint32_t* yip = tv;                            // region A, second life
   uint32_t* sv = yip + sh.pn * 8;
   uint32_t* red = sv + sh.pn * 8;
   const uint32_t tx = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  const uint32_t uj0 = CH_FIXED + sh.n_chal2;    // slots of u_j, then 1/u_j
 
   for (uint32_t i = t; i < sh.n_ch * 8; i += nt) chs[i] = ch[(uint64_t)tx * sh.n_ch * 8 + i];
   __syncthreads();
-  scm z, y_inv;
-  ld_scm(z, chs + 1 * 8);
-  ld_scm(y_inv, chs + 5 * 8);
-  // monomials: challenge^power
-  for (uint32_t j = t; j < sh.n_mono; j += nt) {
-    scm v = scm_one();
-    if (mono_chal[j] != 0xffffffffu) {
-      scm c;
-      ld_scm(c, chs + (CH_FIXED + mono_chal[j]) * 8);
-      v = scm_pow_u32(c, mono_pow[j]);
-    }
-    st_scm(sym + 8 * j, v);
-  }
-  // z^(q+1), y^-i, s_i
-  {
-    const scm zt = scm_pow_u32(z, t + 1);
-    if (t < sh.n_cons) st_scm(zpow + 8 * t, zt);
-    if (sh.n_cons > nt) {
-      const scm zstep = scm_pow_u32(z, nt);
-      scm cur = zt;
-      for (uint32_t q = t + nt; q < sh.n_cons; q += nt) { cur = scm_mul(cur, zstep); st_scm(zpow + 8 * q, cur); }
+  // phase A: the serial bits, one wavefront each: stride chains for z and 1/y, u_j^2, the monomials
+  if (t == 0) {
+    scm c;
+    ld_scm(c, chs + 1 * 8);
+    st_scm(zpow, c);
+    st_scm(zs, c);
+    uint32_t levels = 0;
+    while ((1u << levels) < sh.n_cons) ++levels;
+#pragma unroll 1
+    for (uint32_t L = 1; L < levels; ++L) { c = scm_sq(c); st_scm(zs + 8 * L, c); }
+  } else if (t == 64) {
+    scm c;
+    ld_scm(c, chs + 5 * 8);
+    st_scm(ys, c);
+#pragma unroll 1
+    for (uint32_t L = 1; L < sh.k; ++L) { c = scm_sq(c); st_scm(ys + 8 * L, c); }
+  } else if (t >= 128 && t < 128 + sh.k) {
+    scm c;
+    ld_scm(c, chs + (uj0 + (t - 128)) * 8);
+    st_scm(us2 + 8 * (t - 128), scm_sq(c));
+  } else if (t >= 192) {
+    for (uint32_t j = t - 192; j < sh.n_mono; j += 64) {
+      scm v = scm_one();
+      if (mono_chal[j] != 0xffffffffu) {
+        scm c;
+        ld_scm(c, chs + (CH_FIXED + mono_chal[j]) * 8);
+        v = scm_pow_u32(c, mono_pow[j]);
+      }
+      st_scm(sym + 8 * j, v);
     }
   }
   __syncthreads();
-  // plan replay: one product per term, then one sum per target
+  // phase B: zpow[q] = z^(q+1) by doubling
+#pragma unroll 1
+  for (uint32_t L = 0, half = 1; half < sh.n_cons; ++L, half <<= 1) {
+    const uint32_t end = min(2 * half, sh.n_cons);
+    for (uint32_t q = half + t; q < end; q += nt) {
+      scm a, b;
+      ld_scm(a, zpow + 8 * (q - half));
+      ld_scm(b, zs + 8 * L);
+      st_scm(zpow + 8 * q, scm_mul(a, b));
+    }
+    __syncthreads();
+  }
+  // phase C: plan replay, one product per term (two when a second-phase challenge is involved) ...
   for (uint32_t e = t; e < sh.n_terms; e += nt) {
-    scm c, m, zq;
+    scm c, zq;
     ld_scm(c, term_coef + 8 * (uint64_t)e);
-    ld_scm(m, sym + 8 * term_mono[e]);
     ld_scm(zq, zpow + 8 * term_q[e]);
-    st_scm(tv + 8 * e, scm_mul(scm_mul(c, m), zq));
+    const uint32_t mi = term_mono[e];
+    if (mi != 0) { scm m; ld_scm(m, sym + 8 * mi); c = scm_mul(c, m); }
+    st_scm(tv + 8 * e, scm_mul(c, zq));
   }
   __syncthreads();
+  // ... then one sum per target
   for (uint32_t g = t; g < sh.n_targets; g += nt) {
     bool heavy = false;
     for (uint32_t hI = 0; hI < sh.n_heavy; ++hI) heavy |= (sh.heavy[hI] == g);
@@ -242,7 +280,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     st_scm(wv + 8 * g, acc);
   }
   // heavy targets: every lane sums a strided share, wavefront shuffles fold the lanes, lane 0 of
-  // each wave parks its sum in wv-adjacent scratch (the tail of tv is free: use 4 slots after n_terms)
+  // each wave parks its sum in the free tail of tv (4 slots per heavy target after n_terms)
   for (uint32_t hI = 0; hI < sh.n_heavy; ++hI) {
     const uint32_t g = sh.heavy[hI];
     scm acc = scm_zero();
@@ -264,32 +302,46 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     }
   }
   __syncthreads();
-  // region A is dead now: y^-i and s_i take its place
-  for (uint32_t i = t; i < sh.pn; i += nt) {
-    st_scm(yip + 8 * i, scm_pow_u32(y_inv, i));
-    // s_i = prod_j (bit (k-1-j) of i ? u_j : 1/u_j): the first challenge pairs with the top bit
-    scm s = scm_one();
-    for (uint32_t j = 0; j < sh.k; ++j) {
-      scm f;
-      const bool bit = (i >> (sh.k - 1 - j)) & 1;
-      ld_scm(f, chs + (CH_FIXED + sh.n_chal2 + (bit ? j : sh.k + j)) * 8);
-      s = scm_mul(s, f);
-    }
-    st_scm(sv + 8 * i, s);
+  // phase E (region A is dead): yip[i] = y^-i in plain form, sv[i] = s_i (Montgomery), by doubling:
+  // setting bit L of i turns the factor 1/u_j of s_i, j = k-1-L, into u_j
+  if (t == 0) {
+    scm one_plain = scm_zero();
+    one_plain.v[0] = 1;
+    st_scm(yip, one_plain);
+    scm s0;
+    ld_scm(s0, chs + 6 * 8);
+    st_scm(sv, s0);
   }
   __syncthreads();
+#pragma unroll 1
+  for (uint32_t L = 0, half = 1; half < sh.pn; ++L, half <<= 1) {
+    for (uint32_t idx = t; idx < 2 * half; idx += nt) {
+      scm a, b;
+      if (idx < half) {
+        ld_scm(a, yip + 8 * idx);
+        ld_scm(b, ys + 8 * L);
+        st_scm(yip + 8 * (idx + half), scm_mul(a, b));
+      } else {
+        const uint32_t i = idx - half;
+        ld_scm(a, sv + 8 * i);
+        ld_scm(b, us2 + 8 * (sh.k - 1 - L));
+        st_scm(sv + 8 * (i + half), scm_mul(a, b));
+      }
+    }
+    __syncthreads();
+  }
   const uint32_t* wL = wv;
   const uint32_t* wR = wv + sh.n * 8;
   const uint32_t* wO = wv + 2 * sh.n * 8;
   const uint32_t* wV = wv + 3 * sh.n * 8;
   const uint32_t* wc = wV + sh.m * 8;
-  // delta = sum_{i<n} y^-i wR_i wL_i  (block reduction in LDS)
+  // delta = sum_{i<n} y^-i wR_i wL_i  (plain partial sums, block reduction in LDS)
   {
     scm part = scm_zero();
     for (uint32_t i = t; i < sh.n; i += nt) {
       scm a, b, c;
       ld_scm(a, yip + 8 * i); ld_scm(b, wR + 8 * i); ld_scm(c, wL + 8 * i);
-      part = scm_add(part, scm_mul(scm_mul(a, b), c));
+      part = scm_add(part, scm_mul(scm_mul(b, c), a));
     }
     st_scm(red + 8 * t, part);
     __syncthreads();
@@ -299,7 +351,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     }
   }
   scm delta, x, u, r, a_, b_, w_, t_x, t_x_bl, e_bl;
-  ld_scm(delta, red);
+  delta = scm_from_words(red);                  // plain sum -> Montgomery
   ld_scm(u, chs + 2 * 8); ld_scm(x, chs + 3 * 8); ld_scm(w_, chs + 4 * 8); ld_scm(r, chs + 7 * 8);
   ld_scm(t_x, chs + 8 * 8); ld_scm(t_x_bl, chs + 9 * 8); ld_scm(e_bl, chs + 10 * 8);
   ld_scm(a_, chs + 11 * 8); ld_scm(b_, chs + 12 * 8);
@@ -310,19 +362,30 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   const uint32_t* p = pw + (uint64_t)tx * sh.proof_words;
   const uint32_t* c = com + (uint64_t)tx * sh.m * 8;
   const uint32_t* lr = p + 112;
-  // generator scalars
-  for (uint32_t i = t; i < sh.pn; i += nt) {
-    scm yi, si, sr, g, h, wl = scm_zero(), wr = scm_zero(), wo = scm_zero();
-    ld_scm(yi, yip + 8 * i); ld_scm(si, sv + 8 * i); ld_scm(sr, sv + 8 * (sh.pn - 1 - i));
-    if (i < sh.n) { ld_scm(wl, wL + 8 * i); ld_scm(wr, wR + 8 * i); ld_scm(wo, wO + 8 * i); }
-    g = scm_sub(scm_mul(x, scm_mul(wr, yi)), scm_mul(a_, si));
-    h = scm_sub(scm_mul(yi, scm_sub(scm_add(scm_mul(x, wl), wo), scm_mul(b_, sr))), scm_one());
-    if (i >= sh.n1) { g = scm_mul(g, u); h = scm_mul(h, u); }
-    uint32_t o[8];
-    scm_to_words(o, g);
-    for (int q = 0; q < 8; ++q) ss[(2 + i) * 8 + q] = o[q];
-    scm_to_words(o, h);
-    for (int q = 0; q < 8; ++q) ss[(2 + sh.pn + i) * 8 + q] = o[q];
+  // generator scalars, canonical words straight out of the products (plain operand: yip, a_plain):
+  //   g_i = x wR_i y^-i - a s_i            h_i = y^-i (x wL_i + wO_i - b s_{pn-1-i}) - 1      (times u for i >= n1)
+  {
+    scm a_plain, one_plain = scm_zero();
+    one_plain.v[0] = 1;
+    scm_to_words(a_plain.v, a_);
+    for (uint32_t i = t; i < sh.pn; i += nt) {
+      scm yp, si, sr;
+      ld_scm(yp, yip + 8 * i); ld_scm(si, sv + 8 * i); ld_scm(sr, sv + 8 * (sh.pn - 1 - i));
+      scm g = scm_neg(scm_mul(a_plain, si));
+      scm inner = scm_neg(scm_mul(b_, sr));
+      if (i < sh.n) {
+        scm wl, wr, wo;
+        ld_scm(wl, wL + 8 * i); ld_scm(wr, wR + 8 * i); ld_scm(wo, wO + 8 * i);
+        g = scm_add(g, scm_mul(scm_mul(x, wr), yp));
+        inner = scm_add(inner, scm_add(scm_mul(x, wl), wo));
+      }
+      scm h = scm_sub(scm_mul(yp, inner), one_plain);
+      if (i >= sh.n1) { g = scm_mul(g, u); h = scm_mul(h, u); }
+      uint4* og = reinterpret_cast<uint4*>(ss + (2 + i) * 8);
+      uint4* oh = reinterpret_cast<uint4*>(ss + (2 + sh.pn + i) * 8);
+      og[0] = make_uint4(g.v[0], g.v[1], g.v[2], g.v[3]); og[1] = make_uint4(g.v[4], g.v[5], g.v[6], g.v[7]);
+      oh[0] = make_uint4(h.v[0], h.v[1], h.v[2], h.v[3]); oh[1] = make_uint4(h.v[4], h.v[5], h.v[6], h.v[7]);
+    }
   }
   // proof-point scalars (and B, B_blinding), one lane each
   if (t < sh.n_dyn + 2) {

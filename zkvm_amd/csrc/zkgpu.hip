@@ -1263,8 +1263,7 @@ int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t 
   s.n_heavy = 0;
   for (uint32_t t = 0; t < s.n_targets && s.n_heavy < 8; ++t)
     if (h.tgt_off[t + 1] - h.tgt_off[t] > 24) s.heavy[s.n_heavy++] = t;
-  const size_t region_a = std::max<size_t>((size_t)s.n_cons + s.n_terms + 4 * 8, (size_t)2 * s.pn + 256);
-  p->lds_bytes = ((size_t)s.n_ch + s.n_mono + s.n_targets + region_a) * 32;
+  p->lds_bytes = prepare_lds_slots(s) * 32;
   if (p->lds_bytes > 160 * 1024) { delete p; c->last_error = "plan does not fit the 160 KiB LDS of a CU"; return ZKGPU_EINVAL; }
   // STROBE state after Transcript::new("ZkVM.r1cs") + r1cs_domain_sep()
   Transcript tr("ZkVM.r1cs");
