@@ -195,9 +195,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="transactions per GPU")
-    ap.add_argument("--table-bits", type=int, default=int(os.environ.get("ZKGPU_TABLE_BITS", "13")),
+    ap.add_argument("--table-bits", type=int, default=int(os.environ.get("ZKGPU_TABLE_BITS", "16")),
                     help="window width of the fixed-base generator tables (0 = no tables: Pippenger for every term)")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKGPU_INFLIGHT", "3")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKGPU_INFLIGHT", "4")),
                     help="independent verify calls in flight per GPU (contexts x host threads)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-msm", action="store_true", help="skip the 2^20 MSM microbench")

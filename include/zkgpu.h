@@ -89,7 +89,8 @@ size_t zkgpu_pointset_size(const zkgpu_pointset *ps);
  * ((255/w + 1) * n * 2^(w-1) rows of 128 B; w = 12, n = 514: 2.96 GB).  With
  * tables present zkgpu_verify_batch_ps* sums static terms straight out of them:
  * one mixed addition per term and window, no doublings, no sorting.  One-time
- * cost of tens of milliseconds; results are identical with or without tables. */
+ * cost of tens of milliseconds (seconds at 16 bits, whose tables take 50 MB per point);
+ * results are identical with or without tables.  2 <= window_bits <= 16. */
 int zkgpu_pointset_build_tables(zkgpu_ctx *ctx, zkgpu_pointset *ps, int window_bits);
 size_t zkgpu_pointset_table_bytes(const zkgpu_pointset *ps);
 

@@ -241,7 +241,7 @@ def test_msm_batch_values_vs_oracle(ctx, oracle):
     assert bits(ok, len(sizes)) == [1, 1, 1, 0, 1, 1, 1]
 
 
-@pytest.mark.parametrize("w", [4, 7, 9])
+@pytest.mark.parametrize("w", [4, 7, 9, 16])
 def test_fixed_base_tables_equal_generic_path(ctx, oracle, w):
     """Generator terms summed out of the fixed-base window tables must give the same accept bits as the
     Pippenger path and as the oracle -- ragged rows, index lists, zero / edge scalars, bad dynamic points."""
@@ -257,7 +257,9 @@ def test_fixed_base_tables_equal_generic_path(ctx, oracle, w):
     for i in range(B):
         cnt = rng.choice([0, 1, 5, n_gen])
         idx = rng.sample(range(n_gen), cnt)
-        ks = [rng.choice([0, 1, L - 1, 2**252 - 1, rng.randrange(L), rng.randrange(L)]) for _ in idx]
+        # 0x7fffffff / 0x8000...: digits of exactly +2^(w-1) at w = 16 (stored wrapped in the int16 digit array)
+        ks = [rng.choice([0, 1, L - 1, 2**252 - 1, 0x7FFFFFFF, 0x8000800080008000 << 64, rng.randrange(L), rng.randrange(L)])
+              for _ in idx]
         pts = [oracle.decode(gens[32 * j: 32 * j + 32]) for j in idx]
         tot = oracle.encode(oracle.msm_points("vartime", ks, pts)) if cnt else bytes(32)
         kind = i % 6

@@ -1091,7 +1091,8 @@ k_static_accumulate(const int16_t* __restrict__ digits, const uint64_t* __restri
   ge acc;
   ge_identity(acc);
   auto fetch = [&](uint64_t k, ge_niels& q, bool& neg) {
-    const int d = dig[k];
+    int d = dig[k];
+    d = (d == -32768) ? 32768 : d;   // w = 16: +2^15 is stored wrapped (the recoding never yields -2^15)
     const uint32_t idx = st_index ? st_index[k] : (uint32_t)(k - k0);
     const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
     const uint32_t* row = table + ((tbase + idx) * H + (mag ? mag - 1 : 0)) * TABLE_WORDS;

@@ -27,7 +27,15 @@ struct PrepShape {
   uint32_t n_dyn, n_static; // 11 + m + 2k, 2 + 2 pn
   uint32_t n_heavy;         // targets with many terms (e.g. wc) are summed by the whole workgroup
   uint32_t heavy[8];
+  // slots per transaction in the challenge buffer: n_ch challenges | n_mono monomials | PREP_STRIDES
+  uint32_t n_ch_ext;
+  // the flattening runs in n_chunks passes over target ranges [chunk_tgt[i], chunk_tgt[i+1]) so that the
+  // per-term products of one pass fit tv_cap LDS slots
+  uint32_t n_chunks, tv_cap;
+  uint32_t chunk_tgt[6];
 };
+
+constexpr uint32_t PREP_STRIDES = 48;   // z^(2^L) [0..15] | y^-(2^L) [16..31] | u_j^2 [32..47]
 
 __device__ __forceinline__ void ld_scm(scm& s, const uint32_t* p) {
 #pragma unroll
@@ -75,7 +83,8 @@ __global__ void __launch_bounds__(64)
 k_transcript(PrepShape sh, const uint32_t* __restrict__ init_state /*50 words + pos + pos_begin*/,
              const uint8_t* __restrict__ chal_label, const uint32_t* __restrict__ com /*[B][m][8]*/,
              const uint32_t* __restrict__ pw /*[B][proof_words]*/, const uint32_t* __restrict__ rbytes /*[B][16]*/,
-             uint32_t batch, uint32_t* __restrict__ ch /*[B][n_ch][8]*/, uint32_t* __restrict__ wellformed) {
+             uint32_t batch, uint32_t* __restrict__ ch /*[B][n_ch_ext][8]*/, uint32_t* __restrict__ wellformed,
+             const uint32_t* __restrict__ mono_chal, const uint32_t* __restrict__ mono_pow) {
   __shared__ uint32_t lds[52 * 64];
   const uint32_t lane = threadIdx.x;
   const uint32_t tx_raw = blockIdx.x * 64 + lane;
@@ -89,7 +98,7 @@ k_transcript(PrepShape sh, const uint32_t* __restrict__ init_state /*50 words + 
   s.pos_begin = init_state[51];
   const uint32_t* c = com + (uint64_t)tx * sh.m * 8;
   const uint32_t* p = pw + (uint64_t)tx * sh.proof_words;
-  uint32_t* out = ch + (uint64_t)tx * sh.n_ch * 8;
+  uint32_t* out = ch + (uint64_t)tx * sh.n_ch_ext * 8;
   bool ok = true;
 
   for (uint32_t i = 0; i < sh.m; ++i) s.append_message_words("V", 1, c + 8 * i, 8);
@@ -175,22 +184,48 @@ k_transcript(PrepShape sh, const uint32_t* __restrict__ init_state /*50 words + 
   scm allinv = scm_one();
   for (uint32_t j = 0; j < sh.k; ++j) { scm t; ld_scm(t, ujinv + 8 * j); allinv = scm_mul(allinv, t); }
   st_scm(out + 6 * 8, allinv);
+  // the serial chains k_prepare needs, done here where every lane has one to do: second-phase
+  // monomials, z^(2^L), y^-(2^L), u_j^2
+  uint32_t* sym = out + sh.n_ch * 8;
+  uint32_t* strides = sym + sh.n_mono * 8;
+#pragma unroll 1
+  for (uint32_t j = 0; j < sh.n_mono; ++j) {
+    scm v = scm_one();
+    if (mono_chal[j] != 0xffffffffu) {
+      scm c;
+      ld_scm(c, out + (CH_FIXED + mono_chal[j]) * 8);
+      v = scm_pow_u32(c, mono_pow[j]);
+    }
+    st_scm(sym + 8 * j, v);
+  }
+  {
+    scm c;
+    ld_scm(c, out + 1 * 8);
+    st_scm(strides, c);
+#pragma unroll 1
+    for (uint32_t L = 1; (1u << L) < sh.n_cons; ++L) { c = scm_sq(c); st_scm(strides + 8 * L, c); }
+    c = inv;                                     // 1 / y
+    st_scm(strides + 16 * 8, c);
+#pragma unroll 1
+    for (uint32_t L = 1; L < sh.k; ++L) { c = scm_sq(c); st_scm(strides + (16 + L) * 8, c); }
+#pragma unroll 1
+    for (uint32_t j = 0; j < sh.k; ++j) { ld_scm(c, uj + 8 * j); st_scm(strides + (32 + j) * 8, scm_sq(c)); }
+  }
   if (live && !ok) atomicAnd(&wellformed[tx], 0u);
 }
 
 // ---- k_prepare ------------------------------------------------------------------------------
-// LDS (8-word slots): chs[n_ch] | sym[n_mono] | wv[n_targets] | strides[PREP_STRIDES] | zpow[n_cons] |
-// region A: tv[n_terms + 32], and once the flattening is done yip[pn] sv[pn] red[256] in its place.
+// LDS (8-word slots): chs[n_ch] | sym[n_mono] | strides[PREP_STRIDES] (these three straight from
+// k_transcript) | wv[n_targets] | region A: zpow[n_cons] tv[tv_cap + 32], and once the flattening is
+// done yip[pn] sv[pn] red[8] in its place.
 //
 // Power tables are built by doubling (entry q + 2^L = entry q * stride_L, one product per entry)
 // instead of one square-and-multiply per entry, and y^-i is kept in PLAIN form: a Montgomery
 // product with one plain operand yields a plain result, so the generator scalars come out as
 // canonical words without a conversion product of their own.
-constexpr uint32_t PREP_STRIDES = 64;   // z^(2^L) [0..15] | y^-(2^L) [16..31] | u_j^2 [32..47] | (spare)
-
 __host__ __device__ inline size_t prepare_lds_slots(const PrepShape& sh) {
-  const size_t tv = (size_t)sh.n_terms + 32, second = (size_t)2 * sh.pn + 256;
-  return (size_t)sh.n_ch + sh.n_mono + sh.n_targets + PREP_STRIDES + sh.n_cons + (tv > second ? tv : second);
+  const size_t first = (size_t)sh.n_cons + sh.tv_cap + 32, second = (size_t)2 * sh.pn + 8;
+  return (size_t)sh.n_ch_ext + sh.n_targets + (first > second ? first : second);
 }
 
 __global__ void __launch_bounds__(256)
@@ -202,51 +237,20 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* chs = lds;
   uint32_t* sym = chs + sh.n_ch * 8;
-  uint32_t* wv = sym + sh.n_mono * 8;
-  uint32_t* zs = wv + sh.n_targets * 8;         // z^(2^L)
+  uint32_t* zs = sym + sh.n_mono * 8;           // z^(2^L)
   uint32_t* ys = zs + 16 * 8;                    // y^-(2^L)
   uint32_t* us2 = ys + 16 * 8;                   // u_j^2
-  uint32_t* zpow = zs + PREP_STRIDES * 8;
-  uint32_t* tv = zpow + sh.n_cons * 8;           // region A, first life
-  uint32_t* yip = tv;                            // region A, second life
+  uint32_t* wv = chs + sh.n_ch_ext * 8;
+  uint32_t* zpow = wv + sh.n_targets * 8;        // region A, first life
+  uint32_t* tv = zpow + sh.n_cons * 8;
+  uint32_t* yip = zpow;                          // region A, second life
   uint32_t* sv = yip + sh.pn * 8;
   uint32_t* red = sv + sh.pn * 8;
   const uint32_t tx = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
-  const uint32_t uj0 = CH_FIXED + sh.n_chal2;    // slots of u_j, then 1/u_j
 
-  for (uint32_t i = t; i < sh.n_ch * 8; i += nt) chs[i] = ch[(uint64_t)tx * sh.n_ch * 8 + i];
+  for (uint32_t i = t; i < sh.n_ch_ext * 8; i += nt) chs[i] = ch[(uint64_t)tx * sh.n_ch_ext * 8 + i];
   __syncthreads();
-  // phase A: the serial bits, one wavefront each: stride chains for z and 1/y, u_j^2, the monomials
-  if (t == 0) {
-    scm c;
-    ld_scm(c, chs + 1 * 8);
-    st_scm(zpow, c);
-    st_scm(zs, c);
-    uint32_t levels = 0;
-    while ((1u << levels) < sh.n_cons) ++levels;
-#pragma unroll 1
-    for (uint32_t L = 1; L < levels; ++L) { c = scm_sq(c); st_scm(zs + 8 * L, c); }
-  } else if (t == 64) {
-    scm c;
-    ld_scm(c, chs + 5 * 8);
-    st_scm(ys, c);
-#pragma unroll 1
-    for (uint32_t L = 1; L < sh.k; ++L) { c = scm_sq(c); st_scm(ys + 8 * L, c); }
-  } else if (t >= 128 && t < 128 + sh.k) {
-    scm c;
-    ld_scm(c, chs + (uj0 + (t - 128)) * 8);
-    st_scm(us2 + 8 * (t - 128), scm_sq(c));
-  } else if (t >= 192) {
-    for (uint32_t j = t - 192; j < sh.n_mono; j += 64) {
-      scm v = scm_one();
-      if (mono_chal[j] != 0xffffffffu) {
-        scm c;
-        ld_scm(c, chs + (CH_FIXED + mono_chal[j]) * 8);
-        v = scm_pow_u32(c, mono_pow[j]);
-      }
-      st_scm(sym + 8 * j, v);
-    }
-  }
+  if (t < 8) zpow[t] = zs[t];
   __syncthreads();
   // phase B: zpow[q] = z^(q+1) by doubling
 #pragma unroll 1
@@ -260,48 +264,54 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     }
     __syncthreads();
   }
-  // phase C: plan replay, one product per term (two when a second-phase challenge is involved) ...
-  for (uint32_t e = t; e < sh.n_terms; e += nt) {
-    scm c, zq;
-    ld_scm(c, term_coef + 8 * (uint64_t)e);
-    ld_scm(zq, zpow + 8 * term_q[e]);
-    const uint32_t mi = term_mono[e];
-    if (mi != 0) { scm m; ld_scm(m, sym + 8 * mi); c = scm_mul(c, m); }
-    st_scm(tv + 8 * e, scm_mul(c, zq));
-  }
-  __syncthreads();
-  // ... then one sum per target
-  for (uint32_t g = t; g < sh.n_targets; g += nt) {
-    bool heavy = false;
-    for (uint32_t hI = 0; hI < sh.n_heavy; ++hI) heavy |= (sh.heavy[hI] == g);
-    if (heavy) continue;
-    scm acc = scm_zero();
-    for (uint32_t e = tgt_off[g]; e < tgt_off[g + 1]; ++e) { scm v; ld_scm(v, tv + 8 * e); acc = scm_add(acc, v); }
-    st_scm(wv + 8 * g, acc);
-  }
-  // heavy targets: every lane sums a strided share, wavefront shuffles fold the lanes, lane 0 of
-  // each wave parks its sum in the free tail of tv (4 slots per heavy target after n_terms)
-  for (uint32_t hI = 0; hI < sh.n_heavy; ++hI) {
-    const uint32_t g = sh.heavy[hI];
-    scm acc = scm_zero();
-    for (uint32_t e = tgt_off[g] + t; e < tgt_off[g + 1]; e += nt) { scm v; ld_scm(v, tv + 8 * e); acc = scm_add(acc, v); }
+  // phase C: plan replay, a range of targets at a time: one product per term (two when a second-phase
+  // challenge is involved), then one sum per target
 #pragma unroll 1
-    for (int delta = 32; delta >= 1; delta >>= 1) {
-      scm o;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) o.v[q] = __shfl_down(acc.v[q], delta);
-      acc = scm_add(acc, o);
+  for (uint32_t ck = 0; ck < sh.n_chunks; ++ck) {
+    const uint32_t g0 = sh.chunk_tgt[ck], g1 = sh.chunk_tgt[ck + 1];
+    const uint32_t e0 = tgt_off[g0], e1 = tgt_off[g1];
+    for (uint32_t e = e0 + t; e < e1; e += nt) {
+      scm c, zq;
+      ld_scm(c, term_coef + 8 * (uint64_t)e);
+      ld_scm(zq, zpow + 8 * term_q[e]);
+      const uint32_t mi = term_mono[e];
+      if (mi != 0) { scm m; ld_scm(m, sym + 8 * mi); c = scm_mul(c, m); }
+      st_scm(tv + 8 * (e - e0), scm_mul(c, zq));
     }
-    uint32_t* wave_sums = tv + (sh.n_terms + 4 * hI) * 8;
-    if ((t & 63) == 0) st_scm(wave_sums + 8 * (t >> 6), acc);
     __syncthreads();
-    if (t == 0) {
-      scm tot = scm_zero();
-      for (uint32_t wI = 0; wI < (nt >> 6); ++wI) { scm v; ld_scm(v, wave_sums + 8 * wI); tot = scm_add(tot, v); }
-      st_scm(wv + 8 * g, tot);
+    for (uint32_t g = g0 + t; g < g1; g += nt) {
+      bool heavy = false;
+      for (uint32_t hI = 0; hI < sh.n_heavy; ++hI) heavy |= (sh.heavy[hI] == g);
+      if (heavy) continue;
+      scm acc = scm_zero();
+      for (uint32_t e = tgt_off[g]; e < tgt_off[g + 1]; ++e) { scm v; ld_scm(v, tv + 8 * (e - e0)); acc = scm_add(acc, v); }
+      st_scm(wv + 8 * g, acc);
     }
+    // heavy targets: every lane sums a strided share, wavefront shuffles fold the lanes, lane 0 of
+    // each wave parks its sum in the scratch slots after the products (4 per heavy target)
+    for (uint32_t hI = 0; hI < sh.n_heavy; ++hI) {
+      const uint32_t g = sh.heavy[hI];
+      if (g < g0 || g >= g1) continue;
+      scm acc = scm_zero();
+      for (uint32_t e = tgt_off[g] + t; e < tgt_off[g + 1]; e += nt) { scm v; ld_scm(v, tv + 8 * (e - e0)); acc = scm_add(acc, v); }
+#pragma unroll 1
+      for (int delta = 32; delta >= 1; delta >>= 1) {
+        scm o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o.v[q] = __shfl_down(acc.v[q], delta);
+        acc = scm_add(acc, o);
+      }
+      uint32_t* wave_sums = tv + (sh.tv_cap + 4 * hI) * 8;
+      if ((t & 63) == 0) st_scm(wave_sums + 8 * (t >> 6), acc);
+      __syncthreads();
+      if (t == 0) {
+        scm tot = scm_zero();
+        for (uint32_t wI = 0; wI < (nt >> 6); ++wI) { scm v; ld_scm(v, wave_sums + 8 * wI); tot = scm_add(tot, v); }
+        st_scm(wv + 8 * g, tot);
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // phase E (region A is dead): yip[i] = y^-i in plain form, sv[i] = s_i (Montgomery), by doubling:
   // setting bit L of i turns the factor 1/u_j of s_i, j = k-1-L, into u_j
   if (t == 0) {
@@ -343,12 +353,21 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
       ld_scm(a, yip + 8 * i); ld_scm(b, wR + 8 * i); ld_scm(c, wL + 8 * i);
       part = scm_add(part, scm_mul(scm_mul(b, c), a));
     }
-    st_scm(red + 8 * t, part);
-    __syncthreads();
-    for (uint32_t s2 = nt >> 1; s2 > 0; s2 >>= 1) {
-      if (t < s2) { scm a, b; ld_scm(a, red + 8 * t); ld_scm(b, red + 8 * (t + s2)); st_scm(red + 8 * t, scm_add(a, b)); }
-      __syncthreads();
+#pragma unroll 1
+    for (int sh_d = 32; sh_d >= 1; sh_d >>= 1) {
+      scm o;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o.v[q] = __shfl_down(part.v[q], sh_d);
+      part = scm_add(part, o);
     }
+    if ((t & 63) == 0) st_scm(red + 8 * (1 + (t >> 6)), part);
+    __syncthreads();
+    if (t == 0) {
+      scm tot = scm_zero();
+      for (uint32_t wI = 0; wI < (nt >> 6); ++wI) { scm v; ld_scm(v, red + 8 * (1 + wI)); tot = scm_add(tot, v); }
+      st_scm(red, tot);
+    }
+    __syncthreads();
   }
   scm delta, x, u, r, a_, b_, w_, t_x, t_x_bl, e_bl;
   delta = scm_from_words(red);                  // plain sum -> Montgomery

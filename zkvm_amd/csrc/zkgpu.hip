@@ -663,7 +663,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
       Launch l(c, "k_transcript", L);
       hipLaunchKernelGGL(k_transcript, dim3(blocks_for(B, 64)), dim3(64), 0, L, sh, prep->d_init, prep->d_chal_label,
                          prep->d_com, (const uint32_t*)c->prep_pw.p, prep->d_r, (uint32_t)B, (uint32_t*)c->prep_ch.p,
-                         (uint32_t*)c->prep_wf.p);
+                         (uint32_t*)c->prep_wf.p, prep->d_mono_chal, prep->d_mono_pow);
     }
   }
   HIP_TRY(c, hipEventRecord(c->ev_t, L));
@@ -997,7 +997,7 @@ void zkgpu_pointset_destroy(zkgpu_pointset* ps) {
 size_t zkgpu_pointset_size(const zkgpu_pointset* ps) { return ps ? ps->n : 0; }
 
 int zkgpu_pointset_build_tables(zkgpu_ctx* c, zkgpu_pointset* ps, int window_bits) {
-  if (!c || !ps || ps->ctx != c || window_bits < 2 || window_bits > 15 || ps->n == 0) return ZKGPU_EINVAL;  // digits are int16
+  if (!c || !ps || ps->ctx != c || window_bits < 2 || window_bits > 16 || ps->n == 0) return ZKGPU_EINVAL;  // digits are int16
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   DeviceGuard g(c->device);
   if (ps->table) { HIP_TRY(c, hipFree(ps->table)); ps->table = nullptr; }
@@ -1263,6 +1263,23 @@ int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t 
   s.n_heavy = 0;
   for (uint32_t t = 0; t < s.n_targets && s.n_heavy < 8; ++t)
     if (h.tgt_off[t + 1] - h.tgt_off[t] > 24) s.heavy[s.n_heavy++] = t;
+  s.n_ch_ext = s.n_ch + s.n_mono + PREP_STRIDES;
+  // fewest flattening passes (<= 5) whose per-pass products keep the workgroup at <= 40 KB of LDS
+  // (four workgroups per CU); the split points are target boundaries
+  for (uint32_t chunks = 1; chunks <= 5; ++chunks) {
+    s.n_chunks = chunks;
+    s.chunk_tgt[0] = 0;
+    uint32_t cap = 0, g = 0;
+    for (uint32_t ck = 0; ck < chunks; ++ck) {
+      const uint32_t goal = (uint32_t)(((uint64_t)s.n_terms * (ck + 1)) / chunks);
+      while (g < s.n_targets && (h.tgt_off[g + 1] <= goal || ck + 1 == chunks)) ++g;
+      if (ck + 1 == chunks) g = s.n_targets;
+      s.chunk_tgt[ck + 1] = g;
+      cap = std::max(cap, h.tgt_off[g] - h.tgt_off[s.chunk_tgt[ck]]);
+    }
+    s.tv_cap = cap;
+    if (prepare_lds_slots(s) * 32 <= 40 * 1024) break;
+  }
   p->lds_bytes = prepare_lds_slots(s) * 32;
   if (p->lds_bytes > 160 * 1024) { delete p; c->last_error = "plan does not fit the 160 KiB LDS of a CU"; return ZKGPU_EINVAL; }
   // STROBE state after Transcript::new("ZkVM.r1cs") + r1cs_domain_sep()
@@ -1365,7 +1382,7 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
   const PrepShape& sh = plan->shape;
   const uint32_t B = (uint32_t)batch;
   TRY(ensure(c, c->prep_pw, (size_t)B * sh.proof_words * 4));
-  TRY(ensure(c, c->prep_ch, (size_t)B * sh.n_ch * 32));
+  TRY(ensure(c, c->prep_ch, (size_t)B * sh.n_ch_ext * 32));
   TRY(ensure(c, c->prep_wf, (size_t)B * 4));
   TRY(ensure(c, c->prep_dyn_sc, (size_t)B * sh.n_dyn * 32));
   TRY(ensure(c, c->prep_dyn_pt, (size_t)B * sh.n_dyn * 32));
@@ -1428,7 +1445,8 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
     Launch l(c, "k_transcript");
     hipLaunchKernelGGL(k_transcript, dim3(blocks_for(B, 64)), dim3(64), 0, s, sh, (const uint32_t*)plan->d_init,
                        (const uint8_t*)plan->d_chal_label, d_com, (const uint32_t*)c->prep_pw.p,
-                       d_r, B, (uint32_t*)c->prep_ch.p, (uint32_t*)c->prep_wf.p);
+                       d_r, B, (uint32_t*)c->prep_ch.p, (uint32_t*)c->prep_wf.p, (const uint32_t*)plan->d_mono_chal,
+                       (const uint32_t*)plan->d_mono_pow);
   }
   {
     Launch l(c, "k_prepare");

@@ -32,7 +32,8 @@ class ZkGpuError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(HERE, "lib", "libzkgpu.so")
+    # ZKGPU_LIB: another build of the same library (A/B experiments); never a different implementation
+    return os.environ.get("ZKGPU_LIB") or os.path.join(HERE, "lib", "libzkgpu.so")
 
 
 def load_library():
