@@ -199,6 +199,8 @@ def main():
                     help="window width of the fixed-base generator tables (0 = no tables: Pippenger for every term)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKGPU_INFLIGHT", "4")),
                     help="independent verify calls in flight per GPU (contexts x host threads)")
+    ap.add_argument("--group", type=int, default=int(os.environ.get("ZKGPU_GROUP", "16")),
+                    help="transactions per group check (zkgpu_set_group_size); 1 = every transaction on its own")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-msm", action="store_true", help="skip the 2^20 MSM microbench")
     args = ap.parse_args()
@@ -246,6 +248,7 @@ def main():
     # One host thread submits step i + M only after collecting step i.  Every step is still one
     # complete, independent verification of the whole batch; K steps are timed as a whole.
     from concurrent.futures import ThreadPoolExecutor
+    ctx.set_group_size(args.group)               # forks inherit it
     ctxs = [ctx] + [ctx.fork() for _ in range(max(1, args.inflight) - 1)]
     lanes = [ThreadPoolExecutor(max_workers=1) for _ in ctxs]
 
@@ -276,6 +279,8 @@ def main():
             dist.all_gather_into_tensor(d_all, d_bm)    # RCCL over xGMI: the per-shard accept bitmaps
         return bm
 
+    host_time = {"submit": 0.0, "n": 0}
+
     def run_steps(n, submit=None):
         submit = submit or submit_verify
         depth = len(ctxs)
@@ -284,7 +289,10 @@ def main():
             c = ctxs[i % depth]
             if i >= depth:
                 bm = collect(c)
+            ts = time.perf_counter()
             submit(c)
+            host_time["submit"] += time.perf_counter() - ts
+            host_time["n"] += 1
         for i in range(max(n - depth, 0), n):
             bm = collect(ctxs[i % depth])
         return bm
@@ -297,11 +305,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_time.update(submit=0.0, n=0)
     bm = run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    submit_ms = host_time["submit"] / max(host_time["n"], 1) * 1e3
     for c in ctxs:
         c.profile(False)
     if world > 1:
@@ -384,6 +394,15 @@ def main():
         t0 = time.perf_counter()
         run_steps(args.steps, submit_msm_only)
         msm_only_s = (time.perf_counter() - t0) / args.steps
+        # the same complete verification with every transaction checked on its own (no group checks)
+        for c in ctxs:
+            c.set_group_size(1)
+        assert run_steps(len(ctxs)) == bm
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        per_tx_s = (time.perf_counter() - t0) / args.steps
+        for c in ctxs:
+            c.set_group_size(args.group)
         line = {
             "metric": "ZkVM tx verifications/sec (batch)",
             "value": round(batch * world * args.steps / elapsed, 1),
@@ -404,7 +423,7 @@ def main():
                                    "the 549-term mega_check MSM (n=256, k=8, m=8; 514 terms on shared generators), "
                                    "identity test -> accept bitmap" % batch,
                        "tx_per_gpu": batch, "terms_per_tx": N_DYN + N_STATIC, "window_bits": wbits,
-                       "generator_table_bits": tbits, "calls_in_flight": len(ctxs),
+                       "generator_table_bits": tbits, "calls_in_flight": len(ctxs), "group_size": args.group,
                        "parallelism": "tx-sharded x%d, RCCL all-gather of accept bitmaps" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
@@ -422,6 +441,11 @@ def main():
             "kernel_ms_per_step": {k: round(x, 4) for k, x in sorted(kern_ms.items())},
             "kernel_ms_solo": {k: round(x, 4) for k, x in sorted(solo.items())},
             "kernel_ms_total_per_step": round(total_kernel_ms, 4),
+            "host_submit_ms_per_step": round(submit_ms, 4),
+            "per_tx_checks": {"tx_per_s": round(batch / per_tx_s, 1), "ms_per_step": round(per_tx_s * 1e3, 4),
+                              "note": "the same step with zkgpu_set_group_size(1): 1024 independent 549-term multiscalar "
+                                      "multiplications instead of %d group checks + individual re-checks of the groups "
+                                      "that hold a bad transaction" % ((batch + max(args.group, 1) - 1) // max(args.group, 1))},
             "msm_boundary": {"tx_per_s": round(batch / msm_only_s, 1), "ms_per_step": round(msm_only_s * 1e3, 4),
                              "note": "zkgpu_verify_batch_ps_dev alone: decompress + MSM + identity test on scalars "
                                      "prepared beforehand (the argument list of dalek's mega_check resident in HBM)"},

@@ -166,6 +166,22 @@ int zkgpu_cloak_verify_batch_gpu_dev(zkgpu_ctx *ctx, const zkgpu_pointset *ps, z
  * (Replaces: a Rust caller running `Verifier::verify` for several blocks on a thread pool.) */
 int zkgpu_ctx_fork(zkgpu_ctx* parent, zkgpu_ctx** out);
 
+/* Group checks for whole proofs (zkgpu_cloak_verify_batch_gpu*, *_submit_dev): the verification
+ * equations of `group` transactions are added up under independent random weights (the square of
+ * each transaction's verifier randomness r) and checked by ONE multiscalar multiplication, in which
+ * the generator terms of the whole group collapse into one set of scalars; the transactions of a
+ * group that fails are then re-checked one by one.  The accept bitmap is the one of per-transaction
+ * verification (a bad transaction passes only with the ~2^-250 probability it already has against
+ * r).  1 <= group <= 64; default 16; 1 = every transaction on its own.
+ * (Same device as upstream bulletproofs' batched range-proof verification; applies to
+ * r1cs::Verifier::verify of many proofs over one BulletproofGens.) */
+int zkgpu_set_group_size(zkgpu_ctx* ctx, int group);
+
+/* Test hook: intermediate buffers of the last device-side preparation on this context.
+ * what = "challenges" (per transaction n_ch_ext slots of 32 B, Montgomery form R = 2^256),
+ * "static_scalars", "dyn_scalars", "dyn_points" (canonical 32-byte values).  Returns bytes copied. */
+long long zkgpu_debug_read(zkgpu_ctx* ctx, const char* what, void* out, size_t bytes);
+
 /* Plain device memory for callers without a HIP binding of their own: what the *_dev entry points
  * take.  zkgpu_upload is a blocking host-to-device copy. */
 int zkgpu_malloc(zkgpu_ctx* ctx, size_t bytes, void** out);

@@ -142,3 +142,51 @@ def test_batches_in_flight_equal_synchronous_calls(ctx, oracle):
     for c in forks[1:]:
         c.close()
     gens.close()
+
+
+@pytest.mark.parametrize("group", [1, 3, 16, 64])
+def test_group_checks_give_per_transaction_verdicts(ctx, oracle, group):
+    """zkgpu_set_group_size: whatever the group size, the accept bitmap is the oracle's per-transaction
+    one -- clean batch, a batch with bad transactions spread over several groups (bad proof scalar, bad
+    commitment, undecodable proof point, non-canonical scalar, wrong version), a batch of only bad ones,
+    and a batch size that is not a multiple of the group."""
+    from zkvm_amd.verifier import BulletproofGens, CloakTx, Verifier
+    gens = BulletproofGens(ctx, 256, table_bits=8)
+    v = Verifier(ctx, gens)
+    ctx.set_group_size(group)
+    try:
+        base = _txs(oracle, 77, 2, 2, b"\x31" * 32)
+        plen = len(base[0].proof)
+
+        def run(txs, tag):
+            r = hashlib.shake_256(b"group " + tag).digest(64 * len(txs))
+            want = [int(oracle.cloak_verify(t.commitments, 2, 2, t.proof, r[64 * i: 64 * i + 64])) for i, t in enumerate(txs)]
+            got = bits(v.verify_packed_gpu(2, 2, len(txs), b"".join(t.commitments for t in txs),
+                                           b"".join(t.proof for t in txs), plen, r), len(txs))
+            assert got == want, tag
+            return want
+
+        assert run(base, b"clean") == [1] * 77
+        bad = list(base)
+        def mut(i, off, val=None, com=False):
+            t = bad[i]
+            buf = bytearray(t.commitments if com else t.proof)
+            if val is None:
+                buf[off] ^= 0x40
+            else:
+                buf[off: off + len(val)] = val
+            bad[i] = CloakTx(2, 2, bytes(buf) if com else t.commitments, t.proof if com else bytes(buf))
+        mut(0, 1 + 32 * 11 + 1)                                   # t_x
+        mut(5, 9, com=True)                                       # a commitment
+        mut(17, 1 + 32 * 3, bytes([0xFF] * 32))                   # A_I2: not a ristretto encoding
+        mut(18, 1 + 32 * 12, L.to_bytes(32, "little"))            # t_x_blinding = l (non-canonical)
+        mut(40, 0, bytes([7]))                                    # version byte
+        mut(76, 1 + 32 * (14 + 3) + 2)                            # an L/R point of the inner-product argument
+        want = run(bad, b"spread")
+        assert want.count(0) >= 5
+        assert run([bad[i] for i in (0, 5, 17, 18, 40)], b"all bad") == [0] * 5
+        assert run(bad[:group + 1] if group > 1 else bad[:2], b"ragged")[0] == 0
+    finally:
+        ctx.set_group_size(16)
+        v.close()
+        gens.close()

@@ -105,3 +105,27 @@ def test_verifier_prepare_rejects_malformed(host, oracle):
     bad = bytearray(proof); bad[-32:] = L.to_bytes(32, "little")
     assert _prepare(host, com, 2, 2, bytes(bad), r, 256) is None                   # b not canonical
     assert _prepare(host, com, 1, 1, proof, r, 256) is None                        # k does not match the statement
+
+
+def _golden_cloak():
+    import struct
+    raw = open(os.path.join(ROOT, "tests", "golden", "cloak_2x2_proofs.bin"), "rb").read()
+    assert raw[:8] == b"ZKCLOAK1"
+    count, n_in, n_out, plen = struct.unpack("<IIII", raw[8:24])
+    w = 64 * (n_in + n_out)
+    body = raw[24:]
+    return [(body[(w + plen) * i: (w + plen) * i + w], body[(w + plen) * i + w: (w + plen) * (i + 1)]) for i in range(count)]
+
+
+def test_transcript_tape_equals_transcript_class(host):
+    """The per-shape STROBE tape that k_transcript runs on the device (transcript_tape.hpp: constant
+    bytes merged per word, data runs, permutation points, challenge slots) replayed by the host
+    interpreter yields the challenges of the Transcript class on the same proof bytes."""
+    txs = _golden_cloak()
+    for i in (0, 7, 63):
+        com, proof = txs[i]
+        a, b = C.create_string_buffer(32 * 64), C.create_string_buffer(32 * 64)
+        n = host.zkhost_tape_challenges(2, 2, com, proof, C.c_size_t(len(proof)), a, b, C.c_size_t(64))
+        assert n == 5 + 8 + 8
+        assert a.raw[: 32 * n] == b.raw[: 32 * n]
+        assert len({a.raw[32 * j: 32 * j + 32] for j in range(n)}) == n

@@ -8,8 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "zkgpu.hip")
 OUT = os.path.join(HERE, "lib", "libzkgpu.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("zkgpu.hip", "kernels.hpp", "quad.hpp", "curve.hpp", "field.hpp", "constants.inc",
-                                                  "keccak.hpp", "scalar.hpp", "merlin.hpp", "r1cs_verifier.hpp", "hostlib.cpp")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc")))
+        if f.endswith((".hip", ".hpp", ".cpp", ".inc", ".h"))]   # every source: a stale library is a silent wrong answer
 HOST_SRC = os.path.join(HERE, "csrc", "hostlib.cpp")
 HOST_OUT = os.path.join(HERE, "lib", "libzkhost.so")
 DEPS.append(os.path.join(HERE, "..", "include", "zkgpu.h"))

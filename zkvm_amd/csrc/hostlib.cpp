@@ -2,6 +2,10 @@
 // R1CS verifier scalar preparation) as a plain C++ shared library, so that the CPU test
 // tier can exercise it without a GPU.  libzkgpu.so compiles the very same headers.
 #include "r1cs_verifier.hpp"
+#include "cloak_plan.hpp"
+#include "transcript_tape.hpp"
+
+#include <map>
 
 #include <cstring>
 
@@ -55,6 +59,82 @@ int zkhost_cloak_prepare(const uint8_t* commitments, size_t n_in, size_t n_out, 
   std::memcpy(static_scalars, m.static_scalars.data(), m.static_scalars.size());
   std::memcpy(static_index, m.static_index.data(), m.static_index.size() * 4);
   return 0;
+}
+
+// The device-side transcript tape (transcript_tape.hpp) against the Transcript class on the same
+// proof: out_tape / out_direct receive 32-byte challenge scalars in slot order y z u x w, the
+// second-phase challenges, the k inner-product challenges.  Returns their count, or -1.
+int zkhost_tape_challenges(uint32_t n_in, uint32_t n_out, const uint8_t* commitments, const uint8_t* proof,
+                           size_t proof_len, uint8_t* out_tape, uint8_t* out_direct, size_t capacity) {
+  const CloakPlan plan = PlanBuilder::build(n_in, n_out);
+  const uint32_t m = plan.m, k = plan.k, n_chal2 = (uint32_t)plan.chal_label.size();
+  if (proof_len != 1 + 32ull * (16 + 2 * k)) return -1;
+  const uint32_t ch_fixed = 14;
+  Transcript tr("ZkVM.r1cs");
+  tr.append_message("dom-sep", (const uint8_t*)"r1cs v1", 7);
+  uint32_t init[52];
+  tr.export_state(init);
+  const std::vector<uint32_t> tape = build_r1cs_verifier_tape(init[50], init[51], m, plan.chal_label, k, plan.pn, ch_fixed);
+  uint8_t state[200];
+  std::memcpy(state, init, 200);
+  std::map<uint32_t, std::vector<uint8_t>> got;
+  run_tape_host(tape, state, commitments, proof + 1, [](uint8_t* st) {
+    uint64_t a[25];
+    std::memcpy(a, st, 200);
+    keccak_f1600(a);
+    std::memcpy(st, a, 200);
+  }, got);
+  std::vector<uint32_t> order = {0, 1, 2, 3, 4};
+  for (uint32_t j = 0; j < n_chal2; ++j) order.push_back(ch_fixed + j);
+  for (uint32_t j = 0; j < k; ++j) order.push_back(ch_fixed + n_chal2 + j);
+  if (order.size() > capacity) return -1;
+  for (size_t i = 0; i < order.size(); ++i) {
+    if (!got.count(order[i])) return -1;
+    Scalar::from_wide(got[order[i]].data()).to_bytes(out_tape + 32 * i);
+  }
+  // the same sequence through the Transcript class
+  const uint8_t* f = proof + 1;
+  std::vector<Scalar> direct(order.size());
+  for (uint32_t i = 0; i < m; ++i) tr.append_message("V", commitments + 32 * i, 32);
+  {
+    uint8_t b[8] = {0};
+    for (int q = 0; q < 8; ++q) b[q] = (uint8_t)((uint64_t)m >> (8 * q));
+    tr.append_message("m", b, 8);
+  }
+  tr.append_message("A_I1", f, 32); tr.append_message("A_O1", f + 32, 32); tr.append_message("S1", f + 64, 32);
+  if (n_chal2 == 0) {
+    tr.append_message("dom-sep", (const uint8_t*)"r1cs-1phase", 11);
+  } else {
+    tr.append_message("dom-sep", (const uint8_t*)"r1cs-2phase", 11);
+    for (uint32_t j = 0; j < n_chal2; ++j) {
+      const uint8_t id = plan.chal_label[j];
+      direct[5 + j] = tr.challenge_scalar(id == 0 ? "mix challenge" : id == 1 ? "k-value shuffle challenge" : "shuffle challenge");
+    }
+  }
+  tr.append_message("A_I2", f + 96, 32); tr.append_message("A_O2", f + 128, 32); tr.append_message("S2", f + 160, 32);
+  direct[0] = tr.challenge_scalar("y");
+  direct[1] = tr.challenge_scalar("z");
+  const char* tl[5] = {"T_1", "T_3", "T_4", "T_5", "T_6"};
+  for (int i = 0; i < 5; ++i) tr.append_message(tl[i], f + 32 * (6 + i), 32);
+  direct[2] = tr.challenge_scalar("u");
+  direct[3] = tr.challenge_scalar("x");
+  tr.append_message("t_x", f + 32 * 11, 32);
+  tr.append_message("t_x_blinding", f + 32 * 12, 32);
+  tr.append_message("e_blinding", f + 32 * 13, 32);
+  direct[4] = tr.challenge_scalar("w");
+  tr.append_message("dom-sep", (const uint8_t*)"ipp v1", 6);
+  {
+    uint8_t b[8] = {0};
+    for (int q = 0; q < 8; ++q) b[q] = (uint8_t)((uint64_t)plan.pn >> (8 * q));
+    tr.append_message("n", b, 8);
+  }
+  for (uint32_t j = 0; j < k; ++j) {
+    tr.append_message("L", f + 32 * (14 + 2 * j), 32);
+    tr.append_message("R", f + 32 * (14 + 2 * j + 1), 32);
+    direct[5 + n_chal2 + j] = tr.challenge_scalar("u");
+  }
+  for (size_t i = 0; i < order.size(); ++i) direct[i].to_bytes(out_direct + 32 * i);
+  return (int)order.size();
 }
 
 }  // extern "C"

@@ -1078,13 +1078,17 @@ k_static_digits(const uint32_t* __restrict__ st_scalars, int16_t* __restrict__ d
 __global__ void __launch_bounds__(256)
 k_static_accumulate(const int16_t* __restrict__ digits, const uint64_t* __restrict__ st_offsets,
                     const uint32_t* __restrict__ st_index, const uint32_t* __restrict__ table, uint32_t n_set,
-                    uint32_t H, int W, int P, uint32_t n_msm, uint64_t n_static, uint32_t* __restrict__ partials) {
+                    uint32_t H, int W, int P, uint32_t n_msm, uint64_t n_static, uint32_t* __restrict__ partials,
+                    const uint32_t* __restrict__ row_map /*optional: slot -> MSM*/,
+                    const uint32_t* __restrict__ n_active /*optional: slots in use, device side*/) {
   const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= (uint64_t)n_msm * W * P) return;
   // window-major lane order: the chip sweeps the table one window slice at a time
   const uint32_t part = (uint32_t)(lane % P);
-  const uint32_t tx = (uint32_t)((lane / P) % n_msm);
+  const uint32_t slot = (uint32_t)((lane / P) % n_msm);
   const uint32_t t = (uint32_t)(lane / ((uint64_t)P * n_msm));
+  if (n_active && slot >= *n_active) return;
+  const uint32_t tx = row_map ? row_map[slot] : slot;
   const uint64_t k0 = st_offsets[tx], k1 = st_offsets[tx + 1];
   const int16_t* dig = digits + (uint64_t)t * n_static;
   const uint64_t tbase = (uint64_t)t * n_set;
@@ -1111,22 +1115,26 @@ k_static_accumulate(const int16_t* __restrict__ digits, const uint64_t* __restri
     cur = nxt; cur_neg = nxt_neg;
     k = kn;
   }
-  store_ext(partials + (((uint64_t)tx * W + t) * P + part) * EXT_WORDS, acc);
+  store_ext(partials + (((uint64_t)slot * W + t) * P + part) * EXT_WORDS, acc);
 }
 
 // one wave per tx: sum the W*P static partials and the dynamic-term sum, then
 // the ristretto identity test.  Lane sums are folded with wavefront shuffles.
+// With row_map / n_active (the per-transaction re-check of failed groups) block b handles
+// MSM row_map[b]; its partials sit at slot b.
 __global__ void __launch_bounds__(64)
 k_static_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
-                 const uint8_t* __restrict__ dyn_ok, const uint32_t* __restrict__ status_unused,
-                 uint8_t* __restrict__ accept) {
-  const uint32_t tx = blockIdx.x;
+                 const uint8_t* __restrict__ dyn_ok, const uint32_t* __restrict__ row_map,
+                 const uint32_t* __restrict__ n_active, uint8_t* __restrict__ accept) {
+  if (n_active && blockIdx.x >= *n_active) return;
+  const uint32_t slot = blockIdx.x;
+  const uint32_t tx = row_map ? row_map[slot] : slot;
   const int lane = threadIdx.x;
   ge acc;
   ge_identity(acc);
   for (uint32_t c = lane; c < n_partials; c += 64) {
     ge p;
-    load_ext(p, partials + ((uint64_t)tx * n_partials + c) * EXT_WORDS);
+    load_ext(p, partials + ((uint64_t)slot * n_partials + c) * EXT_WORDS);
     ge_add(acc, acc, p);
   }
   if (lane == 0 && dyn_sum) {
@@ -1141,6 +1149,58 @@ k_static_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, con
     if (lane < delta) ge_add(acc, acc, other);
   }
   if (lane == 0) accept[tx] = (ge_is_identity(acc) && (!dyn_ok || dyn_ok[tx])) ? 1 : 0;
+}
+
+// ---- group checks ---------------------------------------------------------------------
+// A group of transactions whose equations are weighted by independent random rho's (k_transcript)
+// sums to the identity iff every one of them does (up to probability ~2^-250), and the generator
+// terms of the sum collapse into ONE set of n_static scalars for the whole group: g times fewer
+// table gathers.  Groups that fail are re-checked transaction by transaction.
+//
+// one wave per group: generator partials of the group + the proof-point sums of its transactions
+__global__ void __launch_bounds__(64)
+k_group_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
+                const uint8_t* __restrict__ dyn_ok, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
+                uint32_t group, uint8_t* __restrict__ group_ok, uint8_t* __restrict__ accept,
+                uint32_t* __restrict__ row_map, uint32_t* __restrict__ n_active) {
+  const uint32_t G = blockIdx.x;
+  const int lane = threadIdx.x;
+  ge acc;
+  ge_identity(acc);
+  for (uint32_t c = lane; c < n_partials; c += 64) {
+    ge p;
+    load_ext(p, partials + ((uint64_t)G * n_partials + c) * EXT_WORDS);
+    ge_add(acc, acc, p);
+  }
+  bool fine = true;
+  for (uint32_t i = lane; i < group; i += 64) {
+    const uint32_t tx = G * group + i;
+    if (tx < n_msm) {
+      ge p;
+      load_ext(p, dyn_sum + (uint64_t)tx * EXT_WORDS);
+      ge_add(acc, acc, p);
+      fine = fine && dyn_ok[tx] && (!wellformed || wellformed[tx]);
+    }
+  }
+#pragma unroll 1
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    ge other;
+    shfl_down_ge(other, acc, delta);
+    if (lane < delta) ge_add(acc, acc, other);
+  }
+  const bool all_fine = __all(fine);
+  // verdict for the group's transactions: accepted together, or queued for the individual re-check
+  const int ok = __shfl((lane == 0 && all_fine && ge_is_identity(acc)) ? 1 : 0, 0);
+  if (lane == 0) group_ok[G] = (uint8_t)ok;
+  uint32_t base = 0;
+  const uint32_t in_group = min(group, n_msm - G * group);
+  if (!ok && lane == 0) base = atomicAdd(n_active, in_group);
+  base = __shfl(base, 0);
+  for (uint32_t i = lane; i < in_group; i += 64) {
+    const uint32_t tx = G * group + i;
+    accept[tx] = ok ? 1 : 0;
+    if (!ok) row_map[base + i] = tx;
+  }
 }
 
 }  // namespace zk

@@ -10,15 +10,17 @@
 //                    delta, g_i / h_i and the proof-point scalars
 //
 // Challenge slots of a transaction (scm, Montgomery form):
-//   0 y  1 z  2 u  3 x  4 w  5 1/y  6 prod 1/u_j  7 r  8 t_x  9 t_x_blinding
-//   10 e_blinding  11 a  12 b  | 13.. second-phase challenges | u_j | 1/u_j
+//   0 y  1 z  2 u  3 x  4 w  5 P1 = prod u_j  6 U = prod u_j^2  7 r  8 t_x  9 t_x_blinding
+//   10 e_blinding  11 a  12 b  13 rho (weight of this transaction in a group check, 1 when checked alone)
+//   | 14.. second-phase challenges | u_j | prod_{l != j} u_l^2
 #pragma once
 #include "merlin_dev.hpp"
 #include "sc_dev.hpp"
+#include "transcript_tape.hpp"
 
 namespace zk {
 
-constexpr int CH_FIXED = 13;
+constexpr int CH_FIXED = 14;
 
 struct PrepShape {
   uint32_t m, n1, n, pn, k, n_cons, n_chal2, n_mono, n_targets, n_terms;
@@ -78,138 +80,140 @@ __device__ __forceinline__ bool words_are_zero(const uint32_t* w) {
   return acc == 0;
 }
 
-// init: the STROBE state after Transcript::new("ZkVM.r1cs") + r1cs_domain_sep (same for every tx)
+// One lane per transaction runs the shape's tape (transcript_tape.hpp).  LDS per lane, word-
+// interleaved over the 64 lanes of the block: the 50 words of STROBE state.
+// init: the STROBE state after Transcript::new("ZkVM.r1cs") + r1cs_domain_sep (same for every tx).
+//
+// No inversion anywhere: the verification equation is used multiplied through by
+// c = y^(pn-1) prod_j u_j^2, which turns every y^-i, 1/u_j and u_j^-2 into a product of positive
+// powers (k_prepare); "sum == identity" is unchanged by a non-zero factor, and a zero y or u_j
+// (where the reference's inversion has no answer either) rejects the proof.
 __global__ void __launch_bounds__(64)
-k_transcript(PrepShape sh, const uint32_t* __restrict__ init_state /*50 words + pos + pos_begin*/,
-             const uint8_t* __restrict__ chal_label, const uint32_t* __restrict__ com /*[B][m][8]*/,
+k_transcript(PrepShape sh, const uint32_t* __restrict__ init_state /*50 words*/, const uint4* __restrict__ tape,
+             uint32_t n_ops, const uint32_t* __restrict__ com /*[B][m][8]*/,
              const uint32_t* __restrict__ pw /*[B][proof_words]*/, const uint32_t* __restrict__ rbytes /*[B][16]*/,
              uint32_t batch, uint32_t* __restrict__ ch /*[B][n_ch_ext][8]*/, uint32_t* __restrict__ wellformed,
-             const uint32_t* __restrict__ mono_chal, const uint32_t* __restrict__ mono_pow) {
-  __shared__ uint32_t lds[52 * 64];
+             const uint32_t* __restrict__ mono_chal, const uint32_t* __restrict__ mono_pow, uint32_t grouped) {
+  __shared__ uint32_t lds[50 * 64];
   const uint32_t lane = threadIdx.x;
   const uint32_t tx_raw = blockIdx.x * 64 + lane;
   const bool live = tx_raw < batch;
   const uint32_t tx = live ? tx_raw : batch - 1;
-  StrobeDev s;
-  s.st = lds + lane;
-  s.stride = 64;
-  for (int i = 0; i < 50; ++i) s.st[i * 64] = init_state[i];
-  s.pos = init_state[50];
-  s.pos_begin = init_state[51];
+  uint32_t* st = lds + lane;                    // word w of this lane: st[w * 64]
+  for (int i = 0; i < 50; ++i) st[i * 64] = init_state[i];
   const uint32_t* c = com + (uint64_t)tx * sh.m * 8;
   const uint32_t* p = pw + (uint64_t)tx * sh.proof_words;
   uint32_t* out = ch + (uint64_t)tx * sh.n_ch_ext * 8;
-  bool ok = true;
-
-  for (uint32_t i = 0; i < sh.m; ++i) s.append_message_words("V", 1, c + 8 * i, 8);
-  s.append_u64("m", 1, sh.m);
-  ok &= !words_are_zero(p) & !words_are_zero(p + 8) & !words_are_zero(p + 16);
-  s.append_message_words("A_I1", 4, p, 8);
-  s.append_message_words("A_O1", 4, p + 8, 8);
-  s.append_message_words("S1", 2, p + 16, 8);
-  uint32_t wide[16];
-  if (sh.n_chal2 == 0) {
-    s.append_message_const("dom-sep", 7, "r1cs-1phase", 11);
-  } else {
-    s.append_message_const("dom-sep", 7, "r1cs-2phase", 11);
-    for (uint32_t j = 0; j < sh.n_chal2; ++j) {
-      const uint32_t id = chal_label[j];
-      if (id == 0) s.challenge_wide("mix challenge", 13, wide);
-      else if (id == 1) s.challenge_wide("k-value shuffle challenge", 25, wide);
-      else s.challenge_wide("shuffle challenge", 17, wide);
-      st_scm(out + (CH_FIXED + j) * 8, scm_from_wide(wide));
+#pragma unroll 1
+  for (uint32_t i = 0; i < n_ops; ++i) {
+    const uint4 op = tape[i];
+    if (op.x == TAPE_XOR) {
+      st[op.y * 64] ^= op.z;
+    } else if (op.x == TAPE_DATA) {
+      const uint32_t* src = op.y == TAPE_SRC_PROOF ? p : c;
+      const int last_word = (int)(op.y == TAPE_SRC_PROOF ? sh.proof_words : sh.m * 8) - 1;
+      const uint32_t spos = op.w & 0xffffu, n = op.w >> 16;
+      const int delta = (int)op.z - (int)spos;            // source byte = state byte + delta
+#pragma unroll 1
+      for (uint32_t w = spos >> 2; w <= (spos + n - 1) >> 2; ++w) {
+        const int sb = (int)(4 * w) + delta;              // source byte under state byte 4w
+        const int wi = sb >> 2;
+        const uint32_t sh8 = (uint32_t)(sb & 3) * 8;
+        const uint32_t lo = src[min(max(wi, 0), last_word)], hi = src[min(max(wi + 1, 0), last_word)];
+        const uint32_t v = sh8 ? (lo >> sh8) | (hi << (32 - sh8)) : lo;
+        const uint32_t first = max(spos, 4 * w) - 4 * w, last = min(spos + n, 4 * w + 4) - 4 * w;
+        const uint32_t mask = (last == 4 ? 0xffffffffu : ((1u << (8 * last)) - 1)) & ~((1u << (8 * first)) - 1);
+        st[w * 64] ^= v & mask;
+      }
+    } else if (op.x == TAPE_PERM) {
+      uint64_t a[25];
+#pragma unroll
+      for (int q = 0; q < 25; ++q) a[q] = (uint64_t)st[(2 * q) * 64] | ((uint64_t)st[(2 * q + 1) * 64] << 32);
+      keccak_f1600_regs(a);
+#pragma unroll
+      for (int q = 0; q < 25; ++q) { st[(2 * q) * 64] = (uint32_t)a[q]; st[(2 * q + 1) * 64] = (uint32_t)(a[q] >> 32); }
+    } else {                                               // TAPE_CHAL
+      uint32_t wv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { wv[q] = st[q * 64]; st[q * 64] = 0; }
+      st_scm(out + op.y * 8, scm_from_wide(wv));
     }
   }
-  s.append_message_words("A_I2", 4, p + 24, 8);
-  s.append_message_words("A_O2", 4, p + 32, 8);
-  s.append_message_words("S2", 2, p + 40, 8);
-  s.challenge_wide("y", 1, wide);
-  const scm y = scm_from_wide(wide);
-  s.challenge_wide("z", 1, wide);
-  st_scm(out + 1 * 8, scm_from_wide(wide));
-  for (int i = 6; i < 11; ++i) ok &= !words_are_zero(p + 8 * i);
-  s.append_message_words("T_1", 3, p + 48, 8);
-  s.append_message_words("T_3", 3, p + 56, 8);
-  s.append_message_words("T_4", 3, p + 64, 8);
-  s.append_message_words("T_5", 3, p + 72, 8);
-  s.append_message_words("T_6", 3, p + 80, 8);
-  s.challenge_wide("u", 1, wide);
-  st_scm(out + 2 * 8, scm_from_wide(wide));
-  s.challenge_wide("x", 1, wide);
-  st_scm(out + 3 * 8, scm_from_wide(wide));
+  // well-formedness: no identity among the proof points, canonical scalars
+  bool ok = true;
+  // (A_I2, A_O2, S2 are the identity in single-phase proofs: not tested, as in the reference)
+  for (int i = 0; i < 11; ++i) ok &= (i >= 3 && i < 6) | !words_are_zero(p + 8 * i);
   const uint32_t* sc3 = p + 88;               // t_x, t_x_blinding, e_blinding
   const uint32_t* lr = p + 112;               // L_0 R_0 L_1 R_1 ...
   const uint32_t* ab = lr + 16 * sh.k;        // a, b
   ok &= scm_is_canonical(sc3) & scm_is_canonical(sc3 + 8) & scm_is_canonical(sc3 + 16) & scm_is_canonical(ab) &
         scm_is_canonical(ab + 8);
-  s.append_message_words("t_x", 3, sc3, 8);
-  s.append_message_words("t_x_blinding", 12, sc3 + 8, 8);
-  s.append_message_words("e_blinding", 10, sc3 + 16, 8);
-  s.challenge_wide("w", 1, wide);
-  st_scm(out + 4 * 8, scm_from_wide(wide));
-  st_scm(out + 8 * 8, scm_from_words(sc3));
-  st_scm(out + 9 * 8, scm_from_words(sc3 + 8));
-  st_scm(out + 10 * 8, scm_from_words(sc3 + 16));
-  st_scm(out + 11 * 8, scm_from_words(ab));
-  st_scm(out + 12 * 8, scm_from_words(ab + 8));
-  st_scm(out + 7 * 8, scm_from_wide(rbytes + (uint64_t)tx * 16));
-  // inner-product argument
-  s.append_message_const("dom-sep", 7, "ipp v1", 6);
-  s.append_u64("n", 1, sh.pn);
-  uint32_t* uj = out + (CH_FIXED + sh.n_chal2) * 8;
-  uint32_t* ujinv = uj + 8 * sh.k;
-  scm prod = y;                               // running product y * u_0 * ... (prefixes parked in the 1/u_j slots)
-  for (uint32_t j = 0; j < sh.k; ++j) {
-    ok &= !words_are_zero(lr + 16 * j) & !words_are_zero(lr + 16 * j + 8);
-    s.append_message_words("L", 1, lr + 16 * j, 8);
-    s.append_message_words("R", 1, lr + 16 * j + 8, 8);
-    s.challenge_wide("u", 1, wide);
-    const scm u = scm_from_wide(wide);
-    st_scm(uj + 8 * j, u);
-    st_scm(ujinv + 8 * j, prod);              // prefix product BEFORE u_j
-    prod = scm_mul(prod, u);
+  for (uint32_t j = 0; j < sh.k; ++j) ok &= !words_are_zero(lr + 16 * j) & !words_are_zero(lr + 16 * j + 8);
+#pragma unroll 1
+  for (int q = 0; q < 5; ++q) st_scm(out + (8 + q) * 8, scm_from_words(q < 3 ? sc3 + 8 * q : ab + 8 * (q - 3)));
+  {
+    // r combines the two halves of this proof's equation; rho = r^2 weighs the whole equation inside a
+    // group of transactions checked by one multiscalar multiplication (coefficients r^2, r^3 of a
+    // transaction's two halves: a polynomial identity in independent r's, Schwartz-Zippel as for r alone)
+    const scm rr = scm_from_wide(rbytes + (uint64_t)tx * 16);
+    st_scm(out + 7 * 8, rr);
+    scm rho = grouped ? scm_sq(rr) : scm_one();
+    uint32_t any = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) any |= rho.v[q];
+    if (any == 0) rho = scm_one();
+    st_scm(out + 13 * 8, rho);
   }
-  // one inversion for y and every u_j (Montgomery's trick)
-  scm inv = scm_invert(prod);
-  for (uint32_t j = sh.k; j-- > 0;) {
-    scm pre, u;
-    ld_scm(pre, ujinv + 8 * j);
-    ld_scm(u, uj + 8 * j);
-    st_scm(ujinv + 8 * j, scm_mul(inv, pre));  // 1 / u_j
-    inv = scm_mul(inv, u);
-  }
-  // inv = 1 / y now; prod 1/u_j = (1 / (y prod u_j)) * y
-  st_scm(out + 0 * 8, y);
-  st_scm(out + 5 * 8, inv);
-  scm allinv = scm_one();
-  for (uint32_t j = 0; j < sh.k; ++j) { scm t; ld_scm(t, ujinv + 8 * j); allinv = scm_mul(allinv, t); }
-  st_scm(out + 6 * 8, allinv);
   // the serial chains k_prepare needs, done here where every lane has one to do: second-phase
-  // monomials, z^(2^L), y^-(2^L), u_j^2
+  // monomials, z^(2^L), y^(2^L), u_j^2, U = prod u_j^2, prod_{l != j} u_l^2
   uint32_t* sym = out + sh.n_ch * 8;
   uint32_t* strides = sym + sh.n_mono * 8;
+  uint32_t* uj = out + (CH_FIXED + sh.n_chal2) * 8;
+  uint32_t* uex = uj + 8 * sh.k;
 #pragma unroll 1
   for (uint32_t j = 0; j < sh.n_mono; ++j) {
     scm v = scm_one();
     if (mono_chal[j] != 0xffffffffu) {
-      scm c;
-      ld_scm(c, out + (CH_FIXED + mono_chal[j]) * 8);
-      v = scm_pow_u32(c, mono_pow[j]);
+      scm cc;
+      ld_scm(cc, out + (CH_FIXED + mono_chal[j]) * 8);
+      v = scm_pow_u32(cc, mono_pow[j]);
     }
     st_scm(sym + 8 * j, v);
   }
   {
-    scm c;
-    ld_scm(c, out + 1 * 8);
-    st_scm(strides, c);
+    scm cc;
+    ld_scm(cc, out + 1 * 8);
+    st_scm(strides, cc);
 #pragma unroll 1
-    for (uint32_t L = 1; (1u << L) < sh.n_cons; ++L) { c = scm_sq(c); st_scm(strides + 8 * L, c); }
-    c = inv;                                     // 1 / y
-    st_scm(strides + 16 * 8, c);
+    for (uint32_t L = 1; (1u << L) < sh.n_cons; ++L) { cc = scm_sq(cc); st_scm(strides + 8 * L, cc); }
+    ld_scm(cc, out + 0 * 8);                      // y
+    ok &= !words_are_zero(cc.v);
+    st_scm(strides + 16 * 8, cc);
 #pragma unroll 1
-    for (uint32_t L = 1; L < sh.k; ++L) { c = scm_sq(c); st_scm(strides + (16 + L) * 8, c); }
+    for (uint32_t L = 1; L < sh.k; ++L) { cc = scm_sq(cc); st_scm(strides + (16 + L) * 8, cc); }
+    // prefix products of the u_j^2 go to the "excluded" slots, then the suffix pass completes them
+    scm run = scm_one(), p1 = scm_one();
 #pragma unroll 1
-    for (uint32_t j = 0; j < sh.k; ++j) { ld_scm(c, uj + 8 * j); st_scm(strides + (32 + j) * 8, scm_sq(c)); }
+    for (uint32_t j = 0; j < sh.k; ++j) {
+      ld_scm(cc, uj + 8 * j);
+      ok &= !words_are_zero(cc.v);
+      p1 = scm_mul(p1, cc);
+      const scm sq = scm_sq(cc);
+      st_scm(strides + (32 + j) * 8, sq);
+      st_scm(uex + 8 * j, run);                   // prod_{l < j} u_l^2
+      run = scm_mul(run, sq);
+    }
+    st_scm(out + 6 * 8, run);                     // U = prod u_j^2
+    st_scm(out + 5 * 8, p1);                      // P1 = prod u_j
+    run = scm_one();
+#pragma unroll 1
+    for (uint32_t j = sh.k; j-- > 0;) {
+      scm pre, sq;
+      ld_scm(pre, uex + 8 * j);
+      st_scm(uex + 8 * j, scm_mul(pre, run));     // prod_{l != j} u_l^2
+      ld_scm(sq, strides + (32 + j) * 8);
+      run = scm_mul(run, sq);
+    }
   }
   if (live && !ok) atomicAnd(&wellformed[tx], 0u);
 }
@@ -312,15 +316,19 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     }
     __syncthreads();
   }
-  // phase E (region A is dead): yip[i] = y^-i in plain form, sv[i] = s_i (Montgomery), by doubling:
-  // setting bit L of i turns the factor 1/u_j of s_i, j = k-1-L, into u_j
+  // phase E (region A is dead).  The whole equation is taken times c' = rho y^(pn-1) U, U = prod u_j^2
+  // (rho: chs slot 13, 1 unless the batch is checked in groups), which needs no inverse:
+  //     c' y^-i        = U * yp[pn-1-i]             yp[j] = rho y^j, kept in PLAIN form
+  //     c' s_i         = yp[pn-1] * P1 * sU[i]      sU[i] = prod_j u_j^(2 bit_(k-1-j)(i)),  P1 = prod u_j
+  //     c' y^-i s_r    = yp[pn-1-i] * P1 * sU[r]    (U s_i = prod u_j^(2 +- 1) = P1 sU[i])
+  // Both tables grow by doubling (entry + 2^L = entry * stride_L); a Montgomery product with one plain
+  // operand is plain, so the generator scalars come out as canonical words directly.
   if (t == 0) {
-    scm one_plain = scm_zero();
-    one_plain.v[0] = 1;
-    st_scm(yip, one_plain);
-    scm s0;
-    ld_scm(s0, chs + 6 * 8);
-    st_scm(sv, s0);
+    scm rho, rho_plain;
+    ld_scm(rho, chs + 13 * 8);
+    scm_to_words(rho_plain.v, rho);
+    st_scm(yip, rho_plain);
+    st_scm(sv, scm_one());
   }
   __syncthreads();
 #pragma unroll 1
@@ -345,12 +353,12 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   const uint32_t* wO = wv + 2 * sh.n * 8;
   const uint32_t* wV = wv + 3 * sh.n * 8;
   const uint32_t* wc = wV + sh.m * 8;
-  // delta = sum_{i<n} y^-i wR_i wL_i  (plain partial sums, block reduction in LDS)
+  // dsum = rho sum_{i<n} y^(pn-1-i) wR_i wL_i  (= c' delta / U; plain partial sums, block reduction)
   {
     scm part = scm_zero();
     for (uint32_t i = t; i < sh.n; i += nt) {
       scm a, b, c;
-      ld_scm(a, yip + 8 * i); ld_scm(b, wR + 8 * i); ld_scm(c, wL + 8 * i);
+      ld_scm(a, yip + 8 * (sh.pn - 1 - i)); ld_scm(b, wR + 8 * i); ld_scm(c, wL + 8 * i);
       part = scm_add(part, scm_mul(scm_mul(b, c), a));
     }
 #pragma unroll 1
@@ -369,11 +377,14 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     }
     __syncthreads();
   }
-  scm delta, x, u, r, a_, b_, w_, t_x, t_x_bl, e_bl;
-  delta = scm_from_words(red);                  // plain sum -> Montgomery
-  ld_scm(u, chs + 2 * 8); ld_scm(x, chs + 3 * 8); ld_scm(w_, chs + 4 * 8); ld_scm(r, chs + 7 * 8);
+  scm x, u, r, a_, b_, w_, t_x, t_x_bl, e_bl, U, rhoY_plain, cp_plain, cp;
+  const scm dsum = scm_from_words(red);          // plain sum -> Montgomery
+  ld_scm(u, chs + 2 * 8); ld_scm(x, chs + 3 * 8); ld_scm(w_, chs + 4 * 8); ld_scm(U, chs + 6 * 8); ld_scm(r, chs + 7 * 8);
   ld_scm(t_x, chs + 8 * 8); ld_scm(t_x_bl, chs + 9 * 8); ld_scm(e_bl, chs + 10 * 8);
   ld_scm(a_, chs + 11 * 8); ld_scm(b_, chs + 12 * 8);
+  ld_scm(rhoY_plain, yip + 8 * (sh.pn - 1));     // rho y^(pn-1), plain
+  cp_plain = scm_mul(U, rhoY_plain);             // c', plain
+  cp = scm_from_words(cp_plain.v);               // c', Montgomery
   const scm xx = scm_sq(x), xxx = scm_mul(xx, x), rxx = scm_mul(r, xx);
   uint32_t* ds = dyn_scalars + (uint64_t)tx * sh.n_dyn * 8;
   uint32_t* dp = dyn_points + (uint64_t)tx * sh.n_dyn * 8;
@@ -381,24 +392,27 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   const uint32_t* p = pw + (uint64_t)tx * sh.proof_words;
   const uint32_t* c = com + (uint64_t)tx * sh.m * 8;
   const uint32_t* lr = p + 112;
-  // generator scalars, canonical words straight out of the products (plain operand: yip, a_plain):
-  //   g_i = x wR_i y^-i - a s_i            h_i = y^-i (x wL_i + wO_i - b s_{pn-1-i}) - 1      (times u for i >= n1)
+  // generator scalars (times c'), canonical words straight out of the products:
+  //   c' g_i = (x U) wR_i yp[pn-1-i] - (a P1 rho Y) sU_i
+  //   c' h_i = yp[pn-1-i] ((x U) wL_i + U wO_i - (b P1) sU_(pn-1-i)) - c'        (times u for i >= n1)
   {
-    scm a_plain, one_plain = scm_zero();
-    one_plain.v[0] = 1;
-    scm_to_words(a_plain.v, a_);
+    scm P1;
+    ld_scm(P1, chs + 5 * 8);
+    const scm xU = scm_mul(x, U);
+    const scm aY_plain = scm_mul(scm_mul(a_, P1), rhoY_plain);
+    const scm bP = scm_mul(b_, P1);
     for (uint32_t i = t; i < sh.pn; i += nt) {
       scm yp, si, sr;
-      ld_scm(yp, yip + 8 * i); ld_scm(si, sv + 8 * i); ld_scm(sr, sv + 8 * (sh.pn - 1 - i));
-      scm g = scm_neg(scm_mul(a_plain, si));
-      scm inner = scm_neg(scm_mul(b_, sr));
+      ld_scm(yp, yip + 8 * (sh.pn - 1 - i)); ld_scm(si, sv + 8 * i); ld_scm(sr, sv + 8 * (sh.pn - 1 - i));
+      scm g = scm_neg(scm_mul(aY_plain, si));
+      scm inner = scm_neg(scm_mul(bP, sr));
       if (i < sh.n) {
         scm wl, wr, wo;
         ld_scm(wl, wL + 8 * i); ld_scm(wr, wR + 8 * i); ld_scm(wo, wO + 8 * i);
-        g = scm_add(g, scm_mul(scm_mul(x, wr), yp));
-        inner = scm_add(inner, scm_add(scm_mul(x, wl), wo));
+        g = scm_add(g, scm_mul(scm_mul(xU, wr), yp));
+        inner = scm_add(inner, scm_add(scm_mul(xU, wl), scm_mul(U, wo)));
       }
-      scm h = scm_sub(scm_mul(yp, inner), one_plain);
+      scm h = scm_sub(scm_mul(yp, inner), cp_plain);
       if (i >= sh.n1) { g = scm_mul(g, u); h = scm_mul(h, u); }
       uint4* og = reinterpret_cast<uint4*>(ss + (2 + i) * 8);
       uint4* oh = reinterpret_cast<uint4*>(ss + (2 + sh.pn + i) * 8);
@@ -406,9 +420,11 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
       oh[0] = make_uint4(h.v[0], h.v[1], h.v[2], h.v[3]); oh[1] = make_uint4(h.v[4], h.v[5], h.v[6], h.v[7]);
     }
   }
-  // proof-point scalars (and B, B_blinding), one lane each
+  // proof-point scalars (and B, B_blinding), one lane each; the factor c' rides on the final
+  // Montgomery -> canonical conversion (a product with the plain c' instead of with 1)
   if (t < sh.n_dyn + 2) {
     scm v;
+    scm conv_by = cp_plain;
     const uint32_t* pt = nullptr;
     const uint32_t j = t;
     if (j < 6) {
@@ -427,27 +443,58 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
       for (uint32_t e = 0; e < reps; ++e) v = scm_mul(v, x);
       pt = p + 8 * (6 + q);
     } else if (j < sh.n_dyn) {
-      const uint32_t q = j - 6 - sh.m - 5;  // u_j^2 for L_j, then u_j^-2 for R_j
-      scm f;
-      if (q < sh.k) { ld_scm(f, chs + (CH_FIXED + sh.n_chal2 + q) * 8); pt = lr + 16 * q; }
-      else { ld_scm(f, chs + (CH_FIXED + sh.n_chal2 + sh.k + (q - sh.k)) * 8); pt = lr + 16 * (q - sh.k) + 8; }
-      v = scm_sq(f);
-    } else if (j == sh.n_dyn) {             // B: w (t_x - a b) + r (xx (wc + delta) - t_x)
+      const uint32_t q = j - 6 - sh.m - 5;  // u_j^2 for L_j; u_j^-2 for R_j, i.e. c' u_j^-2 = rho Y prod_{l != j} u_l^2
+      if (q < sh.k) {
+        scm f;
+        ld_scm(f, chs + (CH_FIXED + sh.n_chal2 + q) * 8);
+        v = scm_sq(f);
+        pt = lr + 16 * q;
+      } else {
+        ld_scm(v, chs + (CH_FIXED + sh.n_chal2 + sh.k + (q - sh.k)) * 8);
+        conv_by = rhoY_plain;
+        pt = lr + 16 * (q - sh.k) + 8;
+      }
+    } else if (j == sh.n_dyn) {             // B: c' (w (t_x - a b) + r (xx (wc + delta) - t_x)), with c' delta = U dsum
       scm wcv; ld_scm(wcv, wc);
-      const scm t1 = scm_mul(w_, scm_sub(t_x, scm_mul(a_, b_)));
-      const scm t2 = scm_mul(r, scm_sub(scm_mul(xx, scm_add(wcv, delta)), t_x));
+      const scm t1 = scm_mul(cp, scm_mul(w_, scm_sub(t_x, scm_mul(a_, b_))));
+      const scm t2 = scm_mul(r, scm_sub(scm_mul(xx, scm_add(scm_mul(cp, wcv), scm_mul(U, dsum))), scm_mul(cp, t_x)));
       v = scm_add(t1, t2);
+      conv_by = scm_zero();
+      conv_by.v[0] = 1;
     } else {                                // B_blinding: -(e_blinding + r t_x_blinding)
       v = scm_neg(scm_add(e_bl, scm_mul(r, t_x_bl)));
     }
-    uint32_t o[8];
-    scm_to_words(o, v);
+    const scm conv = scm_mul(v, conv_by);   // Montgomery -> canonical words, times the plain factor
+    const uint32_t* o = conv.v;
     if (j < sh.n_dyn) {
       for (int q = 0; q < 8; ++q) { ds[j * 8 + q] = o[q]; dp[j * 8 + q] = pt[q]; }
     } else {
       for (int q = 0; q < 8; ++q) ss[(j - sh.n_dyn) * 8 + q] = o[q];
     }
   }
+}
+
+// generator scalars of a group: sum over its transactions (canonical words in and out)
+__global__ void __launch_bounds__(256)
+k_group_scalars(const uint32_t* __restrict__ st_scalars /*[B][n_static][8]*/, uint32_t n_msm, uint32_t n_static,
+                uint32_t group, uint32_t* __restrict__ out /*[groups][n_static][8]*/) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n_groups = (n_msm + group - 1) / group;
+  if (g >= (uint64_t)n_groups * n_static) return;
+  const uint32_t G = (uint32_t)(g / n_static), j = (uint32_t)(g % n_static);
+  scm acc = scm_zero();
+  for (uint32_t i = 0; i < group; ++i) {
+    const uint32_t tx = G * group + i;
+    if (tx >= n_msm) break;
+    const uint4* src = reinterpret_cast<const uint4*>(st_scalars + ((uint64_t)tx * n_static + j) * 8);
+    const uint4 a = src[0], b = src[1];
+    scm v;
+    v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w; v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
+    acc = scm_add(acc, v);
+  }
+  uint4* dst = reinterpret_cast<uint4*>(out + g * 8);
+  dst[0] = make_uint4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]);
+  dst[1] = make_uint4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
 }
 
 }  // namespace zk

@@ -76,6 +76,9 @@ struct zkgpu_ctx {
   Buffer msm_fail, status, accept, bitmap, ok_bytes, values, uniform;
   Buffer digits, st_partials, dynsum, accept2, bin_order, class_count, part_hist, part_entries, part_lo, dec_scratch, heavy;
   Buffer small_tbl, recoded;
+  Buffer grp_sc, grp_digits, grp_partials, grp_ok, row_map;
+  int group_size = 16;             // transactions per group check (1 = every transaction on its own)
+  hipEvent_t ev_dig = nullptr;
   Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
   int forced_parts = 0;
   void* pinned = nullptr;   // host staging for results
@@ -153,12 +156,29 @@ struct Launch {
   }
 };
 
+// ZKGPU_TIMELINE=<file>: every profiled launch as "ctx name start_ms end_ms" on one device-wide clock
+// (a debugging aid for the batches-in-flight pipeline; the reference event is recorded at first use)
+hipEvent_t g_timeline_ref = nullptr;
+FILE* g_timeline = nullptr;
+std::mutex g_timeline_mu;
+
 void prof_collect(zkgpu_ctx* c) {
+  static const char* tl_path = getenv("ZKGPU_TIMELINE");
   for (auto& u : c->ev_used) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->ev_pool[u.second].first, c->ev_pool[u.second].second) == hipSuccess) {
       c->prof[u.first].launches += 1;
       c->prof[u.first].ms += ms;
+    }
+    if (tl_path && g_timeline_ref) {
+      std::lock_guard<std::mutex> lk(g_timeline_mu);
+      if (!g_timeline) g_timeline = fopen(tl_path, "w");
+      float a = 0, b = 0;
+      if (g_timeline && hipEventElapsedTime(&a, g_timeline_ref, c->ev_pool[u.second].first) == hipSuccess &&
+          hipEventElapsedTime(&b, g_timeline_ref, c->ev_pool[u.second].second) == hipSuccess) {
+        fprintf(g_timeline, "%p %s %.4f %.4f\n", (void*)c, c->prof[u.first].name, a, b);
+        fflush(g_timeline);
+      }
     }
   }
   c->ev_used.clear();
@@ -569,7 +589,8 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
     Launch l(c, "k_static_accumulate", s2);
     hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s2,
                        (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
-                       (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)B, job.n_static, (uint32_t*)c->st_partials.p);
+                       (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)B, job.n_static, (uint32_t*)c->st_partials.p,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
   }
   HIP_TRY(c, hipEventRecord(c->ev_join, s2));
   HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
@@ -578,7 +599,7 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
     hipLaunchKernelGGL(k_static_combine, dim3((unsigned)B), dim3(64), 0, s, (const uint32_t*)c->st_partials.p,
                        (uint32_t)(W * P), has_dyn ? (const uint32_t*)c->dynsum.p : (const uint32_t*)nullptr,
                        has_dyn ? (const uint8_t*)c->accept.p : (const uint8_t*)nullptr, (const uint32_t*)nullptr,
-                       (uint8_t*)c->accept2.p);
+                       (const uint32_t*)nullptr, (uint8_t*)c->accept2.p);
   }
   {
     Launch l(c, "k_pack_bitmap");
@@ -611,7 +632,8 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
 struct PrepLaunch {
   PrepShape sh;
   const uint32_t *d_init, *d_mono_chal, *d_mono_pow, *d_tgt_off, *d_term_q, *d_term_mono, *d_term_coef;
-  const uint8_t* d_chal_label;
+  const uint32_t* d_tape;
+  uint32_t n_ops;
   size_t lds_bytes;
   const uint32_t* d_com;
   const uint8_t* d_proofs;
@@ -634,13 +656,29 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     P = std::max(1, std::min(16, P));
   }
   const uint64_t n_lanes = (uint64_t)B * W * P;
+  // group checks (k_group_combine): only for whole proofs (the weights come from k_transcript)
+  const uint32_t group = (prep && c->group_size > 1) ? (uint32_t)std::min<size_t>(c->group_size, B) : 1;
+  const uint32_t n_groups = (uint32_t)((B + group - 1) / group);
+  const uint32_t ns = prep ? prep->sh.n_static : 0;
+  // parts per (check, window) of the group launch and of the individual re-check (few checks each:
+  // short chains of additions per lane keep their latency down)
+  int Pg = 1;
+  const int Pf = 32;
+  if (group > 1) {
+    Pg = (int)std::max<uint64_t>(1, std::min<uint64_t>(32, (65536 + (uint64_t)n_groups * W - 1) / ((uint64_t)n_groups * W)));
+    TRY(ensure(c, c->grp_sc, (size_t)n_groups * ns * 32));
+    TRY(ensure(c, c->grp_digits, (size_t)n_groups * ns * W * 2));
+    TRY(ensure(c, c->grp_partials, (size_t)n_groups * W * Pg * EXT_WORDS * 4));
+    TRY(ensure(c, c->grp_ok, n_groups));
+    TRY(ensure(c, c->row_map, B * 4));
+  }
   TRY(ensure(c, c->accept, B));
   TRY(ensure(c, c->accept2, B));
   TRY(ensure(c, c->bitmap, nbytes));
   TRY(ensure_pinned(c, nbytes + 64));
   TRY(ensure(c, c->status, 64));
   TRY(ensure(c, c->digits, std::max<uint64_t>(job.n_static, 1) * W * 2));
-  TRY(ensure(c, c->st_partials, n_lanes * EXT_WORDS * 4));
+  TRY(ensure(c, c->st_partials, std::max<uint64_t>(n_lanes, group > 1 ? (uint64_t)B * W * Pf : 0) * EXT_WORDS * 4));
   TRY(ensure(c, c->dynsum, B * EXT_WORDS * 4));
   TRY(ensure(c, c->dyn_rows, std::max<uint64_t>(job.n_dyn, 1) * NIELS_WORDS * 4));
   TRY(ensure(c, c->window_sums, (size_t)B * 64 * EXT_WORDS * 4));
@@ -649,6 +687,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   c->last_w = 4;
   HIP_TRY(c, hipMemsetAsync(c->status.p, 0, 8, L));
   HIP_TRY(c, hipMemsetAsync((char*)c->status.p + 8, 0xff, 8, L));
+  HIP_TRY(c, hipMemsetAsync((char*)c->status.p + 32, 0, 4, L));     // transactions queued for the individual re-check
   HIP_TRY(c, hipMemsetAsync(c->msm_fail.p, 0, (size_t)B * 4, L));
   if (prep) {
     const PrepShape& sh = prep->sh;
@@ -661,9 +700,9 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     }
     {
       Launch l(c, "k_transcript", L);
-      hipLaunchKernelGGL(k_transcript, dim3(blocks_for(B, 64)), dim3(64), 0, L, sh, prep->d_init, prep->d_chal_label,
-                         prep->d_com, (const uint32_t*)c->prep_pw.p, prep->d_r, (uint32_t)B, (uint32_t*)c->prep_ch.p,
-                         (uint32_t*)c->prep_wf.p, prep->d_mono_chal, prep->d_mono_pow);
+      hipLaunchKernelGGL(k_transcript, dim3(blocks_for(B, 64)), dim3(64), 0, L, sh, prep->d_init,
+                         (const uint4*)prep->d_tape, prep->n_ops, prep->d_com, (const uint32_t*)c->prep_pw.p, prep->d_r, (uint32_t)B, (uint32_t*)c->prep_ch.p,
+                         (uint32_t*)c->prep_wf.p, prep->d_mono_chal, prep->d_mono_pow, group > 1 ? 1u : 0u);
     }
   }
   HIP_TRY(c, hipEventRecord(c->ev_t, L));
@@ -679,18 +718,48 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   HIP_TRY(c, hipEventRecord(c->ev_p, prep ? c->stream3 : L));
   HIP_TRY(c, hipStreamWaitEvent(H1, c->ev_p, 0));
   HIP_TRY(c, hipStreamWaitEvent(H2, c->ev_p, 0));
-  {
-    Launch l(c, "k_static_digits", H2);
-    hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, H2, job.d_st_scalars,
-                       (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p);
+  uint32_t* n_recheck = (uint32_t*)((char*)c->status.p + 32);
+  if (group > 1) {
+    {
+      Launch l(c, "k_group_scalars", H2);
+      hipLaunchKernelGGL(k_group_scalars, dim3(blocks_for((uint64_t)n_groups * ns, 256)), dim3(256), 0, H2,
+                         job.d_st_scalars, (uint32_t)B, ns, group, (uint32_t*)c->grp_sc.p);
+    }
+    {
+      Launch l(c, "k_static_digits", H2);
+      hipLaunchKernelGGL(k_static_digits, dim3(blocks_for((uint64_t)n_groups * ns, 256)), dim3(256), 0, H2,
+                         (const uint32_t*)c->grp_sc.p, (int16_t*)c->grp_digits.p, (uint64_t)n_groups * ns, ps->tbl_w, W,
+                         (uint32_t*)c->status.p);
+    }
+    {
+      Launch l(c, "k_static_accumulate", H2);
+      hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)n_groups * W * Pg, 256)), dim3(256), 0, H2,
+                         (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
+                         (uint32_t)ps->n, ps->tbl_H, W, Pg, n_groups, (uint64_t)n_groups * ns,
+                         (uint32_t*)c->grp_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_sa, H2));
+    {
+      Launch l(c, "k_static_digits", H2);       // per transaction, for the groups that fail
+      hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, H2, job.d_st_scalars,
+                         (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p);
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_dig, H2));
+  } else {
+    {
+      Launch l(c, "k_static_digits", H2);
+      hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, H2, job.d_st_scalars,
+                         (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p);
+    }
+    {
+      Launch l(c, "k_static_accumulate", H2);
+      hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, H2,
+                         (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
+                         (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)B, job.n_static, (uint32_t*)c->st_partials.p,
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_sa, H2));
   }
-  {
-    Launch l(c, "k_static_accumulate", H2);
-    hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, H2,
-                       (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
-                       (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)B, job.n_static, (uint32_t*)c->st_partials.p);
-  }
-  HIP_TRY(c, hipEventRecord(c->ev_sa, H2));
   {
     Launch l(c, "k_decompress", H1);
     hipLaunchKernelGGL(k_decompress, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, H1, job.d_dyn_points,
@@ -708,11 +777,34 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
                        (uint32_t*)c->dynsum.p, (uint32_t)B, 4, 64);
   }
   HIP_TRY(c, hipStreamWaitEvent(L, c->ev_sa, 0));
-  {
+  if (group > 1) {
+    {
+      Launch l(c, "k_group_combine", L);
+      hipLaunchKernelGGL(k_group_combine, dim3(n_groups), dim3(64), 0, L, (const uint32_t*)c->grp_partials.p,
+                         (uint32_t)(W * Pg), (const uint32_t*)c->dynsum.p, (const uint8_t*)c->accept.p,
+                         job.d_wellformed, (uint32_t)B, group, (uint8_t*)c->grp_ok.p, (uint8_t*)c->accept2.p,
+                         (uint32_t*)c->row_map.p, n_recheck);
+    }
+    // failed groups, transaction by transaction: full-size grids, lanes beyond the queued count leave at once
+    HIP_TRY(c, hipStreamWaitEvent(L, c->ev_dig, 0));
+    {
+      Launch l(c, "k_static_accumulate", L);
+      hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)B * W * Pf, 256)), dim3(256), 0, L,
+                         (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
+                         (uint32_t)ps->n, ps->tbl_H, W, Pf, (uint32_t)B, job.n_static, (uint32_t*)c->st_partials.p,
+                         (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck);
+    }
+    {
+      Launch l(c, "k_static_combine", L);
+      hipLaunchKernelGGL(k_static_combine, dim3((unsigned)B), dim3(64), 0, L, (const uint32_t*)c->st_partials.p,
+                         (uint32_t)(W * Pf), (const uint32_t*)c->dynsum.p, (const uint8_t*)c->accept.p,
+                         (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, (uint8_t*)c->accept2.p);
+    }
+  } else {
     Launch l(c, "k_static_combine", L);
     hipLaunchKernelGGL(k_static_combine, dim3((unsigned)B), dim3(64), 0, L, (const uint32_t*)c->st_partials.p,
                        (uint32_t)(W * P), (const uint32_t*)c->dynsum.p, (const uint8_t*)c->accept.p,
-                       (const uint32_t*)nullptr, (uint8_t*)c->accept2.p);
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)c->accept2.p);
   }
   {
     Launch l(c, "k_pack_bitmap", L);
@@ -813,13 +905,19 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
     c->stream2 = parent->stream2;
     c->stream3 = parent->stream3;
     c->owns_streams = false;
+    c->group_size = parent->group_size;
   } else {
     ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
          hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
          hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   }
-  ok = ok && hipStreamCreateWithPriority(&c->stream_l, hipStreamNonBlocking, prio_greatest) == hipSuccess;
-  hipEvent_t* evs[] = {&c->ev_fork, &c->ev_join, &c->ev_t, &c->ev_p, &c->ev_sm, &c->ev_sa, &c->ev_done};
+  {
+    int lp = prio_greatest;
+    if (const char* e = getenv("ZKGPU_L_PRIO")) lp = atoi(e);
+    ok = ok && hipStreamCreateWithPriority(&c->stream_l, hipStreamNonBlocking, lp) == hipSuccess;
+    if (getenv("ZKGPU_L_PRIO")) fprintf(stderr, "prio range least=%d greatest=%d L=%d\n", prio_least, prio_greatest, lp);
+  }
+  hipEvent_t* evs[] = {&c->ev_fork, &c->ev_join, &c->ev_t, &c->ev_p, &c->ev_sm, &c->ev_sa, &c->ev_done, &c->ev_dig};
   for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   if (!ok) { delete c; return ZKGPU_EHIP; }
   *out = c;
@@ -880,7 +978,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
                     &c->in_st_offsets, &c->dyn_rows, &c->bins, &c->block_sums, &c->entries, &c->buckets,
                     &c->partials, &c->partial_flags, &c->window_sums, &c->window_flags, &c->msm_fail,
                     &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform,
-                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->small_tbl, &c->recoded, &c->prep_com, &c->prep_proofs, &c->prep_r,
+                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->small_tbl, &c->recoded, &c->grp_sc, &c->grp_digits, &c->grp_partials, &c->grp_ok, &c->row_map, &c->prep_com, &c->prep_proofs, &c->prep_r,
                     &c->prep_pw, &c->prep_ch, &c->prep_wf, &c->prep_dyn_sc, &c->prep_dyn_pt, &c->prep_st_sc};
   for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -891,7 +989,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
   }
   if (c->stream_l) (void)hipStreamDestroy(c->stream_l);
-  hipEvent_t evs[] = {c->ev_fork, c->ev_join, c->ev_t, c->ev_p, c->ev_sm, c->ev_sa, c->ev_done};
+  hipEvent_t evs[] = {c->ev_fork, c->ev_join, c->ev_t, c->ev_p, c->ev_sm, c->ev_sa, c->ev_done, c->ev_dig};
   for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
   delete c;
 }
@@ -1038,6 +1136,29 @@ int zkgpu_pointset_build_tables(zkgpu_ctx* c, zkgpu_pointset* ps, int window_bit
 
 size_t zkgpu_pointset_table_bytes(const zkgpu_pointset* ps) {
   return (ps && ps->table) ? (size_t)ps->tbl_W * ps->n * ps->tbl_H * TABLE_WORDS * 4 : 0;
+}
+
+// Test hook: the intermediate buffers of the last device-side preparation on this context
+// ("challenges": n_ch_ext x 32 B per transaction, Montgomery form; "static_scalars", "dyn_scalars",
+// "dyn_points": canonical 32-byte values).  Copies min(bytes, size) bytes; returns the bytes copied or < 0.
+long long zkgpu_debug_read(zkgpu_ctx* c, const char* what, void* out, size_t bytes) {
+  if (!c || !what || !out) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  const std::string w(what);
+  const Buffer* b = w == "challenges" ? &c->prep_ch : w == "static_scalars" ? &c->prep_st_sc :
+                    w == "dyn_scalars" ? &c->prep_dyn_sc : w == "dyn_points" ? &c->prep_dyn_pt : nullptr;
+  if (!b || !b->p) return ZKGPU_EINVAL;
+  const size_t n = std::min(bytes, b->cap);
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, b->p, n, hipMemcpyDeviceToHost) != hipSuccess) return ZKGPU_EHIP;
+  return (long long)n;
+}
+
+int zkgpu_set_group_size(zkgpu_ctx* c, int group) {
+  if (!c || group < 1 || group > 64) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->group_size = group;
+  return ZKGPU_OK;
 }
 
 int zkgpu_set_static_parts(zkgpu_ctx* c, int parts) {
@@ -1216,6 +1337,8 @@ struct zkgpu_cloak_plan {
   uint32_t *d_init = nullptr, *d_mono_chal = nullptr, *d_mono_pow = nullptr, *d_tgt_off = nullptr, *d_term_q = nullptr,
            *d_term_mono = nullptr, *d_term_coef = nullptr;
   uint8_t* d_chal_label = nullptr;
+  uint32_t* d_tape = nullptr;     // transcript_tape.hpp, four words per operation
+  uint32_t n_ops = 0;
   // per-batch-size cached CSR scaffolding
   size_t cached_batch = 0;
   uint64_t *d_dyn_off = nullptr, *d_st_off = nullptr;
@@ -1288,6 +1411,11 @@ int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t 
   std::vector<uint32_t> init(52);
   tr.export_state(init.data());
   TRY(plan_upload(c, &p->d_init, init));
+  {
+    const std::vector<uint32_t> tape = build_r1cs_verifier_tape(init[50], init[51], s.m, h.chal_label, s.k, s.pn, CH_FIXED);
+    p->n_ops = (uint32_t)(tape.size() / 4);
+    TRY(plan_upload(c, &p->d_tape, tape));
+  }
   TRY(plan_upload(c, &p->d_chal_label, h.chal_label));
   TRY(plan_upload(c, &p->d_mono_chal, h.mono_chal));
   TRY(plan_upload(c, &p->d_mono_pow, h.mono_pow));
@@ -1303,7 +1431,7 @@ int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t 
 void zkgpu_cloak_plan_destroy(zkgpu_cloak_plan* p) {
   if (!p) return;
   DeviceGuard g(p->ctx->device);
-  void* ptrs[] = {p->d_init, p->d_chal_label, p->d_mono_chal, p->d_mono_pow, p->d_tgt_off, p->d_term_q, p->d_term_mono,
+  void* ptrs[] = {p->d_tape, p->d_init, p->d_chal_label, p->d_mono_chal, p->d_mono_pow, p->d_tgt_off, p->d_term_q, p->d_term_mono,
                   p->d_term_coef, p->d_dyn_off, p->d_st_off, p->d_st_index};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   delete p;
@@ -1427,7 +1555,7 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
     pl.sh = sh;
     pl.d_init = plan->d_init; pl.d_mono_chal = plan->d_mono_chal; pl.d_mono_pow = plan->d_mono_pow;
     pl.d_tgt_off = plan->d_tgt_off; pl.d_term_q = plan->d_term_q; pl.d_term_mono = plan->d_term_mono;
-    pl.d_term_coef = plan->d_term_coef; pl.d_chal_label = plan->d_chal_label; pl.lds_bytes = plan->lds_bytes;
+    pl.d_term_coef = plan->d_term_coef; pl.d_tape = plan->d_tape; pl.n_ops = plan->n_ops; pl.lds_bytes = plan->lds_bytes;
     pl.d_com = d_com; pl.d_proofs = d_proofs; pl.d_r = d_r; pl.proof_len = proof_len;
     return pipe_enqueue(c, job, ps, &pl);
   }
@@ -1444,9 +1572,9 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
   {
     Launch l(c, "k_transcript");
     hipLaunchKernelGGL(k_transcript, dim3(blocks_for(B, 64)), dim3(64), 0, s, sh, (const uint32_t*)plan->d_init,
-                       (const uint8_t*)plan->d_chal_label, d_com, (const uint32_t*)c->prep_pw.p,
+                       (const uint4*)plan->d_tape, plan->n_ops, d_com, (const uint32_t*)c->prep_pw.p,
                        d_r, B, (uint32_t*)c->prep_ch.p, (uint32_t*)c->prep_wf.p, (const uint32_t*)plan->d_mono_chal,
-                       (const uint32_t*)plan->d_mono_pow);
+                       (const uint32_t*)plan->d_mono_pow, 0u);
   }
   {
     Launch l(c, "k_prepare");
@@ -1628,6 +1756,18 @@ int zkgpu_profile_enable(zkgpu_ctx* c, int on) {
   if (!c) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   c->profiling = on != 0;
+  if (on && getenv("ZKGPU_TIMELINE")) {
+    std::lock_guard<std::mutex> tl(g_timeline_mu);
+    if (!g_timeline_ref) {
+      DeviceGuard g(c->device);
+      if (hipEventCreate(&g_timeline_ref) == hipSuccess) {
+        (void)hipEventRecord(g_timeline_ref, c->stream_l);
+        (void)hipEventSynchronize(g_timeline_ref);
+      } else {
+        g_timeline_ref = nullptr;
+      }
+    }
+  }
   return ZKGPU_OK;
 }
 
