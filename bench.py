@@ -197,7 +197,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="transactions per GPU")
     ap.add_argument("--table-bits", type=int, default=int(os.environ.get("ZKGPU_TABLE_BITS", "16")),
                     help="window width of the fixed-base generator tables (0 = no tables: Pippenger for every term)")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKGPU_INFLIGHT", "4")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKGPU_INFLIGHT", "6")),
                     help="independent verify calls in flight per GPU (contexts x host threads)")
     ap.add_argument("--group", type=int, default=int(os.environ.get("ZKGPU_GROUP", "16")),
                     help="transactions per group check (zkgpu_set_group_size); 1 = every transaction on its own")
@@ -298,7 +298,11 @@ def main():
         return bm
 
     bm = run_steps(max(args.warmup, len(ctxs)))
-    for c in ctxs:
+    # HIP events around every launch of ONE of the contexts in flight (every len(ctxs)-th step): the
+    # per-kernel durations of the roofline object are measured inside the timed region without
+    # fencing every kernel of every batch
+    prof_ctxs = ctxs[:1]
+    for c in prof_ctxs:
         c.profile_reset()
         c.profile(True)
     if world > 1:
@@ -312,7 +316,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     submit_ms = host_time["submit"] / max(host_time["n"], 1) * 1e3
-    for c in ctxs:
+    for c in prof_ctxs:
         c.profile(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -325,12 +329,13 @@ def main():
 
     if rank == 0:
         prof = {}
-        for c in ctxs:
+        for c in prof_ctxs:
             for k, v in c.profile_read().items():
                 a = prof.get(k, (0, 0.0))
                 prof[k] = (a[0] + v[0], a[1] + v[1])
         kern_ms = {k: v[1] / v[0] for k, v in prof.items() if v[0]}
-        total_kernel_ms = sum(v[1] for v in prof.values()) / max(args.steps, 1)
+        profiled_steps = max(1, (args.steps + len(ctxs) - 1) // len(ctxs))
+        total_kernel_ms = sum(v[1] for v in prof.values()) / profiled_steps
         # Dominant kernel = the one that issues most of the step's VALU work, not the longest-lived one:
         # with several calls in flight the latency-bound tail kernels (k_msm_finish: 16-64 wavefronts
         # walking a 255-doubling chain) show long durations while occupying a sliver of the chip.
@@ -344,9 +349,19 @@ def main():
         tbits = args.table_bits
         # Per-launch algorithmic bytes (64 B per proof-specific term, 32 B per
         # generator scalar, generator points amortised) and mixed additions of the kernels that carry them.
+        # k_static_accumulate runs twice per step when the batch is checked in groups: once over the
+        # n_groups summed checks, once over the transactions of the groups that failed
+        n_win = (255 // tbits + 1) if tbits else 0
+        if args.group > 1:
+            g = min(args.group, batch)
+            n_groups = (batch + g - 1) // g
+            recheck = sum(min(g, batch - G * g) for G in range(n_groups) if not all(w["expected"][G * g: (G + 1) * g]))
+            sa_terms, sa_launches = (n_groups + recheck) * N_STATIC, 2
+        else:
+            n_groups, recheck = batch, 0
+            sa_terms, sa_launches = batch * N_STATIC, 1
         per_kernel = {
-            "k_static_accumulate": {"bytes": 32 * N_STATIC * batch,
-                                    "madds": batch * N_STATIC * (255 // tbits + 1) if tbits else 0},
+            "k_static_accumulate": {"bytes": 32 * sa_terms / sa_launches, "madds": sa_terms * n_win / sa_launches},
             "k_bucket_accumulate": {"bytes": (64 * N_DYN + (0 if tbits else 32 * N_STATIC)) * batch,
                                     "madds": batch * (N_DYN + (0 if tbits else N_STATIC)) * (255 // wbits + 1)},
         }
@@ -354,13 +369,15 @@ def main():
         alg_bytes = info["bytes"]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         mads = info["madds"] * MADS_PER_MADD
-        # solo pass: the same kernels with nothing else in flight (one context, profiling on)
+        # solo pass: every kernel of a batch alone on the chip (one context, one stream, profiling on)
         ctx.profile_reset()
+        ctx.set_serial(True)
         ctx.profile(True)
         for _ in range(5):
             submit_verify(ctx)
             ctx.verify_wait()
         ctx.profile(False)
+        ctx.set_serial(False)
         solo = {k: v[1] / v[0] for k, v in ctx.profile_read().items() if v[0]}
         solo_ms = solo.get(dom, dom_ms)
         traffic = None
@@ -432,8 +449,12 @@ def main():
                          "achieved_solo": round(alg_bytes / (solo_ms * 1e-3) / 1e9, 3),
                          "note": "avg_launch_ms is measured with %d verify calls in flight (kernels of different "
                                  "calls share the chip); *_solo is the same kernel alone" % len(ctxs),
-                         "binding_resource": "integer VALU (v_mad_u64_u32) and random 128-B table gathers, "
-                                             "not streaming HBM bandwidth",
+                         "binding_resource": "random 96-B gathers from the generator tables (one per mixed addition, "
+                                             "no reuse: %.1f GB of tables) and integer VALU (v_mad_u64_u32); "
+                                             "not streaming HBM bandwidth" % (int(ctx.lib.zkgpu_pointset_table_bytes(w["gens"].points.h)) / 1e9),
+                         "table_gather": {"bytes_per_launch": int(info["madds"] * 96),
+                                          "GBs_solo": round(info["madds"] * 96 / (solo_ms * 1e-3) / 1e9, 1),
+                                          "frac_of_hbm_peak_solo": round(info["madds"] * 96 / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                          "valu_int": {"achieved_Gmad_s": round(mads / (solo_ms * 1e-3) / 1e9, 1),
                                       "peak_Gmad_s": MAD_PEAK_GOPS,
                                       "frac": round(mads / (solo_ms * 1e-3) / 1e9 / MAD_PEAK_GOPS, 4),

@@ -177,6 +177,10 @@ int zkgpu_ctx_fork(zkgpu_ctx* parent, zkgpu_ctx** out);
  * r1cs::Verifier::verify of many proofs over one BulletproofGens.) */
 int zkgpu_set_group_size(zkgpu_ctx* ctx, int group);
 
+/* Measurement aid: with on != 0 the kernels of a batch run one after another on a single stream
+ * (no overlap), so that the profile hooks report each kernel's duration alone on the chip. */
+int zkgpu_set_serial(zkgpu_ctx* ctx, int on);
+
 /* Test hook: intermediate buffers of the last device-side preparation on this context.
  * what = "challenges" (per transaction n_ch_ext slots of 32 B, Montgomery form R = 2^256),
  * "static_scalars", "dyn_scalars", "dyn_points" (canonical 32-byte values).  Returns bytes copied. */

@@ -61,6 +61,11 @@ struct zkgpu_ctx {
   // the contexts forked from this one (zkgpu_ctx_fork), so that those run first-in first-out
   hipStream_t stream_l = nullptr;
   hipStream_t stream3 = nullptr;        // shared like stream/stream2: the scalar preparation (k_prepare)
+  // a parent keeps ZKGPU_LANES (default 2) sets of the three shared streams; fork i uses set i mod lanes:
+  // consecutive batches alternate between the sets, so the latency-bound chains of two neighbours
+  // overlap while each set still runs its batches first-in first-out
+  std::vector<hipStream_t> lane_streams;   // owned by the parent: sets 1.. (set 0 = stream, stream2, stream3)
+  int n_forks = 0;
   bool owns_streams = true;
   hipEvent_t ev_t = nullptr, ev_p = nullptr, ev_sm = nullptr, ev_sa = nullptr, ev_done = nullptr;
   bool pending = false;            // a submitted batch has not been waited for yet
@@ -78,6 +83,7 @@ struct zkgpu_ctx {
   Buffer small_tbl, recoded;
   Buffer grp_sc, grp_digits, grp_partials, grp_ok, row_map;
   int group_size = 16;             // transactions per group check (1 = every transaction on its own)
+  bool serial = false;             // measurement aid: the whole DAG of a batch on one stream
   hipEvent_t ev_dig = nullptr;
   Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
   int forced_parts = 0;
@@ -648,7 +654,8 @@ bool pipe_eligible(const zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps)
 int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const PrepLaunch* prep) {
   const size_t B = job.n_msm;
   const size_t nbytes = (B + 7) / 8;
-  hipStream_t L = c->stream_l, H1 = c->stream, H2 = c->stream2;
+  hipStream_t L = c->stream_l, H1 = c->serial ? L : c->stream, H2 = c->serial ? L : c->stream2;
+  const hipStream_t H3s = c->serial ? L : c->stream3;
   const int W = ps->tbl_W;
   int P = c->forced_parts;
   if (P <= 0) {
@@ -707,7 +714,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   }
   HIP_TRY(c, hipEventRecord(c->ev_t, L));
   if (prep) {
-    hipStream_t H3 = c->stream3;
+    hipStream_t H3 = H3s;
     HIP_TRY(c, hipStreamWaitEvent(H3, c->ev_t, 0));
     Launch l(c, "k_prepare", H3);
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)B), dim3(256), prep->lds_bytes, H3, prep->sh, prep->d_mono_chal,
@@ -715,7 +722,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
                        (const uint32_t*)c->prep_ch.p, prep->d_com, (const uint32_t*)c->prep_pw.p,
                        (uint32_t*)c->prep_dyn_sc.p, (uint32_t*)c->prep_dyn_pt.p, (uint32_t*)c->prep_st_sc.p);
   }
-  HIP_TRY(c, hipEventRecord(c->ev_p, prep ? c->stream3 : L));
+  HIP_TRY(c, hipEventRecord(c->ev_p, prep ? H3s : L));
   HIP_TRY(c, hipStreamWaitEvent(H1, c->ev_p, 0));
   HIP_TRY(c, hipStreamWaitEvent(H2, c->ev_p, 0));
   uint32_t* n_recheck = (uint32_t*)((char*)c->status.p + 32);
@@ -901,9 +908,23 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   bool ok = true;
   if (parent) {
-    c->stream = parent->stream;
-    c->stream2 = parent->stream2;
-    c->stream3 = parent->stream3;
+    static const int lanes = [] { const char* e = getenv("ZKGPU_LANES"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    const int set = (++parent->n_forks) % lanes;
+    while (ok && (int)parent->lane_streams.size() < 3 * (lanes - 1)) {
+      hipStream_t st = nullptr;
+      const int which = (int)parent->lane_streams.size() % 3;
+      ok = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, which == 1 ? prio_least : prio_greatest) == hipSuccess;
+      if (ok) parent->lane_streams.push_back(st);
+    }
+    if (ok && set > 0) {
+      c->stream = parent->lane_streams[3 * (set - 1)];
+      c->stream2 = parent->lane_streams[3 * (set - 1) + 1];
+      c->stream3 = parent->lane_streams[3 * (set - 1) + 2];
+    } else {
+      c->stream = parent->stream;
+      c->stream2 = parent->stream2;
+      c->stream3 = parent->stream3;
+    }
     c->owns_streams = false;
     c->group_size = parent->group_size;
   } else {
@@ -987,6 +1008,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
     (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    for (hipStream_t st : c->lane_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   }
   if (c->stream_l) (void)hipStreamDestroy(c->stream_l);
   hipEvent_t evs[] = {c->ev_fork, c->ev_join, c->ev_t, c->ev_p, c->ev_sm, c->ev_sa, c->ev_done, c->ev_dig};
@@ -1152,6 +1174,15 @@ long long zkgpu_debug_read(zkgpu_ctx* c, const char* what, void* out, size_t byt
   const size_t n = std::min(bytes, b->cap);
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, b->p, n, hipMemcpyDeviceToHost) != hipSuccess) return ZKGPU_EHIP;
   return (long long)n;
+}
+
+// Measurement aid: run the kernels of each batch one after another on a single stream, so that
+// profiled durations are those of each kernel alone on the chip.
+int zkgpu_set_serial(zkgpu_ctx* c, int on) {
+  if (!c) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->serial = on != 0;
+  return ZKGPU_OK;
 }
 
 int zkgpu_set_group_size(zkgpu_ctx* c, int group) {

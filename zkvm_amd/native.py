@@ -81,6 +81,7 @@ def load_library():
     lib.zkgpu_cloak_verify_batch_gpu_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, u8p]
     lib.zkgpu_ctx_fork.argtypes = [vp, C.POINTER(vp)]
     lib.zkgpu_set_group_size.argtypes = [vp, C.c_int]
+    lib.zkgpu_set_serial.argtypes = [vp, C.c_int]
     lib.zkgpu_malloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.zkgpu_free.argtypes = [vp, vp]
     lib.zkgpu_upload.argtypes = [vp, vp, u8p, sz]
@@ -175,6 +176,10 @@ class Context:
     def set_group_size(self, group: int) -> None:
         """zkgpu_set_group_size: transactions per group check of the whole-proof paths (1 = none)."""
         self._check(self.lib.zkgpu_set_group_size(self.h, group))
+
+    def set_serial(self, on: bool) -> None:
+        """zkgpu_set_serial: one stream for the whole batch (measurement aid)."""
+        self._check(self.lib.zkgpu_set_serial(self.h, 1 if on else 0))
 
     def fork(self) -> "Context":
         """zkgpu_ctx_fork: own workspace + light stream, the parent's heavy streams (batches in flight)."""
