@@ -201,6 +201,8 @@ def main():
                     help="independent verify calls in flight per GPU (contexts x host threads)")
     ap.add_argument("--group", type=int, default=int(os.environ.get("ZKGPU_GROUP", "16")),
                     help="transactions per group check (zkgpu_set_group_size); 1 = every transaction on its own")
+    ap.add_argument("--lean", action="store_true",
+                    help="the timed steps and the solo pass only (no extra legs): what tools/profile_bench.sh profiles")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-msm", action="store_true", help="skip the 2^20 MSM microbench")
     args = ap.parse_args()
@@ -387,39 +389,41 @@ def main():
                 traffic = json.load(open(pmc)).get(dom)
             except Exception:
                 traffic = None
-        # proof bytes -> accept bits, host half included (Merlin replay etc. on the host cores)
-        v = w["verifier"]
-        t0 = time.perf_counter()
-        bm_e2e = v.verify_bitmap(w["txs"], w["r_bytes"])
-        e2e_s = time.perf_counter() - t0
-        assert bm_e2e == bm
-        # the same call with its inputs in HOST memory (PCIe copies + python marshalling included)
-        packed_com = b"".join(t.commitments for t in w["txs"])
-        packed_proofs = b"".join(t.proof for t in w["txs"])
-        n_e2e = 6 * len(ctxs)
-        t0 = time.perf_counter()
-        hvs = [Verifier(c, w["gens"]) for c in ctxs]
-        for hv in hvs:
-            hv.__dict__["_plans"] = gv.__dict__["_plans"]     # one device plan per shape, shared
-        futs = [lanes[i % len(ctxs)].submit(hvs[i % len(ctxs)].verify_packed_gpu, tx0.n_in, tx0.n_out, batch,
-                                            packed_com, packed_proofs, proof_len, w["r_bytes"]) for i in range(n_e2e)]
-        outs = [f.result() for f in futs]
-        e2e_gpu_s = (time.perf_counter() - t0) / n_e2e
-        assert all(o == bm for o in outs)
-        # the multiscalar-multiplication boundary alone (scalars prepared beforehand by the host verifier)
-        assert run_steps(len(ctxs), submit_msm_only) == bm
-        t0 = time.perf_counter()
-        run_steps(args.steps, submit_msm_only)
-        msm_only_s = (time.perf_counter() - t0) / args.steps
-        # the same complete verification with every transaction checked on its own (no group checks)
-        for c in ctxs:
-            c.set_group_size(1)
-        assert run_steps(len(ctxs)) == bm
-        t0 = time.perf_counter()
-        run_steps(args.steps)
-        per_tx_s = (time.perf_counter() - t0) / args.steps
-        for c in ctxs:
-            c.set_group_size(args.group)
+        e2e_s = e2e_gpu_s = msm_only_s = per_tx_s = float("nan")
+        if not args.lean:
+            # proof bytes -> accept bits, host half included (Merlin replay etc. on the host cores)
+            v = w["verifier"]
+            t0 = time.perf_counter()
+            bm_e2e = v.verify_bitmap(w["txs"], w["r_bytes"])
+            e2e_s = time.perf_counter() - t0
+            assert bm_e2e == bm
+            # the same call with its inputs in HOST memory (PCIe copies + python marshalling included)
+            packed_com = b"".join(t.commitments for t in w["txs"])
+            packed_proofs = b"".join(t.proof for t in w["txs"])
+            n_e2e = 6 * len(ctxs)
+            t0 = time.perf_counter()
+            hvs = [Verifier(c, w["gens"]) for c in ctxs]
+            for hv in hvs:
+                hv.__dict__["_plans"] = gv.__dict__["_plans"]     # one device plan per shape, shared
+            futs = [lanes[i % len(ctxs)].submit(hvs[i % len(ctxs)].verify_packed_gpu, tx0.n_in, tx0.n_out, batch,
+                                                packed_com, packed_proofs, proof_len, w["r_bytes"]) for i in range(n_e2e)]
+            outs = [f.result() for f in futs]
+            e2e_gpu_s = (time.perf_counter() - t0) / n_e2e
+            assert all(o == bm for o in outs)
+            # the multiscalar-multiplication boundary alone (scalars prepared beforehand by the host verifier)
+            assert run_steps(len(ctxs), submit_msm_only) == bm
+            t0 = time.perf_counter()
+            run_steps(args.steps, submit_msm_only)
+            msm_only_s = (time.perf_counter() - t0) / args.steps
+            # the same complete verification with every transaction checked on its own (no group checks)
+            for c in ctxs:
+                c.set_group_size(1)
+            assert run_steps(len(ctxs)) == bm
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            per_tx_s = (time.perf_counter() - t0) / args.steps
+            for c in ctxs:
+                c.set_group_size(args.group)
         line = {
             "metric": "ZkVM tx verifications/sec (batch)",
             "value": round(batch * world * args.steps / elapsed, 1),
@@ -478,9 +482,12 @@ def main():
                                     "the device).  host_prepared: zkgpu_cloak_verify_batch (transcript replay and scalar "
                                     "preparation on %d host threads, host-bound).  Neither is `value`." % host_threads},
         }
-        if world == 1 and not args.no_cpu:
+        if args.lean:
+            for key in ("per_tx_checks", "msm_boundary", "host_memory"):
+                line.pop(key, None)
+        if world == 1 and not args.no_cpu and not args.lean:
             line["cpu_baseline"] = cpu_baseline(ctx, w, bm, batch)
-        if world == 1 and not args.no_msm:
+        if world == 1 and not args.no_msm and not args.lean:
             line["msm_2p20"] = msm_microbench(ctx, torch, dev)
         print(json.dumps(line))
     if world > 1:
