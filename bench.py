@@ -401,13 +401,11 @@ def main():
             packed_com = b"".join(t.commitments for t in w["txs"])
             packed_proofs = b"".join(t.proof for t in w["txs"])
             n_e2e = 6 * len(ctxs)
+            def submit_host(c):
+                gv.submit_packed_gpu(tx0.n_in, tx0.n_out, batch, packed_com, packed_proofs, proof_len, w["r_bytes"], ctx=c)
+            assert run_steps(len(ctxs), submit_host) == bm
             t0 = time.perf_counter()
-            hvs = [Verifier(c, w["gens"]) for c in ctxs]
-            for hv in hvs:
-                hv.__dict__["_plans"] = gv.__dict__["_plans"]     # one device plan per shape, shared
-            futs = [lanes[i % len(ctxs)].submit(hvs[i % len(ctxs)].verify_packed_gpu, tx0.n_in, tx0.n_out, batch,
-                                                packed_com, packed_proofs, proof_len, w["r_bytes"]) for i in range(n_e2e)]
-            outs = [f.result() for f in futs]
+            outs = [run_steps(n_e2e, submit_host)]
             e2e_gpu_s = (time.perf_counter() - t0) / n_e2e
             assert all(o == bm for o in outs)
             # the multiscalar-multiplication boundary alone (scalars prepared beforehand by the host verifier)

@@ -159,8 +159,9 @@ int zkgpu_cloak_verify_batch_gpu_dev(zkgpu_ctx *ctx, const zkgpu_pointset *ps, z
  * chip-filling kernels, so that those run first-in first-out across the batches in flight.  The
  * parent must outlive its forks.  A fork is a full context: every entry point accepts it.
  *
- * zkgpu_cloak_verify_submit_dev / zkgpu_verify_batch_ps_submit_dev: as the *_dev calls of the same
- * name without `submit`, but return once the work is queued; at most one batch may be pending per
+ * zkgpu_cloak_verify_submit (host buffers: staged through pinned memory, free for reuse on return) /
+ * zkgpu_cloak_verify_submit_dev / zkgpu_verify_batch_ps_submit_dev: as the calls of the same name
+ * without `submit`, but return once the work is queued; at most one batch may be pending per
  * context.  zkgpu_verify_wait blocks until that batch is done and writes its accept bitmap
  * ((batch + 7) / 8 bytes; zeroed on any error: fail-closed).
  * (Replaces: a Rust caller running `Verifier::verify` for several blocks on a thread pool.) */
@@ -191,6 +192,9 @@ long long zkgpu_debug_read(zkgpu_ctx* ctx, const char* what, void* out, size_t b
 int zkgpu_malloc(zkgpu_ctx* ctx, size_t bytes, void** out);
 int zkgpu_free(zkgpu_ctx* ctx, void* d_ptr);
 int zkgpu_upload(zkgpu_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int zkgpu_cloak_verify_submit(zkgpu_ctx* ctx, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
+                              const uint8_t* commitments, const uint8_t* proofs, size_t proof_len,
+                              const uint8_t* r_bytes);
 int zkgpu_cloak_verify_submit_dev(zkgpu_ctx* ctx, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
                                   const void* d_commitments, const void* d_proofs, size_t proof_len, const void* d_r);
 int zkgpu_verify_batch_ps_submit_dev(zkgpu_ctx* ctx, const zkgpu_pointset* ps, size_t batch, const void* d_dyn_scalars,

@@ -89,6 +89,8 @@ struct zkgpu_ctx {
   int forced_parts = 0;
   void* pinned = nullptr;   // host staging for results
   size_t pinned_cap = 0;
+  void* pinned_in = nullptr;   // host staging for inputs handed over in host memory
+  size_t pinned_in_cap = 0;
   // profiling
   bool profiling = false;
   std::vector<ProfEntry> prof;
@@ -1003,6 +1005,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
                     &c->prep_pw, &c->prep_ch, &c->prep_wf, &c->prep_dyn_sc, &c->prep_dyn_pt, &c->prep_st_sc};
   for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->pinned_in) (void)hipHostFree(c->pinned_in);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->owns_streams) {
     (void)hipStreamDestroy(c->stream);
@@ -1484,10 +1487,65 @@ int zkgpu_cloak_plan_info(const zkgpu_cloak_plan* p, uint32_t* multipliers, uint
 // then the multiscalar multiplications.  All `batch` statements have the plan's shape.
 namespace {
 // shared body: d_com / d_proofs / d_r are device pointers
+int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
+                             const uint32_t* d_com, const uint8_t* d_proofs, const uint32_t* d_r, size_t proof_len);
 int cloak_verify_gpu_body(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
                           const uint32_t* d_com, const uint8_t* d_proofs, const uint32_t* d_r, size_t proof_len,
                           uint8_t* accept_bitmap);
 }  // namespace
+
+namespace {
+// host buffers -> pinned staging -> device, queued on the context's light stream (no host wait: the
+// caller's buffers are free again when this returns, the copies overlap the batches in flight)
+int stage_inputs(zkgpu_ctx* c, const PrepShape& sh, size_t batch, const uint8_t* commitments, const uint8_t* proofs,
+                 size_t proof_len, const uint8_t* r_bytes) {
+  const size_t n_com = batch * sh.m * 32, n_pr = batch * proof_len, n_r = batch * 64;
+  const size_t o_pr = (n_com + 255) & ~(size_t)255, o_r = (o_pr + n_pr + 255) & ~(size_t)255;
+  if (c->pinned_in_cap < o_r + n_r) {
+    if (c->pinned_in) HIP_TRY(c, hipHostFree(c->pinned_in));
+    c->pinned_in = nullptr; c->pinned_in_cap = 0;
+    HIP_TRY(c, hipHostMalloc(&c->pinned_in, o_r + n_r + 4096, hipHostMallocDefault));
+    c->pinned_in_cap = o_r + n_r + 4096;
+  }
+  char* h = (char*)c->pinned_in;
+  memcpy(h, commitments, n_com);
+  memcpy(h + o_pr, proofs, n_pr);
+  if (r_bytes) {
+    memcpy(h + o_r, r_bytes, n_r);
+  } else {             // verifier randomness from the OS
+    std::random_device rd;
+    for (size_t i = 0; i < n_r; i += 4) { uint32_t v = rd(); memcpy(h + o_r + i, &v, 4); }
+  }
+  TRY(ensure(c, c->prep_com, std::max<size_t>(n_com, 16)));
+  TRY(ensure(c, c->prep_proofs, std::max<size_t>(n_pr, 16)));
+  TRY(ensure(c, c->prep_r, std::max<size_t>(n_r, 16)));
+  HIP_TRY(c, hipMemcpyAsync(c->prep_com.p, h, n_com, hipMemcpyHostToDevice, c->stream_l));
+  HIP_TRY(c, hipMemcpyAsync(c->prep_proofs.p, h + o_pr, n_pr, hipMemcpyHostToDevice, c->stream_l));
+  HIP_TRY(c, hipMemcpyAsync(c->prep_r.p, h + o_r, n_r, hipMemcpyHostToDevice, c->stream_l));
+  return ZKGPU_OK;
+}
+}  // namespace
+
+// Asynchronous form of zkgpu_cloak_verify_batch_gpu (inputs in host memory; they may be reused as
+// soon as this returns); zkgpu_verify_wait collects the bitmap.
+int zkgpu_cloak_verify_submit(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
+                              const uint8_t* commitments, const uint8_t* proofs, size_t proof_len,
+                              const uint8_t* r_bytes) {
+  if (!c || !ps || !plan || plan->device != c->device || ps->ctx->device != c->device) return ZKGPU_EINVAL;
+  if (batch == 0 || !commitments || !proofs || batch >= (1ull << 24)) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  if (c->pending) return ZKGPU_EINVAL;
+  const PrepShape& sh = plan->shape;
+  if (proof_len != 1 + 4ull * sh.proof_words) {     // wrong length for this statement: every proof is Err
+    std::vector<uint8_t> z((batch + 7) / 8, 0);
+    park_sync_result(c, ZKGPU_OK, z.data(), batch);
+    return ZKGPU_OK;
+  }
+  DeviceGuard g(c->device);
+  TRY(stage_inputs(c, sh, batch, commitments, proofs, proof_len, r_bytes));
+  return cloak_verify_gpu_enqueue(c, ps, plan, batch, (const uint32_t*)c->prep_com.p, (const uint8_t*)c->prep_proofs.p,
+                                  (const uint32_t*)c->prep_r.p, proof_len);
+}
 
 int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch,
                                  const uint8_t* commitments, const uint8_t* proofs, size_t proof_len,
@@ -1495,24 +1553,12 @@ int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_c
   if (!c || !ps || !plan || plan->device != c->device || ps->ctx->device != c->device || !accept_bitmap) return ZKGPU_EINVAL;
   memset(accept_bitmap, 0, (batch + 7) / 8);
   if (batch == 0) return ZKGPU_OK;
-  if (!commitments || !proofs || batch >= (1ull << 24)) return ZKGPU_EINVAL;
-  const PrepShape& sh = plan->shape;
-  if (proof_len != 1 + 4ull * sh.proof_words) return ZKGPU_OK;   // wrong length for this statement: every proof is Err
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  TRY(zkgpu_cloak_verify_submit(c, ps, plan, batch, commitments, proofs, proof_len, r_bytes));
   DeviceGuard g(c->device);
-  std::vector<uint8_t> rnd;
-  if (!r_bytes) {
-    rnd.resize(64 * batch);
-    std::random_device rd;
-    for (size_t i = 0; i < rnd.size(); i += 4) { uint32_t v = rd(); memcpy(&rnd[i], &v, 4); }
-    r_bytes = rnd.data();
-  }
-  TRY(upload(c, c->prep_com, commitments, batch * sh.m * 32, c->stream_l));
-  TRY(upload(c, c->prep_proofs, proofs, batch * proof_len, c->stream_l));
-  TRY(upload(c, c->prep_r, r_bytes, batch * 64, c->stream_l));
-  HIP_TRY(c, hipStreamSynchronize(c->stream_l));   // the sources are caller-owned (pageable) host memory
-  return cloak_verify_gpu_body(c, ps, plan, batch, (const uint32_t*)c->prep_com.p, (const uint8_t*)c->prep_proofs.p,
-                               (const uint32_t*)c->prep_r.p, proof_len, accept_bitmap);
+  int rc = pipe_wait(c, accept_bitmap);
+  if (rc != ZKGPU_OK) memset(accept_bitmap, 0, (batch + 7) / 8);
+  return rc;
 }
 
 // Inputs already resident in HBM (what bench.py times): d_commitments = batch x 64 (n_in + n_out)

@@ -86,6 +86,7 @@ def load_library():
     lib.zkgpu_free.argtypes = [vp, vp]
     lib.zkgpu_upload.argtypes = [vp, vp, u8p, sz]
     lib.zkgpu_cloak_verify_submit_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp]
+    lib.zkgpu_cloak_verify_submit.argtypes = [vp, vp, vp, sz, u8p, u8p, sz, u8p]
     lib.zkgpu_verify_batch_ps_submit_dev.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, sz]
     lib.zkgpu_verify_wait.argtypes = [vp, u8p]
     lib.zkgpu_cloak_prepare_batch.argtypes = [sz, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p, u8p,

@@ -151,6 +151,15 @@ class Verifier:
         c._pending_batch = batch
         return c
 
+    def submit_packed_gpu(self, n_in: int, n_out: int, batch: int, commitments: bytes, proofs: bytes, proof_len: int,
+                          r_bytes: Optional[bytes] = None, ctx: Optional[Context] = None) -> Context:
+        """zkgpu_cloak_verify_submit: as submit_packed_gpu_dev with the inputs in host memory."""
+        c = ctx or self.ctx
+        c._check(c.lib.zkgpu_cloak_verify_submit(c.h, self.bp_gens.points.h, self._plan(n_in, n_out), batch,
+                                                 commitments, proofs, proof_len, r_bytes))
+        c._pending_batch = batch
+        return c
+
     def close(self) -> None:
         for h in self.__dict__.get("_plans", {}).values():
             self.ctx.lib.zkgpu_cloak_plan_destroy(h)
