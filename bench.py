@@ -33,7 +33,7 @@ import os
 # Each batch in flight has a stream of its own for its latency-bound kernels; the HIP runtime maps
 # streams onto 4 hardware queues by default, which would serialise those streams again.  Must be set
 # before the runtime initialises (i.e. before torch is imported).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import argparse
 import hashlib
@@ -251,7 +251,7 @@ def main():
     # complete, independent verification of the whole batch; K steps are timed as a whole.
     from concurrent.futures import ThreadPoolExecutor
     ctx.set_group_size(args.group)               # forks inherit it
-    ctxs = [ctx] + [ctx.fork() for _ in range(max(1, args.inflight) - 1)]
+    ctxs = [ctx] + [ctx.fork() for _ in range(min(max(1, args.inflight), 10) - 1)]   # at most 9 forks per context
     lanes = [ThreadPoolExecutor(max_workers=1) for _ in ctxs]
 
     # THE STEP: the complete r1cs::Verifier::verify of every transaction of the batch, on the device,

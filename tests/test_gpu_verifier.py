@@ -190,3 +190,27 @@ def test_group_checks_give_per_transaction_verdicts(ctx, oracle, group):
         ctx.set_group_size(16)
         v.close()
         gens.close()
+
+
+def test_larger_shape_4x4_on_device(ctx, oracle):
+    """4-in/4-out cloak: 312 multipliers, padded n = 512, k = 9, 12 second-phase challenges -- the shape
+    whose plan needs the most LDS and flattening passes -- through the device-side verifier, with and
+    without group checks, against the oracle (SURVEY.md sec 8(d) config 4 draws from these shapes)."""
+    from zkvm_amd.verifier import BulletproofGens, CloakTx, Verifier
+    gens = BulletproofGens(ctx, 512, table_bits=6)
+    v = Verifier(ctx, gens)
+    txs = _txs(oracle, 9, 4, 4, b"\x44" * 32)
+    p = bytearray(txs[4].proof); p[1 + 32 * 13 + 7] ^= 2; txs[4] = CloakTx(4, 4, txs[4].commitments, bytes(p))   # e_blinding
+    r = hashlib.shake_256(b"4x4").digest(64 * len(txs))
+    want = [int(oracle.cloak_verify(t.commitments, 4, 4, t.proof, r[64 * i: 64 * i + 64])) for i, t in enumerate(txs)]
+    assert want == [1, 1, 1, 1, 0, 1, 1, 1, 1]
+    info = v.plan_info(4, 4)
+    assert info["padded_n"] == 512 and info["proof_len"] == len(txs[0].proof)
+    try:
+        for group in (16, 1, 4):
+            ctx.set_group_size(group)
+            assert bits(v.verify_bitmap_gpu(txs, r), len(txs)) == want, group
+    finally:
+        ctx.set_group_size(16)
+        v.close()
+        gens.close()

@@ -10,7 +10,7 @@ import os as _os
 
 # batches in flight use one light stream each (zkgpu_ctx_fork): let the HIP runtime give them hardware
 # queues of their own (default 4).  Only effective when set before the runtime initialises.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 from .native import Context, PointSet, ZkGpuError, lib_path, load_library  # noqa: F401
 

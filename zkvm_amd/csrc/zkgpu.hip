@@ -951,6 +951,11 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
 int zkgpu_init(int device, zkgpu_ctx** out) {
   if (!out) return ZKGPU_EINVAL;
   *out = nullptr;
+  // Batches in flight use a stream each plus six shared ones; the runtime maps streams onto 4
+  // hardware queues unless told otherwise, and streams that share a queue while waiting on each
+  // other's events crawl.  Only effective if the HIP runtime has not started yet in this process
+  // (otherwise the embedding application must export it itself); never overrides the caller.
+  setenv("GPU_MAX_HW_QUEUES", "24", 0);
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ZKGPU_ENODEVICE;
   if (hipSetDevice(device) != hipSuccess) return ZKGPU_ENODEVICE;
@@ -986,6 +991,10 @@ int zkgpu_upload(zkgpu_ctx* c, void* d_dst, const void* src, size_t bytes) {
 int zkgpu_ctx_fork(zkgpu_ctx* parent, zkgpu_ctx** out) {
   if (!parent || !out) return ZKGPU_EINVAL;
   *out = nullptr;
+  if (parent->n_forks >= 9) {
+    parent->last_error = "at most 9 forks per context (each batch in flight holds a hardware queue)";
+    return ZKGPU_EINVAL;
+  }
   DeviceGuard g(parent->device);
   return ctx_create(parent->device, parent, out);
 }
