@@ -94,6 +94,15 @@ size_t zkgpu_pointset_size(const zkgpu_pointset *ps);
 int zkgpu_pointset_build_tables(zkgpu_ctx *ctx, zkgpu_pointset *ps, int window_bits);
 size_t zkgpu_pointset_table_bytes(const zkgpu_pointset *ps);
 
+/* Values of `batch` multiscalar multiplications over a resident set with tables:
+ * out[32 m] = ENCODE(sum_k scalars[k] * ps[index[k]]) for k in [offsets[m], offsets[m+1]);
+ * index == NULL: term k of row m uses point k - offsets[m].  The prover-side primitive
+ * (replaces: RistrettoPoint::multiscalar_mul over BulletproofGens / PedersenGens in
+ * bulletproofs' r1cs::Prover -- A_I, A_O, S, T_i -- and in InnerProductProof::create when the
+ * folded generators are kept as coefficient vectors over the original ones). */
+int zkgpu_msm_ps_batch(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t batch, const uint8_t *scalars,
+                       const uint32_t *index, const uint64_t *offsets, uint8_t *out);
+
 /* As zkgpu_verify_batch, with each check made of two CSR rows: "dynamic" terms
  * carrying their own compressed points (proof points, commitments) and "static"
  * terms that name a point of `ps` by index (generators).  static_index may be

@@ -312,3 +312,45 @@ def test_msm_adversarial_bin_loads(ctx, oracle):
     n = 1 << 20
     got = ctx.msm(k.to_bytes(32, "little") * n, one_pt * n)
     assert got == ctx.msm(((n * k) % L).to_bytes(32, "little"), one_pt)
+
+
+@pytest.mark.parametrize("w", [5, 12])
+def test_msm_values_over_resident_set(ctx, oracle, w):
+    """zkgpu_msm_ps_batch (the prover-side primitive: Pedersen vector commitments out of the fixed-base
+    tables): values equal the oracle's MSM -- whole-set rows, index lists with repeats, empty rows, edge
+    scalars; a Pedersen vector commitment over the real Bulletproof generators equals the oracle's."""
+    from zkvm_amd import PointSet, ZkGpuError
+    rng = random.Random(70 + w)
+    n_gen = 45
+    gens = points(oracle, "valgens", n_gen)
+    ps = PointSet(ctx, gens)
+    with pytest.raises(ZkGpuError):
+        ctx.msm_ps_batch(ps, (1).to_bytes(32, "little"), [0, 1])       # no tables yet
+    ps.build_tables(w)
+    dec = [oracle.decode(gens[32 * j: 32 * j + 32]) for j in range(n_gen)]
+    sc, idx, offs, want = b"", [], [0], []
+    for i in range(23):
+        cnt = rng.choice([0, 1, 7, n_gen, 2 * n_gen])
+        ind = [rng.randrange(n_gen) for _ in range(cnt)]
+        ks = [rng.choice([0, 1, L - 1, 2**252 - 1, rng.randrange(L), rng.randrange(L)]) for _ in ind]
+        sc += b"".join(k.to_bytes(32, "little") for k in ks)
+        idx += ind
+        offs.append(offs[-1] + cnt)
+        want.append(oracle.encode(oracle.msm_points("vartime", ks, [dec[j] for j in ind])) if cnt else bytes(32))
+    got = ctx.msm_ps_batch(ps, sc, offs, index=idx)
+    assert [got[32 * i: 32 * i + 32] for i in range(23)] == want
+    # implicit index: row m uses points 0 .. len-1
+    ks = [rng.randrange(L) for _ in range(n_gen)]
+    one = ctx.msm_ps_batch(ps, b"".join(k.to_bytes(32, "little") for k in ks), [0, n_gen])
+    assert one == oracle.encode(oracle.msm_points("vartime", ks, dec))
+    ps.close()
+    # A_I-style commitment over PedersenGens + BulletproofGens(64): blinding * B_blinding + <a_L, G> + <a_R, H>
+    B, Bb = ctx.pedersen_gens()
+    G, H = ctx.bulletproof_gens(64)
+    allp = B + Bb + G + H
+    ps2 = PointSet(ctx, allp)
+    ps2.build_tables(w)
+    ks = [0, rng.randrange(L)] + [rng.randrange(2) for _ in range(64)] + [rng.randrange(L) for _ in range(64)]
+    val = ctx.msm_ps_batch(ps2, b"".join(k.to_bytes(32, "little") for k in ks), [0, len(ks)])
+    assert val == oracle.encode(oracle.msm_points("vartime", ks, [oracle.decode(allp[32 * j: 32 * j + 32]) for j in range(130)]))
+    ps2.close()

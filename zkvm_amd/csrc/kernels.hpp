@@ -1151,6 +1151,34 @@ k_static_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, con
   if (lane == 0) accept[tx] = (ge_is_identity(acc) && (!dyn_ok || dyn_ok[tx])) ? 1 : 0;
 }
 
+// one wave per MSM over the resident set: sum of its W*P table partials -> canonical ristretto
+// encoding (the value of a Pedersen vector commitment: the prover-side use of the tables)
+__global__ void __launch_bounds__(64)
+k_static_values(const uint32_t* __restrict__ partials, uint32_t n_partials, uint32_t* __restrict__ out_enc) {
+  const uint32_t m = blockIdx.x;
+  const int lane = threadIdx.x;
+  ge acc;
+  ge_identity(acc);
+  for (uint32_t c = lane; c < n_partials; c += 64) {
+    ge p;
+    load_ext(p, partials + ((uint64_t)m * n_partials + c) * EXT_WORDS);
+    ge_add(acc, acc, p);
+  }
+#pragma unroll 1
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    ge other;
+    shfl_down_ge(other, acc, delta);
+    if (lane < delta) ge_add(acc, acc, other);
+  }
+  if (lane == 0) {
+    uint32_t enc[8];
+    ristretto_encode(enc, acc);
+    uint4* o = reinterpret_cast<uint4*>(out_enc + 8 * (uint64_t)m);
+    o[0] = make_uint4(enc[0], enc[1], enc[2], enc[3]);
+    o[1] = make_uint4(enc[4], enc[5], enc[6], enc[7]);
+  }
+}
+
 // ---- group checks ---------------------------------------------------------------------
 // A group of transactions whose equations are weighted by independent random rho's (k_transcript)
 // sums to the identity iff every one of them does (up to probability ~2^-250), and the generator

@@ -1265,6 +1265,69 @@ int zkgpu_verify_batch_ps(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, 
                                    c->in_st_offsets.p, ns, accept_bitmap);
 }
 
+// Values of `batch` multiscalar multiplications over the points of a resident set that carries
+// fixed-base tables: out[32 m] = ENCODE(sum_k scalars[k] * ps[index[k]]), k in [offsets[m], offsets[m+1]).
+// This is the prover's primitive (Pedersen vector commitments A_I, A_O, S, T_i, and every L_j / R_j of an
+// inner-product argument kept as coefficient vectors over the original generators): one mixed
+// addition per term and window, no doublings.  index == NULL: term k of row m uses point k - offsets[m].
+int zkgpu_msm_ps_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, const uint8_t* scalars,
+                       const uint32_t* index, const uint64_t* offsets, uint8_t* out) {
+  if (!c || !ps || ps->ctx->device != c->device || !offsets || !out || batch >= (1ull << 31)) return ZKGPU_EINVAL;
+  memset(out, 0, 32 * batch);
+  if (batch == 0) return ZKGPU_OK;
+  if (!ps->table) { c->last_error = "zkgpu_msm_ps_batch needs zkgpu_pointset_build_tables first"; return ZKGPU_EINVAL; }
+  uint64_t n = 0;
+  if (!offsets_ok(offsets, batch, &n) || (n && !scalars)) return ZKGPU_EINVAL;
+  if (index) {
+    for (uint64_t k = 0; k < n; ++k) if (index[k] >= ps->n) return ZKGPU_EINVAL;
+  } else {
+    for (size_t i = 0; i < batch; ++i) if (offsets[i + 1] - offsets[i] > ps->n) return ZKGPU_EINVAL;
+  }
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  hipStream_t s = c->stream;
+  const int W = ps->tbl_W;
+  const int P = (int)std::max<uint64_t>(1, std::min<uint64_t>(64, (131072 + batch * W - 1) / (batch * W)));
+  const uint64_t n_lanes = (uint64_t)batch * W * P;
+  TRY(upload(c, c->in_st_scalars, scalars, n * 32));
+  if (index) TRY(upload(c, c->in_st_index, index, n * 4));
+  TRY(upload(c, c->in_st_offsets, offsets, (batch + 1) * 8));
+  TRY(ensure(c, c->status, 64));
+  TRY(ensure(c, c->digits, std::max<uint64_t>(n, 1) * W * 2));
+  TRY(ensure(c, c->st_partials, n_lanes * EXT_WORDS * 4));
+  TRY(ensure(c, c->values, 32 * batch));
+  TRY(ensure_pinned(c, 32 * batch + 64));
+  HIP_TRY(c, hipMemsetAsync(c->status.p, 0, 8, s));
+  if (n) {
+    Launch l(c, "k_static_digits");
+    hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(n, 256)), dim3(256), 0, s, (const uint32_t*)c->in_st_scalars.p,
+                       (int16_t*)c->digits.p, n, ps->tbl_w, W, (uint32_t*)c->status.p);
+  }
+  {
+    Launch l(c, "k_static_accumulate");
+    hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s, (const int16_t*)c->digits.p,
+                       (const uint64_t*)c->in_st_offsets.p, index ? (const uint32_t*)c->in_st_index.p : (const uint32_t*)nullptr,
+                       (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)batch, n,
+                       (uint32_t*)c->st_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+  }
+  {
+    Launch l(c, "k_static_values");
+    hipLaunchKernelGGL(k_static_values, dim3((unsigned)batch), dim3(64), 0, s, (const uint32_t*)c->st_partials.p,
+                       (uint32_t)(W * P), (uint32_t*)c->values.p);
+  }
+  HIP_TRY(c, hipGetLastError());
+  char* h = (char*)c->pinned;
+  HIP_TRY(c, hipMemcpyAsync(h, c->values.p, 32 * batch, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(h + 32 * batch, c->status.p, 16, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (c->profiling) prof_collect(c);
+  uint32_t st;
+  memcpy(&st, h + 32 * batch, 4);
+  if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
+  memcpy(out, h, 32 * batch);
+  return ZKGPU_OK;
+}
+
 int zkgpu_decode_check(zkgpu_ctx* c, const uint8_t* points, size_t n, uint8_t* ok) {
   if (!c || (n && (!points || !ok))) return ZKGPU_EINVAL;
   if (n == 0) return ZKGPU_OK;

@@ -69,6 +69,7 @@ def load_library():
     lib.zkgpu_pointset_build_tables.argtypes = [vp, vp, C.c_int]
     lib.zkgpu_pointset_table_bytes.argtypes = [vp]
     lib.zkgpu_pointset_table_bytes.restype = sz
+    lib.zkgpu_msm_ps_batch.argtypes = [vp, vp, sz, u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), u8p]
     lib.zkgpu_set_static_parts.argtypes = [vp, C.c_int]
     lib.zkgpu_decode_check.argtypes = [vp, u8p, sz, u8p]
     lib.zkgpu_cloak_verify_batch.argtypes = [vp, vp, sz, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p, u8p,
@@ -273,6 +274,15 @@ class Context:
                                                 _ptr(d_static_offsets), n_static, bm)
         self._check(rc)
         return bm.raw[: (batch + 7) // 8]
+
+    def msm_ps_batch(self, ps: PointSet, scalars: bytes, offsets: Sequence[int],
+                     index: Optional[Sequence[int]] = None) -> bytes:
+        """zkgpu_msm_ps_batch: values (32-byte encodings) of MSMs over a resident set with tables."""
+        batch = len(offsets) - 1
+        out = C.create_string_buffer(max(32 * batch, 1))
+        idx = (C.c_uint32 * max(len(index), 1))(*index) if index is not None else None
+        self._check(self.lib.zkgpu_msm_ps_batch(self.h, ps.h, batch, scalars, idx, _u64arr(list(offsets)), out))
+        return out.raw[: 32 * batch]
 
     def msm_batch(self, scalars: bytes, points: bytes, offsets: Sequence[int]) -> Tuple[bytes, bytes]:
         """-> (batch x 32-byte encodings, ok bitmap)"""
