@@ -103,6 +103,19 @@ size_t zkgpu_pointset_table_bytes(const zkgpu_pointset *ps);
 int zkgpu_msm_ps_batch(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t batch, const uint8_t *scalars,
                        const uint32_t *index, const uint64_t *offsets, uint8_t *out);
 
+/* Proves `batch` ZkVM cloak statements of one shape (n_in inputs, n_out outputs) over the generator
+ * set ps = [B, B_blinding, G_0..G_{cap-1}, H_0..H_{cap-1}] (tables built).  The provers run in
+ * lockstep on `host_threads` host threads; each phase of the whole batch is one zkgpu_msm_ps_batch.
+ * quantities: batch x (n_in + n_out) u64 (inputs first); flavors: 32 B per value; seeds: 32 B per
+ * statement (commitment blindings and the TranscriptRng's external randomness derive from it).
+ * Out: commitments batch x 64 (n_in + n_out) B (quantity, flavor per value); proofs batch x
+ * proof_stride B, *proof_len bytes of each used (R1CSProof wire format, 1 + 32 (16 + 2k)).
+ * (Replaces: spacesuit::cloak + bulletproofs r1cs::Prover::prove per transaction.) */
+int zkgpu_cloak_prove_batch(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t gens_capacity, size_t batch,
+                            uint32_t n_in, uint32_t n_out, const uint64_t *quantities, const uint8_t *flavors,
+                            const uint8_t *seeds, int host_threads, uint8_t *commitments, uint8_t *proofs,
+                            size_t proof_stride, size_t *proof_len);
+
 /* As zkgpu_verify_batch, with each check made of two CSR rows: "dynamic" terms
  * carrying their own compressed points (proof points, commitments) and "static"
  * terms that name a point of `ps` by index (generators).  static_index may be

@@ -214,3 +214,50 @@ def test_larger_shape_4x4_on_device(ctx, oracle):
         ctx.set_group_size(16)
         v.close()
         gens.close()
+
+
+def _witness(rng, n_in, n_out, two):
+    fl = [rng.randrange(2**250).to_bytes(32, "little") for _ in range(2)]
+    q_in = [rng.randrange(2**40) for _ in range(n_in)]
+    f_in = [fl[j & 1] if two else fl[0] for j in range(n_in)]
+    tot = [0, 0]
+    for a, f in zip(q_in, f_in):
+        tot[fl.index(f)] += a
+    q_out, f_out = [], []
+    for j in range(n_out):
+        fi = (j & 1) if two else 0
+        last = all(((jj & 1) if two else 0) != fi for jj in range(j + 1, n_out))
+        a = tot[fi] if last else tot[fi] // 3
+        tot[fi] -= a
+        q_out.append(a)
+        f_out.append(fl[fi])
+    return q_in + q_out, f_in + f_out
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (1, 1), (3, 2)])
+def test_gpu_prover_equals_oracle_prover_and_verifies(ctx, oracle, shape):
+    """zkgpu_cloak_prove_batch (config 5 / sec 8 row f-4): every commitment and proof byte equals the
+    oracle prover's on the same witness and seed; the device-side verifier and the oracle accept them;
+    an unbalanced witness yields a proof that both reject."""
+    import random
+    from zkvm_amd.verifier import BulletproofGens, Prover, Verifier
+    n_in, n_out = shape
+    rng = random.Random(77 + 10 * n_in + n_out)
+    gens = BulletproofGens(ctx, 256, table_bits=8)
+    batch = 21
+    qs, fs, seeds = [], [], []
+    for i in range(batch):
+        q, f = _witness(rng, n_in, n_out, two=(i & 1) and n_in >= 2 and n_out >= 2)
+        qs.append(q); fs.append(f); seeds.append(hashlib.sha256(b"gpu prover %d" % i).digest())
+    qs[5] = list(qs[5]); qs[5][-1] += 1                        # unbalanced: outputs exceed inputs by one
+    txs = Prover(ctx, gens, host_threads=8).prove(n_in, n_out, qs, fs, seeds)
+    for i in range(batch):
+        rc, want_com, want_proof, _ = oracle.cloak_prove(qs[i], fs[i], n_in, n_out, seeds[i])
+        assert rc == 0 and txs[i].commitments == want_com and txs[i].proof == want_proof, i
+    r = hashlib.shake_256(b"prover r").digest(64 * batch)
+    want = [int(oracle.cloak_verify(t.commitments, n_in, n_out, t.proof, r[64 * i: 64 * i + 64])) for i, t in enumerate(txs)]
+    assert want == [0 if i == 5 else 1 for i in range(batch)]
+    v = Verifier(ctx, gens)
+    assert bits(v.verify_bitmap_gpu(txs, r), batch) == want
+    v.close()
+    gens.close()

@@ -129,3 +129,51 @@ def test_transcript_tape_equals_transcript_class(host):
         assert n == 5 + 8 + 8
         assert a.raw[: 32 * n] == b.raw[: 32 * n]
         assert len({a.raw[32 * j: 32 * j + 32] for j in range(n)}) == n
+
+
+def _gens_bytes(oracle, cap):
+    B, Bb = oracle.pedersen_gens()
+    return B + Bb + b"".join(oracle.bulletproof_gens(cap, "G")) + b"".join(oracle.bulletproof_gens(cap, "H"))
+
+
+@pytest.mark.parametrize("shape,cap", [((1, 1), 64), ((2, 2), 256), ((1, 2), 256), ((3, 2), 256)])
+def test_product_prover_equals_oracle_prover(host, oracle, shape, cap):
+    """r1cs_prover.hpp (phased prover, MSM rows over the generator set; here evaluated by the test
+    library's reference MSM) against the oracle's prover on the same witness and seed: commitments and
+    proof are byte-identical (same transcript, same TranscriptRng draws, same gadget witness), and the
+    oracle's verifier accepts.  Covers merge + split (one flavor), pass-through (two flavors), padding."""
+    n_in, n_out = shape
+    rng = random.Random(1000 * n_in + n_out)
+    gens = _gens_bytes(oracle, cap)
+    for case in range(2):
+        fl = [rng.randrange(2**250).to_bytes(32, "little") for _ in range(2)]
+        two = case == 1 and n_in >= 2 and n_out >= 2
+        q_in = [rng.randrange(2**40) for _ in range(n_in)]
+        f_in = [fl[j & 1] if two else fl[0] for j in range(n_in)]
+        tot = [0, 0]
+        for a, f in zip(q_in, f_in):
+            tot[fl.index(f)] += a
+        q_out, f_out = [], []
+        for j in range(n_out):
+            fi = (j & 1) if two else 0
+            last = all(((jj & 1) if two else 0) != fi for jj in range(j + 1, n_out))
+            a = tot[fi] if last else tot[fi] // 3
+            tot[fi] -= a
+            q_out.append(a)
+            f_out.append(fl[fi])
+        assert tot == [0, 0]
+        q, f = q_in + q_out, f_in + f_out
+        seed = hashlib.sha256(b"prover %d %d %d" % (n_in, n_out, case)).digest()
+        rc, want_com, want_proof, want_n = oracle.cloak_prove(q, f, n_in, n_out, seed)
+        assert rc == 0
+        qa = (C.c_uint64 * len(q))(*q)
+        com = C.create_string_buffer(64 * len(q))
+        proof = C.create_string_buffer(4096)
+        plen, nm = C.c_size_t(0), C.c_size_t(0)
+        rc = host.zkhost_cloak_prove(n_in, n_out, qa, b"".join(f), seed, gens, C.c_size_t(cap), com, proof,
+                                     C.c_size_t(4096), C.byref(plen), C.byref(nm))
+        assert rc == 0
+        assert nm.value == want_n
+        assert com.raw == want_com
+        assert proof.raw[: plen.value] == want_proof
+        assert oracle.cloak_verify(com.raw, n_in, n_out, proof.raw[: plen.value], bytes(range(64)))

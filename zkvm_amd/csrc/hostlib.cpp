@@ -3,8 +3,11 @@
 // tier can exercise it without a GPU.  libzkgpu.so compiles the very same headers.
 #include "r1cs_verifier.hpp"
 #include "cloak_plan.hpp"
+#include "curve.hpp"
+#include "r1cs_prover.hpp"
 #include "transcript_tape.hpp"
 
+#include <array>
 #include <map>
 
 #include <cstring>
@@ -135,6 +138,75 @@ int zkhost_tape_challenges(uint32_t n_in, uint32_t n_out, const uint8_t* commitm
   }
   for (size_t i = 0; i < order.size(); ++i) direct[i].to_bytes(out_direct + 32 * i);
   return (int)order.size();
+}
+
+}  // extern "C"
+
+namespace {
+// Reference evaluation of prover rows on the host (CPU tests only; the product evaluates them with
+// zkgpu_msm_ps_batch): bucket method, window 8, over decoded generator points.
+void host_rows(const std::vector<ge>& gens, const std::vector<MsmRow>& rows, std::vector<uint8_t>& out) {
+  out.assign(32 * rows.size(), 0);
+  for (size_t r = 0; r < rows.size(); ++r) {
+    const MsmRow& row = rows[r];
+    ge acc;
+    ge_identity(acc);
+    std::vector<std::array<uint8_t, 32>> sb(row.scalars.size());
+    for (size_t i = 0; i < sb.size(); ++i) row.scalars[i].to_bytes(sb[i].data());
+    for (int win = 31; win >= 0; --win) {
+      for (int d = 0; d < 8; ++d) ge_double(acc, acc);
+      std::vector<ge> bucket(256);
+      std::vector<char> used(256, 0);
+      for (size_t i = 0; i < sb.size(); ++i) {
+        const unsigned b = sb[i][win];
+        if (!b) continue;
+        if (used[b]) ge_add(bucket[b], bucket[b], gens[row.index[i]]);
+        else { bucket[b] = gens[row.index[i]]; used[b] = 1; }
+      }
+      ge run, sum;
+      ge_identity(run);
+      ge_identity(sum);
+      for (int b = 255; b >= 1; --b) {
+        if (used[b]) ge_add(run, run, bucket[b]);
+        ge_add(sum, sum, run);
+      }
+      ge_add(acc, acc, sum);
+    }
+    uint32_t enc[8];
+    ristretto_encode(enc, acc);
+    std::memcpy(&out[32 * r], enc, 32);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+// One cloak proof on the host: the product's prover (r1cs_prover.hpp) with its rows evaluated by the
+// reference MSM above.  generators = [B, B_blinding, G_0..G_{cap-1}, H_0..H_{cap-1}] compressed.
+// Returns 0; commitments = 64 (n_in + n_out) bytes, proof_len_out = bytes written to proof.
+int zkhost_cloak_prove(uint32_t n_in, uint32_t n_out, const uint64_t* quantities, const uint8_t* flavors,
+                       const uint8_t seed[32], const uint8_t* generators, size_t gens_capacity, uint8_t* commitments,
+                       uint8_t* proof, size_t proof_cap, size_t* proof_len_out, size_t* multipliers) {
+  std::vector<ge> gens(2 + 2 * gens_capacity);
+  for (size_t i = 0; i < gens.size(); ++i) {
+    uint32_t w[8];
+    std::memcpy(w, generators + 32 * i, 32);
+    if (!ristretto_decode(gens[i], w)) return -1;
+  }
+  CloakProver pr(n_in, n_out, quantities, flavors, seed, gens_capacity);
+  std::vector<MsmRow> rows;
+  std::vector<uint8_t> pts;
+  pr.begin(rows);
+  while (!pr.done()) {
+    host_rows(gens, rows, pts);
+    pr.step(pts.data(), rows);
+  }
+  if (pr.failed() || pr.proof().size() > proof_cap) return -2;
+  std::memcpy(commitments, pr.commitments().data(), pr.commitments().size());
+  std::memcpy(proof, pr.proof().data(), pr.proof().size());
+  *proof_len_out = pr.proof().size();
+  if (multipliers) *multipliers = pr.multipliers();
+  return 0;
 }
 
 }  // extern "C"

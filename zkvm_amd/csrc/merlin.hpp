@@ -31,6 +31,14 @@ class Strobe128 {
     out[50] = pos_;
     out[51] = pos_begin_;
   }
+  // KEY: overwrite the state with the key bytes (STROBE v1.0.2 sec 6; used by Merlin's TranscriptRng)
+  void key(const uint8_t* d, size_t n, bool more) {
+    begin_op(kA | kC, more);
+    for (size_t i = 0; i < n; ++i) {
+      put(pos_, d[i]);
+      if (++pos_ == kRate) run_f();
+    }
+  }
   void prf(uint8_t* out, size_t n) {
     begin_op(kI | kA | kC, false);
     for (size_t i = 0; i < n; ++i) {
@@ -99,6 +107,24 @@ class Transcript {
     s_.prf(out, n);
   }
   void export_state(uint32_t out[52]) const { s_.export_state(out); }
+  // merlin::TranscriptRngBuilder / TranscriptRng (prover side: blinding factors).  Call on a COPY of
+  // the transcript: rekey_with_witness_bytes for every secret, finalize with external randomness,
+  // then fill.
+  void rekey_with_witness(const char* label, const uint8_t* w, size_t n) {
+    uint8_t len[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
+    s_.meta_ad((const uint8_t*)label, std::strlen(label), false);
+    s_.meta_ad(len, 4, true);
+    s_.key(w, n, false);
+  }
+  void finalize_rng(const uint8_t seed[32]) {
+    s_.meta_ad((const uint8_t*)"rng", 3, false);
+    s_.key(seed, 32, false);
+  }
+  void rng_fill(uint8_t* out, size_t n) {
+    uint8_t len[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
+    s_.meta_ad(len, 4, false);
+    s_.prf(out, n);
+  }
   Scalar challenge_scalar(const char* label) {
     uint8_t b[64];
     challenge_bytes(label, b, 64);

@@ -56,14 +56,15 @@ class ConstraintSystemT {
 
   void constrain(LC lc) { cons_.push_back(std::move(lc)); }
   // (left, right, out) of a fresh multiplier constrained to the two combinations
-  void multiply(LC left, LC right, Var out[3]) {
+  // (virtual: the prover, r1cs_prover.hpp, evaluates the combinations on its witness)
+  virtual void multiply(LC left, LC right, Var out[3]) {
     allocate_multiplier(out);
     left.sub(out[0], S::one());
     right.sub(out[1], S::one());
     constrain(std::move(left));
     constrain(std::move(right));
   }
-  void allocate_multiplier(Var out[3]) {
+  virtual void allocate_multiplier(Var out[3]) {
     const uint32_t i = num_vars_++;
     out[0] = Var{VarKind::MulLeft, i}; out[1] = Var{VarKind::MulRight, i}; out[2] = Var{VarKind::MulOut, i};
   }

@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <random>
@@ -23,6 +25,7 @@
 #include "r1cs_verifier.hpp"
 #include "cloak_plan.hpp"
 #include "prep_kernels.hpp"
+#include "r1cs_prover.hpp"
 
 using namespace zk;
 
@@ -1325,6 +1328,75 @@ int zkgpu_msm_ps_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, con
   memcpy(&st, h + 32 * batch, 4);
   if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
   memcpy(out, h, 32 * batch);
+  return ZKGPU_OK;
+}
+
+// Proves `batch` cloak statements of one shape (BASELINE.json configs[4]).
+// The provers run in lockstep on host threads (r1cs_prover.hpp: transcripts, witness, polynomial and
+// inner-product algebra); every phase of the whole batch is ONE zkgpu_msm_ps_batch over the generator
+// tables of `ps` = [B, B_blinding, G_0..G_{cap-1}, H_0..H_{cap-1}]: 2 (n_in + n_out) value commitments,
+// A_I A_O S of both phases, T_1 T_3..T_6, then L_j R_j of each inner-product round (513 terms each
+// for padded n = 256).  quantities: batch x (n_in + n_out) u64; flavors: 32 B each; seeds: 32 B per
+// statement (blindings and TranscriptRng randomness are derived from it).  commitments: batch x
+// 64 (n_in + n_out) B; proofs: batch x proof_stride B, *proof_len bytes used of each.
+int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_capacity, size_t batch, uint32_t n_in,
+                            uint32_t n_out, const uint64_t* quantities, const uint8_t* flavors, const uint8_t* seeds,
+                            int host_threads, uint8_t* commitments, uint8_t* proofs, size_t proof_stride,
+                            size_t* proof_len) {
+  if (!c || !ps || !commitments || !proofs || !proof_len) return ZKGPU_EINVAL;
+  *proof_len = 0;
+  if (batch == 0) return ZKGPU_OK;
+  if (!quantities || !flavors || !seeds || ps->n < 2 + 2 * gens_capacity || n_in + n_out == 0) return ZKGPU_EINVAL;
+  if (!ps->table) { c->last_error = "zkgpu_cloak_prove_batch needs zkgpu_pointset_build_tables first"; return ZKGPU_EINVAL; }
+  const size_t nv = (size_t)n_in + n_out;
+  std::vector<std::unique_ptr<CloakProver>> pr(batch);
+  std::vector<std::vector<MsmRow>> rows(batch);
+  const int nt = std::max(1, std::min<int>(host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency(), 256));
+  auto parallel = [&](const std::function<void(size_t)>& f) {
+    if (nt == 1 || batch == 1) { for (size_t i = 0; i < batch; ++i) f(i); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { for (size_t i = (size_t)t; i < batch; i += (size_t)nt) f(i); });
+    for (auto& t : th) t.join();
+  };
+  parallel([&](size_t i) {
+    pr[i].reset(new CloakProver(n_in, n_out, quantities + nv * i, flavors + 32 * nv * i, seeds + 32 * i, gens_capacity));
+    pr[i]->begin(rows[i]);
+  });
+  std::vector<uint64_t> offs, row_of(batch + 1);
+  std::vector<uint8_t> sc, pts;
+  std::vector<uint32_t> idx;
+  for (;;) {
+    bool any = false, bad = false;
+    for (size_t i = 0; i < batch; ++i) { any |= !pr[i]->done(); bad |= pr[i]->failed(); }
+    if (bad) { c->last_error = "prover: inconsistent witness or too few generators"; return ZKGPU_EINVAL; }
+    if (!any) break;
+    // CSR over all rows of all statements
+    offs.assign(1, 0);
+    row_of[0] = 0;
+    for (size_t i = 0; i < batch; ++i) {
+      for (const MsmRow& r : rows[i]) offs.push_back(offs.back() + r.scalars.size());
+      row_of[i + 1] = offs.size() - 1;
+    }
+    sc.resize(32 * offs.back());
+    idx.resize(offs.back());
+    parallel([&](size_t i) {
+      uint64_t k = offs[row_of[i]];
+      for (const MsmRow& r : rows[i])
+        for (size_t j = 0; j < r.scalars.size(); ++j, ++k) { r.scalars[j].to_bytes(&sc[32 * k]); idx[k] = r.index[j]; }
+    });
+    const size_t n_rows = offs.size() - 1;
+    pts.resize(32 * n_rows);
+    TRY(zkgpu_msm_ps_batch(c, ps, n_rows, sc.data(), idx.data(), offs.data(), pts.data()));
+    parallel([&](size_t i) { if (!pr[i]->done()) pr[i]->step(&pts[32 * row_of[i]], rows[i]); });
+  }
+  const size_t plen = pr[0]->proof().size();
+  if (plen > proof_stride) return ZKGPU_EINVAL;
+  for (size_t i = 0; i < batch; ++i) {
+    if (pr[i]->proof().size() != plen) return ZKGPU_EINVAL;
+    memcpy(commitments + 64 * nv * i, pr[i]->commitments().data(), 64 * nv);
+    memcpy(proofs + proof_stride * i, pr[i]->proof().data(), plen);
+  }
+  *proof_len = plen;
   return ZKGPU_OK;
 }
 

@@ -69,6 +69,8 @@ def load_library():
     lib.zkgpu_pointset_build_tables.argtypes = [vp, vp, C.c_int]
     lib.zkgpu_pointset_table_bytes.argtypes = [vp]
     lib.zkgpu_pointset_table_bytes.restype = sz
+    lib.zkgpu_cloak_prove_batch.argtypes = [vp, vp, sz, sz, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), u8p, u8p, C.c_int,
+                                            u8p, u8p, sz, C.POINTER(sz)]
     lib.zkgpu_msm_ps_batch.argtypes = [vp, vp, sz, u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), u8p]
     lib.zkgpu_set_static_parts.argtypes = [vp, C.c_int]
     lib.zkgpu_decode_check.argtypes = [vp, u8p, sz, u8p]

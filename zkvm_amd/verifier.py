@@ -54,6 +54,32 @@ class BulletproofGens:
         self.points.close()
 
 
+class Prover:
+    """Batch prover for cloak statements (zkgpu_cloak_prove_batch): host threads drive the provers in
+    lockstep, every multiscalar multiplication of every phase runs on the generator tables."""
+
+    def __init__(self, ctx: Context, bp_gens: BulletproofGens, host_threads: int = 0):
+        self.ctx = ctx
+        self.bp_gens = bp_gens
+        self.host_threads = host_threads
+
+    def prove(self, n_in: int, n_out: int, quantities: Sequence[Sequence[int]], flavors: Sequence[Sequence[bytes]],
+              seeds: Sequence[bytes]) -> List[CloakTx]:
+        batch, nv = len(seeds), n_in + n_out
+        assert len(quantities) == batch and len(flavors) == batch
+        qa = (C.c_uint64 * max(batch * nv, 1))(*[q for row in quantities for q in row])
+        fl = b"".join(f for row in flavors for f in row)
+        com = C.create_string_buffer(max(64 * nv * batch, 1))
+        stride = 1 + 32 * (16 + 2 * 16)
+        proofs = C.create_string_buffer(max(stride * batch, 1))
+        plen = C.c_size_t(0)
+        self.ctx._check(self.ctx.lib.zkgpu_cloak_prove_batch(
+            self.ctx.h, self.bp_gens.points.h, self.bp_gens.gens_capacity, batch, n_in, n_out, qa, fl, b"".join(seeds),
+            self.host_threads, com, proofs, stride, C.byref(plen)))
+        return [CloakTx(n_in, n_out, com.raw[64 * nv * i: 64 * nv * (i + 1)], proofs.raw[stride * i: stride * i + plen.value])
+                for i in range(batch)]
+
+
 class Verifier:
     """Batch verifier; `verify_cloak_txs` returns one Optional[VMError] per transaction
     (None = Ok), the shape of `txs.iter().map(|tx| tx.verify(bp_gens))`."""
