@@ -255,13 +255,22 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libzkgpu has no CPU fallback)")
+    # ZKGPU_BENCH_SHARE_GPU=1 (testing the N > 1 code path on a 1-GPU box): every rank uses device 0 and the
+    # bitmaps travel over gloo from host memory instead of RCCL (which refuses two ranks on one device)
+    share_gpu = os.environ.get("ZKGPU_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    coll_dev = torch.device("cpu") if share_gpu else dev
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from zkvm_amd import Context
     ctx = Context(local)
@@ -278,8 +287,8 @@ def main():
     d_dyn_off = torch.tensor(w["dyn_off"], dtype=torch.int64, device=dev)
     d_st_off = torch.tensor(w["st_off"], dtype=torch.int64, device=dev)
     nbytes = (batch + 7) // 8
-    d_bm = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-    d_all = torch.zeros(nbytes * world, dtype=torch.uint8, device=dev) if world > 1 else None
+    d_bm = torch.zeros(nbytes, dtype=torch.uint8, device=coll_dev)
+    d_all = torch.zeros(nbytes * world, dtype=torch.uint8, device=coll_dev) if world > 1 else None
     torch.cuda.synchronize()
 
     # `--inflight M`: M batches in flight.  Each has its own forked context (workspace + a light stream
@@ -312,29 +321,30 @@ def main():
         c.verify_batch_ps_submit_dev(ps, batch, d_dyn_sc, d_dyn_pt, d_dyn_off, batch * N_DYN,
                                      d_st_sc, d_st_idx, d_st_off, batch * N_STATIC)
 
-    def collect(c):
+    def collect(c, gather=True):
         bm = c.verify_wait()
-        if world > 1:
+        if world > 1 and gather:
             d_bm.copy_(torch.frombuffer(bytearray(bm), dtype=torch.uint8))
             dist.all_gather_into_tensor(d_all, d_bm)    # RCCL over xGMI: the per-shard accept bitmaps
         return bm
 
     host_time = {"submit": 0.0, "n": 0}
 
-    def run_steps(n, submit=None):
+    def run_steps(n, submit=None, gather=True):
+        # gather=False: the rank-0-only extra legs (no collective: the other ranks are not in them)
         submit = submit or submit_verify
         depth = len(ctxs)
         bm = None
         for i in range(n):
             c = ctxs[i % depth]
             if i >= depth:
-                bm = collect(c)
+                bm = collect(c, gather)
             ts = time.perf_counter()
             submit(c)
             host_time["submit"] += time.perf_counter() - ts
             host_time["n"] += 1
         for i in range(max(n - depth, 0), n):
-            bm = collect(ctxs[i % depth])
+            bm = collect(ctxs[i % depth], gather)
         return bm
 
     bm = run_steps(max(args.warmup, len(ctxs)))
@@ -359,7 +369,7 @@ def main():
     for c in prof_ctxs:
         c.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         gathered = bytes(d_all.cpu().numpy().tobytes())
@@ -441,22 +451,22 @@ def main():
             n_e2e = 6 * len(ctxs)
             def submit_host(c):
                 gv.submit_packed_gpu(tx0.n_in, tx0.n_out, batch, packed_com, packed_proofs, proof_len, w["r_bytes"], ctx=c)
-            assert run_steps(len(ctxs), submit_host) == bm
+            assert run_steps(len(ctxs), submit_host, gather=False) == bm
             t0 = time.perf_counter()
-            outs = [run_steps(n_e2e, submit_host)]
+            outs = [run_steps(n_e2e, submit_host, gather=False)]
             e2e_gpu_s = (time.perf_counter() - t0) / n_e2e
             assert all(o == bm for o in outs)
             # the multiscalar-multiplication boundary alone (scalars prepared beforehand by the host verifier)
-            assert run_steps(len(ctxs), submit_msm_only) == bm
+            assert run_steps(len(ctxs), submit_msm_only, gather=False) == bm
             t0 = time.perf_counter()
-            run_steps(args.steps, submit_msm_only)
+            run_steps(args.steps, submit_msm_only, gather=False)
             msm_only_s = (time.perf_counter() - t0) / args.steps
             # the same complete verification with every transaction checked on its own (no group checks)
             for c in ctxs:
                 c.set_group_size(1)
-            assert run_steps(len(ctxs)) == bm
+            assert run_steps(len(ctxs), gather=False) == bm
             t0 = time.perf_counter()
-            run_steps(args.steps)
+            run_steps(args.steps, gather=False)
             per_tx_s = (time.perf_counter() - t0) / args.steps
             for c in ctxs:
                 c.set_group_size(args.group)
