@@ -133,18 +133,36 @@ class Verifier:
         groups = {}
         for i, t in enumerate(txs):
             groups.setdefault((t.n_in, t.n_out, len(t.proof)), []).append(i)
-        for (n_in, n_out, plen), idx in groups.items():
+        # one batch per shape, kept in flight together on forked contexts (zkgpu_ctx_fork): the device
+        # works on the shapes concurrently instead of draining after each
+        lanes = self._lanes(min(len(groups), 4))
+        pending = []
+
+        def collect(entry):
+            c, idx = entry
+            bm = c.verify_wait()
+            for j, i in enumerate(idx):
+                if (bm[j // 8] >> (j % 8)) & 1:
+                    out[i // 8] |= 1 << (i % 8)
+
+        for g, ((n_in, n_out, plen), idx) in enumerate(groups.items()):
+            if len(pending) >= len(lanes):
+                collect(pending.pop(0))
+            c = lanes[g % len(lanes)]
             sub = [txs[i] for i in idx]
             rb = b"".join(r_bytes[64 * i: 64 * i + 64] for i in idx) if r_bytes is not None else None
-            bm = C.create_string_buffer(max((len(sub) + 7) // 8, 1))
-            rc = self.ctx.lib.zkgpu_cloak_verify_batch_gpu(
-                self.ctx.h, self.bp_gens.points.h, self._plan(n_in, n_out), len(sub),
-                b"".join(t.commitments for t in sub), b"".join(t.proof for t in sub), plen, rb, bm)
-            self.ctx._check(rc)
-            for j, i in enumerate(idx):
-                if (bm.raw[j // 8] >> (j % 8)) & 1:
-                    out[i // 8] |= 1 << (i % 8)
+            self.submit_packed_gpu(n_in, n_out, len(sub), b"".join(t.commitments for t in sub),
+                                   b"".join(t.proof for t in sub), plen, rb, ctx=c)
+            pending.append((c, idx))
+        while pending:
+            collect(pending.pop(0))
         return bytes(out)
+
+    def _lanes(self, n: int):
+        lanes = self.__dict__.setdefault("_lane_ctxs", [self.ctx])
+        while len(lanes) < n:
+            lanes.append(self.ctx.fork())
+        return lanes[:max(n, 1)]
 
     def verify_packed_gpu(self, n_in: int, n_out: int, batch: int, commitments: bytes, proofs: bytes, proof_len: int,
                           r_bytes: Optional[bytes] = None) -> bytes:
@@ -187,6 +205,9 @@ class Verifier:
         return c
 
     def close(self) -> None:
+        for c in self.__dict__.get("_lane_ctxs", [])[1:]:
+            c.close()
+        self.__dict__["_lane_ctxs"] = [self.ctx]
         for h in self.__dict__.get("_plans", {}).values():
             self.ctx.lib.zkgpu_cloak_plan_destroy(h)
         self.__dict__["_plans"] = {}
