@@ -296,10 +296,8 @@ def main():
     # kernels of all of them go first-in first-out through the parent's two streams (zkgpu_ctx_fork).
     # One host thread submits step i + M only after collecting step i.  Every step is still one
     # complete, independent verification of the whole batch; K steps are timed as a whole.
-    from concurrent.futures import ThreadPoolExecutor
     ctx.set_group_size(args.group)               # forks inherit it
     ctxs = [ctx] + [ctx.fork() for _ in range(min(max(1, args.inflight), 10) - 1)]   # at most 9 forks per context
-    lanes = [ThreadPoolExecutor(max_workers=1) for _ in ctxs]
 
     # THE STEP: the complete r1cs::Verifier::verify of every transaction of the batch, on the device,
     # from commitments + proof bytes + verifier randomness resident in HBM: Merlin transcript replay
@@ -541,8 +539,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for ex in lanes:
-        ex.shutdown()
     gv.close()
     for c in ctxs[1:]:
         c.close()

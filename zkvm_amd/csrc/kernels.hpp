@@ -971,6 +971,23 @@ k_from_uniform(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint
   o[1] = make_uint4(enc[4], enc[5], enc[6], enc[7]);
 }
 
+// per-batch scratch state in one launch (instead of five fills): status words, per-MSM failure
+// flags, per-transaction wellformed flags
+__global__ void __launch_bounds__(256)
+k_batch_init(uint32_t* __restrict__ status, uint32_t* __restrict__ msm_fail, uint32_t* __restrict__ wellformed,
+             uint32_t n_msm) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_msm) {
+    msm_fail[i] = 0;
+    if (wellformed) wellformed[i] = 0xffffffffu;
+  }
+  if (i == 0) {
+    status[0] = 0; status[1] = 0;                      // flags
+    status[2] = 0xffffffffu; status[3] = 0xffffffffu;  // lowest undecodable index (atomicMin)
+    status[8] = 0;                                     // transactions queued for the individual re-check
+  }
+}
+
 // pack accept bytes into a bitmap (byte i/8, bit i%8)
 __global__ void __launch_bounds__(256)
 k_pack_bitmap(const uint8_t* __restrict__ accept, const uint32_t* __restrict__ wellformed /*optional*/,

@@ -25,7 +25,7 @@ class Strobe128 {
   }
   void meta_ad(const uint8_t* d, size_t n, bool more) { begin_op(kM | kA, more); absorb(d, n); }
   void ad(const uint8_t* d, size_t n, bool more) { begin_op(kA, more); absorb(d, n); }
-  // 50 state words + position + begin marker (seed of the device-side replay, merlin_dev.hpp)
+  // 50 state words + position + begin marker (seed of the device-side replay: transcript_tape.hpp, k_transcript)
   void export_state(uint32_t out[52]) const {
     for (int i = 0; i < 25; ++i) { out[2 * i] = (uint32_t)st_[i]; out[2 * i + 1] = (uint32_t)(st_[i] >> 32); }
     out[50] = pos_;

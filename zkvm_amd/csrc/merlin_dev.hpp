@@ -1,14 +1,7 @@
-// merlin_dev.hpp -- Keccak-f[1600] / STROBE-128 / Merlin on the device.
-//
-// The Fiat-Shamir transcript of r1cs::Verifier::verify is strictly sequential
-// per proof, so it runs one lane per transaction.  The 200-byte STROBE state
-// lives in LDS as 50 words per lane, word-interleaved over the lanes of the
-// block (address = word * blockDim + lane: conflict-free), because STROBE
-// touches it at byte positions that are only known at run time; Keccak-f pulls
-// it into registers, runs 24 rolled rounds, and puts it back.  All lanes of a
-// launch replay transcripts of the same shape, so every position is
-// wave-uniform and there is no divergence.
-// (merlin.cool, STROBE v1.0.2, FIPS 202.)
+// merlin_dev.hpp -- Keccak-f[1600] on the device, one state per lane in registers
+// (24 rolled rounds).  The STROBE / Merlin framing around it is data, not code: the
+// per-shape tape of transcript_tape.hpp, run by k_transcript (prep_kernels.hpp).
+// (FIPS 202.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -49,89 +42,5 @@ __device__ inline void keccak_f1600_regs(uint64_t a[25]) {
     a[0] ^= RC[rnd];
   }
 }
-
-// STROBE-128 state of one lane inside a block-wide LDS array
-struct StrobeDev {
-  uint32_t* st;        // &lds[lane]; word w of this lane is st[w * stride]
-  uint32_t stride;
-  uint32_t pos, pos_begin;
-
-  static constexpr uint32_t R = 166;
-  __device__ __forceinline__ void xor_byte(uint32_t i, uint32_t b) { st[(i >> 2) * stride] ^= b << (8 * (i & 3)); }
-  __device__ __forceinline__ uint32_t get_byte(uint32_t i) const { return (st[(i >> 2) * stride] >> (8 * (i & 3))) & 0xff; }
-  __device__ __forceinline__ void clear_byte(uint32_t i) { st[(i >> 2) * stride] &= ~(0xffu << (8 * (i & 3))); }
-
-  __device__ inline void permute() {
-    uint64_t a[25];
-#pragma unroll
-    for (int i = 0; i < 25; ++i) a[i] = (uint64_t)st[(2 * i) * stride] | ((uint64_t)st[(2 * i + 1) * stride] << 32);
-    keccak_f1600_regs(a);
-#pragma unroll
-    for (int i = 0; i < 25; ++i) { st[(2 * i) * stride] = (uint32_t)a[i]; st[(2 * i + 1) * stride] = (uint32_t)(a[i] >> 32); }
-  }
-  __device__ inline void run_f() {
-    xor_byte(pos, pos_begin);
-    xor_byte(pos + 1, 0x04);
-    xor_byte(R + 1, 0x80);
-    permute();
-    pos = 0;
-    pos_begin = 0;
-  }
-  __device__ inline void absorb_byte(uint32_t b) {
-    xor_byte(pos, b);
-    if (++pos == R) run_f();
-  }
-  __device__ inline void begin_op(uint32_t flags) {
-    const uint32_t old_begin = pos_begin;
-    pos_begin = pos + 1;
-    absorb_byte(old_begin);
-    absorb_byte(flags);
-    if ((flags & (4u | 32u)) && pos != 0) run_f();
-  }
-  // uniform bytes (labels, lengths)
-  __device__ inline void absorb_const(const char* s, uint32_t n) { for (uint32_t i = 0; i < n; ++i) absorb_byte((uint8_t)s[i]); }
-  // per-lane little-endian words
-  __device__ inline void absorb_words(const uint32_t* w, uint32_t nwords) {
-    for (uint32_t i = 0; i < nwords; ++i) {
-      const uint32_t v = w[i];
-      absorb_byte(v & 0xff); absorb_byte((v >> 8) & 0xff); absorb_byte((v >> 16) & 0xff); absorb_byte(v >> 24);
-    }
-  }
-  __device__ inline void le32(uint32_t n) { absorb_byte(n & 0xff); absorb_byte((n >> 8) & 0xff); absorb_byte((n >> 16) & 0xff); absorb_byte(n >> 24); }
-
-  // Merlin framing
-  __device__ inline void append_message_words(const char* label, uint32_t label_len, const uint32_t* w, uint32_t nwords) {
-    begin_op(16u | 2u); absorb_const(label, label_len);   // meta-AD(label)
-    le32(4 * nwords);                                      // meta-AD(len), continuation
-    begin_op(2u); absorb_words(w, nwords);                 // AD(data)
-  }
-  __device__ inline void append_message_const(const char* label, uint32_t label_len, const char* msg, uint32_t n) {
-    begin_op(16u | 2u); absorb_const(label, label_len);
-    le32(n);
-    begin_op(2u); absorb_const(msg, n);
-  }
-  __device__ inline void append_u64(const char* label, uint32_t label_len, uint64_t x) {
-    begin_op(16u | 2u); absorb_const(label, label_len);
-    le32(8);
-    begin_op(2u);
-    for (int i = 0; i < 8; ++i) absorb_byte((uint32_t)(x >> (8 * i)) & 0xff);
-  }
-  // 64 challenge bytes as 16 words
-  __device__ inline void challenge_wide(const char* label, uint32_t label_len, uint32_t out[16]) {
-    begin_op(16u | 2u); absorb_const(label, label_len);
-    le32(64);
-    begin_op(1u | 2u | 4u);                                // PRF
-#pragma unroll 1
-    for (int i = 0; i < 16; ++i) {
-      uint32_t v = 0;
-      for (int k = 0; k < 4; ++k) {
-        v |= get_byte(pos) << (8 * k);
-        clear_byte(pos);
-        if (++pos == R) run_f();
-      }
-      out[i] = v;
-    }
-  }
-};
 
 }  // namespace zk

@@ -697,13 +697,13 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   TRY(ensure(c, c->window_flags, (size_t)B * 64 * 4));
   TRY(ensure(c, c->msm_fail, (size_t)B * 4));
   c->last_w = 4;
-  HIP_TRY(c, hipMemsetAsync(c->status.p, 0, 8, L));
-  HIP_TRY(c, hipMemsetAsync((char*)c->status.p + 8, 0xff, 8, L));
-  HIP_TRY(c, hipMemsetAsync((char*)c->status.p + 32, 0, 4, L));     // transactions queued for the individual re-check
-  HIP_TRY(c, hipMemsetAsync(c->msm_fail.p, 0, (size_t)B * 4, L));
+  {
+    Launch l(c, "k_batch_init", L);
+    hipLaunchKernelGGL(k_batch_init, dim3(blocks_for(B, 256)), dim3(256), 0, L, (uint32_t*)c->status.p,
+                       (uint32_t*)c->msm_fail.p, prep ? (uint32_t*)c->prep_wf.p : (uint32_t*)nullptr, (uint32_t)B);
+  }
   if (prep) {
     const PrepShape& sh = prep->sh;
-    HIP_TRY(c, hipMemsetAsync(c->prep_wf.p, 0xff, (size_t)B * 4, L));
     {
       Launch l(c, "k_proof_unpack", L);
       hipLaunchKernelGGL(k_proof_unpack, dim3(blocks_for((uint64_t)B * sh.proof_words, 256)), dim3(256), 0, L,
@@ -1514,7 +1514,6 @@ struct zkgpu_cloak_plan {
   size_t gens_capacity;
   uint32_t *d_init = nullptr, *d_mono_chal = nullptr, *d_mono_pow = nullptr, *d_tgt_off = nullptr, *d_term_q = nullptr,
            *d_term_mono = nullptr, *d_term_coef = nullptr;
-  uint8_t* d_chal_label = nullptr;
   uint32_t* d_tape = nullptr;     // transcript_tape.hpp, four words per operation
   uint32_t n_ops = 0;
   // per-batch-size cached CSR scaffolding
@@ -1594,7 +1593,6 @@ int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t 
     p->n_ops = (uint32_t)(tape.size() / 4);
     TRY(plan_upload(c, &p->d_tape, tape));
   }
-  TRY(plan_upload(c, &p->d_chal_label, h.chal_label));
   TRY(plan_upload(c, &p->d_mono_chal, h.mono_chal));
   TRY(plan_upload(c, &p->d_mono_pow, h.mono_pow));
   TRY(plan_upload(c, &p->d_tgt_off, h.tgt_off));
@@ -1609,7 +1607,7 @@ int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t 
 void zkgpu_cloak_plan_destroy(zkgpu_cloak_plan* p) {
   if (!p) return;
   DeviceGuard g(p->ctx->device);
-  void* ptrs[] = {p->d_tape, p->d_init, p->d_chal_label, p->d_mono_chal, p->d_mono_pow, p->d_tgt_off, p->d_term_q, p->d_term_mono,
+  void* ptrs[] = {p->d_tape, p->d_init, p->d_mono_chal, p->d_mono_pow, p->d_tgt_off, p->d_term_q, p->d_term_mono,
                   p->d_term_coef, p->d_dyn_off, p->d_st_off, p->d_st_index};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   delete p;
