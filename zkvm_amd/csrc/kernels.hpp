@@ -827,15 +827,19 @@ k_small_tables(const uint32_t* __restrict__ dyn_scalars, const uint32_t* __restr
                uint32_t* __restrict__ status) {
   const uint64_t k = (uint64_t)blockIdx.x * 64 + threadIdx.x;
   if (k >= n) return;
-  // s' = s + 0x8888...8 (mod 2^256; a wrap leaves top nibble 0, which k_small_accumulate reads as +8)
-  const uint32_t* sc = dyn_scalars + 8 * k;
-  if (sc[7] >> 31) atomicOr(&status[0], 2u);
-  uint32_t carry = 0;
+  // s' = s + 0x8888...8 (mod 2^256; a wrap leaves top nibble 0, which k_small_accumulate reads as +8).
+  // dyn_scalars == NULL: the scalars are not known yet (the tables are built while the transcript is
+  // still being replayed) and k_prepare writes the recoded form itself.
+  if (dyn_scalars) {
+    const uint32_t* sc = dyn_scalars + 8 * k;
+    if (sc[7] >> 31) atomicOr(&status[0], 2u);
+    uint32_t carry = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint64_t v = (uint64_t)sc[i] + 0x88888888u + carry;
-    recoded[8 * k + i] = (uint32_t)v;
-    carry = (uint32_t)(v >> 32);
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t v = (uint64_t)sc[i] + 0x88888888u + carry;
+      recoded[8 * k + i] = (uint32_t)v;
+      carry = (uint32_t)(v >> 32);
+    }
   }
   // one rolled loop (a mixed addition + the cached-form conversion): the body stays in the
   // instruction cache, where a straight-line chain of different doublings / additions does not

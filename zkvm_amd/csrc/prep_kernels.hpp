@@ -237,7 +237,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
           const uint32_t* __restrict__ tgt_off, const uint32_t* __restrict__ term_q,
           const uint32_t* __restrict__ term_mono, const uint32_t* __restrict__ term_coef,
           const uint32_t* __restrict__ ch, const uint32_t* __restrict__ com, const uint32_t* __restrict__ pw,
-          uint32_t* __restrict__ dyn_scalars, uint32_t* __restrict__ dyn_points, uint32_t* __restrict__ static_scalars) {
+          uint32_t* __restrict__ dyn_scalars, uint32_t* __restrict__ dyn_recoded, uint32_t* __restrict__ static_scalars) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* chs = lds;
   uint32_t* sym = chs + sh.n_ch * 8;
@@ -387,7 +387,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   cp = scm_from_words(cp_plain.v);               // c', Montgomery
   const scm xx = scm_sq(x), xxx = scm_mul(xx, x), rxx = scm_mul(r, xx);
   uint32_t* ds = dyn_scalars + (uint64_t)tx * sh.n_dyn * 8;
-  uint32_t* dp = dyn_points + (uint64_t)tx * sh.n_dyn * 8;
+  uint32_t* dr = dyn_recoded + (uint64_t)tx * sh.n_dyn * 8;
   uint32_t* ss = static_scalars + (uint64_t)tx * sh.n_static * 8;
   const uint32_t* p = pw + (uint64_t)tx * sh.proof_words;
   const uint32_t* c = com + (uint64_t)tx * sh.m * 8;
@@ -467,11 +467,41 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     const scm conv = scm_mul(v, conv_by);   // Montgomery -> canonical words, times the plain factor
     const uint32_t* o = conv.v;
     if (j < sh.n_dyn) {
-      for (int q = 0; q < 8; ++q) { ds[j * 8 + q] = o[q]; dp[j * 8 + q] = pt[q]; }
+      // the scalar, and its recoded form s + 0x88..8 for k_small_accumulate (digit t = nibble t - 8)
+      uint32_t carry = 0;
+      for (int q = 0; q < 8; ++q) {
+        ds[j * 8 + q] = o[q];
+        const uint64_t v = (uint64_t)o[q] + 0x88888888u + carry;
+        dr[j * 8 + q] = (uint32_t)v;
+        carry = (uint32_t)(v >> 32);
+      }
+      (void)pt;
     } else {
       for (int q = 0; q < 8; ++q) ss[(j - sh.n_dyn) * 8 + q] = o[q];
     }
   }
+}
+
+// the proof-specific points of every transaction in the order of the MSM's dynamic terms
+// [A_I1 A_O1 S1 A_I2 A_O2 S2 | V.. | T_1 T_3 T_4 T_5 T_6 | L.. | R..]: needs the proof bytes only, so the
+// decompression and the per-point tables run while the transcript is still being replayed
+__global__ void __launch_bounds__(256)
+k_gather_dyn_points(PrepShape sh, const uint32_t* __restrict__ com, const uint32_t* __restrict__ pw, uint32_t batch,
+                    uint32_t* __restrict__ dyn_points) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)batch * sh.n_dyn * 8) return;
+  const uint32_t q = (uint32_t)(g & 7), j = (uint32_t)((g >> 3) % sh.n_dyn), tx = (uint32_t)((g >> 3) / sh.n_dyn);
+  const uint32_t* p = pw + (uint64_t)tx * sh.proof_words;
+  const uint32_t* c = com + (uint64_t)tx * sh.m * 8;
+  const uint32_t* src;
+  if (j < 6) src = p + 8 * j;
+  else if (j < 6 + sh.m) src = c + 8 * (j - 6);
+  else if (j < 11 + sh.m) src = p + 8 * (6 + (j - 6 - sh.m));
+  else {
+    const uint32_t r = j - 11 - sh.m;
+    src = p + 112 + (r < sh.k ? 16 * r : 16 * (r - sh.k) + 8);
+  }
+  dyn_points[g] = src[q];
 }
 
 // generator scalars of a group: sum over its transactions (canonical words in and out)

@@ -87,7 +87,7 @@ struct zkgpu_ctx {
   Buffer grp_sc, grp_digits, grp_partials, grp_ok, row_map;
   int group_size = 16;             // transactions per group check (1 = every transaction on its own)
   bool serial = false;             // measurement aid: the whole DAG of a batch on one stream
-  hipEvent_t ev_dig = nullptr;
+  hipEvent_t ev_dig = nullptr, ev_u = nullptr;
   Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
   int forced_parts = 0;
   void* pinned = nullptr;   // host staging for results
@@ -510,25 +510,31 @@ int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap, uint8_t* 
   return ZKGPU_OK;
 }
 
-// window sums of many small MSMs (few proof-specific points each): see kernels.hpp, k_small_tables
-int small_msm_launch(zkgpu_ctx* c, const Job& job, hipStream_t st) {
-  const size_t B = job.n_msm;
-  TRY(ensure(c, c->small_tbl, std::max<uint64_t>(job.n_dyn, 1) * SMALL_TBL * EXT_WORDS * 4));
-  TRY(ensure(c, c->recoded, std::max<uint64_t>(job.n_dyn, 1) * 32));
-  {
-    Launch l(c, "k_small_tables", st);
-    hipLaunchKernelGGL(k_small_tables, dim3(blocks_for(job.n_dyn, 64)), dim3(64), 0, st, job.d_dyn_scalars,
-                       (const uint32_t*)c->dyn_rows.p, job.n_dyn, (uint32_t*)c->small_tbl.p, (uint32_t*)c->recoded.p,
-                       (uint32_t*)c->status.p);
-  }
-  {
-    Launch l(c, "k_small_accumulate", st);
-    const int parts = small_parts(B);
-    hipLaunchKernelGGL(k_small_accumulate, dim3((unsigned)B), dim3(64 * parts), (size_t)(parts - 1) * 41 * 64 * 4, st,
-                       (const uint32_t*)c->recoded.p, job.d_dyn_offsets, (const uint32_t*)c->small_tbl.p, (uint32_t)B,
-                       (uint32_t*)c->window_sums.p, (uint32_t*)c->window_flags.p);
-  }
+// window sums of many small MSMs (few proof-specific points each): see kernels.hpp, k_small_tables.
+// d_scalars == nullptr: the scalars are not known yet; whoever produces them writes c->recoded too.
+int small_tables_launch(zkgpu_ctx* c, const uint32_t* d_scalars, uint64_t n_dyn, hipStream_t st) {
+  TRY(ensure(c, c->small_tbl, std::max<uint64_t>(n_dyn, 1) * SMALL_TBL * EXT_WORDS * 4));
+  TRY(ensure(c, c->recoded, std::max<uint64_t>(n_dyn, 1) * 32));
+  Launch l(c, "k_small_tables", st);
+  hipLaunchKernelGGL(k_small_tables, dim3(blocks_for(n_dyn, 64)), dim3(64), 0, st, d_scalars,
+                     (const uint32_t*)c->dyn_rows.p, n_dyn, (uint32_t*)c->small_tbl.p, (uint32_t*)c->recoded.p,
+                     (uint32_t*)c->status.p);
   return ZKGPU_OK;
+}
+
+int small_accumulate_launch(zkgpu_ctx* c, const Job& job, hipStream_t st) {
+  const size_t B = job.n_msm;
+  Launch l(c, "k_small_accumulate", st);
+  const int parts = small_parts(B);
+  hipLaunchKernelGGL(k_small_accumulate, dim3((unsigned)B), dim3(64 * parts), (size_t)(parts - 1) * 41 * 64 * 4, st,
+                     (const uint32_t*)c->recoded.p, job.d_dyn_offsets, (const uint32_t*)c->small_tbl.p, (uint32_t)B,
+                     (uint32_t*)c->window_sums.p, (uint32_t*)c->window_flags.p);
+  return ZKGPU_OK;
+}
+
+int small_msm_launch(zkgpu_ctx* c, const Job& job, hipStream_t st) {
+  TRY(small_tables_launch(c, job.d_dyn_scalars, job.n_dyn, st));
+  return small_accumulate_launch(c, job, st);
 }
 
 // Batch path when the point set carries fixed-base tables: generator terms are
@@ -696,6 +702,8 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   TRY(ensure(c, c->window_sums, (size_t)B * 64 * EXT_WORDS * 4));
   TRY(ensure(c, c->window_flags, (size_t)B * 64 * 4));
   TRY(ensure(c, c->msm_fail, (size_t)B * 4));
+  TRY(ensure(c, c->small_tbl, std::max<uint64_t>(job.n_dyn, 1) * SMALL_TBL * EXT_WORDS * 4));
+  TRY(ensure(c, c->recoded, std::max<uint64_t>(job.n_dyn, 1) * 32));
   c->last_w = 4;
   {
     Launch l(c, "k_batch_init", L);
@@ -710,6 +718,22 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
                          prep->d_proofs, (uint64_t)prep->proof_len, (uint32_t*)c->prep_pw.p, sh.proof_words,
                          (uint32_t)B, (uint32_t*)c->prep_wf.p);
     }
+    // the proof-specific points need the proof bytes only: gather, decompress and build their small
+    // tables on the shared stream while the transcript is replayed
+    HIP_TRY(c, hipEventRecord(c->ev_u, L));
+    HIP_TRY(c, hipStreamWaitEvent(H1, c->ev_u, 0));
+    {
+      Launch l(c, "k_gather_dyn_points", H1);
+      hipLaunchKernelGGL(k_gather_dyn_points, dim3(blocks_for((uint64_t)B * sh.n_dyn * 8, 256)), dim3(256), 0, H1, sh,
+                         prep->d_com, (const uint32_t*)c->prep_pw.p, (uint32_t)B, (uint32_t*)c->prep_dyn_pt.p);
+    }
+    {
+      Launch l(c, "k_decompress", H1);
+      hipLaunchKernelGGL(k_decompress, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, H1, job.d_dyn_points,
+                         (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, (uint32_t)B, (uint32_t*)c->msm_fail.p,
+                         (unsigned long long*)((char*)c->status.p + 8), (uint8_t*)nullptr);
+    }
+    TRY(small_tables_launch(c, nullptr, job.n_dyn, H1));
     {
       Launch l(c, "k_transcript", L);
       hipLaunchKernelGGL(k_transcript, dim3(blocks_for(B, 64)), dim3(64), 0, L, sh, prep->d_init,
@@ -725,7 +749,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)B), dim3(256), prep->lds_bytes, H3, prep->sh, prep->d_mono_chal,
                        prep->d_mono_pow, prep->d_tgt_off, prep->d_term_q, prep->d_term_mono, prep->d_term_coef,
                        (const uint32_t*)c->prep_ch.p, prep->d_com, (const uint32_t*)c->prep_pw.p,
-                       (uint32_t*)c->prep_dyn_sc.p, (uint32_t*)c->prep_dyn_pt.p, (uint32_t*)c->prep_st_sc.p);
+                       (uint32_t*)c->prep_dyn_sc.p, (uint32_t*)c->recoded.p, (uint32_t*)c->prep_st_sc.p);
   }
   HIP_TRY(c, hipEventRecord(c->ev_p, prep ? H3s : L));
   HIP_TRY(c, hipStreamWaitEvent(H1, c->ev_p, 0));
@@ -772,13 +796,17 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     }
     HIP_TRY(c, hipEventRecord(c->ev_sa, H2));
   }
-  {
-    Launch l(c, "k_decompress", H1);
-    hipLaunchKernelGGL(k_decompress, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, H1, job.d_dyn_points,
-                       (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, (uint32_t)B, (uint32_t*)c->msm_fail.p,
-                       (unsigned long long*)((char*)c->status.p + 8), (uint8_t*)nullptr);
+  if (prep) {
+    TRY(small_accumulate_launch(c, job, H1));       // points and tables were done beside the transcript
+  } else {
+    {
+      Launch l(c, "k_decompress", H1);
+      hipLaunchKernelGGL(k_decompress, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, H1, job.d_dyn_points,
+                         (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, (uint32_t)B, (uint32_t*)c->msm_fail.p,
+                         (unsigned long long*)((char*)c->status.p + 8), (uint8_t*)nullptr);
+    }
+    TRY(small_msm_launch(c, job, H1));
   }
-  TRY(small_msm_launch(c, job, H1));
   HIP_TRY(c, hipEventRecord(c->ev_sm, H1));
   HIP_TRY(c, hipStreamWaitEvent(L, c->ev_sm, 0));
   {
@@ -943,7 +971,7 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
     ok = ok && hipStreamCreateWithPriority(&c->stream_l, hipStreamNonBlocking, lp) == hipSuccess;
     if (getenv("ZKGPU_L_PRIO")) fprintf(stderr, "prio range least=%d greatest=%d L=%d\n", prio_least, prio_greatest, lp);
   }
-  hipEvent_t* evs[] = {&c->ev_fork, &c->ev_join, &c->ev_t, &c->ev_p, &c->ev_sm, &c->ev_sa, &c->ev_done, &c->ev_dig};
+  hipEvent_t* evs[] = {&c->ev_fork, &c->ev_join, &c->ev_t, &c->ev_p, &c->ev_sm, &c->ev_sa, &c->ev_done, &c->ev_dig, &c->ev_u};
   for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   if (!ok) { delete c; return ZKGPU_EHIP; }
   *out = c;
@@ -1026,7 +1054,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
     for (hipStream_t st : c->lane_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   }
   if (c->stream_l) (void)hipStreamDestroy(c->stream_l);
-  hipEvent_t evs[] = {c->ev_fork, c->ev_join, c->ev_t, c->ev_p, c->ev_sm, c->ev_sa, c->ev_done, c->ev_dig};
+  hipEvent_t evs[] = {c->ev_fork, c->ev_join, c->ev_t, c->ev_p, c->ev_sm, c->ev_sa, c->ev_done, c->ev_dig, c->ev_u};
   for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
   delete c;
 }
@@ -1780,6 +1808,7 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
   }
   // general shapes (no generator tables, forced window width, many proof points): one stream, synchronous
   hipStream_t s = c->stream;
+  TRY(ensure(c, c->recoded, std::max<uint64_t>(job.n_dyn, 1) * 32));
   HIP_TRY(c, hipStreamSynchronize(c->stream_l));      // uploads, if any, were queued on the light stream
   HIP_TRY(c, hipMemsetAsync(c->prep_wf.p, 0xff, (size_t)B * 4, s));
   {
@@ -1801,7 +1830,9 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
                        (const uint32_t*)plan->d_mono_pow, (const uint32_t*)plan->d_tgt_off, (const uint32_t*)plan->d_term_q,
                        (const uint32_t*)plan->d_term_mono, (const uint32_t*)plan->d_term_coef, (const uint32_t*)c->prep_ch.p,
                        d_com, (const uint32_t*)c->prep_pw.p, (uint32_t*)c->prep_dyn_sc.p,
-                       (uint32_t*)c->prep_dyn_pt.p, (uint32_t*)c->prep_st_sc.p);
+                       (uint32_t*)c->recoded.p, (uint32_t*)c->prep_st_sc.p);
+    hipLaunchKernelGGL(k_gather_dyn_points, dim3(blocks_for((uint64_t)B * sh.n_dyn * 8, 256)), dim3(256), 0, s, sh, d_com,
+                       (const uint32_t*)c->prep_pw.p, B, (uint32_t*)c->prep_dyn_pt.p);
   }
   HIP_TRY(c, hipGetLastError());
   std::vector<uint8_t> bm((batch + 7) / 8, 0);
