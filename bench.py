@@ -230,8 +230,8 @@ def prover_microbench(ctx, w, host_threads: int, with_cpu: bool, batch: int = 51
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024, help="transactions per GPU")
     ap.add_argument("--table-bits", type=int, default=int(os.environ.get("ZKGPU_TABLE_BITS", "16")),
                     help="window width of the fixed-base generator tables (0 = no tables: Pippenger for every term)")
