@@ -297,7 +297,9 @@ def main():
     # One host thread submits step i + M only after collecting step i.  Every step is still one
     # complete, independent verification of the whole batch; K steps are timed as a whole.
     ctx.set_group_size(args.group)               # forks inherit it
-    ctxs = [ctx] + [ctx.fork() for _ in range(min(max(1, args.inflight), 10) - 1)]   # at most 9 forks per context
+    lanes_env = min(max(int(os.environ.get("ZKGPU_LANES", "2")), 1), 4)
+    max_inflight = 1 + min(9, 19 - 3 * lanes_env)          # the library's fork limit (hardware queues)
+    ctxs = [ctx] + [ctx.fork() for _ in range(min(max(1, args.inflight), max_inflight) - 1)]
 
     # THE STEP: the complete r1cs::Verifier::verify of every transaction of the batch, on the device,
     # from commitments + proof bytes + verifier randomness resident in HBM: Merlin transcript replay
