@@ -261,3 +261,37 @@ def test_gpu_prover_equals_oracle_prover_and_verifies(ctx, oracle, shape):
     assert bits(v.verify_bitmap_gpu(txs, r), batch) == want
     v.close()
     gens.close()
+
+
+def test_full_size_batches_vs_oracle(ctx, oracle):
+    """BASELINE.json configs[1] size (1024) and beyond (4096): the committed golden proofs replicated under
+    per-transaction verifier randomness with a sprinkle of corruptions, complete verification on the device
+    (group checks on), every accept bit against the oracle's full verifier (OpenMP)."""
+    import os
+    import struct
+    from zkvm_amd.verifier import BulletproofGens, Verifier
+    raw = open(os.path.join(os.path.dirname(__file__), "golden", "cloak_2x2_proofs.bin"), "rb").read()
+    count, n_in, n_out, plen = struct.unpack("<IIII", raw[8:24])
+    w = 64 * (n_in + n_out)
+    fix = [(raw[24 + (w + plen) * i: 24 + (w + plen) * i + w], raw[24 + (w + plen) * i + w: 24 + (w + plen) * (i + 1)])
+           for i in range(count)]
+    gens = BulletproofGens(ctx, 256, table_bits=13)
+    v = Verifier(ctx, gens)
+    try:
+        for batch in (1024, 4096):
+            coms, proofs = [], []
+            for i in range(batch):
+                com, proof = fix[(i * 7 + batch) % count]
+                if i % 97 == 5:
+                    p = bytearray(proof); p[1 + 32 * (11 + i % 3) + (i % 31)] ^= 1 << (i % 8); proof = bytes(p)
+                if i % 389 == 11:
+                    cm = bytearray(com); cm[i % w] ^= 0x20; com = bytes(cm)
+                coms.append(com); proofs.append(proof)
+            r = hashlib.shake_256(b"full size %d" % batch).digest(64 * batch)
+            want = list(oracle.cloak_verify_batch(b"".join(coms), n_in, n_out, b"".join(proofs), plen, r, threads=8))
+            assert 0 < want.count(0) < batch // 20
+            got = bits(v.verify_packed_gpu(n_in, n_out, batch, b"".join(coms), b"".join(proofs), plen, r), batch)
+            assert got == want
+    finally:
+        v.close()
+        gens.close()
