@@ -126,12 +126,12 @@ k_transcript(PrepShape sh, const uint32_t* __restrict__ init_state /*50 words*/,
         st[w * 64] ^= v & mask;
       }
     } else if (op.x == TAPE_PERM) {
-      uint64_t a[25];
+      uint32_t klo[25], khi[25];
 #pragma unroll
-      for (int q = 0; q < 25; ++q) a[q] = (uint64_t)st[(2 * q) * 64] | ((uint64_t)st[(2 * q + 1) * 64] << 32);
-      keccak_f1600_regs(a);
+      for (int q = 0; q < 25; ++q) { klo[q] = st[(2 * q) * 64]; khi[q] = st[(2 * q + 1) * 64]; }
+      keccak_f1600_halves(klo, khi);
 #pragma unroll
-      for (int q = 0; q < 25; ++q) { st[(2 * q) * 64] = (uint32_t)a[q]; st[(2 * q + 1) * 64] = (uint32_t)(a[q] >> 32); }
+      for (int q = 0; q < 25; ++q) { st[(2 * q) * 64] = klo[q]; st[(2 * q + 1) * 64] = khi[q]; }
     } else {                                               // TAPE_CHAL
       uint32_t wv[16];
 #pragma unroll
