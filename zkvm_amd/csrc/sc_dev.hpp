@@ -69,8 +69,12 @@ ZK_HD scm scm_sub(const scm& a, const scm& b) {
 ZK_HD scm scm_neg(const scm& a) { return scm_sub(scm_zero(), a); }
 
 // Montgomery product a * b / 2^256 mod l (CIOS).  a < 2^256, b < l  ->  result < l.
-// (~400 instructions.  Measured: making this a real, non-inlined function is slower -- k_prepare
-// 0.30 -> 0.38 ms -- even though it shrinks that kernel from 150 KB to 19 KB of code.)
+// (629 VALU instructions as compiled, half of them moves that pair registers around the 32-bit
+// carries.  Measured alternatives, all slower in k_prepare: a real non-inlined function (0.30 -> 0.38 ms,
+// although it shrinks the kernel from 150 KB to 19 KB of code); product scanning with the carry-out of
+// v_mad_u64_u32 taken through inline asm (336 instructions, but one dependent multiply-add chain:
+// 0.25 -> 0.34 ms; two chains per column: 0.37 ms).  The moves are full-rate and the operand-scanning
+// form keeps ~8 independent multiply-adds in flight.)
 ZK_HD scm scm_mul_core(const scm& av, const scm& bv) {
   const uint32_t* a = av.v;
   const uint32_t* b = bv.v;
