@@ -1,21 +1,23 @@
 // sc_dev.hpp -- integers mod l for the device (and the host tests): eight 32-bit
-// limbs in Montgomery form (R = 2^256), CIOS multiplication built on
-// v_mad_u64_u32.  This is the verifier's challenge algebra moved onto the GPU
+// limbs in Montgomery form (R = 2^260); the product works on ten 26-bit limbs
+// (carry-free v_mad_u64_u32 columns).  This is the verifier's challenge algebra moved onto the GPU
 // (curve25519-dalek `Scalar`, RFC 9496 sec 4.4).
 #pragma once
 #include "field.hpp"   // ZK_HD, ZK_UNROLL
 
 namespace zk {
 
-struct scm {          // value * 2^256 mod l, always < l
+struct scm {          // value * 2^260 mod l, always < l
   uint32_t v[8];
 };
 
 #define ZK_SC_L { 0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0x00000000u, 0x00000000u, 0x00000000u, 0x10000000u }
-#define ZK_SC_NPRIME 0x12547e1bu
-#define ZK_SC_R1 { 0x8d98951du, 0xd6ec3174u, 0x737dcf70u, 0xc6ef5bf4u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0x0fffffffu }
-#define ZK_SC_R2 { 0x449c0f01u, 0xa40611e3u, 0x68859347u, 0xd00e1ba7u, 0x17f5be65u, 0xceec73d2u, 0x7c309a3du, 0x0399411bu }
-#define ZK_SC_R3 { 0x7b83a2dbu, 0x2a9e4968u, 0xaef7f3ecu, 0x278324e6u, 0x04ec5b65u, 0x8065dc6cu, 0x3599cec7u, 0x0e530b77u }
+// Montgomery radix R = 2^260 (ten 26-bit limbs inside the product, see scm_mul_core)
+#define ZK_SC_NPRIME26 0x2547e1bu   // -l^-1 mod 2^26
+#define ZK_SC_L26 { 0x0f5d3edu, 0x098c697u, 0x1cd6581u, 0x37a8bdeu, 0x014def9u, 0u, 0u, 0u, 0u, 0x0040000u }
+#define ZK_SC_R1 { 0x6721e6edu, 0x45af48bdu, 0xab5ac67eu, 0x35e51b3bu, 0xffffffebu, 0xffffffffu, 0xffffffffu, 0x0fffffffu }
+#define ZK_SC_R2 { 0xe952d13bu, 0x69f9d265u, 0x3c715beau, 0x687604d6u, 0xf5be65cbu, 0xec73d217u, 0x309a3dceu, 0x09411b7cu }
+#define ZK_SC_R3 { 0x5bbc47ffu, 0xd5d6c1e6u, 0x3074a06du, 0xd7af6287u, 0xec5b6514u, 0x65dc6c04u, 0x99cec780u, 0x030b7735u }
 #define ZK_SC_LM2 { 0x5cf5d3ebu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0x00000000u, 0x00000000u, 0x00000000u, 0x10000000u }
 
 ZK_HD scm scm_zero() { scm r; ZK_UNROLL for (int i = 0; i < 8; ++i) r.v[i] = 0; return r; }
@@ -68,45 +70,50 @@ ZK_HD scm scm_sub(const scm& a, const scm& b) {
 
 ZK_HD scm scm_neg(const scm& a) { return scm_sub(scm_zero(), a); }
 
-// Montgomery product a * b / 2^256 mod l (CIOS).  a < 2^256, b < l  ->  result < l.
-// (629 VALU instructions as compiled, half of them moves that pair registers around the 32-bit
-// carries.  Measured alternatives, all slower in k_prepare: a real non-inlined function (0.30 -> 0.38 ms,
-// although it shrinks the kernel from 150 KB to 19 KB of code); product scanning with the carry-out of
-// v_mad_u64_u32 taken through inline asm (336 instructions, but one dependent multiply-add chain:
-// 0.25 -> 0.34 ms; two chains per column: 0.37 ms).  The moves are full-rate and the operand-scanning
-// form keeps ~8 independent multiply-adds in flight.)
-ZK_HD scm scm_mul_core(const scm& av, const scm& bv) {
-  const uint32_t* a = av.v;
-  const uint32_t* b = bv.v;
-  const uint32_t l[8] = ZK_SC_L;
-  uint32_t t[10];
-  ZK_UNROLL for (int i = 0; i < 10; ++i) t[i] = 0;
-  ZK_UNROLL for (int i = 0; i < 8; ++i) {
-    uint64_t c = 0;
-    ZK_UNROLL for (int j = 0; j < 8; ++j) {
-      c += (uint64_t)a[j] * b[i] + t[j];
-      t[j] = (uint32_t)c;
-      c >>= 32;
-    }
-    c += t[8];
-    t[8] = (uint32_t)c;
-    t[9] = (uint32_t)(c >> 32);
-    const uint32_t m = t[0] * ZK_SC_NPRIME;
-    c = (uint64_t)m * l[0] + t[0];
-    c >>= 32;
-    ZK_UNROLL for (int j = 1; j < 8; ++j) {
-      c += (uint64_t)m * l[j] + t[j];
-      t[j - 1] = (uint32_t)c;
-      c >>= 32;
-    }
-    c += t[8];
-    t[7] = (uint32_t)c;
-    t[8] = t[9] + (uint32_t)(c >> 32);
+// Montgomery product a * b / R mod l, R = 2^260.  a < 2^256, b < l  ->  result < l.
+// The operands are split into ten 26-bit limbs, so that -- exactly as in fe_mul -- every partial
+// product is one v_mad_u64_u32 into a 64-bit column that cannot overflow (<= 16 products of 52 bits),
+// with no carries and no register pairing inside the product; the reduction adds m_i * l column by
+// column (l = 2^252 + c has only limbs 0..4 and 9 non-zero: six products per step).  The operand-
+// scanning form on 32-bit limbs compiled to 629 VALU instructions (96 multiply-adds, 133 64-bit adds,
+// 321 moves pairing registers around 32-bit carries).
+ZK_HD void scm_limbs26(uint32_t out[10], const uint32_t w[8]) {
+  ZK_UNROLL for (int i = 0; i < 10; ++i) {
+    const int o = 26 * i, k = o >> 5, sft = o & 31;
+    uint64_t two = w[k];
+    if (k + 1 < 8) two |= (uint64_t)w[k + 1] << 32;
+    out[i] = (uint32_t)(two >> sft) & 0x3ffffffu;
   }
+}
+
+ZK_HD scm scm_mul_core(const scm& av, const scm& bv) {
+  const uint32_t l26[10] = ZK_SC_L26;
+  uint32_t A[10], B[10];
+  scm_limbs26(A, av.v);
+  scm_limbs26(B, bv.v);
+  uint64_t t[20];
+  ZK_UNROLL for (int k = 0; k < 20; ++k) t[k] = 0;
+  ZK_UNROLL for (int i = 0; i < 10; ++i)
+    ZK_UNROLL for (int j = 0; j < 10; ++j) t[i + j] += (uint64_t)A[i] * B[j];
+  ZK_UNROLL for (int i = 0; i < 10; ++i) {
+    const uint32_t m = ((uint32_t)t[i] * ZK_SC_NPRIME26) & 0x3ffffffu;
+    ZK_UNROLL for (int j = 0; j < 10; ++j)
+      if (j <= 4 || j == 9) t[i + j] += (uint64_t)m * l26[j];
+    t[i + 1] += t[i] >> 26;               // the low 26 bits of t[i] are zero now
+  }
+  // limbs 10..19 -> eight 32-bit words
+  ZK_UNROLL for (int k = 10; k < 19; ++k) { t[k + 1] += t[k] >> 26; t[k] &= 0x3ffffffu; }
   scm r;
-  ZK_UNROLL for (int i = 0; i < 8; ++i) r.v[i] = t[i];
-  // t < 2l (t[8] can only be 0 here because 2l < 2^256)
-  scm_cond_sub_l(r.v, t[8] != 0 || scm_geq_l(r.v));
+  ZK_UNROLL for (int i = 0; i < 8; ++i) {
+    // word i = bits [32 i, 32 i + 32) of sum_k t[10 + k] 2^(26 k)
+    const int lo_limb = (32 * i) / 26, sft = (32 * i) % 26;
+    uint64_t v = t[10 + lo_limb] >> sft;
+    v |= t[10 + lo_limb + 1] << (26 - sft);
+    if (10 + lo_limb + 2 < 20) v |= t[10 + lo_limb + 2] << (52 - sft);
+    r.v[i] = (uint32_t)v;
+  }
+  // result < 2l < 2^254: fits the eight words
+  scm_cond_sub_l(r.v, scm_geq_l(r.v));
   return r;
 }
 
