@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -1402,7 +1403,10 @@ int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_
   std::vector<uint64_t> offs, row_of(batch + 1);
   std::vector<uint8_t> sc, pts;
   std::vector<uint32_t> idx;
-  for (;;) {
+  const bool timing = getenv("ZKGPU_PROVER_TIMING") != nullptr;
+  double t_flat = 0, t_gpu = 0, t_step = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  for (int phase = 0;; ++phase) {
     bool any = false, bad = false;
     for (size_t i = 0; i < batch; ++i) { any |= !pr[i]->done(); bad |= pr[i]->failed(); }
     if (bad) { c->last_error = "prover: inconsistent witness or too few generators"; return ZKGPU_EINVAL; }
@@ -1414,6 +1418,7 @@ int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_
       for (const MsmRow& r : rows[i]) offs.push_back(offs.back() + r.scalars.size());
       row_of[i + 1] = offs.size() - 1;
     }
+    const double t0 = now();
     sc.resize(32 * offs.back());
     idx.resize(offs.back());
     parallel([&](size_t i) {
@@ -1423,9 +1428,17 @@ int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_
     });
     const size_t n_rows = offs.size() - 1;
     pts.resize(32 * n_rows);
+    const double t1 = now();
     TRY(zkgpu_msm_ps_batch(c, ps, n_rows, sc.data(), idx.data(), offs.data(), pts.data()));
+    const double t2 = now();
     parallel([&](size_t i) { if (!pr[i]->done()) pr[i]->step(&pts[32 * row_of[i]], rows[i]); });
+    const double t3 = now();
+    t_flat += t1 - t0; t_gpu += t2 - t1; t_step += t3 - t2;
+    if (timing) fprintf(stderr, "prover phase %d: %zu rows, %llu terms: flatten %.1f ms, msm %.1f ms, host step %.1f ms\n", phase,
+                        n_rows, (unsigned long long)offs.back(), (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3);
   }
+  if (timing) fprintf(stderr, "prover total: flatten %.1f ms, msm %.1f ms, host steps %.1f ms (%zu proofs, %d threads)\n",
+                      t_flat * 1e3, t_gpu * 1e3, t_step * 1e3, batch, nt);
   const size_t plen = pr[0]->proof().size();
   if (plen > proof_stride) return ZKGPU_EINVAL;
   for (size_t i = 0; i < batch; ++i) {
