@@ -152,8 +152,13 @@ def cpu_baseline(ctx, w, gpu_bitmap: bytes, batch: int):
     gpu_bits = [(gpu_bitmap[i // 8] >> (i % 8)) & 1 for i in range(batch)]
     assert list(acc) == gpu_bits, "GPU accept bitmap differs from the CPU oracle"
     assert list(acc1) == gpu_bits[:one]
+    # the oracle's PROVER on the same cores (baseline of the `prover` leg)
+    n_pr = 4 * cores
+    t0 = time.perf_counter()
+    oracle.cloak_prove_batch(n_pr, 2, 2, b"bench prover cpu".ljust(32, b"\0"), threads=cores)
+    prover_rate = n_pr / (time.perf_counter() - t0)
     return {"value": round(batch * reps / tall, 1), "unit": "tx/s", "cores": cores, "kind": "port",
-            "value_1core": round(one / t1, 2),
+            "value_1core": round(one / t1, 2), "prover_proofs_per_s": round(prover_rate, 1),
             "sample": "%d x the full %d-tx batch (oracle Verifier: transcript replay + scalars + 549-term MSM per tx, "
                       "same proof bytes and verifier randomness as the GPU step) on %d OpenMP threads = this box's "
                       "cgroup CPU quota (%.1f s); 1-core figure on %d tx (%.1f s); all %d accept bits compared "
@@ -189,7 +194,7 @@ def msm_microbench(ctx, torch, dev):
             "accumulate_GBps": round(64 * n / (acc_ms * 1e-3) / 1e9, 2) if acc_ms else None}
 
 
-def prover_microbench(ctx, w, host_threads: int, with_cpu: bool, batch: int = 512):
+def prover_microbench(ctx, w, host_threads: int, batch: int = 512):
     """BASELINE configs[4] (prover side): `batch` 2-in/2-out cloak proofs, host threads for the transcripts and
     the witness / polynomial algebra, every multiscalar multiplication on the generator tables."""
     import random
@@ -216,14 +221,6 @@ def prover_microbench(ctx, w, host_threads: int, with_cpu: bool, batch: int = 51
            "note": "zkgpu_cloak_prove_batch: provers in lockstep on host threads (host-bound: scalar algebra of the "
                    "coefficient-vector inner-product argument), all MSMs in 13 zkgpu_msm_ps_batch calls on the tables; "
                    "every proof verified by the device-side verifier"}
-    if with_cpu:
-        from oracle import binding as oracle
-        cores = usable_cores(oracle.max_threads())
-        n = 4 * cores
-        t0 = time.perf_counter()
-        com, proofs = oracle.cloak_prove_batch(n, 2, 2, b"bench prover cpu".ljust(32, b"\0"), threads=cores)
-        out["cpu_oracle_proofs_per_s"] = round(n / (time.perf_counter() - t0), 1)
-        out["cpu_cores"] = cores
     return out
 
 
@@ -534,7 +531,9 @@ def main():
         if world == 1 and not args.no_cpu and not args.lean:
             line["cpu_baseline"] = cpu_baseline(ctx, w, bm, batch)
         if world == 1 and not args.no_msm and not args.lean:
-            line["prover"] = prover_microbench(ctx, w, host_threads, not args.no_cpu)
+            line["prover"] = prover_microbench(ctx, w, host_threads)
+            if "cpu_baseline" in line:
+                line["prover"]["cpu_oracle_proofs_per_s"] = line["cpu_baseline"].get("prover_proofs_per_s")
         if world == 1 and not args.no_msm and not args.lean:
             line["msm_2p20"] = msm_microbench(ctx, torch, dev)
         print(json.dumps(line))
