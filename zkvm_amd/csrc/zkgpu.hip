@@ -292,17 +292,29 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
   uint32_t* status = (uint32_t*)c->status.p;
   unsigned long long* bad_index = (unsigned long long*)((char*)c->status.p + 8);
 
+  bool decompress_aside = false;
   if (job.n_dyn >= 131072) {
-    // many points: run the squaring chain in its own lean kernel (kernels.hpp "split decompression")
+    // many points: run the squaring chain in its own lean kernel (kernels.hpp "split decompression"),
+    // and on the second stream: the digit sort below needs the scalars only, is bound by LDS atomics
+    // and memory while this is pure integer VALU work, so the two overlap; joined before the buckets
     TRY(ensure(c, c->dec_scratch, job.n_dyn * DEC_WORDS * 4));
-    Launch l(c, "k_decompress");
-    hipLaunchKernelGGL(k_decompress_pre, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, s, job.d_dyn_points,
-                       (uint32_t*)c->dec_scratch.p, job.n_dyn);
-    hipLaunchKernelGGL(k_pow22523, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, s, (uint32_t*)c->dec_scratch.p,
-                       job.n_dyn);
-    hipLaunchKernelGGL(k_decompress_post, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, s,
-                       (const uint32_t*)c->dec_scratch.p, (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets,
-                       job.n_msm, (uint32_t*)c->msm_fail.p, bad_index);
+    hipStream_t sd = c->stream2 ? c->stream2 : s;
+    decompress_aside = sd != s;
+    if (decompress_aside) {
+      HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+      HIP_TRY(c, hipStreamWaitEvent(sd, c->ev_fork, 0));
+    }
+    {
+      Launch l(c, "k_decompress", sd);
+      hipLaunchKernelGGL(k_decompress_pre, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, sd, job.d_dyn_points,
+                         (uint32_t*)c->dec_scratch.p, job.n_dyn);
+      hipLaunchKernelGGL(k_pow22523, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, sd, (uint32_t*)c->dec_scratch.p,
+                         job.n_dyn);
+      hipLaunchKernelGGL(k_decompress_post, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, sd,
+                         (const uint32_t*)c->dec_scratch.p, (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets,
+                         job.n_msm, (uint32_t*)c->msm_fail.p, bad_index);
+    }
+    if (decompress_aside) HIP_TRY(c, hipEventRecord(c->ev_join, sd));
   } else if (job.n_dyn) {
     Launch l(c, "k_decompress");
     hipLaunchKernelGGL(k_decompress, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, s, job.d_dyn_points,
@@ -383,6 +395,7 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
     hipLaunchKernelGGL(k_bin_order, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p, n_bins,
                        class_cursor, (uint32_t*)c->bin_order.p, (uint32_t*)c->heavy.p);
   }
+  if (decompress_aside) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
   {
     Launch l(c, "k_bucket_accumulate");
     hipLaunchKernelGGL(k_bucket_accumulate, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s,
