@@ -586,17 +586,20 @@ k_bucket_accumulate(const uint32_t* __restrict__ cursor, const uint32_t* __restr
   if (start == end || end - start > HEAVY_BIN) return;   // heavy bins: k_bucket_heavy
   ge acc;
   ge_identity(acc);
-  auto fetch = [&](uint32_t k, ge_niels& q, bool& neg) {
-    const uint32_t e = entries[k];
+  // two dependent gathers per term (entry -> row): entries run two terms ahead, rows one
+  auto fetch_row = [&](uint32_t e, ge_niels& q, bool& neg) {
     const uint32_t* row = ((e & ENTRY_DYN) ? dyn_rows : static_rows) + (uint64_t)(e & ENTRY_IDX) * NIELS_WORDS;
     load_niels(q, row);
     neg = (e & ENTRY_NEG) != 0;
   };
   ge_niels cur, nxt;
   bool cur_neg = false, nxt_neg = false;
-  fetch(start, cur, cur_neg);
+  fetch_row(entries[start], cur, cur_neg);
+  uint32_t e_next = start + 1 < end ? entries[start + 1] : 0u;
   for (uint32_t k = start; k < end; ++k) {
-    if (k + 1 < end) fetch(k + 1, nxt, nxt_neg);
+    const uint32_t e_cur = e_next;
+    if (k + 2 < end) e_next = entries[k + 2];
+    if (k + 1 < end) fetch_row(e_cur, nxt, nxt_neg);
     ge_madd(acc, acc, cur, cur_neg);
     cur = nxt; cur_neg = nxt_neg;
   }
