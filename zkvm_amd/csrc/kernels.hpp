@@ -1087,9 +1087,15 @@ k_tbl_multiples(const uint32_t* __restrict__ base, uint32_t* __restrict__ tmp, u
 // lane k (one static term): all W signed digits of its scalar -> digits[t * n_static + k]
 __global__ void __launch_bounds__(256)
 k_static_digits(const uint32_t* __restrict__ st_scalars, int16_t* __restrict__ digits, uint64_t n_static, int w,
-                int W, uint32_t* __restrict__ status) {
-  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                int W, uint32_t* __restrict__ status, const uint32_t* __restrict__ row_map /*optional*/,
+                const uint32_t* __restrict__ n_active /*optional*/, uint32_t rows_per_msm) {
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_static) return;
+  if (row_map) {   // only the terms of the MSMs queued in row_map (uniform rows of rows_per_msm terms)
+    const uint32_t slot = (uint32_t)(k / rows_per_msm);
+    if (slot >= *n_active) return;
+    k = (uint64_t)row_map[slot] * rows_per_msm + k % rows_per_msm;
+  }
   const uint32_t* sc = st_scalars + 8 * k;
   if (sc[7] >> 31) atomicOr(&status[0], 2u);
   for (int t = 0; t < W; ++t) digits[(uint64_t)t * n_static + k] = 0;

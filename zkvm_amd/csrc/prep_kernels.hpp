@@ -507,13 +507,58 @@ k_gather_dyn_points(PrepShape sh, const uint32_t* __restrict__ com, const uint32
   dyn_points[g] = src[q];
 }
 
+// The same gather fused with the RFC 9496 DECODE and the per-point tables of the small-MSM path
+// (kernels.hpp, k_small_tables): one launch instead of three on the shared stream -- under load every
+// small kernel there waits for CU slots behind the long ones, and the waits add up along the chain.
+__global__ void __launch_bounds__(256)
+k_points_tables(PrepShape sh, const uint32_t* __restrict__ com, const uint32_t* __restrict__ pw, uint32_t batch,
+                uint32_t* __restrict__ tbl /*[B n_dyn][8][40]*/, uint32_t* __restrict__ msm_fail,
+                unsigned long long* __restrict__ bad_index) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)batch * sh.n_dyn) return;
+  const uint32_t j = (uint32_t)(g % sh.n_dyn), tx = (uint32_t)(g / sh.n_dyn);
+  const uint32_t* p = pw + (uint64_t)tx * sh.proof_words;
+  const uint32_t* c = com + (uint64_t)tx * sh.m * 8;
+  const uint32_t* src;
+  if (j < 6) src = p + 8 * j;
+  else if (j < 6 + sh.m) src = c + 8 * (j - 6);
+  else if (j < 11 + sh.m) src = p + 8 * (6 + (j - 6 - sh.m));
+  else {
+    const uint32_t r = j - 11 - sh.m;
+    src = p + 112 + (r < sh.k ? 16 * r : 16 * (r - sh.k) + 8);
+  }
+  uint32_t w[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) w[q] = src[q];
+  fe x, y;
+  const bool ok = ristretto_decode_affine(x, y, w);
+  ge_niels nq;
+  niels_from_affine(nq, x, y);
+  if (!ok) {
+    niels_identity(nq);
+    atomicMin(bad_index, (unsigned long long)g);
+    atomicOr(&msm_fail[tx], 1u);
+  }
+  ge cur;
+  ge_identity(cur);
+  uint32_t* row = tbl + g * (SMALL_TBL * EXT_WORDS);
+#pragma unroll 1
+  for (int e = 0; e < SMALL_TBL; ++e) {
+    ge_madd(cur, cur, nq, false);
+    store_cached(row + e * EXT_WORDS, cur);
+  }
+}
+
 // generator scalars of a group: sum over its transactions (canonical words in and out)
 __global__ void __launch_bounds__(256)
 k_group_scalars(const uint32_t* __restrict__ st_scalars /*[B][n_static][8]*/, uint32_t n_msm, uint32_t n_static,
-                uint32_t group, uint32_t* __restrict__ out /*[groups][n_static][8]*/) {
+                uint32_t group, uint32_t* __restrict__ out /*[groups][n_static][8]*/,
+                int16_t* __restrict__ digits /*optional: [W][groups * n_static], as k_static_digits writes them*/,
+                int w, int W) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n_groups = (n_msm + group - 1) / group;
-  if (g >= (uint64_t)n_groups * n_static) return;
+  const uint64_t total = (uint64_t)n_groups * n_static;
+  if (g >= total) return;
   const uint32_t G = (uint32_t)(g / n_static), j = (uint32_t)(g % n_static);
   scm acc = scm_zero();
   for (uint32_t i = 0; i < group; ++i) {
@@ -528,6 +573,10 @@ k_group_scalars(const uint32_t* __restrict__ st_scalars /*[B][n_static][8]*/, ui
   uint4* dst = reinterpret_cast<uint4*>(out + g * 8);
   dst[0] = make_uint4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]);
   dst[1] = make_uint4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
+  if (digits) {   // the sum is < l: no range flag to raise; digits straight from the registers' copy
+    for (int t = 0; t < W; ++t) digits[(uint64_t)t * total + g] = 0;
+    for_each_digit(out + g * 8, w, W, [&](int t, int d) { digits[(uint64_t)t * total + g] = (int16_t)d; });
+  }
 }
 
 }  // namespace zk

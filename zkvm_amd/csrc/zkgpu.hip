@@ -614,7 +614,8 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
   if (job.n_static) {
     Launch l(c, "k_static_digits", s2);
     hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, s2, job.d_st_scalars,
-                       (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p);
+                       (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
   }
   {
     Launch l(c, "k_static_accumulate", s2);
@@ -736,18 +737,26 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     // tables on the shared stream while the transcript is replayed
     HIP_TRY(c, hipEventRecord(c->ev_u, L));
     HIP_TRY(c, hipStreamWaitEvent(H1, c->ev_u, 0));
-    {
-      Launch l(c, "k_gather_dyn_points", H1);
-      hipLaunchKernelGGL(k_gather_dyn_points, dim3(blocks_for((uint64_t)B * sh.n_dyn * 8, 256)), dim3(256), 0, H1, sh,
-                         prep->d_com, (const uint32_t*)c->prep_pw.p, (uint32_t)B, (uint32_t*)c->prep_dyn_pt.p);
+    static const bool fuse_points = [] { const char* e = getenv("ZKGPU_FUSE_POINTS"); return e ? atoi(e) != 0 : true; }();
+    if (fuse_points) {
+      Launch l(c, "k_points_tables", H1);
+      hipLaunchKernelGGL(k_points_tables, dim3(blocks_for((uint64_t)B * sh.n_dyn, 256)), dim3(256), 0, H1, sh,
+                         prep->d_com, (const uint32_t*)c->prep_pw.p, (uint32_t)B, (uint32_t*)c->small_tbl.p,
+                         (uint32_t*)c->msm_fail.p, (unsigned long long*)((char*)c->status.p + 8));
+    } else {
+      {
+        Launch l(c, "k_gather_dyn_points", H1);
+        hipLaunchKernelGGL(k_gather_dyn_points, dim3(blocks_for((uint64_t)B * sh.n_dyn * 8, 256)), dim3(256), 0, H1, sh,
+                           prep->d_com, (const uint32_t*)c->prep_pw.p, (uint32_t)B, (uint32_t*)c->prep_dyn_pt.p);
+      }
+      {
+        Launch l(c, "k_decompress", H1);
+        hipLaunchKernelGGL(k_decompress, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, H1, job.d_dyn_points,
+                           (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, (uint32_t)B, (uint32_t*)c->msm_fail.p,
+                           (unsigned long long*)((char*)c->status.p + 8), (uint8_t*)nullptr);
+      }
+      TRY(small_tables_launch(c, nullptr, job.n_dyn, H1));
     }
-    {
-      Launch l(c, "k_decompress", H1);
-      hipLaunchKernelGGL(k_decompress, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, H1, job.d_dyn_points,
-                         (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, (uint32_t)B, (uint32_t*)c->msm_fail.p,
-                         (unsigned long long*)((char*)c->status.p + 8), (uint8_t*)nullptr);
-    }
-    TRY(small_tables_launch(c, nullptr, job.n_dyn, H1));
     {
       Launch l(c, "k_transcript", L);
       hipLaunchKernelGGL(k_transcript, dim3(blocks_for(B, 64)), dim3(64), 0, L, sh, prep->d_init,
@@ -771,15 +780,10 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   uint32_t* n_recheck = (uint32_t*)((char*)c->status.p + 32);
   if (group > 1) {
     {
-      Launch l(c, "k_group_scalars", H2);
+      Launch l(c, "k_group_scalars", H2);     // sums and their digits in one launch
       hipLaunchKernelGGL(k_group_scalars, dim3(blocks_for((uint64_t)n_groups * ns, 256)), dim3(256), 0, H2,
-                         job.d_st_scalars, (uint32_t)B, ns, group, (uint32_t*)c->grp_sc.p);
-    }
-    {
-      Launch l(c, "k_static_digits", H2);
-      hipLaunchKernelGGL(k_static_digits, dim3(blocks_for((uint64_t)n_groups * ns, 256)), dim3(256), 0, H2,
-                         (const uint32_t*)c->grp_sc.p, (int16_t*)c->grp_digits.p, (uint64_t)n_groups * ns, ps->tbl_w, W,
-                         (uint32_t*)c->status.p);
+                         job.d_st_scalars, (uint32_t)B, ns, group, (uint32_t*)c->grp_sc.p, (int16_t*)c->grp_digits.p,
+                         ps->tbl_w, W);
     }
     {
       Launch l(c, "k_static_accumulate", H2);
@@ -789,17 +793,12 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
                          (uint32_t*)c->grp_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     }
     HIP_TRY(c, hipEventRecord(c->ev_sa, H2));
-    {
-      Launch l(c, "k_static_digits", H2);       // per transaction, for the groups that fail
-      hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, H2, job.d_st_scalars,
-                         (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p);
-    }
-    HIP_TRY(c, hipEventRecord(c->ev_dig, H2));
   } else {
     {
       Launch l(c, "k_static_digits", H2);
       hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, H2, job.d_st_scalars,
-                         (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p);
+                         (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p,
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
     }
     {
       Launch l(c, "k_static_accumulate", H2);
@@ -840,7 +839,12 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
                          (uint32_t*)c->row_map.p, n_recheck);
     }
     // failed groups, transaction by transaction: full-size grids, lanes beyond the queued count leave at once
-    HIP_TRY(c, hipStreamWaitEvent(L, c->ev_dig, 0));
+    {
+      Launch l(c, "k_static_digits", L);        // digits of the queued transactions only
+      hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, L, job.d_st_scalars,
+                         (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p,
+                         (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, ns);
+    }
     {
       Launch l(c, "k_static_accumulate", L);
       hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)B * W * Pf, 256)), dim3(256), 0, L,
@@ -1355,7 +1359,8 @@ int zkgpu_msm_ps_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, con
   if (n) {
     Launch l(c, "k_static_digits");
     hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(n, 256)), dim3(256), 0, s, (const uint32_t*)c->in_st_scalars.p,
-                       (int16_t*)c->digits.p, n, ps->tbl_w, W, (uint32_t*)c->status.p);
+                       (int16_t*)c->digits.p, n, ps->tbl_w, W, (uint32_t*)c->status.p, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, 0u);
   }
   {
     Launch l(c, "k_static_accumulate");
