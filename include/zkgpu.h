@@ -23,9 +23,9 @@
  *     points: 32-byte ristretto255 encodings (RFC 9496 sec 4.3.1);
  *   - every call returns ZKGPU_OK (0) or a negative error code; on ANY error
  *     the outputs are zeroed (fail-closed: an error is never an "accept");
- *   - a context is bound to one GPU and one HIP stream, and serialises its own
- *     calls; use one context per thread / per GPU (one process per GPU under
- *     torch.distributed);
+ *   - a context is bound to one GPU, owns its HIP streams (three chip-filling ones, shared with
+ *     its forks, and a light one of its own) and serialises its own calls; use one context per
+ *     thread, one process per GPU (zkgpu_comm joins the processes of a node over RCCL);
  *   - `*_dev` variants take device pointers (inputs already resident in HBM) and
  *     are what bench.py times; host-pointer variants add the PCIe copies.
  */
@@ -45,6 +45,8 @@ extern "C" {
 #define ZKGPU_EHIP (-3)            /* HIP runtime error; see zkgpu_last_error */
 #define ZKGPU_ENOMEM (-4)
 #define ZKGPU_ENODEVICE (-5)
+#define ZKGPU_ENOCOMM (-6)         /* RCCL could not be loaded / initialised, or a collective failed */
+#define ZKGPU_EREMOTE (-7)         /* sharded verification: another rank reported an error (bitmap zeroed everywhere) */
 
 typedef struct zkgpu_ctx zkgpu_ctx;
 typedef struct zkgpu_pointset zkgpu_pointset;
@@ -86,11 +88,12 @@ size_t zkgpu_pointset_size(const zkgpu_pointset *ps);
 
 /* Build fixed-base window tables for the set: for every window position t and
  * point j the affine multiples d * 2^(w t) * P_j, d = 1 .. 2^(w-1)
- * ((255/w + 1) * n * 2^(w-1) rows of 128 B; w = 12, n = 514: 2.96 GB).  With
- * tables present zkgpu_verify_batch_ps* sums static terms straight out of them:
- * one mixed addition per term and window, no doublings, no sorting.  One-time
- * cost of tens of milliseconds (seconds at 16 bits, whose tables take 50 MB per point);
- * results are identical with or without tables.  2 <= window_bits <= 16. */
+ * ((255/w + 1) * n * 2^(w-1) packed rows of 96 B; w = 16, n = 514: 25.9 GB, n = 1026: 51.7 GB;
+ * w = 12, n = 514: 2.2 GB).  With tables present zkgpu_verify_batch_ps* and every whole-proof
+ * entry point sum static terms straight out of them: one mixed addition per term and window,
+ * no doublings, no sorting.  One-time cost: ~0.2 s at 16 bits and 514 points (50 MB per point),
+ * milliseconds at 8-12 bits; results are identical with or without tables.
+ * 2 <= window_bits <= 16. */
 int zkgpu_pointset_build_tables(zkgpu_ctx *ctx, zkgpu_pointset *ps, int window_bits);
 size_t zkgpu_pointset_table_bytes(const zkgpu_pointset *ps);
 
@@ -205,9 +208,18 @@ int zkgpu_set_group_size(zkgpu_ctx* ctx, int group);
 int zkgpu_set_serial(zkgpu_ctx* ctx, int on);
 
 /* Test hook: intermediate buffers of the last device-side preparation on this context.
- * what = "challenges" (per transaction n_ch_ext slots of 32 B, Montgomery form R = 2^256),
- * "static_scalars", "dyn_scalars", "dyn_points" (canonical 32-byte values).  Returns bytes copied. */
+ * what = "challenges": per transaction layout[0] slots of 32 B, each x * 2^260 mod l (Montgomery form):
+ *          0 y  1 z  2 u  3 x  4 w  5 prod u_j  6 prod u_j^2  7 r  8 t_x  9 t_x_blinding  10 e_blinding
+ *          11 a  12 b  13 rho (weight inside a group check; 1 when transactions are checked alone)
+ *          14.. the layout[2] second-phase challenges, then the k inner-product challenges u_j, ...
+ *        "static_scalars" (layout[4] per transaction: B, B_blinding, G_i, H_i) and "dyn_scalars"
+ *        (layout[3]: A_I1 A_O1 S1 A_I2 A_O2 S2 | V | T_1 T_3..T_6 | L | R): canonical 32-byte scalars of
+ *        the verification equation MULTIPLIED THROUGH by c' = rho * y^(padded_n - 1) * prod u_j^2 (the
+ *        device evaluates the equation in this inversion-free form).
+ * Returns bytes copied.  zkgpu_cloak_plan_layout fills layout[0..7] = slots per transaction, challenge
+ * slots proper, second-phase challenges, dynamic terms, static terms, k, m, monomials. */
 long long zkgpu_debug_read(zkgpu_ctx* ctx, const char* what, void* out, size_t bytes);
+int zkgpu_cloak_plan_layout(const zkgpu_cloak_plan* plan, uint32_t layout[8]);
 
 /* Plain device memory for callers without a HIP binding of their own: what the *_dev entry points
  * take.  zkgpu_upload is a blocking host-to-device copy. */
@@ -255,7 +267,74 @@ int zkgpu_bulletproof_gens(zkgpu_ctx *ctx, size_t capacity, uint32_t party, uint
 /* Decode-only helper (CompressedRistretto::decompress validity): ok[i] = 1/0. */
 int zkgpu_decode_check(zkgpu_ctx *ctx, const uint8_t *points, size_t n, uint8_t *ok);
 
-/* ---- measurement hooks (used by bench.py; not part of the reference API) ---- */
+/* ---- whole blocks of transactions of mixed shapes (BASELINE configs[3]) -----------------------
+ * zkgpu_verifier mirrors the reference's `Verifier` for a block: it owns up to `batches_in_flight`
+ * contexts (the given one and forks of it; 0 = default 6) and one device plan per statement shape,
+ * created on first use.  zkgpu_verifier_verify takes the block as Tx::verify sees it -- per
+ * transaction (n_in, n_out), its 64 (n_in + n_out) commitment bytes back to back, its R1CSProof bytes
+ * (CSR) and 64 bytes of verifier randomness (NULL: getrandom(2)) -- groups the transactions by shape,
+ * verifies the groups as uniform batches of at most `chunk` transactions (default 2048) kept in flight
+ * on its contexts, and writes one accept bit per transaction in block order.  A transaction whose
+ * shape the generator set cannot serve (more multipliers than generators, no values, > 64 inputs or
+ * outputs) or whose proof has the wrong length for its shape is rejected on its own, as in the
+ * reference (InvalidGeneratorsLength / malformed proof); it never fails the block.
+ * zkgpu_txblock keeps a block resident in HBM, grouped by shape (what bench.py --config 4 times);
+ * zkgpu_verifier_verify = create + verify_block + destroy.  One call at a time per verifier. */
+typedef struct zkgpu_verifier zkgpu_verifier;
+typedef struct zkgpu_txblock zkgpu_txblock;
+int zkgpu_verifier_create(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t gens_capacity, int batches_in_flight,
+                          zkgpu_verifier **out);
+void zkgpu_verifier_destroy(zkgpu_verifier *v);
+int zkgpu_verifier_set_chunk(zkgpu_verifier *v, size_t transactions);
+int zkgpu_verifier_lanes(const zkgpu_verifier *v);
+const char *zkgpu_verifier_last_error(const zkgpu_verifier *v);
+int zkgpu_verifier_verify(zkgpu_verifier *v, size_t batch, const uint32_t *n_in, const uint32_t *n_out,
+                          const uint8_t *commitments, const uint8_t *proofs, const uint64_t *proof_offsets,
+                          const uint8_t *r_bytes, uint8_t *accept_bitmap);
+int zkgpu_txblock_create(zkgpu_verifier *v, size_t batch, const uint32_t *n_in, const uint32_t *n_out,
+                         const uint8_t *commitments, const uint8_t *proofs, const uint64_t *proof_offsets,
+                         const uint8_t *r_bytes, zkgpu_txblock **out);
+void zkgpu_txblock_destroy(zkgpu_txblock *block);
+size_t zkgpu_txblock_size(const zkgpu_txblock *block);
+size_t zkgpu_txblock_shapes(const zkgpu_txblock *block);
+int zkgpu_verifier_verify_block(zkgpu_verifier *v, const zkgpu_txblock *block, uint8_t *accept_bitmap);
+
+/* ---- one process per GPU: sharding and the RCCL exchange ------------------
+ * Transactions are independent, so a block is cut into `world` contiguous shards balanced by the
+ * number of multiscalar-multiplication terms (zkgpu_cloak_msm_terms of each shape; zkgpu_shard_cuts
+ * fills cuts[0..world]), rank r verifies [cuts[r], cuts[r+1]) on its own GPU, and the only exchange is
+ * one ncclAllGather of the per-shard accept bitmaps (a status word + ceil(shard/8) bytes per rank:
+ * latency-bound, xGMI bandwidth irrelevant).  zkgpu_comm wraps the communicator: rank 0 calls
+ * zkgpu_comm_unique_id and ships the 128 bytes to the other processes by whatever channel the host
+ * has; every process then calls zkgpu_comm_create on its own context.  RCCL is bound with dlopen at
+ * first use (librccl.so.1): without it these calls return ZKGPU_ENOCOMM and nothing else is affected;
+ * a world of one needs no RCCL (id == NULL).
+ * zkgpu_comm_allgather_bitmap is fail-closed ACROSS ranks: if any rank passes a non-zero local_status
+ * every rank gets an all-zero bitmap and an error (its own, or ZKGPU_EREMOTE) -- and no rank is left
+ * waiting in the collective.  zkgpu_verifier_verify_sharded = cuts + verify own shard + that gather,
+ * with the whole block in host memory on every rank. */
+#define ZKGPU_COMM_ID_BYTES 128
+typedef struct zkgpu_comm zkgpu_comm;
+uint64_t zkgpu_cloak_msm_terms(uint32_t n_in, uint32_t n_out);
+int zkgpu_shard_cuts(size_t batch, const uint32_t *n_in, const uint32_t *n_out, int world, uint64_t *cuts);
+int zkgpu_comm_unique_id(uint8_t id[ZKGPU_COMM_ID_BYTES]);
+int zkgpu_comm_create(zkgpu_ctx *ctx, int rank, int world, const uint8_t id[ZKGPU_COMM_ID_BYTES], zkgpu_comm **out);
+void zkgpu_comm_destroy(zkgpu_comm *comm);
+int zkgpu_comm_rank(const zkgpu_comm *comm);
+int zkgpu_comm_world(const zkgpu_comm *comm);
+int zkgpu_comm_allgather(zkgpu_comm *comm, const uint8_t *local, size_t bytes, uint8_t *all);
+int zkgpu_comm_allgather_bitmap(zkgpu_comm *comm, const uint64_t *cuts, const uint8_t *local_bitmap, int local_status,
+                                uint8_t *whole_bitmap);
+int zkgpu_verifier_verify_sharded(zkgpu_verifier *v, zkgpu_comm *comm, size_t batch, const uint32_t *n_in,
+                                  const uint32_t *n_out, const uint8_t *commitments, const uint8_t *proofs,
+                                  const uint64_t *proof_offsets, const uint8_t *r_bytes, uint8_t *accept_bitmap);
+
+/* ---- measurement hooks (used by bench.py; not part of the reference API) ----
+ * Environment variables read by the library, none of which changes a result:
+ *   ZKGPU_TIMELINE=<file>     with profiling on, every launch as "ctx kernel start_ms end_ms"
+ *   ZKGPU_PROVER_TIMING=1     zkgpu_cloak_prove_batch prints per-phase host / device times to stderr
+ * and GPU_MAX_HW_QUEUES (a HIP runtime variable): zkgpu_init sets it to 24 if it is unset and the
+ * runtime has not started; batches in flight need a hardware queue per context. */
 /* When enabled, every kernel launch of this context is bracketed by HIP events
  * on the context's own stream. */
 int zkgpu_profile_enable(zkgpu_ctx *ctx, int on);

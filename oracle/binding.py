@@ -314,6 +314,19 @@ def cloak_verify_prepare(commitments: bytes, n_in: int, n_out: int, proof: bytes
     return out
 
 
+def cloak_verify_challenges(commitments: bytes, n_in: int, n_out: int, proof: bytes, r_bytes: bytes):
+    """-> None when the proof is malformed, else the verifier's challenges in transcript order as ints:
+    second-phase challenges, y, z, u, x, w, the k inner-product challenges"""
+    cap = 128
+    buf = C.create_string_buffer(32 * cap)
+    n = C.c_size_t(0)
+    rc = load().zko_cloak_verify_challenges(commitments, C.c_size_t(n_in), C.c_size_t(n_out), proof, C.c_size_t(len(proof)),
+                                            r_bytes, buf, C.c_size_t(cap), C.byref(n))
+    if rc != 0:
+        return None
+    return [int.from_bytes(buf.raw[32 * i: 32 * i + 32], "little") for i in range(n.value)]
+
+
 def cloak_verify_batch(commitments: bytes, n_in: int, n_out: int, proofs: bytes, proof_len: int, r_bytes: bytes,
                        threads: int = 1) -> bytes:
     """Full CPU verification (transcript replay + MSM) of count = len(proofs) / proof_len proofs; -> accept bytes"""

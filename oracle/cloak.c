@@ -319,6 +319,18 @@ int zko_cloak_verify_prepare(const uint8_t *commitments, size_t n_in, size_t n_o
   return rc;
 }
 
+int zko_cloak_verify_challenges(const uint8_t *commitments, size_t n_in, size_t n_out, const uint8_t *proof,
+                                size_t proof_len, const uint8_t r_bytes[64], uint8_t *challenges, size_t cap,
+                                size_t *n_challenges) {
+  r1cs_cs *cs = cloak_verifier(commitments, n_in, n_out);
+  if (!cs) return -1;
+  r1cs_msm m;
+  int rc = r1cs_verify_prepare(cs, proof, proof_len, r_bytes, &m);
+  if (rc == 0) { *n_challenges = r1cs_challenge_log(cs, challenges, cap); r1cs_msm_free(&m); }
+  r1cs_free(cs);
+  return rc;
+}
+
 /* count proofs of one shape with seeded witnesses: tx i moves q0, q1 of flavor(s) chosen by i:
  * even i: one flavor (merge + split exercised), odd i: two flavors (pass-through). */
 int zko_cloak_prove_batch(size_t count, size_t n_in, size_t n_out, const uint8_t seed[32], uint8_t *commitments,

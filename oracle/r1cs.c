@@ -64,7 +64,25 @@ struct r1cs_cs {
   sc *aL, *aR, *aO; size_t cap_vars;
   sc *v, *v_blinding; uint8_t (*V)[32]; size_t m, cap_m;
   struct { r1cs_rand_fn fn; void *ud; } *deferred; size_t n_def, cap_def;
+  /* every Fiat-Shamir challenge drawn through this system, in transcript order (tests compare the
+   * device-side transcript replay with these byte for byte) */
+  sc *chal_log; size_t n_chal, cap_chal;
 };
+
+static void draw_challenge(r1cs_cs *cs, const char *label, sc *out) {
+  merlin_challenge_scalar(&cs->tr, label, out);
+  if (cs->n_chal == cs->cap_chal) {
+    cs->cap_chal = cs->cap_chal ? 2 * cs->cap_chal : 32;
+    cs->chal_log = realloc(cs->chal_log, sizeof(sc) * cs->cap_chal);
+  }
+  cs->chal_log[cs->n_chal++] = *out;
+}
+
+size_t r1cs_challenge_log(const r1cs_cs *cs, uint8_t *out, size_t cap) {
+  size_t n = cs->n_chal < cap ? cs->n_chal : cap;
+  for (size_t i = 0; i < n; ++i) sc_to_bytes(out + 32 * i, &cs->chal_log[i]);
+  return cs->n_chal;
+}
 
 static r1cs_cs *cs_new(int is_prover, const uint8_t *label, size_t len) {
   r1cs_cs *cs = calloc(1, sizeof *cs);
@@ -81,7 +99,7 @@ void r1cs_free(r1cs_cs *cs) {
   if (!cs) return;
   for (size_t i = 0; i < cs->n_cons; ++i) lc_free(&cs->cons[i]);
   free(cs->cons); free(cs->aL); free(cs->aR); free(cs->aO); free(cs->v); free(cs->v_blinding); free(cs->V);
-  free(cs->deferred); free(cs);
+  free(cs->deferred); free(cs->chal_log); free(cs);
 }
 
 static void grow_m(r1cs_cs *cs) {
@@ -208,7 +226,7 @@ int r1cs_specify_randomized_constraints(r1cs_cs *cs, r1cs_rand_fn fn, void *ud) 
   return 0;
 }
 
-void r1cs_challenge_scalar(r1cs_cs *cs, const char *label, sc *out) { merlin_challenge_scalar(&cs->tr, label, out); }
+void r1cs_challenge_scalar(r1cs_cs *cs, const char *label, sc *out) { draw_challenge(cs, label, out); }
 
 static int create_randomized_constraints(r1cs_cs *cs) {
   cs->pending = -1;
@@ -534,18 +552,18 @@ int r1cs_verify_prepare(r1cs_cs *cs, const uint8_t *proof, size_t proof_len, con
   merlin_append_point(tr, "A_O2", pt + 128);
   merlin_append_point(tr, "S2", pt + 160);
   sc y, z, u, x, w;
-  merlin_challenge_scalar(tr, "y", &y);
-  merlin_challenge_scalar(tr, "z", &z);
+  draw_challenge(cs, "y", &y);
+  draw_challenge(cs, "z", &z);
   for (int i = 6; i < 11; ++i) VALIDATE(pt + 32 * i);
   merlin_append_point(tr, "T_1", pt + 192); merlin_append_point(tr, "T_3", pt + 224);
   merlin_append_point(tr, "T_4", pt + 256); merlin_append_point(tr, "T_5", pt + 288);
   merlin_append_point(tr, "T_6", pt + 320);
-  merlin_challenge_scalar(tr, "u", &u);
-  merlin_challenge_scalar(tr, "x", &x);
+  draw_challenge(cs, "u", &u);
+  draw_challenge(cs, "x", &x);
   merlin_append_scalar(tr, "t_x", &t_x);
   merlin_append_scalar(tr, "t_x_blinding", &t_x_bl);
   merlin_append_scalar(tr, "e_blinding", &e_bl);
-  merlin_challenge_scalar(tr, "w", &w);
+  draw_challenge(cs, "w", &w);
 
   sc *wL = malloc(sizeof(sc) * (n + 1)), *wR = malloc(sizeof(sc) * (n + 1)), *wO = malloc(sizeof(sc) * (n + 1));
   sc *wV = malloc(sizeof(sc) * (cs->m + 1)), wc;
@@ -560,7 +578,7 @@ int r1cs_verify_prepare(r1cs_cs *cs, const uint8_t *proof, size_t proof_len, con
     if (memcmp(lr + 64 * j, ident, 32) == 0 || memcmp(lr + 64 * j + 32, ident, 32) == 0) rc = -4;
     merlin_append_point(tr, "L", lr + 64 * j);
     merlin_append_point(tr, "R", lr + 64 * j + 32);
-    merlin_challenge_scalar(tr, "u", &ch[j]);
+    draw_challenge(cs, "u", &ch[j]);
   }
   if (rc) { free(wL); free(wR); free(wO); free(wV); free(ch); free(ch_inv); return rc; }
   sc one, zero, allinv;

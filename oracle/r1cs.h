@@ -38,6 +38,8 @@ int r1cs_is_prover(const r1cs_cs *cs);
 size_t r1cs_num_multipliers(const r1cs_cs *cs);
 size_t r1cs_num_constraints(const r1cs_cs *cs);
 size_t r1cs_num_commitments(const r1cs_cs *cs);
+/* challenges drawn so far, in transcript order, as canonical 32-byte scalars; returns their number */
+size_t r1cs_challenge_log(const r1cs_cs *cs, uint8_t *out, size_t cap);
 
 size_t r1cs_proof_size(size_t padded_n);
 int r1cs_prove(r1cs_cs *cs, const uint8_t rng_seed[32], uint8_t *proof, size_t proof_cap, size_t *proof_len);
@@ -65,6 +67,11 @@ int zko_cloak_verify(const uint8_t *commitments, size_t n_in, size_t n_out, cons
                      const uint8_t r_bytes[64]);
 int zko_cloak_verify_prepare(const uint8_t *commitments, size_t n_in, size_t n_out, const uint8_t *proof,
                              size_t proof_len, const uint8_t r_bytes[64], r1cs_msm *out);
+/* as zko_cloak_verify_prepare, also returning the verifier's challenges in transcript order: the second-phase
+ * challenges, y, z, u, x, w, then the k inner-product challenges (canonical 32-byte scalars) */
+int zko_cloak_verify_challenges(const uint8_t *commitments, size_t n_in, size_t n_out, const uint8_t *proof,
+                                size_t proof_len, const uint8_t r_bytes[64], uint8_t *challenges, size_t cap,
+                                size_t *n_challenges);
 int zko_cloak_verify_batch(size_t count, size_t n_in, size_t n_out, const uint8_t *commitments, const uint8_t *proofs,
                            size_t proof_stride, size_t proof_len, const uint8_t *r_bytes, uint8_t *accept,
                            int threads);

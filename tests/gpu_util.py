@@ -24,3 +24,98 @@ def points(oracle, tag: str, n: int, distinct: int = 0) -> bytes:
 
 def bits(bm: bytes, n: int):
     return [(bm[i // 8] >> (i % 8)) & 1 for i in range(n)]
+
+
+# ---- committed proof fixtures (tests/golden/gen_cloak_fixtures_r2.py) -----------------------------
+def load_cloak_fixture(name: str = "cloak_2x2_1024.bin"):
+    """-> ([(commitments, proof), ...], n_in, n_out, proof_len)"""
+    import os
+    import struct
+    raw = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name), "rb").read()
+    assert raw[:8] == b"ZKCLOAK1"
+    count, n_in, n_out, plen = struct.unpack("<IIII", raw[8:24])
+    w = 64 * (n_in + n_out)
+    rec = w + plen
+    return [(raw[24 + rec * i: 24 + rec * i + w], raw[24 + rec * i + w: 24 + rec * (i + 1)]) for i in range(count)], n_in, n_out, plen
+
+
+def load_mixed_fixture():
+    """-> {(n_in, n_out): [(commitments, proof), ...]} for the shapes 1x1, 1x2, 2x2, 3x3, 4x4"""
+    import os
+    import struct
+    raw = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cloak_mixed.bin"), "rb").read()
+    assert raw[:8] == b"ZKCLOAKM"
+    (groups,) = struct.unpack("<I", raw[8:12])
+    pos, out = 12, {}
+    for _ in range(groups):
+        count, n_in, n_out, plen = struct.unpack("<IIII", raw[pos: pos + 16])
+        pos += 16
+        w = 64 * (n_in + n_out)
+        recs = []
+        for _ in range(count):
+            recs.append((raw[pos: pos + w], raw[pos + w: pos + w + plen]))
+            pos += w + plen
+        out[(n_in, n_out)] = recs
+    assert pos == len(raw)
+    return out
+
+
+def mixed_block(count: int, seed: int, bad_every: int = 61):
+    """`count` transactions drawn from the mixed fixture with a fixed seed (shapes
+    {1x1, 1x2, 2x2, 3x3, 4x4}); every bad_every-th one corrupted, the kind of corruption cycling so that every
+    shape meets every kind.  -> list of (n_in, n_out, commitments, proof)"""
+    import random
+    fix = load_mixed_fixture()
+    shapes = sorted(fix)
+    rng = random.Random(seed)
+    txs, kinds = [], {s: 0 for s in shapes}
+    for i in range(count):
+        s = shapes[rng.randrange(len(shapes))]
+        j = rng.randrange(len(fix[s]))
+        com, proof = fix[s][j]
+        if i % bad_every == 3:
+            kind = kinds[s] % 6
+            kinds[s] += 1
+            if kind == 0:      # a bit of t_x / t_x_blinding / e_blinding
+                p = bytearray(proof); p[1 + 32 * (11 + i % 3) + (i % 31)] ^= 1 << (i % 8); proof = bytes(p)
+            elif kind == 1:    # a commitment byte
+                c = bytearray(com); c[i % len(com)] ^= 0x20; com = bytes(c)
+            elif kind == 2:    # inner-product scalar a + 1 (canonical)
+                a = (int.from_bytes(proof[-64:-32], "little") + 1) % L
+                proof = proof[:-64] + a.to_bytes(32, "little") + proof[-32:]
+            elif kind == 3:    # somebody else's proof of the same shape
+                proof = fix[s][(j + 1) % len(fix[s])][1]
+            elif kind == 4:    # truncated: wrong length for the shape
+                proof = proof[:-32]
+            else:              # wire-format version byte
+                proof = bytes([2]) + proof[1:]
+        txs.append((s[0], s[1], com, proof))
+    return txs
+
+
+def oracle_block_bits(oracle, txs, r: bytes, threads: int = 8):
+    """Accept bits of the oracle's full verifier for a mixed block (groups of equal shape and proof length in
+    one OpenMP call each)."""
+    groups = {}
+    for i, (n_in, n_out, com, proof) in enumerate(txs):
+        groups.setdefault((n_in, n_out, len(proof)), []).append(i)
+    out = [0] * len(txs)
+    for (n_in, n_out, plen), idx in groups.items():
+        acc = oracle.cloak_verify_batch(b"".join(txs[i][2] for i in idx), n_in, n_out, b"".join(txs[i][3] for i in idx), plen,
+                                        b"".join(r[64 * i: 64 * i + 64] for i in idx), threads=threads)
+        for j, i in enumerate(idx):
+            out[i] = acc[j]
+    return out
+
+
+# ---- BASELINE configs[2]: the 2^20-term MSM (tests/golden/gen_msm_2p20.py) ---------------------------
+MSM_SEED = 0x5A6B564D
+
+
+def msm_2p20_inputs(n: int):
+    """-> (scalars n x 32 B, uniform n x 64 B): the scalars reduced mod l here, the points still to be mapped
+    with from_uniform_bytes (on the device: Context.hash_to_points)."""
+    raw_p = hashlib.shake_256(MSM_SEED.to_bytes(4, "little") + b"msm2p20").digest(64 * n)
+    raw_s = hashlib.shake_256(MSM_SEED.to_bytes(4, "little") + b"msm2p20 scalars").digest(64 * n)
+    sc = b"".join((int.from_bytes(raw_s[64 * i: 64 * i + 64], "little") % L).to_bytes(32, "little") for i in range(n))
+    return sc, raw_p

@@ -1,0 +1,246 @@
+"""GPU parity for whole blocks of mixed shapes (BASELINE.json configs[3]), the exchange step behind the C ABI,
+the device-side verifier head byte by byte, the benched configuration, and the 2^20 MSM against its committed
+expected value (configs[2])."""
+import hashlib
+import json
+import os
+
+import pytest
+
+from gpu_util import L, bits, load_cloak_fixture, load_mixed_fixture, mixed_block, msm_2p20_inputs, oracle_block_bits
+
+pytestmark = pytest.mark.gpu
+R260_INV = pow(pow(2, 260, L), -1, L)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from zkvm_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def gens512(ctx):
+    """ONE table set for every shape up to 4x4 (padded n = 512): 16-bit windows, 51.7 GB."""
+    from zkvm_amd.verifier import BulletproofGens
+    g = BulletproofGens(ctx, 512, table_bits=16)
+    yield g
+    g.close()
+
+
+def _cloak(txs):
+    from zkvm_amd.verifier import CloakTx
+    return [CloakTx(a, b, c, p) for a, b, c, p in txs]
+
+
+def test_mixed_arity_shard_8192_vs_oracle(ctx, gens512, oracle):
+    """An 8 192-transaction shard of SURVEY.md sec 8(d) config 4 (shapes 1x1, 1x2, 2x2, 3x3, 4x4 drawn with a
+    fixed seed, > 1 % corrupted, every kind of corruption in every shape) through zkgpu_verifier_verify
+    (host memory) and zkgpu_txblock + zkgpu_verifier_verify_block (resident in HBM): every accept bit equals the
+    oracle's full verifier."""
+    from zkvm_amd.verifier import BlockVerifier
+    n = 8192
+    txs = mixed_block(n, seed=4)
+    r = hashlib.shake_256(b"config 4 shard").digest(64 * n)
+    want = oracle_block_bits(oracle, txs, r, threads=16)
+    bad = [i for i in range(n) if not want[i]]
+    assert n // 100 < len(bad) < n // 20
+    assert {(txs[i][0], txs[i][1]) for i in bad} == set(load_mixed_fixture())      # every shape has rejected ones
+    bv = BlockVerifier(ctx, gens512)
+    assert bv.lanes() == 6
+    try:
+        assert bits(bv.verify(_cloak(txs), r), n) == want
+        blk = bv.block(_cloak(txs), r)
+        assert blk.shapes() >= 6              # five shapes + the truncated proofs
+        for _ in range(2):
+            assert bits(bv.verify_block(blk), n) == want
+        blk.close()
+        assert bits(bv.verify(_cloak(txs)), n) == want          # verifier randomness from getrandom(2)
+        assert bv.verify([]) == b""
+    finally:
+        bv.close()
+
+
+def test_block_rejects_unverifiable_shapes_one_by_one(ctx, oracle):
+    """Too few generators for a shape, a statement with no values, a proof of the wrong length: that transaction is
+    rejected (InvalidGeneratorsLength / malformed proof in the reference), its neighbours are verified, and the
+    verifier keeps working afterwards (nothing left pending on its contexts)."""
+    from zkvm_amd.verifier import BlockVerifier, BulletproofGens, CloakTx, Verifier
+    fix = load_mixed_fixture()
+    gens = BulletproofGens(ctx, 128, table_bits=8)        # 1x1 needs 64, 2x2 needs 256
+    bv = BlockVerifier(ctx, gens, batches_in_flight=3)
+    try:
+        one = [CloakTx(1, 1, c, p) for c, p in fix[(1, 1)][:5]]
+        two = [CloakTx(2, 2, c, p) for c, p in fix[(2, 2)][:3]]
+        txs = [one[0], two[0], one[1], CloakTx(0, 0, b"", one[2].proof), two[1], CloakTx(1, 1, one[3].commitments, one[3].proof[:-32]),
+               one[4], two[2]]
+        r = hashlib.shake_256(b"bad shapes").digest(64 * len(txs))
+        want = [1, 0, 1, 0, 0, 0, 1, 0]
+        assert [int(oracle.cloak_verify(t.commitments, t.n_in, t.n_out, t.proof, r[64 * i: 64 * i + 64]))
+                for i, t in enumerate(txs) if i in (0, 2, 6)] == [1, 1, 1]
+        for _ in range(3):
+            assert bits(bv.verify(txs, r), len(txs)) == want
+        assert bits(Verifier(ctx, gens).verify_bitmap(txs, r), len(txs)) == want      # the host-prepared path agrees
+    finally:
+        bv.close()
+        gens.close()
+
+
+def test_exchange_step_behind_the_abi(ctx, oracle):
+    """zkgpu_comm over RCCL in a world of one (the 1-GPU box): unique id, communicator, ncclAllGather of raw bytes
+    and of bitmaps, the fail-closed status word, zkgpu_verifier_verify_sharded; and the RCCL-free world of one."""
+    from zkvm_amd import ZkGpuError
+    from zkvm_amd.native import Comm, shard_cuts
+    from zkvm_amd.verifier import BlockVerifier, BulletproofGens
+    for uid in (Comm.unique_id(), None):
+        comm = Comm(ctx, 0, 1, uid)
+        payload = bytes(range(256)) * 5
+        assert comm.allgather(payload) == payload
+        n = 1000
+        bm = hashlib.shake_256(b"bitmap").digest((n + 7) // 8 - 1) + b"\x7f"
+        assert comm.allgather_bitmap([0, n], bm) == bm
+        with pytest.raises(ZkGpuError) as e:
+            comm.allgather_bitmap([0, n], bm, local_status=-3)
+        assert e.value.code == -3
+        comm.close()
+    gens = BulletproofGens(ctx, 256, table_bits=8)
+    bv = BlockVerifier(ctx, gens, batches_in_flight=2)
+    comm = Comm(ctx, 0, 1, Comm.unique_id())
+    try:
+        txs = mixed_block(150, seed=9, bad_every=17)
+        txs = [t for t in txs if (t[0], t[1]) != (4, 4)]          # 256 generators: no 4x4
+        r = hashlib.shake_256(b"sharded").digest(64 * len(txs))
+        want = oracle_block_bits(oracle, txs, r)
+        assert bits(bv.verify_sharded(comm, _cloak(txs), r), len(txs)) == want
+        assert shard_cuts([(t[0], t[1]) for t in txs], 1) == [0, len(txs)]
+    finally:
+        comm.close()
+        bv.close()
+        gens.close()
+
+
+@pytest.mark.parametrize("group", [1, 16])
+def test_device_verifier_head_bytes_equal_oracle(ctx, gens512, oracle, group):
+    """zkgpu_debug_read after a batch: the challenges of the device-side transcript replay (k_transcript) equal
+    the oracle transcript's byte for byte, and every scalar of the verification equation the device prepares
+    (k_prepare) equals the oracle's times the documented factor c' = rho y^(pn-1) prod u_j^2 -- for 1x1, 1x2, 2x2,
+    3x3 and 4x4, transactions checked alone (rho = 1) and in groups (rho = r^2)."""
+    from zkvm_amd.verifier import Verifier
+    fix = load_mixed_fixture()
+    v = Verifier(ctx, gens512)
+    ctx.set_group_size(group)
+    try:
+        for (n_in, n_out), recs in sorted(fix.items()):
+            batch = 5
+            lay = v.plan_layout(n_in, n_out)
+            info = v.plan_info(n_in, n_out)
+            plen, pn, k, n2 = info["proof_len"], info["padded_n"], lay["k"], lay["n_chal2"]
+            r = hashlib.shake_256(b"head %d %d" % (n_in, n_out)).digest(64 * batch)
+            com = b"".join(c for c, _ in recs[:batch])
+            proofs = b"".join(p for _, p in recs[:batch])
+            assert bits(v.verify_packed_gpu(n_in, n_out, batch, com, proofs, plen, r), batch) == [1] * batch
+            ch = ctx.debug_read("challenges", batch * lay["slots"] * 32)
+            st = ctx.debug_read("static_scalars", batch * lay["n_static"] * 32)
+            dy = ctx.debug_read("dyn_scalars", batch * lay["n_dyn"] * 32)
+            for i in range(batch):
+                c_i, p_i, r_i = recs[i][0], recs[i][1], r[64 * i: 64 * i + 64]
+                want_ch = oracle.cloak_verify_challenges(c_i, n_in, n_out, p_i, r_i)
+                assert len(want_ch) == n2 + 5 + k
+
+                def slot(j):
+                    o = (i * lay["slots"] + j) * 32
+                    return int.from_bytes(ch[o: o + 32], "little") * R260_INV % L
+                got_ch = [slot(14 + j) for j in range(n2)] + [slot(j) for j in range(5)] + [slot(14 + n2 + j) for j in range(k)]
+                assert got_ch == want_ch, (n_in, n_out, i)
+                y, uj = want_ch[n2], want_ch[n2 + 5:]
+                rr = int.from_bytes(r_i, "little") % L
+                assert slot(7) == rr
+                rho = rr * rr % L if group > 1 else 1
+                assert slot(13) == rho
+                cp = rho * pow(y, pn - 1, L) % L
+                for u in uj:
+                    cp = cp * u * u % L
+                ds, _, ss, opn = oracle.cloak_verify_prepare(c_i, n_in, n_out, p_i, r_i)
+                assert opn == pn
+                for name, got, want, cnt in (("static", st, ss, lay["n_static"]), ("dyn", dy, ds, lay["n_dyn"])):
+                    assert len(want) == 32 * cnt
+                    for j in range(cnt):
+                        g = int.from_bytes(got[(i * cnt + j) * 32: (i * cnt + j + 1) * 32], "little")
+                        w = int.from_bytes(want[32 * j: 32 * j + 32], "little") * cp % L
+                        assert g == w, (n_in, n_out, i, name, j)
+    finally:
+        ctx.set_group_size(16)
+        v.close()
+
+
+def test_benched_configuration_full_size_vs_oracle(ctx, oracle):
+    """What bench.py times, as a parity test: 16-bit generator tables (25.9 GB), six batches in flight on forked
+    contexts sharing the chip-filling streams, groups of 16, the 1024 DISTINCT golden proofs per batch (every step
+    under fresh verifier randomness and its own corruptions), inputs resident in HBM -- every accept bit of
+    every step against the oracle's full verifier; then one 4096-transaction batch."""
+    from zkvm_amd.verifier import BulletproofGens, Verifier
+    fix, n_in, n_out, plen = load_cloak_fixture()
+    assert len(fix) == 1024 and len({p for _, p in fix}) == 1024
+    gens = BulletproofGens(ctx, 256, table_bits=16)
+    v = Verifier(ctx, gens)
+    lanes = [ctx] + [ctx.fork() for _ in range(5)]
+    ctx.set_group_size(16)
+    w = 64 * (n_in + n_out)
+    try:
+        steps, batch = 12, 1024
+        work = []
+        for s in range(steps):
+            coms, proofs = [], []
+            for i in range(batch):
+                com, proof = fix[(i + 31 * s) % 1024]
+                if (i + s) % 97 == 5:
+                    p = bytearray(proof); p[1 + 32 * (11 + i % 3) + (i % 31)] ^= 1 << (i % 8); proof = bytes(p)
+                if (i + s) % 389 == 11:
+                    cm = bytearray(com); cm[i % w] ^= 0x20; com = bytes(cm)
+                coms.append(com); proofs.append(proof)
+            r = hashlib.shake_256(b"benched %d" % s).digest(64 * batch)
+            want = list(oracle.cloak_verify_batch(b"".join(coms), n_in, n_out, b"".join(proofs), plen, r, threads=16))
+            assert 0 < want.count(0) < batch // 20
+            work.append((ctx.to_device(b"".join(coms)), ctx.to_device(b"".join(proofs)), ctx.to_device(r), want))
+        got = [None] * steps
+        for s in range(steps + len(lanes)):
+            c = lanes[s % len(lanes)]
+            if s >= len(lanes):
+                got[s - len(lanes)] = bits(c.verify_wait(), batch)
+            if s < steps:
+                d_com, d_pr, d_r, _ = work[s]
+                v.submit_packed_gpu_dev(n_in, n_out, batch, d_com, d_pr, plen, d_r, ctx=c)
+        for s in range(steps):
+            assert got[s] == work[s][3], s
+        for d_com, d_pr, d_r, _ in work:
+            for d in (d_com, d_pr, d_r):
+                ctx.free_device(d)
+        big = 4096
+        coms = [fix[(7 * i) % 1024][0] for i in range(big)]
+        proofs = [fix[(7 * i) % 1024][1] for i in range(big)]
+        for i in range(5, big, 211):
+            p = bytearray(proofs[i]); p[-1 - (i % 64)] ^= 1; proofs[i] = bytes(p)
+        r = hashlib.shake_256(b"benched big").digest(64 * big)
+        want = list(oracle.cloak_verify_batch(b"".join(coms), n_in, n_out, b"".join(proofs), plen, r, threads=16))
+        assert bits(v.verify_packed_gpu(n_in, n_out, big, b"".join(coms), b"".join(proofs), plen, r), big) == want
+    finally:
+        v.close()
+        for c in lanes[1:]:
+            c.close()
+        gens.close()
+
+
+def test_msm_2p20_equals_committed_expected_value(ctx):
+    """BASELINE.json configs[2] at full size against tests/golden/msm_2p20.json (the oracle's result, computed in
+    the build container): inputs regenerated from SHAKE256 here, points mapped on the device -- whose 32 MiB of
+    encodings must hash to the digest the oracle's from_uniform_bytes produced."""
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "msm_2p20.json")))
+    n = gold["n"]
+    sc, uniform = msm_2p20_inputs(n)
+    assert hashlib.sha256(sc).hexdigest() == gold["scalars_sha256"]
+    pts = ctx.hash_to_points(uniform)
+    assert hashlib.sha256(pts).hexdigest() == gold["points_sha256"]
+    for m, want in sorted((int(a), b) for a, b in gold["results"].items()):
+        assert ctx.msm(sc[: 32 * m], pts[: 32 * m]).hex() == want, m

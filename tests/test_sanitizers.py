@@ -1,0 +1,80 @@
+"""CPU tier of SURVEY.md sec 5 (race / memory-error detection; GPU AddressSanitizer is not available on the
+pool): the product's host logic (zkvm_amd/csrc/hostlib.cpp -> the same headers libzkgpu.so compiles) and the
+oracle, built with AddressSanitizer + UndefinedBehaviorSanitizer and driven through a proof verification, a
+malformed-proof sweep and the prover in a child process (the sanitizer runtime must be loaded first)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "oracle", "_build")
+
+DRIVER = textwrap.dedent(r"""
+    import ctypes as C, os, sys, struct
+    root, host_so, oracle_so = sys.argv[1:4]
+    host, orc = C.CDLL(host_so), C.CDLL(oracle_so)
+    raw = open(os.path.join(root, "tests", "golden", "cloak_mixed.bin"), "rb").read()
+    pos, fix = 12, {}
+    for _ in range(struct.unpack("<I", raw[8:12])[0]):
+        count, n_in, n_out, plen = struct.unpack("<IIII", raw[pos:pos + 16]); pos += 16
+        w = 64 * (n_in + n_out); recs = []
+        for _ in range(count):
+            recs.append((raw[pos:pos + w], raw[pos + w:pos + w + plen])); pos += w + plen
+        fix[(n_in, n_out)] = recs
+    r = bytes(range(64))
+    def host_prepare(com, n_in, n_out, proof, cap=512):
+        ds, dp = C.create_string_buffer(32 * 128), C.create_string_buffer(32 * 128)
+        ss, si = C.create_string_buffer(32 * (2 + 2 * cap)), (C.c_uint32 * (2 + 2 * cap))()
+        nd, ns, pn = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        return host.zkhost_cloak_prepare(com, C.c_size_t(n_in), C.c_size_t(n_out), proof, C.c_size_t(len(proof)), r,
+                                         C.c_size_t(cap), ds, dp, C.byref(nd), ss, si, C.byref(ns), C.byref(pn))
+    for (n_in, n_out), recs in sorted(fix.items()):
+        com, proof = recs[0]
+        assert host_prepare(com, n_in, n_out, proof) == 0
+        assert orc.zko_cloak_verify(com, C.c_size_t(n_in), C.c_size_t(n_out), proof, C.c_size_t(len(proof)), r) == 1
+        # malformed inputs: every truncation to a multiple of 32 (+1), empty, version byte, oversized
+        for cut in list(range(0, len(proof), 97)) + [1, 33, len(proof) - 32, len(proof) - 1]:
+            bad = proof[:cut]
+            assert host_prepare(com, n_in, n_out, bad) != 0
+            assert orc.zko_cloak_verify(com, C.c_size_t(n_in), C.c_size_t(n_out), bad, C.c_size_t(len(bad)), r) == 0
+        assert host_prepare(com, n_in, n_out, proof + bytes(64)) != 0
+        assert host_prepare(com, n_in, n_out, b"\x07" + proof[1:]) != 0
+        assert host_prepare(com, n_in, n_out, proof, cap=8) != 0
+    # the oracle prover (and the product prover's host half through zkhost, if exported)
+    com = C.create_string_buffer(64 * 2); pr = C.create_string_buffer(4096); plen = C.c_size_t(0)
+    q = (C.c_uint64 * 2)(5, 5); fl = bytes(range(32)) * 2
+    fl = bytes([1] + [0] * 31) * 2
+    assert orc.zko_cloak_prove(q, fl, C.c_size_t(1), C.c_size_t(1), bytes(32), com, pr, C.c_size_t(4096), C.byref(plen), None) == 0
+    assert orc.zko_cloak_verify(com.raw, C.c_size_t(1), C.c_size_t(1), pr.raw[:plen.value], plen, r) == 1
+    out = C.create_string_buffer(32)
+    for op in range(6):
+        assert host.zkhost_scalar_op(op, bytes([255]) * 64, bytes(range(64)), out) == 0
+    print("sanitized run ok")
+""")
+
+
+def _libasan():
+    p = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+@pytest.mark.timeout(600)
+def test_host_logic_and_oracle_under_asan_ubsan(tmp_path):
+    asan = _libasan()
+    if asan is None:
+        pytest.skip("gcc has no libasan here")
+    os.makedirs(OUT, exist_ok=True)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "_build/liboracle_asan.so"], check=True, capture_output=True)
+    host_so = os.path.join(OUT, "libzkhost_asan.so")
+    src = os.path.join(ROOT, "zkvm_amd", "csrc", "hostlib.cpp")
+    deps = [os.path.join(ROOT, "zkvm_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "zkvm_amd", "csrc"))]
+    if not os.path.exists(host_so) or any(os.path.getmtime(d) > os.path.getmtime(host_so) for d in deps):
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fsanitize=address,undefined",
+                        "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-o", host_so, src], check=True)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    p = subprocess.run([sys.executable, "-c", DRIVER, ROOT, host_so, os.path.join(OUT, "liboracle_asan.so")], env=env,
+                       capture_output=True, text=True, timeout=500)
+    assert p.returncode == 0 and "sanitized run ok" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])

@@ -34,6 +34,31 @@ def _batch():
     return sc, pt, offs, want
 
 
+def _worker_failing(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from zkvm_amd.sharded import ShardError, verify_sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    offs = list(range(0, 41, 2))
+
+    def verify_rows(lo, hi):
+        if rank == 1:
+            raise RuntimeError("device fault on rank 1")
+        return bytes([0xFF]) * ((hi - lo + 7) // 8)
+
+    try:
+        verify_sharded(verify_rows, offs, dist)
+        q.put((rank, "returned"))
+    except ShardError as e:
+        q.put((rank, "ShardError"))
+    except RuntimeError as e:
+        q.put((rank, "own error: " + str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -87,3 +112,46 @@ def test_two_rank_gloo_bitmap_equals_single_process():
         p.join(timeout=30)
         assert p.exitcode == 0
     assert got[0] == single and got[1] == single
+
+
+@pytest.mark.timeout(120)
+def test_a_failing_rank_fails_every_rank_and_nobody_hangs():
+    """One rank's verifier raises: it still enters the collective with its error flag, every rank gets an error
+    instead of a verdict (fail-closed), and the ranks stay in step (the barrier afterwards completes)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_failing, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=100) for _ in range(2))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert got[0] == "ShardError" and got[1].startswith("own error: device fault")
+
+
+def test_shard_cuts_of_the_library_equal_the_python_partition():
+    """zkgpu_shard_cuts (behind the C ABI, no GPU needed) = sharded.partition over the same per-transaction costs
+    (terms of the verification MSM of each shape); every transaction in exactly one shard."""
+    import random
+    from zkvm_amd.native import load_library, shard_cuts
+    from zkvm_amd.sharded import partition
+    lib = load_library()
+    terms = {s: int(lib.zkgpu_cloak_msm_terms(*s)) for s in [(1, 1), (1, 2), (2, 2), (3, 3), (4, 4)]}
+    assert terms == {(1, 1): 157, (1, 2): 547, (2, 2): 549, (3, 3): 553, (4, 4): 1071}      # 11 + m + 2k + 2 + 2 pn
+    assert lib.zkgpu_cloak_msm_terms(0, 0) == 0 and lib.zkgpu_cloak_msm_terms(65, 1) == 0
+    rng = random.Random(3)
+    for n in (0, 1, 7, 1000, 8192):
+        shapes = [rng.choice(list(terms)) for _ in range(n)]
+        offs = [0]
+        for s in shapes:
+            offs.append(offs[-1] + terms[s])
+        for world in (1, 2, 3, 8):
+            cuts = shard_cuts(shapes, world)
+            assert cuts[0] == 0 and cuts[-1] == n and all(a <= b for a, b in zip(cuts, cuts[1:]))
+            assert [(cuts[i], cuts[i + 1]) for i in range(world)] == partition(offs, world)
+            if n >= 1000:
+                loads = [offs[cuts[i + 1]] - offs[cuts[i]] for i in range(world)]
+                assert max(loads) - min(loads) <= 2 * 1071

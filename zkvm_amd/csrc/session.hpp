@@ -1,0 +1,480 @@
+// session.hpp -- mixed-arity blocks of transactions and the multi-GPU exchange, behind the C ABI.
+//
+// Included at the end of zkgpu.hip (it uses the pipeline internals of that file).
+//
+//   zkgpu_verifier   mirror of the reference's `Verifier` for whole blocks: owns the contexts that keep
+//                    several batches in flight and one device plan per statement shape.
+//   zkgpu_txblock    a block of transactions of any mix of shapes, grouped by shape and resident in HBM
+//                    (what `Tx::verify` would hand over for every transaction of a block).
+//   zkgpu_comm       one RCCL communicator per process (= per GPU); the only exchange of the sharded
+//                    verification is the all-gather of the per-shard accept bitmaps.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1, the soname torch's bundled copy also carries), so
+// the library loads and every single-GPU entry point works on a machine without it.
+#pragma once
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct zkgpu_verifier {
+  zkgpu_ctx* root = nullptr;
+  const zkgpu_pointset* ps = nullptr;
+  size_t gens_capacity = 0;
+  std::vector<zkgpu_ctx*> lanes;                      // root + forks: one batch in flight on each
+  std::map<std::pair<uint32_t, uint32_t>, zkgpu_cloak_plan*> plans;   // nullptr: the shape cannot be verified here
+  std::map<std::pair<uint32_t, uint32_t>, uint64_t> costs;
+  size_t chunk = 2048;                                // transactions per batch in flight
+  std::mutex mu;
+  std::string last_error;
+};
+
+struct zkgpu_txblock {
+  zkgpu_verifier* v = nullptr;
+  size_t batch = 0;
+  struct Group {
+    uint32_t n_in, n_out;
+    size_t proof_len;
+    zkgpu_cloak_plan* plan;                           // nullptr: every transaction of the group is rejected
+    std::vector<uint32_t> idx;                        // positions in the block, in order
+    size_t com_off, proof_off, r_off;                 // byte offsets into `dev`
+  };
+  std::vector<Group> groups;
+  char* dev = nullptr;                                // one allocation: commitments | proofs | r, group after group
+  size_t dev_bytes = 0;
+};
+
+struct zkgpu_comm {
+  zkgpu_ctx* ctx = nullptr;
+  int rank = 0, world = 1;
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  void* d_send = nullptr; void* d_recv = nullptr; size_t d_cap = 0;
+  void* h_pin = nullptr; size_t h_cap = 0;
+  std::mutex mu;
+  std::string last_error;
+};
+
+namespace {
+
+// ---- RCCL, bound on first use -------------------------------------------------------------
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+  bool ok() const { return handle && GetUniqueId && CommInitRank && AllGather && CommDestroy && GetErrorString; }
+};
+
+RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.handle) break;
+    }
+    if (!api.handle) { api.error = std::string("RCCL not found: ") + dlerror(); return; }
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
+    api.AllGather = (decltype(api.AllGather))dlsym(api.handle, "ncclAllGather");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+    if (!api.ok()) api.error = "RCCL library lacks an expected symbol";
+  });
+  return api;
+}
+
+// number of terms of the verification multiscalar multiplication of one cloak statement: the weight
+// by which a mixed block is balanced over the GPUs (0: not a provable shape)
+uint64_t cloak_msm_terms(uint32_t n_in, uint32_t n_out) {
+  if (n_in + n_out == 0 || n_in > 64 || n_out > 64) return 0;
+  try {
+    const CloakPlan p = PlanBuilder::build(n_in, n_out);
+    return 11ull + p.m + 2ull * p.k + 2 + 2ull * p.pn;
+  } catch (const std::exception&) {
+    return 0;
+  }
+}
+
+// plan of a shape, created on first use; shapes the generator set cannot serve (more multipliers than
+// generators, no values, more than 64 inputs / outputs) map to nullptr: the reference rejects exactly
+// those transactions (InvalidGeneratorsLength / a VM error) and so does the caller, one by one
+zkgpu_cloak_plan* verifier_plan(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out) {
+  const auto key = std::make_pair(n_in, n_out);
+  auto it = v->plans.find(key);
+  if (it != v->plans.end()) return it->second;
+  zkgpu_cloak_plan* p = nullptr;
+  const int rc = zkgpu_cloak_plan_create(v->root, n_in, n_out, v->gens_capacity, &p);
+  if (rc != ZKGPU_OK) p = nullptr;
+  v->plans[key] = p;
+  return p;
+}
+
+int drain(zkgpu_verifier* v, std::vector<uint8_t>& scratch) {
+  int first = ZKGPU_OK;
+  for (zkgpu_ctx* c : v->lanes) {
+    bool pending;
+    size_t nb;
+    { std::lock_guard<std::recursive_mutex> lk(c->mu); pending = c->pending; nb = (c->pending_batch + 7) / 8; }
+    if (!pending) continue;
+    scratch.resize(std::max<size_t>(nb, 1));
+    const int rc = zkgpu_verify_wait(c, scratch.data());
+    if (rc != ZKGPU_OK && first == ZKGPU_OK) first = rc;
+  }
+  return first;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zkgpu_verifier_create(zkgpu_ctx* ctx, const zkgpu_pointset* ps, size_t gens_capacity, int batches_in_flight,
+                          zkgpu_verifier** out) {
+  if (!ctx || !ps || !out || ps->ctx->device != ctx->device || ps->n < 2 + 2 * gens_capacity) return ZKGPU_EINVAL;
+  *out = nullptr;
+  if (batches_in_flight <= 0) batches_in_flight = 6;
+  batches_in_flight = std::min(batches_in_flight, 1 + MAX_FORKS);
+  zkgpu_verifier* v = new zkgpu_verifier();
+  v->root = ctx; v->ps = ps; v->gens_capacity = gens_capacity;
+  v->lanes.push_back(ctx);
+  for (int i = 1; i < batches_in_flight; ++i) {
+    zkgpu_ctx* f = nullptr;
+    if (zkgpu_ctx_fork(ctx, &f) != ZKGPU_OK) break;     // fewer lanes than asked for: still correct
+    v->lanes.push_back(f);
+  }
+  *out = v;
+  return ZKGPU_OK;
+}
+
+void zkgpu_verifier_destroy(zkgpu_verifier* v) {
+  if (!v) return;
+  std::vector<uint8_t> scratch;
+  (void)drain(v, scratch);
+  for (size_t i = 1; i < v->lanes.size(); ++i) zkgpu_destroy(v->lanes[i]);
+  for (auto& kv : v->plans) if (kv.second) zkgpu_cloak_plan_destroy(kv.second);
+  delete v;
+}
+
+int zkgpu_verifier_set_chunk(zkgpu_verifier* v, size_t transactions) {
+  if (!v || transactions == 0 || transactions >= (1u << 24)) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  v->chunk = transactions;
+  return ZKGPU_OK;
+}
+
+int zkgpu_verifier_lanes(const zkgpu_verifier* v) { return v ? (int)v->lanes.size() : 0; }
+
+const char* zkgpu_verifier_last_error(const zkgpu_verifier* v) { return v ? v->last_error.c_str() : ""; }
+
+uint64_t zkgpu_cloak_msm_terms(uint32_t n_in, uint32_t n_out) { return cloak_msm_terms(n_in, n_out); }
+
+void zkgpu_txblock_destroy(zkgpu_txblock* b) {
+  if (!b) return;
+  if (b->dev) { DeviceGuard g(b->v->root->device); (void)hipFree(b->dev); }
+  delete b;
+}
+
+size_t zkgpu_txblock_size(const zkgpu_txblock* b) { return b ? b->batch : 0; }
+size_t zkgpu_txblock_shapes(const zkgpu_txblock* b) { return b ? b->groups.size() : 0; }
+
+int zkgpu_txblock_create(zkgpu_verifier* v, size_t batch, const uint32_t* n_in, const uint32_t* n_out,
+                         const uint8_t* commitments, const uint8_t* proofs, const uint64_t* proof_offsets,
+                         const uint8_t* r_bytes, zkgpu_txblock** out) {
+  if (!v || !out) return ZKGPU_EINVAL;
+  *out = nullptr;
+  if (batch && (!n_in || !n_out || !commitments || !proofs || !proof_offsets)) return ZKGPU_EINVAL;
+  if (batch >= (1ull << 31)) return ZKGPU_EINVAL;
+  for (size_t i = 0; i < batch; ++i) if (proof_offsets[i + 1] < proof_offsets[i]) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  zkgpu_ctx* c = v->root;
+  std::unique_ptr<zkgpu_txblock> b(new zkgpu_txblock());
+  b->v = v; b->batch = batch;
+  // group by (inputs, outputs, proof length): one uniform device batch per group
+  std::map<std::tuple<uint32_t, uint32_t, uint64_t>, size_t> where;
+  std::vector<uint64_t> com_off(batch + 1, 0);
+  for (size_t i = 0; i < batch; ++i) {
+    com_off[i + 1] = com_off[i] + 64ull * ((uint64_t)n_in[i] + n_out[i]);
+    const uint64_t plen = proof_offsets[i + 1] - proof_offsets[i];
+    const auto key = std::make_tuple(n_in[i], n_out[i], plen);
+    auto it = where.find(key);
+    if (it == where.end()) {
+      zkgpu_txblock::Group g;
+      g.n_in = n_in[i]; g.n_out = n_out[i]; g.proof_len = (size_t)plen;
+      g.plan = verifier_plan(v, n_in[i], n_out[i]);
+      if (g.plan && plen != 1 + 4ull * g.plan->shape.proof_words) g.plan = nullptr;   // wrong length for the statement
+      g.com_off = g.proof_off = g.r_off = 0;
+      it = where.emplace(key, b->groups.size()).first;
+      b->groups.push_back(std::move(g));
+    }
+    b->groups[it->second].idx.push_back((uint32_t)i);
+  }
+  // layout in HBM (256-byte aligned pieces), only for the groups that will run
+  size_t total = 0;
+  auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  for (auto& g : b->groups) {
+    if (!g.plan) continue;
+    const size_t n = g.idx.size(), wcom = 64 * ((size_t)g.n_in + g.n_out);
+    g.com_off = total; total = align(total + n * wcom);
+    g.proof_off = total; total = align(total + n * g.proof_len);
+    g.r_off = total; total = align(total + n * 64);
+  }
+  if (total) {
+    DeviceGuard dg(c->device);
+    std::vector<uint8_t> host(total);
+    for (auto& g : b->groups) {
+      if (!g.plan) continue;
+      const size_t wcom = 64 * ((size_t)g.n_in + g.n_out);
+      for (size_t j = 0; j < g.idx.size(); ++j) {
+        const size_t i = g.idx[j];
+        memcpy(&host[g.com_off + j * wcom], commitments + com_off[i], wcom);
+        memcpy(&host[g.proof_off + j * g.proof_len], proofs + proof_offsets[i], g.proof_len);
+        if (r_bytes) memcpy(&host[g.r_off + j * 64], r_bytes + 64 * i, 64);
+      }
+      if (!r_bytes && !os_random(&host[g.r_off], g.idx.size() * 64)) { v->last_error = "getrandom failed"; return ZKGPU_EINVAL; }
+    }
+    hipError_t e = hipMalloc((void**)&b->dev, total);
+    if (e != hipSuccess) { v->last_error = std::string("hipMalloc: ") + hipGetErrorString(e); b->dev = nullptr; return ZKGPU_ENOMEM; }
+    b->dev_bytes = total;
+    e = hipMemcpy(b->dev, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { v->last_error = hipGetErrorString(e); (void)hipFree(b->dev); b->dev = nullptr; return ZKGPU_EHIP; }
+  }
+  *out = b.release();
+  return ZKGPU_OK;
+}
+
+// Verifies every transaction of a resident block: the groups are cut into batches of at most `chunk`
+// transactions, which go round the verifier's lanes (one batch in flight on each); bit i of
+// accept_bitmap is the verdict of transaction i of the block.  Any device error: all bits zero.
+int zkgpu_verifier_verify_block(zkgpu_verifier* v, const zkgpu_txblock* b, uint8_t* accept_bitmap) {
+  if (!v || !b || b->v != v || !accept_bitmap) return ZKGPU_EINVAL;
+  const size_t nbytes = (b->batch + 7) / 8;
+  memset(accept_bitmap, 0, nbytes);
+  std::lock_guard<std::mutex> lk(v->mu);
+  struct InFlight { const zkgpu_txblock::Group* g; size_t off, n; };
+  std::vector<InFlight> on_lane(v->lanes.size(), InFlight{nullptr, 0, 0});
+  std::vector<uint8_t> bm;
+  int rc = ZKGPU_OK;
+  auto collect = [&](size_t lane) -> int {
+    InFlight& f = on_lane[lane];
+    if (!f.g) return ZKGPU_OK;
+    bm.assign((f.n + 7) / 8, 0);
+    const int r = zkgpu_verify_wait(v->lanes[lane], bm.data());
+    if (r == ZKGPU_OK)
+      for (size_t j = 0; j < f.n; ++j)
+        if ((bm[j / 8] >> (j % 8)) & 1) { const uint32_t i = f.g->idx[f.off + j]; accept_bitmap[i / 8] |= (uint8_t)(1u << (i % 8)); }
+    f.g = nullptr;
+    return r;
+  };
+  size_t turn = 0;
+  for (const auto& g : b->groups) {
+    if (!g.plan || rc != ZKGPU_OK) continue;
+    const size_t wcom = 64 * ((size_t)g.n_in + g.n_out);
+    for (size_t off = 0; off < g.idx.size() && rc == ZKGPU_OK; off += v->chunk) {
+      const size_t n = std::min(v->chunk, g.idx.size() - off);
+      const size_t lane = turn++ % v->lanes.size();
+      rc = collect(lane);
+      if (rc != ZKGPU_OK) break;
+      rc = zkgpu_cloak_verify_submit_dev(v->lanes[lane], v->ps, g.plan, n, b->dev + g.com_off + off * wcom,
+                                         b->dev + g.proof_off + off * g.proof_len, g.proof_len, b->dev + g.r_off + off * 64);
+      if (rc == ZKGPU_OK) on_lane[lane] = InFlight{&g, off, n};
+      else v->last_error = zkgpu_last_error(v->lanes[lane]);
+    }
+  }
+  for (size_t lane = 0; lane < v->lanes.size(); ++lane) {
+    const int r = collect(lane);          // always drains: no lane is left pending after an error
+    if (r != ZKGPU_OK && rc == ZKGPU_OK) { rc = r; v->last_error = zkgpu_last_error(v->lanes[lane]); }
+  }
+  if (rc != ZKGPU_OK) memset(accept_bitmap, 0, nbytes);
+  return rc;
+}
+
+// Host-memory form: block -> HBM -> verdicts (PCIe copies included).
+int zkgpu_verifier_verify(zkgpu_verifier* v, size_t batch, const uint32_t* n_in, const uint32_t* n_out,
+                          const uint8_t* commitments, const uint8_t* proofs, const uint64_t* proof_offsets,
+                          const uint8_t* r_bytes, uint8_t* accept_bitmap) {
+  if (!v || !accept_bitmap) return ZKGPU_EINVAL;
+  memset(accept_bitmap, 0, (batch + 7) / 8);
+  if (batch == 0) return ZKGPU_OK;
+  zkgpu_txblock* b = nullptr;
+  TRY(zkgpu_txblock_create(v, batch, n_in, n_out, commitments, proofs, proof_offsets, r_bytes, &b));
+  const int rc = zkgpu_verifier_verify_block(v, b, accept_bitmap);
+  zkgpu_txblock_destroy(b);
+  return rc;
+}
+
+// ---- sharding over the GPUs of a node --------------------------------------------------------
+// cuts[0] = 0 <= cuts[1] <= ... <= cuts[world] = batch: rank r verifies transactions
+// [cuts[r], cuts[r+1]).  Contiguous, balanced by the number of multiscalar-multiplication terms.
+int zkgpu_shard_cuts(size_t batch, const uint32_t* n_in, const uint32_t* n_out, int world, uint64_t* cuts) {
+  if (world <= 0 || !cuts || (batch && (!n_in || !n_out))) return ZKGPU_EINVAL;
+  std::map<std::pair<uint32_t, uint32_t>, uint64_t> cost;
+  std::vector<uint64_t> prefix(batch + 1, 0);
+  for (size_t i = 0; i < batch; ++i) {
+    const auto key = std::make_pair(n_in[i], n_out[i]);
+    auto it = cost.find(key);
+    if (it == cost.end()) it = cost.emplace(key, std::max<uint64_t>(1, cloak_msm_terms(n_in[i], n_out[i]))).first;
+    prefix[i + 1] = prefix[i] + it->second;
+  }
+  const uint64_t total = prefix[batch];
+  cuts[0] = 0;
+  size_t row = 0;
+  for (int r = 1; r < world; ++r) {
+    // 128-bit product: total * r overflows 64 bits only beyond 2^57 terms
+    const uint64_t target = (uint64_t)(((unsigned __int128)total * (unsigned)r) / (unsigned)world);
+    while (row < batch && prefix[row + 1] <= target) ++row;
+    cuts[r] = row;
+  }
+  cuts[world] = batch;
+  return ZKGPU_OK;
+}
+
+int zkgpu_comm_unique_id(uint8_t id[ZKGPU_COMM_ID_BYTES]) {
+  if (!id) return ZKGPU_EINVAL;
+  static_assert(sizeof(ncclUniqueId) == ZKGPU_COMM_ID_BYTES, "unique id size");
+  RcclApi& api = rccl();
+  if (!api.ok()) return ZKGPU_ENOCOMM;
+  ncclUniqueId uid;
+  if (api.GetUniqueId(&uid) != ncclSuccess) return ZKGPU_ENOCOMM;
+  memcpy(id, &uid, sizeof uid);
+  return ZKGPU_OK;
+}
+
+int zkgpu_comm_create(zkgpu_ctx* ctx, int rank, int world, const uint8_t id[ZKGPU_COMM_ID_BYTES], zkgpu_comm** out) {
+  if (!ctx || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) return ZKGPU_EINVAL;
+  *out = nullptr;
+  std::unique_ptr<zkgpu_comm> cm(new zkgpu_comm());
+  cm->ctx = ctx; cm->rank = rank; cm->world = world;
+  if (world > 1 || id) {
+    RcclApi& api = rccl();
+    if (!api.ok()) { ctx->last_error = api.error; return ZKGPU_ENOCOMM; }
+    DeviceGuard g(ctx->device);
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking));
+    const ncclResult_t r = api.CommInitRank(&cm->comm, world, uid, rank);
+    if (r != ncclSuccess) {
+      ctx->last_error = std::string("ncclCommInitRank: ") + api.GetErrorString(r);
+      (void)hipStreamDestroy(cm->stream);
+      return ZKGPU_ENOCOMM;
+    }
+  }
+  *out = cm.release();
+  return ZKGPU_OK;
+}
+
+void zkgpu_comm_destroy(zkgpu_comm* cm) {
+  if (!cm) return;
+  DeviceGuard g(cm->ctx->device);
+  if (cm->comm) (void)rccl().CommDestroy(cm->comm);
+  if (cm->stream) (void)hipStreamDestroy(cm->stream);
+  if (cm->d_send) (void)hipFree(cm->d_send);
+  if (cm->d_recv) (void)hipFree(cm->d_recv);
+  if (cm->h_pin) (void)hipHostFree(cm->h_pin);
+  delete cm;
+}
+
+int zkgpu_comm_rank(const zkgpu_comm* cm) { return cm ? cm->rank : -1; }
+int zkgpu_comm_world(const zkgpu_comm* cm) { return cm ? cm->world : 0; }
+
+// Every rank contributes `bytes` bytes; `all` receives world * bytes (rank-major), in host memory.
+int zkgpu_comm_allgather(zkgpu_comm* cm, const uint8_t* local, size_t bytes, uint8_t* all) {
+  if (!cm || !all || (bytes && !local)) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(cm->mu);
+  if (bytes == 0) return ZKGPU_OK;
+  if (!cm->comm) {                      // a world of one without RCCL
+    if (cm->world != 1) return ZKGPU_ENOCOMM;
+    memmove(all, local, bytes);
+    return ZKGPU_OK;
+  }
+  zkgpu_ctx* c = cm->ctx;
+  DeviceGuard g(c->device);
+  const size_t total = bytes * (size_t)cm->world;
+  if (cm->d_cap < total) {
+    if (cm->d_send) { (void)hipFree(cm->d_send); (void)hipFree(cm->d_recv); (void)hipHostFree(cm->h_pin); }
+    cm->d_send = cm->d_recv = cm->h_pin = nullptr; cm->d_cap = 0;
+    const size_t cap = std::max<size_t>(2 * total, 4096);
+    HIP_TRY(c, hipMalloc(&cm->d_send, cap));
+    HIP_TRY(c, hipMalloc(&cm->d_recv, cap));
+    HIP_TRY(c, hipHostMalloc(&cm->h_pin, 2 * cap, hipHostMallocDefault));
+    cm->d_cap = cap;
+  }
+  char* h = (char*)cm->h_pin;
+  memcpy(h, local, bytes);
+  HIP_TRY(c, hipMemcpyAsync(cm->d_send, h, bytes, hipMemcpyHostToDevice, cm->stream));
+  const ncclResult_t r = rccl().AllGather(cm->d_send, cm->d_recv, bytes, ncclUint8, cm->comm, cm->stream);
+  if (r != ncclSuccess) { c->last_error = std::string("ncclAllGather: ") + rccl().GetErrorString(r); return ZKGPU_ENOCOMM; }
+  HIP_TRY(c, hipMemcpyAsync(h + cm->d_cap, cm->d_recv, total, hipMemcpyDeviceToHost, cm->stream));
+  HIP_TRY(c, hipStreamSynchronize(cm->stream));
+  memcpy(all, h + cm->d_cap, total);
+  return ZKGPU_OK;
+}
+
+// The exchange step of the sharded verification: rank r holds the accept bitmap of transactions
+// [cuts[r], cuts[r+1]) (bit 0 = transaction cuts[r]) and the status of its own verification; every rank
+// receives the bitmap of the whole batch.  If ANY rank reports an error every rank returns an error
+// and an all-zero bitmap: one GPU's fault never turns into an accept, and never into a hang.
+int zkgpu_comm_allgather_bitmap(zkgpu_comm* cm, const uint64_t* cuts, const uint8_t* local_bitmap, int local_status,
+                                uint8_t* whole_bitmap) {
+  if (!cm || !cuts || !whole_bitmap) return ZKGPU_EINVAL;
+  const int world = cm->world;
+  const uint64_t batch = cuts[world];
+  memset(whole_bitmap, 0, (size_t)((batch + 7) / 8));
+  size_t width = 0;
+  for (int r = 0; r < world; ++r) {
+    if (cuts[r + 1] < cuts[r]) return ZKGPU_EINVAL;
+    width = std::max<size_t>(width, (size_t)((cuts[r + 1] - cuts[r] + 7) / 8));
+  }
+  const size_t slot = 8 + ((width + 7) & ~(size_t)7);      // status word, then the bitmap
+  std::vector<uint8_t> mine(slot, 0), all(slot * (size_t)world, 0);
+  const uint64_t mine_n = cuts[cm->rank + 1] - cuts[cm->rank];
+  const int32_t st = local_status;
+  memcpy(mine.data(), &st, 4);
+  if (local_status == ZKGPU_OK && mine_n) {
+    if (!local_bitmap) return ZKGPU_EINVAL;
+    memcpy(mine.data() + 8, local_bitmap, (size_t)((mine_n + 7) / 8));
+  }
+  TRY(zkgpu_comm_allgather(cm, mine.data(), slot, all.data()));
+  int rc = ZKGPU_OK;
+  for (int r = 0; r < world; ++r) {
+    int32_t s;
+    memcpy(&s, &all[slot * (size_t)r], 4);
+    if (s != ZKGPU_OK && rc == ZKGPU_OK) rc = (r == cm->rank) ? s : ZKGPU_EREMOTE;
+  }
+  if (rc != ZKGPU_OK) return rc;
+  for (int r = 0; r < world; ++r) {
+    const uint8_t* bmr = &all[slot * (size_t)r + 8];
+    for (uint64_t j = 0, i = cuts[r]; i < cuts[r + 1]; ++j, ++i)
+      if ((bmr[j / 8] >> (j % 8)) & 1) whole_bitmap[i / 8] |= (uint8_t)(1u << (i % 8));
+  }
+  return ZKGPU_OK;
+}
+
+// Whole batch in host memory on every rank (a block of transactions as every node of the network
+// sees it) -> this rank verifies its shard, the verdicts of all shards are gathered over RCCL.
+int zkgpu_verifier_verify_sharded(zkgpu_verifier* v, zkgpu_comm* cm, size_t batch, const uint32_t* n_in,
+                                  const uint32_t* n_out, const uint8_t* commitments, const uint8_t* proofs,
+                                  const uint64_t* proof_offsets, const uint8_t* r_bytes, uint8_t* accept_bitmap) {
+  if (!v || !cm || !accept_bitmap) return ZKGPU_EINVAL;
+  memset(accept_bitmap, 0, (batch + 7) / 8);
+  if (batch == 0) return ZKGPU_OK;
+  if (!n_in || !n_out || !commitments || !proofs || !proof_offsets) return ZKGPU_EINVAL;
+  std::vector<uint64_t> cuts((size_t)cm->world + 1);
+  TRY(zkgpu_shard_cuts(batch, n_in, n_out, cm->world, cuts.data()));
+  const size_t lo = (size_t)cuts[cm->rank], hi = (size_t)cuts[cm->rank + 1];
+  std::vector<uint8_t> local((hi - lo + 7) / 8 + 1, 0);
+  int rc = ZKGPU_OK;
+  if (hi > lo) {
+    uint64_t com_lo = 0;
+    for (size_t i = 0; i < lo; ++i) com_lo += 64ull * ((uint64_t)n_in[i] + n_out[i]);
+    std::vector<uint64_t> po(hi - lo + 1);
+    for (size_t i = lo; i <= hi; ++i) po[i - lo] = proof_offsets[i] - proof_offsets[lo];
+    rc = zkgpu_verifier_verify(v, hi - lo, n_in + lo, n_out + lo, commitments + com_lo, proofs + proof_offsets[lo],
+                               po.data(), r_bytes ? r_bytes + 64 * lo : nullptr, local.data());
+  }
+  return zkgpu_comm_allgather_bitmap(cm, cuts.data(), local.data(), rc, accept_bitmap);
+}
+
+}  // extern "C"

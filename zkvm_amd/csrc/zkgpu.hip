@@ -13,13 +13,16 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
 #include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
-#include <random>
+#include <map>
+#include <atomic>
+#include <sys/random.h>
 #include <thread>
 #include <vector>
 
@@ -65,11 +68,13 @@ struct zkgpu_ctx {
   // the contexts forked from this one (zkgpu_ctx_fork), so that those run first-in first-out
   hipStream_t stream_l = nullptr;
   hipStream_t stream3 = nullptr;        // shared like stream/stream2: the scalar preparation (k_prepare)
-  // a parent keeps ZKGPU_LANES (default 2) sets of the three shared streams; fork i uses set i mod lanes:
+  // a parent keeps STREAM_SETS (2) sets of the three shared streams; fork i uses set i mod 2:
   // consecutive batches alternate between the sets, so the latency-bound chains of two neighbours
   // overlap while each set still runs its batches first-in first-out
   std::vector<hipStream_t> lane_streams;   // owned by the parent: sets 1.. (set 0 = stream, stream2, stream3)
-  int n_forks = 0;
+  int n_forks = 0;                      // live forks (each holds a hardware queue)
+  unsigned fork_seq = 0;                // forks ever made: consecutive ones alternate between the stream sets
+  zkgpu_ctx* parent = nullptr;
   bool owns_streams = true;
   hipEvent_t ev_t = nullptr, ev_p = nullptr, ev_sm = nullptr, ev_sa = nullptr, ev_done = nullptr;
   bool pending = false;            // a submitted batch has not been waited for yet
@@ -142,6 +147,19 @@ int ensure_pinned(zkgpu_ctx* c, size_t bytes) {
 
 #define TRY(expr) do { int rc__ = (expr); if (rc__ != ZKGPU_OK) return rc__; } while (0)
 
+// Verifier randomness (the weight r of each proof's two equation halves and of a transaction inside
+// a group check is the soundness parameter): from the kernel's CSPRNG, getrandom(2).  false = no
+// randomness available: the caller fails closed.
+bool os_random(void* out, size_t n) {
+  uint8_t* p = (uint8_t*)out;
+  while (n) {
+    const ssize_t got = getrandom(p, n, 0);
+    if (got < 0) { if (errno == EINTR) continue; return false; }
+    p += got; n -= (size_t)got;
+  }
+  return true;
+}
+
 int prof_index(zkgpu_ctx* c, const char* name) {
   for (size_t i = 0; i < c->prof.size(); ++i) if (strcmp(c->prof[i].name, name) == 0) return (int)i;
   c->prof.push_back({name, 0, 0.0});
@@ -197,15 +215,18 @@ void prof_collect(zkgpu_ctx* c) {
   c->ev_next = 0;
 }
 
-// wavefronts per MSM in k_small_accumulate: about three per SIMD (1024 SIMDs) over the whole launch;
-// ZKGPU_SMALL_PARTS overrides for experiments
+// wavefronts per MSM in k_small_accumulate: about three per SIMD (1024 SIMDs) over the whole launch
 inline int small_parts(uint64_t B) {
-  static const int forced = [] { const char* e = getenv("ZKGPU_SMALL_PARTS"); return e ? atoi(e) : 0; }();
-  if (forced >= 1 && forced <= 4) return forced;
   return (int)std::max<uint64_t>(1, std::min<uint64_t>(4, (3072 + B / 2) / std::max<uint64_t>(B, 1)));
 }
 
 inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+// sets of shared chip-filling streams per parent context (consecutive forks alternate between them) and the
+// fork limit that keeps the process under the ~22 hardware queues the runtime hands out before it
+// multiplexes them in software (measured: 100-200 ms per step beyond that)
+constexpr int STREAM_SETS = 2;
+constexpr int MAX_FORKS = 9;
 
 // window width minimising  W * (terms + 2 * 2^(w-1) * msms)  point additions
 int choose_window(uint64_t n_terms, uint32_t n_msm) {
@@ -737,25 +758,11 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     // tables on the shared stream while the transcript is replayed
     HIP_TRY(c, hipEventRecord(c->ev_u, L));
     HIP_TRY(c, hipStreamWaitEvent(H1, c->ev_u, 0));
-    static const bool fuse_points = [] { const char* e = getenv("ZKGPU_FUSE_POINTS"); return e ? atoi(e) != 0 : true; }();
-    if (fuse_points) {
+    {
       Launch l(c, "k_points_tables", H1);
       hipLaunchKernelGGL(k_points_tables, dim3(blocks_for((uint64_t)B * sh.n_dyn, 256)), dim3(256), 0, H1, sh,
                          prep->d_com, (const uint32_t*)c->prep_pw.p, (uint32_t)B, (uint32_t*)c->small_tbl.p,
                          (uint32_t*)c->msm_fail.p, (unsigned long long*)((char*)c->status.p + 8));
-    } else {
-      {
-        Launch l(c, "k_gather_dyn_points", H1);
-        hipLaunchKernelGGL(k_gather_dyn_points, dim3(blocks_for((uint64_t)B * sh.n_dyn * 8, 256)), dim3(256), 0, H1, sh,
-                           prep->d_com, (const uint32_t*)c->prep_pw.p, (uint32_t)B, (uint32_t*)c->prep_dyn_pt.p);
-      }
-      {
-        Launch l(c, "k_decompress", H1);
-        hipLaunchKernelGGL(k_decompress, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, H1, job.d_dyn_points,
-                           (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, (uint32_t)B, (uint32_t*)c->msm_fail.p,
-                           (unsigned long long*)((char*)c->status.p + 8), (uint8_t*)nullptr);
-      }
-      TRY(small_tables_launch(c, nullptr, job.n_dyn, H1));
     }
     {
       Launch l(c, "k_transcript", L);
@@ -933,7 +940,7 @@ struct DeviceGuard {
 // =============================== C ABI =========================================
 extern "C" {
 
-int zkgpu_abi_version(void) { return 1; }
+int zkgpu_abi_version(void) { return 2; }
 
 const char* zkgpu_strerror(int code) {
   switch (code) {
@@ -943,6 +950,8 @@ const char* zkgpu_strerror(int code) {
     case ZKGPU_EHIP: return "HIP runtime error";
     case ZKGPU_ENOMEM: return "out of device memory";
     case ZKGPU_ENODEVICE: return "no usable HIP device";
+    case ZKGPU_ENOCOMM: return "RCCL unavailable or a collective failed";
+    case ZKGPU_EREMOTE: return "another rank of the sharded verification failed";
     default: return "unknown error";
   }
 }
@@ -959,8 +968,10 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   bool ok = true;
   if (parent) {
-    static const int lanes = [] { const char* e = getenv("ZKGPU_LANES"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
-    const int set = (++parent->n_forks) % lanes;
+    constexpr int lanes = STREAM_SETS;
+    ++parent->n_forks;
+    const int set = (int)(++parent->fork_seq % lanes);
+    c->parent = parent;
     while (ok && (int)parent->lane_streams.size() < 3 * (lanes - 1)) {
       hipStream_t st = nullptr;
       const int which = (int)parent->lane_streams.size() % 3;
@@ -983,15 +994,10 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
          hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
          hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   }
-  {
-    int lp = prio_greatest;
-    if (const char* e = getenv("ZKGPU_L_PRIO")) lp = atoi(e);
-    ok = ok && hipStreamCreateWithPriority(&c->stream_l, hipStreamNonBlocking, lp) == hipSuccess;
-    if (getenv("ZKGPU_L_PRIO")) fprintf(stderr, "prio range least=%d greatest=%d L=%d\n", prio_least, prio_greatest, lp);
-  }
+  ok = ok && hipStreamCreateWithPriority(&c->stream_l, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   hipEvent_t* evs[] = {&c->ev_fork, &c->ev_join, &c->ev_t, &c->ev_p, &c->ev_sm, &c->ev_sa, &c->ev_done, &c->ev_dig, &c->ev_u};
   for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-  if (!ok) { delete c; return ZKGPU_EHIP; }
+  if (!ok) { if (parent) --parent->n_forks; delete c; return ZKGPU_EHIP; }
   *out = c;
   return ZKGPU_OK;
 }
@@ -1043,15 +1049,10 @@ int zkgpu_ctx_fork(zkgpu_ctx* parent, zkgpu_ctx** out) {
   // every fork holds a hardware queue for its light stream, every set of shared streams three more;
   // past ~22 queues per process the runtime multiplexes them in software and streams that wait on
   // each other's events crawl (measured: 200 ms per step instead of 0.7)
-  {
-    const char* e = getenv("ZKGPU_LANES");
-    int lanes = e ? atoi(e) : 2;
-    lanes = lanes < 1 ? 1 : (lanes > 4 ? 4 : lanes);
-    const int max_forks = std::min(9, 19 - 3 * lanes);
-    if (parent->n_forks >= max_forks) {
-      parent->last_error = "too many forks of one context (each batch in flight holds a hardware queue)";
-      return ZKGPU_EINVAL;
-    }
+  std::lock_guard<std::recursive_mutex> lk(parent->mu);      // n_forks and the lane streams belong to the parent
+  if (parent->n_forks >= MAX_FORKS) {
+    parent->last_error = "too many forks of one context (each batch in flight holds a hardware queue)";
+    return ZKGPU_EINVAL;
   }
   DeviceGuard g(parent->device);
   return ctx_create(parent->device, parent, out);
@@ -1083,6 +1084,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
   if (c->stream_l) (void)hipStreamDestroy(c->stream_l);
   hipEvent_t evs[] = {c->ev_fork, c->ev_join, c->ev_t, c->ev_p, c->ev_sm, c->ev_sa, c->ev_done, c->ev_dig, c->ev_u};
   for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+  if (c->parent) { std::lock_guard<std::recursive_mutex> lk(c->parent->mu); --c->parent->n_forks; }
   delete c;
 }
 
@@ -1509,8 +1511,7 @@ int prepare_cloak_batch(size_t gens_capacity, size_t batch, const uint32_t* n_in
   std::vector<uint8_t> rnd;
   if (!r_bytes) {
     rnd.resize(64 * batch);
-    std::random_device rd;
-    for (size_t i = 0; i < rnd.size(); i += 4) { uint32_t v = rd(); memcpy(&rnd[i], &v, 4); }
+    if (!os_random(rnd.data(), rnd.size())) return ZKGPU_EINVAL;
     r_bytes = rnd.data();
   }
   const int nt = std::max(1, std::min<int>(host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency(), 256));
@@ -1584,10 +1585,14 @@ struct zkgpu_cloak_plan {
            *d_term_mono = nullptr, *d_term_coef = nullptr;
   uint32_t* d_tape = nullptr;     // transcript_tape.hpp, four words per operation
   uint32_t n_ops = 0;
-  // per-batch-size cached CSR scaffolding
+  // CSR scaffolding of a uniform batch (offsets, generator index template) for the largest batch seen so
+  // far; a prefix of it serves every smaller batch.  It only grows: a larger one is built beside the old
+  // one, which batches in flight on other contexts may still be reading and which is therefore kept
+  // until the plan is destroyed (`retired`).  Read the three pointers under `mu`.
   size_t cached_batch = 0;
   uint64_t *d_dyn_off = nullptr, *d_st_off = nullptr;
   uint32_t* d_st_index = nullptr;
+  std::vector<void*> retired;
   size_t lds_bytes = 0;
 };
 
@@ -1678,6 +1683,7 @@ void zkgpu_cloak_plan_destroy(zkgpu_cloak_plan* p) {
   void* ptrs[] = {p->d_tape, p->d_init, p->d_mono_chal, p->d_mono_pow, p->d_tgt_off, p->d_term_q, p->d_term_mono,
                   p->d_term_coef, p->d_dyn_off, p->d_st_off, p->d_st_index};
   for (void* q : ptrs) if (q) (void)hipFree(q);
+  for (void* q : p->retired) (void)hipFree(q);
   delete p;
 }
 
@@ -1689,6 +1695,17 @@ int zkgpu_cloak_plan_info(const zkgpu_cloak_plan* p, uint32_t* multipliers, uint
   if (constraints) *constraints = p->host.n_cons;
   if (terms) *terms = (uint32_t)p->host.term_q.size();
   if (proof_len) *proof_len = 1 + 32 * (16 + 2 * p->host.k);
+  return ZKGPU_OK;
+}
+
+// Buffer layout of the device-side preparation for this plan (what zkgpu_debug_read returns):
+// out[0] slots per transaction in "challenges", [1] challenge slots proper, [2] second-phase challenges,
+// [3] dynamic terms, [4] static terms, [5] k, [6] commitments m, [7] monomials.
+int zkgpu_cloak_plan_layout(const zkgpu_cloak_plan* p, uint32_t out[8]) {
+  if (!p || !out) return ZKGPU_EINVAL;
+  const PrepShape& s = p->shape;
+  out[0] = s.n_ch_ext; out[1] = s.n_ch; out[2] = s.n_chal2; out[3] = s.n_dyn; out[4] = s.n_static; out[5] = s.k;
+  out[6] = s.m; out[7] = s.n_mono;
   return ZKGPU_OK;
 }
 
@@ -1722,9 +1739,9 @@ int stage_inputs(zkgpu_ctx* c, const PrepShape& sh, size_t batch, const uint8_t*
   memcpy(h + o_pr, proofs, n_pr);
   if (r_bytes) {
     memcpy(h + o_r, r_bytes, n_r);
-  } else {             // verifier randomness from the OS
-    std::random_device rd;
-    for (size_t i = 0; i < n_r; i += 4) { uint32_t v = rd(); memcpy(h + o_r + i, &v, 4); }
+  } else if (!os_random(h + o_r, n_r)) {   // verifier randomness from the OS
+    c->last_error = "getrandom failed";
+    return ZKGPU_EINVAL;
   }
   TRY(ensure(c, c->prep_com, std::max<size_t>(n_com, 16)));
   TRY(ensure(c, c->prep_proofs, std::max<size_t>(n_pr, 16)));
@@ -1802,37 +1819,45 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
   TRY(ensure(c, c->prep_dyn_sc, (size_t)B * sh.n_dyn * 32));
   TRY(ensure(c, c->prep_dyn_pt, (size_t)B * sh.n_dyn * 32));
   TRY(ensure(c, c->prep_st_sc, (size_t)B * sh.n_static * 32));
+  const uint64_t *d_dyn_off, *d_st_off;
+  const uint32_t* d_st_index;
   {
     std::lock_guard<std::mutex> plk(plan->mu);
-    if (plan->cached_batch < batch) {   // CSR scaffolding of a uniform batch: offsets and the generator index template
-      // (a prefix of a larger scaffolding serves every smaller batch; contexts in flight may still be
-      // reading the old one, so drain the device before it is replaced)
-      HIP_TRY(c, hipDeviceSynchronize());
-      if (plan->d_dyn_off) { (void)hipFree(plan->d_dyn_off); (void)hipFree(plan->d_st_off); (void)hipFree(plan->d_st_index); }
-      plan->d_dyn_off = nullptr; plan->d_st_off = nullptr; plan->d_st_index = nullptr;
-      plan->cached_batch = 0;
-      std::vector<uint64_t> doff(batch + 1), soff(batch + 1);
-      for (size_t i = 0; i <= batch; ++i) { doff[i] = i * sh.n_dyn; soff[i] = i * sh.n_static; }
-      std::vector<uint32_t> idx((size_t)batch * sh.n_static);
-      for (size_t i = 0; i < batch; ++i) {
+    if (plan->cached_batch < batch) {
+      const size_t nb = std::max(batch, 2 * plan->cached_batch);
+      std::vector<uint64_t> doff(nb + 1), soff(nb + 1);
+      for (size_t i = 0; i <= nb; ++i) { doff[i] = i * sh.n_dyn; soff[i] = i * sh.n_static; }
+      std::vector<uint32_t> idx((size_t)nb * sh.n_static);
+      for (size_t i = 0; i < nb; ++i) {
         uint32_t* row = &idx[i * sh.n_static];
         row[0] = 0; row[1] = 1;
         for (uint32_t j = 0; j < sh.pn; ++j) { row[2 + j] = 2 + j; row[2 + sh.pn + j] = (uint32_t)(2 + plan->gens_capacity + j); }
       }
-      TRY(plan_upload(c, &plan->d_dyn_off, doff));
-      TRY(plan_upload(c, &plan->d_st_off, soff));
-      TRY(plan_upload(c, &plan->d_st_index, idx));
-      plan->cached_batch = batch;
+      uint64_t *nd = nullptr, *ns = nullptr;
+      uint32_t* ni = nullptr;
+      int rc = plan_upload(c, &nd, doff);
+      if (rc == ZKGPU_OK) rc = plan_upload(c, &ns, soff);
+      if (rc == ZKGPU_OK) rc = plan_upload(c, &ni, idx);
+      if (rc != ZKGPU_OK) {
+        if (nd) (void)hipFree(nd);
+        if (ns) (void)hipFree(ns);
+        if (ni) (void)hipFree(ni);
+        return rc;
+      }
+      if (plan->d_dyn_off) { plan->retired.push_back(plan->d_dyn_off); plan->retired.push_back(plan->d_st_off); plan->retired.push_back(plan->d_st_index); }
+      plan->d_dyn_off = nd; plan->d_st_off = ns; plan->d_st_index = ni;
+      plan->cached_batch = nb;
     }
+    d_dyn_off = plan->d_dyn_off; d_st_off = plan->d_st_off; d_st_index = plan->d_st_index;
   }
   Job job;
   job.d_dyn_scalars = (const uint32_t*)c->prep_dyn_sc.p;
   job.d_dyn_points = (const uint32_t*)c->prep_dyn_pt.p;
-  job.d_dyn_offsets = plan->d_dyn_off;
+  job.d_dyn_offsets = d_dyn_off;
   job.n_dyn = (uint64_t)B * sh.n_dyn;
   job.d_st_scalars = (const uint32_t*)c->prep_st_sc.p;
-  job.d_st_index = plan->d_st_index;
-  job.d_st_offsets = plan->d_st_off;
+  job.d_st_index = d_st_index;
+  job.d_st_offsets = d_st_off;
   job.n_static = (uint64_t)B * sh.n_static;
   job.d_static_rows = ps->rows;
   job.n_msm = B;
@@ -2087,3 +2112,5 @@ int zkgpu_set_window_bits(zkgpu_ctx* c, int w) {
 }
 
 }  // extern "C"
+
+#include "session.hpp"

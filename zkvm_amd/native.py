@@ -108,6 +108,38 @@ def load_library():
     lib.zkgpu_last_bucket_adds.argtypes = [vp]
     lib.zkgpu_last_bucket_adds.restype = C.c_uint64
     lib.zkgpu_set_window_bits.argtypes = [vp, C.c_int]
+    u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    lib.zkgpu_verifier_create.argtypes = [vp, vp, sz, C.c_int, C.POINTER(vp)]
+    lib.zkgpu_verifier_destroy.argtypes = [vp]
+    lib.zkgpu_verifier_destroy.restype = None
+    lib.zkgpu_verifier_set_chunk.argtypes = [vp, sz]
+    lib.zkgpu_verifier_lanes.argtypes = [vp]
+    lib.zkgpu_verifier_last_error.argtypes = [vp]
+    lib.zkgpu_verifier_last_error.restype = C.c_char_p
+    lib.zkgpu_verifier_verify.argtypes = [vp, sz, u32p, u32p, u8p, u8p, u64p, u8p, u8p]
+    lib.zkgpu_txblock_create.argtypes = [vp, sz, u32p, u32p, u8p, u8p, u64p, u8p, C.POINTER(vp)]
+    lib.zkgpu_txblock_destroy.argtypes = [vp]
+    lib.zkgpu_txblock_destroy.restype = None
+    lib.zkgpu_txblock_size.argtypes = [vp]
+    lib.zkgpu_txblock_size.restype = sz
+    lib.zkgpu_txblock_shapes.argtypes = [vp]
+    lib.zkgpu_txblock_shapes.restype = sz
+    lib.zkgpu_verifier_verify_block.argtypes = [vp, vp, u8p]
+    lib.zkgpu_cloak_msm_terms.argtypes = [C.c_uint32, C.c_uint32]
+    lib.zkgpu_cloak_msm_terms.restype = C.c_uint64
+    lib.zkgpu_shard_cuts.argtypes = [sz, u32p, u32p, C.c_int, u64p]
+    lib.zkgpu_comm_unique_id.argtypes = [u8p]
+    lib.zkgpu_comm_create.argtypes = [vp, C.c_int, C.c_int, u8p, C.POINTER(vp)]
+    lib.zkgpu_comm_destroy.argtypes = [vp]
+    lib.zkgpu_comm_destroy.restype = None
+    lib.zkgpu_comm_rank.argtypes = [vp]
+    lib.zkgpu_comm_world.argtypes = [vp]
+    lib.zkgpu_comm_allgather.argtypes = [vp, u8p, sz, u8p]
+    lib.zkgpu_comm_allgather_bitmap.argtypes = [vp, u64p, u8p, C.c_int, u8p]
+    lib.zkgpu_verifier_verify_sharded.argtypes = [vp, vp, sz, u32p, u32p, u8p, u8p, u64p, u8p, u8p]
+    lib.zkgpu_cloak_plan_layout.argtypes = [vp, C.POINTER(C.c_uint32)]
+    lib.zkgpu_debug_read.argtypes = [vp, C.c_char_p, vp, sz]
+    lib.zkgpu_debug_read.restype = C.c_longlong
     _LIB = lib
     return lib
 
@@ -331,6 +363,14 @@ class Context:
             out[name.value.decode()] = (int(n.value), float(ms.value))
         return out
 
+    def debug_read(self, what: str, nbytes: int) -> bytes:
+        """zkgpu_debug_read: an intermediate buffer of the last device-side preparation on this context."""
+        buf = C.create_string_buffer(max(nbytes, 1))
+        n = int(self.lib.zkgpu_debug_read(self.h, what.encode(), buf, nbytes))
+        if n < 0:
+            raise ZkGpuError(n, "zkgpu_debug_read(%s)" % what)
+        return buf.raw[:n]
+
     def last_window_bits(self) -> int:
         return int(self.lib.zkgpu_last_window_bits(self.h))
 
@@ -339,3 +379,57 @@ class Context:
 
     def set_window_bits(self, w: int) -> None:
         self._check(self.lib.zkgpu_set_window_bits(self.h, w))
+
+
+def shard_cuts(shapes: Sequence[Tuple[int, int]], world: int):
+    """zkgpu_shard_cuts: contiguous shards of a block, balanced by multiscalar-multiplication terms (no GPU needed)."""
+    lib = load_library()
+    n = len(shapes)
+    a = (C.c_uint32 * max(n, 1))(*[s[0] for s in shapes])
+    b = (C.c_uint32 * max(n, 1))(*[s[1] for s in shapes])
+    cuts = (C.c_uint64 * (world + 1))()
+    rc = lib.zkgpu_shard_cuts(n, a, b, world, cuts)
+    if rc != OK:
+        raise ZkGpuError(rc, lib.zkgpu_strerror(rc).decode())
+    return list(cuts)
+
+
+class Comm:
+    """zkgpu_comm: the RCCL communicator of this process's GPU (one process per GPU)."""
+
+    def __init__(self, ctx: Context, rank: int, world: int, unique_id: Optional[bytes]):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        ctx._check(ctx.lib.zkgpu_comm_create(ctx.h, rank, world, unique_id, C.byref(self.h)))
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.zkgpu_comm_unique_id(buf)
+        if rc != OK:
+            raise ZkGpuError(rc, lib.zkgpu_strerror(rc).decode())
+        return buf.raw
+
+    def allgather(self, local: bytes) -> bytes:
+        out = C.create_string_buffer(max(len(local) * self.world, 1))
+        self.ctx._check(self.ctx.lib.zkgpu_comm_allgather(self.h, local, len(local), out))
+        return out.raw[: len(local) * self.world]
+
+    def allgather_bitmap(self, cuts: Sequence[int], local_bitmap: bytes, local_status: int = 0) -> bytes:
+        n = cuts[-1]
+        out = C.create_string_buffer(max((n + 7) // 8, 1))
+        self.ctx._check(self.ctx.lib.zkgpu_comm_allgather_bitmap(self.h, _u64arr(list(cuts)), local_bitmap, local_status, out))
+        return out.raw[: (n + 7) // 8]
+
+    def close(self) -> None:
+        if self.h:
+            self.ctx.lib.zkgpu_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

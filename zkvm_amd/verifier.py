@@ -80,6 +80,110 @@ class Prover:
                 for i in range(batch)]
 
 
+def _check_packed(n_in: int, n_out: int, batch: int, commitments: bytes, proofs: bytes, proof_len: int,
+                  r_bytes: Optional[bytes]) -> None:
+    """The C ABI sees pointers only: a short buffer would be a host heap over-read."""
+    if len(commitments) != batch * 64 * (n_in + n_out):
+        raise ValueError("commitments must hold 64 bytes per value and transaction")
+    if len(proofs) != batch * proof_len:
+        raise ValueError("proofs must hold proof_len bytes per transaction")
+    if r_bytes is not None and len(r_bytes) != 64 * batch:
+        raise ValueError("r_bytes must hold 64 bytes per transaction")
+
+
+def _marshal_block(txs: Sequence[CloakTx], r_bytes: Optional[bytes]):
+    batch = len(txs)
+    offs = [0]
+    for t in txs:
+        if len(t.commitments) != 64 * (t.n_in + t.n_out):
+            raise ValueError("commitments must hold 64 bytes per value")
+        offs.append(offs[-1] + len(t.proof))
+    if r_bytes is not None and len(r_bytes) != 64 * batch:
+        raise ValueError("r_bytes must hold 64 bytes per transaction")
+    return ((C.c_uint32 * max(batch, 1))(*[t.n_in for t in txs]), (C.c_uint32 * max(batch, 1))(*[t.n_out for t in txs]),
+            b"".join(t.commitments for t in txs), b"".join(t.proof for t in txs), (C.c_uint64 * (batch + 1))(*offs))
+
+
+class TxBlock:
+    """zkgpu_txblock: a block of transactions of mixed shapes, grouped by shape and resident in HBM."""
+
+    def __init__(self, bv: "BlockVerifier", txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None):
+        self.bv = bv
+        self.n = len(txs)
+        self.h = C.c_void_p()
+        n_in, n_out, com, proofs, po = _marshal_block(txs, r_bytes)
+        bv._check(bv.lib.zkgpu_txblock_create(bv.h, self.n, n_in, n_out, com, proofs, po, r_bytes, C.byref(self.h)))
+
+    def shapes(self) -> int:
+        return int(self.bv.lib.zkgpu_txblock_shapes(self.h))
+
+    def close(self) -> None:
+        if self.h:
+            self.bv.lib.zkgpu_txblock_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BlockVerifier:
+    """zkgpu_verifier: whole blocks of transactions of any mix of shapes (BASELINE configs[3]); the shape
+    grouping, the plans and the batches in flight are the library's."""
+
+    def __init__(self, ctx: Context, bp_gens: BulletproofGens, batches_in_flight: int = 0, chunk: int = 0):
+        self.ctx, self.lib, self.bp_gens = ctx, ctx.lib, bp_gens
+        self.h = C.c_void_p()
+        ctx._check(self.lib.zkgpu_verifier_create(ctx.h, bp_gens.points.h, bp_gens.gens_capacity, batches_in_flight,
+                                                  C.byref(self.h)))
+        if chunk:
+            self._check(self.lib.zkgpu_verifier_set_chunk(self.h, chunk))
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            detail = self.lib.zkgpu_verifier_last_error(self.h).decode() if self.h else ""
+            raise ZkGpuError(rc, self.lib.zkgpu_strerror(rc).decode() + (": " + detail if detail else ""))
+
+    def lanes(self) -> int:
+        return int(self.lib.zkgpu_verifier_lanes(self.h))
+
+    def verify(self, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None) -> bytes:
+        batch = len(txs)
+        n_in, n_out, com, proofs, po = _marshal_block(txs, r_bytes)
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        self._check(self.lib.zkgpu_verifier_verify(self.h, batch, n_in, n_out, com, proofs, po, r_bytes, bm))
+        return bm.raw[: (batch + 7) // 8]
+
+    def block(self, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None) -> TxBlock:
+        return TxBlock(self, txs, r_bytes)
+
+    def verify_block(self, block: TxBlock) -> bytes:
+        bm = C.create_string_buffer(max((block.n + 7) // 8, 1))
+        self._check(self.lib.zkgpu_verifier_verify_block(self.h, block.h, bm))
+        return bm.raw[: (block.n + 7) // 8]
+
+    def verify_sharded(self, comm, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None) -> bytes:
+        """zkgpu_verifier_verify_sharded: every rank passes the whole block and receives the whole bitmap."""
+        batch = len(txs)
+        n_in, n_out, com, proofs, po = _marshal_block(txs, r_bytes)
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        self._check(self.lib.zkgpu_verifier_verify_sharded(self.h, comm.h, batch, n_in, n_out, com, proofs, po, r_bytes, bm))
+        return bm.raw[: (batch + 7) // 8]
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.zkgpu_verifier_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Verifier:
     """Batch verifier; `verify_cloak_txs` returns one Optional[VMError] per transaction
     (None = Ok), the shape of `txs.iter().map(|tx| tx.verify(bp_gens))`."""
@@ -124,49 +228,29 @@ class Verifier:
         self.ctx._check(self.ctx.lib.zkgpu_cloak_plan_info(self._plan(n_in, n_out), *[C.byref(v) for v in vals]))
         return dict(zip(("multipliers", "padded_n", "constraints", "terms", "proof_len"), [v.value for v in vals]))
 
+    def _block_verifier(self) -> "BlockVerifier":
+        bv = self.__dict__.get("_bv")
+        if bv is None:
+            bv = self.__dict__["_bv"] = BlockVerifier(self.ctx, self.bp_gens)
+        return bv
+
     def verify_bitmap_gpu(self, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None) -> bytes:
-        """As verify_bitmap, with the transcript replay and the scalar preparation on the GPU.
-        Transactions are grouped by shape (one device plan per shape); a proof whose length does
-        not fit its shape is rejected, as in the reference."""
-        batch = len(txs)
-        out = bytearray((batch + 7) // 8)
-        groups = {}
-        for i, t in enumerate(txs):
-            groups.setdefault((t.n_in, t.n_out, len(t.proof)), []).append(i)
-        # one batch per shape, kept in flight together on forked contexts (zkgpu_ctx_fork): the device
-        # works on the shapes concurrently instead of draining after each
-        lanes = self._lanes(min(len(groups), 4))
-        pending = []
+        """As verify_bitmap, with the transcript replay and the scalar preparation on the GPU
+        (zkgpu_verifier_verify: shape grouping, one device plan per shape and the batches in flight all live
+        behind the C ABI).  A transaction whose shape cannot be verified over these generators, or whose
+        proof length does not fit its shape, is rejected on its own, as in the reference."""
+        return self._block_verifier().verify(txs, r_bytes)
 
-        def collect(entry):
-            c, idx = entry
-            bm = c.verify_wait()
-            for j, i in enumerate(idx):
-                if (bm[j // 8] >> (j % 8)) & 1:
-                    out[i // 8] |= 1 << (i % 8)
-
-        for g, ((n_in, n_out, plen), idx) in enumerate(groups.items()):
-            if len(pending) >= len(lanes):
-                collect(pending.pop(0))
-            c = lanes[g % len(lanes)]
-            sub = [txs[i] for i in idx]
-            rb = b"".join(r_bytes[64 * i: 64 * i + 64] for i in idx) if r_bytes is not None else None
-            self.submit_packed_gpu(n_in, n_out, len(sub), b"".join(t.commitments for t in sub),
-                                   b"".join(t.proof for t in sub), plen, rb, ctx=c)
-            pending.append((c, idx))
-        while pending:
-            collect(pending.pop(0))
-        return bytes(out)
-
-    def _lanes(self, n: int):
-        lanes = self.__dict__.setdefault("_lane_ctxs", [self.ctx])
-        while len(lanes) < n:
-            lanes.append(self.ctx.fork())
-        return lanes[:max(n, 1)]
+    def plan_layout(self, n_in: int, n_out: int) -> dict:
+        """zkgpu_cloak_plan_layout: sizes of the buffers zkgpu_debug_read returns for this shape."""
+        out = (C.c_uint32 * 8)()
+        self.ctx._check(self.ctx.lib.zkgpu_cloak_plan_layout(self._plan(n_in, n_out), out))
+        return dict(zip(("slots", "n_ch", "n_chal2", "n_dyn", "n_static", "k", "m", "n_mono"), list(out)))
 
     def verify_packed_gpu(self, n_in: int, n_out: int, batch: int, commitments: bytes, proofs: bytes, proof_len: int,
                           r_bytes: Optional[bytes] = None) -> bytes:
         """zkgpu_cloak_verify_batch_gpu on already-contiguous buffers (what a Rust caller would hand over)."""
+        _check_packed(n_in, n_out, batch, commitments, proofs, proof_len, r_bytes)
         bm = C.create_string_buffer(max((batch + 7) // 8, 1))
         rc = self.ctx.lib.zkgpu_cloak_verify_batch_gpu(self.ctx.h, self.bp_gens.points.h, self._plan(n_in, n_out), batch,
                                                        commitments, proofs, proof_len, r_bytes, bm)
@@ -198,6 +282,7 @@ class Verifier:
     def submit_packed_gpu(self, n_in: int, n_out: int, batch: int, commitments: bytes, proofs: bytes, proof_len: int,
                           r_bytes: Optional[bytes] = None, ctx: Optional[Context] = None) -> Context:
         """zkgpu_cloak_verify_submit: as submit_packed_gpu_dev with the inputs in host memory."""
+        _check_packed(n_in, n_out, batch, commitments, proofs, proof_len, r_bytes)
         c = ctx or self.ctx
         c._check(c.lib.zkgpu_cloak_verify_submit(c.h, self.bp_gens.points.h, self._plan(n_in, n_out), batch,
                                                  commitments, proofs, proof_len, r_bytes))
@@ -205,9 +290,9 @@ class Verifier:
         return c
 
     def close(self) -> None:
-        for c in self.__dict__.get("_lane_ctxs", [])[1:]:
-            c.close()
-        self.__dict__["_lane_ctxs"] = [self.ctx]
+        bv = self.__dict__.pop("_bv", None)
+        if bv is not None:
+            bv.close()
         for h in self.__dict__.get("_plans", {}).values():
             self.ctx.lib.zkgpu_cloak_plan_destroy(h)
         self.__dict__["_plans"] = {}
