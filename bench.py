@@ -2,29 +2,38 @@
 """bench.py -- batch verification throughput of ZkVM cloak transactions on MI355X.
 
 One "step" = one complete `r1cs::Verifier::verify` of every transaction of one batch, on the
-device, from inputs resident in HBM (zkgpu_cloak_verify_batch_gpu_dev): Merlin transcript
-replay, verification scalars (inner-product-argument s vector, constraint flattening, g_i /
-h_i), decompression of the proof points, the 549-term multiscalar multiplication per
-transaction and the ristretto identity test -> accept bitmap (copied to the host).
-Workload = BASELINE.json configs[1]: 1024 2-in/2-out cloak transactions per GPU.  The proofs
-are REAL Bulletproofs R1CS proofs of the cloak statement (tests/golden/cloak_2x2_proofs.bin:
-64 proofs from the oracle prover, committed as data); transaction i verifies proof
-i mod 64 under its own verifier randomness r_i, so all 1024 verification equations differ
-(n = 256 multipliers, k = 8, m = 8 commitments: 35 proof-specific points + 514 shared
-generators per transaction).  ~1.5 % of the transactions are corrupted (undecodable
-commitment, wrong IPA scalar, someone else's proof) so the accept bitmap is not trivial.
+device, from inputs resident in HBM: Merlin transcript replay, verification scalars
+(inner-product-argument s vector, constraint flattening, g_i / h_i), decompression of the proof
+points, the multiscalar multiplication per transaction and the ristretto identity test -> accept
+bitmap (copied to the host).
 
-Launch:  python bench.py [--gpus N --steps K --warmup W]
-         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-One process per GPU; shards are independent (weak scaling: 1024 tx per GPU); the only
-collective is the RCCL all-gather of the per-shard accept bitmaps.
+  --config 2 (default)  BASELINE.json configs[1]: 1024 2-in/2-out cloak transactions per GPU -- the
+                        1024 DISTINCT real proofs of tests/golden/cloak_2x2_1024.bin (oracle prover,
+                        committed as data), ~1.5 % corrupted (n = 256 multipliers, k = 8, m = 8: 35
+                        proof-specific points + 514 shared generators per transaction).
+                        zkgpu_cloak_verify_submit_dev / zkgpu_verify_wait, several batches in flight.
+  --config 4            BASELINE.json configs[3]: 8192 x N mixed-arity transactions (shapes 1x1, 1x2,
+                        2x2, 3x3, 4x4 drawn with a fixed seed from tests/golden/cloak_mixed.bin; at
+                        N = 8 the 65 536 of the config), cut into N contiguous shards balanced by the
+                        number of multiscalar-multiplication terms (zkgpu_shard_cuts); each rank keeps
+                        its shard resident in HBM (zkgpu_txblock), verifies it shape-grouped with
+                        batches in flight (zkgpu_verifier_verify_block) and the per-shard accept bitmaps
+                        are all-gathered over RCCL behind the C ABI (zkgpu_comm_allgather_bitmap);
+                        every rank checks the bitmap of the WHOLE batch.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel vs the HBM
-roofline the north-star names, plus the integer-ALU figure that actually binds),
-"cpu_baseline" (the CPU oracle's full verifier -- a port of the reference's algorithm; the
-reference itself is not mounted -- on this box's host cores), "msm_boundary" (the
-multiscalar-multiplication tail alone), "host_memory" (the same calls fed from host memory),
-"msm_2p20" (BASELINE configs[2] microbench).
+Launch:  python bench.py [--gpus N --steps K --warmup W] [--config 4]
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+                --master-port P bench.py --gpus N --steps K --warmup W [--config 4]
+One process per GPU; shards are independent (weak scaling); the only collective on the data path is
+the all-gather of the accept bitmaps.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (the dominant kernel of the step -- by
+summed solo kernel time -- against the HBM roofline the north-star names, the whole step against
+it, and the integer-ALU figure that actually binds), "setup" (one-time costs that `value` does not
+contain: table build, table bytes), "cpu_baseline" (the CPU oracle's full verifier -- a port of the
+reference's algorithm; the reference itself is not mounted -- on this box's host cores), and in
+config 2 "msm_boundary", "per_tx_checks", "host_memory", "prover", "msm_2p20" (BASELINE configs[2],
+checked against tests/golden/msm_2p20.json).
 """
 from __future__ import annotations
 
@@ -32,77 +41,42 @@ import os
 
 # Each batch in flight has a stream of its own for its latency-bound kernels; the HIP runtime maps
 # streams onto 4 hardware queues by default, which would serialise those streams again.  Must be set
-# before the runtime initialises (i.e. before torch is imported).
+# before the runtime initialises (i.e. before torch is imported): this file is the process's entry
+# point, so it is.
+_HWQ_PRESET = "GPU_MAX_HW_QUEUES" in os.environ
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# stdout carries exactly ONE line, the JSON record: whatever libraries print there (RCCL's version banner, gloo's
+# connection chatter) is sent to stderr instead
+_JSON_OUT = os.fdopen(os.dup(1), "w")
+os.dup2(2, 1)
 
 import argparse
 import hashlib
 import json
-import os
-import struct
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
 
 L = 2**252 + 27742317777372353535851937790883648493
 SEED = 0x5A6B564D  # "ZkVM"
-N_MULT, LG_N, N_COMMIT = 256, 8, 8
-N_DYN = 6 + N_COMMIT + 5 + 2 * LG_N          # 35 proof-specific points
-N_STATIC = 2 + 2 * N_MULT                    # 514 generator terms
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s spec
 MAD_PEAK_GOPS = 33864.9                      # measured v_mad_u64_u32 rate, profiles/r01_valu_rates.txt
-MADS_PER_MADD = 700                          # 7 field multiplications x 100 (field.hpp)
+VALU_PEAK_GINST = 1024 * 2.4 / 4 * 64        # 1024 SIMDs x 2.4 GHz / 4 cycles per wave instruction x 64 lanes
 BAD_POINT = bytes.fromhex("01" + "00" * 31)
+SHAPE_TERMS = {}                             # (n_in, n_out) -> (n_dyn, n_static), filled from the library
+
+
+def emit(record) -> None:
+    _JSON_OUT.write(json.dumps(record) + "\n")
+    _JSON_OUT.flush()
 
 
 def shake(tag: bytes, n: int) -> bytes:
     return hashlib.shake_256(SEED.to_bytes(4, "little") + tag).digest(n)
-
-
-def load_fixture():
-    path = os.path.join(ROOT, "tests", "golden", "cloak_2x2_proofs.bin")
-    raw = open(path, "rb").read()
-    assert raw[:8] == b"ZKCLOAK1"
-    count, n_in, n_out, plen = struct.unpack("<IIII", raw[8:24])
-    w = 64 * (n_in + n_out)
-    rec = w + plen
-    return [(raw[24 + rec * i: 24 + rec * i + w], raw[24 + rec * i + w: 24 + rec * (i + 1)]) for i in range(count)], n_in, n_out
-
-
-def build_workload(ctx, batch: int, rank: int, table_bits: int, host_threads: int):
-    """Real proofs -> verification equations, with the product's own host verifier."""
-    from zkvm_amd.verifier import BulletproofGens, CloakTx, Verifier
-    fixture, n_in, n_out = load_fixture()
-    gens = BulletproofGens(ctx, N_MULT, table_bits=table_bits)
-    txs, expected = [], []
-    for i in range(batch):
-        com, proof = fixture[(i + 7 * rank) % len(fixture)]
-        ok = 1
-        if i % 64 == 7:
-            ok = 0
-            c = (i // 64) % 3
-            if c == 0:      # commitment that is not a ristretto255 encoding
-                com = com[:96] + BAD_POINT + com[128:]
-            elif c == 1:    # IPA scalar a off by one (still canonical)
-                a = (int.from_bytes(proof[-64:-32], "little") + 1) % L
-                proof = proof[:-64] + a.to_bytes(32, "little") + proof[-32:]
-            else:           # a valid proof of a different statement
-                proof = fixture[(i + 7 * rank + 1) % len(fixture)][1]
-        txs.append(CloakTx(n_in, n_out, com, proof))
-        expected.append(ok)
-    r_bytes = shake(b"verifier-r|%d" % rank, 64 * batch)
-    v = Verifier(ctx, gens, host_threads=host_threads)
-    t0 = time.perf_counter()
-    prep = v.prepare(txs, r_bytes)
-    prep_s = time.perf_counter() - t0
-    assert all(prep["wellformed"]), "bench corruptions keep proofs well-formed so the GPU sees every row"
-    assert prep["dyn_off"][-1] == batch * N_DYN and prep["st_off"][-1] == batch * N_STATIC
-    prep.update({"gens": gens, "txs": txs, "r_bytes": r_bytes, "expected": expected, "verifier": v,
-                 "prepare_s": prep_s})
-    return prep
 
 
 def bitmap_of(bits) -> bytes:
@@ -111,6 +85,10 @@ def bitmap_of(bits) -> bytes:
         if b:
             out[i // 8] |= 1 << (i % 8)
     return bytes(out)
+
+
+def bits_of(bm: bytes, n: int):
+    return [(bm[i // 8] >> (i % 8)) & 1 for i in range(n)]
 
 
 def usable_cores(omp_threads: int) -> int:
@@ -125,57 +103,156 @@ def usable_cores(omp_threads: int) -> int:
     return max(1, n)
 
 
-def cpu_baseline(ctx, w, gpu_bitmap: bytes, batch: int):
-    """Time the CPU oracle's full verifier (kind "port": transcript replay + scalars + MSM with the same
-    radix-2^51 field and Straus/Pippenger split as the reference's dalek back end; the Rust reference
-    itself is not mounted) on the same proof bytes, and compare every accept bit with the GPU's."""
+def shape_terms(lib, n_in: int, n_out: int):
+    """(dynamic terms, static terms) of the verification MSM of a shape: 11 + m + 2k and 2 + 2 pn."""
+    key = (n_in, n_out)
+    if key not in SHAPE_TERMS:
+        total = int(lib.zkgpu_cloak_msm_terms(n_in, n_out))
+        m = 2 * (n_in + n_out)
+        # total = 11 + m + 2k + 2 + 2 * 2^k: solve for k
+        k = next(k for k in range(1, 20) if 13 + m + 2 * k + 2 * (1 << k) == total)
+        SHAPE_TERMS[key] = (11 + m + 2 * k, 2 + 2 * (1 << k))
+    return SHAPE_TERMS[key]
+
+
+def algorithmic_bytes(lib, shapes) -> int:
+    """64 B per proof-specific term (scalar + compressed point) + 32 B per generator scalar."""
+    tot = 0
+    for s in shapes:
+        nd, ns = shape_terms(lib, *s)
+        tot += 64 * nd + 32 * ns
+    return tot
+
+
+# ---- workloads ---------------------------------------------------------------------------------
+def workload_2x2(batch: int, rank: int):
+    """configs[1]: the committed distinct proofs, ~1.5 % corrupted -> (txs, expected bits)"""
+    from gpu_util import load_cloak_fixture
+    fixture, n_in, n_out, _ = load_cloak_fixture("cloak_2x2_1024.bin")
+    txs, expected = [], []
+    for i in range(batch):
+        com, proof = fixture[(i + 37 * rank) % len(fixture)]
+        ok = 1
+        if i % 64 == 7:
+            ok = 0
+            c = (i // 64) % 3
+            if c == 0:      # commitment that is not a ristretto255 encoding
+                com = com[:96] + BAD_POINT + com[128:]
+            elif c == 1:    # IPA scalar a off by one (still canonical)
+                a = (int.from_bytes(proof[-64:-32], "little") + 1) % L
+                proof = proof[:-64] + a.to_bytes(32, "little") + proof[-32:]
+            else:           # a valid proof of a different statement
+                proof = fixture[(i + 37 * rank + 1) % len(fixture)][1]
+        txs.append((n_in, n_out, com, proof))
+        expected.append(ok)
+    return txs, expected
+
+
+def profile_lanes(ctxs):
+    prof = {}
+    for c in ctxs:
+        for k, v in c.profile_read().items():
+            a = prof.get(k, (0, 0.0))
+            prof[k] = (a[0] + v[0], a[1] + v[1])
+    return prof
+
+
+def pmc_tables():
+    """profiles/pmc_traffic.json (+ pmc_valu.json): HBM bytes and VALU instructions per launch of each kernel,
+    from the separate rocprofv3 --pmc passes of tools/profile_bench.sh (None when absent)."""
+    out = {}
+    for name in ("pmc_traffic", "pmc_valu"):
+        path = os.path.join(ROOT, "profiles", name + ".json")
+        try:
+            out[name] = json.load(open(path))
+        except Exception:
+            out[name] = None
+    return out
+
+
+def roofline_object(solo, launches_per_step, in_flight_ms, alg_bytes_step, units_step, ms_per_step, table_bytes, note):
+    """solo: kernel -> mean ms alone on the chip (HIP events, measured live after the timed region);
+    launches_per_step: kernel -> launches per step; dominant = largest summed solo time per step."""
+    per_step = {k: solo[k] * launches_per_step.get(k, 1.0) for k in solo}
+    dom = max(per_step, key=per_step.get)
+    pmc = pmc_tables()
+    traffic_tbl, valu_tbl = pmc["pmc_traffic"], pmc["pmc_valu"]
+    # the dominant kernel processes every unit of the step in its launches
+    alg_per_launch = alg_bytes_step / max(launches_per_step.get(dom, 1.0), 1e-9)
+    achieved = alg_per_launch / (solo[dom] * 1e-3) / 1e9
+    step_traffic = step_valu = None
+    if traffic_tbl:
+        step_traffic = int(sum(traffic_tbl.get(k, 0) * launches_per_step.get(k, 1.0) for k in solo))
+    if valu_tbl:
+        step_valu = int(sum(valu_tbl.get(k, 0) * launches_per_step.get(k, 1.0) for k in solo))
+    step = {"algorithmic_bytes": int(alg_bytes_step), "achieved": round(alg_bytes_step / (ms_per_step * 1e-3) / 1e9, 3),
+            "frac": round(alg_bytes_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": step_traffic,
+            "traffic_over_algorithmic": round(step_traffic / alg_bytes_step, 1) if step_traffic else None,
+            "hbm_busy_frac": round(step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if step_traffic else None,
+            "valu_wave_instructions": step_valu,
+            "valu_issue_frac": round(step_valu * 64 / (ms_per_step * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if step_valu else None,
+            "solo_kernel_ms_sum": round(sum(per_step.values()), 4)}
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": (traffic_tbl or {}).get(dom),
+            "algorithmic_bytes_per_launch": int(alg_per_launch),
+            "units_per_launch": round(units_step / max(launches_per_step.get(dom, 1.0), 1e-9), 1),
+            "avg_launch_ms": round(solo[dom], 4), "launches_per_step": round(launches_per_step.get(dom, 1.0), 2),
+            "avg_launch_ms_in_flight": round(in_flight_ms.get(dom, float("nan")), 4),
+            "dominant_by": "largest summed solo duration per step (HIP events around each kernel alone on the chip, same "
+                           "process, after the timed region; `bench.py --solo` under rocprofv3 --stats gives the same averages)",
+            "step": step,
+            "binding_resource": "integer VALU (v_mad_u64_u32 field arithmetic) and the depth of the per-batch kernel DAG; "
+                                "HBM moves a fraction of a percent of its peak algorithmically.  The generator tables (%.1f GB, "
+                                "one random 96-B row per mixed addition) are what `traffic` mostly is." % (table_bytes / 1e9),
+            "note": note}
+
+
+# ---- cpu baseline ------------------------------------------------------------------------------
+def cpu_baseline(txs, r_bytes, gpu_bits, budget_s=10.0):
+    """Time the CPU oracle's full verifier (kind "port": transcript replay + scalars + MSM with the same radix-2^51
+    field and Straus/Pippenger split as the reference's dalek back end; the Rust reference itself is not mounted)
+    on a bounded sample of the same workload, and compare every accept bit with the GPU's."""
+    from gpu_util import oracle_block_bits
     from oracle import binding as oracle
     cores = usable_cores(oracle.max_threads())
-    tx0 = w["txs"][0]
-    plen = len(tx0.proof)
-    com = b"".join(t.commitments for t in w["txs"])
-    proofs = b"".join(t.proof for t in w["txs"])
-    wcom = 64 * (tx0.n_in + tx0.n_out)
-    one = 32
+    one = min(32, len(txs))
     t0 = time.perf_counter()
-    acc1 = oracle.cloak_verify_batch(com[: wcom * one], tx0.n_in, tx0.n_out, proofs[: plen * one], plen,
-                                     w["r_bytes"][: 64 * one], threads=1)
+    acc1 = oracle_block_bits(oracle, txs[:one], r_bytes[: 64 * one], threads=1)
     t1 = time.perf_counter() - t0
+    assert list(acc1) == gpu_bits[:one], "GPU accept bits differ from the CPU oracle"
+    est = (one / t1) * cores * 0.9
+    sample = max(one, min(len(txs), int(est * budget_s)))
     reps = 0
     t0 = time.perf_counter()
     while True:
-        acc = oracle.cloak_verify_batch(com, tx0.n_in, tx0.n_out, proofs, plen, w["r_bytes"], threads=cores)
+        acc = oracle_block_bits(oracle, txs[:sample], r_bytes[: 64 * sample], threads=cores)
         reps += 1
-        if time.perf_counter() - t0 > 8.0 or reps >= 50:
+        if time.perf_counter() - t0 > budget_s * 0.8 or reps >= 64:
             break
     tall = time.perf_counter() - t0
-    gpu_bits = [(gpu_bitmap[i // 8] >> (i % 8)) & 1 for i in range(batch)]
-    assert list(acc) == gpu_bits, "GPU accept bitmap differs from the CPU oracle"
-    assert list(acc1) == gpu_bits[:one]
-    # the oracle's PROVER on the same cores (baseline of the `prover` leg)
-    n_pr = 4 * cores
-    t0 = time.perf_counter()
-    oracle.cloak_prove_batch(n_pr, 2, 2, b"bench prover cpu".ljust(32, b"\0"), threads=cores)
-    prover_rate = n_pr / (time.perf_counter() - t0)
-    return {"value": round(batch * reps / tall, 1), "unit": "tx/s", "cores": cores, "kind": "port",
-            "value_1core": round(one / t1, 2), "prover_proofs_per_s": round(prover_rate, 1),
-            "sample": "%d x the full %d-tx batch (oracle Verifier: transcript replay + scalars + 549-term MSM per tx, "
-                      "same proof bytes and verifier randomness as the GPU step) on %d OpenMP threads = this box's "
-                      "cgroup CPU quota (%.1f s); 1-core figure on %d tx (%.1f s); all %d accept bits compared "
-                      "with the GPU's" % (reps, batch, cores, tall, one, t1, batch)}
+    assert list(acc) == gpu_bits[:sample], "GPU accept bits differ from the CPU oracle"
+    return {"value": round(sample * reps / tall, 1), "unit": "tx/s", "cores": cores, "kind": "port",
+            "value_1core": round(one / t1, 2),
+            "sample": "%d x the first %d transactions of rank 0's workload (oracle Verifier: transcript replay + scalars + MSM "
+                      "per tx, same proof bytes and verifier randomness as the GPU step) on %d OpenMP threads = this box's "
+                      "cgroup CPU quota (%.1f s); 1-core figure on %d tx (%.1f s); every accept bit compared with the GPU's"
+                      % (reps, sample, cores, tall, one, t1)}
 
 
 def msm_microbench(ctx, torch, dev):
-    """BASELINE configs[2]: one 2^20-term MSM, 64 B/term (32 B scalar + 32 B compressed point)."""
-    n = 1 << 20
-    pts = ctx.hash_to_points(shake(b"msm2p20", 64 * n))
-    g = torch.Generator(device="cpu").manual_seed(SEED)
-    sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g)
-    sc[:, 31] &= 0x0F                                    # < 2^252 < l
-    d_sc = sc.to(dev)
+    """BASELINE configs[2]: one 2^20-term MSM, 64 B/term (32 B scalar + 32 B compressed point), inputs regenerated from
+    SHAKE256 and the result compared with the oracle's committed value (tests/golden/msm_2p20.json)."""
+    from gpu_util import msm_2p20_inputs
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "msm_2p20.json")))
+    n = gold["n"]
+    sc, uniform = msm_2p20_inputs(n)
+    pts = ctx.hash_to_points(uniform)
+    assert hashlib.sha256(sc).hexdigest() == gold["scalars_sha256"] and hashlib.sha256(pts).hexdigest() == gold["points_sha256"]
+    d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).to(dev)
     d_pt = torch.frombuffer(bytearray(pts), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
     r0 = ctx.msm_dev(d_sc, d_pt, n)
+    assert r0.hex() == gold["results"][str(n)], "2^20 MSM differs from the committed expected value"
     ctx.profile_reset()
     ctx.profile(True)
     iters = 5
@@ -188,15 +265,22 @@ def msm_microbench(ctx, torch, dev):
     prof = ctx.profile_read()
     kern = {k: round(v[1] / v[0], 4) for k, v in prof.items() if v[0]}
     acc_ms = kern.get("k_bucket_accumulate", 0.0)
-    return {"terms": n, "pairs_per_s": round(n / dt, 1), "ms": round(dt * 1e3, 3), "window_bits": ctx.last_window_bits(),
-            "algorithmic_GBps_whole_call": round(64 * n / dt / 1e9, 2),
-            "kernel_ms": kern, "result": r.hex()[:16],
-            "accumulate_GBps": round(64 * n / (acc_ms * 1e-3) / 1e9, 2) if acc_ms else None}
+    n_win = 255 // ctx.last_window_bits() + 1
+    out = {"terms": n, "pairs_per_s": round(n / dt, 1), "ms": round(dt * 1e3, 3), "window_bits": ctx.last_window_bits(),
+           "result": r.hex(), "equals_committed_expected_value": True, "kernel_ms": kern}
+    if acc_ms:
+        madds = n * n_win                      # one mixed addition per term and window (bucket accumulation)
+        out["roofline"] = {"bound": "hbm", "kernel": "k_bucket_accumulate", "algorithmic_bytes_per_launch": 64 * n,
+                           "achieved": round(64 * n / (acc_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(64 * n / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "avg_launch_ms": acc_ms,
+                           "whole_call_GBps": round(64 * n / dt / 1e9, 2),
+                           "valu_int": {"achieved_Gmad_s": round(madds * 700 / (acc_ms * 1e-3) / 1e9, 1), "peak_Gmad_s": MAD_PEAK_GOPS,
+                                        "frac": round(madds * 700 / (acc_ms * 1e-3) / 1e9 / MAD_PEAK_GOPS, 4)}}
+    return out
 
 
-def prover_microbench(ctx, w, host_threads: int, batch: int = 512):
-    """BASELINE configs[4] (prover side): `batch` 2-in/2-out cloak proofs, host threads for the transcripts and
-    the witness / polynomial algebra, every multiscalar multiplication on the generator tables."""
+def prover_microbench(ctx, gens, host_threads: int, batch: int = 512):
+    """BASELINE configs[4] (prover side): `batch` 2-in/2-out cloak proofs; every proof verified by the device verifier."""
     import random
     from zkvm_amd.verifier import Prover, Verifier
     rng = random.Random(SEED)
@@ -207,133 +291,143 @@ def prover_microbench(ctx, w, host_threads: int, batch: int = 512):
         qs.append([a, b, (a + b) // 3, a + b - (a + b) // 3])
         fs.append([f] * 4)
         seeds.append(hashlib.sha256(b"bench prover %d" % i).digest())
-    pr = Prover(ctx, w["gens"], host_threads=host_threads)
+    pr = Prover(ctx, gens, host_threads=host_threads)
     pr.prove(2, 2, qs[:8], fs[:8], seeds[:8])
     t0 = time.perf_counter()
     txs = pr.prove(2, 2, qs, fs, seeds)
     dt = time.perf_counter() - t0
-    v = Verifier(ctx, w["gens"])
+    v = Verifier(ctx, gens)
     bm = v.verify_bitmap_gpu(txs, shake(b"prover-r", 64 * batch))
     v.close()
     assert bm == bitmap_of([1] * batch), "a proof of the GPU prover did not verify"
-    out = {"proofs_per_s": round(batch / dt, 1), "batch": batch, "ms_per_proof": round(dt / batch * 1e3, 4),
-           "host_threads": host_threads, "msm_terms_per_proof": 2 * 4 * 2 + 3 * 273 + 3 * 29 + 5 * 2 + 16 * 513,
-           "note": "zkgpu_cloak_prove_batch: provers in lockstep on host threads (host-bound: scalar algebra of the "
-                   "coefficient-vector inner-product argument), all MSMs in 13 zkgpu_msm_ps_batch calls on the tables; "
-                   "every proof verified by the device-side verifier"}
-    return out
+    return {"proofs_per_s": round(batch / dt, 1), "batch": batch, "ms_per_proof": round(dt / batch * 1e3, 4),
+            "host_threads": host_threads,
+            "note": "zkgpu_cloak_prove_batch: provers in lockstep on host threads, all MSMs on the generator tables; every "
+                    "proof verified by the device-side verifier"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1024, help="transactions per GPU")
-    ap.add_argument("--table-bits", type=int, default=int(os.environ.get("ZKGPU_TABLE_BITS", "16")),
-                    help="window width of the fixed-base generator tables (0 = no tables: Pippenger for every term)")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKGPU_INFLIGHT", "6")),
-                    help="independent verify calls in flight per GPU (contexts x host threads)")
-    ap.add_argument("--group", type=int, default=int(os.environ.get("ZKGPU_GROUP", "16")),
-                    help="transactions per group check (zkgpu_set_group_size); 1 = every transaction on its own")
-    ap.add_argument("--lean", action="store_true",
-                    help="the timed steps and the solo pass only (no extra legs): what tools/profile_bench.sh profiles")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-msm", action="store_true", help="skip the 2^20 MSM microbench")
-    args = ap.parse_args()
+# ---- distributed plumbing ------------------------------------------------------------------------
+class World:
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus and self.world > 1:
+            raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (self.world, args.gpus))
+        if args.gpus > 1 and self.world == 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (libzkgpu has no CPU fallback)")
+        # ZKGPU_BENCH_SHARE_GPU=1 (exercising the N > 1 code path on a 1-GPU box): every rank uses device 0 and the
+        # bitmaps travel over gloo from host memory instead of RCCL (which refuses two ranks on one device)
+        self.share_gpu = os.environ.get("ZKGPU_BENCH_SHARE_GPU") == "1"
+        self.local = 0 if self.share_gpu else local
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device("cuda", self.local)
+        self.coll_dev = torch.device("cpu") if self.share_gpu else self.dev
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.share_gpu:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            self.dist = dist
 
-    import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (libzkgpu has no CPU fallback)")
-    # ZKGPU_BENCH_SHARE_GPU=1 (testing the N > 1 code path on a 1-GPU box): every rank uses device 0 and the
-    # bitmaps travel over gloo from host memory instead of RCCL (which refuses two ranks on one device)
-    share_gpu = os.environ.get("ZKGPU_BENCH_SHARE_GPU") == "1"
-    if share_gpu:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    coll_dev = torch.device("cpu") if share_gpu else dev
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
 
+    def max_over_ranks(self, x: float) -> float:
+        if not self.dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.coll_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def broadcast_bytes(self, b: bytes, n: int) -> bytes:
+        if not self.dist:
+            return b
+        t = self.torch.frombuffer(bytearray(b if self.rank == 0 else bytes(n)), dtype=self.torch.uint8).to(self.coll_dev)
+        self.dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+
+    def close(self):
+        if self.dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def common_line(args, W, value, elapsed, data, config):
+    return {"metric": "ZkVM tx verifications/sec (batch)", "value": round(value, 1), "unit": "tx/s", "n_gpus": W.world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 limb pairs of radix-2^51 (v_mad_u64_u32)", "data": data, "config": config}
+
+
+# ---- config 2: the headline --------------------------------------------------------------------
+def run_config2(args, W):
+    torch, dev, rank, world = W.torch, W.dev, W.rank, W.world
     from zkvm_amd import Context
-    ctx = Context(local)
+    from zkvm_amd.verifier import BulletproofGens, CloakTx, Verifier
+    ctx = Context(W.local)
+    lib = ctx.lib
     batch = args.batch
     host_threads = max(1, usable_cores(os.cpu_count() or 1) // max(1, world))
-    w = build_workload(ctx, batch, rank, args.table_bits, host_threads)
-    ps = w["gens"].points
+    txs, expected = workload_2x2(batch, rank)
+    n_in, n_out = txs[0][0], txs[0][1]
+    n_dyn, n_static = shape_terms(lib, n_in, n_out)
+    t0 = time.perf_counter()
+    gens = BulletproofGens(ctx, 256, table_bits=args.table_bits)
+    table_s = time.perf_counter() - t0
+    table_bytes = int(lib.zkgpu_pointset_table_bytes(gens.points.h))
+    r_bytes = shake(b"verifier-r|%d" % rank, 64 * batch)
+    ctxs_txs = [CloakTx(*t) for t in txs]
+    proof_len = len(txs[0][3])
 
     def to_dev(b, dtype=torch.uint8):
         return torch.frombuffer(bytearray(b), dtype=dtype).to(dev)
 
-    d_dyn_sc, d_dyn_pt, d_st_sc = to_dev(w["dyn_sc"]), to_dev(w["dyn_pt"]), to_dev(w["st_sc"])
-    d_st_idx = torch.tensor(w["st_idx"], dtype=torch.int32, device=dev)
-    d_dyn_off = torch.tensor(w["dyn_off"], dtype=torch.int64, device=dev)
-    d_st_off = torch.tensor(w["st_off"], dtype=torch.int64, device=dev)
     nbytes = (batch + 7) // 8
-    d_bm = torch.zeros(nbytes, dtype=torch.uint8, device=coll_dev)
-    d_all = torch.zeros(nbytes * world, dtype=torch.uint8, device=coll_dev) if world > 1 else None
-    torch.cuda.synchronize()
+    d_bm = torch.zeros(nbytes, dtype=torch.uint8, device=W.coll_dev)
+    d_all = torch.zeros(nbytes * world, dtype=torch.uint8, device=W.coll_dev) if world > 1 else None
 
-    # `--inflight M`: M batches in flight.  Each has its own forked context (workspace + a light stream
-    # for its latency-bound kernels: the Merlin replay, the 255-doubling Horner tail); the chip-filling
-    # kernels of all of them go first-in first-out through the parent's two streams (zkgpu_ctx_fork).
-    # One host thread submits step i + M only after collecting step i.  Every step is still one
-    # complete, independent verification of the whole batch; K steps are timed as a whole.
+    # `--inflight M`: M batches in flight.  Each has its own forked context (workspace + a light stream for its
+    # latency-bound kernels); the chip-filling kernels of all of them go first-in first-out through the parent's
+    # shared streams (zkgpu_ctx_fork).  One host thread submits step i + M only after collecting step i.  Every step
+    # is one complete, independent verification of the whole batch; K steps are timed as a whole.
     ctx.set_group_size(args.group)               # forks inherit it
-    lanes_env = min(max(int(os.environ.get("ZKGPU_LANES", "2")), 1), 4)
-    max_inflight = 1 + min(9, 19 - 3 * lanes_env)          # the library's fork limit (hardware queues)
-    ctxs = [ctx] + [ctx.fork() for _ in range(min(max(1, args.inflight), max_inflight) - 1)]
-
-    # THE STEP: the complete r1cs::Verifier::verify of every transaction of the batch, on the device,
-    # from commitments + proof bytes + verifier randomness resident in HBM: Merlin transcript replay
-    # (k_transcript), verification scalars incl. the inner-product-argument s vector (k_prepare), point
-    # decompression, the multiscalar multiplications and the identity test -> accept bitmap.
-    from zkvm_amd.verifier import Verifier
-    tx0 = w["txs"][0]
-    proof_len = len(tx0.proof)
-    d_com = to_dev(b"".join(t.commitments for t in w["txs"]))
-    d_proofs = to_dev(b"".join(t.proof for t in w["txs"]))
-    d_r = to_dev(w["r_bytes"])
-    gv = Verifier(ctx, w["gens"])
+    ctxs = [ctx] + [ctx.fork() for _ in range(min(max(1, args.inflight), 10) - 1)]
+    d_com = to_dev(b"".join(t[2] for t in txs))
+    d_proofs = to_dev(b"".join(t[3] for t in txs))
+    d_r = to_dev(r_bytes)
+    gv = Verifier(ctx, gens)
     torch.cuda.synchronize()
 
     def submit_verify(c):
-        gv.submit_packed_gpu_dev(tx0.n_in, tx0.n_out, batch, d_com, d_proofs, proof_len, d_r, ctx=c)
-
-    def submit_msm_only(c):   # the MSM boundary alone: scalars prepared beforehand (by the host verifier)
-        c.verify_batch_ps_submit_dev(ps, batch, d_dyn_sc, d_dyn_pt, d_dyn_off, batch * N_DYN,
-                                     d_st_sc, d_st_idx, d_st_off, batch * N_STATIC)
+        gv.submit_packed_gpu_dev(n_in, n_out, batch, d_com, d_proofs, proof_len, d_r, ctx=c)
 
     def collect(c, gather=True):
         bm = c.verify_wait()
         if world > 1 and gather:
             d_bm.copy_(torch.frombuffer(bytearray(bm), dtype=torch.uint8))
-            dist.all_gather_into_tensor(d_all, d_bm)    # RCCL over xGMI: the per-shard accept bitmaps
+            W.dist.all_gather_into_tensor(d_all, d_bm)    # RCCL over xGMI: the per-shard accept bitmaps
         return bm
 
     host_time = {"submit": 0.0, "n": 0}
 
-    def run_steps(n, submit=None, gather=True):
+    def run_steps(n, submit=None, gather=True, lanes=None):
         # gather=False: the rank-0-only extra legs (no collective: the other ranks are not in them)
         submit = submit or submit_verify
-        depth = len(ctxs)
+        lanes = lanes or ctxs
+        depth = len(lanes)
         bm = None
         for i in range(n):
-            c = ctxs[i % depth]
+            c = lanes[i % depth]
             if i >= depth:
                 bm = collect(c, gather)
             ts = time.perf_counter()
@@ -341,123 +435,118 @@ def main():
             host_time["submit"] += time.perf_counter() - ts
             host_time["n"] += 1
         for i in range(max(n - depth, 0), n):
-            bm = collect(ctxs[i % depth], gather)
+            bm = collect(lanes[i % depth], gather)
         return bm
 
+    def solo_pass(reps=5):
+        ctx.profile_reset()
+        ctx.set_serial(True)
+        ctx.profile(True)
+        for _ in range(reps):
+            submit_verify(ctx)
+            assert ctx.verify_wait() == bitmap_of(expected)
+        ctx.profile(False)
+        ctx.set_serial(False)
+        prof = ctx.profile_read()
+        return {k: v[1] / v[0] for k, v in prof.items() if v[0]}, {k: v[0] / reps for k, v in prof.items() if v[0]}
+
+    if args.solo:      # what tools/profile_bench.sh runs under rocprofv3 --stats: every kernel alone on the chip
+        run_steps(2, lanes=[ctx])
+        solo, launches = solo_pass(max(args.steps, 5))
+        if rank == 0:
+            emit({"solo_kernel_ms": {k: round(v, 4) for k, v in sorted(solo.items())}, "launches_per_step": launches, "batch": batch})
+        gv.close()
+        for c in ctxs[1:]:
+            c.close()
+        gens.close()
+        ctx.close()
+        return
+
     bm = run_steps(max(args.warmup, len(ctxs)))
-    # HIP events around every launch of ONE of the contexts in flight (every len(ctxs)-th step): the
-    # per-kernel durations of the roofline object are measured inside the timed region without
-    # fencing every kernel of every batch
+    # HIP events around every launch of ONE of the contexts in flight (every len(ctxs)-th step)
     prof_ctxs = ctxs[:1]
     for c in prof_ctxs:
         c.profile_reset()
         c.profile(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    W.barrier()
     t0 = time.perf_counter()
     host_time.update(submit=0.0, n=0)
     bm = run_steps(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    W.barrier()
     elapsed = time.perf_counter() - t0
     submit_ms = host_time["submit"] / max(host_time["n"], 1) * 1e3
     for c in prof_ctxs:
         c.profile(False)
+    elapsed = W.max_over_ranks(elapsed)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         gathered = bytes(d_all.cpu().numpy().tobytes())
         assert gathered[rank * nbytes:(rank + 1) * nbytes] == bm
-
-    assert bm == bitmap_of(w["expected"]), "accept bitmap differs from the constructed expectation"
+    assert bm == bitmap_of(expected), "accept bitmap differs from the constructed expectation"
 
     if rank == 0:
-        prof = {}
-        for c in prof_ctxs:
-            for k, v in c.profile_read().items():
-                a = prof.get(k, (0, 0.0))
-                prof[k] = (a[0] + v[0], a[1] + v[1])
-        kern_ms = {k: v[1] / v[0] for k, v in prof.items() if v[0]}
-        profiled_steps = max(1, (args.steps + len(ctxs) - 1) // len(ctxs))
-        total_kernel_ms = sum(v[1] for v in prof.values()) / profiled_steps
-        # Dominant kernel = the one that issues most of the step's VALU work, not the longest-lived one:
-        # with several calls in flight the latency-bound tail kernels (k_msm_finish: 16-64 wavefronts
-        # walking a 255-doubling chain) show long durations while occupying a sliver of the chip.
-        # SQ_INSTS_VALU per launch (profiles/r01c_pmc_SQ_WAVE_CYCLES.txt): k_static_accumulate 203 M,
-        # k_bucket_accumulate / k_small_msm_windows ~100 M, k_msm_finish 15 M.
-        dom = "k_static_accumulate" if (args.table_bits and "k_static_accumulate" in kern_ms) else "k_bucket_accumulate"
-        if dom not in kern_ms:
-            dom = max(kern_ms, key=kern_ms.get)
-        dom_ms = kern_ms[dom]
-        wbits = ctx.last_window_bits()                 # Pippenger width of the proof-point pipeline
-        tbits = args.table_bits
-        # Per-launch algorithmic bytes (64 B per proof-specific term, 32 B per
-        # generator scalar, generator points amortised) and mixed additions of the kernels that carry them.
-        # k_static_accumulate runs twice per step when the batch is checked in groups: once over the
-        # n_groups summed checks, once over the transactions of the groups that failed
-        n_win = (255 // tbits + 1) if tbits else 0
-        if args.group > 1:
-            g = min(args.group, batch)
-            n_groups = (batch + g - 1) // g
-            recheck = sum(min(g, batch - G * g) for G in range(n_groups) if not all(w["expected"][G * g: (G + 1) * g]))
-            sa_terms, sa_launches = (n_groups + recheck) * N_STATIC, 2
-        else:
-            n_groups, recheck = batch, 0
-            sa_terms, sa_launches = batch * N_STATIC, 1
-        per_kernel = {
-            "k_static_accumulate": {"bytes": 32 * sa_terms / sa_launches, "madds": sa_terms * n_win / sa_launches},
-            "k_bucket_accumulate": {"bytes": (64 * N_DYN + (0 if tbits else 32 * N_STATIC)) * batch,
-                                    "madds": batch * (N_DYN + (0 if tbits else N_STATIC)) * (255 // wbits + 1)},
-        }
-        info = per_kernel.get(dom, {"bytes": (64 * N_DYN + 32 * N_STATIC) * batch, "madds": 0})
-        alg_bytes = info["bytes"]
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        mads = info["madds"] * MADS_PER_MADD
-        # solo pass: every kernel of a batch alone on the chip (one context, one stream, profiling on)
-        ctx.profile_reset()
-        ctx.set_serial(True)
-        ctx.profile(True)
-        for _ in range(5):
-            submit_verify(ctx)
-            ctx.verify_wait()
-        ctx.profile(False)
-        ctx.set_serial(False)
-        solo = {k: v[1] / v[0] for k, v in ctx.profile_read().items() if v[0]}
-        solo_ms = solo.get(dom, dom_ms)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(dom)
-            except Exception:
-                traffic = None
-        e2e_s = e2e_gpu_s = msm_only_s = per_tx_s = float("nan")
+        prof = profile_lanes(prof_ctxs)
+        in_flight_ms = {k: v[1] / v[0] for k, v in prof.items() if v[0]}
+        solo, launches = solo_pass()
+        ms_per_step = elapsed / args.steps * 1e3
+        alg_step = algorithmic_bytes(lib, [(n_in, n_out)] * batch)
+        line = common_line(args, W, batch * world * args.steps / elapsed, elapsed,
+                           "synthetic: 1024 distinct real R1CS proofs of the 2-in/2-out cloak statement (committed fixture, oracle "
+                           "prover), each verified under per-transaction verifier randomness; ~1.5% corrupted",
+                           {"workload": "BASELINE configs[1]: batch of %d 2-in/2-out cloak tx per GPU, complete r1cs::Verifier::verify "
+                                        "on the device from commitments + R1CSProof bytes + verifier randomness resident in HBM: "
+                                        "Merlin replay, verification scalars (IPA s vector, constraint flattening), decompression, "
+                                        "the %d-term mega_check MSM (n=256, k=8, m=8; %d terms on shared generators), identity "
+                                        "test -> accept bitmap" % (batch, n_dyn + n_static, n_static),
+                            "tx_per_gpu": batch, "terms_per_tx": n_dyn + n_static, "generator_table_bits": args.table_bits,
+                            "calls_in_flight": len(ctxs), "group_size": args.group,
+                            "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "hw_queues_set_by": "caller" if _HWQ_PRESET else "bench.py, before the HIP runtime started",
+                            "parallelism": "tx-sharded x%d, RCCL all-gather of accept bitmaps" % world})
+        line["roofline"] = roofline_object(solo, launches, in_flight_ms, alg_step, batch, ms_per_step, table_bytes,
+                                           "algorithmic bytes per launch = %d B per transaction (64 B x %d proof-specific terms + 32 B x "
+                                           "%d generator scalars) x the %d transactions a launch processes" % (alg_step // batch, n_dyn, n_static, batch))
+        line["setup"] = {"table_build_ms": round(table_s * 1e3, 1), "table_bytes": table_bytes,
+                         "note": "one-time per generator set (generators + fixed-base tables, zkgpu_pointset_build_tables); not in `value`"}
+        line["kernel_ms_in_flight"] = {k: round(x, 4) for k, x in sorted(in_flight_ms.items())}
+        line["kernel_ms_solo"] = {k: round(x, 4) for k, x in sorted(solo.items())}
+        line["host_submit_ms_per_step"] = round(submit_ms, 4)
         if not args.lean:
-            # proof bytes -> accept bits, host half included (Merlin replay etc. on the host cores)
-            v = w["verifier"]
+            ps = gens.points
+            # the multiscalar-multiplication boundary alone: scalars prepared beforehand by the product's host verifier
+            hv = Verifier(ctx, gens, host_threads=host_threads)
             t0 = time.perf_counter()
-            bm_e2e = v.verify_bitmap(w["txs"], w["r_bytes"])
-            e2e_s = time.perf_counter() - t0
-            assert bm_e2e == bm
-            # the same call with its inputs in HOST memory (PCIe copies + python marshalling included)
-            packed_com = b"".join(t.commitments for t in w["txs"])
-            packed_proofs = b"".join(t.proof for t in w["txs"])
-            n_e2e = 6 * len(ctxs)
-            def submit_host(c):
-                gv.submit_packed_gpu(tx0.n_in, tx0.n_out, batch, packed_com, packed_proofs, proof_len, w["r_bytes"], ctx=c)
-            assert run_steps(len(ctxs), submit_host, gather=False) == bm
-            t0 = time.perf_counter()
-            outs = [run_steps(n_e2e, submit_host, gather=False)]
-            e2e_gpu_s = (time.perf_counter() - t0) / n_e2e
-            assert all(o == bm for o in outs)
-            # the multiscalar-multiplication boundary alone (scalars prepared beforehand by the host verifier)
-            assert run_steps(len(ctxs), submit_msm_only, gather=False) == bm
+            prep = hv.prepare(ctxs_txs, r_bytes)
+            prep_s = time.perf_counter() - t0
+            d_dyn_sc, d_dyn_pt, d_st_sc = to_dev(prep["dyn_sc"]), to_dev(prep["dyn_pt"]), to_dev(prep["st_sc"])
+            d_st_idx = torch.tensor(prep["st_idx"], dtype=torch.int32, device=dev)
+            d_dyn_off = torch.tensor(prep["dyn_off"], dtype=torch.int64, device=dev)
+            d_st_off = torch.tensor(prep["st_off"], dtype=torch.int64, device=dev)
+
+            def submit_msm_only(c):
+                c.verify_batch_ps_submit_dev(ps, batch, d_dyn_sc, d_dyn_pt, d_dyn_off, batch * n_dyn,
+                                             d_st_sc, d_st_idx, d_st_off, batch * n_static)
+            wf = [int(x) for x in prep["wellformed"]]
+            want_msm = bitmap_of([e for e in expected])
+            assert all(wf)
+            assert run_steps(len(ctxs), submit_msm_only, gather=False) == want_msm
             t0 = time.perf_counter()
             run_steps(args.steps, submit_msm_only, gather=False)
             msm_only_s = (time.perf_counter() - t0) / args.steps
+            # proof bytes -> accept bits with the verifier head on host threads
+            t0 = time.perf_counter()
+            bm_e2e = hv.verify_bitmap(ctxs_txs, r_bytes)
+            e2e_s = time.perf_counter() - t0
+            assert bm_e2e == bm
+            # the device path fed from HOST memory (PCIe copies + python marshalling included)
+            packed_com = b"".join(t[2] for t in txs)
+            packed_proofs = b"".join(t[3] for t in txs)
+            n_e2e = 6 * len(ctxs)
+
+            def submit_host(c):
+                gv.submit_packed_gpu(n_in, n_out, batch, packed_com, packed_proofs, proof_len, r_bytes, ctx=c)
+            assert run_steps(len(ctxs), submit_host, gather=False) == bm
+            t0 = time.perf_counter()
+            assert run_steps(n_e2e, submit_host, gather=False) == bm
+            e2e_gpu_s = (time.perf_counter() - t0) / n_e2e
             # the same complete verification with every transaction checked on its own (no group checks)
             for c in ctxs:
                 c.set_group_size(1)
@@ -467,84 +556,180 @@ def main():
             per_tx_s = (time.perf_counter() - t0) / args.steps
             for c in ctxs:
                 c.set_group_size(args.group)
-        line = {
-            "metric": "ZkVM tx verifications/sec (batch)",
-            "value": round(batch * world * args.steps / elapsed, 1),
-            "unit": "tx/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32 limb pairs of radix-2^51 (v_mad_u64_u32)",
-            "data": "synthetic: 64 real R1CS proofs of the 2-in/2-out cloak statement (committed fixture), "
-                    "each verified under per-transaction verifier randomness; ~1.5% corrupted",
-            "config": {"workload": "batch of %d 2-in/2-out cloak tx per GPU, complete r1cs::Verifier::verify on the device "
-                                   "from commitments + R1CSProof bytes + verifier randomness resident in HBM: Merlin "
-                                   "replay, verification scalars (IPA s vector, constraint flattening), decompression, "
-                                   "the 549-term mega_check MSM (n=256, k=8, m=8; 514 terms on shared generators), "
-                                   "identity test -> accept bitmap" % batch,
-                       "tx_per_gpu": batch, "terms_per_tx": N_DYN + N_STATIC, "window_bits": wbits,
-                       "generator_table_bits": tbits, "calls_in_flight": len(ctxs), "group_size": args.group,
-                       "parallelism": "tx-sharded x%d, RCCL all-gather of accept bitmaps" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
-                         "avg_launch_ms_solo": round(solo_ms, 4),
-                         "achieved_solo": round(alg_bytes / (solo_ms * 1e-3) / 1e9, 3),
-                         "note": "avg_launch_ms is measured with %d verify calls in flight (kernels of different "
-                                 "calls share the chip); *_solo is the same kernel alone" % len(ctxs),
-                         "binding_resource": "random 96-B gathers from the generator tables (one per mixed addition, "
-                                             "no reuse: %.1f GB of tables) and integer VALU (v_mad_u64_u32); "
-                                             "not streaming HBM bandwidth" % (int(ctx.lib.zkgpu_pointset_table_bytes(w["gens"].points.h)) / 1e9),
-                         "table_gather": {"bytes_per_launch": int(info["madds"] * 96),
-                                          "GBs_solo": round(info["madds"] * 96 / (solo_ms * 1e-3) / 1e9, 1),
-                                          "frac_of_hbm_peak_solo": round(info["madds"] * 96 / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                         "valu_int": {"achieved_Gmad_s": round(mads / (solo_ms * 1e-3) / 1e9, 1),
-                                      "peak_Gmad_s": MAD_PEAK_GOPS,
-                                      "frac": round(mads / (solo_ms * 1e-3) / 1e9 / MAD_PEAK_GOPS, 4),
-                                      "basis": "solo launch"}},
-            "kernel_ms_per_step": {k: round(x, 4) for k, x in sorted(kern_ms.items())},
-            "kernel_ms_solo": {k: round(x, 4) for k, x in sorted(solo.items())},
-            "kernel_ms_total_per_step": round(total_kernel_ms, 4),
-            "host_submit_ms_per_step": round(submit_ms, 4),
-            "per_tx_checks": {"tx_per_s": round(batch / per_tx_s, 1), "ms_per_step": round(per_tx_s * 1e3, 4),
-                              "note": "the same step with zkgpu_set_group_size(1): 1024 independent 549-term multiscalar "
-                                      "multiplications instead of %d group checks + individual re-checks of the groups "
-                                      "that hold a bad transaction" % ((batch + max(args.group, 1) - 1) // max(args.group, 1))},
-            "msm_boundary": {"tx_per_s": round(batch / msm_only_s, 1), "ms_per_step": round(msm_only_s * 1e3, 4),
-                             "note": "zkgpu_verify_batch_ps_dev alone: decompress + MSM + identity test on scalars "
-                                     "prepared beforehand (the argument list of dalek's mega_check resident in HBM)"},
-            "host_memory": {"gpu_resident_tx_per_s": round(batch / e2e_gpu_s, 1),
-                            "host_prepared_tx_per_s": round(batch / e2e_s, 1), "host_threads": host_threads,
-                            "host_prepare_ms_per_batch": round(w["prepare_s"] * 1e3, 2),
-                            "note": "proof bytes in host memory -> accept bits, PCIe copies and python marshalling "
-                                    "included.  gpu_resident: zkgpu_cloak_verify_batch_gpu (everything after the copy on "
-                                    "the device).  host_prepared: zkgpu_cloak_verify_batch (transcript replay and scalar "
-                                    "preparation on %d host threads, host-bound).  Neither is `value`." % host_threads},
-        }
-        if args.lean:
-            for key in ("per_tx_checks", "msm_boundary", "host_memory"):
-                line.pop(key, None)
-        if world == 1 and not args.no_cpu and not args.lean:
-            line["cpu_baseline"] = cpu_baseline(ctx, w, bm, batch)
-        if world == 1 and not args.no_msm and not args.lean:
-            line["prover"] = prover_microbench(ctx, w, host_threads)
-            if "cpu_baseline" in line:
-                line["prover"]["cpu_oracle_proofs_per_s"] = line["cpu_baseline"].get("prover_proofs_per_s")
-        if world == 1 and not args.no_msm and not args.lean:
-            line["msm_2p20"] = msm_microbench(ctx, torch, dev)
-        print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+            line["per_tx_checks"] = {"tx_per_s": round(batch / per_tx_s, 1), "ms_per_step": round(per_tx_s * 1e3, 4),
+                                     "note": "the same step with zkgpu_set_group_size(1): every transaction's MSM on its own"}
+            line["msm_boundary"] = {"tx_per_s": round(batch / msm_only_s, 1), "ms_per_step": round(msm_only_s * 1e3, 4),
+                                    "note": "zkgpu_verify_batch_ps_submit_dev alone: decompress + MSM + identity test on scalars "
+                                            "prepared beforehand (the argument list of dalek's mega_check resident in HBM)"}
+            line["host_memory"] = {"gpu_resident_tx_per_s": round(batch / e2e_gpu_s, 1),
+                                   "host_prepared_tx_per_s": round(batch / e2e_s, 1), "host_threads": host_threads,
+                                   "host_prepare_ms_per_batch": round(prep_s * 1e3, 2),
+                                   "note": "proof bytes in host memory -> accept bits, PCIe copies and python marshalling included.  "
+                                           "gpu_resident: zkgpu_cloak_verify_submit (everything after the copy on the device).  "
+                                           "host_prepared: zkgpu_cloak_verify_batch (verifier head on %d host threads).  Neither is "
+                                           "`value`." % host_threads}
+            hv.close()
+            if world == 1 and not args.no_cpu:
+                line["cpu_baseline"] = cpu_baseline(txs, r_bytes, bits_of(bm, batch))
+            if world == 1 and not args.no_msm:
+                line["prover"] = prover_microbench(ctx, gens, host_threads)
+                line["msm_2p20"] = msm_microbench(ctx, torch, dev)
+        emit(line)
+    W.close()
     gv.close()
     for c in ctxs[1:]:
         c.close()
-    w["gens"].close()
+    gens.close()
     ctx.close()
+
+
+# ---- config 4: mixed-arity blocks sharded over the node -------------------------------------------
+def run_config4(args, W):
+    torch, rank, world = W.torch, W.rank, W.world
+    from gpu_util import mixed_block
+    from zkvm_amd import Context, ZkGpuError
+    from zkvm_amd.native import Comm, shard_cuts
+    from zkvm_amd.sharded import gather_bitmaps
+    from zkvm_amd.verifier import BlockVerifier, BulletproofGens, CloakTx
+    ctx = Context(W.local)
+    lib = ctx.lib
+    per_gpu = args.batch if args.batch != 1024 else 8192
+    total = per_gpu * world
+    # the whole batch is known to every rank (a block as every node of the network sees it); deterministic
+    txs = mixed_block(total, seed=SEED)
+    r_bytes = shake(b"config4 verifier-r", 64 * total)
+    shapes = [(t[0], t[1]) for t in txs]
+    cuts = shard_cuts(shapes, world)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    t0 = time.perf_counter()
+    gens = BulletproofGens(ctx, 512, table_bits=args.table_bits)
+    table_s = time.perf_counter() - t0
+    table_bytes = int(lib.zkgpu_pointset_table_bytes(gens.points.h))
+    bv = BlockVerifier(ctx, gens, batches_in_flight=args.inflight, chunk=args.chunk)
+    for i in range(bv.lanes()):
+        bv.lane(i).set_group_size(args.group)
+    mine = [CloakTx(*t) for t in txs[lo:hi]]
+    block = bv.block(mine, r_bytes[64 * lo: 64 * hi])          # this rank's shard, resident in HBM, grouped by shape
+    # the exchange step: RCCL behind the C ABI (zkgpu_comm); gloo when several ranks share one GPU
+    comm = None
+    if not W.share_gpu:
+        uid = W.broadcast_bytes(Comm.unique_id() if rank == 0 else b"", 128)
+        comm = Comm(ctx, rank, world, uid)
+    parts = [(cuts[i], cuts[i + 1]) for i in range(world)]
+
+    def step():
+        status, local = 0, b""
+        try:
+            local = bv.verify_block(block)
+        except ZkGpuError as e:
+            status = e.code
+        if comm is not None:
+            return comm.allgather_bitmap(cuts, local, status)
+        return gather_bitmaps(parts, local, status != 0, W.dist, None) if W.dist else local
+
+    whole = None
+    for _ in range(max(args.warmup, 1)):
+        whole = step()
+    W.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        whole = step()
+    W.barrier()
+    elapsed = W.max_over_ranks(time.perf_counter() - t0)
+    # expectation by construction: the corruptions of mixed_block reject, everything else is a valid proof;
+    # the -m gpu test compares the same construction bit by bit with the oracle
+    expected = [0 if i % 61 == 3 else 1 for i in range(total)]
+    assert whole == bitmap_of(expected), "whole-batch accept bitmap differs from the constructed expectation (rank %d)" % rank
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        counts = {}
+        for s in shapes:
+            counts["%dx%d" % s] = counts.get("%dx%d" % s, 0) + 1
+        shard_terms = [sum(sum(shape_terms(lib, *s)) for s in shapes[a:b]) for a, b in parts]
+        alg_step = algorithmic_bytes(lib, shapes[lo:hi])
+        # per-kernel durations: a second verifier with ONE lane, every kernel alone on the chip
+        solo_v = BlockVerifier(ctx, gens, batches_in_flight=1, chunk=args.chunk)
+        lane0 = solo_v.lane(0)
+        lane0.set_group_size(args.group)
+        sblock = solo_v.block(mine, r_bytes[64 * lo: 64 * hi])
+        solo_v.verify_block(sblock)
+        lane0.profile_reset()
+        lane0.set_serial(True)
+        lane0.profile(True)
+        reps = 2
+        for _ in range(reps):
+            assert solo_v.verify_block(sblock) == bitmap_of(expected[lo:hi])
+        lane0.profile(False)
+        lane0.set_serial(False)
+        prof = lane0.profile_read()
+        solo = {k: v[1] / v[0] for k, v in prof.items() if v[0]}
+        launches = {k: v[0] / reps for k, v in prof.items() if v[0]}
+        sblock.close()
+        solo_v.close()
+        line = common_line(args, W, total * args.steps / elapsed, elapsed,
+                           "synthetic: 160 real R1CS proofs (32 of each shape, committed fixture, oracle prover) drawn with a fixed "
+                           "seed, every transaction under its own verifier randomness; 1 in 61 corrupted (six kinds, every shape)",
+                           {"workload": "BASELINE configs[3]: %d mixed-arity cloak tx (%d per GPU; shapes 1x1, 1x2, 2x2, 3x3, 4x4), "
+                                        "sharded over %d GPU(s) by multiscalar-multiplication terms, each shard resident in HBM and "
+                                        "verified shape-grouped with batches in flight, RCCL all-gather of the accept bitmaps behind "
+                                        "the C ABI, whole bitmap checked on every rank" % (total, per_gpu, world),
+                            "tx_total": total, "tx_per_gpu": per_gpu, "per_shape": counts,
+                            "shard_tx": [b - a for a, b in parts], "shard_terms": shard_terms,
+                            "generator_table_bits": args.table_bits, "gens_capacity": 512, "calls_in_flight": bv.lanes(),
+                            "chunk": args.chunk or 2048, "group_size": args.group,
+                            "exchange": "gloo (ranks share one GPU)" if W.share_gpu else "ncclAllGather via zkgpu_comm_allgather_bitmap",
+                            "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
+                            "parallelism": "tx-sharded x%d" % world})
+        line["roofline"] = roofline_object(solo, launches, {}, alg_step, hi - lo, ms_per_step, table_bytes,
+                                           "rank 0's shard: %d transactions, %d algorithmic bytes (64 B per proof-specific term + 32 B "
+                                           "per generator scalar, per shape)" % (hi - lo, alg_step))
+        line["setup"] = {"table_build_ms": round(table_s * 1e3, 1), "table_bytes": table_bytes,
+                         "note": "one table set for every shape up to 4x4 (512 + 512 generators); not in `value`"}
+        line["kernel_ms_solo"] = {k: round(x, 4) for k, x in sorted(solo.items())}
+        if not args.lean:
+            # the same shard handed over in HOST memory (grouping, PCIe copies, python marshalling included)
+            t0 = time.perf_counter()
+            hb = bv.verify(mine, r_bytes[64 * lo: 64 * hi])
+            host_s = time.perf_counter() - t0
+            assert hb == bitmap_of(expected[lo:hi])
+            line["host_memory"] = {"tx_per_s": round((hi - lo) / host_s, 1),
+                                   "note": "zkgpu_verifier_verify on rank 0's shard from host memory; not `value`"}
+            if world == 1 and not args.no_cpu:
+                line["cpu_baseline"] = cpu_baseline(txs[lo:hi], r_bytes[64 * lo: 64 * hi], bits_of(whole, total)[lo:hi])
+        emit(line)
+    W.close()
+    block.close()
+    if comm is not None:
+        comm.close()
+    bv.close()
+    gens.close()
+    ctx.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4),
+                    help="2: BASELINE configs[1], 1024 2x2 tx per GPU (default, the headline); 4: configs[3], mixed arity, sharded")
+    ap.add_argument("--batch", type=int, default=1024, help="transactions per GPU (config 4: default 8192)")
+    ap.add_argument("--table-bits", type=int, default=16, help="window width of the fixed-base generator tables")
+    ap.add_argument("--inflight", type=int, default=6, help="batches in flight per GPU")
+    ap.add_argument("--group", type=int, default=16, help="transactions per group check (1 = every transaction on its own)")
+    ap.add_argument("--chunk", type=int, default=0, help="config 4: transactions per batch in flight (0 = library default)")
+    ap.add_argument("--lean", action="store_true", help="the timed steps and the solo pass only (what tools/profile_bench.sh profiles)")
+    ap.add_argument("--solo", action="store_true", help="config 2: only serial steps, every kernel alone on the chip (for rocprofv3 --stats)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-msm", action="store_true", help="skip the prover and 2^20 MSM legs")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.config == 2 else 20
+    if args.warmup is None:
+        args.warmup = 10 if args.config == 2 else 3
+    W = World(args)
+    (run_config2 if args.config == 2 else run_config4)(args, W)
 
 
 if __name__ == "__main__":

@@ -287,6 +287,9 @@ int zkgpu_verifier_create(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t gens_
 void zkgpu_verifier_destroy(zkgpu_verifier *v);
 int zkgpu_verifier_set_chunk(zkgpu_verifier *v, size_t transactions);
 int zkgpu_verifier_lanes(const zkgpu_verifier *v);
+/* context of lane i (0 = the one given to zkgpu_verifier_create), for zkgpu_set_group_size and the
+ * measurement hooks below; owned by the verifier */
+zkgpu_ctx *zkgpu_verifier_lane(zkgpu_verifier *v, int i);
 const char *zkgpu_verifier_last_error(const zkgpu_verifier *v);
 int zkgpu_verifier_verify(zkgpu_verifier *v, size_t batch, const uint32_t *n_in, const uint32_t *n_out,
                           const uint8_t *commitments, const uint8_t *proofs, const uint64_t *proof_offsets,

@@ -167,6 +167,12 @@ int zkgpu_verifier_set_chunk(zkgpu_verifier* v, size_t transactions) {
 
 int zkgpu_verifier_lanes(const zkgpu_verifier* v) { return v ? (int)v->lanes.size() : 0; }
 
+// the context of lane i (0 = the one the verifier was created on): for the measurement hooks
+// (zkgpu_profile_*, zkgpu_set_serial, zkgpu_set_group_size); owned by the verifier
+zkgpu_ctx* zkgpu_verifier_lane(zkgpu_verifier* v, int i) {
+  return (v && i >= 0 && i < (int)v->lanes.size()) ? v->lanes[(size_t)i] : nullptr;
+}
+
 const char* zkgpu_verifier_last_error(const zkgpu_verifier* v) { return v ? v->last_error.c_str() : ""; }
 
 uint64_t zkgpu_cloak_msm_terms(uint32_t n_in, uint32_t n_out) { return cloak_msm_terms(n_in, n_out); }

@@ -114,6 +114,8 @@ def load_library():
     lib.zkgpu_verifier_destroy.restype = None
     lib.zkgpu_verifier_set_chunk.argtypes = [vp, sz]
     lib.zkgpu_verifier_lanes.argtypes = [vp]
+    lib.zkgpu_verifier_lane.argtypes = [vp, C.c_int]
+    lib.zkgpu_verifier_lane.restype = vp
     lib.zkgpu_verifier_last_error.argtypes = [vp]
     lib.zkgpu_verifier_last_error.restype = C.c_char_p
     lib.zkgpu_verifier_verify.argtypes = [vp, sz, u32p, u32p, u8p, u8p, u64p, u8p, u8p]
@@ -186,12 +188,16 @@ class PointSet:
 class Context:
     """One GPU, one HIP stream.  Use one Context per process / per GPU."""
 
-    def __init__(self, device: int = 0, _parent: Optional["Context"] = None):
+    def __init__(self, device: int = 0, _parent: Optional["Context"] = None, _borrowed: Optional[int] = None):
         self.lib = load_library()
         self.h = C.c_void_p()
         self.parent = _parent          # a fork shares its parent's chip-filling streams: keep the parent alive
         self._forks = weakref.WeakSet()
         self._pending_batch = 0
+        self._borrowed = _borrowed is not None
+        if self._borrowed:             # a context owned by a zkgpu_verifier: a view for the measurement hooks
+            self.h = C.c_void_p(_borrowed)
+            return
         if _parent is not None:
             rc = self.lib.zkgpu_ctx_fork(_parent.h, C.byref(self.h))
         else:
@@ -239,6 +245,9 @@ class Context:
         return bm.raw[:n]
 
     def close(self) -> None:
+        if self.h and self._borrowed:
+            self.h = C.c_void_p()
+            return
         if self.h:
             for f in list(self._forks):     # forks borrow this context's streams: they go first
                 f.close()

@@ -149,6 +149,10 @@ class BlockVerifier:
     def lanes(self) -> int:
         return int(self.lib.zkgpu_verifier_lanes(self.h))
 
+    def lane(self, i: int) -> Context:
+        """zkgpu_verifier_lane: lane i's context (owned by the verifier) for set_group_size / the profile hooks."""
+        return Context(_borrowed=int(self.lib.zkgpu_verifier_lane(self.h, i)))
+
     def verify(self, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None) -> bytes:
         batch = len(txs)
         n_in, n_out, com, proofs, po = _marshal_block(txs, r_bytes)
