@@ -203,6 +203,18 @@ int zkgpu_ctx_fork(zkgpu_ctx* parent, zkgpu_ctx** out);
  * r1cs::Verifier::verify of many proofs over one BulletproofGens.) */
 int zkgpu_set_group_size(zkgpu_ctx* ctx, int group);
 
+/* Transcript replay of the whole-proof paths: 0 automatic (default: one WAVEFRONT per transaction --
+ * Keccak-f with the state spread over the lanes, keccak_coop.hpp -- for batches of up to 4096
+ * transactions, where it shortens the batch's dependent chain; one LANE per transaction beyond, where
+ * throughput matters and latency is hidden), 1 always one lane, 2 always one wavefront.  Results are
+ * identical.  Forks inherit the setting.
+ * zkgpu_debug_coop_selftest: test hook -- the cross-lane primitives of the cooperative Keccak on given
+ * inputs (in: 3 x 64 words a, b, gather byte addresses; out: 8 x 64 words: row_ror:8(a), row_shr:1(a),
+ * row_shl:1(a), permlane16_swap(a, b) -> (a', b'), permlane32_swap(a, b) -> (a', b'), ds_bpermute(addr, a))
+ * and Keccak-f[1600] of n_states states (25 u64 each, in place), one wavefront per state. */
+int zkgpu_set_transcript_mode(zkgpu_ctx* ctx, int mode);
+int zkgpu_debug_coop_selftest(zkgpu_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t* states, size_t n_states);
+
 /* Measurement aid: with on != 0 the kernels of a batch run one after another on a single stream
  * (no overlap), so that the profile hooks report each kernel's duration alone on the chip. */
 int zkgpu_set_serial(zkgpu_ctx* ctx, int on);

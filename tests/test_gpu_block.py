@@ -121,16 +121,52 @@ def test_exchange_step_behind_the_abi(ctx, oracle):
         gens.close()
 
 
+def test_cooperative_keccak_primitives_and_permutation(ctx, oracle):
+    """keccak_coop.hpp on the hardware: every cross-lane primitive (DPP row_ror:8 / row_shr:1 / row_shl:1,
+    v_permlane16_swap, v_permlane32_swap, ds_bpermute) behaves as the host emulation assumes, and Keccak-f[1600] with
+    one state per wavefront equals the oracle's on random states."""
+    import ctypes as C
+    import random
+    rng = random.Random(5)
+    a = [rng.getrandbits(32) for _ in range(64)]
+    b = [rng.getrandbits(32) for _ in range(64)]
+    addr = [4 * rng.randrange(64) for _ in range(64)]
+    states = [[0] * 25] + [[rng.getrandbits(64) for _ in range(25)] for _ in range(200)]
+    out, got = ctx.coop_selftest(a, b, addr, states)
+    assert out[0] == [a[(i & ~15) | ((i + 8) & 15)] for i in range(64)]                      # row_ror:8
+    assert out[1] == [a[i - 1] if i & 15 else a[i] for i in range(64)]                       # row_shr:1 (row-lane 0 keeps its value)
+    assert out[2] == [a[i + 1] if (i & 15) != 15 else a[i] for i in range(64)]               # row_shl:1
+    x, y = list(a), list(b)
+    for row in (1, 3):
+        for i in range(16):
+            x[16 * row + i], y[16 * (row - 1) + i] = y[16 * (row - 1) + i], x[16 * row + i]
+    assert out[3] == x and out[4] == y                                                       # v_permlane16_swap
+    x, y = list(a), list(b)
+    for i in range(32):
+        x[32 + i], y[i] = y[i], x[32 + i]
+    assert out[5] == x and out[6] == y                                                       # v_permlane32_swap
+    assert out[7] == [a[addr[i] // 4] for i in range(64)]                                    # ds_bpermute
+    lib = oracle.load()
+    for st, g in zip(states, got):
+        w = (C.c_uint64 * 25)(*st)
+        lib.keccak_f1600(w)
+        assert list(w) == g
+
+
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("group", [1, 16])
-def test_device_verifier_head_bytes_equal_oracle(ctx, gens512, oracle, group):
+def test_device_verifier_head_bytes_equal_oracle(ctx, gens512, oracle, group, mode):
     """zkgpu_debug_read after a batch: the challenges of the device-side transcript replay (k_transcript) equal
     the oracle transcript's byte for byte, and every scalar of the verification equation the device prepares
     (k_prepare) equals the oracle's times the documented factor c' = rho y^(pn-1) prod u_j^2 -- for 1x1, 1x2, 2x2,
-    3x3 and 4x4, transactions checked alone (rho = 1) and in groups (rho = r^2)."""
+    3x3 and 4x4, transactions checked alone (rho = 1) and in groups (rho = r^2), with the transcript replayed one
+    lane per transaction (k_transcript) and one wavefront per transaction (k_tape_gather, k_transcript_coop,
+    k_challenges)."""
     from zkvm_amd.verifier import Verifier
     fix = load_mixed_fixture()
     v = Verifier(ctx, gens512)
     ctx.set_group_size(group)
+    ctx.set_transcript_mode(mode)
     try:
         for (n_in, n_out), recs in sorted(fix.items()):
             batch = 5
@@ -170,8 +206,14 @@ def test_device_verifier_head_bytes_equal_oracle(ctx, gens512, oracle, group):
                         g = int.from_bytes(got[(i * cnt + j) * 32: (i * cnt + j + 1) * 32], "little")
                         w = int.from_bytes(want[32 * j: 32 * j + 32], "little") * cp % L
                         assert g == w, (n_in, n_out, i, name, j)
+            # a malformed scalar, an identity point and a zeroed commitment: rejected in this mode too
+            bad = bytearray(proofs)
+            bad[1 + 32 * 11: 1 + 32 * 12] = L.to_bytes(32, "little")                         # t_x = l in transaction 0
+            bad[plen + 1 + 32 * 6: plen + 1 + 32 * 7] = bytes(32)                             # T_1 = identity in transaction 1
+            assert bits(v.verify_packed_gpu(n_in, n_out, batch, com, bytes(bad), plen, r), batch) == [0, 0, 1, 1, 1]
     finally:
         ctx.set_group_size(16)
+        ctx.set_transcript_mode(0)
         v.close()
 
 

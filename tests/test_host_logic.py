@@ -177,3 +177,40 @@ def test_product_prover_equals_oracle_prover(host, oracle, shape, cap):
         assert com.raw == want_com
         assert proof.raw[: plen.value] == want_proof
         assert oracle.cloak_verify(com.raw, n_in, n_out, proof.raw[: plen.value], bytes(range(64)))
+
+
+def test_cooperative_keccak_emulation_equals_keccak(host, oracle):
+    """keccak_coop.hpp -- one Keccak state spread over a wavefront (DPP row shifts, row swaps, ds_bpermute),
+    run on the host with emulated cross-lane primitives -- against the oracle's Keccak-f[1600]."""
+    lib = oracle.load()
+    rng = random.Random(11)
+    for it in range(40):
+        st = [0] * 25 if it == 0 else [rng.getrandbits(64) for _ in range(25)]
+        a = (C.c_uint64 * 25)(*st)
+        b = (C.c_uint64 * 25)(*st)
+        host.zkhost_keccak_coop(a)
+        lib.keccak_f1600(b)
+        assert list(a) == list(b), it
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 2), (2, 2), (3, 3), (4, 4)])
+def test_cooperative_transcript_segments_equal_tape(host, shape):
+    """The tape regrouped into segments for k_transcript_coop (constants + byte map per permutation, challenges
+    leaving at segment starts), run through the emulated wavefront: same challenges as the tape interpreter and
+    the Transcript class, for every shape of the mixed fixture."""
+    import struct
+    raw = open(os.path.join(ROOT, "tests", "golden", "cloak_mixed.bin"), "rb").read()
+    pos, fix = 12, {}
+    for _ in range(struct.unpack("<I", raw[8:12])[0]):
+        count, n_in, n_out, plen = struct.unpack("<IIII", raw[pos:pos + 16]); pos += 16
+        w = 64 * (n_in + n_out)
+        fix[(n_in, n_out)] = [(raw[pos + (w + plen) * i: pos + (w + plen) * i + w], raw[pos + (w + plen) * i + w: pos + (w + plen) * (i + 1)])
+                              for i in range(count)]
+        pos += (w + plen) * count
+    n_in, n_out = shape
+    for com, proof in fix[shape][:3]:
+        a, b, c = (C.create_string_buffer(32 * 64) for _ in range(3))
+        n = host.zkhost_tape_challenges(n_in, n_out, com, proof, C.c_size_t(len(proof)), a, b, C.c_size_t(64))
+        n2 = host.zkhost_coop_challenges(n_in, n_out, com, proof, C.c_size_t(len(proof)), c, C.c_size_t(64))
+        assert n == n2 > 5
+        assert a.raw[: 32 * n] == b.raw[: 32 * n] == c.raw[: 32 * n]

@@ -6,6 +6,7 @@
 #include "curve.hpp"
 #include "r1cs_prover.hpp"
 #include "transcript_tape.hpp"
+#include "keccak_coop.hpp"
 
 #include <array>
 #include <map>
@@ -62,6 +63,69 @@ int zkhost_cloak_prepare(const uint8_t* commitments, size_t n_in, size_t n_out, 
   std::memcpy(static_scalars, m.static_scalars.data(), m.static_scalars.size());
   std::memcpy(static_index, m.static_index.data(), m.static_index.size() * 4);
   return 0;
+}
+
+// Keccak-f[1600] through the emulated wavefront of keccak_coop.hpp (the algorithm k_transcript_coop runs)
+void zkhost_keccak_coop(uint64_t state[25]) { coop::keccak_f1600_emulated(state); }
+
+// The cooperative form of the transcript on the host: the tape regrouped into segments
+// (build_coop_segments), each word's absorbed bytes gathered as k_tape_gather does, the state spread over
+// an emulated wavefront as in k_transcript_coop.  out: 32-byte challenge scalars in the order of
+// zkhost_tape_challenges; returns their count or -1.
+int zkhost_coop_challenges(uint32_t n_in, uint32_t n_out, const uint8_t* commitments, const uint8_t* proof,
+                           size_t proof_len, uint8_t* out, size_t capacity) {
+  const CloakPlan plan = PlanBuilder::build(n_in, n_out);
+  const uint32_t m = plan.m, k = plan.k, n_chal2 = (uint32_t)plan.chal_label.size();
+  if (proof_len != 1 + 32ull * (16 + 2 * k)) return -1;
+  const uint32_t ch_fixed = 14;
+  Transcript tr("ZkVM.r1cs");
+  tr.append_message("dom-sep", (const uint8_t*)"r1cs v1", 7);
+  uint32_t init[52];
+  tr.export_state(init);
+  const std::vector<uint32_t> tape = build_r1cs_verifier_tape(init[50], init[51], m, plan.chal_label, k, plan.pn, ch_fixed);
+  const CoopSegments segs = build_coop_segments(tape, m);
+  if (!segs.n_seg()) return -1;
+  using KC = coop::KeccakCoop<coop::HostTraits>;
+  const auto consts = coop::host_consts();
+  coop::LaneVec lo, hi;
+  for (uint32_t i = 0; i < 64; ++i) {
+    const coop::KcLane kl = coop::kc_lane(i);
+    lo.l[i] = kl.live ? init[2 * kl.q] : 0;
+    hi.l[i] = kl.live ? init[2 * kl.q + 1] : 0;
+  }
+  std::map<uint32_t, std::vector<uint8_t>> got;
+  for (uint32_t sgm = 0; sgm < segs.n_seg(); ++sgm) {
+    const uint32_t info = segs.info[sgm], slot = info & 0xffffu;
+    if (slot) {
+      std::vector<uint8_t> bytes(64);
+      for (uint32_t i = 0; i < 64; ++i) {
+        const coop::KcLane kl = coop::kc_lane(i);
+        if (kl.primary && kl.q < 8) { std::memcpy(&bytes[8 * kl.q], &lo.l[i], 4); std::memcpy(&bytes[8 * kl.q + 4], &hi.l[i], 4); }
+        if (kl.live && kl.q < 8) { lo.l[i] = 0; hi.l[i] = 0; }
+      }
+      got[slot - 1] = bytes;
+    }
+    for (uint32_t i = 0; i < 64; ++i) {
+      const coop::KcLane kl = coop::kc_lane(i);
+      if (!kl.live) continue;
+      uint64_t w = (uint64_t)segs.consts[sgm * 50 + 2 * kl.q] | ((uint64_t)segs.consts[sgm * 50 + 2 * kl.q + 1] << 32);
+      for (int b = 0; b < 8; ++b) {
+        const uint32_t idx = segs.map[sgm * 200 + 8 * kl.q + b];
+        if (idx) { const uint32_t j = idx - 1; w ^= (uint64_t)(j < 32 * m ? commitments[j] : proof[1 + j - 32 * m]) << (8 * b); }
+      }
+      lo.l[i] ^= (uint32_t)w; hi.l[i] ^= (uint32_t)(w >> 32);
+    }
+    if (info >> 31) KC::permute(lo, hi, consts);
+  }
+  std::vector<uint32_t> order = {0, 1, 2, 3, 4};
+  for (uint32_t j = 0; j < n_chal2; ++j) order.push_back(ch_fixed + j);
+  for (uint32_t j = 0; j < k; ++j) order.push_back(ch_fixed + n_chal2 + j);
+  if (order.size() > capacity) return -1;
+  for (size_t i = 0; i < order.size(); ++i) {
+    if (!got.count(order[i])) return -1;
+    Scalar::from_wide(got[order[i]].data()).to_bytes(out + 32 * i);
+  }
+  return (int)order.size();
 }
 
 // The device-side transcript tape (transcript_tape.hpp) against the Transcript class on the same

@@ -14,6 +14,7 @@
 //   10 e_blinding  11 a  12 b  13 rho (weight of this transaction in a group check, 1 when checked alone)
 //   | 14.. second-phase challenges | u_j | prod_{l != j} u_l^2
 #pragma once
+#include "keccak_coop.hpp"
 #include "merlin_dev.hpp"
 #include "sc_dev.hpp"
 #include "transcript_tape.hpp"
@@ -219,6 +220,247 @@ k_transcript(PrepShape sh, const uint32_t* __restrict__ init_state /*50 words*/,
     }
   }
   if (live && !ok) atomicAnd(&wellformed[tx], 0u);
+}
+
+// ---- the cooperative transcript: k_tape_gather + k_transcript_coop + k_challenges ------------------
+// The same tape with ONE Keccak state per WAVEFRONT (keccak_coop.hpp) instead of one per lane: a
+// 1024-transaction batch is 1024 wavefronts walking ~36 permutations of ~36 instructions per round,
+// instead of 16 wavefronts walking ~36 permutations of ~180.  Three launches:
+//   k_tape_gather      fully parallel: per (transaction, segment, state word) the 8 bytes that segment
+//                      XORs into that word (constants | proof / commitment bytes), as one u64
+//   k_transcript_coop  one wavefront per transaction: [challenge bytes out] ^= absorb, permute; no
+//                      scalar arithmetic, no byte fiddling, one 8-byte load per lane and segment
+//   k_challenges       two wavefronts per transaction: 64-byte challenges -> scalars mod l (one lane
+//                      each), then the serial power chains k_prepare needs, one chain per lane
+// Together they write exactly what k_transcript writes (tests compare the bytes with the oracle's).
+struct DevKcTraits {
+  using V = uint32_t;
+  static __device__ __forceinline__ V splat(uint32_t x) { return x; }
+  static __device__ __forceinline__ V xor2(V a, V b) { return a ^ b; }
+  static __device__ __forceinline__ V xor3(V a, V b, V c) { return a ^ b ^ c; }
+  static __device__ __forceinline__ V chi(V a, V b, V c) { return a ^ (~b & c); }
+  static __device__ __forceinline__ V xor_and(V a, V b, V m) { return a ^ (b & m); }
+  static __device__ __forceinline__ V and_(V a, V m) { return a & m; }
+  static __device__ __forceinline__ V sel(V m, V a, V b) { return (a & m) | (b & ~m); }
+  static __device__ __forceinline__ V alignbit(V hi, V lo, V s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
+  static __device__ __forceinline__ V ror8(V v) { return (V)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false); }
+  static __device__ __forceinline__ V shr1(V v) { return (V)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false); }
+  static __device__ __forceinline__ V shl1(V v) { return (V)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x101, 0xf, 0xf, false); }
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ void swap16(V& a, V& b) { const u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = r.x; b = r.y; }
+  static __device__ __forceinline__ void swap32(V& a, V& b) { const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = r.x; b = r.y; }
+  static __device__ __forceinline__ V gather(V addr, V v) { return (V)__builtin_amdgcn_ds_bpermute((int)addr, (int)v); }
+};
+
+// Test hook: the cross-lane primitives exactly as the cooperative Keccak uses them, so that a GPU test can
+// compare the hardware's semantics with the host emulation (coop::HostTraits) primitive by primitive, and
+// one Keccak-f per wavefront on caller-supplied states.  out: [8][64] words | states permuted in place.
+__global__ void __launch_bounds__(64)
+k_coop_selftest(const uint32_t* __restrict__ in /*[3][64]: a, b, addr*/, uint32_t* __restrict__ out /*[8][64]*/,
+                uint2* __restrict__ states /*[n][25]*/, uint32_t n_states) {
+  const uint32_t lane = threadIdx.x;
+  if (blockIdx.x == 0) {
+    const uint32_t a = in[lane], b = in[64 + lane], addr = in[128 + lane];
+    out[lane] = DevKcTraits::ror8(a);
+    out[64 + lane] = DevKcTraits::shr1(a);
+    out[128 + lane] = DevKcTraits::shl1(a);
+    uint32_t x = a, y = b;
+    DevKcTraits::swap16(x, y);
+    out[192 + lane] = x; out[256 + lane] = y;
+    x = a; y = b;
+    DevKcTraits::swap32(x, y);
+    out[320 + lane] = x; out[384 + lane] = y;
+    out[448 + lane] = DevKcTraits::gather(addr, a);
+  }
+  const coop::KcLane k = coop::kc_lane(lane);
+  coop::KeccakCoop<DevKcTraits>::Consts c = {k.live, k.rot_swap, k.rot_t, k.src[0], k.src[1], k.src[2], k.iota};
+  for (uint32_t i = blockIdx.x; i < n_states; i += gridDim.x) {
+    uint2 w = k.live ? states[(uint64_t)i * 25 + k.q] : make_uint2(0, 0);
+    coop::KeccakCoop<DevKcTraits>::permute(w.x, w.y, c);
+    if (k.primary) states[(uint64_t)i * 25 + k.q] = w;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_tape_gather(PrepShape sh, uint32_t n_seg, const uint32_t* __restrict__ seg_const /*[n_seg][50]*/,
+              const uint16_t* __restrict__ seg_map /*[n_seg][200]*/, const uint32_t* __restrict__ com,
+              const uint32_t* __restrict__ pw, uint32_t batch, uint2* __restrict__ absorb /*[B][n_seg][25]*/) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t per_tx = n_seg * 25;
+  if (g >= (uint64_t)batch * per_tx) return;
+  const uint32_t tx = (uint32_t)(g / per_tx), rem = (uint32_t)(g % per_tx), seg = rem / 25, q = rem % 25;
+  const uint4 mp4 = *reinterpret_cast<const uint4*>(seg_map + (uint64_t)seg * 200 + 8 * q);
+  const uint32_t mp[4] = {mp4.x, mp4.y, mp4.z, mp4.w};
+  const uint32_t* c = com + (uint64_t)tx * sh.m * 8;
+  const uint32_t* p = pw + (uint64_t)tx * sh.proof_words;
+  const uint32_t n_com_bytes = 32 * sh.m;
+  uint32_t lo = seg_const[seg * 50 + 2 * q], hi = seg_const[seg * 50 + 2 * q + 1];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const uint32_t idx = (mp[b >> 1] >> (16 * (b & 1))) & 0xffffu;
+    if (idx) {
+      const uint32_t i = idx - 1;
+      const uint32_t word = i < n_com_bytes ? c[i >> 2] : p[(i - n_com_bytes) >> 2];
+      const uint32_t byte = (word >> (8 * (i & 3))) & 0xffu;
+      if (b < 4) lo ^= byte << (8 * b); else hi ^= byte << (8 * (b - 4));
+    }
+  }
+  absorb[g] = make_uint2(lo, hi);
+}
+
+__global__ void __launch_bounds__(64)
+k_transcript_coop(uint32_t n_seg, const uint32_t* __restrict__ seg_info, const uint32_t* __restrict__ init_state /*50 words*/,
+                  const uint2* __restrict__ absorb /*[B][n_seg][25]*/, uint32_t batch, uint32_t n_ch,
+                  uint32_t* __restrict__ raw /*[B][n_ch][16]*/) {
+  const uint32_t tx = blockIdx.x, lane = threadIdx.x;
+  if (tx >= batch) return;
+  const coop::KcLane k = coop::kc_lane(lane);
+  const coop::KeccakCoop<DevKcTraits>::Consts c = {k.live, k.rot_swap, k.rot_t, k.src[0], k.src[1], k.src[2], k.iota};
+  uint32_t lo = k.live ? init_state[2 * k.q] : 0, hi = k.live ? init_state[2 * k.q + 1] : 0;
+  const uint2* ab = absorb + (uint64_t)tx * n_seg * 25 + k.q;
+  const bool first8 = k.live && k.q < 8;           // state bytes 0..63: what a challenge squeezes
+  uint2 nxt = k.live ? ab[0] : make_uint2(0, 0);
+#pragma unroll 1
+  for (uint32_t seg = 0; seg < n_seg; ++seg) {
+    const uint32_t info = seg_info[seg];
+    const uint2 cur = nxt;
+    if (seg + 1 < n_seg && k.live) nxt = ab[(uint64_t)(seg + 1) * 25];      // in flight during the permutation
+    const uint32_t slot = info & 0xffffu;
+    if (slot) {
+      if (k.primary && k.q < 8) {
+        uint32_t* o = raw + ((uint64_t)tx * n_ch + (slot - 1)) * 16 + 2 * k.q;
+        o[0] = lo; o[1] = hi;
+      }
+      if (first8) { lo = 0; hi = 0; }
+    }
+    lo ^= cur.x; hi ^= cur.y;
+    if (info >> 31) coop::KeccakCoop<DevKcTraits>::permute(lo, hi, c);
+  }
+}
+
+// blockDim = 128: wavefront 0 reduces the challenges and runs the power chains, wavefront 1 the
+// well-formedness checks and the products of the inner-product challenges.
+__global__ void __launch_bounds__(128)
+k_challenges(PrepShape sh, const uint32_t* __restrict__ raw /*[B][n_ch][16]*/, const uint32_t* __restrict__ pw,
+             const uint32_t* __restrict__ rbytes, uint32_t batch, uint32_t* __restrict__ ch /*[B][n_ch_ext][8]*/,
+             uint32_t* __restrict__ wellformed, const uint32_t* __restrict__ mono_chal, const uint32_t* __restrict__ mono_pow,
+             uint32_t grouped) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];     // n_ch slots of 8 words
+  const uint32_t tx = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  if (tx >= batch) return;
+  const uint32_t* p = pw + (uint64_t)tx * sh.proof_words;
+  uint32_t* out = ch + (uint64_t)tx * sh.n_ch_ext * 8;
+  const uint32_t n2 = sh.n_chal2, k = sh.k;
+  // phase 1: every slot is the reduction of 64 little-endian bytes (8-word sources padded with zeros)
+  for (uint32_t s = t; s < sh.n_ch; s += nt) {
+    uint32_t w[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w[q] = 0;
+    const bool is_chal = s < 5 || (s >= (uint32_t)CH_FIXED && s < CH_FIXED + n2 + k);
+    const uint32_t* src = nullptr;
+    int words = 0;
+    if (is_chal) { src = raw + ((uint64_t)tx * sh.n_ch + s) * 16; words = 16; }
+    else if (s == 7 || s == 13) { src = rbytes + (uint64_t)tx * 16; words = 16; }
+    else if (s >= 8 && s <= 12) { src = s <= 10 ? p + 88 + 8 * (s - 8) : p + 112 + 16 * k + 8 * (s - 11); words = 8; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) if (q < words) w[q] = src[q];
+    scm v = scm_from_wide(w);
+    if (s == 13) {               // rho = r^2 inside a group check (1 when the transaction is checked alone, or r = 0)
+      v = grouped ? scm_sq(v) : scm_one();
+      uint32_t any = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) any |= v.v[q];
+      if (any == 0) v = scm_one();
+    }
+    if (words) { st_scm(lds + 8 * s, v); st_scm(out + 8 * s, v); }
+  }
+  __syncthreads();
+  uint32_t* sym = out + sh.n_ch * 8;
+  uint32_t* strides = sym + sh.n_mono * 8;
+  if (t < 64) {
+    // chains, one per lane: 0 the squarings of z, 1 those of y, 2 + j the monomial j (challenge^power).
+    // Uniform loop: acc = acc^2 [* base]; a chain stores what it needs as it goes.
+    const uint32_t n_chains = 2 + sh.n_mono;
+    uint32_t n_zs = 1;
+    while ((1u << n_zs) < sh.n_cons) ++n_zs;           // strides z^(2^L), L < n_zs
+    for (uint32_t base0 = 0; base0 < n_chains; base0 += 64) {
+      const uint32_t cid = base0 + t;
+      scm base = scm_one(), acc = scm_one();
+      uint32_t steps = 0, e = 0;
+      if (cid == 0) { ld_scm(base, lds + 8 * 1); acc = base; steps = n_zs - 1; st_scm(strides, acc); }
+      else if (cid == 1) { ld_scm(base, lds + 8 * 0); acc = base; steps = k ? k - 1 : 0; st_scm(strides + 16 * 8, acc); }
+      else if (cid < n_chains) {
+        const uint32_t j = cid - 2, mc = mono_chal[j];
+        e = mono_pow[j];
+        if (mc != 0xffffffffu && e != 0) {
+          ld_scm(base, lds + 8 * (CH_FIXED + mc));
+          acc = base;
+          steps = 31 - __clz(e);                        // bits below the top one
+        } else {
+          e = 0;
+        }
+      }
+      uint32_t max_steps = steps;
+#pragma unroll 1
+      for (int d = 32; d >= 1; d >>= 1) max_steps = max(max_steps, (uint32_t)__shfl_xor((int)max_steps, d));
+#pragma unroll 1
+      for (uint32_t i = 1; i <= max_steps; ++i) {
+        const bool on = i <= steps;
+        const scm sq = scm_sq(acc);
+        if (on) acc = sq;
+        const bool mul = on && cid >= 2 && ((e >> (steps - i)) & 1);
+        if (__any(mul)) { const scm m = scm_mul(acc, base); if (mul) acc = m; }
+        if (on && cid == 0) st_scm(strides + 8 * i, acc);
+        if (on && cid == 1) st_scm(strides + (16 + i) * 8, acc);
+      }
+      if (cid >= 2 && cid < n_chains) st_scm(sym + 8 * (cid - 2), acc);
+    }
+    return;
+  }
+  // wavefront 1
+  const uint32_t lane = t - 64;
+  bool ok = true;
+  if (lane == 0) {
+    // well-formedness: no identity among the proof points (A_I2, A_O2, S2 are the identity in single-phase
+    // proofs: not tested, as in the reference), canonical scalars
+    for (int i = 0; i < 11; ++i) ok &= (i >= 3 && i < 6) | !words_are_zero(p + 8 * i);
+    const uint32_t* sc3 = p + 88;
+    const uint32_t* lr = p + 112;
+    const uint32_t* ab = lr + 16 * k;
+    ok &= scm_is_canonical(sc3) & scm_is_canonical(sc3 + 8) & scm_is_canonical(sc3 + 16) & scm_is_canonical(ab) &
+          scm_is_canonical(ab + 8);
+    for (uint32_t j = 0; j < k; ++j) ok &= !words_are_zero(lr + 16 * j) & !words_are_zero(lr + 16 * j + 8);
+    ok &= !words_are_zero(lds + 0);                    // y = 0: the reference's inversion has no answer either
+  }
+  // products of the inner-product challenges u_j (lane j < k <= 16): prefix and suffix products by
+  // doubling steps, then P1 = prod u_j, U = P1^2, u_j^2 and prod_{l != j} u_l^2 = (prefix_{j-1} suffix_{j+1})^2
+  uint32_t* uj = lds + (CH_FIXED + n2) * 8;
+  uint32_t* uex = out + (CH_FIXED + n2 + k) * 8;
+  scm u = scm_one();
+  if (lane < k) { ld_scm(u, uj + 8 * lane); ok &= !words_are_zero(u.v); }
+  scm pre = u, suf = u;
+#pragma unroll 1
+  for (uint32_t d = 1; d < k; d <<= 1) {
+    scm a, b;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { a.v[q] = (uint32_t)__shfl_up((int)pre.v[q], d); b.v[q] = (uint32_t)__shfl_down((int)suf.v[q], d); }
+    const scm pa = scm_mul(pre, a), sb = scm_mul(suf, b);
+    if (lane >= d && lane < k) pre = pa;
+    if (lane + d < k) suf = sb;
+  }
+  scm pm, sp;                                           // prefix_{j-1}, suffix_{j+1}
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { pm.v[q] = (uint32_t)__shfl_up((int)pre.v[q], 1); sp.v[q] = (uint32_t)__shfl_down((int)suf.v[q], 1); }
+  if (lane == 0) pm = scm_one();
+  if (lane + 1 >= k) sp = scm_one();
+  const scm ex = scm_mul(pm, sp), ex2 = scm_sq(ex), u2 = scm_sq(u);
+  if (lane < k) { st_scm(strides + (32 + lane) * 8, u2); st_scm(uex + 8 * lane, ex2); }
+  if (k == 0 ? lane == 0 : lane == k - 1) {
+    const scm p1 = k ? pre : scm_one();
+    st_scm(out + 5 * 8, p1);
+    st_scm(out + 6 * 8, scm_sq(p1));
+  }
+  if (!__all(ok) && lane == 0) atomicAnd(&wellformed[tx], 0u);
 }
 
 // ---- k_prepare ------------------------------------------------------------------------------

@@ -154,6 +154,56 @@ inline std::vector<uint32_t> build_r1cs_verifier_tape(uint32_t pos, uint32_t pos
   return rec.finish();
 }
 
+// The same tape regrouped for the cooperative kernel (prep_kernels.hpp, k_transcript_coop: one Keccak state
+// spread over a wavefront): a SEGMENT is everything up to and including one permutation --
+//     [CHAL slot]  the 64 challenge bytes leave the state (always the first thing after a permutation)
+//     absorb       constant bytes and proof / commitment bytes XORed into the state, in any order
+//     [PERM]
+// info[s]   bit 31: the segment ends with a permutation; bits 0..15: 1 + challenge slot, 0 = none
+// consts    [n_seg][50] words XORed into the state
+// map       [n_seg][200]: per state byte 0 = nothing, else 1 + index of the byte absorbed there, counted
+//           in the concatenation (commitments, 32 m bytes | proof after its version byte)
+struct CoopSegments {
+  std::vector<uint32_t> info, consts;
+  std::vector<uint16_t> map;
+  uint32_t n_seg() const { return (uint32_t)info.size(); }
+};
+
+inline CoopSegments build_coop_segments(const std::vector<uint32_t>& tape, uint32_t m) {
+  CoopSegments out;
+  std::vector<uint32_t> c(50, 0);
+  std::vector<uint16_t> mp(200, 0);
+  uint32_t chal = 0;
+  bool dirty = false;
+  auto close = [&](bool perm) {
+    out.info.push_back((perm ? 0x80000000u : 0u) | chal);
+    out.consts.insert(out.consts.end(), c.begin(), c.end());
+    out.map.insert(out.map.end(), mp.begin(), mp.end());
+    c.assign(50, 0); mp.assign(200, 0); chal = 0; dirty = false;
+  };
+  for (size_t i = 0; i + 3 < tape.size(); i += 4) {
+    const uint32_t kind = tape[i], a = tape[i + 1], b = tape[i + 2], w = tape[i + 3];
+    if (kind == TAPE_XOR) {
+      c[a] ^= b; dirty = true;
+    } else if (kind == TAPE_DATA) {
+      const uint32_t pos = w & 0xffffu, n = w >> 16;
+      for (uint32_t q = 0; q < n; ++q) {
+        const uint32_t idx = (a == TAPE_SRC_PROOF ? 32 * m : 0) + b + q;
+        if (mp[pos + q] != 0 || idx >= 0xffffu) { out.info.clear(); return out; }   // not representable: caller falls back
+        mp[pos + q] = (uint16_t)(idx + 1);
+      }
+      dirty = true;
+    } else if (kind == TAPE_PERM) {
+      close(true);
+    } else {
+      if (dirty || chal != 0 || a >= 0xffffu) { out.info.clear(); return out; }
+      chal = a + 1;
+    }
+  }
+  if (dirty || chal != 0) close(false);
+  return out;
+}
+
 // Host interpreter of a tape (the reference semantics of k_transcript's loop; used by the CPU tests):
 // state = 200 bytes, challenges[slot] = the 64 squeezed bytes.
 template <typename Permute>

@@ -95,6 +95,8 @@ struct zkgpu_ctx {
   bool serial = false;             // measurement aid: the whole DAG of a batch on one stream
   hipEvent_t ev_dig = nullptr, ev_u = nullptr;
   Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
+  Buffer prep_absorb, prep_raw;    // cooperative transcript: absorbed words per segment, raw challenge bytes
+  int transcript_mode = 0;         // 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction
   int forced_parts = 0;
   void* pinned = nullptr;   // host staging for results
   size_t pinned_cap = 0;
@@ -227,6 +229,7 @@ inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + pe
 // multiplexes them in software (measured: 100-200 ms per step beyond that)
 constexpr int STREAM_SETS = 2;
 constexpr int MAX_FORKS = 9;
+constexpr size_t COOP_TRANSCRIPT_MAX = 4096;   // transactions per batch up to which the transcript runs one wavefront each
 
 // window width minimising  W * (terms + 2 * 2^(w-1) * msms)  point additions
 int choose_window(uint64_t n_terms, uint32_t n_msm) {
@@ -687,6 +690,9 @@ struct PrepLaunch {
   const uint32_t *d_init, *d_mono_chal, *d_mono_pow, *d_tgt_off, *d_term_q, *d_term_mono, *d_term_coef;
   const uint32_t* d_tape;
   uint32_t n_ops;
+  const uint32_t *d_seg_info = nullptr, *d_seg_const = nullptr;   // cooperative transcript (n_seg = 0: not available)
+  const uint16_t* d_seg_map = nullptr;
+  uint32_t n_seg = 0;
   size_t lds_bytes;
   const uint32_t* d_com;
   const uint8_t* d_proofs;
@@ -764,7 +770,28 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
                          prep->d_com, (const uint32_t*)c->prep_pw.p, (uint32_t)B, (uint32_t*)c->small_tbl.p,
                          (uint32_t*)c->msm_fail.p, (unsigned long long*)((char*)c->status.p + 8));
     }
-    {
+    // one wavefront per transaction while that still leaves the chip room (the cooperative form costs ~9x the
+    // wave-instructions of the one-lane form, and buys latency only); beyond that, one lane per transaction
+    const bool coop = prep->n_seg && (c->transcript_mode == 2 || (c->transcript_mode == 0 && B <= COOP_TRANSCRIPT_MAX));
+    if (coop) {
+      {
+        Launch l(c, "k_tape_gather", L);
+        hipLaunchKernelGGL(k_tape_gather, dim3(blocks_for((uint64_t)B * prep->n_seg * 25, 256)), dim3(256), 0, L, sh, prep->n_seg,
+                           prep->d_seg_const, prep->d_seg_map, prep->d_com, (const uint32_t*)c->prep_pw.p, (uint32_t)B,
+                           (uint2*)c->prep_absorb.p);
+      }
+      {
+        Launch l(c, "k_transcript_coop", L);
+        hipLaunchKernelGGL(k_transcript_coop, dim3((unsigned)B), dim3(64), 0, L, prep->n_seg, prep->d_seg_info, prep->d_init,
+                           (const uint2*)c->prep_absorb.p, (uint32_t)B, sh.n_ch, (uint32_t*)c->prep_raw.p);
+      }
+      {
+        Launch l(c, "k_challenges", L);
+        hipLaunchKernelGGL(k_challenges, dim3((unsigned)B), dim3(128), (size_t)sh.n_ch * 32, L, sh, (const uint32_t*)c->prep_raw.p,
+                           (const uint32_t*)c->prep_pw.p, prep->d_r, (uint32_t)B, (uint32_t*)c->prep_ch.p,
+                           (uint32_t*)c->prep_wf.p, prep->d_mono_chal, prep->d_mono_pow, group > 1 ? 1u : 0u);
+      }
+    } else {
       Launch l(c, "k_transcript", L);
       hipLaunchKernelGGL(k_transcript, dim3(blocks_for(B, 64)), dim3(64), 0, L, sh, prep->d_init,
                          (const uint4*)prep->d_tape, prep->n_ops, prep->d_com, (const uint32_t*)c->prep_pw.p, prep->d_r, (uint32_t)B, (uint32_t*)c->prep_ch.p,
@@ -989,6 +1016,7 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
     }
     c->owns_streams = false;
     c->group_size = parent->group_size;
+    c->transcript_mode = parent->transcript_mode;
   } else {
     ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
          hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
@@ -1070,7 +1098,8 @@ void zkgpu_destroy(zkgpu_ctx* c) {
                     &c->partials, &c->partial_flags, &c->window_sums, &c->window_flags, &c->msm_fail,
                     &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform,
                     &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->small_tbl, &c->recoded, &c->grp_sc, &c->grp_digits, &c->grp_partials, &c->grp_ok, &c->row_map, &c->prep_com, &c->prep_proofs, &c->prep_r,
-                    &c->prep_pw, &c->prep_ch, &c->prep_wf, &c->prep_dyn_sc, &c->prep_dyn_pt, &c->prep_st_sc};
+                    &c->prep_pw, &c->prep_ch, &c->prep_wf, &c->prep_dyn_sc, &c->prep_dyn_pt, &c->prep_st_sc,
+                    &c->prep_absorb, &c->prep_raw};
   for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->pinned_in) (void)hipHostFree(c->pinned_in);
@@ -1254,6 +1283,36 @@ int zkgpu_set_serial(zkgpu_ctx* c, int on) {
   if (!c) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   c->serial = on != 0;
+  return ZKGPU_OK;
+}
+
+// Transcript replay: 0 automatic (one wavefront per transaction up to COOP_TRANSCRIPT_MAX transactions per batch,
+// one lane per transaction beyond), 1 always one lane per transaction (k_transcript), 2 always one wavefront
+// (k_tape_gather + k_transcript_coop + k_challenges).  Same results either way.
+int zkgpu_set_transcript_mode(zkgpu_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 2) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->transcript_mode = mode;
+  return ZKGPU_OK;
+}
+
+// Test hook for the cooperative Keccak (keccak_coop.hpp): `in` = 3 x 64 words (a, b, gather addresses), `out` =
+// 8 x 64 words (row_ror:8, row_shr:1, row_shl:1 of a; both outputs of permlane16_swap(a, b) and of
+// permlane32_swap(a, b); ds_bpermute(addr, a)); `states` = n_states x 25 u64, permuted in place by Keccak-f[1600]
+// with one state per wavefront.
+int zkgpu_debug_coop_selftest(zkgpu_ctx* c, const uint32_t* in, uint32_t* out, uint64_t* states, size_t n_states) {
+  if (!c || !in || !out || (n_states && !states)) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  TRY(upload(c, c->in_scalars, in, 192 * 4));
+  TRY(ensure(c, c->values, 512 * 4));
+  TRY(upload(c, c->in_points, states, std::max<size_t>(n_states, 1) * 200));
+  hipLaunchKernelGGL(k_coop_selftest, dim3((unsigned)std::max<size_t>(1, std::min<size_t>(n_states, 1024))), dim3(64), 0, c->stream,
+                     (const uint32_t*)c->in_scalars.p, (uint32_t*)c->values.p, (uint2*)c->in_points.p, (uint32_t)n_states);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out, c->values.p, 512 * 4, hipMemcpyDeviceToHost, c->stream));
+  if (n_states) HIP_TRY(c, hipMemcpyAsync(states, c->in_points.p, n_states * 200, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ZKGPU_OK;
 }
 
@@ -1585,6 +1644,9 @@ struct zkgpu_cloak_plan {
            *d_term_mono = nullptr, *d_term_coef = nullptr;
   uint32_t* d_tape = nullptr;     // transcript_tape.hpp, four words per operation
   uint32_t n_ops = 0;
+  uint32_t *d_seg_info = nullptr, *d_seg_const = nullptr;   // the tape regrouped for k_transcript_coop
+  uint16_t* d_seg_map = nullptr;
+  uint32_t n_seg = 0;
   // CSR scaffolding of a uniform batch (offsets, generator index template) for the largest batch seen so
   // far; a prefix of it serves every smaller batch.  It only grows: a larger one is built beside the old
   // one, which batches in flight on other contexts may still be reading and which is therefore kept
@@ -1665,6 +1727,13 @@ int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t 
     const std::vector<uint32_t> tape = build_r1cs_verifier_tape(init[50], init[51], s.m, h.chal_label, s.k, s.pn, CH_FIXED);
     p->n_ops = (uint32_t)(tape.size() / 4);
     TRY(plan_upload(c, &p->d_tape, tape));
+    const CoopSegments segs = build_coop_segments(tape, s.m);
+    if (segs.n_seg() && s.n_ch <= 0xffffu) {
+      p->n_seg = segs.n_seg();
+      TRY(plan_upload(c, &p->d_seg_info, segs.info));
+      TRY(plan_upload(c, &p->d_seg_const, segs.consts));
+      TRY(plan_upload(c, &p->d_seg_map, segs.map));
+    }
   }
   TRY(plan_upload(c, &p->d_mono_chal, h.mono_chal));
   TRY(plan_upload(c, &p->d_mono_pow, h.mono_pow));
@@ -1680,7 +1749,7 @@ int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t 
 void zkgpu_cloak_plan_destroy(zkgpu_cloak_plan* p) {
   if (!p) return;
   DeviceGuard g(p->ctx->device);
-  void* ptrs[] = {p->d_tape, p->d_init, p->d_mono_chal, p->d_mono_pow, p->d_tgt_off, p->d_term_q, p->d_term_mono,
+  void* ptrs[] = {p->d_seg_info, p->d_seg_const, p->d_seg_map, p->d_tape, p->d_init, p->d_mono_chal, p->d_mono_pow, p->d_tgt_off, p->d_term_q, p->d_term_mono,
                   p->d_term_coef, p->d_dyn_off, p->d_st_off, p->d_st_index};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   for (void* q : p->retired) (void)hipFree(q);
@@ -1819,6 +1888,10 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
   TRY(ensure(c, c->prep_dyn_sc, (size_t)B * sh.n_dyn * 32));
   TRY(ensure(c, c->prep_dyn_pt, (size_t)B * sh.n_dyn * 32));
   TRY(ensure(c, c->prep_st_sc, (size_t)B * sh.n_static * 32));
+  if (plan->n_seg && (c->transcript_mode == 2 || (c->transcript_mode == 0 && batch <= COOP_TRANSCRIPT_MAX))) {
+    TRY(ensure(c, c->prep_absorb, (size_t)B * plan->n_seg * 25 * 8));
+    TRY(ensure(c, c->prep_raw, (size_t)B * sh.n_ch * 64));
+  }
   const uint64_t *d_dyn_off, *d_st_off;
   const uint32_t* d_st_index;
   {
@@ -1868,6 +1941,7 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
     pl.d_init = plan->d_init; pl.d_mono_chal = plan->d_mono_chal; pl.d_mono_pow = plan->d_mono_pow;
     pl.d_tgt_off = plan->d_tgt_off; pl.d_term_q = plan->d_term_q; pl.d_term_mono = plan->d_term_mono;
     pl.d_term_coef = plan->d_term_coef; pl.d_tape = plan->d_tape; pl.n_ops = plan->n_ops; pl.lds_bytes = plan->lds_bytes;
+    pl.d_seg_info = plan->d_seg_info; pl.d_seg_const = plan->d_seg_const; pl.d_seg_map = plan->d_seg_map; pl.n_seg = plan->n_seg;
     pl.d_com = d_com; pl.d_proofs = d_proofs; pl.d_r = d_r; pl.proof_len = proof_len;
     return pipe_enqueue(c, job, ps, &pl);
   }

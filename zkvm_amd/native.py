@@ -139,6 +139,8 @@ def load_library():
     lib.zkgpu_comm_allgather.argtypes = [vp, u8p, sz, u8p]
     lib.zkgpu_comm_allgather_bitmap.argtypes = [vp, u64p, u8p, C.c_int, u8p]
     lib.zkgpu_verifier_verify_sharded.argtypes = [vp, vp, sz, u32p, u32p, u8p, u8p, u64p, u8p, u8p]
+    lib.zkgpu_set_transcript_mode.argtypes = [vp, C.c_int]
+    lib.zkgpu_debug_coop_selftest.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), sz]
     lib.zkgpu_cloak_plan_layout.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.zkgpu_debug_read.argtypes = [vp, C.c_char_p, vp, sz]
     lib.zkgpu_debug_read.restype = C.c_longlong
@@ -218,6 +220,19 @@ class Context:
     def set_group_size(self, group: int) -> None:
         """zkgpu_set_group_size: transactions per group check of the whole-proof paths (1 = none)."""
         self._check(self.lib.zkgpu_set_group_size(self.h, group))
+
+    def set_transcript_mode(self, mode: int) -> None:
+        """zkgpu_set_transcript_mode: 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction."""
+        self._check(self.lib.zkgpu_set_transcript_mode(self.h, mode))
+
+    def coop_selftest(self, a, b, addr, states):
+        """zkgpu_debug_coop_selftest -> (8 x 64 words of primitive outputs, permuted states)"""
+        inp = (C.c_uint32 * 192)(*(list(a) + list(b) + list(addr)))
+        out = (C.c_uint32 * 512)()
+        flat = [w for st in states for w in st]
+        st = (C.c_uint64 * max(len(flat), 1))(*flat)
+        self._check(self.lib.zkgpu_debug_coop_selftest(self.h, inp, out, st, len(states)))
+        return [list(out[64 * i: 64 * i + 64]) for i in range(8)], [list(st[25 * i: 25 * i + 25]) for i in range(len(states))]
 
     def set_serial(self, on: bool) -> None:
         """zkgpu_set_serial: one stream for the whole batch (measurement aid)."""
