@@ -125,7 +125,7 @@ def algorithmic_bytes(lib, shapes) -> int:
 
 
 # ---- workloads ---------------------------------------------------------------------------------
-def workload_2x2(batch: int, rank: int):
+def workload_2x2(batch: int, rank: int, bad_every: int = 64):
     """configs[1]: the committed distinct proofs, ~1.5 % corrupted -> (txs, expected bits)"""
     from gpu_util import load_cloak_fixture
     fixture, n_in, n_out, _ = load_cloak_fixture("cloak_2x2_1024.bin")
@@ -133,9 +133,9 @@ def workload_2x2(batch: int, rank: int):
     for i in range(batch):
         com, proof = fixture[(i + 37 * rank) % len(fixture)]
         ok = 1
-        if i % 64 == 7:
+        if bad_every and i % bad_every == 7 % bad_every:
             ok = 0
-            c = (i // 64) % 3
+            c = (i // bad_every) % 3
             if c == 0:      # commitment that is not a ristretto255 encoding
                 com = com[:96] + BAD_POINT + com[128:]
             elif c == 1:    # IPA scalar a off by one (still canonical)
@@ -378,7 +378,7 @@ def run_config2(args, W):
     lib = ctx.lib
     batch = args.batch
     host_threads = max(1, usable_cores(os.cpu_count() or 1) // max(1, world))
-    txs, expected = workload_2x2(batch, rank)
+    txs, expected = workload_2x2(batch, rank, args.bad_every)
     n_in, n_out = txs[0][0], txs[0][1]
     n_dyn, n_static = shape_terms(lib, n_in, n_out)
     t0 = time.perf_counter()
@@ -401,6 +401,8 @@ def run_config2(args, W):
     # shared streams (zkgpu_ctx_fork).  One host thread submits step i + M only after collecting step i.  Every step
     # is one complete, independent verification of the whole batch; K steps are timed as a whole.
     ctx.set_group_size(args.group)               # forks inherit it
+    ctx.set_transcript_mode(args.transcript_mode)
+    ctx.set_locate_mode(args.locate_mode)
     ctxs = [ctx] + [ctx.fork() for _ in range(min(max(1, args.inflight), 10) - 1)]
     d_com = to_dev(b"".join(t[2] for t in txs))
     d_proofs = to_dev(b"".join(t[3] for t in txs))
@@ -608,6 +610,8 @@ def run_config4(args, W):
     bv = BlockVerifier(ctx, gens, batches_in_flight=args.inflight, chunk=args.chunk)
     for i in range(bv.lanes()):
         bv.lane(i).set_group_size(args.group)
+        bv.lane(i).set_transcript_mode(args.transcript_mode)
+        bv.lane(i).set_locate_mode(args.locate_mode)
     mine = [CloakTx(*t) for t in txs[lo:hi]]
     block = bv.block(mine, r_bytes[64 * lo: 64 * hi])          # this rank's shard, resident in HBM, grouped by shape
     # the exchange step: RCCL behind the C ABI (zkgpu_comm); gloo when several ranks share one GPU
@@ -719,6 +723,10 @@ def main():
     ap.add_argument("--inflight", type=int, default=6, help="batches in flight per GPU")
     ap.add_argument("--group", type=int, default=16, help="transactions per group check (1 = every transaction on its own)")
     ap.add_argument("--chunk", type=int, default=0, help="config 4: transactions per batch in flight (0 = library default)")
+    ap.add_argument("--bad-every", type=int, default=64, help="config 2: one transaction in this many is corrupted (0 = none)")
+    ap.add_argument("--locate-mode", type=int, default=0, choices=(0, 1, 2), help="zkgpu_set_locate_mode")
+    ap.add_argument("--transcript-mode", type=int, default=0, choices=(0, 1, 2),
+                    help="zkgpu_set_transcript_mode: 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction")
     ap.add_argument("--lean", action="store_true", help="the timed steps and the solo pass only (what tools/profile_bench.sh profiles)")
     ap.add_argument("--solo", action="store_true", help="config 2: only serial steps, every kernel alone on the chip (for rocprofv3 --stats)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

@@ -202,6 +202,20 @@ int zkgpu_ctx_fork(zkgpu_ctx* parent, zkgpu_ctx** out);
  * (Same device as upstream bulletproofs' batched range-proof verification; applies to
  * r1cs::Verifier::verify of many proofs over one BulletproofGens.) */
 int zkgpu_set_group_size(zkgpu_ctx* ctx, int group);
+/* A group that fails is resolved with ONE more multiscalar multiplication when a single transaction is to
+ * blame: with S1 = sum E_t and S2 = sum i_t E_t over the group (i_t = position), the culprit b satisfies
+ * S2 = i_b S1; it alone is then checked on its own and the others are accepted iff S1 - E_b is the identity
+ * (the group check restricted to them).  Groups with several bad transactions are re-checked one by one as
+ * before; transactions known to be bad before the sums are formed (undecodable point, malformed proof) are
+ * left out of their group.  Should a located transaction ever fail to account for its group (~2^-248),
+ * zkgpu_verify_wait re-runs the batch ungrouped.  Test hook: zkgpu_debug_force_regroup(ctx, 1) forces that
+ * re-run; the call returns the number of re-runs so far.  With *_dev inputs the caller's device buffers must
+ * stay valid until zkgpu_verify_wait returns. */
+long long zkgpu_debug_force_regroup(zkgpu_ctx* ctx, int on);
+/* 0 automatic (default: locate from 2048 transactions per batch on -- below that the two extra dependent stages cost
+ * more latency than the saved work is worth, and a failed group is simply re-checked transaction by transaction),
+ * 1 never locate, 2 always locate.  Forks inherit the setting. */
+int zkgpu_set_locate_mode(zkgpu_ctx* ctx, int mode);
 
 /* Transcript replay of the whole-proof paths: 0 automatic (default: one WAVEFRONT per transaction --
  * Keccak-f with the state spread over the lanes, keccak_coop.hpp -- for batches of up to 4096

@@ -286,3 +286,58 @@ def test_msm_2p20_equals_committed_expected_value(ctx):
     assert hashlib.sha256(pts).hexdigest() == gold["points_sha256"]
     for m, want in sorted((int(a), b) for a, b in gold["results"].items()):
         assert ctx.msm(sc[: 32 * m], pts[: 32 * m]).hex() == want, m
+
+
+def test_failed_groups_are_located_and_every_pattern_of_bad_transactions_resolves(ctx, oracle):
+    """Group checks with a failing group: one bad transaction per group (located by the index-weighted sum, checked
+    alone, the others accepted through S1 - E_b), two and three bad ones in one group (no single culprit: re-checked
+    one by one), bad ones at the first / last position, a bad one next to a transaction that is left out of the group
+    (undecodable point, malformed proof), every transaction of a group bad -- always the oracle's per-transaction
+    verdicts; and the ungrouped re-run (forced through the test hook) gives the same bits."""
+    from zkvm_amd.verifier import BulletproofGens, Verifier
+    fix, n_in, n_out, plen = load_cloak_fixture()
+    gens = BulletproofGens(ctx, 256, table_bits=10)
+    v = Verifier(ctx, gens)
+    ctx.set_group_size(16)
+    n = 16 * 12 + 5                                           # a ragged last group too
+    coms = [bytearray(fix[i][0]) for i in range(n)]
+    proofs = [bytearray(fix[i][1]) for i in range(n)]
+
+    def bad_scalar(i): proofs[i][1 + 32 * 11 + (i % 29)] ^= 1 << (i % 8)          # t_x: only the MSM can tell
+    def bad_a(i):
+        a = (int.from_bytes(proofs[i][-64:-32], "little") + 1) % L
+        proofs[i][-64:-32] = a.to_bytes(32, "little")
+    def bad_point(i): coms[i][32:64] = bytes.fromhex("01" + "00" * 31)             # undecodable: known before the sums
+    def malformed(i): proofs[i][1 + 32 * 12: 1 + 32 * 13] = L.to_bytes(32, "little")   # non-canonical scalar
+    bad_scalar(16 * 0 + 7)                                    # group 0: one bad, in the middle
+    bad_a(16 * 1 + 0)                                         # group 1: first position
+    bad_scalar(16 * 2 + 15)                                   # group 2: last position
+    bad_scalar(16 * 3 + 2); bad_a(16 * 3 + 9)                 # group 3: two bad
+    bad_scalar(16 * 4 + 1); bad_scalar(16 * 4 + 2); bad_a(16 * 4 + 3)   # group 4: three
+    bad_point(16 * 5 + 4)                                     # group 5: only a left-out one -> the group passes
+    bad_point(16 * 6 + 4); bad_scalar(16 * 6 + 11)            # group 6: left-out + one culprit
+    malformed(16 * 7 + 0); bad_a(16 * 7 + 15)                 # group 7: malformed + culprit
+    for i in range(16):
+        bad_scalar(16 * 8 + i)                                # group 8: all bad
+    bad_scalar(16 * 12 + 4)                                   # the ragged group (5 transactions)
+    r = hashlib.shake_256(b"locate").digest(64 * n)
+    com_b, proof_b = b"".join(bytes(c) for c in coms), b"".join(bytes(p) for p in proofs)
+    want = list(oracle.cloak_verify_batch(com_b, n_in, n_out, proof_b, plen, r, threads=16))
+    assert want.count(0) == 1 + 1 + 1 + 2 + 3 + 1 + 2 + 2 + 16 + 1
+    try:
+        before = ctx.force_regroup(False)
+        for mode in (1, 2, 2):                                  # re-check in full; locate (the default from 2048 per batch on)
+            ctx.set_locate_mode(mode)
+            assert bits(v.verify_packed_gpu(n_in, n_out, n, com_b, proof_b, plen, r), n) == want, mode
+        assert ctx.force_regroup(True) == before               # nothing above needed the ungrouped re-run
+        assert bits(v.verify_packed_gpu(n_in, n_out, n, com_b, proof_b, plen, r), n) == want
+        assert ctx.force_regroup(False) == before + 1          # ... and here it was taken
+        for group in (4, 64, 1):
+            ctx.set_group_size(group)
+            assert bits(v.verify_packed_gpu(n_in, n_out, n, com_b, proof_b, plen, r), n) == want, group
+    finally:
+        ctx.set_group_size(16)
+        ctx.set_locate_mode(0)
+        ctx.force_regroup(False)
+        v.close()
+        gens.close()

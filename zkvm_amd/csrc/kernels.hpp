@@ -25,6 +25,7 @@
 #pragma once
 #include "curve.hpp"
 #include "quad.hpp"
+#include "sc_dev.hpp"
 
 namespace zk {
 
@@ -992,6 +993,7 @@ k_batch_init(uint32_t* __restrict__ status, uint32_t* __restrict__ msm_fail, uin
     status[0] = 0; status[1] = 0;                      // flags
     status[2] = 0xffffffffu; status[3] = 0xffffffffu;  // lowest undecodable index (atomicMin)
     status[8] = 0;                                     // transactions queued for the individual re-check
+    status[9] = 0;                                     // groups whose check failed
   }
 }
 
@@ -1155,7 +1157,8 @@ k_static_accumulate(const int16_t* __restrict__ digits, const uint64_t* __restri
 __global__ void __launch_bounds__(64)
 k_static_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
                  const uint8_t* __restrict__ dyn_ok, const uint32_t* __restrict__ row_map,
-                 const uint32_t* __restrict__ n_active, uint8_t* __restrict__ accept) {
+                 const uint32_t* __restrict__ n_active, uint8_t* __restrict__ accept,
+                 uint32_t* __restrict__ out_points /*optional: the sum of slot b, extended, for k_locate_finish*/) {
   if (n_active && blockIdx.x >= *n_active) return;
   const uint32_t slot = blockIdx.x;
   const uint32_t tx = row_map ? row_map[slot] : slot;
@@ -1178,7 +1181,10 @@ k_static_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, con
     shfl_down_ge(other, acc, delta);
     if (lane < delta) ge_add(acc, acc, other);
   }
-  if (lane == 0) accept[tx] = (ge_is_identity(acc) && (!dyn_ok || dyn_ok[tx])) ? 1 : 0;
+  if (lane == 0) {
+    accept[tx] = (ge_is_identity(acc) && (!dyn_ok || dyn_ok[tx])) ? 1 : 0;
+    if (out_points) store_ext(out_points + (uint64_t)slot * EXT_WORDS, acc);
+  }
 }
 
 // one wave per MSM over the resident set: sum of its W*P table partials -> canonical ristretto
@@ -1210,55 +1216,285 @@ k_static_values(const uint32_t* __restrict__ partials, uint32_t n_partials, uint
 }
 
 // ---- group checks ---------------------------------------------------------------------
-// A group of transactions whose equations are weighted by independent random rho's (k_transcript)
+// A group of transactions whose equations E_t are weighted by independent random rho's (k_transcript)
 // sums to the identity iff every one of them does (up to probability ~2^-250), and the generator
 // terms of the sum collapse into ONE set of n_static scalars for the whole group: g times fewer
-// table gathers.  Groups that fail are re-checked transaction by transaction.
+// table gathers.  Transactions already known to be bad when the sums are formed (an undecodable proof
+// point, a malformed proof) are left out of their group and rejected on the spot.
 //
-// one wave per group: generator partials of the group + the proof-point sums of its transactions
-__global__ void __launch_bounds__(64)
-k_group_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
-                const uint8_t* __restrict__ dyn_ok, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
-                uint32_t group, uint8_t* __restrict__ group_ok, uint8_t* __restrict__ accept,
-                uint32_t* __restrict__ row_map, uint32_t* __restrict__ n_active) {
-  const uint32_t G = blockIdx.x;
-  const int lane = threadIdx.x;
-  ge acc;
-  ge_identity(acc);
-  for (uint32_t c = lane; c < n_partials; c += 64) {
-    ge p;
-    load_ext(p, partials + ((uint64_t)G * n_partials + c) * EXT_WORDS);
-    ge_add(acc, acc, p);
+// A group that fails is not re-checked transaction by transaction (g multiscalar multiplications) but
+// LOCATED with one more: with S1 = sum_t E_t and S2 = sum_t i_t E_t (i_t = 1, 2, .. the position in the
+// group), a single bad transaction b gives S2 = i_b S1, and i_b is found by trying the g candidates.
+// Transaction b alone is then checked on its own (E_b != 0: rejected), and the others are accepted iff
+// S1 - E_b is the identity -- the very group check, restricted to them.  Only when no i fits (two or more
+// bad transactions in one group) are all of its transactions checked individually.  Every accept is
+// therefore still backed by a random-weighted identity test, every reject by a non-zero equation.
+// (If S1 != E_b although an i fitted -- probability ~2^-248 -- the batch is flagged in status[0] bit 2 and
+// the host re-runs it with every transaction on its own.)
+constexpr uint32_t LOCATE_NONE = 0xffffffffu;
+
+__device__ __forceinline__ bool tx_excluded(const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t tx) {
+  return (msm_fail && msm_fail[tx]) || (wellformed && !wellformed[tx]);
+}
+
+// k * p for a small k (< 2^bits): double-and-add from the top bit, the same instruction stream on every lane
+__device__ inline void ge_small_mul(ge& r, const ge& p, uint32_t k, int bits) {
+  ge_identity(r);
+#pragma unroll 1
+  for (int bit = bits - 1; bit >= 0; --bit) {
+    ge d;
+    ge_double<true>(d, r);
+    r = d;
+    ge s;
+    ge_add(s, r, p);
+    if ((k >> bit) & 1) r = s;
   }
-  bool fine = true;
-  for (uint32_t i = lane; i < group; i += 64) {
-    const uint32_t tx = G * group + i;
-    if (tx < n_msm) {
+}
+
+// RFC 9496 sec 4.3.3 equality of the ristretto elements two curve points represent
+__device__ inline bool ge_ristretto_eq(const ge& p, const ge& q) {
+  fe a, b, c, d;
+  fe_mul(a, p.X, q.Y);
+  fe_mul(b, p.Y, q.X);
+  fe_mul(c, p.Y, q.Y);
+  fe_mul(d, p.X, q.X);
+  return fe_eq(a, b) | fe_eq(c, d);
+}
+
+__device__ __forceinline__ void shfl_ge(ge& out, const ge& in, int src_lane) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    out.X.v[i] = __shfl(in.X.v[i], src_lane);
+    out.Y.v[i] = __shfl(in.Y.v[i], src_lane);
+    out.Z.v[i] = __shfl(in.Z.v[i], src_lane);
+    out.T.v[i] = __shfl(in.T.v[i], src_lane);
+  }
+}
+
+// one wave per group: generator partials of the group + the proof-point sums of its transactions
+// blockDim = 256: wavefront 0 sums the points; a failed group's locating scalars are then spread over all four.
+// locate == 0 (small batches, where the extra stage costs more latency than it saves work): a failed group queues
+// all of its transactions for the individual re-check right here (cand = LOCATE_NONE).
+__global__ void __launch_bounds__(256)
+k_group_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
+                const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
+                uint32_t group, uint8_t* __restrict__ accept, uint32_t* __restrict__ grp_state /*[n_groups]: 0 passed, f + 1 failed*/,
+                uint32_t* __restrict__ fail_list, uint32_t* __restrict__ fail_sum /*[n_groups][40]*/, uint32_t* __restrict__ n_fail,
+                const uint32_t* __restrict__ st_scalars, uint32_t n_static, uint32_t* __restrict__ loc_sc /*[n_groups][n_static][8]*/,
+                int16_t* __restrict__ loc_digits, int w, int W, uint32_t locate, uint32_t* __restrict__ row_map,
+                uint32_t* __restrict__ n_recheck, uint32_t* __restrict__ cand) {
+  __shared__ uint32_t sh_fail;           // 0: the group passed, else f + 1
+  const uint32_t G = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63;
+  const uint32_t in_group = min(group, n_msm - G * group);
+  if (t < 64) {
+    ge acc;
+    ge_identity(acc);
+    for (uint32_t c = lane; c < n_partials; c += 64) {
       ge p;
-      load_ext(p, dyn_sum + (uint64_t)tx * EXT_WORDS);
+      load_ext(p, partials + ((uint64_t)G * n_partials + c) * EXT_WORDS);
       ge_add(acc, acc, p);
-      fine = fine && dyn_ok[tx] && (!wellformed || wellformed[tx]);
+    }
+    for (uint32_t i = lane; i < group; i += 64) {
+      const uint32_t tx = G * group + i;
+      if (tx < n_msm && !tx_excluded(msm_fail, wellformed, tx)) {
+        ge p;
+        load_ext(p, dyn_sum + (uint64_t)tx * EXT_WORDS);
+        ge_add(acc, acc, p);
+      }
+    }
+#pragma unroll 1
+    for (int delta = 32; delta >= 1; delta >>= 1) {
+      ge other;
+      shfl_down_ge(other, acc, delta);
+      if (lane < delta) ge_add(acc, acc, other);
+    }
+    const int ok = __shfl((lane == 0 && ge_is_identity(acc)) ? 1 : 0, 0);
+    for (uint32_t i = lane; i < in_group; i += 64) {
+      const uint32_t tx = G * group + i;
+      accept[tx] = (ok && !tx_excluded(msm_fail, wellformed, tx)) ? 1 : 0;
+    }
+    if (lane == 0) {
+      uint32_t f1 = 0;
+      if (!ok) {
+        const uint32_t f = atomicAdd(n_fail, 1u);
+        fail_list[f] = G;
+        store_ext(fail_sum + (uint64_t)f * EXT_WORDS, acc);
+        f1 = f + 1;
+      }
+      grp_state[G] = f1;
+      sh_fail = f1;
+    }
+    if (!ok && !locate) {                 // every transaction of the group, one by one
+      unsigned long long lives = 0;
+      for (uint32_t i0 = 0; i0 < in_group; i0 += 64) {
+        const uint32_t i = i0 + lane, tx = G * group + i;
+        const bool live = i < in_group && !tx_excluded(msm_fail, wellformed, tx);
+        lives = __ballot(live);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(n_recheck, (uint32_t)__popcll(lives));
+        base = __shfl(base, 0);
+        if (live) row_map[base + (uint32_t)__popcll(lives & ((1ull << lane) - 1))] = tx;
+      }
     }
   }
+  __syncthreads();
+  const uint32_t f1 = sh_fail;
+  if (f1 == 0) return;
+  const uint32_t f = f1 - 1;
+  if (!locate) { if (t == 0) cand[f] = LOCATE_NONE; return; }
+  // failed: the generator scalars of the group's LOCATING sum, sum_t i_t s_(t,j) (i_t = 1, 2, .. the position in the
+  // group), and their digits, stored at the group's place in the failed list
+  const uint32_t n_groups = (n_msm + group - 1) / group;
+  const uint64_t stride = (uint64_t)n_groups * n_static;
+  for (uint32_t j = (uint32_t)t; j < n_static; j += blockDim.x) {
+    scm run = scm_zero(), sum = scm_zero();
+    for (uint32_t i = in_group; i-- > 0;) {        // sum_k (sum_{t >= k} s_t) = sum_t (t + 1) s_t
+      const uint32_t tx = G * group + i;
+      if (!tx_excluded(msm_fail, wellformed, tx)) {
+        const uint4* src = reinterpret_cast<const uint4*>(st_scalars + ((uint64_t)tx * n_static + j) * 8);
+        const uint4 a = src[0], b = src[1];
+        scm v;
+        v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w; v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
+        run = scm_add(run, v);
+      }
+      sum = scm_add(sum, run);
+    }
+    uint32_t* o = loc_sc + ((uint64_t)f * n_static + j) * 8;
+    uint4* dst = reinterpret_cast<uint4*>(o);
+    dst[0] = make_uint4(sum.v[0], sum.v[1], sum.v[2], sum.v[3]);
+    dst[1] = make_uint4(sum.v[4], sum.v[5], sum.v[6], sum.v[7]);
+    const uint64_t g = (uint64_t)f * n_static + j;
+    for (int tt = 0; tt < W; ++tt) loc_digits[(uint64_t)tt * stride + g] = 0;
+    for_each_digit(o, w, W, [&](int tt, int d) { loc_digits[(uint64_t)tt * stride + g] = (int16_t)d; });
+  }
+}
+
+// one wave per failed group f: S2 = generator partials of the locating sum + sum_t i_t dyn_t; the position i
+// with i S1 = S2 names the one bad transaction, which alone is queued for the individual check (cand[f] =
+// its slot in row_map); no such i: every transaction of the group is queued (cand[f] = LOCATE_NONE)
+__global__ void __launch_bounds__(256)
+k_locate_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
+                 const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
+                 uint32_t group, const uint32_t* __restrict__ fail_list, const uint32_t* __restrict__ n_fail,
+                 const uint32_t* __restrict__ fail_sum, uint32_t* __restrict__ row_map, uint32_t* __restrict__ n_recheck,
+                 uint32_t* __restrict__ cand, const uint32_t* __restrict__ st_scalars, uint32_t n_static,
+                 int16_t* __restrict__ digits /*[W][n_msm * n_static], as k_static_digits writes them*/, int w, int W) {
+  __shared__ unsigned long long sh_queue;    // bit i: transaction i of the group is queued for the individual check
+  const uint32_t f = blockIdx.x;
+  if (f >= *n_fail) return;
+  const uint32_t G = fail_list[f];
+  const int t = threadIdx.x, lane = t & 63;
+  if (t < 64) {
+    ge acc;
+    ge_identity(acc);
+    for (uint32_t c = lane; c < n_partials; c += 64) {
+      ge p;
+      load_ext(p, partials + ((uint64_t)f * n_partials + c) * EXT_WORDS);
+      ge_add(acc, acc, p);
+    }
+    const uint32_t tx = G * group + (uint32_t)lane;
+    const bool live = (uint32_t)lane < group && tx < n_msm && !tx_excluded(msm_fail, wellformed, tx);
+    const int bits = 32 - __clz(group);          // positions 1 .. group
+    // (lane + 1) * dyn_lane and (lane + 1) * S1 by one double-and-add loop (two independent chains)
+    ge d, S1, md, M;
+    ge_identity(d);
+    if (live) load_ext(d, dyn_sum + (uint64_t)tx * EXT_WORDS);
+    load_ext(S1, fail_sum + (uint64_t)f * EXT_WORDS);
+    ge_identity(md);
+    ge_identity(M);
+    const uint32_t k = (uint32_t)lane + 1;
 #pragma unroll 1
-  for (int delta = 32; delta >= 1; delta >>= 1) {
-    ge other;
-    shfl_down_ge(other, acc, delta);
-    if (lane < delta) ge_add(acc, acc, other);
+    for (int bit = bits - 1; bit >= 0; --bit) {
+      ge x, y;
+      ge_double<true>(x, md); md = x;
+      ge_double<true>(y, M); M = y;
+      ge_add(x, md, d);
+      ge_add(y, M, S1);
+      if ((k >> bit) & 1) { md = x; M = y; }
+    }
+    ge_add(acc, acc, md);                        // identity stays the identity for the lanes without a transaction
+#pragma unroll 1
+    for (int delta = 32; delta >= 1; delta >>= 1) {
+      ge other;
+      shfl_down_ge(other, acc, delta);
+      if (lane < delta) ge_add(acc, acc, other);
+    }
+    ge S2;
+    shfl_ge(S2, acc, 0);
+    const bool match = live && ge_ristretto_eq(M, S2);
+    const unsigned long long hits = __ballot(match);
+    const unsigned long long lives = __ballot(live);
+    if (hits) {
+      const int b = __ffsll((long long)hits) - 1;
+      if (lane == 0) {
+        const uint32_t slot = atomicAdd(n_recheck, 1u);
+        row_map[slot] = G * group + (uint32_t)b;
+        cand[f] = slot;
+        sh_queue = 1ull << b;
+      }
+    } else {
+      uint32_t base = 0;
+      if (lane == 0) { base = atomicAdd(n_recheck, (uint32_t)__popcll(lives)); cand[f] = LOCATE_NONE; sh_queue = lives; }
+      base = __shfl(base, 0);
+      if (live) row_map[base + (uint32_t)__popcll(lives & ((1ull << lane) - 1))] = tx;
+    }
   }
-  const bool all_fine = __all(fine);
-  // verdict for the group's transactions: accepted together, or queued for the individual re-check
-  const int ok = __shfl((lane == 0 && all_fine && ge_is_identity(acc)) ? 1 : 0, 0);
-  if (lane == 0) group_ok[G] = (uint8_t)ok;
-  uint32_t base = 0;
-  const uint32_t in_group = min(group, n_msm - G * group);
-  if (!ok && lane == 0) base = atomicAdd(n_active, in_group);
-  base = __shfl(base, 0);
-  for (uint32_t i = lane; i < in_group; i += 64) {
-    const uint32_t tx = G * group + i;
-    accept[tx] = ok ? 1 : 0;
-    if (!ok) row_map[base + i] = tx;
+  __syncthreads();
+  const unsigned long long queue = sh_queue;
+  for (uint32_t i = 0; i < group && i < 64; ++i) {
+    if (!((queue >> i) & 1)) continue;
+    const uint32_t ti = G * group + i;
+    for (uint32_t j = (uint32_t)t; j < n_static; j += blockDim.x) {
+      const uint64_t g = (uint64_t)ti * n_static + j;
+      for (int tt = 0; tt < W; ++tt) digits[(uint64_t)tt * n_msm * n_static + g] = 0;
+      for_each_digit(st_scalars + 8 * g, w, W, [&](int tt, int dd) { digits[(uint64_t)tt * n_msm * n_static + g] = (int16_t)dd; });
+    }
   }
+}
+
+// Final verdicts of a batch checked in groups, packed into the bitmap (byte i / 8, bit i % 8):
+//   transaction of a group that passed, or left out of its group          accept[] as k_group_combine wrote it
+//   ... of a failed group with no single culprit, or the culprit itself    accept[] as k_static_combine wrote it
+//   ... of a failed group with a located culprit b, not b                  accepted iff S1 - E_b is the identity
+// (E_b = points[cand]: the sum k_static_combine formed for b).  Should that last test ever fail, status[0] bit 2
+// is raised and the host re-runs the batch ungrouped.
+__global__ void __launch_bounds__(256)
+k_pack_bitmap_groups(const uint8_t* __restrict__ accept, const uint32_t* __restrict__ wellformed, const uint32_t* __restrict__ msm_fail,
+                     uint8_t* __restrict__ bitmap, uint32_t n_msm, uint32_t group, const uint32_t* __restrict__ grp_state,
+                     const uint32_t* __restrict__ fail_sum, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ row_map,
+                     const uint32_t* __restrict__ points, uint32_t* __restrict__ status, uint32_t force_unresolved /*test hook*/) {
+  const uint32_t byte = blockIdx.x * blockDim.x + threadIdx.x;
+  if (byte >= (n_msm + 7) / 8) return;
+  uint32_t v = 0, seen_group = 0xffffffffu, b = 0;
+  int rest_ok = 0, located = 0;
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t i = byte * 8 + k;
+    if (i >= n_msm) break;
+    const uint32_t G = i / group;
+    if (G != seen_group) {
+      seen_group = G;
+      located = 0;
+      const uint32_t f1 = grp_state[G];
+      if (f1 != 0 && cand[f1 - 1] != LOCATE_NONE) {
+        const uint32_t f = f1 - 1, slot = cand[f];
+        located = 1;
+        b = row_map[slot];
+        ge S1, Eb, nb, d;
+        load_ext(S1, fail_sum + (uint64_t)f * EXT_WORDS);
+        load_ext(Eb, points + (uint64_t)slot * EXT_WORDS);
+        ge_neg(nb, Eb);
+        ge_add(d, S1, nb);
+        rest_ok = (ge_is_identity(d) && !force_unresolved) ? 1 : 0;
+        if (!rest_ok) atomicOr(&status[0], 4u);
+      }
+    }
+    int bit;
+    if (located && i != b) bit = rest_ok && !tx_excluded(msm_fail, wellformed, i);
+    else bit = accept[i] && (!wellformed || wellformed[i]);
+    if (bit) v |= 1u << k;
+  }
+  bitmap[byte] = (uint8_t)v;
 }
 
 }  // namespace zk

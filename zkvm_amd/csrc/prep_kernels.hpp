@@ -796,7 +796,7 @@ __global__ void __launch_bounds__(256)
 k_group_scalars(const uint32_t* __restrict__ st_scalars /*[B][n_static][8]*/, uint32_t n_msm, uint32_t n_static,
                 uint32_t group, uint32_t* __restrict__ out /*[groups][n_static][8]*/,
                 int16_t* __restrict__ digits /*optional: [W][groups * n_static], as k_static_digits writes them*/,
-                int w, int W) {
+                int w, int W, const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n_groups = (n_msm + group - 1) / group;
   const uint64_t total = (uint64_t)n_groups * n_static;
@@ -806,6 +806,7 @@ k_group_scalars(const uint32_t* __restrict__ st_scalars /*[B][n_static][8]*/, ui
   for (uint32_t i = 0; i < group; ++i) {
     const uint32_t tx = G * group + i;
     if (tx >= n_msm) break;
+    if (tx_excluded(msm_fail, wellformed, tx)) continue;   // known bad already: left out of the group, rejected on the spot
     const uint4* src = reinterpret_cast<const uint4*>(st_scalars + ((uint64_t)tx * n_static + j) * 8);
     const uint4 a = src[0], b = src[1];
     scm v;

@@ -24,6 +24,7 @@
 #include <atomic>
 #include <sys/random.h>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "r1cs_verifier.hpp"
@@ -91,11 +92,17 @@ struct zkgpu_ctx {
   Buffer digits, st_partials, dynsum, accept2, bin_order, class_count, part_hist, part_entries, part_lo, dec_scratch, heavy;
   Buffer small_tbl, recoded;
   Buffer grp_sc, grp_digits, grp_partials, grp_ok, row_map;
+  Buffer grp_fail, grp_fail_sum, rechk_pts;   // failed groups: list | located candidate, their sums S1; sums of the re-checked transactions
+  // the batch in flight, kept for the (never expected) ungrouped re-run when a located transaction does not explain its group
+  struct LastBatch { bool valid = false, has_prep = false; const zkgpu_pointset* ps = nullptr; std::vector<uint8_t> job, prep; } last;
+  bool force_unresolved = false;   // test hook: take that re-run path
+  uint64_t regroup_fallbacks = 0;
   int group_size = 16;             // transactions per group check (1 = every transaction on its own)
   bool serial = false;             // measurement aid: the whole DAG of a batch on one stream
   hipEvent_t ev_dig = nullptr, ev_u = nullptr;
   Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
   Buffer prep_absorb, prep_raw;    // cooperative transcript: absorbed words per segment, raw challenge bytes
+  int locate_mode = 0;             // failed groups: 0 automatic, 1 always re-check every transaction, 2 always locate the culprit
   int transcript_mode = 0;         // 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction
   int forced_parts = 0;
   void* pinned = nullptr;   // host staging for results
@@ -229,7 +236,8 @@ inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + pe
 // multiplexes them in software (measured: 100-200 ms per step beyond that)
 constexpr int STREAM_SETS = 2;
 constexpr int MAX_FORKS = 9;
-constexpr size_t COOP_TRANSCRIPT_MAX = 4096;   // transactions per batch up to which the transcript runs one wavefront each
+constexpr size_t LOCATE_MIN_BATCH = 2048;      // transactions per batch from which failed groups are located instead of re-checked in full
+constexpr size_t COOP_TRANSCRIPT_MAX = 1536;   // transactions per batch up to which the transcript runs one wavefront each
 
 // window width minimising  W * (terms + 2 * 2^(w-1) * msms)  point additions
 int choose_window(uint64_t n_terms, uint32_t n_msm) {
@@ -655,7 +663,7 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
     hipLaunchKernelGGL(k_static_combine, dim3((unsigned)B), dim3(64), 0, s, (const uint32_t*)c->st_partials.p,
                        (uint32_t)(W * P), has_dyn ? (const uint32_t*)c->dynsum.p : (const uint32_t*)nullptr,
                        has_dyn ? (const uint8_t*)c->accept.p : (const uint8_t*)nullptr, (const uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, (uint8_t*)c->accept2.p);
+                       (const uint32_t*)nullptr, (uint8_t*)c->accept2.p, (uint32_t*)nullptr);
   }
   {
     Launch l(c, "k_pack_bitmap");
@@ -705,6 +713,14 @@ bool pipe_eligible(const zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps)
 }
 
 int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const PrepLaunch* prep) {
+  static_assert(std::is_trivially_copyable<Job>::value && std::is_trivially_copyable<PrepLaunch>::value, "kept as bytes");
+  {
+    std::vector<uint8_t> jb(sizeof(Job)), pb(prep ? sizeof(PrepLaunch) : 0);     // (job may alias c->last: copy first)
+    memcpy(jb.data(), &job, sizeof(Job));
+    if (prep) memcpy(pb.data(), prep, sizeof(PrepLaunch));
+    c->last.job.swap(jb); c->last.prep.swap(pb);
+    c->last.ps = ps; c->last.has_prep = prep != nullptr; c->last.valid = true;
+  }
   const size_t B = job.n_msm;
   const size_t nbytes = (B + 7) / 8;
   hipStream_t L = c->stream_l, H1 = c->serial ? L : c->stream, H2 = c->serial ? L : c->stream2;
@@ -731,6 +747,9 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     TRY(ensure(c, c->grp_partials, (size_t)n_groups * W * Pg * EXT_WORDS * 4));
     TRY(ensure(c, c->grp_ok, n_groups));
     TRY(ensure(c, c->row_map, B * 4));
+    TRY(ensure(c, c->grp_fail, (size_t)n_groups * 12));
+    TRY(ensure(c, c->grp_fail_sum, (size_t)n_groups * EXT_WORDS * 4));
+    TRY(ensure(c, c->rechk_pts, B * EXT_WORDS * 4));
   }
   TRY(ensure(c, c->accept, B));
   TRY(ensure(c, c->accept2, B));
@@ -770,6 +789,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
                          prep->d_com, (const uint32_t*)c->prep_pw.p, (uint32_t)B, (uint32_t*)c->small_tbl.p,
                          (uint32_t*)c->msm_fail.p, (unsigned long long*)((char*)c->status.p + 8));
     }
+    HIP_TRY(c, hipEventRecord(c->ev_dig, H1));      // msm_fail is final: the group sums leave such transactions out
     // one wavefront per transaction while that still leaves the chip room (the cooperative form costs ~9x the
     // wave-instructions of the one-lane form, and buys latency only); beyond that, one lane per transaction
     const bool coop = prep->n_seg && (c->transcript_mode == 2 || (c->transcript_mode == 0 && B <= COOP_TRANSCRIPT_MAX));
@@ -813,11 +833,12 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   HIP_TRY(c, hipStreamWaitEvent(H2, c->ev_p, 0));
   uint32_t* n_recheck = (uint32_t*)((char*)c->status.p + 32);
   if (group > 1) {
+    HIP_TRY(c, hipStreamWaitEvent(H2, c->ev_dig, 0));
     {
       Launch l(c, "k_group_scalars", H2);     // sums and their digits in one launch
       hipLaunchKernelGGL(k_group_scalars, dim3(blocks_for((uint64_t)n_groups * ns, 256)), dim3(256), 0, H2,
                          job.d_st_scalars, (uint32_t)B, ns, group, (uint32_t*)c->grp_sc.p, (int16_t*)c->grp_digits.p,
-                         ps->tbl_w, W);
+                         ps->tbl_w, W, (const uint32_t*)c->msm_fail.p, job.d_wellformed);
     }
     {
       Launch l(c, "k_static_accumulate", H2);
@@ -865,19 +886,43 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   }
   HIP_TRY(c, hipStreamWaitEvent(L, c->ev_sa, 0));
   if (group > 1) {
+    uint32_t* n_fail = (uint32_t*)((char*)c->status.p + 36);
+    uint32_t* fail_list = (uint32_t*)c->grp_fail.p;
+    uint32_t* cand = fail_list + n_groups;
+    uint32_t* grp_state = cand + n_groups;
+    // locating the culprit of a failed group saves work (one multiscalar multiplication instead of `group`) at the
+    // price of two more dependent stages: worth it once the batch is large enough for the work to matter
+    const bool locate = c->locate_mode == 2 || (c->locate_mode == 0 && B >= LOCATE_MIN_BATCH);
     {
-      Launch l(c, "k_group_combine", L);
-      hipLaunchKernelGGL(k_group_combine, dim3(n_groups), dim3(64), 0, L, (const uint32_t*)c->grp_partials.p,
-                         (uint32_t)(W * Pg), (const uint32_t*)c->dynsum.p, (const uint8_t*)c->accept.p,
-                         job.d_wellformed, (uint32_t)B, group, (uint8_t*)c->grp_ok.p, (uint8_t*)c->accept2.p,
-                         (uint32_t*)c->row_map.p, n_recheck);
+      Launch l(c, "k_group_combine", L);        // verdicts of the groups; a failed group also gets its locating scalars
+      hipLaunchKernelGGL(k_group_combine, dim3(n_groups), dim3(256), 0, L, (const uint32_t*)c->grp_partials.p,
+                         (uint32_t)(W * Pg), (const uint32_t*)c->dynsum.p, (const uint32_t*)c->msm_fail.p,
+                         job.d_wellformed, (uint32_t)B, group, (uint8_t*)c->accept2.p, grp_state, fail_list,
+                         (uint32_t*)c->grp_fail_sum.p, n_fail, job.d_st_scalars, ns, (uint32_t*)c->grp_sc.p,
+                         (int16_t*)c->grp_digits.p, ps->tbl_w, W, locate ? 1u : 0u, (uint32_t*)c->row_map.p, n_recheck, cand);
     }
-    // failed groups, transaction by transaction: full-size grids, lanes beyond the queued count leave at once
-    {
+    // failed groups (kernels.hpp, "group checks"): one more multiscalar multiplication each LOCATES the bad
+    // transaction, which alone is then checked on its own.  Grids are sized for the worst case; lanes beyond the
+    // device-side counts leave at once (no failed group: four near-empty launches).
+    if (locate) {
+      Launch l(c, "k_static_accumulate", L);
+      hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)n_groups * W * Pg, 256)), dim3(256), 0, L,
+                         (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
+                         (uint32_t)ps->n, ps->tbl_H, W, Pg, n_groups, (uint64_t)n_groups * ns,
+                         (uint32_t*)c->grp_partials.p, (const uint32_t*)nullptr, (const uint32_t*)n_fail);
+    }
+    if (!locate) {
       Launch l(c, "k_static_digits", L);        // digits of the queued transactions only
       hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, L, job.d_st_scalars,
                          (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p,
                          (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, ns);
+    } else {
+      Launch l(c, "k_locate_combine", L);       // names the culprit (or queues the whole group) and writes the digits of the queued
+      hipLaunchKernelGGL(k_locate_combine, dim3(n_groups), dim3(256), 0, L, (const uint32_t*)c->grp_partials.p,
+                         (uint32_t)(W * Pg), (const uint32_t*)c->dynsum.p, (const uint32_t*)c->msm_fail.p, job.d_wellformed,
+                         (uint32_t)B, group, (const uint32_t*)fail_list, (const uint32_t*)n_fail,
+                         (const uint32_t*)c->grp_fail_sum.p, (uint32_t*)c->row_map.p, n_recheck, cand, job.d_st_scalars, ns,
+                         (int16_t*)c->digits.p, ps->tbl_w, W);
     }
     {
       Launch l(c, "k_static_accumulate", L);
@@ -890,15 +935,24 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
       Launch l(c, "k_static_combine", L);
       hipLaunchKernelGGL(k_static_combine, dim3((unsigned)B), dim3(64), 0, L, (const uint32_t*)c->st_partials.p,
                          (uint32_t)(W * Pf), (const uint32_t*)c->dynsum.p, (const uint8_t*)c->accept.p,
-                         (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, (uint8_t*)c->accept2.p);
+                         (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, (uint8_t*)c->accept2.p,
+                         (uint32_t*)c->rechk_pts.p);
+    }
+    {
+      Launch l(c, "k_pack_bitmap", L);          // with the verdict of the located groups' other transactions: S1 - E_b
+      hipLaunchKernelGGL(k_pack_bitmap_groups, dim3(blocks_for(nbytes, 256)), dim3(256), 0, L, (const uint8_t*)c->accept2.p,
+                         job.d_wellformed, (const uint32_t*)c->msm_fail.p, (uint8_t*)c->bitmap.p, (uint32_t)B, group,
+                         (const uint32_t*)grp_state, (const uint32_t*)c->grp_fail_sum.p, (const uint32_t*)cand,
+                         (const uint32_t*)c->row_map.p, (const uint32_t*)c->rechk_pts.p, (uint32_t*)c->status.p,
+                         c->force_unresolved ? 1u : 0u);
     }
   } else {
     Launch l(c, "k_static_combine", L);
     hipLaunchKernelGGL(k_static_combine, dim3((unsigned)B), dim3(64), 0, L, (const uint32_t*)c->st_partials.p,
                        (uint32_t)(W * P), (const uint32_t*)c->dynsum.p, (const uint8_t*)c->accept.p,
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)c->accept2.p);
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)c->accept2.p, (uint32_t*)nullptr);
   }
-  {
+  if (group <= 1) {
     Launch l(c, "k_pack_bitmap", L);
     hipLaunchKernelGGL(k_pack_bitmap, dim3(blocks_for(nbytes, 256)), dim3(256), 0, L, (const uint8_t*)c->accept2.p,
                        job.d_wellformed, (uint8_t*)c->bitmap.p, (uint32_t)B);
@@ -906,7 +960,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   HIP_TRY(c, hipGetLastError());
   char* h = (char*)c->pinned;
   HIP_TRY(c, hipMemcpyAsync(h, c->bitmap.p, nbytes, hipMemcpyDeviceToHost, L));
-  HIP_TRY(c, hipMemcpyAsync(h + nbytes, c->status.p, 16, hipMemcpyDeviceToHost, L));
+  HIP_TRY(c, hipMemcpyAsync(h + nbytes, c->status.p, 48, hipMemcpyDeviceToHost, L));
   HIP_TRY(c, hipEventRecord(c->ev_done, L));
   c->pending = true;
   c->pending_batch = B;
@@ -938,6 +992,24 @@ int pipe_wait(zkgpu_ctx* c, uint8_t* accept_bitmap) {
   const char* h = (const char*)c->pinned;
   uint32_t st;
   memcpy(&st, h + nbytes, 4);
+  if ((st & 4u) && c->last.valid && c->group_size > 1) {
+    // a located transaction did not account for its group's sum (probability ~2^-248, or the test hook): verdicts
+    // must not rest on it -- run the same batch again with every transaction checked on its own
+    Job job;
+    PrepLaunch prep;
+    memcpy(&job, c->last.job.data(), sizeof job);
+    if (c->last.has_prep) memcpy(&prep, c->last.prep.data(), sizeof prep);
+    const int saved = c->group_size;
+    c->group_size = 1;
+    const int rc = pipe_enqueue(c, job, c->last.ps, c->last.has_prep ? &prep : nullptr);
+    c->group_size = saved;
+    c->pending = false;
+    ++c->regroup_fallbacks;
+    if (rc != ZKGPU_OK) return rc;
+    HIP_TRY(c, hipEventSynchronize(c->ev_done));
+    if (c->profiling) prof_collect(c);
+    memcpy(&st, h + nbytes, 4);
+  }
   if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
   memcpy(accept_bitmap, h, nbytes);
   return ZKGPU_OK;
@@ -1017,6 +1089,7 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
     c->owns_streams = false;
     c->group_size = parent->group_size;
     c->transcript_mode = parent->transcript_mode;
+    c->locate_mode = parent->locate_mode;
   } else {
     ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
          hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
@@ -1097,7 +1170,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
                     &c->in_st_offsets, &c->dyn_rows, &c->bins, &c->block_sums, &c->entries, &c->buckets,
                     &c->partials, &c->partial_flags, &c->window_sums, &c->window_flags, &c->msm_fail,
                     &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform,
-                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->small_tbl, &c->recoded, &c->grp_sc, &c->grp_digits, &c->grp_partials, &c->grp_ok, &c->row_map, &c->prep_com, &c->prep_proofs, &c->prep_r,
+                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->small_tbl, &c->recoded, &c->grp_sc, &c->grp_digits, &c->grp_partials, &c->grp_ok, &c->row_map, &c->grp_fail, &c->grp_fail_sum, &c->rechk_pts, &c->prep_com, &c->prep_proofs, &c->prep_r,
                     &c->prep_pw, &c->prep_ch, &c->prep_wf, &c->prep_dyn_sc, &c->prep_dyn_pt, &c->prep_st_sc,
                     &c->prep_absorb, &c->prep_raw};
   for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
@@ -1314,6 +1387,24 @@ int zkgpu_debug_coop_selftest(zkgpu_ctx* c, const uint32_t* in, uint32_t* out, u
   if (n_states) HIP_TRY(c, hipMemcpyAsync(states, c->in_points.p, n_states * 200, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ZKGPU_OK;
+}
+
+// Failed groups: 0 automatic (locate the culprit from LOCATE_MIN_BATCH transactions per batch on), 1 always re-check
+// every transaction of a failed group, 2 always locate.  Same verdicts either way.
+int zkgpu_set_locate_mode(zkgpu_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 2) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->locate_mode = mode;
+  return ZKGPU_OK;
+}
+
+// Test hook: with on != 0 every located transaction is treated as NOT accounting for its group's sum, which sends
+// the batch down the ungrouped re-run in zkgpu_verify_wait; returns how many such re-runs this context has made.
+long long zkgpu_debug_force_regroup(zkgpu_ctx* c, int on) {
+  if (!c) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->force_unresolved = on != 0;
+  return (long long)c->regroup_fallbacks;
 }
 
 int zkgpu_set_group_size(zkgpu_ctx* c, int group) {

@@ -140,6 +140,9 @@ def load_library():
     lib.zkgpu_comm_allgather_bitmap.argtypes = [vp, u64p, u8p, C.c_int, u8p]
     lib.zkgpu_verifier_verify_sharded.argtypes = [vp, vp, sz, u32p, u32p, u8p, u8p, u64p, u8p, u8p]
     lib.zkgpu_set_transcript_mode.argtypes = [vp, C.c_int]
+    lib.zkgpu_set_locate_mode.argtypes = [vp, C.c_int]
+    lib.zkgpu_debug_force_regroup.argtypes = [vp, C.c_int]
+    lib.zkgpu_debug_force_regroup.restype = C.c_longlong
     lib.zkgpu_debug_coop_selftest.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), sz]
     lib.zkgpu_cloak_plan_layout.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.zkgpu_debug_read.argtypes = [vp, C.c_char_p, vp, sz]
@@ -233,6 +236,14 @@ class Context:
         st = (C.c_uint64 * max(len(flat), 1))(*flat)
         self._check(self.lib.zkgpu_debug_coop_selftest(self.h, inp, out, st, len(states)))
         return [list(out[64 * i: 64 * i + 64]) for i in range(8)], [list(st[25 * i: 25 * i + 25]) for i in range(len(states))]
+
+    def set_locate_mode(self, mode: int) -> None:
+        """zkgpu_set_locate_mode: failed groups -- 0 automatic, 1 re-check every transaction, 2 locate the culprit."""
+        self._check(self.lib.zkgpu_set_locate_mode(self.h, mode))
+
+    def force_regroup(self, on: bool) -> int:
+        """zkgpu_debug_force_regroup: test hook for the ungrouped re-run; returns the re-runs so far."""
+        return int(self.lib.zkgpu_debug_force_regroup(self.h, 1 if on else 0))
 
     def set_serial(self, on: bool) -> None:
         """zkgpu_set_serial: one stream for the whole batch (measurement aid)."""
