@@ -172,6 +172,55 @@ int zkgpu_cloak_verify_batch_gpu(zkgpu_ctx *ctx, const zkgpu_pointset *ps, zkgpu
                                  const uint8_t *commitments, const uint8_t *proofs, size_t proof_len,
                                  const uint8_t *r_bytes, uint8_t *accept_bitmap);
 
+/* ---- any constraint system, described as data ------------------------------
+ * What lets Tx::verify use the device path for statements that are not a pure cloak: the caller (the Rust
+ * host running the VM) traces its gadgets ONCE per statement shape with symbolic coefficients and hands over
+ * the constraint system as arrays; zkgpu_cloak_plan_create is exactly this, with the library tracing the
+ * cloak gadget itself.  Replaces: bulletproofs::r1cs::Verifier's constraint collection (constrain / multiply /
+ * allocate_multiplier / specify_randomized_constraints + challenge_scalar) for the purposes of verification.
+ *   - n_commitments m: the statement commits V_0 .. V_{m-1} (32 bytes each, in this order, per statement);
+ *   - multipliers [0, n_multipliers_phase1) are allocated before the randomized constraints, the rest by them;
+ *   - challenge_labels: Merlin labels of the challenge scalars the randomized constraints draw, in drawing order
+ *     (none, and no second-phase multipliers: a single-phase statement, dom-sep "r1cs-1phase");
+ *   - constraint q (in the order the constraint system emitted them -- the flattening weighs it z^(q+1)) is
+ *         sum over its terms of  coefficient * variable  = 0
+ *     with variable = (kind, index): 0 committed V_index, 1 / 2 / 3 left / right / output of multiplier index,
+ *     4 the constant one; coefficient = c * challenge[term_challenge]^term_power, c a canonical 32-byte scalar,
+ *     term_challenge = -1 for a plain constant.  (A coefficient involving two different challenges is not
+ *     representable; no ZkVM gadget needs one.)
+ * The resulting plan is a zkgpu_cloak_plan in all but name: every whole-proof entry point takes it
+ * (zkgpu_r1cs_verify_* are the same functions under generic names; commitments = m x 32 bytes per statement;
+ * proof_len = 1 + 32 (16 + 2 lg padded multipliers)).  zkgpu_r1cs_verify_batch is the host-prepared form
+ * (transcript replay and scalars on host threads, as zkgpu_cloak_verify_batch). */
+typedef struct zkgpu_r1cs_desc {
+  const char *transcript_label;          /* Transcript::new(label), e.g. "ZkVM.r1cs" */
+  uint32_t n_commitments;
+  uint32_t n_multipliers_phase1;
+  uint32_t n_multipliers;
+  uint32_t n_challenges;
+  const char *const *challenge_labels;
+  uint32_t n_constraints;
+  const uint64_t *term_offsets;          /* n_constraints + 1 */
+  const uint8_t *term_var_kind;
+  const uint32_t *term_var_index;
+  const uint8_t *term_coeff;             /* 32 bytes per term */
+  const int32_t *term_challenge;
+  const uint32_t *term_power;
+} zkgpu_r1cs_desc;
+typedef zkgpu_cloak_plan zkgpu_r1cs_plan;
+int zkgpu_r1cs_plan_create(zkgpu_ctx *ctx, const zkgpu_r1cs_desc *desc, size_t gens_capacity, zkgpu_r1cs_plan **out);
+void zkgpu_r1cs_plan_destroy(zkgpu_r1cs_plan *plan);
+int zkgpu_r1cs_verify_batch_gpu(zkgpu_ctx *ctx, const zkgpu_pointset *ps, zkgpu_r1cs_plan *plan, size_t batch,
+                                const uint8_t *commitments, const uint8_t *proofs, size_t proof_len,
+                                const uint8_t *r_bytes, uint8_t *accept_bitmap);
+int zkgpu_r1cs_verify_submit(zkgpu_ctx *ctx, const zkgpu_pointset *ps, zkgpu_r1cs_plan *plan, size_t batch,
+                             const uint8_t *commitments, const uint8_t *proofs, size_t proof_len, const uint8_t *r_bytes);
+int zkgpu_r1cs_verify_submit_dev(zkgpu_ctx *ctx, const zkgpu_pointset *ps, zkgpu_r1cs_plan *plan, size_t batch,
+                                 const void *d_commitments, const void *d_proofs, size_t proof_len, const void *d_r);
+int zkgpu_r1cs_verify_batch(zkgpu_ctx *ctx, const zkgpu_pointset *ps, const zkgpu_r1cs_desc *desc, size_t gens_capacity,
+                            size_t batch, const uint8_t *commitments, const uint8_t *proofs, size_t proof_len,
+                            const uint8_t *r_bytes, uint8_t *accept_bitmap, int host_threads);
+
 /* The same with commitments, proofs and verifier randomness already resident in HBM
  * (device pointers; this is what bench.py times as one step). */
 int zkgpu_cloak_verify_batch_gpu_dev(zkgpu_ctx *ctx, const zkgpu_pointset *ps, zkgpu_cloak_plan *plan, size_t batch,

@@ -335,3 +335,50 @@ def cloak_verify_batch(commitments: bytes, n_in: int, n_out: int, proofs: bytes,
     load().zko_cloak_verify_batch(C.c_size_t(count), C.c_size_t(n_in), C.c_size_t(n_out), commitments, proofs,
                                   C.c_size_t(proof_len), C.c_size_t(proof_len), r_bytes, acc, C.c_int(threads))
     return acc.raw[:count]
+
+
+L_ORDER = 2**252 + 27742317777372353535851937790883648493
+
+# ---- statements other than the cloak (oracle/gadgets.c) ----------------------------------------
+GADGET_RANGE, GADGET_SHUFFLE = 1, 2
+
+
+def gadget_commitments(kind: int, param: int) -> int:
+    lib = load()
+    lib.zko_gadget_commitments.restype = C.c_size_t
+    return int(lib.zko_gadget_commitments(C.c_int(kind), C.c_size_t(param)))
+
+
+def gadget_prove(kind: int, param: int, values: Sequence[int], seed: bytes):
+    """-> (rc, commitments m x 32 bytes, proof)"""
+    m = gadget_commitments(kind, param)
+    assert len(values) == m and len(seed) == 32
+    vals = b"".join(int(v % L_ORDER).to_bytes(32, "little") for v in values)
+    com = C.create_string_buffer(32 * m)
+    cap = 1 + 32 * (16 + 2 * 20)
+    proof = C.create_string_buffer(cap)
+    plen = C.c_size_t(0)
+    rc = load().zko_gadget_prove(C.c_int(kind), C.c_size_t(param), vals, seed, com, proof, C.c_size_t(cap), C.byref(plen))
+    return rc, com.raw, proof.raw[: plen.value]
+
+
+def gadget_verify(kind: int, param: int, commitments: bytes, proof: bytes, r_bytes: bytes) -> bool:
+    return bool(load().zko_gadget_verify(C.c_int(kind), C.c_size_t(param), commitments, proof, C.c_size_t(len(proof)), r_bytes))
+
+
+def gadget_verify_prepare(kind: int, param: int, commitments: bytes, proof: bytes, r_bytes: bytes):
+    """-> None when malformed, else (dyn_scalars, dyn_points, static_scalars, padded_n, challenges as ints)"""
+    m = R1csMsm()
+    lib = load()
+    cap = 128
+    buf = C.create_string_buffer(32 * cap)
+    n = C.c_size_t(0)
+    rc = lib.zko_gadget_verify_prepare(C.c_int(kind), C.c_size_t(param), commitments, proof, C.c_size_t(len(proof)), r_bytes,
+                                       C.byref(m), buf, C.c_size_t(cap), C.byref(n))
+    if rc != 0:
+        return None
+    out = (C.string_at(m.dyn_scalars, 32 * m.n_dyn), C.string_at(m.dyn_points, 32 * m.n_dyn),
+           C.string_at(m.static_scalars, 32 * m.n_static), int(m.padded_n),
+           [int.from_bytes(buf.raw[32 * i: 32 * i + 32], "little") for i in range(n.value)])
+    lib.r1cs_msm_free(C.byref(m))
+    return out

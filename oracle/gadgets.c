@@ -1,0 +1,164 @@
+/* gadgets.c -- two statements that are NOT a cloak, proved and verified through the generic constraint
+ * system of r1cs.c: what a ZkVM program other than `cloak` would hand to the proof system.
+ *
+ * TEST INFRASTRUCTURE (see oracle.h).  They exist so that the product's generic entry point
+ * (zkgpu_r1cs_plan_create: a constraint system described as data) can be
+ * checked against an independent implementation on statements the product has no built-in code for:
+ *
+ *   kind 1, param = nbits   "v lies in [0, 2^nbits)" for ONE committed value: the bit-decomposition
+ *                           range proof of the cloak gadget on its own.  No randomized constraints:
+ *                           a single-phase proof.
+ *   kind 2, param = k       "y_1..y_k is a permutation of x_1..x_k" for 2k committed scalars: the
+ *                           scalar shuffle prod (x_i - z) = prod (y_i - z) with a second-phase
+ *                           challenge z ("shuffle challenge").
+ *
+ * Transcript label "zkvm_amd.gadget" (deliberately not the cloak's).  PARITY UNPINNED like r1cs.c. */
+#include "r1cs.h"
+#include <stdlib.h>
+#include <string.h>
+
+static const char G_LABEL[] = "zkvm_amd.gadget";
+
+static void lc_var1(r1cs_lc *l, r1cs_var v) { lc_init(l); lc_push_u64(l, v, 1); }
+static void lc_sub1(r1cs_lc *l, r1cs_var v, const sc *c) { sc n; sc_neg(&n, c); lc_push(l, v, &n); }
+
+static void derive2(const uint8_t seed[32], const char *tag, uint64_t i, uint8_t *out, size_t n) {
+  shake256_ctx c;
+  uint8_t ib[8];
+  for (int k = 0; k < 8; ++k) ib[k] = (uint8_t)(i >> (8 * k));
+  shake256_init(&c);
+  shake256_absorb(&c, seed, 32);
+  shake256_absorb(&c, (const uint8_t *)tag, strlen(tag));
+  shake256_absorb(&c, ib, 8);
+  shake256_squeeze(&c, out, n);
+}
+
+/* bits of v (prover: from its value; verifier: unassigned) */
+static void range_gadget(r1cs_cs *cs, r1cs_var v, const sc *val, int nbits) {
+  sc one, exp2, neg;
+  sc_from_u64(&one, 1);
+  exp2 = one;
+  uint8_t vb[32] = {0};
+  if (val) sc_to_bytes(vb, val);
+  r1cs_lc acc;
+  lc_var1(&acc, v);
+  for (int i = 0; i < nbits; ++i) {
+    uint64_t bit = val ? (vb[i >> 3] >> (i & 7)) & 1 : 0;
+    sc a, b;
+    sc_from_u64(&a, 1 - bit); sc_from_u64(&b, bit);
+    r1cs_var out[3];
+    r1cs_allocate_multiplier(cs, &a, &b, out);
+    r1cs_lc l;
+    lc_var1(&l, out[2]); r1cs_constrain(cs, &l);
+    lc_var1(&l, out[0]); lc_push(&l, out[1], &one); lc_sub1(&l, var_one(), &one);
+    r1cs_constrain(cs, &l);
+    sc_neg(&neg, &exp2);
+    lc_push(&acc, out[1], &neg);
+    sc_add(&exp2, &exp2, &exp2);
+  }
+  r1cs_constrain(cs, &acc);
+}
+
+typedef struct { size_t k; r1cs_var *x, *y; } shuf_ud;
+
+static r1cs_var prod_minus_z(r1cs_cs *cs, const r1cs_var *x, size_t k, const sc *z) {
+  r1cs_lc a, b;
+  r1cs_var out[3];
+  lc_var1(&a, x[k - 1]); lc_sub1(&a, var_one(), z);
+  lc_var1(&b, x[k - 2]); lc_sub1(&b, var_one(), z);
+  r1cs_multiply(cs, &a, &b, out);
+  for (size_t i = k - 2; i-- > 0;) {
+    lc_var1(&a, out[2]);
+    lc_var1(&b, x[i]); lc_sub1(&b, var_one(), z);
+    r1cs_multiply(cs, &a, &b, out);
+  }
+  return out[2];
+}
+
+static int shuf_cb(r1cs_cs *cs, void *p) {
+  shuf_ud *ud = p;
+  sc z, one;
+  sc_from_u64(&one, 1);
+  r1cs_challenge_scalar(cs, "shuffle challenge", &z);
+  r1cs_var px = prod_minus_z(cs, ud->x, ud->k, &z);
+  r1cs_var py = prod_minus_z(cs, ud->y, ud->k, &z);
+  r1cs_lc l;
+  lc_var1(&l, px); lc_sub1(&l, py, &one);
+  r1cs_constrain(cs, &l);
+  free(ud->x); free(ud->y); free(ud);
+  return 0;
+}
+
+static int shuffle_gadget(r1cs_cs *cs, const r1cs_var *x, const r1cs_var *y, size_t k) {
+  sc one; sc_from_u64(&one, 1);
+  if (k == 1) { r1cs_lc l; lc_var1(&l, y[0]); lc_sub1(&l, x[0], &one); r1cs_constrain(cs, &l); return 0; }
+  shuf_ud *ud = malloc(sizeof *ud);
+  ud->k = k;
+  ud->x = malloc(sizeof(r1cs_var) * k); ud->y = malloc(sizeof(r1cs_var) * k);
+  memcpy(ud->x, x, sizeof(r1cs_var) * k); memcpy(ud->y, y, sizeof(r1cs_var) * k);
+  return r1cs_specify_randomized_constraints(cs, shuf_cb, ud);
+}
+
+size_t zko_gadget_commitments(int kind, size_t param) { return kind == 1 ? 1 : kind == 2 ? 2 * param : 0; }
+
+static int build(r1cs_cs *cs, int kind, size_t param, const r1cs_var *vars, const sc *vals) {
+  if (kind == 1) { if (param == 0 || param > 252) return -1; range_gadget(cs, vars[0], vals ? &vals[0] : NULL, (int)param); return 0; }
+  if (kind == 2) { if (param == 0) return -1; return shuffle_gadget(cs, vars, vars + param, param); }
+  return -1;
+}
+
+/* values: one 32-byte canonical scalar per commitment (kind 1: v; kind 2: x_1..x_k, y_1..y_k) */
+int zko_gadget_prove(int kind, size_t param, const uint8_t *values, const uint8_t seed[32], uint8_t *commitments,
+                     uint8_t *proof, size_t proof_cap, size_t *proof_len) {
+  const size_t m = zko_gadget_commitments(kind, param);
+  if (!m) return -1;
+  r1cs_cs *cs = r1cs_prover_new((const uint8_t *)G_LABEL, strlen(G_LABEL));
+  r1cs_var *vars = malloc(sizeof(r1cs_var) * m);
+  sc *vals = malloc(sizeof(sc) * m);
+  for (size_t i = 0; i < m; ++i) {
+    sc bl;
+    uint8_t wide[64];
+    sc_from_bytes_mod_order(&vals[i], values + 32 * i);
+    derive2(seed, "blinding", i, wide, 64); sc_from_bytes_wide(&bl, wide);
+    vars[i] = r1cs_prover_commit(cs, &vals[i], &bl, commitments + 32 * i);
+  }
+  int rc = build(cs, kind, param, vars, vals);
+  uint8_t rng_seed[32];
+  derive2(seed, "rng", 0, rng_seed, 32);
+  if (!rc) rc = r1cs_prove(cs, rng_seed, proof, proof_cap, proof_len);
+  free(vars); free(vals);
+  r1cs_free(cs);
+  return rc;
+}
+
+static r1cs_cs *gadget_verifier(int kind, size_t param, const uint8_t *commitments) {
+  const size_t m = zko_gadget_commitments(kind, param);
+  if (!m) return NULL;
+  r1cs_cs *cs = r1cs_verifier_new((const uint8_t *)G_LABEL, strlen(G_LABEL));
+  r1cs_var *vars = malloc(sizeof(r1cs_var) * m);
+  for (size_t i = 0; i < m; ++i) vars[i] = r1cs_verifier_commit(cs, commitments + 32 * i);
+  int rc = build(cs, kind, param, vars, NULL);
+  free(vars);
+  if (rc) { r1cs_free(cs); return NULL; }
+  return cs;
+}
+
+int zko_gadget_verify(int kind, size_t param, const uint8_t *commitments, const uint8_t *proof, size_t proof_len,
+                      const uint8_t r_bytes[64]) {
+  r1cs_cs *cs = gadget_verifier(kind, param, commitments);
+  if (!cs) return 0;
+  int ok = r1cs_verify(cs, proof, proof_len, r_bytes);
+  r1cs_free(cs);
+  return ok;
+}
+
+/* as zko_cloak_verify_prepare / _challenges */
+int zko_gadget_verify_prepare(int kind, size_t param, const uint8_t *commitments, const uint8_t *proof, size_t proof_len,
+                              const uint8_t r_bytes[64], r1cs_msm *out, uint8_t *challenges, size_t cap, size_t *n_challenges) {
+  r1cs_cs *cs = gadget_verifier(kind, param, commitments);
+  if (!cs) return -1;
+  int rc = r1cs_verify_prepare(cs, proof, proof_len, r_bytes, out);
+  if (rc == 0 && challenges) *n_challenges = r1cs_challenge_log(cs, challenges, cap);
+  r1cs_free(cs);
+  return rc;
+}

@@ -79,6 +79,16 @@ int zko_cloak_verify_batch(size_t count, size_t n_in, size_t n_out, const uint8_
 int zko_cloak_prove_batch(size_t count, size_t n_in, size_t n_out, const uint8_t seed[32], uint8_t *commitments,
                           uint8_t *proofs, size_t proof_stride, size_t *proof_len, int threads);
 
+/* ---- statements other than the cloak (gadgets.c): kind 1 = range proof of one committed value (param = bits),
+ * kind 2 = scalar shuffle of 2 * param committed scalars; transcript label "zkvm_amd.gadget" ---- */
+size_t zko_gadget_commitments(int kind, size_t param);
+int zko_gadget_prove(int kind, size_t param, const uint8_t *values, const uint8_t seed[32], uint8_t *commitments,
+                     uint8_t *proof, size_t proof_cap, size_t *proof_len);
+int zko_gadget_verify(int kind, size_t param, const uint8_t *commitments, const uint8_t *proof, size_t proof_len,
+                      const uint8_t r_bytes[64]);
+int zko_gadget_verify_prepare(int kind, size_t param, const uint8_t *commitments, const uint8_t *proof, size_t proof_len,
+                              const uint8_t r_bytes[64], r1cs_msm *out, uint8_t *challenges, size_t cap, size_t *n_challenges);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,3 +119,50 @@ def msm_2p20_inputs(n: int):
     raw_s = hashlib.shake_256(MSM_SEED.to_bytes(4, "little") + b"msm2p20 scalars").digest(64 * n)
     sc = b"".join((int.from_bytes(raw_s[64 * i: 64 * i + 64], "little") % L).to_bytes(32, "little") for i in range(n))
     return sc, raw_p
+
+
+# ---- constraint systems described as data (include/zkgpu.h, zkgpu_r1cs_desc), written down independently of the
+# ---- library's gadget code and of the oracle's (oracle/gadgets.c): the statements of the generic entry point's tests
+K_COMMITTED, K_LEFT, K_RIGHT, K_OUT, K_ONE = range(5)
+GADGET_LABEL = b"zkvm_amd.gadget"
+
+
+def describe_range(nbits: int):
+    """"v in [0, 2^nbits)" for one committed value: per bit a multiplier (a, b, o) with o = 0 and a + b - 1 = 0, then
+    v - sum b_i 2^i = 0.  Single phase.  -> (m, n1, n, challenge labels, constraints)"""
+    cons = []
+    acc = [(K_COMMITTED, 0, 1, -1, 0)]
+    for i in range(nbits):
+        cons.append([(K_OUT, i, 1, -1, 0)])
+        cons.append([(K_LEFT, i, 1, -1, 0), (K_RIGHT, i, 1, -1, 0), (K_ONE, 0, -1, -1, 0)])
+        acc.append((K_RIGHT, i, -(1 << i), -1, 0))
+    cons.append(acc)
+    return 1, nbits, nbits, [], cons
+
+
+def describe_shuffle(k: int):
+    """"y is a permutation of x" for 2k committed scalars (x = V_0..V_{k-1}, y = V_k..V_{2k-1}): with the second-phase
+    challenge z, prod (x_i - z) = prod (y_i - z), each product a chain of multipliers.  -> (m, n1, n, labels, constraints)"""
+    if k == 1:
+        return 2, 0, 0, [], [[(K_COMMITTED, 1, 1, -1, 0), (K_COMMITTED, 0, -1, -1, 0)]]
+    cons, mult = [], [0]
+
+    def multiply(left, right):
+        i = mult[0]
+        mult[0] += 1
+        cons.append(left + [(K_LEFT, i, -1, -1, 0)])
+        cons.append(right + [(K_RIGHT, i, -1, -1, 0)])
+        return i
+
+    def minus_z(var):
+        return [var + (1, -1, 0), (K_ONE, 0, -1, 0, 1)]          # var - z
+
+    def product(vs):
+        i = multiply(minus_z(vs[-1]), minus_z(vs[-2]))
+        for v in reversed(vs[:-2]):
+            i = multiply([(K_OUT, i, 1, -1, 0)], minus_z(v))
+        return i
+    px = product([(K_COMMITTED, i) for i in range(k)])
+    py = product([(K_COMMITTED, k + i) for i in range(k)])
+    cons.append([(K_OUT, px, 1, -1, 0), (K_OUT, py, -1, -1, 0)])
+    return 2 * k, 0, mult[0], [b"shuffle challenge"], cons

@@ -341,3 +341,80 @@ def test_failed_groups_are_located_and_every_pattern_of_bad_transactions_resolve
         ctx.force_regroup(False)
         v.close()
         gens.close()
+
+
+@pytest.mark.parametrize("kind,param", [(1, 32), (1, 64), (2, 2), (2, 5), (2, 9)])
+def test_described_constraint_systems_on_device(ctx, oracle, kind, param):
+    """zkgpu_r1cs_plan_create: a constraint system handed over as data -- a bare range proof
+    (single phase) and a scalar shuffle (second-phase challenge, multipliers only in phase 2), written down in
+    tests/gpu_util.py independently of the library and of the oracle -- verified with the transcript replay, the scalars
+    and the multiscalar multiplications on the device: verdicts = the oracle's (its own gadget code, oracle/gadgets.c),
+    incl. invalid witnesses and corrupted proofs; the device's challenges and every scalar of the equation = the
+    oracle's (times c'); the host-prepared form (zkgpu_r1cs_verify_batch) agrees."""
+    import random
+    from gpu_util import GADGET_LABEL, describe_range, describe_shuffle
+    from zkvm_amd.native import R1csDescription
+    from zkvm_amd.verifier import BulletproofGens, R1csVerifier
+    rng = random.Random(1000 * kind + param)
+    m, n1, n, labels, cons = describe_range(param) if kind == 1 else describe_shuffle(param)
+    desc = R1csDescription(GADGET_LABEL, m, n1, n, labels, cons)
+    gens = BulletproofGens(ctx, 64, table_bits=8)
+    v = R1csVerifier(ctx, gens, desc)
+    ctx.set_group_size(1)
+    try:
+        info = v.info()
+        batch = 21
+        coms, proofs = [], []
+        for i in range(batch):
+            if kind == 1:
+                values = [rng.randrange(1 << param)]
+                if i == 4:
+                    values = [(1 << param) + 3]                       # out of range: the proof exists but does not verify
+            else:
+                xs = [rng.randrange(L) for _ in range(param)]
+                ys = xs[:]
+                rng.shuffle(ys)
+                if i == 4:
+                    ys[0] = (ys[0] + 1) % L                           # not a permutation
+                values = xs + ys
+            rc, com, proof = oracle.gadget_prove(kind, param, values, hashlib.sha256(b"gadget %d %d %d" % (kind, param, i)).digest())
+            assert rc == 0 and len(proof) == info["proof_len"]
+            coms.append(bytearray(com)); proofs.append(bytearray(proof))
+        proofs[7][1 + 32 * 12 + 5] ^= 0x10                            # t_x_blinding
+        coms[9][3] ^= 1                                               # a commitment
+        proofs[11][1 + 32 * 6: 1 + 32 * 7] = bytes(32)                # T_1 = identity: malformed
+        proofs[13][0] = 3                                             # wire-format version
+        r = hashlib.shake_256(b"gadget r %d %d" % (kind, param)).digest(64 * batch)
+        com_b, proof_b = b"".join(bytes(c) for c in coms), b"".join(bytes(p) for p in proofs)
+        want = [int(oracle.gadget_verify(kind, param, bytes(coms[i]), bytes(proofs[i]), r[64 * i: 64 * i + 64])) for i in range(batch)]
+        assert want == [0 if i in (4, 7, 9, 11, 13) else 1 for i in range(batch)]
+        assert bits(v.verify_gpu(batch, com_b, proof_b, info["proof_len"], r), batch) == want
+        # the device's head, byte by byte (transactions checked alone: rho = 1)
+        ch = ctx.debug_read("challenges", batch * info["slots"] * 32)
+        st = ctx.debug_read("static_scalars", batch * info["n_static"] * 32)
+        dy = ctx.debug_read("dyn_scalars", batch * info["n_dyn"] * 32)
+        n2, k, pn = info["n_chal2"], info["k"], info["padded_n"]
+        for i in (0, 1, 20):
+            ds, _, ss, opn, want_ch = oracle.gadget_verify_prepare(kind, param, bytes(coms[i]), bytes(proofs[i]), r[64 * i: 64 * i + 64])
+            assert opn == pn and len(want_ch) == n2 + 5 + k
+
+            def slot(j):
+                o = (i * info["slots"] + j) * 32
+                return int.from_bytes(ch[o: o + 32], "little") * R260_INV % L
+            assert [slot(14 + j) for j in range(n2)] + [slot(j) for j in range(5)] + [slot(14 + n2 + j) for j in range(k)] == want_ch
+            cp = pow(want_ch[n2], pn - 1, L)
+            for u in want_ch[n2 + 5:]:
+                cp = cp * u * u % L
+            for got, wantb, cnt in ((st, ss, info["n_static"]), (dy, ds, info["n_dyn"])):
+                assert len(wantb) == 32 * cnt
+                for j in range(cnt):
+                    g = int.from_bytes(got[(i * cnt + j) * 32: (i * cnt + j + 1) * 32], "little")
+                    assert g == int.from_bytes(wantb[32 * j: 32 * j + 32], "little") * cp % L, (i, j)
+        assert bits(v.verify_host_prepared(batch, com_b, proof_b, info["proof_len"], r, host_threads=4), batch) == want
+        ctx.set_group_size(16)
+        assert bits(v.verify_gpu(batch, com_b, proof_b, info["proof_len"], r), batch) == want
+        assert bits(v.verify_gpu(batch, com_b, proof_b, info["proof_len"]), batch) == want       # getrandom
+    finally:
+        ctx.set_group_size(16)
+        v.close()
+        gens.close()

@@ -214,3 +214,53 @@ def test_cooperative_transcript_segments_equal_tape(host, shape):
         n2 = host.zkhost_coop_challenges(n_in, n_out, com, proof, C.c_size_t(len(proof)), c, C.c_size_t(64))
         assert n == n2 > 5
         assert a.raw[: 32 * n] == b.raw[: 32 * n] == c.raw[: 32 * n]
+
+
+@pytest.mark.parametrize("kind,param", [(1, 8), (1, 64), (2, 1), (2, 2), (2, 5)])
+def test_described_constraint_system_equals_oracle_gadget(host, oracle, kind, param):
+    """The generic entry point's semantics on the host: a constraint system written down as data in the test
+    (tests/gpu_util.py: a range proof, a scalar shuffle -- statements the library has no built-in code for), run
+    through the product's host verifier (prepare_desc), gives byte for byte the multiscalar-multiplication terms
+    of the oracle's verifier for the same statement built with its own gadget code (oracle/gadgets.c)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from gpu_util import GADGET_LABEL, describe_range, describe_shuffle
+    rng = random.Random(100 * kind + param)
+    m, n1, n, labels, cons = describe_range(param) if kind == 1 else describe_shuffle(param)
+    if kind == 1:
+        values = [rng.randrange(1 << param)]
+    else:
+        xs = [rng.randrange(L) for _ in range(param)]
+        ys = xs[:]
+        rng.shuffle(ys)
+        values = xs + ys
+    rc, com, proof = oracle.gadget_prove(kind, param, values, bytes([kind, param]) * 16)
+    assert rc == 0
+    r = hashlib.shake_256(b"desc %d %d" % (kind, param)).digest(64)
+    assert oracle.gadget_verify(kind, param, com, proof, r)
+    want = oracle.gadget_verify_prepare(kind, param, com, proof, r)
+    offs, kinds, idx, coeff, chal, power = [0], [], [], b"", [], []
+    for con in cons:
+        for (k_, i_, c_, ch_, pw_) in con:
+            kinds.append(k_); idx.append(i_); coeff += (c_ % L).to_bytes(32, "little"); chal.append(ch_); power.append(pw_)
+        offs.append(len(kinds))
+    nt = max(len(kinds), 1)
+    cap = 256
+    ds, dp = C.create_string_buffer(32 * 128), C.create_string_buffer(32 * 128)
+    ss, si = C.create_string_buffer(32 * (2 + 2 * cap)), (C.c_uint32 * (2 + 2 * cap))()
+    nd, ns, pn = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    lab = (C.c_char_p * max(len(labels), 1))(*labels)
+    rc = host.zkhost_r1cs_prepare(GADGET_LABEL, m, n1, n, len(labels), lab, len(cons), (C.c_uint64 * len(offs))(*offs),
+                                  (C.c_uint8 * nt)(*kinds), (C.c_uint32 * nt)(*idx), coeff, (C.c_int32 * nt)(*chal),
+                                  (C.c_uint32 * nt)(*power), com, proof, C.c_size_t(len(proof)), r, C.c_size_t(cap), ds, dp,
+                                  C.byref(nd), ss, si, C.byref(ns), C.byref(pn))
+    assert rc == 0
+    assert pn.value == want[3]
+    assert ds.raw[: 32 * nd.value] == want[0] and dp.raw[: 32 * nd.value] == want[1] and ss.raw[: 32 * ns.value] == want[2]
+    # a mutated proof is malformed or yields different terms; a mutated description (one coefficient) yields different terms
+    bad = bytearray(proof); bad[1 + 32 * 11] ^= 1
+    rc2 = host.zkhost_r1cs_prepare(GADGET_LABEL, m, n1, n, len(labels), lab, len(cons), (C.c_uint64 * len(offs))(*offs),
+                                   (C.c_uint8 * nt)(*kinds), (C.c_uint32 * nt)(*idx), coeff, (C.c_int32 * nt)(*chal),
+                                   (C.c_uint32 * nt)(*power), com, bytes(bad), C.c_size_t(len(proof)), r, C.c_size_t(cap), ds, dp,
+                                   C.byref(nd), ss, si, C.byref(ns), C.byref(pn))
+    assert rc2 != 0 or ss.raw[: 32 * ns.value] != want[2]

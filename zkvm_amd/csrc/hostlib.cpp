@@ -65,6 +65,39 @@ int zkhost_cloak_prepare(const uint8_t* commitments, size_t n_in, size_t n_out, 
   return 0;
 }
 
+// A constraint system described as data (include/zkgpu.h, zkgpu_r1cs_desc) through the host verifier:
+// same argument conventions as zkgpu_r1cs_plan_create; output as zkhost_cloak_prepare.
+int zkhost_r1cs_prepare(const char* label, uint32_t m, uint32_t n1, uint32_t n, uint32_t n_chal, const char* const* chal_labels,
+                        uint32_t n_cons, const uint64_t* term_offsets, const uint8_t* kinds, const uint32_t* idx,
+                        const uint8_t* coeff, const int32_t* chal, const uint32_t* power, const uint8_t* commitments,
+                        const uint8_t* proof, size_t proof_len, const uint8_t r64[64], size_t gens_capacity,
+                        uint8_t* dyn_scalars, uint8_t* dyn_points, size_t* n_dyn, uint8_t* static_scalars,
+                        uint32_t* static_index, size_t* n_static, size_t* padded_n) {
+  R1csDesc d;
+  d.label = label; d.m = m; d.n1 = n1; d.n = n;
+  for (uint32_t i = 0; i < n_chal; ++i) d.chal_names.push_back(chal_labels[i]);
+  for (uint32_t q = 0; q < n_cons; ++q) {
+    std::vector<R1csDesc::Term> con;
+    for (uint64_t t = term_offsets[q]; t < term_offsets[q + 1]; ++t) {
+      Scalar c;
+      if (kinds[t] > 4 || !Scalar::from_canonical(coeff + 32 * t, c)) return -1;
+      con.push_back(R1csDesc::Term{(VarKind)kinds[t], idx[t], c, chal[t], power[t]});
+    }
+    d.cons.push_back(std::move(con));
+  }
+  try { (void)plan_from_desc(d); } catch (const std::exception&) { return -1; }
+  VerifierMsm msm;
+  if (!prepare_desc(d, commitments, proof, proof_len, Scalar::from_wide(r64), gens_capacity, msm)) return 1;
+  *n_dyn = msm.dyn_scalars.size() / 32;
+  *n_static = msm.static_scalars.size() / 32;
+  *padded_n = msm.padded_n;
+  std::memcpy(dyn_scalars, msm.dyn_scalars.data(), msm.dyn_scalars.size());
+  std::memcpy(dyn_points, msm.dyn_points.data(), msm.dyn_points.size());
+  std::memcpy(static_scalars, msm.static_scalars.data(), msm.static_scalars.size());
+  std::memcpy(static_index, msm.static_index.data(), msm.static_index.size() * 4);
+  return 0;
+}
+
 // Keccak-f[1600] through the emulated wavefront of keccak_coop.hpp (the algorithm k_transcript_coop runs)
 void zkhost_keccak_coop(uint64_t state[25]) { coop::keccak_f1600_emulated(state); }
 
@@ -75,14 +108,14 @@ void zkhost_keccak_coop(uint64_t state[25]) { coop::keccak_f1600_emulated(state)
 int zkhost_coop_challenges(uint32_t n_in, uint32_t n_out, const uint8_t* commitments, const uint8_t* proof,
                            size_t proof_len, uint8_t* out, size_t capacity) {
   const CloakPlan plan = PlanBuilder::build(n_in, n_out);
-  const uint32_t m = plan.m, k = plan.k, n_chal2 = (uint32_t)plan.chal_label.size();
+  const uint32_t m = plan.m, k = plan.k, n_chal2 = (uint32_t)plan.chal_names.size();
   if (proof_len != 1 + 32ull * (16 + 2 * k)) return -1;
   const uint32_t ch_fixed = 14;
   Transcript tr("ZkVM.r1cs");
   tr.append_message("dom-sep", (const uint8_t*)"r1cs v1", 7);
   uint32_t init[52];
   tr.export_state(init);
-  const std::vector<uint32_t> tape = build_r1cs_verifier_tape(init[50], init[51], m, plan.chal_label, k, plan.pn, ch_fixed);
+  const std::vector<uint32_t> tape = build_r1cs_verifier_tape(init[50], init[51], m, plan.chal_names, k, plan.pn, ch_fixed);
   const CoopSegments segs = build_coop_segments(tape, m);
   if (!segs.n_seg()) return -1;
   using KC = coop::KeccakCoop<coop::HostTraits>;
@@ -134,14 +167,14 @@ int zkhost_coop_challenges(uint32_t n_in, uint32_t n_out, const uint8_t* commitm
 int zkhost_tape_challenges(uint32_t n_in, uint32_t n_out, const uint8_t* commitments, const uint8_t* proof,
                            size_t proof_len, uint8_t* out_tape, uint8_t* out_direct, size_t capacity) {
   const CloakPlan plan = PlanBuilder::build(n_in, n_out);
-  const uint32_t m = plan.m, k = plan.k, n_chal2 = (uint32_t)plan.chal_label.size();
+  const uint32_t m = plan.m, k = plan.k, n_chal2 = (uint32_t)plan.chal_names.size();
   if (proof_len != 1 + 32ull * (16 + 2 * k)) return -1;
   const uint32_t ch_fixed = 14;
   Transcript tr("ZkVM.r1cs");
   tr.append_message("dom-sep", (const uint8_t*)"r1cs v1", 7);
   uint32_t init[52];
   tr.export_state(init);
-  const std::vector<uint32_t> tape = build_r1cs_verifier_tape(init[50], init[51], m, plan.chal_label, k, plan.pn, ch_fixed);
+  const std::vector<uint32_t> tape = build_r1cs_verifier_tape(init[50], init[51], m, plan.chal_names, k, plan.pn, ch_fixed);
   uint8_t state[200];
   std::memcpy(state, init, 200);
   std::map<uint32_t, std::vector<uint8_t>> got;
@@ -174,8 +207,7 @@ int zkhost_tape_challenges(uint32_t n_in, uint32_t n_out, const uint8_t* commitm
   } else {
     tr.append_message("dom-sep", (const uint8_t*)"r1cs-2phase", 11);
     for (uint32_t j = 0; j < n_chal2; ++j) {
-      const uint8_t id = plan.chal_label[j];
-      direct[5 + j] = tr.challenge_scalar(id == 0 ? "mix challenge" : id == 1 ? "k-value shuffle challenge" : "shuffle challenge");
+      direct[5 + j] = tr.challenge_scalar(plan.chal_names[j].c_str());
     }
   }
   tr.append_message("A_I2", f + 96, 32); tr.append_message("A_O2", f + 128, 32); tr.append_message("S2", f + 160, 32);

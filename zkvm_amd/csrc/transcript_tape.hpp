@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <string>
 #include <vector>
 
 namespace zk {
@@ -108,14 +109,14 @@ class TapeRecorder {
 };
 
 // The transcript of bulletproofs' r1cs::Verifier::verify after the domain separator, for a
-// statement with m commitments, the given second-phase challenge labels (0 "mix challenge",
-// 1 "k-value shuffle challenge", 2 "shuffle challenge") and an inner-product argument of k
+// statement with m commitments, the given second-phase challenge labels (Merlin labels, in the order the
+// randomized constraints draw them) and an inner-product argument of k
 // rounds over pn generators.  Proof bytes are addressed after the version byte: 32 i is field i of
 // A_I1 A_O1 S1 A_I2 A_O2 S2 T_1 T_3 T_4 T_5 T_6 t_x t_x_blinding e_blinding L_0 R_0 ... a b.
 // Challenge slots: y 0, z 1, u 2, x 3, w 4, second phase ch_fixed + j, u_j ch_fixed + n_chal2 + j.
 // (Order and labels: r1cs_verifier.hpp, R1csVerifier::verify -- the same sequence on the host.)
 inline std::vector<uint32_t> build_r1cs_verifier_tape(uint32_t pos, uint32_t pos_begin, uint32_t m,
-                                                      const std::vector<uint8_t>& chal_label, uint32_t k, uint32_t pn,
+                                                      const std::vector<std::string>& chal_label, uint32_t k, uint32_t pn,
                                                       uint32_t ch_fixed) {
   TapeRecorder rec(pos, pos_begin);
   const uint32_t n_chal2 = (uint32_t)chal_label.size();
@@ -127,10 +128,7 @@ inline std::vector<uint32_t> build_r1cs_verifier_tape(uint32_t pos, uint32_t pos
     rec.append_const("dom-sep", "r1cs-1phase", 11);
   } else {
     rec.append_const("dom-sep", "r1cs-2phase", 11);
-    for (uint32_t j = 0; j < n_chal2; ++j) {
-      const uint8_t id = chal_label[j];
-      rec.challenge(id == 0 ? "mix challenge" : id == 1 ? "k-value shuffle challenge" : "shuffle challenge", ch_fixed + j);
-    }
+    for (uint32_t j = 0; j < n_chal2; ++j) rec.challenge(chal_label[j].c_str(), ch_fixed + j);
   }
   const char* second[3] = {"A_I2", "A_O2", "S2"};
   for (uint32_t i = 0; i < 3; ++i) rec.append_data(second[i], TAPE_SRC_PROOF, 32 * (3 + i), 32);

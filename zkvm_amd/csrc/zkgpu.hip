@@ -1758,27 +1758,15 @@ int plan_upload_bytes(zkgpu_ctx* c, void** dst, const void* src, size_t bytes) {
 #define plan_upload(c, dst, vec) plan_upload_bytes((c), (void**)(dst), (vec).data(), (vec).size() * sizeof((vec)[0]))
 }  // namespace
 
-int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t gens_capacity, zkgpu_cloak_plan** out) {
-  if (!c || !out || n_in + n_out == 0 || n_in > 64 || n_out > 64) return ZKGPU_EINVAL;
-  *out = nullptr;
-  std::lock_guard<std::recursive_mutex> lk(c->mu);
-  DeviceGuard g(c->device);
-  zkgpu_cloak_plan* p = new zkgpu_cloak_plan();
-  p->ctx = c;
-  p->device = c->device;
-  p->gens_capacity = gens_capacity;
-  try {
-    p->host = PlanBuilder::build(n_in, n_out);
-  } catch (const std::exception& e) {
-    c->last_error = e.what();
-    delete p;
-    return ZKGPU_EINVAL;
-  }
+namespace {
+bool desc_from_c(zkgpu_ctx* c, const zkgpu_r1cs_desc* d, R1csDesc& desc);
+// common tail of plan creation: p->host is set
+int plan_finish(zkgpu_ctx* c, zkgpu_cloak_plan* p, size_t gens_capacity, zkgpu_cloak_plan** out) {
   const CloakPlan& h = p->host;
   if (h.pn > gens_capacity || h.k > 16) { delete p; c->last_error = "statement needs more generators than the set holds"; return ZKGPU_EINVAL; }
   PrepShape& s = p->shape;
   s.m = h.m; s.n1 = h.n1; s.n = h.n; s.pn = h.pn; s.k = h.k; s.n_cons = h.n_cons;
-  s.n_chal2 = (uint32_t)h.chal_label.size();
+  s.n_chal2 = (uint32_t)h.chal_names.size();
   s.n_mono = (uint32_t)h.mono_chal.size();
   s.n_targets = h.n_targets();
   s.n_terms = (uint32_t)h.term_q.size();
@@ -1809,13 +1797,13 @@ int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t 
   p->lds_bytes = prepare_lds_slots(s) * 32;
   if (p->lds_bytes > 160 * 1024) { delete p; c->last_error = "plan does not fit the 160 KiB LDS of a CU"; return ZKGPU_EINVAL; }
   // STROBE state after Transcript::new("ZkVM.r1cs") + r1cs_domain_sep()
-  Transcript tr("ZkVM.r1cs");
+  Transcript tr(h.label.c_str());
   tr.append_message("dom-sep", (const uint8_t*)"r1cs v1", 7);
   std::vector<uint32_t> init(52);
   tr.export_state(init.data());
   TRY(plan_upload(c, &p->d_init, init));
   {
-    const std::vector<uint32_t> tape = build_r1cs_verifier_tape(init[50], init[51], s.m, h.chal_label, s.k, s.pn, CH_FIXED);
+    const std::vector<uint32_t> tape = build_r1cs_verifier_tape(init[50], init[51], s.m, h.chal_names, s.k, s.pn, CH_FIXED);
     p->n_ops = (uint32_t)(tape.size() / 4);
     TRY(plan_upload(c, &p->d_tape, tape));
     const CoopSegments segs = build_coop_segments(tape, s.m);
@@ -1836,6 +1824,66 @@ int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t 
   *out = p;
   return ZKGPU_OK;
 }
+
+}  // namespace
+
+int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t gens_capacity, zkgpu_cloak_plan** out) {
+  if (!c || !out || n_in + n_out == 0 || n_in > 64 || n_out > 64) return ZKGPU_EINVAL;
+  *out = nullptr;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  zkgpu_cloak_plan* p = new zkgpu_cloak_plan();
+  p->ctx = c;
+  p->device = c->device;
+  p->gens_capacity = gens_capacity;
+  try {
+    p->host = PlanBuilder::build(n_in, n_out);     // the cloak gadget traced into a description, then the generic path
+  } catch (const std::exception& e) {
+    c->last_error = e.what();
+    delete p;
+    return ZKGPU_EINVAL;
+  }
+  return plan_finish(c, p, gens_capacity, out);
+}
+
+// A plan for ANY constraint system, described as data (what lets Tx::verify use the
+// device path for statements that are not a pure cloak).  See include/zkgpu.h for the conventions.
+int zkgpu_r1cs_plan_create(zkgpu_ctx* c, const zkgpu_r1cs_desc* d, size_t gens_capacity, zkgpu_cloak_plan** out) {
+  if (!c || !out || !d) return ZKGPU_EINVAL;
+  *out = nullptr;
+  R1csDesc desc;
+  if (!desc_from_c(c, d, desc)) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  zkgpu_cloak_plan* p = new zkgpu_cloak_plan();
+  p->ctx = c;
+  p->device = c->device;
+  p->gens_capacity = gens_capacity;
+  try {
+    p->host = plan_from_desc(desc);
+  } catch (const std::exception& e) {
+    c->last_error = e.what();
+    delete p;
+    return ZKGPU_EINVAL;
+  }
+  return plan_finish(c, p, gens_capacity, out);
+}
+
+// the whole-proof entry points under their generic names: a plan is a plan, whatever statement it was made from;
+// commitments = m x 32 bytes per statement
+int zkgpu_r1cs_verify_batch_gpu(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch, const uint8_t* commitments,
+                                const uint8_t* proofs, size_t proof_len, const uint8_t* r_bytes, uint8_t* accept_bitmap) {
+  return zkgpu_cloak_verify_batch_gpu(c, ps, plan, batch, commitments, proofs, proof_len, r_bytes, accept_bitmap);
+}
+int zkgpu_r1cs_verify_submit(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch, const uint8_t* commitments,
+                             const uint8_t* proofs, size_t proof_len, const uint8_t* r_bytes) {
+  return zkgpu_cloak_verify_submit(c, ps, plan, batch, commitments, proofs, proof_len, r_bytes);
+}
+int zkgpu_r1cs_verify_submit_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch, const void* d_commitments,
+                                 const void* d_proofs, size_t proof_len, const void* d_r) {
+  return zkgpu_cloak_verify_submit_dev(c, ps, plan, batch, d_commitments, d_proofs, proof_len, d_r);
+}
+void zkgpu_r1cs_plan_destroy(zkgpu_cloak_plan* p) { zkgpu_cloak_plan_destroy(p); }
 
 void zkgpu_cloak_plan_destroy(zkgpu_cloak_plan* p) {
   if (!p) return;
@@ -2155,6 +2203,88 @@ int zkgpu_cloak_verify_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens
   if (rc != ZKGPU_OK) { memset(accept_bitmap, 0, (batch + 7) / 8); return rc; }
   for (size_t i = 0; i < batch; ++i)
     if (!cb.wellformed[i]) accept_bitmap[i / 8] &= (uint8_t)~(1u << (i % 8));
+  return ZKGPU_OK;
+}
+
+namespace {
+// zkgpu_r1cs_desc -> R1csDesc (validated); false: malformed description
+bool desc_from_c(zkgpu_ctx* c, const zkgpu_r1cs_desc* d, R1csDesc& desc) {
+  if (!d || !d->transcript_label || (d->n_challenges && !d->challenge_labels) || (d->n_constraints && !d->term_offsets)) return false;
+  if (d->n_multipliers_phase1 > d->n_multipliers || d->n_multipliers > (1u << 16) || d->n_commitments > (1u << 12)) return false;
+  const uint64_t n_terms = d->n_constraints ? d->term_offsets[d->n_constraints] : 0;
+  if (n_terms && (!d->term_var_kind || !d->term_var_index || !d->term_coeff || !d->term_challenge || !d->term_power)) return false;
+  if (n_terms >= (1ull << 28)) return false;
+  desc.label = d->transcript_label;
+  desc.m = d->n_commitments; desc.n1 = d->n_multipliers_phase1; desc.n = d->n_multipliers;
+  for (uint32_t i = 0; i < d->n_challenges; ++i) {
+    if (!d->challenge_labels[i]) return false;
+    desc.chal_names.push_back(d->challenge_labels[i]);
+  }
+  for (uint32_t q = 0; q < d->n_constraints; ++q) {
+    if (d->term_offsets[q + 1] < d->term_offsets[q] || d->term_offsets[q + 1] > n_terms) return false;
+    std::vector<R1csDesc::Term> con;
+    for (uint64_t t = d->term_offsets[q]; t < d->term_offsets[q + 1]; ++t) {
+      Scalar coef;
+      if (d->term_var_kind[t] > 4 || !Scalar::from_canonical(d->term_coeff + 32 * t, coef)) { if (c) c->last_error = "r1cs description: bad variable kind or non-canonical coefficient"; return false; }
+      if (d->term_challenge[t] >= (int32_t)d->n_challenges || d->term_power[t] > (1u << 20)) { if (c) c->last_error = "r1cs description: challenge index / power out of range"; return false; }
+      con.push_back(R1csDesc::Term{(VarKind)d->term_var_kind[t], d->term_var_index[t], coef, d->term_challenge[t] < 0 ? -1 : d->term_challenge[t],
+                                   d->term_challenge[t] < 0 ? 0u : d->term_power[t]});
+    }
+    desc.cons.push_back(std::move(con));
+  }
+  return true;
+}
+}  // namespace
+
+// Host-prepared form for a described constraint system: transcript replay, flattening and scalars of every
+// statement on host threads (r1cs_verifier.hpp through prepare_desc), the multiscalar multiplications in one
+// device call.  Uniform batch: m x 32 bytes of commitments and proof_len bytes of proof per statement.
+int zkgpu_r1cs_verify_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, const zkgpu_r1cs_desc* d, size_t gens_capacity, size_t batch,
+                            const uint8_t* commitments, const uint8_t* proofs, size_t proof_len, const uint8_t* r_bytes,
+                            uint8_t* accept_bitmap, int host_threads) {
+  if (!c || !ps || !accept_bitmap || !d || (batch && (!commitments || !proofs))) return ZKGPU_EINVAL;
+  memset(accept_bitmap, 0, (batch + 7) / 8);
+  if (ps->n < 2 + 2 * gens_capacity) return ZKGPU_EINVAL;
+  R1csDesc desc;
+  if (!desc_from_c(c, d, desc)) return ZKGPU_EINVAL;
+  try { (void)plan_from_desc(desc); } catch (const std::exception& e) { c->last_error = e.what(); return ZKGPU_EINVAL; }
+  if (batch == 0) return ZKGPU_OK;
+  std::vector<uint8_t> rnd;
+  if (!r_bytes) {
+    rnd.resize(64 * batch);
+    if (!os_random(rnd.data(), rnd.size())) return ZKGPU_EINVAL;
+    r_bytes = rnd.data();
+  }
+  std::vector<VerifierMsm> prep(batch);
+  std::vector<uint8_t> wellformed(batch, 0);
+  const int nt = std::max(1, std::min<int>(host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency(), 256));
+  auto work = [&](int tid) {
+    for (size_t i = (size_t)tid; i < batch; i += (size_t)nt)
+      wellformed[i] = prepare_desc(desc, commitments + 32ull * desc.m * i, proofs + proof_len * i, proof_len,
+                                   Scalar::from_wide(r_bytes + 64 * i), gens_capacity, prep[i]) ? 1 : 0;
+  };
+  if (nt == 1) work(0);
+  else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto& t : th) t.join(); }
+  CloakBatch cb;
+  cb.dyn_off.assign(batch + 1, 0); cb.st_off.assign(batch + 1, 0);
+  for (size_t i = 0; i < batch; ++i) {
+    cb.dyn_off[i + 1] = cb.dyn_off[i] + (wellformed[i] ? prep[i].dyn_scalars.size() / 32 : 0);
+    cb.st_off[i + 1] = cb.st_off[i] + (wellformed[i] ? prep[i].static_scalars.size() / 32 : 0);
+  }
+  cb.dyn_sc.resize(32 * cb.dyn_off[batch]); cb.dyn_pt.resize(32 * cb.dyn_off[batch]);
+  cb.st_sc.resize(32 * cb.st_off[batch]); cb.st_idx.resize(cb.st_off[batch]);
+  for (size_t i = 0; i < batch; ++i) {
+    if (!wellformed[i]) continue;
+    memcpy(&cb.dyn_sc[32 * cb.dyn_off[i]], prep[i].dyn_scalars.data(), prep[i].dyn_scalars.size());
+    memcpy(&cb.dyn_pt[32 * cb.dyn_off[i]], prep[i].dyn_points.data(), prep[i].dyn_points.size());
+    memcpy(&cb.st_sc[32 * cb.st_off[i]], prep[i].static_scalars.data(), prep[i].static_scalars.size());
+    memcpy(&cb.st_idx[cb.st_off[i]], prep[i].static_index.data(), prep[i].static_index.size() * 4);
+  }
+  int rc = zkgpu_verify_batch_ps(c, ps, batch, cb.dyn_sc.data(), cb.dyn_pt.data(), cb.dyn_off.data(), cb.st_sc.data(),
+                                 cb.st_idx.data(), cb.st_off.data(), accept_bitmap);
+  if (rc != ZKGPU_OK) { memset(accept_bitmap, 0, (batch + 7) / 8); return rc; }
+  for (size_t i = 0; i < batch; ++i)
+    if (!wellformed[i]) accept_bitmap[i / 8] &= (uint8_t)~(1u << (i % 8));
   return ZKGPU_OK;
 }
 

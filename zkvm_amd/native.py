@@ -139,6 +139,13 @@ def load_library():
     lib.zkgpu_comm_allgather.argtypes = [vp, u8p, sz, u8p]
     lib.zkgpu_comm_allgather_bitmap.argtypes = [vp, u64p, u8p, C.c_int, u8p]
     lib.zkgpu_verifier_verify_sharded.argtypes = [vp, vp, sz, u32p, u32p, u8p, u8p, u64p, u8p, u8p]
+    lib.zkgpu_r1cs_plan_create.argtypes = [vp, vp, sz, C.POINTER(vp)]
+    lib.zkgpu_r1cs_plan_destroy.argtypes = [vp]
+    lib.zkgpu_r1cs_plan_destroy.restype = None
+    lib.zkgpu_r1cs_verify_batch_gpu.argtypes = [vp, vp, vp, sz, u8p, u8p, sz, u8p, u8p]
+    lib.zkgpu_r1cs_verify_submit.argtypes = [vp, vp, vp, sz, u8p, u8p, sz, u8p]
+    lib.zkgpu_r1cs_verify_submit_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp]
+    lib.zkgpu_r1cs_verify_batch.argtypes = [vp, vp, vp, sz, sz, u8p, u8p, sz, u8p, u8p, C.c_int]
     lib.zkgpu_set_transcript_mode.argtypes = [vp, C.c_int]
     lib.zkgpu_set_locate_mode.argtypes = [vp, C.c_int]
     lib.zkgpu_debug_force_regroup.argtypes = [vp, C.c_int]
@@ -414,6 +421,39 @@ class Context:
 
     def set_window_bits(self, w: int) -> None:
         self._check(self.lib.zkgpu_set_window_bits(self.h, w))
+
+
+class R1csDescStruct(C.Structure):
+    """zkgpu_r1cs_desc"""
+    _fields_ = [("transcript_label", C.c_char_p), ("n_commitments", C.c_uint32), ("n_multipliers_phase1", C.c_uint32),
+                ("n_multipliers", C.c_uint32), ("n_challenges", C.c_uint32), ("challenge_labels", C.POINTER(C.c_char_p)),
+                ("n_constraints", C.c_uint32), ("term_offsets", C.POINTER(C.c_uint64)), ("term_var_kind", C.POINTER(C.c_uint8)),
+                ("term_var_index", C.POINTER(C.c_uint32)), ("term_coeff", C.c_char_p), ("term_challenge", C.POINTER(C.c_int32)),
+                ("term_power", C.POINTER(C.c_uint32))]
+
+
+class R1csDescription:
+    """A constraint system as data (include/zkgpu.h, zkgpu_r1cs_desc).  constraints: list of constraints, each a list of
+    terms (kind, index, coefficient, challenge, power): kind 0 committed, 1 / 2 / 3 left / right / out of a multiplier,
+    4 the constant one; coefficient an int mod l; challenge -1 or the index of a second-phase challenge."""
+    KIND_COMMITTED, KIND_LEFT, KIND_RIGHT, KIND_OUT, KIND_ONE = range(5)
+    L = 2**252 + 27742317777372353535851937790883648493
+
+    def __init__(self, label: bytes, n_commitments: int, n_phase1: int, n_multipliers: int, challenge_labels, constraints):
+        self.label, self.m, self.n1, self.n = label, n_commitments, n_phase1, n_multipliers
+        self.challenge_labels = list(challenge_labels)
+        self.constraints = constraints
+        offs, kinds, idx, coeff, chal, power = [0], [], [], bytearray(), [], []
+        for con in constraints:
+            for (k, i, c, ch, pw) in con:
+                kinds.append(k); idx.append(i); coeff += int(c % self.L).to_bytes(32, "little"); chal.append(ch); power.append(pw)
+            offs.append(len(kinds))
+        nt = max(len(kinds), 1)
+        self._keep = ((C.c_char_p * max(len(self.challenge_labels), 1))(*self.challenge_labels), (C.c_uint64 * len(offs))(*offs),
+                      (C.c_uint8 * nt)(*kinds), (C.c_uint32 * nt)(*idx), bytes(coeff), (C.c_int32 * nt)(*chal), (C.c_uint32 * nt)(*power))
+        k = self._keep
+        self.struct = R1csDescStruct(label, self.m, self.n1, self.n, len(self.challenge_labels), k[0], len(constraints), k[1], k[2], k[3],
+                                     k[4], k[5], k[6])
 
 
 def shard_cuts(shapes: Sequence[Tuple[int, int]], world: int):

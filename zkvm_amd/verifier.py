@@ -188,6 +188,50 @@ class BlockVerifier:
             pass
 
 
+class R1csVerifier:
+    """Any constraint system, described as data (zkgpu_r1cs_plan_create): the device-side verifier for statements that
+    are not a pure cloak -- `r1cs::Verifier::verify` for a uniform batch of proofs of ONE described statement shape."""
+
+    def __init__(self, ctx: Context, bp_gens: BulletproofGens, desc):
+        self.ctx, self.bp_gens, self.desc = ctx, bp_gens, desc
+        self.h = C.c_void_p()
+        ctx._check(ctx.lib.zkgpu_r1cs_plan_create(ctx.h, C.byref(desc.struct), bp_gens.gens_capacity, C.byref(self.h)))
+
+    def info(self) -> dict:
+        vals = [C.c_uint32() for _ in range(5)]
+        self.ctx._check(self.ctx.lib.zkgpu_cloak_plan_info(self.h, *[C.byref(v) for v in vals]))
+        out = dict(zip(("multipliers", "padded_n", "constraints", "terms", "proof_len"), [v.value for v in vals]))
+        lay = (C.c_uint32 * 8)()
+        self.ctx._check(self.ctx.lib.zkgpu_cloak_plan_layout(self.h, lay))
+        out.update(zip(("slots", "n_ch", "n_chal2", "n_dyn", "n_static", "k", "m", "n_mono"), list(lay)))
+        return out
+
+    def verify_gpu(self, batch: int, commitments: bytes, proofs: bytes, proof_len: int, r_bytes: Optional[bytes] = None) -> bytes:
+        """zkgpu_r1cs_verify_batch_gpu: transcript replay, scalars and the multiscalar multiplications on the device."""
+        if len(commitments) != batch * 32 * self.desc.m or len(proofs) != batch * proof_len or (r_bytes is not None and len(r_bytes) != 64 * batch):
+            raise ValueError("commitments: 32 bytes per commitment and statement; proofs: proof_len bytes per statement; r: 64 per statement")
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        self.ctx._check(self.ctx.lib.zkgpu_r1cs_verify_batch_gpu(self.ctx.h, self.bp_gens.points.h, self.h, batch, commitments, proofs,
+                                                                 proof_len, r_bytes, bm))
+        return bm.raw[: (batch + 7) // 8]
+
+    def verify_host_prepared(self, batch: int, commitments: bytes, proofs: bytes, proof_len: int, r_bytes: Optional[bytes] = None,
+                             host_threads: int = 0) -> bytes:
+        """zkgpu_r1cs_verify_batch: the verifier head on host threads, the multiscalar multiplications on the device."""
+        if len(commitments) != batch * 32 * self.desc.m or len(proofs) != batch * proof_len or (r_bytes is not None and len(r_bytes) != 64 * batch):
+            raise ValueError("commitments: 32 bytes per commitment and statement; proofs: proof_len bytes per statement; r: 64 per statement")
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        self.ctx._check(self.ctx.lib.zkgpu_r1cs_verify_batch(self.ctx.h, self.bp_gens.points.h, C.byref(self.desc.struct),
+                                                             self.bp_gens.gens_capacity, batch, commitments, proofs, proof_len, r_bytes, bm,
+                                                             host_threads))
+        return bm.raw[: (batch + 7) // 8]
+
+    def close(self) -> None:
+        if self.h:
+            self.ctx.lib.zkgpu_r1cs_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 class Verifier:
     """Batch verifier; `verify_cloak_txs` returns one Optional[VMError] per transaction
     (None = Ok), the shape of `txs.iter().map(|tx| tx.verify(bp_gens))`."""
