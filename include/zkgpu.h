@@ -221,6 +221,25 @@ int zkgpu_r1cs_verify_batch(zkgpu_ctx *ctx, const zkgpu_pointset *ps, const zkgp
                             size_t batch, const uint8_t *commitments, const uint8_t *proofs, size_t proof_len,
                             const uint8_t *r_bytes, uint8_t *accept_bitmap, int host_threads);
 
+/* The prover for a described constraint system (BASELINE.json configs[4]: "R1CS proving -- Pedersen vector commits +
+ * IPA -- for a 1024-constraint program"; replaces bulletproofs r1cs::Prover::{commit, constraint collection, prove}).
+ * Beyond the description the prover needs the witness:
+ *   values      batch x m x 32: the committed scalars (canonical); blindings: the same shape, or NULL to derive them
+ *               from the statement's seed (SHAKE256(seed || "blinding" || LE64(j)) reduced mod l);
+ *   mult_def    2 x n_multipliers: for multiplier i the indices of the two constraints that DEFINE its left and right
+ *               input (`left - l_i = 0`, `right - r_i = 0`, as a multiply() emits them), or 0xffffffff twice when its
+ *               assignment is given; NULL: every assignment is given.  Defined multipliers are evaluated in index
+ *               order (second-phase ones after the challenges are drawn);
+ *   given       batch x n_given x 64: (left, right) of the given multipliers, in index order;
+ *   seeds       batch x 32: external randomness of the TranscriptRng (and the blindings when derived).
+ * Out: commitments batch x 32 m, proofs batch x proof_stride (*proof_len bytes of each used).  The provers run in
+ * lockstep on host_threads threads; every phase of the whole batch is one multiscalar-multiplication call on the
+ * tables of `ps` = [B, B_blinding, G.., H..]. */
+int zkgpu_r1cs_prove_batch(zkgpu_ctx *ctx, const zkgpu_pointset *ps, const zkgpu_r1cs_desc *desc, const uint32_t *mult_def,
+                           size_t gens_capacity, size_t batch, const uint8_t *values, const uint8_t *blindings,
+                           const uint8_t *given, size_t n_given, const uint8_t *seeds, int host_threads,
+                           uint8_t *commitments, uint8_t *proofs, size_t proof_stride, size_t *proof_len);
+
 /* The same with commitments, proofs and verifier randomness already resident in HBM
  * (device pointers; this is what bench.py times as one step). */
 int zkgpu_cloak_verify_batch_gpu_dev(zkgpu_ctx *ctx, const zkgpu_pointset *ps, zkgpu_cloak_plan *plan, size_t batch,

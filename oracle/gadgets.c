@@ -8,6 +8,8 @@
  *   kind 1, param = nbits   "v lies in [0, 2^nbits)" for ONE committed value: the bit-decomposition
  *                           range proof of the cloak gadget on its own.  No randomized constraints:
  *                           a single-phase proof.
+ *   kind 3, param = count   "every one of `count` committed values lies in [0, 2^64)": count = 8 is the
+ *                           1032-constraint, 512-multiplier program of BASELINE.json configs[4].
  *   kind 2, param = k       "y_1..y_k is a permutation of x_1..x_k" for 2k committed scalars: the
  *                           scalar shuffle prod (x_i - z) = prod (y_i - z) with a second-phase
  *                           challenge z ("shuffle challenge").
@@ -99,11 +101,16 @@ static int shuffle_gadget(r1cs_cs *cs, const r1cs_var *x, const r1cs_var *y, siz
   return r1cs_specify_randomized_constraints(cs, shuf_cb, ud);
 }
 
-size_t zko_gadget_commitments(int kind, size_t param) { return kind == 1 ? 1 : kind == 2 ? 2 * param : 0; }
+size_t zko_gadget_commitments(int kind, size_t param) { return kind == 1 ? 1 : kind == 2 ? 2 * param : kind == 3 ? param : 0; }
 
 static int build(r1cs_cs *cs, int kind, size_t param, const r1cs_var *vars, const sc *vals) {
   if (kind == 1) { if (param == 0 || param > 252) return -1; range_gadget(cs, vars[0], vals ? &vals[0] : NULL, (int)param); return 0; }
   if (kind == 2) { if (param == 0) return -1; return shuffle_gadget(cs, vars, vars + param, param); }
+  if (kind == 3) {          /* param values, each in [0, 2^64): 64 param multipliers, 129 param constraints */
+    if (param == 0) return -1;
+    for (size_t i = 0; i < param; ++i) range_gadget(cs, vars[i], vals ? &vals[i] : NULL, 64);
+    return 0;
+  }
   return -1;
 }
 

@@ -166,3 +166,37 @@ def describe_shuffle(k: int):
     py = product([(K_COMMITTED, k + i) for i in range(k)])
     cons.append([(K_OUT, px, 1, -1, 0), (K_OUT, py, -1, -1, 0)])
     return 2 * k, 0, mult[0], [b"shuffle challenge"], cons
+
+
+def describe_ranges(count: int, nbits: int = 64):
+    """`count` committed values, each in [0, 2^nbits): count * nbits multipliers, count * (2 nbits + 1) constraints
+    (count = 8, nbits = 64: the 1032-constraint program of BASELINE.json configs[4])."""
+    cons = []
+    for v in range(count):
+        acc = [(K_COMMITTED, v, 1, -1, 0)]
+        for i in range(nbits):
+            j = v * nbits + i
+            cons.append([(K_OUT, j, 1, -1, 0)])
+            cons.append([(K_LEFT, j, 1, -1, 0), (K_RIGHT, j, 1, -1, 0), (K_ONE, 0, -1, -1, 0)])
+            acc.append((K_RIGHT, j, -(1 << i), -1, 0))
+        cons.append(acc)
+    return count, count * nbits, count * nbits, [], cons
+
+
+def gadget_witness(kind: int, param: int, values):
+    """(mult_def, given) for the prover of a described statement: kind 1 / 3 range proofs -- every multiplier given as
+    (1 - bit, bit); kind 2 shuffle -- every multiplier defined by the two constraints its multiply() emitted."""
+    if kind in (1, 3):
+        nbits = param if kind == 1 else 64
+        given = []
+        for v in values:
+            for i in range(nbits):
+                bit = (v >> i) & 1
+                given.append((1 - bit, bit))
+        return [0xFFFFFFFF] * (2 * len(given)), given
+    k = param
+    n = 0 if k == 1 else 2 * (k - 1)
+    mult_def = []
+    for i in range(n):
+        mult_def += [2 * i, 2 * i + 1]
+    return mult_def, []

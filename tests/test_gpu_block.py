@@ -418,3 +418,52 @@ def test_described_constraint_systems_on_device(ctx, oracle, kind, param):
         ctx.set_group_size(16)
         v.close()
         gens.close()
+
+
+@pytest.mark.parametrize("kind,param", [(3, 8), (2, 5), (1, 32)])
+def test_described_prover_on_device_equals_oracle_and_verifies(ctx, oracle, kind, param):
+    """zkgpu_r1cs_prove_batch (BASELINE.json configs[4]; kind 3 with 8 values = the 1032-constraint, 512-multiplier
+    program): every commitment and proof byte equals the oracle's gadget prover on the same witness and seed, the
+    device-side verifier (plan made from the same description) and the oracle accept them, and a statement with an
+    invalid witness yields a proof both reject."""
+    import random
+    from gpu_util import GADGET_LABEL, describe_range, describe_ranges, describe_shuffle, gadget_witness
+    from zkvm_amd.native import R1csDescription
+    from zkvm_amd.verifier import BulletproofGens, R1csProver, R1csVerifier
+    rng = random.Random(31 * kind + param)
+    m, n1, n, labels, cons = describe_range(param) if kind == 1 else describe_shuffle(param) if kind == 2 else describe_ranges(param)
+    desc = R1csDescription(GADGET_LABEL, m, n1, n, labels, cons)
+    cap = 1
+    while cap < max(n, 1):
+        cap *= 2
+    gens = BulletproofGens(ctx, cap, table_bits=8)
+    batch = 9
+    vals, givens, seeds, mult_def = [], [], [], None
+    for i in range(batch):
+        if kind == 1:
+            values = [rng.randrange(1 << param)]
+        elif kind == 3:
+            values = [rng.randrange(1 << 64) for _ in range(param)]
+        else:
+            xs = [rng.randrange(L) for _ in range(param)]
+            values = xs + sorted(xs)
+        mult_def, given = gadget_witness(kind, param, values)
+        if i == 5:                                                       # an inconsistent statement
+            if kind == 2:
+                values[-1] = (values[-1] + 1) % L
+            else:
+                values[0] += 1 << (param if kind == 1 else 64)           # the bits given are those of the value mod 2^bits
+        vals.append(values); givens.append(given); seeds.append(hashlib.sha256(b"dev desc prover %d %d %d" % (kind, param, i)).digest())
+    coms, proofs = R1csProver(ctx, gens, desc, mult_def, host_threads=8).prove(vals, givens, seeds)
+    for i in range(batch):
+        rc, want_com, want_proof = oracle.gadget_prove(kind, param, vals[i], seeds[i])
+        assert rc == 0 and coms[i] == want_com and proofs[i] == want_proof, i
+    r = hashlib.shake_256(b"desc prover r").digest(64 * batch)
+    want = [int(oracle.gadget_verify(kind, param, coms[i], proofs[i], r[64 * i: 64 * i + 64])) for i in range(batch)]
+    assert want == [0 if i == 5 else 1 for i in range(batch)]
+    v = R1csVerifier(ctx, gens, desc)
+    try:
+        assert bits(v.verify_gpu(batch, b"".join(coms), b"".join(proofs), len(proofs[0]), r), batch) == want
+    finally:
+        v.close()
+        gens.close()

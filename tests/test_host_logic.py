@@ -264,3 +264,53 @@ def test_described_constraint_system_equals_oracle_gadget(host, oracle, kind, pa
                                    (C.c_uint32 * nt)(*power), com, bytes(bad), C.c_size_t(len(proof)), r, C.c_size_t(cap), ds, dp,
                                    C.byref(nd), ss, si, C.byref(ns), C.byref(pn))
     assert rc2 != 0 or ss.raw[: 32 * ns.value] != want[2]
+
+
+@pytest.mark.parametrize("kind,param", [(1, 8), (1, 64), (2, 2), (2, 5), (3, 2), (3, 8)])
+def test_described_prover_equals_oracle_gadget_prover(host, oracle, kind, param):
+    """desc_prover (r1cs_prover.hpp): the prover for a constraint system described as data -- witness = committed values
+    + given multiplier assignments or defining constraints -- produces byte for byte the commitments and the proof of
+    the oracle's prover for the same statement (its own gadget code) on the same witness and seed; kind 3 with 8 values is
+    the 1032-constraint program of BASELINE.json configs[4]."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from gpu_util import GADGET_LABEL, describe_range, describe_ranges, describe_shuffle, gadget_witness
+    rng = random.Random(7 * kind + param)
+    m, n1, n, labels, cons = describe_range(param) if kind == 1 else describe_shuffle(param) if kind == 2 else describe_ranges(param)
+    if kind == 1:
+        values = [rng.randrange(1 << param)]
+    elif kind == 3:
+        values = [rng.randrange(1 << 64) for _ in range(param)]
+    else:
+        xs = [rng.randrange(L) for _ in range(param)]
+        ys = xs[:]
+        rng.shuffle(ys)
+        values = xs + ys
+    seed = hashlib.sha256(b"desc prover %d %d" % (kind, param)).digest()
+    rc, want_com, want_proof = oracle.gadget_prove(kind, param, values, seed)
+    assert rc == 0
+    cap = 1
+    while cap < max(n, 1):
+        cap *= 2
+    gens = oracle.pedersen_gens()
+    gens = gens[0] + gens[1] + b"".join(oracle.bulletproof_gens(cap, "G")) + b"".join(oracle.bulletproof_gens(cap, "H"))
+    mult_def, given = gadget_witness(kind, param, values)
+    offs, kinds, idx, coeff, chal, power = [0], [], [], b"", [], []
+    for con in cons:
+        for (k_, i_, c_, ch_, pw_) in con:
+            kinds.append(k_); idx.append(i_); coeff += (c_ % L).to_bytes(32, "little"); chal.append(ch_); power.append(pw_)
+        offs.append(len(kinds))
+    nt = max(len(kinds), 1)
+    lab = (C.c_char_p * max(len(labels), 1))(*labels)
+    com = C.create_string_buffer(32 * m)
+    proof = C.create_string_buffer(4096)
+    plen = C.c_size_t(0)
+    gv = b"".join(a.to_bytes(32, "little") + b.to_bytes(32, "little") for a, b in given)
+    rc = host.zkhost_r1cs_prove(GADGET_LABEL, m, n1, n, len(labels), lab, len(cons), (C.c_uint64 * len(offs))(*offs),
+                                (C.c_uint8 * nt)(*kinds), (C.c_uint32 * nt)(*idx), coeff, (C.c_int32 * nt)(*chal),
+                                (C.c_uint32 * nt)(*power), (C.c_uint32 * max(len(mult_def), 1))(*mult_def),
+                                b"".join(v.to_bytes(32, "little") for v in values), gv, C.c_size_t(len(given)), seed, gens,
+                                C.c_size_t(cap), com, proof, C.c_size_t(4096), C.byref(plen))
+    assert rc == 0
+    assert com.raw == want_com and proof.raw[: plen.value] == want_proof
+    assert oracle.gadget_verify(kind, param, com.raw, proof.raw[: plen.value], hashlib.shake_256(b"r").digest(64))

@@ -289,7 +289,8 @@ int zkhost_cloak_prove(uint32_t n_in, uint32_t n_out, const uint64_t* quantities
     std::memcpy(w, generators + 32 * i, 32);
     if (!ristretto_decode(gens[i], w)) return -1;
   }
-  CloakProver pr(n_in, n_out, quantities, flavors, seed, gens_capacity);
+  std::unique_ptr<R1csProver> prp = cloak_prover(n_in, n_out, quantities, flavors, seed, gens_capacity);
+  R1csProver& pr = *prp;
   std::vector<MsmRow> rows;
   std::vector<uint8_t> pts;
   pr.begin(rows);
@@ -302,6 +303,63 @@ int zkhost_cloak_prove(uint32_t n_in, uint32_t n_out, const uint64_t* quantities
   std::memcpy(proof, pr.proof().data(), pr.proof().size());
   *proof_len_out = pr.proof().size();
   if (multipliers) *multipliers = pr.multipliers();
+  return 0;
+}
+
+// The prover for a constraint system described as data (desc_prover) with the reference MSM of this library:
+// description arrays as zkhost_r1cs_prepare; mult_def: 2 per multiplier; values: m x 32 bytes; given: n_given x 64
+// bytes (left, right); blindings derived from the seed as oracle/gadgets.c does ("blinding", i).
+int zkhost_r1cs_prove(const char* label, uint32_t m, uint32_t n1, uint32_t n, uint32_t n_chal, const char* const* chal_labels,
+                      uint32_t n_cons, const uint64_t* term_offsets, const uint8_t* kinds, const uint32_t* idx,
+                      const uint8_t* coeff, const int32_t* chal, const uint32_t* power, const uint32_t* mult_def,
+                      const uint8_t* values, const uint8_t* given, size_t n_given, const uint8_t seed[32],
+                      const uint8_t* generators, size_t gens_capacity, uint8_t* commitments, uint8_t* proof, size_t proof_cap,
+                      size_t* proof_len_out) {
+  R1csDesc d;
+  d.label = label; d.m = m; d.n1 = n1; d.n = n;
+  for (uint32_t i = 0; i < n_chal; ++i) d.chal_names.push_back(chal_labels[i]);
+  for (uint32_t q = 0; q < n_cons; ++q) {
+    std::vector<R1csDesc::Term> con;
+    for (uint64_t t = term_offsets[q]; t < term_offsets[q + 1]; ++t) {
+      Scalar c;
+      if (kinds[t] > 4 || !Scalar::from_canonical(coeff + 32 * t, c)) return -1;
+      con.push_back(R1csDesc::Term{(VarKind)kinds[t], idx[t], c, chal[t], power[t]});
+    }
+    d.cons.push_back(std::move(con));
+  }
+  std::vector<ge> gens(2 + 2 * gens_capacity);
+  for (size_t i = 0; i < gens.size(); ++i) {
+    uint32_t w[8];
+    std::memcpy(w, generators + 32 * i, 32);
+    if (!ristretto_decode(gens[i], w)) return -1;
+  }
+  std::vector<Scalar> vals, bl;
+  for (uint32_t i = 0; i < m; ++i) {
+    uint8_t wide[64] = {0};
+    std::memcpy(wide, values + 32 * i, 32);
+    vals.push_back(Scalar::from_wide(wide));
+    bl.push_back(R1csProver::derive_scalar(seed, "blinding", i));
+  }
+  std::vector<std::pair<Scalar, Scalar>> gv;
+  for (size_t i = 0; i < n_given; ++i) {
+    uint8_t wl[64] = {0}, wr[64] = {0};
+    std::memcpy(wl, given + 64 * i, 32); std::memcpy(wr, given + 64 * i + 32, 32);
+    gv.emplace_back(Scalar::from_wide(wl), Scalar::from_wide(wr));
+  }
+  std::vector<uint32_t> md(mult_def, mult_def + 2 * (size_t)n);
+  std::unique_ptr<R1csProver> prp = desc_prover(d, md, vals, bl, gv, seed, gens_capacity);
+  R1csProver& pr = *prp;
+  std::vector<MsmRow> rows;
+  std::vector<uint8_t> pts;
+  pr.begin(rows);
+  while (!pr.done()) {
+    host_rows(gens, rows, pts);
+    pr.step(pts.data(), rows);
+  }
+  if (pr.failed() || pr.proof().size() > proof_cap) return -2;
+  std::memcpy(commitments, pr.commitments().data(), pr.commitments().size());
+  std::memcpy(proof, pr.proof().data(), pr.proof().size());
+  *proof_len_out = pr.proof().size();
   return 0;
 }
 

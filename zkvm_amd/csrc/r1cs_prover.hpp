@@ -20,9 +20,12 @@
 // fills in the gadget's allocation order.
 #pragma once
 #include "r1cs_verifier.hpp"
+#include "cloak_plan.hpp"
 
 #include <algorithm>
 #include <deque>
+#include <functional>
+#include <memory>
 
 namespace zk {
 
@@ -149,23 +152,36 @@ inline void gadget_witness(const std::vector<Amount>& in, const std::vector<Amou
 
 // One proof in the making.  Usage: begin(rows); then alternately evaluate the rows (one encoding
 // per row, in order) and call step(points, rows) until done(); then proof() / commitments().
-class CloakProver {
+//
+// The statement comes in as (committed values, their blindings, a SYNTHESIS function): the function is
+// called once, after the commitments went into the transcript, with the constraint system and the
+// committed variables; it supplies the first-phase witness (cs.queue) and runs the gadget code --
+// cloak_prover() below for the ZkVM cloak, desc_prover() for a constraint system described as data.
+class R1csProver {
  public:
-  // quantities: n_in + n_out values; flavors: 32 bytes each (reduced mod l); seed: 32 bytes from
-  // which the commitment blindings and the external randomness of the TranscriptRng are derived
-  // (SHAKE256(seed || tag || LE64(i)), as the oracle's zko_cloak_prove)
-  CloakProver(size_t n_in, size_t n_out, const uint64_t* quantities, const uint8_t* flavors, const uint8_t seed[32],
-              size_t gens_capacity)
-      : cs_("ZkVM.r1cs"), n_in_(n_in), n_out_(n_out), cap_(gens_capacity) {
+  using Synthesis = std::function<void(R1csProverCS&, const std::vector<Var>&)>;
+
+  // seed: 32 bytes from which the external randomness of the TranscriptRng is derived
+  // (SHAKE256(seed || "rng" || LE64(0)), as the oracle's provers)
+  R1csProver(const char* label, const uint8_t seed[32], size_t gens_capacity, std::vector<Scalar> values,
+             std::vector<Scalar> blindings, Synthesis synth)
+      : cs_(label), cap_(gens_capacity), values_(std::move(values)), blindings_(std::move(blindings)), synth_(std::move(synth)) {
     std::memcpy(seed_, seed, 32);
-    for (size_t i = 0; i < n_in + n_out; ++i) {
-      cloak::Amount a;
-      a.q = quantities[i];
-      uint8_t wide[64] = {0};
-      std::memcpy(wide, flavors + 32 * i, 32);
-      a.f = Scalar::from_wide(wide);
-      amounts_.push_back(a);
-    }
+  }
+
+  static Scalar derive_scalar(const uint8_t seed[32], const char* tag, uint64_t i) {
+    uint8_t wide[64];
+    derive(seed, tag, i, wide, 64);
+    return Scalar::from_wide(wide);
+  }
+  static void derive(const uint8_t seed[32], const char* tag, uint64_t i, uint8_t* out, size_t n) {
+    Sponge sp = shake256_sponge();
+    uint8_t ib[8];
+    for (int k = 0; k < 8; ++k) ib[k] = (uint8_t)(i >> (8 * k));
+    sp.absorb(seed, 32);
+    sp.absorb((const uint8_t*)tag, std::strlen(tag));
+    sp.absorb(ib, 8);
+    sp.squeeze(out, n);
   }
 
   bool done() const { return stage_ == kDone; }
@@ -176,18 +192,11 @@ class CloakProver {
 
   void begin(std::vector<MsmRow>& rows) {
     rows.clear();
-    const size_t nv = n_in_ + n_out_;
-    for (size_t i = 0; i < nv; ++i) {
-      const Scalar qb = derive_scalar("q_blinding", i), fb = derive_scalar("f_blinding", i);
-      Value val;
-      val.q = cs_.commit(Scalar::from_u64(amounts_[i].q), qb);
-      val.f = cs_.commit(amounts_[i].f, fb);
-      vals_.push_back(val);
-      MsmRow rq, rf;
-      rq.add(Scalar::from_u64(amounts_[i].q), 0); rq.add(qb, 1);
-      rf.add(amounts_[i].f, 0); rf.add(fb, 1);
-      rows.push_back(std::move(rq));
-      rows.push_back(std::move(rf));
+    for (size_t i = 0; i < values_.size(); ++i) {
+      vars_.push_back(cs_.commit(values_[i], blindings_[i]));
+      MsmRow r;
+      r.add(values_[i], 0); r.add(blindings_[i], 1);
+      rows.push_back(std::move(r));
     }
     stage_ = kCommitted;
   }
@@ -208,20 +217,6 @@ class CloakProver {
  private:
   enum Stage { kNew, kCommitted, kPhase1, kPhase2, kT, kIpa, kDone };
 
-  Scalar derive_scalar(const char* tag, uint64_t i) const {
-    uint8_t wide[64];
-    derive(tag, i, wide, 64);
-    return Scalar::from_wide(wide);
-  }
-  void derive(const char* tag, uint64_t i, uint8_t* out, size_t n) const {
-    Sponge sp = shake256_sponge();
-    uint8_t ib[8];
-    for (int k = 0; k < 8; ++k) ib[k] = (uint8_t)(i >> (8 * k));
-    sp.absorb(seed_, 32);
-    sp.absorb((const uint8_t*)tag, std::strlen(tag));
-    sp.absorb(ib, 8);
-    sp.squeeze(out, n);
-  }
   Scalar rng_scalar() {
     uint8_t b[64];
     rng_.rng_fill(b, 64);
@@ -248,10 +243,7 @@ class CloakProver {
     commitments_.assign(pts, pts + 32 * m);
     for (size_t i = 0; i < m; ++i) cs_.tr.append_point("V", pts + 32 * i);
     // constraints + first-phase witness
-    std::vector<cloak::Amount> in(amounts_.begin(), amounts_.begin() + n_in_), out(amounts_.begin() + n_in_, amounts_.end());
-    cloak::gadget_witness(in, out, cs_.queue);
-    std::vector<Value> vin(vals_.begin(), vals_.begin() + n_in_), vout(vals_.begin() + n_in_, vals_.end());
-    cloak::gadget(cs_, vin, vout);
+    synth_(cs_, vars_);
     if (cs_.failed || !cs_.queue.empty()) { failed_ = true; stage_ = kDone; return; }
     cs_.tr.append_u64("m", m);
     rng_ = cs_.tr;
@@ -261,7 +253,7 @@ class CloakProver {
       rng_.rekey_with_witness("v_blinding", b, 32);
     }
     uint8_t rng_seed[32];
-    derive("rng", 0, rng_seed, 32);
+    derive(seed_, "rng", 0, rng_seed, 32);
     rng_.finalize_rng(rng_seed);
     n1_ = cs_.n_vars();
     i_bl1_ = rng_scalar(); o_bl1_ = rng_scalar(); s_bl1_ = rng_scalar();
@@ -457,10 +449,11 @@ class CloakProver {
 
   R1csProverCS cs_;
   Transcript rng_{"unused"};
-  size_t n_in_, n_out_, cap_;
+  size_t cap_;
   uint8_t seed_[32];
-  std::vector<cloak::Amount> amounts_;
-  std::vector<Value> vals_;
+  std::vector<Scalar> values_, blindings_;
+  Synthesis synth_;
+  std::vector<Var> vars_;
   std::vector<uint8_t> commitments_, proof_;
   uint8_t head_[352];   // A_I1 A_O1 S1 A_I2 A_O2 S2 T_1 T_3 T_4 T_5 T_6
   Stage stage_ = kNew;
@@ -470,5 +463,109 @@ class CloakProver {
   Scalar t_[7], tb_[7];
   std::vector<Scalar> sL_, sR_, wV_, l1_, l2_, l3_, r0_, r1_, r3_, yinv_pow_, lv_, rv_, cG_, cH_;
 };
+
+// The ZkVM cloak: n_in + n_out values (quantity, flavor), commitment blindings derived from the seed as the
+// oracle's zko_cloak_prove does ("q_blinding" / "f_blinding", value index).
+inline std::unique_ptr<R1csProver> cloak_prover(size_t n_in, size_t n_out, const uint64_t* quantities, const uint8_t* flavors,
+                                                const uint8_t seed[32], size_t gens_capacity) {
+  std::vector<cloak::Amount> amounts;
+  std::vector<Scalar> values, blindings;
+  for (size_t i = 0; i < n_in + n_out; ++i) {
+    cloak::Amount a;
+    a.q = quantities[i];
+    uint8_t wide[64] = {0};
+    std::memcpy(wide, flavors + 32 * i, 32);
+    a.f = Scalar::from_wide(wide);
+    amounts.push_back(a);
+    values.push_back(Scalar::from_u64(a.q)); blindings.push_back(R1csProver::derive_scalar(seed, "q_blinding", i));
+    values.push_back(a.f); blindings.push_back(R1csProver::derive_scalar(seed, "f_blinding", i));
+  }
+  auto synth = [amounts, n_in](R1csProverCS& cs, const std::vector<Var>& vars) {
+    std::vector<cloak::Amount> in(amounts.begin(), amounts.begin() + n_in), out(amounts.begin() + n_in, amounts.end());
+    cloak::gadget_witness(in, out, cs.queue);
+    std::vector<Value> vals;
+    for (size_t i = 0; i + 1 < vars.size(); i += 2) vals.push_back(Value{vars[i], vars[i + 1]});
+    std::vector<Value> vin(vals.begin(), vals.begin() + n_in), vout(vals.begin() + n_in, vals.end());
+    cloak::gadget(cs, vin, vout);
+  };
+  return std::unique_ptr<R1csProver>(new R1csProver("ZkVM.r1cs", seed, gens_capacity, std::move(values), std::move(blindings), synth));
+}
+
+// A constraint system described as data (R1csDesc): the prover needs, beyond the verifier's description, the
+// WITNESS -- the committed values, and for every multiplier either its (left, right) assignment (`given`, in index
+// order, for multipliers allocated with explicit values) or the two constraints that define it (mult_def[2 i],
+// mult_def[2 i + 1]: the constraints `left - l_i = 0` / `right - r_i = 0` a multiply() emitted; 0xffffffff = given).
+// Defined multipliers are evaluated in index order, second-phase ones once the challenges are drawn.
+constexpr uint32_t MULT_GIVEN = 0xffffffffu;
+
+inline std::unique_ptr<R1csProver> desc_prover(const R1csDesc& d, const std::vector<uint32_t>& mult_def, std::vector<Scalar> values,
+                                               std::vector<Scalar> blindings, const std::vector<std::pair<Scalar, Scalar>>& given,
+                                               const uint8_t seed[32], size_t gens_capacity) {
+  auto synth = [d, mult_def, given](R1csProverCS& cs, const std::vector<Var>&) {
+    auto next_given = std::make_shared<size_t>(0);
+    R1csProverCS* pcs = &cs;
+    auto coef_of = [](const R1csDesc::Term& t, const std::vector<Scalar>& chal) {
+      Scalar c = t.c;
+      if (t.chal >= 0) for (uint32_t e = 0; e < t.pow; ++e) c *= chal[(size_t)t.chal];
+      return c;
+    };
+    // value of the multiplier side (kind, i) from its defining constraint  sum_others + coef * side = 0
+    auto solve = [pcs, coef_of, &d](uint32_t con_idx, VarKind kind, uint32_t i, const std::vector<Scalar>& chal, bool& ok) {
+      Scalar acc = Scalar::zero(), own = Scalar::zero();
+      if (con_idx >= d.cons.size()) { ok = false; return acc; }
+      for (const auto& t : d.cons[con_idx]) {
+        const Scalar c = coef_of(t, chal);
+        if (t.kind == kind && t.idx == i) { own += c; continue; }
+        Scalar val = Scalar::one();
+        const size_t have = pcs->aL.size();
+        switch (t.kind) {
+          case VarKind::MulLeft: if (t.idx >= have) { ok = false; return acc; } val = pcs->aL[t.idx]; break;
+          case VarKind::MulRight: if (t.idx >= have) { ok = false; return acc; } val = pcs->aR[t.idx]; break;
+          case VarKind::MulOut: if (t.idx >= have) { ok = false; return acc; } val = pcs->aO[t.idx]; break;
+          case VarKind::Committed: if (t.idx >= pcs->v.size()) { ok = false; return acc; } val = pcs->v[t.idx]; break;
+          case VarKind::One: break;
+        }
+        acc += c * val;
+      }
+      if (own == Scalar::zero()) { ok = false; return acc; }
+      return own == -Scalar::one() ? acc : acc * (-own).invert();
+    };
+    auto assign = [pcs, solve, next_given, &mult_def, &given](uint32_t i, const std::vector<Scalar>& chal) {
+      Scalar l, r;
+      bool ok = true;
+      const uint32_t dl = 2 * i < mult_def.size() ? mult_def[2 * i] : MULT_GIVEN, dr = 2 * i + 1 < mult_def.size() ? mult_def[2 * i + 1] : MULT_GIVEN;
+      if (dl == MULT_GIVEN || dr == MULT_GIVEN) {
+        if (*next_given >= given.size()) { pcs->failed = true; l = r = Scalar::zero(); }
+        else { l = given[*next_given].first; r = given[*next_given].second; ++*next_given; }
+      } else {
+        l = solve(dl, VarKind::MulLeft, i, chal, ok);
+        r = solve(dr, VarKind::MulRight, i, chal, ok);
+        if (!ok) pcs->failed = true;
+      }
+      pcs->queue.emplace_back(l, r);
+      Var o[3];
+      pcs->allocate_multiplier(o);
+    };
+    auto add_all = [coef_of, &d](ConstraintSystemT<Scalar>& c, const std::vector<Scalar>& chal) {
+      for (const auto& con : d.cons) {
+        LCt<Scalar> lc;
+        for (const auto& t : con) lc.add(Var{t.kind, t.idx}, coef_of(t, chal));
+        c.constrain(std::move(lc));
+      }
+    };
+    for (uint32_t i = 0; i < d.n1; ++i) assign(i, {});
+    if (d.chal_names.empty() && d.n == d.n1) {
+      add_all(cs, {});
+    } else {
+      cs.specify_randomized_constraints([assign, add_all, &d](ConstraintSystemT<Scalar>& c) {
+        std::vector<Scalar> chal;
+        for (const std::string& name : d.chal_names) chal.push_back(c.challenge_scalar(name.c_str()));
+        for (uint32_t i = d.n1; i < d.n; ++i) assign(i, chal);
+        add_all(c, chal);
+      });
+    }
+  };
+  return std::unique_ptr<R1csProver>(new R1csProver(d.label.c_str(), seed, gens_capacity, std::move(values), std::move(blindings), synth));
+}
 
 }  // namespace zk

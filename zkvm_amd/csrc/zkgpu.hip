@@ -1547,17 +1547,13 @@ int zkgpu_msm_ps_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, con
 // for padded n = 256).  quantities: batch x (n_in + n_out) u64; flavors: 32 B each; seeds: 32 B per
 // statement (blindings and TranscriptRng randomness are derived from it).  commitments: batch x
 // 64 (n_in + n_out) B; proofs: batch x proof_stride B, *proof_len bytes used of each.
-int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_capacity, size_t batch, uint32_t n_in,
-                            uint32_t n_out, const uint64_t* quantities, const uint8_t* flavors, const uint8_t* seeds,
-                            int host_threads, uint8_t* commitments, uint8_t* proofs, size_t proof_stride,
-                            size_t* proof_len) {
-  if (!c || !ps || !commitments || !proofs || !proof_len) return ZKGPU_EINVAL;
-  *proof_len = 0;
-  if (batch == 0) return ZKGPU_OK;
-  if (!quantities || !flavors || !seeds || ps->n < 2 + 2 * gens_capacity || n_in + n_out == 0) return ZKGPU_EINVAL;
-  if (!ps->table) { c->last_error = "zkgpu_cloak_prove_batch needs zkgpu_pointset_build_tables first"; return ZKGPU_EINVAL; }
-  const size_t nv = (size_t)n_in + n_out;
-  std::vector<std::unique_ptr<CloakProver>> pr(batch);
+namespace {
+bool desc_from_c(zkgpu_ctx* c, const zkgpu_r1cs_desc* d, R1csDesc& desc);
+// Runs `batch` provers in lockstep: every phase of the whole batch is ONE zkgpu_msm_ps_batch over the tables.
+int prove_lockstep(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, int host_threads,
+                   const std::function<std::unique_ptr<R1csProver>(size_t)>& make, uint8_t* commitments, size_t com_bytes,
+                   uint8_t* proofs, size_t proof_stride, size_t* proof_len) {
+  std::vector<std::unique_ptr<R1csProver>> pr(batch);
   std::vector<std::vector<MsmRow>> rows(batch);
   const int nt = std::max(1, std::min<int>(host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency(), 256));
   auto parallel = [&](const std::function<void(size_t)>& f) {
@@ -1567,7 +1563,7 @@ int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_
     for (auto& t : th) t.join();
   };
   parallel([&](size_t i) {
-    pr[i].reset(new CloakProver(n_in, n_out, quantities + nv * i, flavors + 32 * nv * i, seeds + 32 * i, gens_capacity));
+    pr[i] = make(i);
     pr[i]->begin(rows[i]);
   });
   std::vector<uint64_t> offs, row_of(batch + 1);
@@ -1581,7 +1577,6 @@ int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_
     for (size_t i = 0; i < batch; ++i) { any |= !pr[i]->done(); bad |= pr[i]->failed(); }
     if (bad) { c->last_error = "prover: inconsistent witness or too few generators"; return ZKGPU_EINVAL; }
     if (!any) break;
-    // CSR over all rows of all statements
     offs.assign(1, 0);
     row_of[0] = 0;
     for (size_t i = 0; i < batch; ++i) {
@@ -1612,12 +1607,64 @@ int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_
   const size_t plen = pr[0]->proof().size();
   if (plen > proof_stride) return ZKGPU_EINVAL;
   for (size_t i = 0; i < batch; ++i) {
-    if (pr[i]->proof().size() != plen) return ZKGPU_EINVAL;
-    memcpy(commitments + 64 * nv * i, pr[i]->commitments().data(), 64 * nv);
+    if (pr[i]->proof().size() != plen || pr[i]->commitments().size() != com_bytes) return ZKGPU_EINVAL;
+    memcpy(commitments + com_bytes * i, pr[i]->commitments().data(), com_bytes);
     memcpy(proofs + proof_stride * i, pr[i]->proof().data(), plen);
   }
   *proof_len = plen;
   return ZKGPU_OK;
+}
+}  // namespace
+
+int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_capacity, size_t batch, uint32_t n_in,
+                            uint32_t n_out, const uint64_t* quantities, const uint8_t* flavors, const uint8_t* seeds,
+                            int host_threads, uint8_t* commitments, uint8_t* proofs, size_t proof_stride,
+                            size_t* proof_len) {
+  if (!c || !ps || !commitments || !proofs || !proof_len) return ZKGPU_EINVAL;
+  *proof_len = 0;
+  if (batch == 0) return ZKGPU_OK;
+  if (!quantities || !flavors || !seeds || ps->n < 2 + 2 * gens_capacity || n_in + n_out == 0) return ZKGPU_EINVAL;
+  if (!ps->table) { c->last_error = "zkgpu_cloak_prove_batch needs zkgpu_pointset_build_tables first"; return ZKGPU_EINVAL; }
+  const size_t nv = (size_t)n_in + n_out;
+  return prove_lockstep(c, ps, batch, host_threads, [&](size_t i) {
+    return cloak_prover(n_in, n_out, quantities + nv * i, flavors + 32 * nv * i, seeds + 32 * i, gens_capacity);
+  }, commitments, 64 * nv, proofs, proof_stride, proof_len);
+}
+
+// Proves `batch` statements of ONE described constraint system (BASELINE.json configs[4]: "R1CS proving for a
+// 1024-constraint program"): the description of zkgpu_r1cs_plan_create plus the witness -- see include/zkgpu.h.
+int zkgpu_r1cs_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, const zkgpu_r1cs_desc* d, const uint32_t* mult_def,
+                           size_t gens_capacity, size_t batch, const uint8_t* values, const uint8_t* blindings,
+                           const uint8_t* given, size_t n_given, const uint8_t* seeds, int host_threads,
+                           uint8_t* commitments, uint8_t* proofs, size_t proof_stride, size_t* proof_len) {
+  if (!c || !ps || !d || !commitments || !proofs || !proof_len) return ZKGPU_EINVAL;
+  *proof_len = 0;
+  if (batch == 0) return ZKGPU_OK;
+  if (!seeds || ps->n < 2 + 2 * gens_capacity || (d->n_commitments && !values) || (n_given && !given)) return ZKGPU_EINVAL;
+  if (!ps->table) { c->last_error = "zkgpu_r1cs_prove_batch needs zkgpu_pointset_build_tables first"; return ZKGPU_EINVAL; }
+  R1csDesc desc;
+  if (!desc_from_c(c, d, desc)) return ZKGPU_EINVAL;
+  try { (void)plan_from_desc(desc); } catch (const std::exception& e) { c->last_error = e.what(); return ZKGPU_EINVAL; }
+  std::vector<uint32_t> md(2 * (size_t)desc.n, MULT_GIVEN);
+  if (mult_def) md.assign(mult_def, mult_def + 2 * (size_t)desc.n);
+  const size_t m = desc.m;
+  return prove_lockstep(c, ps, batch, host_threads, [&](size_t i) {
+    std::vector<Scalar> vals, bl;
+    for (size_t j = 0; j < m; ++j) {
+      uint8_t wide[64] = {0};
+      memcpy(wide, values + 32 * (m * i + j), 32);
+      vals.push_back(Scalar::from_wide(wide));
+      if (blindings) { uint8_t wb[64] = {0}; memcpy(wb, blindings + 32 * (m * i + j), 32); bl.push_back(Scalar::from_wide(wb)); }
+      else bl.push_back(R1csProver::derive_scalar(seeds + 32 * i, "blinding", j));
+    }
+    std::vector<std::pair<Scalar, Scalar>> gv;
+    for (size_t j = 0; j < n_given; ++j) {
+      uint8_t wl[64] = {0}, wr[64] = {0};
+      memcpy(wl, given + 64 * (n_given * i + j), 32); memcpy(wr, given + 64 * (n_given * i + j) + 32, 32);
+      gv.emplace_back(Scalar::from_wide(wl), Scalar::from_wide(wr));
+    }
+    return desc_prover(desc, md, std::move(vals), std::move(bl), gv, seeds + 32 * i, gens_capacity);
+  }, commitments, 32 * m, proofs, proof_stride, proof_len);
 }
 
 int zkgpu_decode_check(zkgpu_ctx* c, const uint8_t* points, size_t n, uint8_t* ok) {

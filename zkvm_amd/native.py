@@ -146,6 +146,8 @@ def load_library():
     lib.zkgpu_r1cs_verify_submit.argtypes = [vp, vp, vp, sz, u8p, u8p, sz, u8p]
     lib.zkgpu_r1cs_verify_submit_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp]
     lib.zkgpu_r1cs_verify_batch.argtypes = [vp, vp, vp, sz, sz, u8p, u8p, sz, u8p, u8p, C.c_int]
+    lib.zkgpu_r1cs_prove_batch.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), sz, sz, u8p, u8p, u8p, sz, u8p, C.c_int, u8p, u8p, sz,
+                                           C.POINTER(sz)]
     lib.zkgpu_set_transcript_mode.argtypes = [vp, C.c_int]
     lib.zkgpu_set_locate_mode.argtypes = [vp, C.c_int]
     lib.zkgpu_debug_force_regroup.argtypes = [vp, C.c_int]

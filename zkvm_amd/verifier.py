@@ -188,6 +188,32 @@ class BlockVerifier:
             pass
 
 
+class R1csProver:
+    """zkgpu_r1cs_prove_batch: proofs of a described constraint system (BASELINE.json configs[4])."""
+
+    def __init__(self, ctx: Context, bp_gens: BulletproofGens, desc, mult_def: Optional[Sequence[int]] = None, host_threads: int = 0):
+        self.ctx, self.bp_gens, self.desc, self.host_threads = ctx, bp_gens, desc, host_threads
+        self.mult_def = (C.c_uint32 * max(len(mult_def), 1))(*mult_def) if mult_def is not None else None
+
+    def prove(self, values: Sequence[Sequence[int]], given: Sequence[Sequence[tuple]], seeds: Sequence[bytes]):
+        """values: per statement the m committed scalars; given: per statement the (left, right) assignments of the
+        multipliers not defined by constraints.  -> (commitments per statement, proofs per statement)"""
+        batch, m = len(seeds), self.desc.m
+        n_given = len(given[0]) if batch else 0
+        L = self.desc.L
+        vb = b"".join(int(x % L).to_bytes(32, "little") for row in values for x in row)
+        gb = b"".join(int(a % L).to_bytes(32, "little") + int(b % L).to_bytes(32, "little") for row in given for a, b in row)
+        com = C.create_string_buffer(max(32 * m * batch, 1))
+        stride = 1 + 32 * (16 + 2 * 16)
+        proofs = C.create_string_buffer(max(stride * batch, 1))
+        plen = C.c_size_t(0)
+        self.ctx._check(self.ctx.lib.zkgpu_r1cs_prove_batch(
+            self.ctx.h, self.bp_gens.points.h, C.byref(self.desc.struct), self.mult_def, self.bp_gens.gens_capacity, batch, vb, None,
+            gb, n_given, b"".join(seeds), self.host_threads, com, proofs, stride, C.byref(plen)))
+        return ([com.raw[32 * m * i: 32 * m * (i + 1)] for i in range(batch)],
+                [proofs.raw[stride * i: stride * i + plen.value] for i in range(batch)])
+
+
 class R1csVerifier:
     """Any constraint system, described as data (zkgpu_r1cs_plan_create): the device-side verifier for statements that
     are not a pure cloak -- `r1cs::Verifier::verify` for a uniform batch of proofs of ONE described statement shape."""
