@@ -185,6 +185,32 @@ class R1csProver {
   }
 
   bool done() const { return stage_ == kDone; }
+  // ---- the inner-product argument on the device (zkgpu.hip, ipa_on_device): the vectors leave after the
+  // polynomial phase, the prover keeps only its transcript going ----
+  void set_device_ipa(bool on) { device_ipa_ = on; }
+  bool at_ipa() const { return stage_ == kIpa && device_ipa_; }
+  size_t ipa_len() const { return pn_; }
+  size_t ipa_rounds() const { return k_; }
+  size_t gens_capacity() const { return cap_; }
+  // canonical 32-byte scalars: l, r, the generator coefficient vectors (pn each) and the weight w of Q = w B
+  void ipa_export(uint8_t* lv, uint8_t* rv, uint8_t* cg, uint8_t* ch, uint8_t* w) const {
+    for (size_t i = 0; i < pn_; ++i) { lv_[i].to_bytes(lv + 32 * i); rv_[i].to_bytes(rv + 32 * i); cG_[i].to_bytes(cg + 32 * i); cH_[i].to_bytes(ch + 32 * i); }
+    w_.to_bytes(w);
+  }
+  // L_j, R_j of the current round in; the round's challenge u and 1/u out (canonical)
+  void ipa_absorb(const uint8_t lr[64], uint8_t u_and_inverse[64]) {
+    proof_.insert(proof_.end(), lr, lr + 64);
+    cs_.tr.append_point("L", lr);
+    cs_.tr.append_point("R", lr + 32);
+    const Scalar uu = cs_.tr.challenge_scalar("u"), uu_inv = uu.invert();
+    uu.to_bytes(u_and_inverse);
+    uu_inv.to_bytes(u_and_inverse + 32);
+  }
+  void ipa_finish(const uint8_t a[32], const uint8_t b[32]) {
+    proof_.insert(proof_.end(), a, a + 32);
+    proof_.insert(proof_.end(), b, b + 32);
+    stage_ = kDone;
+  }
   bool failed() const { return failed_; }
   const std::vector<uint8_t>& proof() const { return proof_; }
   const std::vector<uint8_t>& commitments() const { return commitments_; }
@@ -398,7 +424,7 @@ class R1csProver {
     len_ = pn_;
     round_ = 0;
     if (k_ == 0) { finish(); return; }
-    ipa_rows(rows);
+    if (!device_ipa_) ipa_rows(rows);
     stage_ = kIpa;
   }
 
@@ -457,7 +483,7 @@ class R1csProver {
   std::vector<uint8_t> commitments_, proof_;
   uint8_t head_[352];   // A_I1 A_O1 S1 A_I2 A_O2 S2 T_1 T_3 T_4 T_5 T_6
   Stage stage_ = kNew;
-  bool failed_ = false;
+  bool failed_ = false, device_ipa_ = false;
   size_t n1_ = 0, n_ = 0, pn_ = 1, k_ = 0, len_ = 0, round_ = 0;
   Scalar i_bl1_, o_bl1_, s_bl1_, i_bl2_, o_bl2_, s_bl2_, y_, exp_y_, w_;
   Scalar t_[7], tb_[7];

@@ -31,6 +31,7 @@
 #include "cloak_plan.hpp"
 #include "prep_kernels.hpp"
 #include "r1cs_prover.hpp"
+#include "ipa_kernels.hpp"
 
 using namespace zk;
 
@@ -101,6 +102,7 @@ struct zkgpu_ctx {
   bool serial = false;             // measurement aid: the whole DAG of a batch on one stream
   hipEvent_t ev_dig = nullptr, ev_u = nullptr;
   Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
+  Buffer ipa_lv, ipa_rv, ipa_cg, ipa_ch, ipa_w, ipa_u;   // prover: the inner-product argument's vectors (ipa_kernels.hpp)
   Buffer prep_absorb, prep_raw;    // cooperative transcript: absorbed words per segment, raw challenge bytes
   int locate_mode = 0;             // failed groups: 0 automatic, 1 always re-check every transaction, 2 always locate the culprit
   int transcript_mode = 0;         // 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction
@@ -1172,7 +1174,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
                     &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform,
                     &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->small_tbl, &c->recoded, &c->grp_sc, &c->grp_digits, &c->grp_partials, &c->grp_ok, &c->row_map, &c->grp_fail, &c->grp_fail_sum, &c->rechk_pts, &c->prep_com, &c->prep_proofs, &c->prep_r,
                     &c->prep_pw, &c->prep_ch, &c->prep_wf, &c->prep_dyn_sc, &c->prep_dyn_pt, &c->prep_st_sc,
-                    &c->prep_absorb, &c->prep_raw};
+                    &c->prep_absorb, &c->prep_raw, &c->ipa_lv, &c->ipa_rv, &c->ipa_cg, &c->ipa_ch, &c->ipa_w, &c->ipa_u};
   for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->pinned_in) (void)hipHostFree(c->pinned_in);
@@ -1475,6 +1477,52 @@ int zkgpu_verify_batch_ps(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, 
                                    c->in_st_offsets.p, ns, accept_bitmap);
 }
 
+namespace {
+// values of `batch` multiscalar multiplications over the tables, terms resident on the device
+// (d_scalars: n x 8 canonical words, d_index: n generator indices or nullptr, d_offsets: batch + 1) -> 32 bytes each on the host
+int msm_ps_core(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, uint64_t n, const uint32_t* d_scalars, const uint32_t* d_index,
+                const uint64_t* d_offsets, uint8_t* out) {
+  hipStream_t s = c->stream;
+  const int W = ps->tbl_W;
+  const int P = (int)std::max<uint64_t>(1, std::min<uint64_t>(64, (131072 + batch * W - 1) / (batch * W)));
+  const uint64_t n_lanes = (uint64_t)batch * W * P;
+  TRY(ensure(c, c->status, 64));
+  TRY(ensure(c, c->digits, std::max<uint64_t>(n, 1) * W * 2));
+  TRY(ensure(c, c->st_partials, n_lanes * EXT_WORDS * 4));
+  TRY(ensure(c, c->values, 32 * batch));
+  TRY(ensure_pinned(c, 32 * batch + 64));
+  HIP_TRY(c, hipMemsetAsync(c->status.p, 0, 8, s));
+  if (n) {
+    Launch l(c, "k_static_digits");
+    hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_scalars,
+                       (int16_t*)c->digits.p, n, ps->tbl_w, W, (uint32_t*)c->status.p, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, 0u);
+  }
+  {
+    Launch l(c, "k_static_accumulate");
+    hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s, (const int16_t*)c->digits.p,
+                       d_offsets, d_index, (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)batch, n,
+                       (uint32_t*)c->st_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+  }
+  {
+    Launch l(c, "k_static_values");
+    hipLaunchKernelGGL(k_static_values, dim3((unsigned)batch), dim3(64), 0, s, (const uint32_t*)c->st_partials.p,
+                       (uint32_t)(W * P), (uint32_t*)c->values.p);
+  }
+  HIP_TRY(c, hipGetLastError());
+  char* h = (char*)c->pinned;
+  HIP_TRY(c, hipMemcpyAsync(h, c->values.p, 32 * batch, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(h + 32 * batch, c->status.p, 16, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (c->profiling) prof_collect(c);
+  uint32_t st;
+  memcpy(&st, h + 32 * batch, 4);
+  if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
+  memcpy(out, h, 32 * batch);
+  return ZKGPU_OK;
+}
+}  // namespace
+
 // Values of `batch` multiscalar multiplications over the points of a resident set that carries
 // fixed-base tables: out[32 m] = ENCODE(sum_k scalars[k] * ps[index[k]]), k in [offsets[m], offsets[m+1]).
 // This is the prover's primitive (Pedersen vector commitments A_I, A_O, S, T_i, and every L_j / R_j of an
@@ -1495,48 +1543,11 @@ int zkgpu_msm_ps_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, con
   }
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   DeviceGuard g(c->device);
-  hipStream_t s = c->stream;
-  const int W = ps->tbl_W;
-  const int P = (int)std::max<uint64_t>(1, std::min<uint64_t>(64, (131072 + batch * W - 1) / (batch * W)));
-  const uint64_t n_lanes = (uint64_t)batch * W * P;
   TRY(upload(c, c->in_st_scalars, scalars, n * 32));
   if (index) TRY(upload(c, c->in_st_index, index, n * 4));
   TRY(upload(c, c->in_st_offsets, offsets, (batch + 1) * 8));
-  TRY(ensure(c, c->status, 64));
-  TRY(ensure(c, c->digits, std::max<uint64_t>(n, 1) * W * 2));
-  TRY(ensure(c, c->st_partials, n_lanes * EXT_WORDS * 4));
-  TRY(ensure(c, c->values, 32 * batch));
-  TRY(ensure_pinned(c, 32 * batch + 64));
-  HIP_TRY(c, hipMemsetAsync(c->status.p, 0, 8, s));
-  if (n) {
-    Launch l(c, "k_static_digits");
-    hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(n, 256)), dim3(256), 0, s, (const uint32_t*)c->in_st_scalars.p,
-                       (int16_t*)c->digits.p, n, ps->tbl_w, W, (uint32_t*)c->status.p, (const uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, 0u);
-  }
-  {
-    Launch l(c, "k_static_accumulate");
-    hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s, (const int16_t*)c->digits.p,
-                       (const uint64_t*)c->in_st_offsets.p, index ? (const uint32_t*)c->in_st_index.p : (const uint32_t*)nullptr,
-                       (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)batch, n,
-                       (uint32_t*)c->st_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-  }
-  {
-    Launch l(c, "k_static_values");
-    hipLaunchKernelGGL(k_static_values, dim3((unsigned)batch), dim3(64), 0, s, (const uint32_t*)c->st_partials.p,
-                       (uint32_t)(W * P), (uint32_t*)c->values.p);
-  }
-  HIP_TRY(c, hipGetLastError());
-  char* h = (char*)c->pinned;
-  HIP_TRY(c, hipMemcpyAsync(h, c->values.p, 32 * batch, hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipMemcpyAsync(h + 32 * batch, c->status.p, 16, hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipStreamSynchronize(s));
-  if (c->profiling) prof_collect(c);
-  uint32_t st;
-  memcpy(&st, h + 32 * batch, 4);
-  if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
-  memcpy(out, h, 32 * batch);
-  return ZKGPU_OK;
+  return msm_ps_core(c, ps, batch, n, (const uint32_t*)c->in_st_scalars.p, index ? (const uint32_t*)c->in_st_index.p : nullptr,
+                     (const uint64_t*)c->in_st_offsets.p, out);
 }
 
 // Proves `batch` cloak statements of one shape (BASELINE.json configs[4]).
@@ -1549,6 +1560,59 @@ int zkgpu_msm_ps_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, con
 // 64 (n_in + n_out) B; proofs: batch x proof_stride B, *proof_len bytes used of each.
 namespace {
 bool desc_from_c(zkgpu_ctx* c, const zkgpu_r1cs_desc* d, R1csDesc& desc);
+
+int ipa_on_device(zkgpu_ctx* c, const zkgpu_pointset* ps, std::vector<std::unique_ptr<R1csProver>>& pr,
+                  const std::function<void(const std::function<void(size_t)>&)>& parallel) {
+  const size_t batch = pr.size();
+  const size_t pn = pr[0]->ipa_len(), k = pr[0]->ipa_rounds(), cap = pr[0]->gens_capacity();
+  for (size_t i = 0; i < batch; ++i)
+    if (!pr[i]->at_ipa() || pr[i]->ipa_len() != pn) { c->last_error = "prover: statements of one batch must share one shape"; return ZKGPU_EINVAL; }
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  hipStream_t s = c->stream;
+  const size_t vec = pn * 32, row_len = pn + 1, n_rows = 2 * batch;
+  std::vector<uint8_t> h_lv(batch * vec), h_rv(batch * vec), h_cg(batch * vec), h_ch(batch * vec), h_w(batch * 32);
+  parallel([&](size_t i) { pr[i]->ipa_export(&h_lv[i * vec], &h_rv[i * vec], &h_cg[i * vec], &h_ch[i * vec], &h_w[i * 32]); });
+  TRY(upload(c, c->ipa_lv, h_lv.data(), h_lv.size()));
+  TRY(upload(c, c->ipa_rv, h_rv.data(), h_rv.size()));
+  TRY(upload(c, c->ipa_cg, h_cg.data(), h_cg.size()));
+  TRY(upload(c, c->ipa_ch, h_ch.data(), h_ch.size()));
+  TRY(upload(c, c->ipa_w, h_w.data(), h_w.size()));
+  TRY(ensure(c, c->ipa_u, batch * 64));
+  TRY(ensure(c, c->values, 64 * batch));
+  TRY(ensure(c, c->in_st_scalars, n_rows * row_len * 32));
+  TRY(ensure(c, c->in_st_index, n_rows * row_len * 4));
+  std::vector<uint64_t> offs(n_rows + 1);
+  for (size_t r = 0; r <= n_rows; ++r) offs[r] = r * row_len;
+  TRY(upload(c, c->in_st_offsets, offs.data(), offs.size() * 8));
+  hipLaunchKernelGGL(k_ipa_to_mont, dim3(blocks_for(batch * pn, 256)), dim3(256), 0, s, (uint32_t*)c->ipa_lv.p, (uint64_t)batch * pn);
+  hipLaunchKernelGGL(k_ipa_to_mont, dim3(blocks_for(batch * pn, 256)), dim3(256), 0, s, (uint32_t*)c->ipa_rv.p, (uint64_t)batch * pn);
+  std::vector<uint8_t> pts(32 * n_rows), uu(64 * batch), ab(64 * batch);
+  size_t len = pn;
+  for (size_t round = 0; round <= k; ++round) {
+    const bool last = round == k;
+    {
+      Launch l(c, "k_ipa_round");
+      hipLaunchKernelGGL(k_ipa_round, dim3((unsigned)batch), dim3(256), 0, s, (uint32_t*)c->ipa_lv.p, (uint32_t*)c->ipa_rv.p,
+                         (uint32_t*)c->ipa_cg.p, (uint32_t*)c->ipa_ch.p, (const uint32_t*)c->ipa_w.p, (const uint32_t*)c->ipa_u.p,
+                         (uint32_t)pn, (uint32_t)len, (uint32_t)cap, round > 0 ? 1u : 0u, last ? 0u : 1u,
+                         (uint32_t*)c->in_st_scalars.p, (uint32_t*)c->in_st_index.p, (uint32_t*)c->values.p);
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (last) break;
+    TRY(msm_ps_core(c, ps, n_rows, (uint64_t)n_rows * row_len, (const uint32_t*)c->in_st_scalars.p, (const uint32_t*)c->in_st_index.p,
+                    (const uint64_t*)c->in_st_offsets.p, pts.data()));
+    parallel([&](size_t i) { pr[i]->ipa_absorb(&pts[64 * i], &uu[64 * i]); });     // L, R in; u, 1/u out
+    HIP_TRY(c, hipMemcpyAsync(c->ipa_u.p, uu.data(), uu.size(), hipMemcpyHostToDevice, s));
+    len /= 2;
+  }
+  HIP_TRY(c, hipMemcpyAsync(ab.data(), c->values.p, 64 * batch, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (c->profiling) prof_collect(c);
+  parallel([&](size_t i) { pr[i]->ipa_finish(&ab[64 * i], &ab[64 * i + 32]); });
+  return ZKGPU_OK;
+}
+
 // Runs `batch` provers in lockstep: every phase of the whole batch is ONE zkgpu_msm_ps_batch over the tables.
 int prove_lockstep(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, int host_threads,
                    const std::function<std::unique_ptr<R1csProver>(size_t)>& make, uint8_t* commitments, size_t com_bytes,
@@ -1564,6 +1628,7 @@ int prove_lockstep(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, int hos
   };
   parallel([&](size_t i) {
     pr[i] = make(i);
+    pr[i]->set_device_ipa(true);
     pr[i]->begin(rows[i]);
   });
   std::vector<uint64_t> offs, row_of(batch + 1);
@@ -1577,6 +1642,14 @@ int prove_lockstep(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, int hos
     for (size_t i = 0; i < batch; ++i) { any |= !pr[i]->done(); bad |= pr[i]->failed(); }
     if (bad) { c->last_error = "prover: inconsistent witness or too few generators"; return ZKGPU_EINVAL; }
     if (!any) break;
+    if (pr[0]->at_ipa()) {
+      // the inner-product argument of the whole batch: vectors and folds on the device (ipa_kernels.hpp), one
+      // multiscalar-multiplication call per round on the tables, the three transcript messages per round on the host
+      const double t0 = now();
+      TRY(ipa_on_device(c, ps, pr, parallel));
+      if (timing) fprintf(stderr, "prover inner-product argument on the device: %.1f ms\n", (now() - t0) * 1e3);
+      continue;
+    }
     offs.assign(1, 0);
     row_of[0] = 0;
     for (size_t i = 0; i < batch; ++i) {
