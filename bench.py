@@ -436,7 +436,7 @@ def run_config2(args, W):
     ctx.set_group_size(args.group)               # forks inherit it
     ctx.set_transcript_mode(args.transcript_mode)
     ctx.set_locate_mode(args.locate_mode)
-    ctxs = [ctx] + [ctx.fork() for _ in range(min(max(1, args.inflight), 10) - 1)]
+    ctxs = [ctx] + [ctx.fork() for _ in range((min(max(1, args.inflight), 10) if args.tickets <= 0 else 6) - 1)]
     d_com = to_dev(b"".join(t[2] for t in txs))
     d_proofs = to_dev(b"".join(t[3] for t in txs))
     d_r = to_dev(r_bytes)
@@ -473,23 +473,62 @@ def run_config2(args, W):
             bm = collect(lanes[i % depth], gather)
         return bm
 
+    bv = None
+    if args.tickets > 0:
+        from zkvm_amd.verifier import BlockVerifier
+        bv = BlockVerifier(ctx, gens, batches_in_flight=args.inflight)
+        bv.set_merge(args.merge)
+        for i in range(bv.lanes()):
+            bv.lane(i).set_group_size(args.group)
+
+    def run_tickets(n):
+        # `--tickets D`: D batches in flight as tickets; the verifier merges them into device batches of --merge transactions
+        depth = args.tickets
+        q, bm = [], None
+        for i in range(n):
+            if len(q) >= depth:
+                bm = bv.wait(q.pop(0))
+                if world > 1:
+                    d_bm.copy_(torch.frombuffer(bytearray(bm), dtype=torch.uint8))
+                    W.dist.all_gather_into_tensor(d_all, d_bm)
+                assert bm == want_bm
+            ts = time.perf_counter()
+            q.append(bv.submit_dev(n_in, n_out, batch, d_com, d_proofs, proof_len, d_r))
+            host_time["submit"] += time.perf_counter() - ts
+            host_time["n"] += 1
+        while q:
+            bm = bv.wait(q.pop(0))
+            assert bm == want_bm
+        return bm
+
+    want_bm = bitmap_of(expected)
+
+    dev_batch = batch
+    d_com_s, d_proofs_s, d_r_s, want_solo = d_com, d_proofs, d_r, want_bm
+    if bv is not None and args.merge > batch:
+        # the device executes merged batches of --merge transactions: that is what the per-kernel figures describe
+        rep = max(1, args.merge // batch)
+        dev_batch = rep * batch
+        d_com_s, d_proofs_s, d_r_s = d_com.repeat(rep), d_proofs.repeat(rep), d_r.repeat(rep)
+        want_solo = bitmap_of(expected * rep)
+
     def solo_pass(reps=5):
         ctx.profile_reset()
         ctx.set_serial(True)
         ctx.profile(True)
         for _ in range(reps):
-            submit_verify(ctx)
-            assert ctx.verify_wait() == bitmap_of(expected)
+            gv.submit_packed_gpu_dev(n_in, n_out, dev_batch, d_com_s, d_proofs_s, proof_len, d_r_s, ctx=ctx)
+            assert ctx.verify_wait() == want_solo
         ctx.profile(False)
         ctx.set_serial(False)
         prof = ctx.profile_read()
         return {k: v[1] / v[0] for k, v in prof.items() if v[0]}, {k: v[0] / reps for k, v in prof.items() if v[0]}
 
     if args.solo:      # what tools/profile_bench.sh runs under rocprofv3 --stats: every kernel alone on the chip
-        run_steps(2, lanes=[ctx])
+        solo_pass(2)
         solo, launches = solo_pass(max(args.steps, 5))
         if rank == 0:
-            emit({"solo_kernel_ms": {k: round(v, 4) for k, v in sorted(solo.items())}, "launches_per_step": launches, "batch": batch})
+            emit({"solo_kernel_ms": {k: round(v, 4) for k, v in sorted(solo.items())}, "launches_per_step": launches, "batch": dev_batch})
         gv.close()
         for c in ctxs[1:]:
             c.close()
@@ -497,16 +536,17 @@ def run_config2(args, W):
         ctx.close()
         return
 
-    bm = run_steps(max(args.warmup, len(ctxs)))
+    timed = run_tickets if bv is not None else run_steps
+    bm = timed(max(args.warmup, len(ctxs), args.tickets))
     # HIP events around every launch of ONE of the contexts in flight (every len(ctxs)-th step)
-    prof_ctxs = ctxs[:1]
+    prof_ctxs = [bv.lane(i) for i in range(bv.lanes())] if bv is not None else ctxs[:1]
     for c in prof_ctxs:
         c.profile_reset()
         c.profile(True)
     W.barrier()
     t0 = time.perf_counter()
     host_time.update(submit=0.0, n=0)
-    bm = run_steps(args.steps)
+    bm = timed(args.steps)
     W.barrier()
     elapsed = time.perf_counter() - t0
     submit_ms = host_time["submit"] / max(host_time["n"], 1) * 1e3
@@ -524,6 +564,8 @@ def run_config2(args, W):
         solo, launches = solo_pass()
         ms_per_step = elapsed / args.steps * 1e3
         alg_step = algorithmic_bytes(lib, [(n_in, n_out)] * batch)
+        alg_dev = alg_step * (dev_batch // batch)                 # per device batch (the unit the kernels are launched for)
+        ms_per_dev_batch = ms_per_step * (dev_batch // batch)
         line = common_line(args, W, batch * world * args.steps / elapsed, elapsed,
                            "synthetic: 1024 distinct real R1CS proofs of the 2-in/2-out cloak statement (committed fixture, oracle "
                            "prover), each verified under per-transaction verifier randomness; ~1.5% corrupted",
@@ -533,12 +575,14 @@ def run_config2(args, W):
                                         "the %d-term mega_check MSM (n=256, k=8, m=8; %d terms on shared generators), identity "
                                         "test -> accept bitmap" % (batch, n_dyn + n_static, n_static),
                             "tx_per_gpu": batch, "terms_per_tx": n_dyn + n_static, "generator_table_bits": args.table_bits,
-                            "calls_in_flight": len(ctxs), "group_size": args.group,
+                            "calls_in_flight": args.tickets if bv is not None else len(ctxs), "group_size": args.group,
+                            "merged_device_batches": ({"transactions": args.merge, "in_flight": bv.lanes()} if bv is not None else None),
                             "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "hw_queues_set_by": "caller" if _HWQ_PRESET else "bench.py, before the HIP runtime started",
                             "parallelism": "tx-sharded x%d, RCCL all-gather of accept bitmaps" % world})
-        line["roofline"] = roofline_object(solo, launches, in_flight_ms, alg_step, batch, ms_per_step, table_bytes,
+        line["roofline"] = roofline_object(solo, launches, in_flight_ms, alg_dev, dev_batch, ms_per_dev_batch, table_bytes,
                                            "algorithmic bytes per launch = %d B per transaction (64 B x %d proof-specific terms + 32 B x "
-                                           "%d generator scalars) x the %d transactions a launch processes" % (alg_step // batch, n_dyn, n_static, batch))
+                                           "%d generator scalars) x the %d transactions a launch processes (%d batches of %d merged by the "
+                                           "verifier); `step` figures are per device batch" % (alg_step // batch, n_dyn, n_static, dev_batch, dev_batch // batch, batch))
         line["setup"] = {"table_build_ms": round(table_s * 1e3, 1), "table_bytes": table_bytes,
                          "note": "one-time per generator set (generators + fixed-base tables, zkgpu_pointset_build_tables); not in `value`"}
         line["kernel_ms_in_flight"] = {k: round(x, 4) for k, x in sorted(in_flight_ms.items())}
@@ -612,6 +656,8 @@ def run_config2(args, W):
                 line["msm_2p20"] = msm_microbench(ctx, torch, dev)
         emit(line)
     W.close()
+    if bv is not None:
+        bv.close()
     gv.close()
     for c in ctxs[1:]:
         c.close()
@@ -754,10 +800,14 @@ def main():
                     help="2: BASELINE configs[1], 1024 2x2 tx per GPU (default, the headline); 4: configs[3], mixed arity, sharded")
     ap.add_argument("--batch", type=int, default=1024, help="transactions per GPU (config 4: default 8192)")
     ap.add_argument("--table-bits", type=int, default=16, help="window width of the fixed-base generator tables")
-    ap.add_argument("--inflight", type=int, default=6, help="batches in flight per GPU")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="device batches in flight per GPU (contexts): default 3 with --tickets, 6 without, 6 for config 4")
     ap.add_argument("--group", type=int, default=16, help="transactions per group check (1 = every transaction on its own)")
     ap.add_argument("--chunk", type=int, default=0, help="config 4: transactions per batch in flight (0 = library default)")
     ap.add_argument("--bad-every", type=int, default=64, help="config 2: one transaction in this many is corrupted (0 = none)")
+    ap.add_argument("--tickets", type=int, default=32,
+                    help="config 2: batches kept in flight as tickets of a zkgpu_verifier, which merges them into device batches of --merge tx (0 = plain contexts)")
+    ap.add_argument("--merge", type=int, default=8192, help="config 2 with --tickets: transactions per merged device batch")
     ap.add_argument("--locate-mode", type=int, default=0, choices=(0, 1, 2), help="zkgpu_set_locate_mode")
     ap.add_argument("--transcript-mode", type=int, default=0, choices=(0, 1, 2),
                     help="zkgpu_set_transcript_mode: 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction")
@@ -770,6 +820,10 @@ def main():
         args.steps = 200 if args.config == 2 else 20
     if args.warmup is None:
         args.warmup = 10 if args.config == 2 else 3
+    if args.config == 4:
+        args.tickets = 0
+    if args.inflight <= 0:
+        args.inflight = 3 if args.tickets > 0 else 6
     W = World(args)
     (run_config2 if args.config == 2 else run_config4)(args, W)
 

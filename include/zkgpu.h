@@ -395,6 +395,21 @@ void zkgpu_txblock_destroy(zkgpu_txblock *block);
 size_t zkgpu_txblock_size(const zkgpu_txblock *block);
 size_t zkgpu_txblock_shapes(const zkgpu_txblock *block);
 int zkgpu_verifier_verify_block(zkgpu_verifier *v, const zkgpu_txblock *block, uint8_t *accept_bitmap);
+/* Tickets: many small batches in flight, few large device batches.  zkgpu_verifier_submit_dev QUEUES one uniform batch
+ * (inputs resident in HBM, as zkgpu_cloak_verify_submit_dev) and returns a ticket at once; queued batches of one shape
+ * are merged, up to `merge` transactions (zkgpu_verifier_set_merge, default 4096), copied side by side into the
+ * workspace of one of the verifier's contexts (device to device) and launched as ONE batch as soon as the target is
+ * reached and a context is free -- or when a ticket among them is waited for.  zkgpu_verifier_wait blocks until that
+ * ticket's batch is done and writes ITS accept bitmap (ceil(batch / 8) bytes; all zero on any error).  Verdicts are
+ * those of separate batches; what changes is when a batch starts and how well it fills the chip: every kernel of a
+ * 1024-transaction batch is a single round of workgroups, four merged batches run ~1.5x faster per transaction.
+ * This is what bench.py times for the 1024-transaction batches of BASELINE.json configs[1].  Inputs must stay valid
+ * until their ticket has been waited for; do not run zkgpu_verifier_verify* calls concurrently with tickets in flight
+ * (they first finish them).  (A runtime policy -- dynamic batching -- with no counterpart in the reference.) */
+int zkgpu_verifier_set_merge(zkgpu_verifier *v, size_t transactions);
+int zkgpu_verifier_submit_dev(zkgpu_verifier *v, uint32_t n_in, uint32_t n_out, size_t batch, const void *d_commitments,
+                              const void *d_proofs, size_t proof_len, const void *d_r, uint64_t *ticket);
+int zkgpu_verifier_wait(zkgpu_verifier *v, uint64_t ticket, uint8_t *accept_bitmap);
 
 /* ---- one process per GPU: sharding and the RCCL exchange ------------------
  * Transactions are independent, so a block is cut into `world` contiguous shards balanced by the

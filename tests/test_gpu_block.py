@@ -467,3 +467,53 @@ def test_described_prover_on_device_equals_oracle_and_verifies(ctx, oracle, kind
     finally:
         v.close()
         gens.close()
+
+
+def test_tickets_merge_small_batches_and_return_each_its_own_bitmap(ctx, oracle):
+    """zkgpu_verifier_submit_dev / zkgpu_verifier_wait: fifteen batches of two shapes and ragged sizes queued as tickets
+    on a verifier with three contexts, merged into device batches of at most 1500 transactions; every ticket gets the
+    oracle's verdicts for ITS transactions, whatever the order they are waited for in, also with a block verification
+    in between, and tickets of a shape the generators cannot serve are rejected one by one."""
+    import random
+    from zkvm_amd.verifier import BlockVerifier, BulletproofGens
+    fix = load_mixed_fixture()
+    gens = BulletproofGens(ctx, 256, table_bits=9)
+    bv = BlockVerifier(ctx, gens, batches_in_flight=3)
+    bv.set_merge(1500)
+    rng = random.Random(12)
+    try:
+        jobs = []
+        for j in range(15):
+            shape = [(2, 2), (1, 2), (2, 2), (4, 4)][j % 4] if j != 7 else (2, 2)
+            n = rng.choice([1, 37, 256, 400, 640])
+            recs = [fix[shape][rng.randrange(32)] for _ in range(n)]
+            coms = [bytearray(c) for c, _ in recs]
+            proofs = [bytearray(p) for _, p in recs]
+            for i in range(0, n, 29):
+                proofs[i][1 + 32 * 11 + (i % 20)] ^= 1 << (j % 8)
+            r = hashlib.shake_256(b"ticket %d" % j).digest(64 * n)
+            plen = len(proofs[0])
+            com_b, proof_b = b"".join(bytes(c) for c in coms), b"".join(bytes(p) for p in proofs)
+            if shape == (4, 4):
+                want = [0] * n                                          # 512 multipliers, 256 generators
+            else:
+                want = list(oracle.cloak_verify_batch(com_b, shape[0], shape[1], proof_b, plen, r, threads=8))
+            jobs.append((shape, n, ctx.to_device(com_b), ctx.to_device(proof_b), ctx.to_device(r), plen, want))
+        tickets = [bv.submit_dev(s[0], s[1], n, dc, dp, plen, dr) for (s, n, dc, dp, dr, plen, _) in jobs[:10]]
+        order = list(range(10))
+        rng.shuffle(order)
+        for k in order[:4]:
+            assert bits(bv.wait(tickets[k]), jobs[k][1]) == jobs[k][6], k
+        block = mixed_block(90, seed=3, bad_every=11)
+        block = [t for t in block if (t[0], t[1]) != (4, 4)]
+        rb = hashlib.shake_256(b"ticket block").digest(64 * len(block))
+        assert bits(bv.verify(_cloak(block), rb), len(block)) == oracle_block_bits(oracle, block, rb)     # finishes the tickets in flight first
+        tickets += [bv.submit_dev(s[0], s[1], n, dc, dp, plen, dr) for (s, n, dc, dp, dr, plen, _) in jobs[10:]]
+        for k in order[4:] + list(range(10, 15)):
+            assert bits(bv.wait(tickets[k]), jobs[k][1]) == jobs[k][6], k
+        for (_, _, dc, dp, dr, _, _) in jobs:
+            for d in (dc, dp, dr):
+                ctx.free_device(d)
+    finally:
+        bv.close()
+        gens.close()

@@ -13,10 +13,28 @@
 // the library loads and every single-GPU entry point works on a machine without it.
 #pragma once
 
+#include <deque>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+struct zkgpu_request {                 // one submitted batch (zkgpu_verifier_submit_dev)
+  uint64_t id = 0;
+  uint32_t n_in = 0, n_out = 0;
+  size_t batch = 0, proof_len = 0, bit_off = 0;
+  const void *d_com = nullptr, *d_proofs = nullptr, *d_r = nullptr;
+  int state = 0;                       // 0 queued, 1 in flight on `lane`, 2 done
+  int lane = -1, rc = 0;
+  std::vector<uint8_t> bits;
+};
+
 struct zkgpu_verifier {
+  // ---- tickets: requests queued, merged by shape and run on the lanes (zkgpu_verifier_submit_dev / _wait)
+  uint64_t next_id = 1;
+  std::deque<zkgpu_request*> queue;                     // submitted, not launched
+  std::map<uint64_t, zkgpu_request*> requests;          // every ticket not yet waited for
+  std::vector<std::vector<zkgpu_request*>> running;     // per lane: the members of its merged batch in flight
+  std::deque<int> busy;                                 // lanes in flight, oldest first
+  size_t merge_target = 4096;                           // transactions per merged device batch
   zkgpu_ctx* root = nullptr;
   const zkgpu_pointset* ps = nullptr;
   size_t gens_capacity = 0;
@@ -55,6 +73,8 @@ struct zkgpu_comm {
 };
 
 namespace {
+void ticket_collect(zkgpu_verifier* v, int lane);
+int ticket_dispatch(zkgpu_verifier* v, bool force);
 
 // ---- RCCL, bound on first use -------------------------------------------------------------
 struct RcclApi {
@@ -145,6 +165,7 @@ int zkgpu_verifier_create(zkgpu_ctx* ctx, const zkgpu_pointset* ps, size_t gens_
     if (zkgpu_ctx_fork(ctx, &f) != ZKGPU_OK) break;     // fewer lanes than asked for: still correct
     v->lanes.push_back(f);
   }
+  v->running.resize(v->lanes.size());
   *out = v;
   return ZKGPU_OK;
 }
@@ -153,6 +174,7 @@ void zkgpu_verifier_destroy(zkgpu_verifier* v) {
   if (!v) return;
   std::vector<uint8_t> scratch;
   (void)drain(v, scratch);
+  for (auto& kv : v->requests) delete kv.second;
   for (size_t i = 1; i < v->lanes.size(); ++i) zkgpu_destroy(v->lanes[i]);
   for (auto& kv : v->plans) if (kv.second) zkgpu_cloak_plan_destroy(kv.second);
   delete v;
@@ -259,6 +281,8 @@ int zkgpu_verifier_verify_block(zkgpu_verifier* v, const zkgpu_txblock* b, uint8
   const size_t nbytes = (b->batch + 7) / 8;
   memset(accept_bitmap, 0, nbytes);
   std::lock_guard<std::mutex> lk(v->mu);
+  (void)ticket_dispatch(v, true);                      // tickets in flight use the same lanes: finish them first
+  while (!v->busy.empty()) ticket_collect(v, v->busy.front());
   struct InFlight { const zkgpu_txblock::Group* g; size_t off, n; };
   std::vector<InFlight> on_lane(v->lanes.size(), InFlight{nullptr, 0, 0});
   std::vector<uint8_t> bm;
@@ -308,6 +332,140 @@ int zkgpu_verifier_verify(zkgpu_verifier* v, size_t batch, const uint32_t* n_in,
   TRY(zkgpu_txblock_create(v, batch, n_in, n_out, commitments, proofs, proof_offsets, r_bytes, &b));
   const int rc = zkgpu_verifier_verify_block(v, b, accept_bitmap);
   zkgpu_txblock_destroy(b);
+  return rc;
+}
+
+// ---- tickets: many small batches in flight, merged into few large device batches ----------------------
+// A 1024-transaction batch is ONE round of workgroups for every chip-filling kernel: each pays its ramp and its
+// tail, and neighbours cannot share a CU whose register file one of them fills; a 4096-transaction batch runs
+// ~1.5x faster per transaction.  zkgpu_verifier_submit_dev therefore only QUEUES a batch (inputs resident in
+// HBM, uniform shape) and returns a ticket; queued batches of one shape are merged, up to merge_target
+// transactions, copied side by side into a lane's workspace (device to device, ~1.4 KB per transaction) and
+// launched as one batch as soon as the target is reached and a lane is free -- or when someone waits for one of
+// them.  zkgpu_verifier_wait returns that batch's own accept bitmap.  Verdicts are those of separate batches;
+// what changes is when a batch starts.  (A runtime policy, as dynamic batching in a serving system; the reference
+// has no counterpart.)  The inputs must stay valid until the ticket has been waited for.
+namespace {
+
+void ticket_collect(zkgpu_verifier* v, int lane) {       // v->mu held
+  std::vector<zkgpu_request*> members;
+  members.swap(v->running[(size_t)lane]);
+  for (auto it = v->busy.begin(); it != v->busy.end(); ++it) if (*it == lane) { v->busy.erase(it); break; }
+  if (members.empty()) return;
+  size_t total = 0;
+  for (auto* r : members) total += r->batch;
+  std::vector<uint8_t> big((total + 7) / 8, 0);
+  const int rc = zkgpu_verify_wait(v->lanes[(size_t)lane], big.data());
+  if (rc != ZKGPU_OK) v->last_error = zkgpu_last_error(v->lanes[(size_t)lane]);
+  for (auto* r : members) {
+    r->bits.assign((r->batch + 7) / 8, 0);
+    if (rc == ZKGPU_OK)
+      for (size_t i = 0; i < r->batch; ++i) {
+        const size_t b = r->bit_off + i;
+        if ((big[b / 8] >> (b % 8)) & 1) r->bits[i / 8] |= (uint8_t)(1u << (i % 8));
+      }
+    r->rc = rc;
+    r->state = 2;
+  }
+}
+
+// launches the batches at the head of the queue that share its shape; force: even below the merge target, and
+// if no lane is free the oldest one in flight is collected first
+int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
+  while (!v->queue.empty()) {
+    zkgpu_request* head = v->queue.front();
+    std::vector<zkgpu_request*> pick;
+    size_t total = 0;
+    for (zkgpu_request* r : v->queue) {
+      if (r->n_in != head->n_in || r->n_out != head->n_out || r->proof_len != head->proof_len) continue;
+      if (!pick.empty() && total + r->batch > v->merge_target) break;
+      pick.push_back(r);
+      total += r->batch;
+      if (total >= v->merge_target) break;
+    }
+    if (total < v->merge_target && !force) return ZKGPU_OK;
+    int lane = -1;
+    for (size_t i = 0; i < v->lanes.size(); ++i) if (v->running[i].empty()) { lane = (int)i; break; }
+    if (lane < 0) {
+      if (!force) return ZKGPU_OK;
+      ticket_collect(v, v->busy.front());
+      continue;
+    }
+    zkgpu_ctx* L = v->lanes[(size_t)lane];
+    zkgpu_cloak_plan* plan = verifier_plan(v, head->n_in, head->n_out);
+    int rc = ZKGPU_OK;
+    const void *p_com = pick[0]->d_com, *p_proofs = pick[0]->d_proofs, *p_r = pick[0]->d_r;
+    if (plan && head->proof_len == 1 + 4ull * plan->shape.proof_words && pick.size() > 1) {
+      std::lock_guard<std::recursive_mutex> lk(L->mu);
+      DeviceGuard g(L->device);
+      const size_t wcom = (size_t)plan->shape.m * 32;
+      rc = ensure(L, L->coal_com, total * wcom);
+      if (rc == ZKGPU_OK) rc = ensure(L, L->coal_proofs, total * head->proof_len);
+      if (rc == ZKGPU_OK) rc = ensure(L, L->coal_r, total * 64);
+      size_t off = 0;
+      for (zkgpu_request* r : pick) {
+        if (rc != ZKGPU_OK) break;
+        hipError_t e = hipMemcpyAsync((char*)L->coal_com.p + off * wcom, r->d_com, r->batch * wcom, hipMemcpyDeviceToDevice, L->stream_l);
+        if (e == hipSuccess) e = hipMemcpyAsync((char*)L->coal_proofs.p + off * head->proof_len, r->d_proofs, r->batch * head->proof_len, hipMemcpyDeviceToDevice, L->stream_l);
+        if (e == hipSuccess) e = hipMemcpyAsync((char*)L->coal_r.p + off * 64, r->d_r, r->batch * 64, hipMemcpyDeviceToDevice, L->stream_l);
+        if (e != hipSuccess) { L->last_error = hipGetErrorString(e); rc = ZKGPU_EHIP; }
+        off += r->batch;
+      }
+      p_com = L->coal_com.p; p_proofs = L->coal_proofs.p; p_r = L->coal_r.p;
+    }
+    if (rc == ZKGPU_OK && plan) rc = zkgpu_cloak_verify_submit_dev(L, v->ps, plan, total, p_com, p_proofs, head->proof_len, p_r);
+    size_t off = 0;
+    for (zkgpu_request* r : pick) {
+      for (auto it = v->queue.begin(); it != v->queue.end(); ++it) if (*it == r) { v->queue.erase(it); break; }
+      r->bit_off = off; off += r->batch;
+      if (rc == ZKGPU_OK && plan) { r->state = 1; r->lane = lane; }
+      else { r->state = 2; r->rc = plan ? rc : ZKGPU_OK; r->bits.assign((r->batch + 7) / 8, 0); }   // no plan: every proof is Err
+    }
+    if (rc == ZKGPU_OK && plan) { v->running[(size_t)lane] = pick; v->busy.push_back(lane); }
+    else if (rc != ZKGPU_OK) v->last_error = zkgpu_last_error(L);
+  }
+  return ZKGPU_OK;
+}
+
+}  // namespace
+
+int zkgpu_verifier_set_merge(zkgpu_verifier* v, size_t transactions) {
+  if (!v || transactions == 0 || transactions >= (1u << 24)) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  v->merge_target = transactions;
+  return ZKGPU_OK;
+}
+
+int zkgpu_verifier_submit_dev(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, size_t batch, const void* d_commitments,
+                              const void* d_proofs, size_t proof_len, const void* d_r, uint64_t* ticket) {
+  if (!v || !ticket || batch == 0 || batch >= (1ull << 24) || !d_commitments || !d_proofs || !d_r) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  zkgpu_request* r = new zkgpu_request();
+  r->id = v->next_id++;
+  r->n_in = n_in; r->n_out = n_out; r->batch = batch; r->proof_len = proof_len;
+  r->d_com = d_commitments; r->d_proofs = d_proofs; r->d_r = d_r;
+  v->requests[r->id] = r;
+  v->queue.push_back(r);
+  *ticket = r->id;
+  return ticket_dispatch(v, false);
+}
+
+int zkgpu_verifier_wait(zkgpu_verifier* v, uint64_t ticket, uint8_t* accept_bitmap) {
+  if (!v || !accept_bitmap) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  auto it = v->requests.find(ticket);
+  if (it == v->requests.end()) return ZKGPU_EINVAL;
+  zkgpu_request* r = it->second;
+  while (r->state != 2) {
+    if (r->state == 0) (void)ticket_dispatch(v, true);
+    else ticket_collect(v, r->lane);
+  }
+  const int rc = r->rc;
+  memset(accept_bitmap, 0, (r->batch + 7) / 8);
+  if (rc == ZKGPU_OK) memcpy(accept_bitmap, r->bits.data(), r->bits.size());
+  v->requests.erase(it);
+  delete r;
+  if (!v->queue.empty()) (void)ticket_dispatch(v, false);
   return rc;
 }
 

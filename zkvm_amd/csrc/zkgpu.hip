@@ -102,6 +102,7 @@ struct zkgpu_ctx {
   bool serial = false;             // measurement aid: the whole DAG of a batch on one stream
   hipEvent_t ev_dig = nullptr, ev_u = nullptr;
   Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
+  Buffer coal_com, coal_proofs, coal_r;  // merged inputs of the batches a zkgpu_verifier runs as one (session.hpp, tickets)
   Buffer ipa_lv, ipa_rv, ipa_cg, ipa_ch, ipa_w, ipa_u;   // prover: the inner-product argument's vectors (ipa_kernels.hpp)
   Buffer prep_absorb, prep_raw;    // cooperative transcript: absorbed words per segment, raw challenge bytes
   int locate_mode = 0;             // failed groups: 0 automatic, 1 always re-check every transaction, 2 always locate the culprit
@@ -123,7 +124,6 @@ struct zkgpu_ctx {
 };
 
 namespace {
-
 #define HIP_TRY(ctx, expr)                                                                  \
   do {                                                                                      \
     hipError_t e__ = (expr);                                                                \
@@ -1174,7 +1174,8 @@ void zkgpu_destroy(zkgpu_ctx* c) {
                     &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform,
                     &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->small_tbl, &c->recoded, &c->grp_sc, &c->grp_digits, &c->grp_partials, &c->grp_ok, &c->row_map, &c->grp_fail, &c->grp_fail_sum, &c->rechk_pts, &c->prep_com, &c->prep_proofs, &c->prep_r,
                     &c->prep_pw, &c->prep_ch, &c->prep_wf, &c->prep_dyn_sc, &c->prep_dyn_pt, &c->prep_st_sc,
-                    &c->prep_absorb, &c->prep_raw, &c->ipa_lv, &c->ipa_rv, &c->ipa_cg, &c->ipa_ch, &c->ipa_w, &c->ipa_u};
+                    &c->prep_absorb, &c->prep_raw, &c->ipa_lv, &c->ipa_rv, &c->ipa_cg, &c->ipa_ch, &c->ipa_w, &c->ipa_u,
+                    &c->coal_com, &c->coal_proofs, &c->coal_r};
   for (Buffer* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->pinned_in) (void)hipHostFree(c->pinned_in);
@@ -2088,16 +2089,20 @@ int zkgpu_cloak_verify_submit(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloa
                               const uint8_t* r_bytes) {
   if (!c || !ps || !plan || plan->device != c->device || ps->ctx->device != c->device) return ZKGPU_EINVAL;
   if (batch == 0 || !commitments || !proofs || batch >= (1ull << 24)) return ZKGPU_EINVAL;
-  std::lock_guard<std::recursive_mutex> lk(c->mu);
-  if (c->pending) return ZKGPU_EINVAL;
   const PrepShape& sh = plan->shape;
-  if (proof_len != 1 + 4ull * sh.proof_words) {     // wrong length for this statement: every proof is Err
-    std::vector<uint8_t> z((batch + 7) / 8, 0);
-    park_sync_result(c, ZKGPU_OK, z.data(), batch);
-    return ZKGPU_OK;
+  {
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (c->pending) return ZKGPU_EINVAL;
+    if (proof_len != 1 + 4ull * sh.proof_words) {     // wrong length for this statement: every proof is Err
+      std::vector<uint8_t> z((batch + 7) / 8, 0);
+      park_sync_result(c, ZKGPU_OK, z.data(), batch);
+      return ZKGPU_OK;
+    }
+    DeviceGuard g(c->device);
+    TRY(stage_inputs(c, sh, batch, commitments, proofs, proof_len, r_bytes));
   }
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
   DeviceGuard g(c->device);
-  TRY(stage_inputs(c, sh, batch, commitments, proofs, proof_len, r_bytes));
   return cloak_verify_gpu_enqueue(c, ps, plan, batch, (const uint32_t*)c->prep_com.p, (const uint8_t*)c->prep_proofs.p,
                                   (const uint32_t*)c->prep_r.p, proof_len);
 }
@@ -2256,13 +2261,16 @@ int zkgpu_cloak_verify_submit_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_
                                   const void* d_commitments, const void* d_proofs, size_t proof_len, const void* d_r) {
   if (!c || !ps || !plan || plan->device != c->device || ps->ctx->device != c->device) return ZKGPU_EINVAL;
   if (batch == 0 || !d_commitments || !d_proofs || !d_r || batch >= (1ull << 24)) return ZKGPU_EINVAL;
-  std::lock_guard<std::recursive_mutex> lk(c->mu);
-  if (c->pending) return ZKGPU_EINVAL;
-  if (proof_len != 1 + 4ull * plan->shape.proof_words) {     // wrong length for this statement: every proof is Err
-    std::vector<uint8_t> z((batch + 7) / 8, 0);
-    park_sync_result(c, ZKGPU_OK, z.data(), batch);
-    return ZKGPU_OK;
+  {
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (c->pending) return ZKGPU_EINVAL;
+    if (proof_len != 1 + 4ull * plan->shape.proof_words) {     // wrong length for this statement: every proof is Err
+      std::vector<uint8_t> z((batch + 7) / 8, 0);
+      park_sync_result(c, ZKGPU_OK, z.data(), batch);
+      return ZKGPU_OK;
+    }
   }
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
   DeviceGuard g(c->device);
   return cloak_verify_gpu_enqueue(c, ps, plan, batch, (const uint32_t*)d_commitments, (const uint8_t*)d_proofs,
                                   (const uint32_t*)d_r, proof_len);

@@ -160,6 +160,25 @@ class BlockVerifier:
         self._check(self.lib.zkgpu_verifier_verify(self.h, batch, n_in, n_out, com, proofs, po, r_bytes, bm))
         return bm.raw[: (batch + 7) // 8]
 
+    def set_merge(self, transactions: int) -> None:
+        self._check(self.lib.zkgpu_verifier_set_merge(self.h, transactions))
+
+    def submit_dev(self, n_in: int, n_out: int, batch: int, d_commitments, d_proofs, proof_len: int, d_r) -> int:
+        """zkgpu_verifier_submit_dev: queue one uniform batch (device buffers); -> ticket"""
+        from .native import _ptr
+        t = C.c_uint64(0)
+        self._check(self.lib.zkgpu_verifier_submit_dev(self.h, n_in, n_out, batch, _ptr(d_commitments), _ptr(d_proofs), proof_len,
+                                                       _ptr(d_r), C.byref(t)))
+        self.__dict__.setdefault("_ticket_batch", {})[t.value] = batch
+        return int(t.value)
+
+    def wait(self, ticket: int) -> bytes:
+        """zkgpu_verifier_wait: the accept bitmap of that ticket's batch"""
+        batch = self.__dict__["_ticket_batch"].pop(ticket)
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        self._check(self.lib.zkgpu_verifier_wait(self.h, ticket, bm))
+        return bm.raw[: (batch + 7) // 8]
+
     def block(self, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None) -> TxBlock:
         return TxBlock(self, txs, r_bytes)
 
