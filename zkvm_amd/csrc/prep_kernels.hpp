@@ -38,7 +38,7 @@ struct PrepShape {
   uint32_t chunk_tgt[6];
 };
 
-constexpr uint32_t PREP_STRIDES = 48;   // z^(2^L) [0..15] | y^-(2^L) [16..31] | u_j^2 [32..47]
+constexpr uint32_t PREP_STRIDES = 56;   // z^(2^L) [0..15] | y^(2^L) [16..31] | u_j^2 [32..47] | x^2..x^6, r x^2 [48..53] (k_prepare's own)
 
 __device__ __forceinline__ void ld_scm(scm& s, const uint32_t* p) {
 #pragma unroll
@@ -501,15 +501,38 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   __syncthreads();
   if (t < 8) zpow[t] = zs[t];
   __syncthreads();
-  // phase B: zpow[q] = z^(q+1) by doubling
+  // phase B: zpow[q] = z^(q+1) by doubling.  Its first steps keep a handful of lanes busy: two lanes of the last
+  // wavefront use them for the powers of x the proof-point scalars need (xp[0..4] = x^2..x^6, xp[5] = r x^2):
+  //   step 0: x^2 | step 1: x^3, x^4 | step 2: x^5, x^6 -- and r x^2 on the second lane in step 1
+  uint32_t* xp = us2 + 16 * 8;
 #pragma unroll 1
-  for (uint32_t L = 0, half = 1; half < sh.n_cons; ++L, half <<= 1) {
-    const uint32_t end = min(2 * half, sh.n_cons);
+  for (uint32_t L = 0, half = 1; half < sh.n_cons || L < 3; ++L, half <<= 1) {
+    const uint32_t end = half < sh.n_cons ? min(2 * half, sh.n_cons) : 0;
     for (uint32_t q = half + t; q < end; q += nt) {
       scm a, b;
       ld_scm(a, zpow + 8 * (q - half));
       ld_scm(b, zs + 8 * L);
       st_scm(zpow + 8 * q, scm_mul(a, b));
+    }
+    if (L < 3 && t >= nt - 2) {
+      const bool second = t == nt - 1;
+      scm a, b;
+      // first lane: x*x | x^2*x | x^4*x        second lane: - | x^2*x^2, then r*x^2 needs another round: done in step 2 | x^4*x^2
+      if (L == 0) { ld_scm(a, chs + 3 * 8); b = a; if (!second) st_scm(xp + 0 * 8, scm_mul(a, b)); }
+      else if (L == 1) {
+        ld_scm(a, xp + 0 * 8);
+        if (second) b = a; else ld_scm(b, chs + 3 * 8);
+        st_scm(xp + (second ? 2 : 1) * 8, scm_mul(a, b));             // x^4 | x^3
+      } else {
+        ld_scm(a, xp + 2 * 8);
+        if (second) ld_scm(b, xp + 0 * 8); else ld_scm(b, chs + 3 * 8);
+        st_scm(xp + (second ? 4 : 3) * 8, scm_mul(a, b));             // x^6 | x^5
+      }
+    }
+    if (L == 2 && t == nt - 3) {                                       // r x^2
+      scm a, b;
+      ld_scm(a, chs + 7 * 8); ld_scm(b, xp + 0 * 8);
+      st_scm(xp + 5 * 8, scm_mul(a, b));
     }
     __syncthreads();
   }
@@ -622,27 +645,97 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     }
     __syncthreads();
   }
-  scm x, u, r, a_, b_, w_, t_x, t_x_bl, e_bl, U, rhoY_plain, cp_plain, cp;
-  const scm dsum = scm_from_words(red);          // plain sum -> Montgomery
-  ld_scm(u, chs + 2 * 8); ld_scm(x, chs + 3 * 8); ld_scm(w_, chs + 4 * 8); ld_scm(U, chs + 6 * 8); ld_scm(r, chs + 7 * 8);
-  ld_scm(t_x, chs + 8 * 8); ld_scm(t_x_bl, chs + 9 * 8); ld_scm(e_bl, chs + 10 * 8);
-  ld_scm(a_, chs + 11 * 8); ld_scm(b_, chs + 12 * 8);
+  scm x, u, r, U, rhoY_plain, cp_plain, cp;
+  ld_scm(u, chs + 2 * 8); ld_scm(x, chs + 3 * 8); ld_scm(U, chs + 6 * 8); ld_scm(r, chs + 7 * 8);
   ld_scm(rhoY_plain, yip + 8 * (sh.pn - 1));     // rho y^(pn-1), plain
   cp_plain = scm_mul(U, rhoY_plain);             // c', plain
-  cp = scm_from_words(cp_plain.v);               // c', Montgomery
-  const scm xx = scm_sq(x), xxx = scm_mul(xx, x), rxx = scm_mul(r, xx);
   uint32_t* ds = dyn_scalars + (uint64_t)tx * sh.n_dyn * 8;
   uint32_t* dr = dyn_recoded + (uint64_t)tx * sh.n_dyn * 8;
   uint32_t* ss = static_scalars + (uint64_t)tx * sh.n_static * 8;
-  const uint32_t* p = pw + (uint64_t)tx * sh.proof_words;
-  const uint32_t* c = com + (uint64_t)tx * sh.m * 8;
-  const uint32_t* lr = p + 112;
+  // ---- proof-point scalars, B and B_blinding: the last wavefront, BEFORE its share of the generator scalars, so that
+  // this short serial tail runs beside the other wavefronts' generator loop instead of after it.  Every lane does the
+  // same three rounds v = a * b with operands of its own (a lane that needs fewer rounds passes its value through);
+  // the scalar of B is spread over four lanes: with c' delta = U dsum,
+  //     c' (w (t_x - a b) + r (x^2 (wc + delta) - t_x))  =  c' w (t_x - [a b])  +  r (x^2 ([c' wc] + [U dsum]) - [c' t_x])
+  // lane jB: a b, then w (t_x - .), then c' (.);  jB+1: c' wc, then x^2 (. + U dsum), then r (. - c' t_x);
+  // jB+2: U dsum;  jB+3: c' t_x;  the partial results travel by wavefront shuffles.  The factor c' of everything else
+  // rides on the final Montgomery -> canonical conversion (a product with the plain c' instead of with 1).
+  const uint32_t tail0 = nt - 64;
+  if (t >= tail0) {
+    const uint32_t lane = t - tail0, n_dyn = sh.n_dyn;
+    const scm dsum = scm_from_words(red);         // plain sum -> Montgomery
+    cp = scm_from_words(cp_plain.v);              // c', Montgomery
+    // positions: 0 B (a b ..), 1 B's second half (c' wc ..), 2 U dsum, 3 c' t_x, 4 B_blinding, 5 + j the proof point j
+#pragma unroll 1
+    for (uint32_t pos0 = 0; pos0 < n_dyn + 5; pos0 += 64) {
+      const uint32_t pos = pos0 + lane;
+      const uint32_t j = pos - 5;                 // proof-point index when pos >= 5
+      scm a = scm_one(), b = scm_one(), v = scm_one(), conv_by = cp_plain;
+      bool m1 = false;                            // does round 1 multiply?
+      if (pos == 0) { ld_scm(a, chs + 11 * 8); ld_scm(b, chs + 12 * 8); m1 = true; }                        // a b
+      else if (pos == 1) { a = cp; ld_scm(b, wc); m1 = true; }                                              // c' wc
+      else if (pos == 2) { a = U; b = dsum; m1 = true; }                                                    // U dsum
+      else if (pos == 3) { a = cp; ld_scm(b, chs + 8 * 8); m1 = true; }                                     // c' t_x
+      else if (pos == 4) { a = r; ld_scm(b, chs + 9 * 8); m1 = true; }                                      // r t_x_blinding
+      else if (j < 3) { if (j == 0) v = x; else ld_scm(v, xp + (j - 1) * 8); }                              // x, x^2, x^3
+      else if (j < 6) { if (j == 3) a = x; else ld_scm(a, xp + (j - 4) * 8); b = u; m1 = true; }            // u x^(1..3)
+      else if (j < 6 + sh.m) { ld_scm(a, wV + 8 * (j - 6)); ld_scm(b, xp + 5 * 8); m1 = true; }             // wV_j r x^2
+      else if (j < 11 + sh.m) {                                                                             // r x, r x^3 .. r x^6
+        const uint32_t q = j - 6 - sh.m;
+        if (q == 0) a = x; else ld_scm(a, xp + q * 8);
+        b = r; m1 = true;
+      } else if (j < n_dyn) {
+        const uint32_t q = j - 11 - sh.m;         // u_j^2 for L_j; for R_j  c' u_j^-2 = rho Y prod_{l != j} u_l^2
+        if (q < sh.k) { ld_scm(a, chs + (CH_FIXED + sh.n_chal2 + q) * 8); b = a; m1 = true; }
+        else { ld_scm(v, chs + (CH_FIXED + sh.n_chal2 + sh.k + (q - sh.k)) * 8); conv_by = rhoY_plain; }
+      }
+      {
+        const scm pr = scm_mul(a, b);
+        if (m1) v = pr;
+      }
+      if (pos0 == 0) {                            // rounds 2 and 3: the scalars of B and B_blinding (first pass only, lanes 0..4)
+        scm other;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) other.v[q] = (uint32_t)__shfl_down((int)v.v[q], 1);
+        bool m2 = false;
+        if (pos == 0) { scm tx_; ld_scm(tx_, chs + 8 * 8); ld_scm(a, chs + 4 * 8); b = scm_sub(tx_, v); m2 = true; }       // w (t_x - a b)
+        else if (pos == 1) { ld_scm(a, xp + 0 * 8); b = scm_add(v, other); m2 = true; }                                    // x^2 (c' wc + U dsum)
+        else if (pos == 4) { scm e; ld_scm(e, chs + 10 * 8); v = scm_neg(scm_add(e, v)); }                                 // -(e_blinding + r t_x_blinding)
+        const scm pr2 = scm_mul(a, b);
+        if (m2) v = pr2;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) other.v[q] = (uint32_t)__shfl_down((int)v.v[q], 2);
+        bool m3 = false;
+        if (pos == 0) { a = cp; b = v; m3 = true; }                                                                        // c' w (t_x - a b)
+        else if (pos == 1) { a = r; b = scm_sub(v, other); m3 = true; }                                                    // r (x^2 (..) - c' t_x)
+        const scm pr3 = scm_mul(a, b);
+        if (m3) v = pr3;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) other.v[q] = (uint32_t)__shfl_down((int)v.v[q], 1);
+        if (pos == 0) { v = scm_add(v, other); conv_by = scm_zero(); conv_by.v[0] = 1; }
+      }
+      const scm conv = scm_mul(v, conv_by);       // Montgomery -> canonical words, times the plain factor
+      const uint32_t* o = conv.v;
+      if (pos >= 5 && j < n_dyn) {
+        // the scalar, and its recoded form s + 0x88..8 for k_small_accumulate (digit t = nibble t - 8)
+        uint32_t carry = 0;
+        for (int q = 0; q < 8; ++q) {
+          ds[j * 8 + q] = o[q];
+          const uint64_t vv = (uint64_t)o[q] + 0x88888888u + carry;
+          dr[j * 8 + q] = (uint32_t)vv;
+          carry = (uint32_t)(vv >> 32);
+        }
+      } else if (pos == 0 || pos == 4) {
+        for (int q = 0; q < 8; ++q) ss[(pos == 0 ? 0 : 1) * 8 + q] = o[q];
+      }
+    }
+  }
   // generator scalars (times c'), canonical words straight out of the products:
   //   c' g_i = (x U) wR_i yp[pn-1-i] - (a P1 rho Y) sU_i
   //   c' h_i = yp[pn-1-i] ((x U) wL_i + U wO_i - (b P1) sU_(pn-1-i)) - c'        (times u for i >= n1)
   {
-    scm P1;
-    ld_scm(P1, chs + 5 * 8);
+    scm P1, a_, b_;
+    ld_scm(P1, chs + 5 * 8); ld_scm(a_, chs + 11 * 8); ld_scm(b_, chs + 12 * 8);
     const scm xU = scm_mul(x, U);
     const scm aY_plain = scm_mul(scm_mul(a_, P1), rhoY_plain);
     const scm bP = scm_mul(b_, P1);
@@ -663,66 +756,6 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
       uint4* oh = reinterpret_cast<uint4*>(ss + (2 + sh.pn + i) * 8);
       og[0] = make_uint4(g.v[0], g.v[1], g.v[2], g.v[3]); og[1] = make_uint4(g.v[4], g.v[5], g.v[6], g.v[7]);
       oh[0] = make_uint4(h.v[0], h.v[1], h.v[2], h.v[3]); oh[1] = make_uint4(h.v[4], h.v[5], h.v[6], h.v[7]);
-    }
-  }
-  // proof-point scalars (and B, B_blinding), one lane each; the factor c' rides on the final
-  // Montgomery -> canonical conversion (a product with the plain c' instead of with 1)
-  if (t < sh.n_dyn + 2) {
-    scm v;
-    scm conv_by = cp_plain;
-    const uint32_t* pt = nullptr;
-    const uint32_t j = t;
-    if (j < 6) {
-      const scm base = (j % 3 == 0) ? x : (j % 3 == 1 ? xx : xxx);
-      v = j < 3 ? base : scm_mul(u, base);
-      pt = p + 8 * j;
-    } else if (j < 6 + sh.m) {
-      scm wvj; ld_scm(wvj, wV + 8 * (j - 6));
-      v = scm_mul(wvj, rxx);
-      pt = c + 8 * (j - 6);
-    } else if (j < 6 + sh.m + 5) {
-      const uint32_t q = j - 6 - sh.m;      // T_1 T_3 T_4 T_5 T_6 -> r x, r x^3, r x^4, r x^5, r x^6
-      const scm rx = scm_mul(r, x);
-      v = rx;
-      const uint32_t reps = q == 0 ? 0 : q + 1;
-      for (uint32_t e = 0; e < reps; ++e) v = scm_mul(v, x);
-      pt = p + 8 * (6 + q);
-    } else if (j < sh.n_dyn) {
-      const uint32_t q = j - 6 - sh.m - 5;  // u_j^2 for L_j; u_j^-2 for R_j, i.e. c' u_j^-2 = rho Y prod_{l != j} u_l^2
-      if (q < sh.k) {
-        scm f;
-        ld_scm(f, chs + (CH_FIXED + sh.n_chal2 + q) * 8);
-        v = scm_sq(f);
-        pt = lr + 16 * q;
-      } else {
-        ld_scm(v, chs + (CH_FIXED + sh.n_chal2 + sh.k + (q - sh.k)) * 8);
-        conv_by = rhoY_plain;
-        pt = lr + 16 * (q - sh.k) + 8;
-      }
-    } else if (j == sh.n_dyn) {             // B: c' (w (t_x - a b) + r (xx (wc + delta) - t_x)), with c' delta = U dsum
-      scm wcv; ld_scm(wcv, wc);
-      const scm t1 = scm_mul(cp, scm_mul(w_, scm_sub(t_x, scm_mul(a_, b_))));
-      const scm t2 = scm_mul(r, scm_sub(scm_mul(xx, scm_add(scm_mul(cp, wcv), scm_mul(U, dsum))), scm_mul(cp, t_x)));
-      v = scm_add(t1, t2);
-      conv_by = scm_zero();
-      conv_by.v[0] = 1;
-    } else {                                // B_blinding: -(e_blinding + r t_x_blinding)
-      v = scm_neg(scm_add(e_bl, scm_mul(r, t_x_bl)));
-    }
-    const scm conv = scm_mul(v, conv_by);   // Montgomery -> canonical words, times the plain factor
-    const uint32_t* o = conv.v;
-    if (j < sh.n_dyn) {
-      // the scalar, and its recoded form s + 0x88..8 for k_small_accumulate (digit t = nibble t - 8)
-      uint32_t carry = 0;
-      for (int q = 0; q < 8; ++q) {
-        ds[j * 8 + q] = o[q];
-        const uint64_t v = (uint64_t)o[q] + 0x88888888u + carry;
-        dr[j * 8 + q] = (uint32_t)v;
-        carry = (uint32_t)(v >> 32);
-      }
-      (void)pt;
-    } else {
-      for (int q = 0; q < 8; ++q) ss[(j - sh.n_dyn) * 8 + q] = o[q];
     }
   }
 }
