@@ -530,7 +530,7 @@ int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap, uint8_t* 
   TRY(ensure_pinned(c, nbytes + 64 + (values ? 32 * B : 0)));
   if (values) TRY(ensure(c, c->values, 32 * B));
   {
-    Launch l(c, "k_msm_finish");
+    Launch l(c, "k_msm_finish_quad");
     hipLaunchKernelGGL(k_msm_finish_quad, dim3(blocks_for(4 * B, 256)), dim3(256), 0, c->stream,
                        (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p,
                        (const uint32_t*)c->msm_fail.p, (uint8_t*)c->accept.p,
@@ -639,7 +639,7 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
     } else {
       TRY(run_to_windows(c, dj, jd, /*reset_status=*/false));
     }
-    Launch l(c, "k_msm_finish");
+    Launch l(c, "k_msm_finish_quad");
     hipLaunchKernelGGL(k_msm_finish_quad, dim3(blocks_for(4 * B, 256)), dim3(256), 0, s,
                        (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p,
                        (const uint32_t*)c->msm_fail.p, (uint8_t*)c->accept.p, (uint32_t*)nullptr,
@@ -880,7 +880,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   HIP_TRY(c, hipEventRecord(c->ev_sm, H1));
   HIP_TRY(c, hipStreamWaitEvent(L, c->ev_sm, 0));
   {
-    Launch l(c, "k_msm_finish", L);
+    Launch l(c, "k_msm_finish_quad", L);
     hipLaunchKernelGGL(k_msm_finish_quad, dim3(blocks_for(4 * B, 256)), dim3(256), 0, L,
                        (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p,
                        (const uint32_t*)c->msm_fail.p, (uint8_t*)c->accept.p, (uint32_t*)nullptr,
@@ -941,7 +941,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
                          (uint32_t*)c->rechk_pts.p);
     }
     {
-      Launch l(c, "k_pack_bitmap", L);          // with the verdict of the located groups' other transactions: S1 - E_b
+      Launch l(c, "k_pack_bitmap_groups", L);   // with the verdict of the located groups' other transactions: S1 - E_b
       hipLaunchKernelGGL(k_pack_bitmap_groups, dim3(blocks_for(nbytes, 256)), dim3(256), 0, L, (const uint8_t*)c->accept2.p,
                          job.d_wellformed, (const uint32_t*)c->msm_fail.p, (uint8_t*)c->bitmap.p, (uint32_t)B, group,
                          (const uint32_t*)grp_state, (const uint32_t*)c->grp_fail_sum.p, (const uint32_t*)cand,
