@@ -286,9 +286,9 @@ long long zkgpu_debug_force_regroup(zkgpu_ctx* ctx, int on);
 int zkgpu_set_locate_mode(zkgpu_ctx* ctx, int mode);
 
 /* Transcript replay of the whole-proof paths: 0 automatic (default: one WAVEFRONT per transaction --
- * Keccak-f with the state spread over the lanes, keccak_coop.hpp -- for batches of up to 4096
+ * Keccak-f with the state spread over the lanes, keccak_coop.hpp -- for batches of up to 1536
  * transactions, where it shortens the batch's dependent chain; one LANE per transaction beyond, where
- * throughput matters and latency is hidden), 1 always one lane, 2 always one wavefront.  Results are
+ * the 17x wave-instructions of the spread form cost more than the shorter chain saves), 1 always one lane, 2 always one wavefront.  Results are
  * identical.  Forks inherit the setting.
  * zkgpu_debug_coop_selftest: test hook -- the cross-lane primitives of the cooperative Keccak on given
  * inputs (in: 3 x 64 words a, b, gather byte addresses; out: 8 x 64 words: row_ror:8(a), row_shr:1(a),
