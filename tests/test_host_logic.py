@@ -179,6 +179,16 @@ def test_product_prover_equals_oracle_prover(host, oracle, shape, cap):
         assert oracle.cloak_verify(com.raw, n_in, n_out, proof.raw[: plen.value], bytes(range(64)))
 
 
+def test_lazy_scalar_form_equals_canonical(host):
+    """sc_dev.hpp: the lazy ten-limb form k_prepare computes in (scl: products without packing or conditional
+    subtraction, limb-wise sums and differences, one exact reduction at the end) against the canonical Montgomery
+    form on random chains of operations, including the edge values 0 and l - 1."""
+    host.zkhost_scl_selftest.restype = C.c_uint64
+    host.zkhost_scl_selftest.argtypes = [C.c_uint64, C.c_uint32]
+    for seed in (1, 0x5a6b564d, 2 ** 63 + 12345):
+        assert host.zkhost_scl_selftest(seed, 1500) == 0
+
+
 def test_cooperative_keccak_emulation_equals_keccak(host, oracle):
     """keccak_coop.hpp -- one Keccak state spread over a wavefront (DPP row shifts, row swaps, ds_bpermute),
     run on the host with emulated cross-lane primitives -- against the oracle's Keccak-f[1600]."""

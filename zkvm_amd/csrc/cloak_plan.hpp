@@ -55,6 +55,11 @@ struct CloakPlan {
   std::vector<uint32_t> tgt_off;              // 3n + m + 1 targets (+1): wL | wR | wO | wV | wc
   std::vector<uint32_t> term_q, term_mono;
   std::vector<uint32_t> term_coef;            // 8 words per term, Montgomery form, sign folded in
+  // the same terms as k_prepare replays them: a UNIT term (coefficient +-1, no challenge) is read straight from the z
+  // power table -- term_info = 0x80000000 | sign << 30 | q --, every other term is a product computed in a pass of its
+  // own -- term_info = index into the product list (q, monomial, coefficient as ten 26-bit limbs, Montgomery form)
+  std::vector<uint32_t> term_info, prod_q, prod_mono, prod_coef;
+  std::vector<uint32_t> prod_off;             // per target: products before it (n_targets + 1)
   uint32_t n_targets() const { return 3 * n + m + 1; }
 };
 
@@ -109,8 +114,21 @@ inline CloakPlan plan_from_desc(const R1csDesc& d) {
       for (int i = 0; i < 8; ++i) w[i] = (uint32_t)bytes[4 * i] | ((uint32_t)bytes[4 * i + 1] << 8) | ((uint32_t)bytes[4 * i + 2] << 16) | ((uint32_t)bytes[4 * i + 3] << 24);
       const scm mc = scm_from_words(w);
       for (int i = 0; i < 8; ++i) p.term_coef.push_back(mc.v[i]);
+      const bool plus = tm.c == Scalar::one(), minus = tm.c == -Scalar::one();
+      if (tm.mono == 0 && (plus || minus)) {
+        p.term_info.push_back(0x80000000u | (minus ? 0x40000000u : 0u) | tm.q);
+      } else {
+        p.term_info.push_back((uint32_t)p.prod_q.size());
+        p.prod_q.push_back(tm.q);
+        p.prod_mono.push_back(tm.mono);
+        const scl lc = scl_from_scm(mc);
+        for (int i = 0; i < 10; ++i) p.prod_coef.push_back(lc.v[i]);
+      }
     }
+    if (t == 0) p.prod_off.push_back(0);
+    p.prod_off.push_back((uint32_t)p.prod_q.size());
   }
+  if (p.n_cons >= (1u << 24) || p.prod_q.size() >= (1u << 24)) throw std::runtime_error("r1cs plan: too many constraints");
   return p;
 }
 

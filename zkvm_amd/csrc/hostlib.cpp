@@ -99,6 +99,63 @@ int zkhost_r1cs_prepare(const char* label, uint32_t m, uint32_t n1, uint32_t n, 
 }
 
 // Keccak-f[1600] through the emulated wavefront of keccak_coop.hpp (the algorithm k_transcript_coop runs)
+// The lazy scalar form of sc_dev.hpp (scl) against the canonical one (scm) on pseudo-random chains of operations:
+// returns the number of mismatches (tests/test_host_logic.py expects 0).
+uint64_t zkhost_scl_selftest(uint64_t seed, uint32_t rounds) {
+  uint64_t st = seed ? seed : 1, bad = 0;
+  auto rnd = [&st]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 16); };
+  auto rnd_scm = [&]() {
+    uint32_t w[16];
+    for (auto& x : w) x = rnd();
+    return scm_from_wide(w);
+  };
+  auto same = [](const scm& a, const scl& b) {
+    uint32_t w[8];
+    scl_canon_words(w, b);
+    bool ok = true;
+    for (int i = 0; i < 8; ++i) ok &= w[i] == a.v[i];
+    return ok;
+  };
+  for (uint32_t r = 0; r < rounds; ++r) {
+    scm a = rnd_scm(), b = rnd_scm(), c = rnd_scm();
+    if (r == 0) { a = scm_zero(); }
+    if (r == 1) { b = scm_neg(scm_one()); c = b; a = b; }
+    const scl la = scl_from_scm(a), lb = scl_from_scm(b), lc = scl_from_scm(c);
+    if (!same(scm_mul(a, b), scl_mul(la, lb))) ++bad;
+    if (!same(scm_add(a, b), scl_add(la, lb))) ++bad;
+    if (!same(scm_sub(a, b), scl_sub(la, lb))) ++bad;
+    if (!same(scm_neg(a), scl_neg(la))) ++bad;
+    // (a - b) (c - a) + sum of 16 products - b, everything lazy
+    scm acc = scm_mul(scm_sub(a, b), scm_sub(c, a));
+    scl lacc = scl_mul(scl_sub(la, lb), scl_sub(lc, la));
+    scm x = a; scl lx = la;
+    for (int i = 0; i < 16; ++i) {
+      x = scm_mul(x, c); lx = scl_mul(lx, lc);
+      const bool neg = rnd() & 1;
+      acc = neg ? scm_sub(acc, x) : scm_add(acc, x);
+      lacc = scl_add(lacc, scl_cneg(lx, neg));
+    }
+    acc = scm_sub(acc, b); lacc = scl_sub(lacc, lb);
+    if (!same(acc, lacc)) ++bad;
+    if (!same(acc, scl_weak(lacc))) ++bad;
+    if (!same(scm_mul(acc, a), scl_mul(lacc, la))) ++bad;
+    // plain <-> Montgomery
+    uint32_t plain[8];
+    scm_to_words(plain, a);
+    const scl lp = scl_mul(la, scl_plain_one());
+    uint32_t w[8];
+    scl_canon_words(w, lp);
+    for (int i = 0; i < 8; ++i) if (w[i] != plain[i]) { ++bad; break; }
+    if (!same(a, scl_mul(lp, scl_r2()))) ++bad;
+    if (!same(scm_one(), scl_one())) ++bad;
+    // wave-tree shape: 64 values added with a carry after each doubling
+    scl tree = lx; scm stree = x;
+    for (int i = 0; i < 6; ++i) { tree = scl_add_c(tree, tree); stree = scm_add(stree, stree); }
+    if (!same(stree, tree)) ++bad;
+  }
+  return bad;
+}
+
 void zkhost_keccak_coop(uint64_t state[25]) { coop::keccak_f1600_emulated(state); }
 
 // The cooperative form of the transcript on the host: the tape regrouped into segments

@@ -36,6 +36,7 @@ struct PrepShape {
   // per-term products of one pass fit tv_cap LDS slots
   uint32_t n_chunks, tv_cap;
   uint32_t chunk_tgt[6];
+  uint32_t chunk_prod[6];   // first product of each pass (products are stored in target order)
 };
 
 constexpr uint32_t PREP_STRIDES = 56;   // z^(2^L) [0..15] | y^(2^L) [16..31] | u_j^2 [32..47] | x^2..x^6, r x^2 [48..53] (k_prepare's own)
@@ -464,122 +465,173 @@ k_challenges(PrepShape sh, const uint32_t* __restrict__ raw /*[B][n_ch][16]*/, c
 }
 
 // ---- k_prepare ------------------------------------------------------------------------------
-// LDS (8-word slots): chs[n_ch] | sym[n_mono] | strides[PREP_STRIDES] (these three straight from
-// k_transcript) | wv[n_targets] | region A: zpow[n_cons] tv[tv_cap + 32], and once the flattening is
+// Scalars live in the lazy limb form of sc_dev.hpp (scl: ten 26-bit limbs, 40-byte slots) from the moment the
+// challenge slots are copied into LDS until the canonical words are written out: a product is the multiply-adds and
+// one carry pass, sums and differences are limb-wise (bounds in the comments where they matter).
+// LDS (10-word slots): chs[n_ch] | sym[n_mono] | strides[PREP_STRIDES] (these three converted from k_transcript's
+// 8-word Montgomery slots) | wv[n_targets] | region A: zpow[n_cons] tv[tv_cap + 32], and once the flattening is
 // done yip[pn] sv[pn] red[8] in its place.
 //
 // Power tables are built by doubling (entry q + 2^L = entry q * stride_L, one product per entry)
 // instead of one square-and-multiply per entry, and y^-i is kept in PLAIN form: a Montgomery
 // product with one plain operand yields a plain result, so the generator scalars come out as
-// canonical words without a conversion product of their own.
+// plain values without a conversion product of their own.
+//
+// Flattening (plan replay): a term of target g is either a UNIT term, +- z^(q+1) read straight from the power table
+// (three quarters of a cloak's terms), or a product const * monomial * z^(q+1) computed in a pass of its own into tv.
+constexpr uint32_t SCL_WORDS = 10;
+constexpr uint32_t TERM_UNIT = 0x80000000u, TERM_NEG = 0x40000000u, TERM_IDX = 0x00ffffffu;
+constexpr uint32_t HEAVY_TERMS = 16;      // lazy sums are reduced every so many terms; targets with more are summed by the whole workgroup
+
 __host__ __device__ inline size_t prepare_lds_slots(const PrepShape& sh) {
   const size_t first = (size_t)sh.n_cons + sh.tv_cap + 32, second = (size_t)2 * sh.pn + 8;
   return (size_t)sh.n_ch_ext + sh.n_targets + (first > second ? first : second);
 }
 
+__device__ __forceinline__ void ld_scl(scl& s, const uint32_t* p) {
+  const uint2* q = reinterpret_cast<const uint2*>(p);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { const uint2 w = q[i]; s.v[2 * i] = w.x; s.v[2 * i + 1] = w.y; }
+}
+__device__ __forceinline__ void st_scl(uint32_t* p, const scl& s) {
+  uint2* q = reinterpret_cast<uint2*>(p);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) q[i] = make_uint2(s.v[2 * i], s.v[2 * i + 1]);
+}
+__device__ __forceinline__ scl shfl_down_scl(const scl& a, int delta) {
+  scl o;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) o.v[q] = (uint32_t)__shfl_down((int)a.v[q], delta);
+  return o;
+}
+// sum over the wavefront, in lane 0: inputs tight and < 2^255 -> tight, < 2^261
+__device__ __forceinline__ scl wave_sum_scl(scl part) {
+#pragma unroll 1
+  for (int delta = 32; delta >= 1; delta >>= 1) part = scl_add_c(part, shfl_down_scl(part, delta));
+  return part;
+}
+
 __global__ void __launch_bounds__(256)
 k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* __restrict__ mono_pow,
-          const uint32_t* __restrict__ tgt_off, const uint32_t* __restrict__ term_q,
-          const uint32_t* __restrict__ term_mono, const uint32_t* __restrict__ term_coef,
+          const uint32_t* __restrict__ tgt_off, const uint32_t* __restrict__ term_info,
+          const uint2* __restrict__ prod_qm, const uint32_t* __restrict__ prod_coef,
           const uint32_t* __restrict__ ch, const uint32_t* __restrict__ com, const uint32_t* __restrict__ pw,
           uint32_t* __restrict__ dyn_scalars, uint32_t* __restrict__ dyn_recoded, uint32_t* __restrict__ static_scalars) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  constexpr uint32_t SW = SCL_WORDS;
   uint32_t* chs = lds;
-  uint32_t* sym = chs + sh.n_ch * 8;
-  uint32_t* zs = sym + sh.n_mono * 8;           // z^(2^L)
-  uint32_t* ys = zs + 16 * 8;                    // y^-(2^L)
-  uint32_t* us2 = ys + 16 * 8;                   // u_j^2
-  uint32_t* wv = chs + sh.n_ch_ext * 8;
-  uint32_t* zpow = wv + sh.n_targets * 8;        // region A, first life
-  uint32_t* tv = zpow + sh.n_cons * 8;
+  uint32_t* sym = chs + sh.n_ch * SW;
+  uint32_t* zs = sym + sh.n_mono * SW;          // z^(2^L)
+  uint32_t* ys = zs + 16 * SW;                   // y^-(2^L)
+  uint32_t* us2 = ys + 16 * SW;                  // u_j^2
+  uint32_t* wv = chs + sh.n_ch_ext * SW;
+  uint32_t* zpow = wv + sh.n_targets * SW;       // region A, first life
+  uint32_t* tv = zpow + sh.n_cons * SW;
   uint32_t* yip = zpow;                          // region A, second life
-  uint32_t* sv = yip + sh.pn * 8;
-  uint32_t* red = sv + sh.pn * 8;
+  uint32_t* sv = yip + sh.pn * SW;
+  uint32_t* red = sv + sh.pn * SW;
   const uint32_t tx = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
 
-  for (uint32_t i = t; i < sh.n_ch_ext * 8; i += nt) chs[i] = ch[(uint64_t)tx * sh.n_ch_ext * 8 + i];
+  // the transaction's slots (canonical Montgomery words) -> limb form
+  for (uint32_t i = t; i < sh.n_ch_ext; i += nt) {
+    const uint4* src = reinterpret_cast<const uint4*>(ch + ((uint64_t)tx * sh.n_ch_ext + i) * 8);
+    const uint4 a = src[0], b = src[1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    st_scl(chs + i * SW, scl_from_words(w));
+  }
   __syncthreads();
-  if (t < 8) zpow[t] = zs[t];
+  if (t < SW) zpow[t] = zs[t];
   __syncthreads();
   // phase B: zpow[q] = z^(q+1) by doubling.  Its first steps keep a handful of lanes busy: two lanes of the last
   // wavefront use them for the powers of x the proof-point scalars need (xp[0..4] = x^2..x^6, xp[5] = r x^2):
   //   step 0: x^2 | step 1: x^3, x^4 | step 2: x^5, x^6 -- and r x^2 on the second lane in step 1
-  uint32_t* xp = us2 + 16 * 8;
+  uint32_t* xp = us2 + 16 * SW;
 #pragma unroll 1
   for (uint32_t L = 0, half = 1; half < sh.n_cons || L < 3; ++L, half <<= 1) {
     const uint32_t end = half < sh.n_cons ? min(2 * half, sh.n_cons) : 0;
     for (uint32_t q = half + t; q < end; q += nt) {
-      scm a, b;
-      ld_scm(a, zpow + 8 * (q - half));
-      ld_scm(b, zs + 8 * L);
-      st_scm(zpow + 8 * q, scm_mul(a, b));
+      scl a, b;
+      ld_scl(a, zpow + SW * (q - half));
+      ld_scl(b, zs + SW * L);
+      st_scl(zpow + SW * q, scl_mul(a, b));
     }
     if (L < 3 && t >= nt - 2) {
       const bool second = t == nt - 1;
-      scm a, b;
-      // first lane: x*x | x^2*x | x^4*x        second lane: - | x^2*x^2, then r*x^2 needs another round: done in step 2 | x^4*x^2
-      if (L == 0) { ld_scm(a, chs + 3 * 8); b = a; if (!second) st_scm(xp + 0 * 8, scm_mul(a, b)); }
+      scl a, b;
+      // first lane: x*x | x^2*x | x^4*x        second lane: - | x^2*x^2 | x^4*x^2
+      if (L == 0) { ld_scl(a, chs + 3 * SW); b = a; if (!second) st_scl(xp + 0 * SW, scl_mul(a, b)); }
       else if (L == 1) {
-        ld_scm(a, xp + 0 * 8);
-        if (second) b = a; else ld_scm(b, chs + 3 * 8);
-        st_scm(xp + (second ? 2 : 1) * 8, scm_mul(a, b));             // x^4 | x^3
+        ld_scl(a, xp + 0 * SW);
+        if (second) b = a; else ld_scl(b, chs + 3 * SW);
+        st_scl(xp + (second ? 2 : 1) * SW, scl_mul(a, b));             // x^4 | x^3
       } else {
-        ld_scm(a, xp + 2 * 8);
-        if (second) ld_scm(b, xp + 0 * 8); else ld_scm(b, chs + 3 * 8);
-        st_scm(xp + (second ? 4 : 3) * 8, scm_mul(a, b));             // x^6 | x^5
+        ld_scl(a, xp + 2 * SW);
+        if (second) ld_scl(b, xp + 0 * SW); else ld_scl(b, chs + 3 * SW);
+        st_scl(xp + (second ? 4 : 3) * SW, scl_mul(a, b));             // x^6 | x^5
       }
     }
     if (L == 2 && t == nt - 3) {                                       // r x^2
-      scm a, b;
-      ld_scm(a, chs + 7 * 8); ld_scm(b, xp + 0 * 8);
-      st_scm(xp + 5 * 8, scm_mul(a, b));
+      scl a, b;
+      ld_scl(a, chs + 7 * SW); ld_scl(b, xp + 0 * SW);
+      st_scl(xp + 5 * SW, scl_mul(a, b));
     }
     __syncthreads();
   }
-  // phase C: plan replay, a range of targets at a time: one product per term (two when a second-phase
-  // challenge is involved), then one sum per target
+  // phase C: plan replay, a range of targets at a time: the products of the range (one multiplication per product, two
+  // when a second-phase challenge is involved), then one sum per target.  Every stored value is a product (< 2^255) or
+  // a weakly reduced sum (< 2 l).
 #pragma unroll 1
   for (uint32_t ck = 0; ck < sh.n_chunks; ++ck) {
     const uint32_t g0 = sh.chunk_tgt[ck], g1 = sh.chunk_tgt[ck + 1];
-    const uint32_t e0 = tgt_off[g0], e1 = tgt_off[g1];
-    for (uint32_t e = e0 + t; e < e1; e += nt) {
-      scm c, zq;
-      ld_scm(c, term_coef + 8 * (uint64_t)e);
-      ld_scm(zq, zpow + 8 * term_q[e]);
-      const uint32_t mi = term_mono[e];
-      if (mi != 0) { scm m; ld_scm(m, sym + 8 * mi); c = scm_mul(c, m); }
-      st_scm(tv + 8 * (e - e0), scm_mul(c, zq));
+    const uint32_t p0 = sh.chunk_prod[ck], p1 = sh.chunk_prod[ck + 1];
+    for (uint32_t p = p0 + t; p < p1; p += nt) {
+      scl c, zq;
+      ld_scl(c, prod_coef + SW * (uint64_t)p);
+      const uint2 qm = prod_qm[p];
+      ld_scl(zq, zpow + SW * qm.x);
+      if (qm.y != 0) { scl m; ld_scl(m, sym + SW * qm.y); c = scl_mul(c, m); }
+      st_scl(tv + SW * (p - p0), scl_mul(c, zq));
     }
     __syncthreads();
+    // <= HEAVY_TERMS terms, each < 2^255 or its negative (256 l - v, limbs < 2^27.6): limbs < 2^31.6, value < 2^264.1
+    auto term_value = [&](uint32_t e) {
+      const uint32_t info = term_info[e];
+      scl v;
+      if (info & TERM_UNIT) ld_scl(v, zpow + SW * (info & TERM_IDX));
+      else ld_scl(v, tv + SW * ((info & TERM_IDX) - p0));
+      return scl_cneg(v, (info & TERM_NEG) != 0);
+    };
     for (uint32_t g = g0 + t; g < g1; g += nt) {
       bool heavy = false;
       for (uint32_t hI = 0; hI < sh.n_heavy; ++hI) heavy |= (sh.heavy[hI] == g);
       if (heavy) continue;
-      scm acc = scm_zero();
-      for (uint32_t e = tgt_off[g]; e < tgt_off[g + 1]; ++e) { scm v; ld_scm(v, tv + 8 * (e - e0)); acc = scm_add(acc, v); }
-      st_scm(wv + 8 * g, acc);
+      scl acc = scl_zero();
+      uint32_t cnt = 0;
+      for (uint32_t e = tgt_off[g]; e < tgt_off[g + 1]; ++e) {
+        acc = scl_add(acc, term_value(e));
+        if (++cnt == HEAVY_TERMS) { acc = scl_weak(acc); cnt = 1; }
+      }
+      st_scl(wv + SW * g, scl_weak(acc));
     }
     // heavy targets: every lane sums a strided share, wavefront shuffles fold the lanes, lane 0 of
     // each wave parks its sum in the scratch slots after the products (4 per heavy target)
     for (uint32_t hI = 0; hI < sh.n_heavy; ++hI) {
       const uint32_t g = sh.heavy[hI];
       if (g < g0 || g >= g1) continue;
-      scm acc = scm_zero();
-      for (uint32_t e = tgt_off[g] + t; e < tgt_off[g + 1]; e += nt) { scm v; ld_scm(v, tv + 8 * (e - e0)); acc = scm_add(acc, v); }
-#pragma unroll 1
-      for (int delta = 32; delta >= 1; delta >>= 1) {
-        scm o;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) o.v[q] = __shfl_down(acc.v[q], delta);
-        acc = scm_add(acc, o);
+      scl acc = scl_zero();
+      uint32_t cnt = 0;
+      for (uint32_t e = tgt_off[g] + t; e < tgt_off[g + 1]; e += nt) {
+        acc = scl_add(acc, term_value(e));
+        if (++cnt == HEAVY_TERMS) { acc = scl_weak(acc); cnt = 1; }
       }
-      uint32_t* wave_sums = tv + (sh.tv_cap + 4 * hI) * 8;
-      if ((t & 63) == 0) st_scm(wave_sums + 8 * (t >> 6), acc);
+      acc = wave_sum_scl(scl_weak(acc));
+      uint32_t* wave_sums = tv + (sh.tv_cap + 4 * hI) * SW;
+      if ((t & 63) == 0) st_scl(wave_sums + SW * (t >> 6), acc);
       __syncthreads();
       if (t == 0) {
-        scm tot = scm_zero();
-        for (uint32_t wI = 0; wI < (nt >> 6); ++wI) { scm v; ld_scm(v, wave_sums + 8 * wI); tot = scm_add(tot, v); }
-        st_scm(wv + 8 * g, tot);
+        scl tot = scl_zero();
+        for (uint32_t wI = 0; wI < (nt >> 6); ++wI) { scl v; ld_scl(v, wave_sums + SW * wI); tot = scl_add(tot, v); }
+        st_scl(wv + SW * g, scl_weak(tot));
       }
     }
     __syncthreads();
@@ -589,66 +641,60 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   //     c' y^-i        = U * yp[pn-1-i]             yp[j] = rho y^j, kept in PLAIN form
   //     c' s_i         = yp[pn-1] * P1 * sU[i]      sU[i] = prod_j u_j^(2 bit_(k-1-j)(i)),  P1 = prod u_j
   //     c' y^-i s_r    = yp[pn-1-i] * P1 * sU[r]    (U s_i = prod u_j^(2 +- 1) = P1 sU[i])
-  // Both tables grow by doubling (entry + 2^L = entry * stride_L); a Montgomery product with one plain
-  // operand is plain, so the generator scalars come out as canonical words directly.
+  // Both tables grow by doubling (entry + 2^L = entry * stride_L).
   if (t == 0) {
-    scm rho, rho_plain;
-    ld_scm(rho, chs + 13 * 8);
-    scm_to_words(rho_plain.v, rho);
-    st_scm(yip, rho_plain);
-    st_scm(sv, scm_one());
+    scl rho;
+    ld_scl(rho, chs + 13 * SW);
+    st_scl(yip, scl_mul(rho, scl_plain_one()));
+    st_scl(sv, scl_one());
   }
   __syncthreads();
 #pragma unroll 1
   for (uint32_t L = 0, half = 1; half < sh.pn; ++L, half <<= 1) {
     for (uint32_t idx = t; idx < 2 * half; idx += nt) {
-      scm a, b;
+      scl a, b;
       if (idx < half) {
-        ld_scm(a, yip + 8 * idx);
-        ld_scm(b, ys + 8 * L);
-        st_scm(yip + 8 * (idx + half), scm_mul(a, b));
+        ld_scl(a, yip + SW * idx);
+        ld_scl(b, ys + SW * L);
+        st_scl(yip + SW * (idx + half), scl_mul(a, b));
       } else {
         const uint32_t i = idx - half;
-        ld_scm(a, sv + 8 * i);
-        ld_scm(b, us2 + 8 * (sh.k - 1 - L));
-        st_scm(sv + 8 * (i + half), scm_mul(a, b));
+        ld_scl(a, sv + SW * i);
+        ld_scl(b, us2 + SW * (sh.k - 1 - L));
+        st_scl(sv + SW * (i + half), scl_mul(a, b));
       }
     }
     __syncthreads();
   }
   const uint32_t* wL = wv;
-  const uint32_t* wR = wv + sh.n * 8;
-  const uint32_t* wO = wv + 2 * sh.n * 8;
-  const uint32_t* wV = wv + 3 * sh.n * 8;
-  const uint32_t* wc = wV + sh.m * 8;
+  const uint32_t* wR = wv + sh.n * SW;
+  const uint32_t* wO = wv + 2 * sh.n * SW;
+  const uint32_t* wV = wv + 3 * sh.n * SW;
+  const uint32_t* wc = wV + sh.m * SW;
   // dsum = rho sum_{i<n} y^(pn-1-i) wR_i wL_i  (= c' delta / U; plain partial sums, block reduction)
   {
-    scm part = scm_zero();
+    scl part = scl_zero();
+    uint32_t cnt = 0;
     for (uint32_t i = t; i < sh.n; i += nt) {
-      scm a, b, c;
-      ld_scm(a, yip + 8 * (sh.pn - 1 - i)); ld_scm(b, wR + 8 * i); ld_scm(c, wL + 8 * i);
-      part = scm_add(part, scm_mul(scm_mul(b, c), a));
+      scl a, b, c;
+      ld_scl(a, yip + SW * (sh.pn - 1 - i)); ld_scl(b, wR + SW * i); ld_scl(c, wL + SW * i);
+      part = scl_add(part, scl_mul(scl_mul(b, c), a));
+      if (++cnt == 32) { part = scl_weak(part); cnt = 1; }
     }
-#pragma unroll 1
-    for (int sh_d = 32; sh_d >= 1; sh_d >>= 1) {
-      scm o;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) o.v[q] = __shfl_down(part.v[q], sh_d);
-      part = scm_add(part, o);
-    }
-    if ((t & 63) == 0) st_scm(red + 8 * (1 + (t >> 6)), part);
+    part = wave_sum_scl(scl_weak(part));          // <= 32 products, limbs < 2^31
+    if ((t & 63) == 0) st_scl(red + SW * (1 + (t >> 6)), part);
     __syncthreads();
     if (t == 0) {
-      scm tot = scm_zero();
-      for (uint32_t wI = 0; wI < (nt >> 6); ++wI) { scm v; ld_scm(v, red + 8 * (1 + wI)); tot = scm_add(tot, v); }
-      st_scm(red, tot);
+      scl tot = scl_zero();
+      for (uint32_t wI = 0; wI < (nt >> 6); ++wI) { scl v; ld_scl(v, red + SW * (1 + wI)); tot = scl_add(tot, v); }
+      st_scl(red, scl_weak(tot));
     }
     __syncthreads();
   }
-  scm x, u, r, U, rhoY_plain, cp_plain, cp;
-  ld_scm(u, chs + 2 * 8); ld_scm(x, chs + 3 * 8); ld_scm(U, chs + 6 * 8); ld_scm(r, chs + 7 * 8);
-  ld_scm(rhoY_plain, yip + 8 * (sh.pn - 1));     // rho y^(pn-1), plain
-  cp_plain = scm_mul(U, rhoY_plain);             // c', plain
+  scl x, u, r, U, rhoY_plain, cp_plain, cp;
+  ld_scl(u, chs + 2 * SW); ld_scl(x, chs + 3 * SW); ld_scl(U, chs + 6 * SW); ld_scl(r, chs + 7 * SW);
+  ld_scl(rhoY_plain, yip + SW * (sh.pn - 1));    // rho y^(pn-1), plain
+  cp_plain = scl_mul(U, rhoY_plain);             // c', plain
   uint32_t* ds = dyn_scalars + (uint64_t)tx * sh.n_dyn * 8;
   uint32_t* dr = dyn_recoded + (uint64_t)tx * sh.n_dyn * 8;
   uint32_t* ss = static_scalars + (uint64_t)tx * sh.n_static * 8;
@@ -659,66 +705,65 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   //     c' (w (t_x - a b) + r (x^2 (wc + delta) - t_x))  =  c' w (t_x - [a b])  +  r (x^2 ([c' wc] + [U dsum]) - [c' t_x])
   // lane jB: a b, then w (t_x - .), then c' (.);  jB+1: c' wc, then x^2 (. + U dsum), then r (. - c' t_x);
   // jB+2: U dsum;  jB+3: c' t_x;  the partial results travel by wavefront shuffles.  The factor c' of everything else
-  // rides on the final Montgomery -> canonical conversion (a product with the plain c' instead of with 1).
+  // rides on the final Montgomery -> plain conversion (a product with the plain c' instead of with 1).
   const uint32_t tail0 = nt - 64;
   if (t >= tail0) {
     const uint32_t lane = t - tail0, n_dyn = sh.n_dyn;
-    const scm dsum = scm_from_words(red);         // plain sum -> Montgomery
-    cp = scm_from_words(cp_plain.v);              // c', Montgomery
+    scl dsum;
+    ld_scl(dsum, red);
+    dsum = scl_mul(dsum, scl_r2());               // plain sum -> Montgomery
+    cp = scl_mul(cp_plain, scl_r2());             // c', Montgomery
     // positions: 0 B (a b ..), 1 B's second half (c' wc ..), 2 U dsum, 3 c' t_x, 4 B_blinding, 5 + j the proof point j
 #pragma unroll 1
     for (uint32_t pos0 = 0; pos0 < n_dyn + 5; pos0 += 64) {
       const uint32_t pos = pos0 + lane;
       const uint32_t j = pos - 5;                 // proof-point index when pos >= 5
-      scm a = scm_one(), b = scm_one(), v = scm_one(), conv_by = cp_plain;
+      scl a = scl_one(), b = scl_one(), v = scl_one(), conv_by = cp_plain;
       bool m1 = false;                            // does round 1 multiply?
-      if (pos == 0) { ld_scm(a, chs + 11 * 8); ld_scm(b, chs + 12 * 8); m1 = true; }                        // a b
-      else if (pos == 1) { a = cp; ld_scm(b, wc); m1 = true; }                                              // c' wc
-      else if (pos == 2) { a = U; b = dsum; m1 = true; }                                                    // U dsum
-      else if (pos == 3) { a = cp; ld_scm(b, chs + 8 * 8); m1 = true; }                                     // c' t_x
-      else if (pos == 4) { a = r; ld_scm(b, chs + 9 * 8); m1 = true; }                                      // r t_x_blinding
-      else if (j < 3) { if (j == 0) v = x; else ld_scm(v, xp + (j - 1) * 8); }                              // x, x^2, x^3
-      else if (j < 6) { if (j == 3) a = x; else ld_scm(a, xp + (j - 4) * 8); b = u; m1 = true; }            // u x^(1..3)
-      else if (j < 6 + sh.m) { ld_scm(a, wV + 8 * (j - 6)); ld_scm(b, xp + 5 * 8); m1 = true; }             // wV_j r x^2
-      else if (j < 11 + sh.m) {                                                                             // r x, r x^3 .. r x^6
+      if (pos == 0) { ld_scl(a, chs + 11 * SW); ld_scl(b, chs + 12 * SW); m1 = true; }                        // a b
+      else if (pos == 1) { a = cp; ld_scl(b, wc); m1 = true; }                                               // c' wc
+      else if (pos == 2) { a = U; b = dsum; m1 = true; }                                                     // U dsum
+      else if (pos == 3) { a = cp; ld_scl(b, chs + 8 * SW); m1 = true; }                                     // c' t_x
+      else if (pos == 4) { a = r; ld_scl(b, chs + 9 * SW); m1 = true; }                                      // r t_x_blinding
+      else if (j < 3) { if (j == 0) v = x; else ld_scl(v, xp + (j - 1) * SW); }                              // x, x^2, x^3
+      else if (j < 6) { if (j == 3) a = x; else ld_scl(a, xp + (j - 4) * SW); b = u; m1 = true; }            // u x^(1..3)
+      else if (j < 6 + sh.m) { ld_scl(a, wV + SW * (j - 6)); ld_scl(b, xp + 5 * SW); m1 = true; }            // wV_j r x^2
+      else if (j < 11 + sh.m) {                                                                              // r x, r x^3 .. r x^6
         const uint32_t q = j - 6 - sh.m;
-        if (q == 0) a = x; else ld_scm(a, xp + q * 8);
+        if (q == 0) a = x; else ld_scl(a, xp + q * SW);
         b = r; m1 = true;
       } else if (j < n_dyn) {
         const uint32_t q = j - 11 - sh.m;         // u_j^2 for L_j; for R_j  c' u_j^-2 = rho Y prod_{l != j} u_l^2
-        if (q < sh.k) { ld_scm(a, chs + (CH_FIXED + sh.n_chal2 + q) * 8); b = a; m1 = true; }
-        else { ld_scm(v, chs + (CH_FIXED + sh.n_chal2 + sh.k + (q - sh.k)) * 8); conv_by = rhoY_plain; }
+        if (q < sh.k) { ld_scl(a, chs + (CH_FIXED + sh.n_chal2 + q) * SW); b = a; m1 = true; }
+        else { ld_scl(v, chs + (CH_FIXED + sh.n_chal2 + sh.k + (q - sh.k)) * SW); conv_by = rhoY_plain; }
       }
       {
-        const scm pr = scm_mul(a, b);
+        const scl pr = scl_mul(a, b);
         if (m1) v = pr;
       }
       if (pos0 == 0) {                            // rounds 2 and 3: the scalars of B and B_blinding (first pass only, lanes 0..4)
-        scm other;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) other.v[q] = (uint32_t)__shfl_down((int)v.v[q], 1);
+        scl other = shfl_down_scl(v, 1);
         bool m2 = false;
-        if (pos == 0) { scm tx_; ld_scm(tx_, chs + 8 * 8); ld_scm(a, chs + 4 * 8); b = scm_sub(tx_, v); m2 = true; }       // w (t_x - a b)
-        else if (pos == 1) { ld_scm(a, xp + 0 * 8); b = scm_add(v, other); m2 = true; }                                    // x^2 (c' wc + U dsum)
-        else if (pos == 4) { scm e; ld_scm(e, chs + 10 * 8); v = scm_neg(scm_add(e, v)); }                                 // -(e_blinding + r t_x_blinding)
-        const scm pr2 = scm_mul(a, b);
+        if (pos == 0) { scl tx_; ld_scl(tx_, chs + 8 * SW); ld_scl(a, chs + 4 * SW); b = scl_sub(tx_, v); m2 = true; }       // w (t_x - a b)
+        else if (pos == 1) { ld_scl(a, xp + 0 * SW); b = scl_add(v, other); m2 = true; }                                      // x^2 (c' wc + U dsum)
+        else if (pos == 4) { scl e; ld_scl(e, chs + 10 * SW); scl sum = scl_add(e, v); scl_carry(sum); v = scl_neg(sum); }    // -(e_blinding + r t_x_blinding)
+        const scl pr2 = scl_mul(a, b);
         if (m2) v = pr2;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) other.v[q] = (uint32_t)__shfl_down((int)v.v[q], 2);
+        other = shfl_down_scl(v, 2);
         bool m3 = false;
-        if (pos == 0) { a = cp; b = v; m3 = true; }                                                                        // c' w (t_x - a b)
-        else if (pos == 1) { a = r; b = scm_sub(v, other); m3 = true; }                                                    // r (x^2 (..) - c' t_x)
-        const scm pr3 = scm_mul(a, b);
+        if (pos == 0) { a = cp; b = v; m3 = true; }                                                                          // c' w (t_x - a b)
+        else if (pos == 1) { a = r; b = scl_sub(v, other); m3 = true; }                                                      // r (x^2 (..) - c' t_x)
+        const scl pr3 = scl_mul(a, b);
         if (m3) v = pr3;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) other.v[q] = (uint32_t)__shfl_down((int)v.v[q], 1);
-        if (pos == 0) { v = scm_add(v, other); conv_by = scm_zero(); conv_by.v[0] = 1; }
+        other = shfl_down_scl(v, 1);
+        if (pos == 0) { v = scl_add(v, other); conv_by = scl_plain_one(); }
       }
-      const scm conv = scm_mul(v, conv_by);       // Montgomery -> canonical words, times the plain factor
-      const uint32_t* o = conv.v;
+      uint32_t o[8];
+      scl_canon_words(o, scl_mul(v, conv_by));    // Montgomery -> canonical words, times the plain factor
       if (pos >= 5 && j < n_dyn) {
         // the scalar, and its recoded form s + 0x88..8 for k_small_accumulate (digit t = nibble t - 8)
         uint32_t carry = 0;
+#pragma unroll
         for (int q = 0; q < 8; ++q) {
           ds[j * 8 + q] = o[q];
           const uint64_t vv = (uint64_t)o[q] + 0x88888888u + carry;
@@ -726,36 +771,40 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
           carry = (uint32_t)(vv >> 32);
         }
       } else if (pos == 0 || pos == 4) {
+#pragma unroll
         for (int q = 0; q < 8; ++q) ss[(pos == 0 ? 0 : 1) * 8 + q] = o[q];
       }
     }
   }
-  // generator scalars (times c'), canonical words straight out of the products:
+  // generator scalars (times c'), reduced to canonical words at the very end:
   //   c' g_i = (x U) wR_i yp[pn-1-i] - (a P1 rho Y) sU_i
   //   c' h_i = yp[pn-1-i] ((x U) wL_i + U wO_i - (b P1) sU_(pn-1-i)) - c'        (times u for i >= n1)
   {
-    scm P1, a_, b_;
-    ld_scm(P1, chs + 5 * 8); ld_scm(a_, chs + 11 * 8); ld_scm(b_, chs + 12 * 8);
-    const scm xU = scm_mul(x, U);
-    const scm aY_plain = scm_mul(scm_mul(a_, P1), rhoY_plain);
-    const scm bP = scm_mul(b_, P1);
+    scl P1, a_, b_;
+    ld_scl(P1, chs + 5 * SW); ld_scl(a_, chs + 11 * SW); ld_scl(b_, chs + 12 * SW);
+    const scl xU = scl_mul(x, U);
+    const scl aY_plain = scl_mul(scl_mul(a_, P1), rhoY_plain);
+    const scl bP = scl_mul(b_, P1);
     for (uint32_t i = t; i < sh.pn; i += nt) {
-      scm yp, si, sr;
-      ld_scm(yp, yip + 8 * (sh.pn - 1 - i)); ld_scm(si, sv + 8 * i); ld_scm(sr, sv + 8 * (sh.pn - 1 - i));
-      scm g = scm_neg(scm_mul(aY_plain, si));
-      scm inner = scm_neg(scm_mul(bP, sr));
+      scl yp, si, sr;
+      ld_scl(yp, yip + SW * (sh.pn - 1 - i)); ld_scl(si, sv + SW * i); ld_scl(sr, sv + SW * (sh.pn - 1 - i));
+      scl g = scl_neg(scl_mul(aY_plain, si));                 // limbs < 2^27.6, value < 2^260.1
+      scl inner = scl_neg(scl_mul(bP, sr));
       if (i < sh.n) {
-        scm wl, wr, wo;
-        ld_scm(wl, wL + 8 * i); ld_scm(wr, wR + 8 * i); ld_scm(wo, wO + 8 * i);
-        g = scm_add(g, scm_mul(scm_mul(xU, wr), yp));
-        inner = scm_add(inner, scm_add(scm_mul(xU, wl), scm_mul(U, wo)));
+        scl wl, wr, wo;
+        ld_scl(wl, wL + SW * i); ld_scl(wr, wR + SW * i); ld_scl(wo, wO + SW * i);
+        g = scl_add(g, scl_mul(scl_mul(xU, wr), yp));
+        inner = scl_add(inner, scl_add(scl_mul(xU, wl), scl_mul(U, wo)));   // limbs < 2^28, value < 2^260.2
       }
-      scm h = scm_sub(scm_mul(yp, inner), cp_plain);
-      if (i >= sh.n1) { g = scm_mul(g, u); h = scm_mul(h, u); }
+      scl h = scl_sub(scl_mul(yp, inner), cp_plain);          // yp, c' tight and < 2^255
+      if (i >= sh.n1) { g = scl_mul(g, u); h = scl_mul(h, u); }
+      uint32_t gw[8], hw[8];
+      scl_canon_words(gw, g);
+      scl_canon_words(hw, h);
       uint4* og = reinterpret_cast<uint4*>(ss + (2 + i) * 8);
       uint4* oh = reinterpret_cast<uint4*>(ss + (2 + sh.pn + i) * 8);
-      og[0] = make_uint4(g.v[0], g.v[1], g.v[2], g.v[3]); og[1] = make_uint4(g.v[4], g.v[5], g.v[6], g.v[7]);
-      oh[0] = make_uint4(h.v[0], h.v[1], h.v[2], h.v[3]); oh[1] = make_uint4(h.v[4], h.v[5], h.v[6], h.v[7]);
+      og[0] = make_uint4(gw[0], gw[1], gw[2], gw[3]); og[1] = make_uint4(gw[4], gw[5], gw[6], gw[7]);
+      oh[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]); oh[1] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
     }
   }
 }

@@ -826,7 +826,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     HIP_TRY(c, hipStreamWaitEvent(H3, c->ev_t, 0));
     Launch l(c, "k_prepare", H3);
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)B), dim3(256), prep->lds_bytes, H3, prep->sh, prep->d_mono_chal,
-                       prep->d_mono_pow, prep->d_tgt_off, prep->d_term_q, prep->d_term_mono, prep->d_term_coef,
+                       prep->d_mono_pow, prep->d_tgt_off, prep->d_term_q, (const uint2*)prep->d_term_mono, prep->d_term_coef,
                        (const uint32_t*)c->prep_ch.p, prep->d_com, (const uint32_t*)c->prep_pw.p,
                        (uint32_t*)c->prep_dyn_sc.p, (uint32_t*)c->recoded.p, (uint32_t*)c->prep_st_sc.p);
   }
@@ -1897,25 +1897,28 @@ int plan_finish(zkgpu_ctx* c, zkgpu_cloak_plan* p, size_t gens_capacity, zkgpu_c
   s.n_static = 2 + 2 * h.pn;
   s.n_heavy = 0;
   for (uint32_t t = 0; t < s.n_targets && s.n_heavy < 8; ++t)
-    if (h.tgt_off[t + 1] - h.tgt_off[t] > 24) s.heavy[s.n_heavy++] = t;
+    if (h.tgt_off[t + 1] - h.tgt_off[t] > 2 * HEAVY_TERMS) s.heavy[s.n_heavy++] = t;
   s.n_ch_ext = s.n_ch + s.n_mono + PREP_STRIDES;
   // fewest flattening passes (<= 5) whose per-pass products keep the workgroup at <= 40 KB of LDS
   // (four workgroups per CU); the split points are target boundaries
+  const uint32_t n_prod = (uint32_t)h.prod_q.size();
   for (uint32_t chunks = 1; chunks <= 5; ++chunks) {
     s.n_chunks = chunks;
     s.chunk_tgt[0] = 0;
+    s.chunk_prod[0] = 0;
     uint32_t cap = 0, g = 0;
     for (uint32_t ck = 0; ck < chunks; ++ck) {
-      const uint32_t goal = (uint32_t)(((uint64_t)s.n_terms * (ck + 1)) / chunks);
-      while (g < s.n_targets && (h.tgt_off[g + 1] <= goal || ck + 1 == chunks)) ++g;
+      const uint32_t goal = (uint32_t)(((uint64_t)n_prod * (ck + 1)) / chunks);
+      while (g < s.n_targets && (h.prod_off[g + 1] <= goal || ck + 1 == chunks)) ++g;
       if (ck + 1 == chunks) g = s.n_targets;
       s.chunk_tgt[ck + 1] = g;
-      cap = std::max(cap, h.tgt_off[g] - h.tgt_off[s.chunk_tgt[ck]]);
+      s.chunk_prod[ck + 1] = h.prod_off[g];
+      cap = std::max(cap, h.prod_off[g] - h.prod_off[s.chunk_tgt[ck]]);
     }
     s.tv_cap = cap;
-    if (prepare_lds_slots(s) * 32 <= 40 * 1024) break;
+    if (prepare_lds_slots(s) * SCL_WORDS * 4 <= 40 * 1024) break;
   }
-  p->lds_bytes = prepare_lds_slots(s) * 32;
+  p->lds_bytes = prepare_lds_slots(s) * SCL_WORDS * 4;
   if (p->lds_bytes > 160 * 1024) { delete p; c->last_error = "plan does not fit the 160 KiB LDS of a CU"; return ZKGPU_EINVAL; }
   // STROBE state after Transcript::new("ZkVM.r1cs") + r1cs_domain_sep()
   Transcript tr(h.label.c_str());
@@ -1938,9 +1941,13 @@ int plan_finish(zkgpu_ctx* c, zkgpu_cloak_plan* p, size_t gens_capacity, zkgpu_c
   TRY(plan_upload(c, &p->d_mono_chal, h.mono_chal));
   TRY(plan_upload(c, &p->d_mono_pow, h.mono_pow));
   TRY(plan_upload(c, &p->d_tgt_off, h.tgt_off));
-  TRY(plan_upload(c, &p->d_term_q, h.term_q));
-  TRY(plan_upload(c, &p->d_term_mono, h.term_mono));
-  TRY(plan_upload(c, &p->d_term_coef, h.term_coef));
+  {
+    std::vector<uint32_t> qm(2 * h.prod_q.size());
+    for (size_t i = 0; i < h.prod_q.size(); ++i) { qm[2 * i] = h.prod_q[i]; qm[2 * i + 1] = h.prod_mono[i]; }
+    TRY(plan_upload(c, &p->d_term_q, h.term_info));       // k_prepare's term_info
+    TRY(plan_upload(c, &p->d_term_mono, qm));             //             prod_qm
+    TRY(plan_upload(c, &p->d_term_coef, h.prod_coef));    //             prod_coef
+  }
   HIP_TRY(c, hipFuncSetAttribute((const void*)k_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
   *out = p;
   return ZKGPU_OK;
@@ -2231,7 +2238,7 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
     Launch l(c, "k_prepare");
     hipLaunchKernelGGL(k_prepare, dim3(B), dim3(256), plan->lds_bytes, s, sh, (const uint32_t*)plan->d_mono_chal,
                        (const uint32_t*)plan->d_mono_pow, (const uint32_t*)plan->d_tgt_off, (const uint32_t*)plan->d_term_q,
-                       (const uint32_t*)plan->d_term_mono, (const uint32_t*)plan->d_term_coef, (const uint32_t*)c->prep_ch.p,
+                       (const uint2*)plan->d_term_mono, (const uint32_t*)plan->d_term_coef, (const uint32_t*)c->prep_ch.p,
                        d_com, (const uint32_t*)c->prep_pw.p, (uint32_t*)c->prep_dyn_sc.p,
                        (uint32_t*)c->recoded.p, (uint32_t*)c->prep_st_sc.p);
     hipLaunchKernelGGL(k_gather_dyn_points, dim3(blocks_for((uint64_t)B * sh.n_dyn * 8, 256)), dim3(256), 0, s, sh, d_com,
