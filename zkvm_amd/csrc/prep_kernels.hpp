@@ -483,9 +483,10 @@ constexpr uint32_t SCL_WORDS = 10;
 constexpr uint32_t TERM_UNIT = 0x80000000u, TERM_NEG = 0x40000000u, TERM_IDX = 0x00ffffffu;
 constexpr uint32_t HEAVY_TERMS = 16;      // lazy sums are reduced every so many terms; targets with more are summed by the whole workgroup
 
-__host__ __device__ inline size_t prepare_lds_slots(const PrepShape& sh) {
-  const size_t first = (size_t)sh.n_cons + sh.tv_cap + 32, second = (size_t)2 * sh.pn + 8;
-  return (size_t)sh.n_ch_ext + sh.n_targets + (first > second ? first : second);
+// bytes: 40-byte slots, except the two tables of the second life (yip, sv: products < 2^255 packed into 32 bytes)
+__host__ __device__ inline size_t prepare_lds_bytes(const PrepShape& sh) {
+  const size_t first = ((size_t)sh.n_cons + sh.tv_cap + 32) * 40, second = (size_t)2 * sh.pn * 32 + 8 * 40;
+  return ((size_t)sh.n_ch_ext + sh.n_targets) * 40 + 16 + (first > second ? first : second);
 }
 
 __device__ __forceinline__ void ld_scl(scl& s, const uint32_t* p) {
@@ -497,6 +498,19 @@ __device__ __forceinline__ void st_scl(uint32_t* p, const scl& s) {
   uint2* q = reinterpret_cast<uint2*>(p);
 #pragma unroll
   for (int i = 0; i < 5; ++i) q[i] = make_uint2(s.v[2 * i], s.v[2 * i + 1]);
+}
+__device__ __forceinline__ void ld_scl8(scl& s, const uint32_t* p) {    // packed table entry
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1];
+  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  s = scl_from_words(w);
+}
+__device__ __forceinline__ void st_scl8(uint32_t* p, const scl& s) {    // s tight, < 2^256
+  uint32_t w[8];
+  scl_pack8(w, s);
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 __device__ __forceinline__ scl shfl_down_scl(const scl& a, int delta) {
   scl o;
@@ -525,11 +539,11 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   uint32_t* ys = zs + 16 * SW;                   // y^-(2^L)
   uint32_t* us2 = ys + 16 * SW;                  // u_j^2
   uint32_t* wv = chs + sh.n_ch_ext * SW;
-  uint32_t* zpow = wv + sh.n_targets * SW;       // region A, first life
+  uint32_t* zpow = lds + (((sh.n_ch_ext + sh.n_targets) * SW + 3u) & ~3u);   // region A (16-byte aligned), first life
   uint32_t* tv = zpow + sh.n_cons * SW;
-  uint32_t* yip = zpow;                          // region A, second life
-  uint32_t* sv = yip + sh.pn * SW;
-  uint32_t* red = sv + sh.pn * SW;
+  uint32_t* yip = zpow;                          // region A, second life: two packed tables (8 words per entry)
+  uint32_t* sv = yip + sh.pn * 8;
+  uint32_t* red = sv + sh.pn * 8;
   const uint32_t tx = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
 
   // the transaction's slots (canonical Montgomery words) -> limb form
@@ -645,8 +659,8 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   if (t == 0) {
     scl rho;
     ld_scl(rho, chs + 13 * SW);
-    st_scl(yip, scl_mul(rho, scl_plain_one()));
-    st_scl(sv, scl_one());
+    st_scl8(yip, scl_mul(rho, scl_plain_one()));
+    st_scl8(sv, scl_one());
   }
   __syncthreads();
 #pragma unroll 1
@@ -654,14 +668,14 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     for (uint32_t idx = t; idx < 2 * half; idx += nt) {
       scl a, b;
       if (idx < half) {
-        ld_scl(a, yip + SW * idx);
+        ld_scl8(a, yip + 8 * idx);
         ld_scl(b, ys + SW * L);
-        st_scl(yip + SW * (idx + half), scl_mul(a, b));
+        st_scl8(yip + 8 * (idx + half), scl_mul(a, b));
       } else {
         const uint32_t i = idx - half;
-        ld_scl(a, sv + SW * i);
+        ld_scl8(a, sv + 8 * i);
         ld_scl(b, us2 + SW * (sh.k - 1 - L));
-        st_scl(sv + SW * (i + half), scl_mul(a, b));
+        st_scl8(sv + 8 * (i + half), scl_mul(a, b));
       }
     }
     __syncthreads();
@@ -677,7 +691,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     uint32_t cnt = 0;
     for (uint32_t i = t; i < sh.n; i += nt) {
       scl a, b, c;
-      ld_scl(a, yip + SW * (sh.pn - 1 - i)); ld_scl(b, wR + SW * i); ld_scl(c, wL + SW * i);
+      ld_scl8(a, yip + 8 * (sh.pn - 1 - i)); ld_scl(b, wR + SW * i); ld_scl(c, wL + SW * i);
       part = scl_add(part, scl_mul(scl_mul(b, c), a));
       if (++cnt == 32) { part = scl_weak(part); cnt = 1; }
     }
@@ -693,7 +707,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   }
   scl x, u, r, U, rhoY_plain, cp_plain, cp;
   ld_scl(u, chs + 2 * SW); ld_scl(x, chs + 3 * SW); ld_scl(U, chs + 6 * SW); ld_scl(r, chs + 7 * SW);
-  ld_scl(rhoY_plain, yip + SW * (sh.pn - 1));    // rho y^(pn-1), plain
+  ld_scl8(rhoY_plain, yip + 8 * (sh.pn - 1));    // rho y^(pn-1), plain
   cp_plain = scl_mul(U, rhoY_plain);             // c', plain
   uint32_t* ds = dyn_scalars + (uint64_t)tx * sh.n_dyn * 8;
   uint32_t* dr = dyn_recoded + (uint64_t)tx * sh.n_dyn * 8;
@@ -787,7 +801,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     const scl bP = scl_mul(b_, P1);
     for (uint32_t i = t; i < sh.pn; i += nt) {
       scl yp, si, sr;
-      ld_scl(yp, yip + SW * (sh.pn - 1 - i)); ld_scl(si, sv + SW * i); ld_scl(sr, sv + SW * (sh.pn - 1 - i));
+      ld_scl8(yp, yip + 8 * (sh.pn - 1 - i)); ld_scl8(si, sv + 8 * i); ld_scl8(sr, sv + 8 * (sh.pn - 1 - i));
       scl g = scl_neg(scl_mul(aY_plain, si));                 // limbs < 2^27.6, value < 2^260.1
       scl inner = scl_neg(scl_mul(bP, sr));
       if (i < sh.n) {

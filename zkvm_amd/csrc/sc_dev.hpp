@@ -269,6 +269,16 @@ ZK_HD void scl_canon_words(uint32_t out[8], const scl& x) {
     out[i] = w;
   }
 }
+// tight limbs of a value < 2^256 <-> eight words (the compact storage of tables in LDS)
+ZK_HD void scl_pack8(uint32_t out[8], const scl& f) {
+  ZK_UNROLL for (int i = 0; i < 8; ++i) {
+    const int lo = (32 * i) / 26, sft = (32 * i) % 26;
+    uint32_t w = f.v[lo] >> sft;
+    w |= f.v[lo + 1] << (26 - sft);
+    if (lo + 2 < 10 && 52 - sft < 32) w |= f.v[lo + 2] << (52 - sft);
+    out[i] = w;
+  }
+}
 ZK_HD scm scl_to_scm(const scl& a) { scm r; scl_canon_words(r.v, a); return r; }   // same value, canonical range
 
 // a^(l-2)

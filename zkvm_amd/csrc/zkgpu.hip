@@ -1899,9 +1899,11 @@ int plan_finish(zkgpu_ctx* c, zkgpu_cloak_plan* p, size_t gens_capacity, zkgpu_c
   for (uint32_t t = 0; t < s.n_targets && s.n_heavy < 8; ++t)
     if (h.tgt_off[t + 1] - h.tgt_off[t] > 2 * HEAVY_TERMS) s.heavy[s.n_heavy++] = t;
   s.n_ch_ext = s.n_ch + s.n_mono + PREP_STRIDES;
-  // fewest flattening passes (<= 5) whose per-pass products keep the workgroup at <= 40 KB of LDS
-  // (four workgroups per CU); the split points are target boundaries
+  // fewest flattening passes (<= 5) that bring the workgroup to <= 40 KB of LDS (four workgroups per CU) -- or, where
+  // that is out of reach, beyond which the LDS need no longer shrinks; the split points are target boundaries
   const uint32_t n_prod = (uint32_t)h.prod_q.size();
+  PrepShape best = s;
+  size_t best_bytes = 0;
   for (uint32_t chunks = 1; chunks <= 5; ++chunks) {
     s.n_chunks = chunks;
     s.chunk_tgt[0] = 0;
@@ -1916,9 +1918,12 @@ int plan_finish(zkgpu_ctx* c, zkgpu_cloak_plan* p, size_t gens_capacity, zkgpu_c
       cap = std::max(cap, h.prod_off[g] - h.prod_off[s.chunk_tgt[ck]]);
     }
     s.tv_cap = cap;
-    if (prepare_lds_slots(s) * SCL_WORDS * 4 <= 40 * 1024) break;
+    const size_t bytes = prepare_lds_bytes(s);
+    if (best_bytes == 0 || bytes < best_bytes) { best = s; best_bytes = bytes; }
+    if (bytes <= 40 * 1024) break;
   }
-  p->lds_bytes = prepare_lds_slots(s) * SCL_WORDS * 4;
+  s = best;
+  p->lds_bytes = best_bytes;
   if (p->lds_bytes > 160 * 1024) { delete p; c->last_error = "plan does not fit the 160 KiB LDS of a CU"; return ZKGPU_EINVAL; }
   // STROBE state after Transcript::new("ZkVM.r1cs") + r1cs_domain_sep()
   Transcript tr(h.label.c_str());
