@@ -326,9 +326,11 @@ def test_failed_groups_are_located_and_every_pattern_of_bad_transactions_resolve
     assert want.count(0) == 1 + 1 + 1 + 2 + 3 + 1 + 2 + 2 + 16 + 1
     try:
         before = ctx.force_regroup(False)
-        for mode in (1, 2, 2):                                  # re-check in full; locate (the default from 2048 per batch on)
-            ctx.set_locate_mode(mode)
-            assert bits(v.verify_packed_gpu(n_in, n_out, n, com_b, proof_b, plen, r), n) == want, mode
+        for horner in (1, 2, 0):                                # Horner chains per transaction / per group / automatic
+            ctx.set_horner_mode(horner)
+            for mode in (1, 2, 2):                              # re-check in full; locate (the default from 2048 per batch on)
+                ctx.set_locate_mode(mode)
+                assert bits(v.verify_packed_gpu(n_in, n_out, n, com_b, proof_b, plen, r), n) == want, (horner, mode)
         assert ctx.force_regroup(True) == before               # nothing above needed the ungrouped re-run
         assert bits(v.verify_packed_gpu(n_in, n_out, n, com_b, proof_b, plen, r), n) == want
         assert ctx.force_regroup(False) == before + 1          # ... and here it was taken
@@ -338,6 +340,7 @@ def test_failed_groups_are_located_and_every_pattern_of_bad_transactions_resolve
     finally:
         ctx.set_group_size(16)
         ctx.set_locate_mode(0)
+        ctx.set_horner_mode(0)
         ctx.force_regroup(False)
         v.close()
         gens.close()

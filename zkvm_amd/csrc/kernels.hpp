@@ -921,11 +921,14 @@ __global__ void __launch_bounds__(256)
 k_msm_finish_quad(const uint32_t* __restrict__ window_sums, const uint32_t* __restrict__ window_nonempty,
                   const uint32_t* __restrict__ msm_fail, uint8_t* __restrict__ accept,
                   uint32_t* __restrict__ out_enc, uint32_t* __restrict__ out_ext, uint32_t n_msm, int w,
-                  int n_windows) {
+                  int n_windows, const uint32_t* __restrict__ sel_state, uint32_t sel_group) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = g & 3;
   const bool live = (g >> 2) < n_msm;
   const uint32_t m = live ? (g >> 2) : (n_msm - 1);   // keep whole quads active for DPP
+  // sel_state: only the multiscalar multiplications whose group (m / sel_group) is marked take part (the
+  // transactions of the groups whose check failed); a quad leaves as a whole
+  if (sel_state && sel_state[m / sel_group] == 0) return;
   ge acc;
   ge_identity(acc);
   bool have = false;
@@ -944,7 +947,7 @@ k_msm_finish_quad(const uint32_t* __restrict__ window_sums, const uint32_t* __re
   const bool failed = msm_fail && msm_fail[m];
   if (out_ext) {
     store_ext(out_ext + (uint64_t)m * EXT_WORDS, acc);
-    accept[m] = failed ? 0 : 1;
+    if (accept) accept[m] = failed ? 0 : 1;
     return;
   }
   if (out_enc) {
@@ -1271,13 +1274,42 @@ __device__ __forceinline__ void shfl_ge(ge& out, const ge& in, int src_lane) {
   }
 }
 
+// window sums of a GROUP: lane (G, t) adds window t of the group's transactions (those not left out), so that the
+// Horner chain over the windows -- the longest dependent chain of a batch, and a third of its point doublings -- runs
+// once per group instead of once per transaction; only the transactions of a group whose check FAILS get chains of
+// their own afterwards (k_msm_finish_quad with sel_state)
+__global__ void __launch_bounds__(256)
+k_group_windows(const uint32_t* __restrict__ window_sums, const uint32_t* __restrict__ window_nonempty,
+                const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
+                uint32_t group, uint32_t n_windows, uint32_t* __restrict__ out_sums, uint32_t* __restrict__ out_nonempty) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n_groups = (n_msm + group - 1) / group;
+  if (g >= n_groups * n_windows) return;
+  const uint32_t G = g / n_windows, t = g % n_windows;
+  ge acc;
+  bool have = false;
+#pragma unroll 1
+  for (uint32_t i = 0; i < group; ++i) {
+    const uint32_t tx = G * group + i;
+    if (tx >= n_msm) break;
+    if (tx_excluded(msm_fail, wellformed, tx)) continue;
+    const uint64_t win = (uint64_t)tx * n_windows + t;
+    if (!window_nonempty[win]) continue;
+    ge p;
+    load_ext(p, window_sums + win * EXT_WORDS);
+    if (have) ge_add(acc, acc, p); else { acc = p; have = true; }
+  }
+  out_nonempty[g] = have ? 1u : 0u;
+  if (have) store_ext(out_sums + (uint64_t)g * EXT_WORDS, acc);
+}
+
 // one wave per group: generator partials of the group + the proof-point sums of its transactions
 // blockDim = 256: wavefront 0 sums the points; a failed group's locating scalars are then spread over all four.
 // locate == 0 (small batches, where the extra stage costs more latency than it saves work): a failed group queues
 // all of its transactions for the individual re-check right here (cand = LOCATE_NONE).
 __global__ void __launch_bounds__(256)
-k_group_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
-                const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
+k_group_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ grp_dyn /*[n_groups][40], or null: sum dyn_sum over the group*/,
+                const uint32_t* __restrict__ dyn_sum, const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
                 uint32_t group, uint8_t* __restrict__ accept, uint32_t* __restrict__ grp_state /*[n_groups]: 0 passed, f + 1 failed*/,
                 uint32_t* __restrict__ fail_list, uint32_t* __restrict__ fail_sum /*[n_groups][40]*/, uint32_t* __restrict__ n_fail,
                 const uint32_t* __restrict__ st_scalars, uint32_t n_static, uint32_t* __restrict__ loc_sc /*[n_groups][n_static][8]*/,
@@ -1295,12 +1327,20 @@ k_group_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, cons
       load_ext(p, partials + ((uint64_t)G * n_partials + c) * EXT_WORDS);
       ge_add(acc, acc, p);
     }
-    for (uint32_t i = lane; i < group; i += 64) {
-      const uint32_t tx = G * group + i;
-      if (tx < n_msm && !tx_excluded(msm_fail, wellformed, tx)) {
+    if (grp_dyn) {                        // the proof-point sum of the whole group (k_group_windows + one Horner chain)
+      if (lane == 0) {
         ge p;
-        load_ext(p, dyn_sum + (uint64_t)tx * EXT_WORDS);
+        load_ext(p, grp_dyn + (uint64_t)G * EXT_WORDS);
         ge_add(acc, acc, p);
+      }
+    } else {
+      for (uint32_t i = lane; i < group; i += 64) {
+        const uint32_t tx = G * group + i;
+        if (tx < n_msm && !tx_excluded(msm_fail, wellformed, tx)) {
+          ge p;
+          load_ext(p, dyn_sum + (uint64_t)tx * EXT_WORDS);
+          ge_add(acc, acc, p);
+        }
       }
     }
 #pragma unroll 1

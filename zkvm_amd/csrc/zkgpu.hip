@@ -93,6 +93,7 @@ struct zkgpu_ctx {
   Buffer digits, st_partials, dynsum, accept2, bin_order, class_count, part_hist, part_entries, part_lo, dec_scratch, heavy;
   Buffer small_tbl, recoded;
   Buffer grp_sc, grp_digits, grp_partials, grp_ok, row_map;
+  Buffer grp_ws, grp_wf, grp_dyn;             // window sums of the groups, their flags, the groups' proof-point sums
   Buffer grp_fail, grp_fail_sum, rechk_pts;   // failed groups: list | located candidate, their sums S1; sums of the re-checked transactions
   // the batch in flight, kept for the (never expected) ungrouped re-run when a located transaction does not explain its group
   struct LastBatch { bool valid = false, has_prep = false; const zkgpu_pointset* ps = nullptr; std::vector<uint8_t> job, prep; } last;
@@ -100,6 +101,8 @@ struct zkgpu_ctx {
   uint64_t regroup_fallbacks = 0;
   int group_size = 16;             // transactions per group check (1 = every transaction on its own)
   bool serial = false;             // measurement aid: the whole DAG of a batch on one stream
+  int horner_mode = 0;             // 0 automatic, 1 one chain per transaction, 2 one per group (+ the failed groups' transactions)
+  std::atomic<uint32_t> fail_permille{0};   // root context: share of failed groups in the batch finished last (any fork)
   hipEvent_t ev_dig = nullptr, ev_u = nullptr;
   Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
   Buffer coal_com, coal_proofs, coal_r;  // merged inputs of the batches a zkgpu_verifier runs as one (session.hpp, tickets)
@@ -238,6 +241,7 @@ inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + pe
 // multiplexes them in software (measured: 100-200 ms per step beyond that)
 constexpr int STREAM_SETS = 2;
 constexpr int MAX_FORKS = 9;
+constexpr uint32_t HORNER_PER_TX_PERMILLE = 10;   // share of failed groups beyond which every transaction gets its own Horner chain up front
 constexpr size_t LOCATE_MIN_BATCH = 2048;      // transactions per batch from which failed groups are located instead of re-checked in full
 constexpr size_t COOP_TRANSCRIPT_MAX = 1536;   // transactions per batch up to which the transcript runs one wavefront each
 
@@ -535,7 +539,7 @@ int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap, uint8_t* 
                        (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p,
                        (const uint32_t*)c->msm_fail.p, (uint8_t*)c->accept.p,
                        values ? (uint32_t*)c->values.p : (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)B, jd.w,
-                       jd.n_windows);
+                       jd.n_windows, (const uint32_t*)nullptr, 0u);
   }
   {
     Launch l(c, "k_pack_bitmap");
@@ -643,7 +647,7 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
     hipLaunchKernelGGL(k_msm_finish_quad, dim3(blocks_for(4 * B, 256)), dim3(256), 0, s,
                        (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p,
                        (const uint32_t*)c->msm_fail.p, (uint8_t*)c->accept.p, (uint32_t*)nullptr,
-                       (uint32_t*)c->dynsum.p, (uint32_t)B, jd.w, jd.n_windows);
+                       (uint32_t*)c->dynsum.p, (uint32_t)B, jd.w, jd.n_windows, (const uint32_t*)nullptr, 0u);
   }
   if (job.n_static) {
     Launch l(c, "k_static_digits", s2);
@@ -680,6 +684,13 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
   if (c->profiling) prof_collect(c);
   uint32_t st;
   memcpy(&st, h + nbytes, 4);
+  if (c->group_size > 1) {             // the share of failed groups steers the next batches' Horner arrangement
+    uint32_t n_fail;
+    memcpy(&n_fail, h + nbytes + 36, 4);
+    const uint64_t n_groups = (c->pending_batch + c->group_size - 1) / c->group_size;
+    zkgpu_ctx* root = c->parent ? c->parent : c;
+    root->fail_permille.store(n_groups ? (uint32_t)std::min<uint64_t>(1000, (1000ull * n_fail) / n_groups) : 0u);
+  }
   if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
   memcpy(accept_bitmap, h, nbytes);
   return ZKGPU_OK;
@@ -751,6 +762,9 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     TRY(ensure(c, c->row_map, B * 4));
     TRY(ensure(c, c->grp_fail, (size_t)n_groups * 12));
     TRY(ensure(c, c->grp_fail_sum, (size_t)n_groups * EXT_WORDS * 4));
+    TRY(ensure(c, c->grp_ws, (size_t)n_groups * 64 * EXT_WORDS * 4));
+    TRY(ensure(c, c->grp_wf, (size_t)n_groups * 64 * 4));
+    TRY(ensure(c, c->grp_dyn, (size_t)n_groups * EXT_WORDS * 4));
     TRY(ensure(c, c->rechk_pts, B * EXT_WORDS * 4));
   }
   TRY(ensure(c, c->accept, B));
@@ -879,12 +893,30 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   }
   HIP_TRY(c, hipEventRecord(c->ev_sm, H1));
   HIP_TRY(c, hipStreamWaitEvent(L, c->ev_sm, 0));
-  {
+  // Horner chains (the longest dependent chain of a batch): one per GROUP over the summed windows of its transactions,
+  // the transactions of a failed group getting theirs after k_group_combine has named the group -- a third less point
+  // arithmetic when few groups fail, but two chains in a row for the groups that do.  When many fail (the share of
+  // failed groups in the batch this context family finished last, root->fail_permille), one chain per transaction
+  // up front is faster.  Same verdicts either way.
+  zkgpu_ctx* root = c->parent ? c->parent : c;
+  const bool group_first = group > 1 && (c->horner_mode == 2 || (c->horner_mode == 0 && root->fail_permille.load() < HORNER_PER_TX_PERMILLE));
+  if (group_first) {
+    {
+      Launch l(c, "k_group_windows", L);
+      hipLaunchKernelGGL(k_group_windows, dim3(blocks_for((uint64_t)n_groups * 64, 256)), dim3(256), 0, L,
+                         (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p, (const uint32_t*)c->msm_fail.p,
+                         job.d_wellformed, (uint32_t)B, group, 64u, (uint32_t*)c->grp_ws.p, (uint32_t*)c->grp_wf.p);
+    }
+    Launch l(c, "k_msm_finish_quad", L);
+    hipLaunchKernelGGL(k_msm_finish_quad, dim3(blocks_for(4 * (uint64_t)n_groups, 256)), dim3(256), 0, L,
+                       (const uint32_t*)c->grp_ws.p, (const uint32_t*)c->grp_wf.p, (const uint32_t*)nullptr, (uint8_t*)nullptr,
+                       (uint32_t*)nullptr, (uint32_t*)c->grp_dyn.p, n_groups, 4, 64, (const uint32_t*)nullptr, 0u);
+  } else {
     Launch l(c, "k_msm_finish_quad", L);
     hipLaunchKernelGGL(k_msm_finish_quad, dim3(blocks_for(4 * B, 256)), dim3(256), 0, L,
                        (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p,
                        (const uint32_t*)c->msm_fail.p, (uint8_t*)c->accept.p, (uint32_t*)nullptr,
-                       (uint32_t*)c->dynsum.p, (uint32_t)B, 4, 64);
+                       (uint32_t*)c->dynsum.p, (uint32_t)B, 4, 64, (const uint32_t*)nullptr, 0u);
   }
   HIP_TRY(c, hipStreamWaitEvent(L, c->ev_sa, 0));
   if (group > 1) {
@@ -898,10 +930,18 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     {
       Launch l(c, "k_group_combine", L);        // verdicts of the groups; a failed group also gets its locating scalars
       hipLaunchKernelGGL(k_group_combine, dim3(n_groups), dim3(256), 0, L, (const uint32_t*)c->grp_partials.p,
-                         (uint32_t)(W * Pg), (const uint32_t*)c->dynsum.p, (const uint32_t*)c->msm_fail.p,
+                         (uint32_t)(W * Pg), group_first ? (const uint32_t*)c->grp_dyn.p : (const uint32_t*)nullptr,
+                         (const uint32_t*)c->dynsum.p, (const uint32_t*)c->msm_fail.p,
                          job.d_wellformed, (uint32_t)B, group, (uint8_t*)c->accept2.p, grp_state, fail_list,
                          (uint32_t*)c->grp_fail_sum.p, n_fail, job.d_st_scalars, ns, (uint32_t*)c->grp_sc.p,
                          (int16_t*)c->grp_digits.p, ps->tbl_w, W, locate ? 1u : 0u, (uint32_t*)c->row_map.p, n_recheck, cand);
+    }
+    if (group_first) {
+      Launch l(c, "k_msm_finish_quad", L);      // Horner chains of the transactions of the failed groups only
+      hipLaunchKernelGGL(k_msm_finish_quad, dim3(blocks_for(4 * B, 256)), dim3(256), 0, L,
+                         (const uint32_t*)c->window_sums.p, (const uint32_t*)c->window_flags.p,
+                         (const uint32_t*)c->msm_fail.p, (uint8_t*)c->accept.p, (uint32_t*)nullptr,
+                         (uint32_t*)c->dynsum.p, (uint32_t)B, 4, 64, (const uint32_t*)grp_state, group);
     }
     // failed groups (kernels.hpp, "group checks"): one more multiscalar multiplication each LOCATES the bad
     // transaction, which alone is then checked on its own.  Grids are sized for the worst case; lanes beyond the
@@ -1092,6 +1132,7 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
     c->group_size = parent->group_size;
     c->transcript_mode = parent->transcript_mode;
     c->locate_mode = parent->locate_mode;
+    c->horner_mode = parent->horner_mode;
   } else {
     ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
          hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
@@ -1172,7 +1213,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
                     &c->in_st_offsets, &c->dyn_rows, &c->bins, &c->block_sums, &c->entries, &c->buckets,
                     &c->partials, &c->partial_flags, &c->window_sums, &c->window_flags, &c->msm_fail,
                     &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform,
-                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->small_tbl, &c->recoded, &c->grp_sc, &c->grp_digits, &c->grp_partials, &c->grp_ok, &c->row_map, &c->grp_fail, &c->grp_fail_sum, &c->rechk_pts, &c->prep_com, &c->prep_proofs, &c->prep_r,
+                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->small_tbl, &c->recoded, &c->grp_sc, &c->grp_digits, &c->grp_partials, &c->grp_ok, &c->row_map, &c->grp_fail, &c->grp_fail_sum, &c->rechk_pts, &c->grp_ws, &c->grp_wf, &c->grp_dyn, &c->prep_com, &c->prep_proofs, &c->prep_r,
                     &c->prep_pw, &c->prep_ch, &c->prep_wf, &c->prep_dyn_sc, &c->prep_dyn_pt, &c->prep_st_sc,
                     &c->prep_absorb, &c->prep_raw, &c->ipa_lv, &c->ipa_rv, &c->ipa_cg, &c->ipa_ch, &c->ipa_w, &c->ipa_u,
                     &c->coal_com, &c->coal_proofs, &c->coal_r};
@@ -1359,6 +1400,15 @@ int zkgpu_set_serial(zkgpu_ctx* c, int on) {
   if (!c) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   c->serial = on != 0;
+  return ZKGPU_OK;
+}
+
+// Horner chains of a batch checked in groups: 0 automatic (by the share of failed groups in the last finished batch),
+// 1 one chain per transaction up front, 2 one per group and then one per transaction of the failed groups
+int zkgpu_set_horner_mode(zkgpu_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 2) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->horner_mode = mode;
   return ZKGPU_OK;
 }
 
