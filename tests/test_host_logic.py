@@ -177,6 +177,16 @@ def test_product_prover_equals_oracle_prover(host, oracle, shape, cap):
         assert com.raw == want_com
         assert proof.raw[: plen.value] == want_proof
         assert oracle.cloak_verify(com.raw, n_in, n_out, proof.raw[: plen.value], bytes(range(64)))
+        # the DEVICE prover's phase functions (prover_dev.hpp: transcript, TranscriptRng, witness from the traced
+        # description, flattening, polynomials -- what the k_pv_* kernels run, one workgroup per proof) on the host
+        com2 = C.create_string_buffer(64 * len(q))
+        proof2 = C.create_string_buffer(4096)
+        plen2 = C.c_size_t(0)
+        rc = host.zkhost_prove_dev_cloak(n_in, n_out, qa, b"".join(f), seed, gens, C.c_size_t(cap), com2, proof2,
+                                         C.c_size_t(4096), C.byref(plen2))
+        assert rc == 0
+        assert com2.raw == want_com
+        assert proof2.raw[: plen2.value] == want_proof
 
 
 def test_lazy_scalar_form_equals_canonical(host):
@@ -324,3 +334,14 @@ def test_described_prover_equals_oracle_gadget_prover(host, oracle, kind, param)
     assert rc == 0
     assert com.raw == want_com and proof.raw[: plen.value] == want_proof
     assert oracle.gadget_verify(kind, param, com.raw, proof.raw[: plen.value], hashlib.shake_256(b"r").digest(64))
+    # the device prover's phase functions on the host (prover_dev.hpp)
+    com2 = C.create_string_buffer(32 * m)
+    proof2 = C.create_string_buffer(4096)
+    plen2 = C.c_size_t(0)
+    rc = host.zkhost_prove_dev_r1cs(GADGET_LABEL, m, n1, n, len(labels), lab, len(cons), (C.c_uint64 * len(offs))(*offs),
+                                    (C.c_uint8 * nt)(*kinds), (C.c_uint32 * nt)(*idx), coeff, (C.c_int32 * nt)(*chal),
+                                    (C.c_uint32 * nt)(*power), (C.c_uint32 * max(len(mult_def), 1))(*mult_def),
+                                    b"".join(v.to_bytes(32, "little") for v in values), gv, C.c_size_t(len(given)), seed, gens,
+                                    C.c_size_t(cap), com2, proof2, C.c_size_t(4096), C.byref(plen2))
+    assert rc == 0
+    assert com2.raw == want_com and proof2.raw[: plen2.value] == want_proof

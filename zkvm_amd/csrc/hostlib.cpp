@@ -7,6 +7,7 @@
 #include "r1cs_prover.hpp"
 #include "transcript_tape.hpp"
 #include "keccak_coop.hpp"
+#include "prover_plan.hpp"
 
 #include <array>
 #include <map>
@@ -420,4 +421,174 @@ int zkhost_r1cs_prove(const char* label, uint32_t m, uint32_t n1, uint32_t n, ui
   return 0;
 }
 
+}  // extern "C"
+
+// ---- the DEVICE prover (prover_dev.hpp) run on the host with one "thread" per proof: the same phase functions the
+// kernels call, the reference multiscalar multiplication of this library between them.  CPU tests compare the bytes
+// with the host prover's and the oracle's.
+namespace {
+struct PvHostEnv {
+  uint32_t st[52];
+  uint32_t tid() const { return 0; }
+  uint32_t nt() const { return 1; }
+  void sync() {}
+  void sum(scl*, int) {}
+  uint32_t* strobe() { return st; }
+};
+
+void words_of(const uint8_t* b, size_t n_words, std::vector<uint32_t>& out) {
+  for (size_t i = 0; i < n_words; ++i) out.push_back((uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24));
+}
+Scalar scalar_of_words(const uint32_t* w) {
+  uint8_t wide[64] = {0};
+  for (int i = 0; i < 8; ++i) for (int b = 0; b < 4; ++b) wide[4 * i + b] = (uint8_t)(w[i] >> (8 * b));
+  return Scalar::from_wide(wide);
+}
+void rows_points(const std::vector<ge>& gens, const uint32_t* scalars, const PvRows& lay, std::vector<uint32_t>& out_words) {
+  std::vector<MsmRow> rows(lay.offsets.size() - 1);
+  for (size_t r = 0; r + 1 < lay.offsets.size(); ++r)
+    for (uint64_t k = lay.offsets[r]; k < lay.offsets[r + 1]; ++k) rows[r].add(scalar_of_words(scalars + 8 * k), lay.index[k]);
+  std::vector<uint8_t> pts;
+  host_rows(gens, rows, pts);
+  out_words.clear();
+  words_of(pts.data(), pts.size() / 4, out_words);
+}
+
+int pv_emulate(const R1csDesc& d, const std::vector<uint32_t>& mult_def, const std::vector<uint32_t>& values, const std::vector<uint32_t>& blindings,
+               const std::vector<uint32_t>& given, const uint8_t seed[32], const uint8_t* generators, size_t cap, uint8_t* commitments,
+               uint8_t* proof, size_t proof_cap, size_t* proof_len_out) {
+  std::vector<ge> gens(2 + 2 * cap);
+  for (size_t i = 0; i < gens.size(); ++i) {
+    uint32_t w[8];
+    std::memcpy(w, generators + 32 * i, 32);
+    if (!ristretto_decode(gens[i], w)) return -1;
+  }
+  PvHostPlan hp;
+  try { hp = pv_build(d, mult_def, cap); } catch (const std::exception&) { return -3; }
+  const PvShape& sh = hp.sh;
+  if (given.size() != 16 * (size_t)sh.n_given || values.size() != 8 * (size_t)sh.m || sh.proof_len > proof_cap) return -4;
+  const PvPlan P = hp.view();
+  std::vector<uint32_t> state(sh.state_words, 0), rows0(16 * std::max<uint32_t>(sh.m, 1)), rows1(8 * std::max<uint32_t>(sh.r1_terms, 1)), rows2(8 * std::max<uint32_t>(sh.r2_terms, 1)),
+      rows3(5 * 16), lv(8 * sh.pn), rv(8 * sh.pn), cg(8 * sh.pn), ch(8 * sh.pn), w(8), uu(16), rng_seed;
+  uint8_t rs[32];
+  R1csProver::derive(seed, "rng", 0, rs, 32);
+  words_of(rs, 8, rng_seed);
+  std::vector<uint8_t> pbytes(sh.proof_stride, 0);
+  PvBatch B{};
+  B.state = state.data(); B.values = values.data(); B.blindings = blindings.data(); B.given = given.empty() ? values.data() : given.data();
+  B.rng_seed = rng_seed.data(); B.proofs = pbytes.data(); B.rows0 = rows0.data(); B.rows1 = rows1.data(); B.rows2 = rows2.data(); B.rows3 = rows3.data();
+  B.ipa_lv = lv.data(); B.ipa_rv = rv.data(); B.ipa_cg = cg.data(); B.ipa_ch = ch.data(); B.ipa_w = w.data(); B.ipa_u = uu.data();
+  PvHostEnv env;
+  std::vector<uint32_t> pts;
+  pv_phase0(env, sh, B, 0);
+  rows_points(gens, rows0.data(), pv_rows_pairs(sh.m), pts);
+  for (size_t i = 0; i < 8 * (size_t)sh.m; ++i) for (int b = 0; b < 4; ++b) commitments[4 * i + b] = (uint8_t)(pts[i] >> (8 * b));
+  pv_phase1(env, sh, P, B, 0, pts.data());
+  rows_points(gens, rows1.data(), pv_rows_commit(1, 0, sh.n1, cap, false), pts);
+  pv_phase2(env, sh, P, B, 0, pts.data());
+  rows_points(gens, rows2.data(), pv_rows_commit(1, sh.n1, sh.n, cap, true), pts);
+  pv_phase3(env, sh, P, B, 0, pts.data());
+  rows_points(gens, rows3.data(), pv_rows_pairs(5), pts);
+  pv_phase4(env, sh, P, B, 0, pts.data());
+  if (state[sh.o_flag]) return -2;
+  // the inner-product rounds (on the device: k_ipa_round + the tables); here with the host's scalars
+  std::vector<Scalar> L(sh.pn), R(sh.pn), G(sh.pn), H(sh.pn);
+  for (uint32_t i = 0; i < sh.pn; ++i) {
+    uint32_t t[8];
+    scm a; for (int q = 0; q < 8; ++q) a.v[q] = lv[8 * i + q];
+    scm_to_words(t, a); L[i] = scalar_of_words(t);
+    for (int q = 0; q < 8; ++q) a.v[q] = rv[8 * i + q];
+    scm_to_words(t, a); R[i] = scalar_of_words(t);
+    G[i] = scalar_of_words(&cg[8 * i]); H[i] = scalar_of_words(&ch[8 * i]);
+  }
+  const Scalar wq = scalar_of_words(w.data());
+  size_t len = sh.pn;
+  for (uint32_t round = 0; round < sh.k; ++round) {
+    const size_t half = len / 2;
+    Scalar cL = Scalar::zero(), cR = Scalar::zero();
+    for (size_t j = 0; j < half; ++j) { cL += L[j] * R[half + j]; cR += L[half + j] * R[j]; }
+    std::vector<MsmRow> rows(2);
+    for (size_t idx = 0; idx < sh.pn; ++idx) {
+      const size_t j = idx % len;
+      const bool hi = j >= half;
+      const size_t jj = hi ? j - half : j;
+      if (hi) { rows[0].add(L[jj] * G[idx], (uint32_t)(2 + idx)); rows[1].add(R[jj] * H[idx], (uint32_t)(2 + cap + idx)); }
+      else { rows[0].add(R[half + jj] * H[idx], (uint32_t)(2 + cap + idx)); rows[1].add(L[half + jj] * G[idx], (uint32_t)(2 + idx)); }
+    }
+    rows[0].add(cL * wq, 0);
+    rows[1].add(cR * wq, 0);
+    std::vector<uint8_t> lr;
+    host_rows(gens, rows, lr);
+    std::vector<uint32_t> lrw;
+    words_of(lr.data(), 16, lrw);
+    pv_ipa_round(env, sh, B, 0, round, lrw.data());
+    const Scalar u = scalar_of_words(uu.data()), ui = scalar_of_words(uu.data() + 8);
+    for (size_t j = 0; j < half; ++j) {
+      L[j] = L[j] * u + L[half + j] * ui;
+      R[j] = R[j] * ui + R[half + j] * u;
+    }
+    for (size_t idx = 0; idx < sh.pn; ++idx) {
+      const bool hi = (idx % len) >= half;
+      G[idx] *= hi ? u : ui;
+      H[idx] *= hi ? ui : u;
+    }
+    len = half;
+  }
+  uint8_t ab[64];
+  L[0].to_bytes(ab); R[0].to_bytes(ab + 32);
+  std::vector<uint32_t> abw;
+  words_of(ab, 16, abw);
+  pv_finish(sh, B, 0, abw.data());
+  std::memcpy(proof, pbytes.data(), sh.proof_len);
+  *proof_len_out = sh.proof_len;
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+int zkhost_prove_dev_cloak(uint32_t n_in, uint32_t n_out, const uint64_t* quantities, const uint8_t* flavors, const uint8_t seed[32],
+                           const uint8_t* generators, size_t gens_capacity, uint8_t* commitments, uint8_t* proof, size_t proof_cap,
+                           size_t* proof_len_out) {
+  R1csDesc d;
+  std::vector<uint32_t> md, values, blindings, given;
+  PvCloakTrace::trace(n_in, n_out, d, md);
+  for (size_t i = 0; i < (size_t)n_in + n_out; ++i) {
+    uint8_t b[32];
+    Scalar::from_u64(quantities[i]).to_bytes(b); words_of(b, 8, values);
+    words_of(flavors + 32 * i, 8, values);
+    R1csProver::derive_scalar(seed, "q_blinding", i).to_bytes(b); words_of(b, 8, blindings);
+    R1csProver::derive_scalar(seed, "f_blinding", i).to_bytes(b); words_of(b, 8, blindings);
+  }
+  pv_cloak_given(n_in, n_out, quantities, flavors, given);
+  return pv_emulate(d, md, values, blindings, given, seed, generators, gens_capacity, commitments, proof, proof_cap, proof_len_out);
+}
+
+int zkhost_prove_dev_r1cs(const char* label, uint32_t m, uint32_t n1, uint32_t n, uint32_t n_chal, const char* const* chal_labels,
+                          uint32_t n_cons, const uint64_t* term_offsets, const uint8_t* kinds, const uint32_t* idx,
+                          const uint8_t* coeff, const int32_t* chal, const uint32_t* power, const uint32_t* mult_def,
+                          const uint8_t* values, const uint8_t* given, size_t n_given, const uint8_t seed[32],
+                          const uint8_t* generators, size_t gens_capacity, uint8_t* commitments, uint8_t* proof, size_t proof_cap,
+                          size_t* proof_len_out) {
+  R1csDesc d;
+  d.label = label; d.m = m; d.n1 = n1; d.n = n;
+  for (uint32_t i = 0; i < n_chal; ++i) d.chal_names.push_back(chal_labels[i]);
+  for (uint32_t q = 0; q < n_cons; ++q) {
+    std::vector<R1csDesc::Term> con;
+    for (uint64_t t = term_offsets[q]; t < term_offsets[q + 1]; ++t) {
+      Scalar c;
+      if (kinds[t] > 4 || !Scalar::from_canonical(coeff + 32 * t, c)) return -1;
+      con.push_back(R1csDesc::Term{(VarKind)kinds[t], idx[t], c, chal[t], power[t]});
+    }
+    d.cons.push_back(std::move(con));
+  }
+  std::vector<uint32_t> md(mult_def, mult_def + 2 * (size_t)n), vw, bw, gw;
+  words_of(values, 8 * (size_t)m, vw);
+  for (uint32_t i = 0; i < m; ++i) {
+    uint8_t b[32];
+    R1csProver::derive_scalar(seed, "blinding", i).to_bytes(b);
+    words_of(b, 8, bw);
+  }
+  words_of(given, 16 * n_given, gw);
+  return pv_emulate(d, md, vw, bw, gw, seed, generators, gens_capacity, commitments, proof, proof_cap, proof_len_out);
+}
 }  // extern "C"
