@@ -240,6 +240,13 @@ int zkgpu_r1cs_prove_batch(zkgpu_ctx *ctx, const zkgpu_pointset *ps, const zkgpu
                            const uint8_t *given, size_t n_given, const uint8_t *seeds, int host_threads,
                            uint8_t *commitments, uint8_t *proofs, size_t proof_stride, size_t *proof_len);
 
+/* Both provers: 0 (default) = the whole proof on the device -- Merlin transcript, TranscriptRng, witness assignment from
+ * the described system, constraint flattening, polynomial and inner-product algebra in kernels (one workgroup per
+ * proof), the multiscalar multiplications on the tables in between, nothing of a proof in the making on the host;
+ * 1 = the same algorithm on host threads in lockstep, only the multiplications and the inner-product folds on the
+ * device (the round-1 arrangement, kept for comparison).  Byte-identical proofs. */
+int zkgpu_set_prover_mode(zkgpu_ctx *ctx, int mode);
+
 /* The same with commitments, proofs and verifier randomness already resident in HBM
  * (device pointers; this is what bench.py times as one step). */
 int zkgpu_cloak_verify_batch_gpu_dev(zkgpu_ctx *ctx, const zkgpu_pointset *ps, zkgpu_cloak_plan *plan, size_t batch,

@@ -457,10 +457,15 @@ def test_described_prover_on_device_equals_oracle_and_verifies(ctx, oracle, kind
             else:
                 values[0] += 1 << (param if kind == 1 else 64)           # the bits given are those of the value mod 2^bits
         vals.append(values); givens.append(given); seeds.append(hashlib.sha256(b"dev desc prover %d %d %d" % (kind, param, i)).digest())
-    coms, proofs = R1csProver(ctx, gens, desc, mult_def, host_threads=8).prove(vals, givens, seeds)
-    for i in range(batch):
-        rc, want_com, want_proof = oracle.gadget_prove(kind, param, vals[i], seeds[i])
-        assert rc == 0 and coms[i] == want_com and proofs[i] == want_proof, i
+    try:
+        for mode in (1, 0):                                     # host threads in lockstep; the whole proof on the device
+            ctx.set_prover_mode(mode)
+            coms, proofs = R1csProver(ctx, gens, desc, mult_def, host_threads=8).prove(vals, givens, seeds)
+            for i in range(batch):
+                rc, want_com, want_proof = oracle.gadget_prove(kind, param, vals[i], seeds[i])
+                assert rc == 0 and coms[i] == want_com and proofs[i] == want_proof, (mode, i)
+    finally:
+        ctx.set_prover_mode(0)
     r = hashlib.shake_256(b"desc prover r").digest(64 * batch)
     want = [int(oracle.gadget_verify(kind, param, coms[i], proofs[i], r[64 * i: 64 * i + 64])) for i in range(batch)]
     assert want == [0 if i == 5 else 1 for i in range(batch)]

@@ -250,10 +250,15 @@ def test_gpu_prover_equals_oracle_prover_and_verifies(ctx, oracle, shape):
         q, f = _witness(rng, n_in, n_out, two=(i & 1) and n_in >= 2 and n_out >= 2)
         qs.append(q); fs.append(f); seeds.append(hashlib.sha256(b"gpu prover %d" % i).digest())
     qs[5] = list(qs[5]); qs[5][-1] += 1                        # unbalanced: outputs exceed inputs by one
-    txs = Prover(ctx, gens, host_threads=8).prove(n_in, n_out, qs, fs, seeds)
-    for i in range(batch):
-        rc, want_com, want_proof, _ = oracle.cloak_prove(qs[i], fs[i], n_in, n_out, seeds[i])
-        assert rc == 0 and txs[i].commitments == want_com and txs[i].proof == want_proof, i
+    try:
+        for mode in (1, 0):                                     # host threads in lockstep; the whole proof on the device
+            ctx.set_prover_mode(mode)
+            txs = Prover(ctx, gens, host_threads=8).prove(n_in, n_out, qs, fs, seeds)
+            for i in range(batch):
+                rc, want_com, want_proof, _ = oracle.cloak_prove(qs[i], fs[i], n_in, n_out, seeds[i])
+                assert rc == 0 and txs[i].commitments == want_com and txs[i].proof == want_proof, (mode, i)
+    finally:
+        ctx.set_prover_mode(0)
     r = hashlib.shake_256(b"prover r").digest(64 * batch)
     want = [int(oracle.cloak_verify(t.commitments, n_in, n_out, t.proof, r[64 * i: 64 * i + 64])) for i, t in enumerate(txs)]
     assert want == [0 if i == 5 else 1 for i in range(batch)]

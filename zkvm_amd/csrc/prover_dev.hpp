@@ -368,7 +368,10 @@ ZK_HD void pv_phase2(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
   }
   env.sync();
   const uint32_t n2 = sh.n - sh.n1;
-  if (n2 == 0) return;                // three empty rows: the identity
+  if (n2 == 0) {                      // three empty rows (the identity), no second-phase blinding factors
+    if (env.tid() == 0) for (int k = PV_IBL2; k <= PV_SBL2; ++k) pv_st(V.at(sh.o_blind, k), scm_zero());
+    return;
+  }
   pv_assign(env, V, P, B, proof, sh.n1, sh.n);
   if (env.tid() == 0) {
     PvStrobe rng{env.strobe()};

@@ -1,0 +1,86 @@
+// prover_kernels.hpp -- the phase functions of prover_dev.hpp as kernels: one workgroup per proof, thread 0 on the
+// transcript, all threads on the vectors.
+#pragma once
+#include "prover_dev.hpp"
+
+namespace zk {
+
+constexpr uint32_t PV_LDS_WORDS = 52 + 4 * 6 * 10;   // STROBE scratch | per-wavefront partial sums
+
+struct PvDevEnv {
+  uint32_t* lds;
+  __device__ __forceinline__ uint32_t tid() const { return threadIdx.x; }
+  __device__ __forceinline__ uint32_t nt() const { return blockDim.x; }
+  __device__ __forceinline__ void sync() { __threadfence_block(); __syncthreads(); }
+  __device__ __forceinline__ uint32_t* strobe() { return lds; }
+  // sums over the workgroup, left in thread 0 (inputs tight and < 2 l; at most four wavefronts, count <= 6)
+  __device__ inline void sum(scl* v, int count) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;
+    for (int k = 0; k < count; ++k) {
+#pragma unroll 1
+      for (int delta = 32; delta >= 1; delta >>= 1) {
+        scl o;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) o.v[q] = (uint32_t)__shfl_down((int)v[k].v[q], delta);
+        v[k] = scl_add_c(v[k], o);
+      }
+      if (lane == 0) for (int q = 0; q < 10; ++q) lds[52 + (wave * 6 + k) * 10 + q] = v[k].v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int k = 0; k < count; ++k)
+        for (uint32_t wv = 1; wv < waves; ++wv) {
+          scl o;
+          for (int q = 0; q < 10; ++q) o.v[q] = lds[52 + (wv * 6 + k) * 10 + q];
+          v[k] = scl_add_c(v[k], o);
+        }
+    }
+    __syncthreads();
+  }
+};
+
+__global__ void __launch_bounds__(64)
+k_pv_phase0(PvShape sh, PvBatch B) {
+  __shared__ uint32_t lds[PV_LDS_WORDS];
+  PvDevEnv env{lds};
+  pv_phase0(env, sh, B, blockIdx.x);
+}
+__global__ void __launch_bounds__(256)
+k_pv_phase1(PvShape sh, PvPlan P, PvBatch B, const uint32_t* __restrict__ points) {
+  __shared__ uint32_t lds[PV_LDS_WORDS];
+  PvDevEnv env{lds};
+  pv_phase1(env, sh, P, B, blockIdx.x, points + (uint64_t)blockIdx.x * sh.m * 8);
+}
+__global__ void __launch_bounds__(256)
+k_pv_phase2(PvShape sh, PvPlan P, PvBatch B, const uint32_t* __restrict__ points) {
+  __shared__ uint32_t lds[PV_LDS_WORDS];
+  PvDevEnv env{lds};
+  pv_phase2(env, sh, P, B, blockIdx.x, points + (uint64_t)blockIdx.x * 24);
+}
+__global__ void __launch_bounds__(256)
+k_pv_phase3(PvShape sh, PvPlan P, PvBatch B, const uint32_t* __restrict__ points) {
+  __shared__ uint32_t lds[PV_LDS_WORDS];
+  PvDevEnv env{lds};
+  pv_phase3(env, sh, P, B, blockIdx.x, points + (uint64_t)blockIdx.x * 24);
+}
+__global__ void __launch_bounds__(256)
+k_pv_phase4(PvShape sh, PvPlan P, PvBatch B, const uint32_t* __restrict__ points) {
+  __shared__ uint32_t lds[PV_LDS_WORDS];
+  PvDevEnv env{lds};
+  pv_phase4(env, sh, P, B, blockIdx.x, points + (uint64_t)blockIdx.x * 40);
+}
+__global__ void __launch_bounds__(64)
+k_pv_ipa(PvShape sh, PvBatch B, uint32_t round, const uint32_t* __restrict__ points) {
+  __shared__ uint32_t lds[PV_LDS_WORDS];
+  PvDevEnv env{lds};
+  pv_ipa_round(env, sh, B, blockIdx.x, round, points + (uint64_t)blockIdx.x * 16);
+}
+__global__ void __launch_bounds__(256)
+k_pv_finish(PvShape sh, PvBatch B, const uint32_t* __restrict__ ab, uint32_t batch, uint32_t* __restrict__ status) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= batch) return;
+  pv_finish(sh, B, p, ab + (uint64_t)p * 16);
+  if (B.state[(uint64_t)p * sh.state_words + sh.o_flag]) atomicOr(status, 1u);
+}
+
+}  // namespace zk

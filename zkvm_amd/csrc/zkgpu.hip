@@ -32,6 +32,8 @@
 #include "prep_kernels.hpp"
 #include "r1cs_prover.hpp"
 #include "ipa_kernels.hpp"
+#include "prover_plan.hpp"
+#include "prover_kernels.hpp"
 
 using namespace zk;
 
@@ -107,6 +109,10 @@ struct zkgpu_ctx {
   Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
   Buffer coal_com, coal_proofs, coal_r;  // merged inputs of the batches a zkgpu_verifier runs as one (session.hpp, tickets)
   Buffer ipa_lv, ipa_rv, ipa_cg, ipa_ch, ipa_w, ipa_u;   // prover: the inner-product argument's vectors (ipa_kernels.hpp)
+  // the device prover (prover_kernels.hpp): constant tables, per-proof state, inputs, the rows of the phases' multiscalar
+  // multiplications with their offsets / generator indices, the points coming back, the proofs
+  Buffer pv_plan, pv_state, pv_in, pv_rows0, pv_rows1, pv_rows2, pv_rows3, pv_lay, pv_pts, pv_com, pv_ab, pv_proofs;
+  int prover_mode = 0;             // 0: everything between the multiplications on the device, 1: host threads in lockstep
   Buffer prep_absorb, prep_raw;    // cooperative transcript: absorbed words per segment, raw challenge bytes
   int locate_mode = 0;             // failed groups: 0 automatic, 1 always re-check every transaction, 2 always locate the culprit
   int transcript_mode = 0;         // 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction
@@ -1213,7 +1219,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
                     &c->in_st_offsets, &c->dyn_rows, &c->bins, &c->block_sums, &c->entries, &c->buckets,
                     &c->partials, &c->partial_flags, &c->window_sums, &c->window_flags, &c->msm_fail,
                     &c->status, &c->accept, &c->bitmap, &c->ok_bytes, &c->values, &c->uniform,
-                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->small_tbl, &c->recoded, &c->grp_sc, &c->grp_digits, &c->grp_partials, &c->grp_ok, &c->row_map, &c->grp_fail, &c->grp_fail_sum, &c->rechk_pts, &c->grp_ws, &c->grp_wf, &c->grp_dyn, &c->prep_com, &c->prep_proofs, &c->prep_r,
+                    &c->digits, &c->st_partials, &c->dynsum, &c->accept2, &c->bin_order, &c->class_count, &c->part_hist, &c->part_entries, &c->part_lo, &c->dec_scratch, &c->heavy, &c->small_tbl, &c->recoded, &c->grp_sc, &c->grp_digits, &c->grp_partials, &c->grp_ok, &c->row_map, &c->grp_fail, &c->grp_fail_sum, &c->rechk_pts, &c->grp_ws, &c->grp_wf, &c->grp_dyn, &c->pv_plan, &c->pv_state, &c->pv_in, &c->pv_rows0, &c->pv_rows1, &c->pv_rows2, &c->pv_rows3, &c->pv_lay, &c->pv_pts, &c->pv_com, &c->pv_ab, &c->pv_proofs, &c->prep_com, &c->prep_proofs, &c->prep_r,
                     &c->prep_pw, &c->prep_ch, &c->prep_wf, &c->prep_dyn_sc, &c->prep_dyn_pt, &c->prep_st_sc,
                     &c->prep_absorb, &c->prep_raw, &c->ipa_lv, &c->ipa_rv, &c->ipa_cg, &c->ipa_ch, &c->ipa_w, &c->ipa_u,
                     &c->coal_com, &c->coal_proofs, &c->coal_r};
@@ -1400,6 +1406,15 @@ int zkgpu_set_serial(zkgpu_ctx* c, int on) {
   if (!c) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   c->serial = on != 0;
+  return ZKGPU_OK;
+}
+
+// The provers (zkgpu_cloak_prove_batch, zkgpu_r1cs_prove_batch): 0 everything between the multiscalar multiplications on
+// the device (prover_kernels.hpp), 1 host threads in lockstep (r1cs_prover.hpp).  Same proofs.
+int zkgpu_set_prover_mode(zkgpu_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 1) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->prover_mode = mode;
   return ZKGPU_OK;
 }
 
@@ -1664,6 +1679,167 @@ int ipa_on_device(zkgpu_ctx* c, const zkgpu_pointset* ps, std::vector<std::uniqu
   return ZKGPU_OK;
 }
 
+// ---- the device prover ------------------------------------------------------------------------------------
+// f(i) for i < n on up to `threads` host threads (0: hardware concurrency)
+void host_parallel(size_t n, int threads, const std::function<void(size_t)>& f) {
+  const int nt = (int)std::max<size_t>(1, std::min<size_t>(n / 16 + 1, (size_t)std::min<int>(threads > 0 ? threads : (int)std::thread::hardware_concurrency(), 256)));
+  if (nt <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { for (size_t i = (size_t)t; i < n; i += (size_t)nt) f(i); });
+  for (auto& t : th) t.join();
+}
+
+// values of `rows` multiscalar multiplications over the tables, everything resident: queued on the context's stream,
+// encodings written to d_out (32 bytes per row)
+int msm_ps_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t rows, uint64_t n, const uint32_t* d_scalars, const uint32_t* d_index,
+               const uint64_t* d_offsets, uint32_t* d_out) {
+  hipStream_t s = c->stream;
+  const int W = ps->tbl_W;
+  const int P = (int)std::max<uint64_t>(1, std::min<uint64_t>(64, (131072 + rows * W - 1) / (rows * W)));
+  const uint64_t n_lanes = (uint64_t)rows * W * P;
+  TRY(ensure(c, c->status, 64));
+  TRY(ensure(c, c->digits, std::max<uint64_t>(n, 1) * W * 2));
+  TRY(ensure(c, c->st_partials, n_lanes * EXT_WORDS * 4));
+  if (n) {
+    Launch l(c, "k_static_digits");
+    hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_scalars, (int16_t*)c->digits.p, n, ps->tbl_w, W,
+                       (uint32_t*)c->status.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
+  }
+  {
+    Launch l(c, "k_static_accumulate");
+    hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s, (const int16_t*)c->digits.p, d_offsets,
+                       d_index, (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)rows, n,
+                       (uint32_t*)c->st_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+  }
+  {
+    Launch l(c, "k_static_values");
+    hipLaunchKernelGGL(k_static_values, dim3((unsigned)rows), dim3(64), 0, s, (const uint32_t*)c->st_partials.p, (uint32_t)(W * P), d_out);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return ZKGPU_OK;
+}
+
+// Proves `batch` statements of one described system.  Host: the constant tables (once per call), the inputs' upload,
+// a queue of kernels; device: everything else.  values / blindings: batch x m x 32 bytes (any 256-bit values, reduced
+// on the device), given: batch x n_given x 64, rng_seeds: batch x 32.
+int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, size_t batch, const uint8_t* values, const uint8_t* blindings,
+                 const uint8_t* given, const uint8_t* rng_seeds, uint8_t* commitments, uint8_t* proofs, size_t proof_stride, size_t* proof_len) {
+  const PvShape& sh = hp.sh;
+  if (sh.proof_len > proof_stride) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  hipStream_t s = c->stream;
+  // constant tables: one blob
+  std::vector<uint32_t> blob;
+  auto put = [&blob](const std::vector<uint32_t>& v) { const size_t at = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); while (blob.size() & 3) blob.push_back(0); return at; };
+  const size_t o_init = put(hp.init), o_mc = put(hp.mono_chal), o_mp = put(hp.mono_pow), o_co = put(hp.con_off), o_tk = put(hp.t_kind),
+               o_ti = put(hp.t_idx), o_tm = put(hp.t_mono), o_tc = put(hp.t_coef), o_md = put(hp.mult_def), o_gs = put(hp.given_slot),
+               o_to = put(hp.tgt_off), o_tinf = put(hp.term_info), o_pq = put(hp.prod_qm), o_pc = put(hp.prod_coef);
+  std::vector<uint32_t> labels((hp.chal_labels.size() + 3) / 4, 0);
+  memcpy(labels.data(), hp.chal_labels.data(), hp.chal_labels.size());
+  const size_t o_lab = put(labels);
+  TRY(upload(c, c->pv_plan, blob.data(), blob.size() * 4));
+  const uint32_t* base = (const uint32_t*)c->pv_plan.p;
+  PvPlan P;
+  P.init = base + o_init; P.chal_labels = (const uint8_t*)(base + o_lab); P.mono_chal = base + o_mc; P.mono_pow = base + o_mp;
+  P.con_off = base + o_co; P.t_kind = base + o_tk; P.t_idx = base + o_ti; P.t_mono = base + o_tm; P.t_coef = base + o_tc;
+  P.mult_def = base + o_md; P.given_slot = base + o_gs; P.tgt_off = base + o_to; P.term_info = base + o_tinf; P.prod_qm = base + o_pq;
+  P.prod_coef = base + o_pc;
+  // inputs: values | blindings | given | seeds
+  const size_t b_val = batch * sh.m * 32, b_giv = batch * (size_t)sh.n_given * 64, b_seed = batch * 32;
+  TRY(ensure(c, c->pv_in, 2 * b_val + b_giv + b_seed + 64));
+  char* in = (char*)c->pv_in.p;
+  if (b_val) {
+    HIP_TRY(c, hipMemcpyAsync(in, values, b_val, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(in + b_val, blindings, b_val, hipMemcpyHostToDevice, s));
+  }
+  if (b_giv) HIP_TRY(c, hipMemcpyAsync(in + 2 * b_val, given, b_giv, hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipMemcpyAsync(in + 2 * b_val + b_giv, rng_seeds, b_seed, hipMemcpyHostToDevice, s));
+  // rows and their scaffolding
+  const size_t cap = sh.gens_capacity;
+  const PvRows l0 = pv_rows_pairs(batch * sh.m), l1 = pv_rows_commit(batch, 0, sh.n1, cap, false),
+               l2 = pv_rows_commit(batch, sh.n1, sh.n, cap, true), l3 = pv_rows_pairs(batch * 5);
+  const size_t row_len = (size_t)sh.pn + 1, n_ipa_rows = 2 * batch;
+  std::vector<uint64_t> ipa_offs(n_ipa_rows + 1);
+  for (size_t r = 0; r <= n_ipa_rows; ++r) ipa_offs[r] = r * row_len;
+  std::vector<uint8_t> lay;
+  auto put_lay = [&lay](const void* p, size_t bytes) { const size_t at = lay.size(); lay.insert(lay.end(), (const uint8_t*)p, (const uint8_t*)p + bytes); while (lay.size() & 15) lay.push_back(0); return at; };
+  const PvRows* lays[4] = {&l0, &l1, &l2, &l3};
+  size_t o_off[4], o_idx[4];
+  for (int i = 0; i < 4; ++i) { o_off[i] = put_lay(lays[i]->offsets.data(), lays[i]->offsets.size() * 8); o_idx[i] = put_lay(lays[i]->index.data(), lays[i]->index.size() * 4); }
+  const size_t o_ipa = put_lay(ipa_offs.data(), ipa_offs.size() * 8);
+  TRY(upload(c, c->pv_lay, lay.data(), lay.size()));
+  const char* lb = (const char*)c->pv_lay.p;
+  TRY(ensure(c, c->pv_state, batch * (size_t)sh.state_words * 4));
+  TRY(ensure(c, c->pv_rows0, std::max<size_t>(batch * sh.m, 1) * 64));
+  TRY(ensure(c, c->pv_rows1, batch * (size_t)sh.r1_terms * 32));
+  TRY(ensure(c, c->pv_rows2, std::max<size_t>(batch * (size_t)sh.r2_terms, 1) * 32));
+  TRY(ensure(c, c->pv_rows3, batch * 5 * 64));
+  TRY(ensure(c, c->pv_pts, std::max<size_t>(batch * 5, batch * sh.m) * 32 + 64));
+  TRY(ensure(c, c->pv_com, std::max<size_t>(batch * sh.m, 1) * 32));
+  TRY(ensure(c, c->pv_ab, batch * 64));
+  TRY(ensure(c, c->pv_proofs, batch * (size_t)sh.proof_stride));
+  const size_t vec = (size_t)sh.pn * 32;
+  TRY(ensure(c, c->ipa_lv, batch * vec)); TRY(ensure(c, c->ipa_rv, batch * vec)); TRY(ensure(c, c->ipa_cg, batch * vec));
+  TRY(ensure(c, c->ipa_ch, batch * vec)); TRY(ensure(c, c->ipa_w, batch * 32)); TRY(ensure(c, c->ipa_u, batch * 64));
+  TRY(ensure(c, c->in_st_scalars, n_ipa_rows * row_len * 32));
+  TRY(ensure(c, c->in_st_index, n_ipa_rows * row_len * 4));
+  TRY(ensure(c, c->status, 64));
+  HIP_TRY(c, hipMemsetAsync(c->status.p, 0, 64, s));
+  PvBatch B;
+  B.state = (uint32_t*)c->pv_state.p;
+  B.values = (const uint32_t*)in; B.blindings = (const uint32_t*)(in + b_val); B.given = (const uint32_t*)(in + 2 * b_val);
+  B.rng_seed = (const uint32_t*)(in + 2 * b_val + b_giv);
+  B.proofs = (uint8_t*)c->pv_proofs.p;
+  B.rows0 = (uint32_t*)c->pv_rows0.p; B.rows1 = (uint32_t*)c->pv_rows1.p; B.rows2 = (uint32_t*)c->pv_rows2.p; B.rows3 = (uint32_t*)c->pv_rows3.p;
+  B.ipa_lv = (uint32_t*)c->ipa_lv.p; B.ipa_rv = (uint32_t*)c->ipa_rv.p; B.ipa_cg = (uint32_t*)c->ipa_cg.p; B.ipa_ch = (uint32_t*)c->ipa_ch.p;
+  B.ipa_w = (uint32_t*)c->ipa_w.p; B.ipa_u = (uint32_t*)c->ipa_u.p;
+  uint32_t* pts = (uint32_t*)c->pv_pts.p;
+  auto msm = [&](int which, const uint32_t* rows, uint32_t* out) {
+    return msm_ps_dev(c, ps, lays[which]->offsets.size() - 1, lays[which]->index.size(), rows, (const uint32_t*)(lb + o_idx[which]),
+                      (const uint64_t*)(lb + o_off[which]), out);
+  };
+  const unsigned nb = (unsigned)batch;
+  { Launch l(c, "k_pv_phase0"); hipLaunchKernelGGL(k_pv_phase0, dim3(nb), dim3(64), 0, s, sh, B); }
+  if (sh.m) TRY(msm(0, B.rows0, (uint32_t*)c->pv_com.p));
+  { Launch l(c, "k_pv_phase1"); hipLaunchKernelGGL(k_pv_phase1, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)c->pv_com.p); }
+  TRY(msm(1, B.rows1, pts));
+  { Launch l(c, "k_pv_phase2"); hipLaunchKernelGGL(k_pv_phase2, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)pts); }
+  TRY(msm(2, B.rows2, pts));
+  { Launch l(c, "k_pv_phase3"); hipLaunchKernelGGL(k_pv_phase3, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)pts); }
+  TRY(msm(3, B.rows3, pts));
+  { Launch l(c, "k_pv_phase4"); hipLaunchKernelGGL(k_pv_phase4, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)pts); }
+  size_t len = sh.pn;
+  for (uint32_t round = 0; round <= sh.k; ++round) {
+    const bool last = round == sh.k;
+    {
+      Launch l(c, "k_ipa_round");
+      hipLaunchKernelGGL(k_ipa_round, dim3(nb), dim3(256), 0, s, B.ipa_lv, B.ipa_rv, B.ipa_cg, B.ipa_ch, (const uint32_t*)B.ipa_w,
+                         (const uint32_t*)B.ipa_u, sh.pn, (uint32_t)len, (uint32_t)cap, round > 0 ? 1u : 0u, last ? 0u : 1u,
+                         (uint32_t*)c->in_st_scalars.p, (uint32_t*)c->in_st_index.p, (uint32_t*)c->pv_ab.p);
+    }
+    if (last) break;
+    TRY(msm_ps_dev(c, ps, n_ipa_rows, (uint64_t)n_ipa_rows * row_len, (const uint32_t*)c->in_st_scalars.p, (const uint32_t*)c->in_st_index.p,
+                   (const uint64_t*)(lb + o_ipa), pts));
+    { Launch l(c, "k_pv_ipa"); hipLaunchKernelGGL(k_pv_ipa, dim3(nb), dim3(64), 0, s, sh, B, round, (const uint32_t*)pts); }
+    len /= 2;
+  }
+  { Launch l(c, "k_pv_finish"); hipLaunchKernelGGL(k_pv_finish, dim3(blocks_for(batch, 256)), dim3(256), 0, s, sh, B, (const uint32_t*)c->pv_ab.p, nb, (uint32_t*)c->status.p); }
+  HIP_TRY(c, hipGetLastError());
+  std::vector<uint8_t> h_proofs(batch * (size_t)sh.proof_stride);
+  uint32_t st[2] = {0, 0};
+  HIP_TRY(c, hipMemcpyAsync(h_proofs.data(), c->pv_proofs.p, h_proofs.size(), hipMemcpyDeviceToHost, s));
+  if (sh.m) HIP_TRY(c, hipMemcpyAsync(commitments, c->pv_com.p, batch * sh.m * 32, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(st, c->status.p, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (c->profiling) prof_collect(c);
+  if (st[0] & 1u) { c->last_error = "prover: inconsistent witness (a multiplier's defining constraint cannot be solved)"; return ZKGPU_EINVAL; }
+  if (st[0] & 2u) { c->last_error = "prover: scalar out of range"; return ZKGPU_EHIP; }
+  for (size_t i = 0; i < batch; ++i) memcpy(proofs + proof_stride * i, h_proofs.data() + (size_t)sh.proof_stride * i, sh.proof_len);
+  *proof_len = sh.proof_len;
+  return ZKGPU_OK;
+}
+
 // Runs `batch` provers in lockstep: every phase of the whole batch is ONE zkgpu_msm_ps_batch over the tables.
 int prove_lockstep(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, int host_threads,
                    const std::function<std::unique_ptr<R1csProver>(size_t)>& make, uint8_t* commitments, size_t com_bytes,
@@ -1750,9 +1926,37 @@ int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_
   if (!quantities || !flavors || !seeds || ps->n < 2 + 2 * gens_capacity || n_in + n_out == 0) return ZKGPU_EINVAL;
   if (!ps->table) { c->last_error = "zkgpu_cloak_prove_batch needs zkgpu_pointset_build_tables first"; return ZKGPU_EINVAL; }
   const size_t nv = (size_t)n_in + n_out;
-  return prove_lockstep(c, ps, batch, host_threads, [&](size_t i) {
-    return cloak_prover(n_in, n_out, quantities + nv * i, flavors + 32 * nv * i, seeds + 32 * i, gens_capacity);
-  }, commitments, 64 * nv, proofs, proof_stride, proof_len);
+  if (c->prover_mode == 1)
+    return prove_lockstep(c, ps, batch, host_threads, [&](size_t i) {
+      return cloak_prover(n_in, n_out, quantities + nv * i, flavors + 32 * nv * i, seeds + 32 * i, gens_capacity);
+    }, commitments, 64 * nv, proofs, proof_stride, proof_len);
+  // the cloak as a described system (traced once), its witness queue per statement, blindings from the seeds
+  R1csDesc desc;
+  std::vector<uint32_t> md;
+  PvHostPlan hp;
+  try {
+    PvCloakTrace::trace(n_in, n_out, desc, md);
+    hp = pv_build(desc, md, gens_capacity);
+  } catch (const std::exception& e) { c->last_error = e.what(); return ZKGPU_EINVAL; }
+  const size_t m = 2 * nv;
+  std::vector<uint8_t> vals(batch * m * 32), bl(batch * m * 32), giv(batch * (size_t)hp.sh.n_given * 64), rs(batch * 32);
+  std::atomic<bool> bad{false};
+  host_parallel(batch, host_threads, [&](size_t i) {
+    const uint8_t* seed = seeds + 32 * i;
+    for (size_t j = 0; j < nv; ++j) {
+      Scalar::from_u64(quantities[nv * i + j]).to_bytes(&vals[(i * m + 2 * j) * 32]);
+      memcpy(&vals[(i * m + 2 * j + 1) * 32], flavors + 32 * (nv * i + j), 32);
+      R1csProver::derive_scalar(seed, "q_blinding", j).to_bytes(&bl[(i * m + 2 * j) * 32]);
+      R1csProver::derive_scalar(seed, "f_blinding", j).to_bytes(&bl[(i * m + 2 * j + 1) * 32]);
+    }
+    std::vector<uint32_t> gw;
+    pv_cloak_given(n_in, n_out, quantities + nv * i, flavors + 32 * nv * i, gw);
+    if (gw.size() != 16 * (size_t)hp.sh.n_given) { bad = true; return; }
+    memcpy(&giv[i * (size_t)hp.sh.n_given * 64], gw.data(), gw.size() * 4);
+    R1csProver::derive(seed, "rng", 0, &rs[32 * i], 32);
+  });
+  if (bad) { c->last_error = "prover: the cloak witness does not fit the traced gadget"; return ZKGPU_EINVAL; }
+  return prove_device(c, ps, hp, batch, vals.data(), bl.data(), giv.data(), rs.data(), commitments, proofs, proof_stride, proof_len);
 }
 
 // Proves `batch` statements of ONE described constraint system (BASELINE.json configs[4]: "R1CS proving for a
@@ -1772,23 +1976,34 @@ int zkgpu_r1cs_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, const zkgpu_r
   std::vector<uint32_t> md(2 * (size_t)desc.n, MULT_GIVEN);
   if (mult_def) md.assign(mult_def, mult_def + 2 * (size_t)desc.n);
   const size_t m = desc.m;
-  return prove_lockstep(c, ps, batch, host_threads, [&](size_t i) {
-    std::vector<Scalar> vals, bl;
-    for (size_t j = 0; j < m; ++j) {
-      uint8_t wide[64] = {0};
-      memcpy(wide, values + 32 * (m * i + j), 32);
-      vals.push_back(Scalar::from_wide(wide));
-      if (blindings) { uint8_t wb[64] = {0}; memcpy(wb, blindings + 32 * (m * i + j), 32); bl.push_back(Scalar::from_wide(wb)); }
-      else bl.push_back(R1csProver::derive_scalar(seeds + 32 * i, "blinding", j));
-    }
-    std::vector<std::pair<Scalar, Scalar>> gv;
-    for (size_t j = 0; j < n_given; ++j) {
-      uint8_t wl[64] = {0}, wr[64] = {0};
-      memcpy(wl, given + 64 * (n_given * i + j), 32); memcpy(wr, given + 64 * (n_given * i + j) + 32, 32);
-      gv.emplace_back(Scalar::from_wide(wl), Scalar::from_wide(wr));
-    }
-    return desc_prover(desc, md, std::move(vals), std::move(bl), gv, seeds + 32 * i, gens_capacity);
-  }, commitments, 32 * m, proofs, proof_stride, proof_len);
+  if (c->prover_mode == 1)
+    return prove_lockstep(c, ps, batch, host_threads, [&](size_t i) {
+      std::vector<Scalar> vals, bl;
+      for (size_t j = 0; j < m; ++j) {
+        uint8_t wide[64] = {0};
+        memcpy(wide, values + 32 * (m * i + j), 32);
+        vals.push_back(Scalar::from_wide(wide));
+        if (blindings) { uint8_t wb[64] = {0}; memcpy(wb, blindings + 32 * (m * i + j), 32); bl.push_back(Scalar::from_wide(wb)); }
+        else bl.push_back(R1csProver::derive_scalar(seeds + 32 * i, "blinding", j));
+      }
+      std::vector<std::pair<Scalar, Scalar>> gv;
+      for (size_t j = 0; j < n_given; ++j) {
+        uint8_t wl[64] = {0}, wr[64] = {0};
+        memcpy(wl, given + 64 * (n_given * i + j), 32); memcpy(wr, given + 64 * (n_given * i + j) + 32, 32);
+        gv.emplace_back(Scalar::from_wide(wl), Scalar::from_wide(wr));
+      }
+      return desc_prover(desc, md, std::move(vals), std::move(bl), gv, seeds + 32 * i, gens_capacity);
+    }, commitments, 32 * m, proofs, proof_stride, proof_len);
+  PvHostPlan hp;
+  try { hp = pv_build(desc, md, gens_capacity); } catch (const std::exception& e) { c->last_error = e.what(); return ZKGPU_EINVAL; }
+  if (hp.sh.n_given != n_given) { c->last_error = "prover: n_given does not match the multipliers without defining constraints"; return ZKGPU_EINVAL; }
+  std::vector<uint8_t> bl, rs(batch * 32);
+  if (!blindings) bl.resize(batch * m * 32);
+  host_parallel(batch, host_threads, [&](size_t i) {
+    if (!blindings) for (size_t j = 0; j < m; ++j) R1csProver::derive_scalar(seeds + 32 * i, "blinding", j).to_bytes(&bl[(i * m + j) * 32]);
+    R1csProver::derive(seeds + 32 * i, "rng", 0, &rs[32 * i], 32);
+  });
+  return prove_device(c, ps, hp, batch, values, blindings ? blindings : bl.data(), given, rs.data(), commitments, proofs, proof_stride, proof_len);
 }
 
 int zkgpu_decode_check(zkgpu_ctx* c, const uint8_t* points, size_t n, uint8_t* ok) {

@@ -154,6 +154,7 @@ def load_library():
     lib.zkgpu_set_transcript_mode.argtypes = [vp, C.c_int]
     lib.zkgpu_set_locate_mode.argtypes = [vp, C.c_int]
     lib.zkgpu_set_horner_mode.argtypes = [vp, C.c_int]
+    lib.zkgpu_set_prover_mode.argtypes = [vp, C.c_int]
     lib.zkgpu_debug_force_regroup.argtypes = [vp, C.c_int]
     lib.zkgpu_debug_force_regroup.restype = C.c_longlong
     lib.zkgpu_debug_coop_selftest.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), sz]
@@ -249,6 +250,10 @@ class Context:
         st = (C.c_uint64 * max(len(flat), 1))(*flat)
         self._check(self.lib.zkgpu_debug_coop_selftest(self.h, inp, out, st, len(states)))
         return [list(out[64 * i: 64 * i + 64]) for i in range(8)], [list(st[25 * i: 25 * i + 25]) for i in range(len(states))]
+
+    def set_prover_mode(self, mode: int) -> None:
+        """zkgpu_set_prover_mode: 0 the whole proof on the device, 1 host threads in lockstep."""
+        self._check(self.lib.zkgpu_set_prover_mode(self.h, mode))
 
     def set_horner_mode(self, mode: int) -> None:
         """zkgpu_set_horner_mode: 0 automatic, 1 one Horner chain per transaction, 2 one per group (+ failed groups' transactions)."""
