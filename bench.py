@@ -279,7 +279,7 @@ def msm_microbench(ctx, torch, dev):
     return out
 
 
-def prover_program_microbench(ctx, host_threads: int, batch: int = 256):
+def prover_program_microbench(ctx, host_threads: int, batch: int = 1024):
     """BASELINE configs[4]: R1CS proving of a 1024-constraint program -- here 8 committed values, each shown to lie in
     [0, 2^64): 512 multipliers, 1032 constraints, handed over as DATA (zkgpu_r1cs_prove_batch); every proof verified
     by the device-side verifier through a plan made from the same description."""
@@ -297,10 +297,14 @@ def prover_program_microbench(ctx, host_threads: int, batch: int = 256):
         mult_def, given = gadget_witness(3, 8, values)
         vals.append(values); givens.append(given); seeds.append(hashlib.sha256(b"bench program %d" % i).digest())
     pr = R1csProver(ctx, gens, desc, mult_def, host_threads=host_threads)
+    ctx.set_prover_mode(1)                                     # the round-1 arrangement: host threads in lockstep
     pr.prove(vals[:8], givens[:8], seeds[:8])
-    t0 = time.perf_counter()
+    pr.prove(vals[:256], givens[:256], seeds[:256])
+    dt_host = pr.last_call_s
+    ctx.set_prover_mode(0)                                     # the whole proof on the device
+    pr.prove(vals[:8], givens[:8], seeds[:8])
     coms, proofs = pr.prove(vals, givens, seeds)
-    dt = time.perf_counter() - t0
+    dt = pr.last_call_s
     v = R1csVerifier(ctx, gens, desc)
     bm = v.verify_gpu(batch, b"".join(coms), b"".join(proofs), len(proofs[0]), shake(b"program-r", 64 * batch))
     v.close()
@@ -308,11 +312,14 @@ def prover_program_microbench(ctx, host_threads: int, batch: int = 256):
     assert bm == bitmap_of([1] * batch), "a proof of the 1032-constraint program did not verify"
     return {"proofs_per_s": round(batch / dt, 1), "batch": batch, "ms_per_proof": round(dt / batch * 1e3, 4),
             "constraints": len(cons), "multipliers": n, "commitments": m, "proof_bytes": len(proofs[0]), "host_threads": host_threads,
-            "note": "zkgpu_r1cs_prove_batch on a described constraint system: 8 x 64-bit range proofs; Pedersen vector "
-                    "commitments and every L_j / R_j on the generator tables, the inner-product folds on the device"}
+            "host_lockstep_proofs_per_s": round(256 / dt_host, 1),
+            "note": "zkgpu_r1cs_prove_batch on a described constraint system (8 x 64-bit range proofs), time of the library "
+                    "call: transcript, TranscriptRng, witness, flattening, polynomials and inner-product folds in kernels, "
+                    "Pedersen vector commitments and every L_j / R_j on the generator tables; host_lockstep = the same with "
+                    "the algebra on host threads (zkgpu_set_prover_mode 1, batch 256)"}
 
 
-def prover_microbench(ctx, gens, host_threads: int, batch: int = 512):
+def prover_microbench(ctx, gens, host_threads: int, batch: int = 2048):
     """BASELINE configs[4] (prover side): `batch` 2-in/2-out cloak proofs; every proof verified by the device verifier."""
     import random
     from zkvm_amd.verifier import Prover, Verifier
@@ -325,18 +332,24 @@ def prover_microbench(ctx, gens, host_threads: int, batch: int = 512):
         fs.append([f] * 4)
         seeds.append(hashlib.sha256(b"bench prover %d" % i).digest())
     pr = Prover(ctx, gens, host_threads=host_threads)
+    ctx.set_prover_mode(1)                                     # the round-1 arrangement: host threads in lockstep
     pr.prove(2, 2, qs[:8], fs[:8], seeds[:8])
-    t0 = time.perf_counter()
+    pr.prove(2, 2, qs[:512], fs[:512], seeds[:512])
+    dt_host = pr.last_call_s
+    ctx.set_prover_mode(0)                                     # the whole proof on the device
+    pr.prove(2, 2, qs[:8], fs[:8], seeds[:8])
     txs = pr.prove(2, 2, qs, fs, seeds)
-    dt = time.perf_counter() - t0
+    dt = pr.last_call_s
     v = Verifier(ctx, gens)
     bm = v.verify_bitmap_gpu(txs, shake(b"prover-r", 64 * batch))
     v.close()
     assert bm == bitmap_of([1] * batch), "a proof of the GPU prover did not verify"
     return {"proofs_per_s": round(batch / dt, 1), "batch": batch, "ms_per_proof": round(dt / batch * 1e3, 4),
-            "host_threads": host_threads,
-            "note": "zkgpu_cloak_prove_batch: provers in lockstep on host threads, all MSMs on the generator tables; every "
-                    "proof verified by the device-side verifier"}
+            "host_threads": host_threads, "host_lockstep_proofs_per_s": round(512 / dt_host, 1),
+            "note": "zkgpu_cloak_prove_batch, time of the library call: the whole proof on the device (k_pv_* kernels, one "
+                    "workgroup per proof), all multiscalar multiplications on the generator tables; host threads only derive "
+                    "the blinding factors and the gadget's witness queue; host_lockstep = zkgpu_set_prover_mode 1 (batch 512); "
+                    "every proof verified by the device-side verifier"}
 
 
 # ---- distributed plumbing ------------------------------------------------------------------------

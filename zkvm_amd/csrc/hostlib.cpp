@@ -484,13 +484,15 @@ int pv_emulate(const R1csDesc& d, const std::vector<uint32_t>& mult_def, const s
   rows_points(gens, rows0.data(), pv_rows_pairs(sh.m), pts);
   for (size_t i = 0; i < 8 * (size_t)sh.m; ++i) for (int b = 0; b < 4; ++b) commitments[4 * i + b] = (uint8_t)(pts[i] >> (8 * b));
   pv_phase1(env, sh, P, B, 0, pts.data());
+  pv_rng_draw(sh, state.data(), rows1.data(), 0, sh.n1, PV_IBL1);
   rows_points(gens, rows1.data(), pv_rows_commit(1, 0, sh.n1, cap, false), pts);
   pv_phase2(env, sh, P, B, 0, pts.data());
+  if (sh.n > sh.n1) pv_rng_draw(sh, state.data(), rows2.data(), sh.n1, sh.n, PV_IBL2);
   rows_points(gens, rows2.data(), pv_rows_commit(1, sh.n1, sh.n, cap, true), pts);
   pv_phase3(env, sh, P, B, 0, pts.data());
   rows_points(gens, rows3.data(), pv_rows_pairs(5), pts);
   pv_phase4(env, sh, P, B, 0, pts.data());
-  if (state[sh.o_flag]) return -2;
+  if (state[sh.o_flag]) return -2 - (int)state[sh.o_flag];
   // the inner-product rounds (on the device: k_ipa_round + the tables); here with the host's scalars
   std::vector<Scalar> L(sh.pn), R(sh.pn), G(sh.pn), H(sh.pn);
   for (uint32_t i = 0; i < sh.pn; ++i) {

@@ -1218,6 +1218,44 @@ k_static_values(const uint32_t* __restrict__ partials, uint32_t n_partials, uint
   }
 }
 
+// The same in two steps for many rows (the prover's phases: thousands of rows per call): the sums as extended points,
+// one wave per row -- then the encodings one LANE per row, so that the inverse square root of RFC 9496's ENCODE (the
+// long dependent chain of this step) runs on 64 rows per wavefront instead of on one lane of each
+__global__ void __launch_bounds__(64)
+k_static_row_sums(const uint32_t* __restrict__ partials, uint32_t n_partials, uint32_t* __restrict__ out_ext) {
+  const uint32_t m = blockIdx.x;
+  const int lane = threadIdx.x;
+  ge acc;
+  ge_identity(acc);
+  for (uint32_t c = lane; c < n_partials; c += 64) {
+    ge p;
+    load_ext(p, partials + ((uint64_t)m * n_partials + c) * EXT_WORDS);
+    ge_add(acc, acc, p);
+  }
+  uint32_t np2 = 1;
+  while (np2 < n_partials) np2 <<= 1;
+#pragma unroll 1
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    if ((uint32_t)delta >= np2) continue;      // lanes beyond the partials hold the identity
+    ge other;
+    shfl_down_ge(other, acc, delta);
+    if (lane < delta) ge_add(acc, acc, other);
+  }
+  if (lane == 0) store_ext(out_ext + (uint64_t)m * EXT_WORDS, acc);
+}
+__global__ void __launch_bounds__(64)
+k_encode_rows(const uint32_t* __restrict__ ext, uint32_t n_rows, uint32_t* __restrict__ out_enc) {
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_rows) return;
+  ge p;
+  load_ext(p, ext + (uint64_t)m * EXT_WORDS);
+  uint32_t enc[8];
+  ristretto_encode(enc, p);
+  uint4* o = reinterpret_cast<uint4*>(out_enc + 8 * (uint64_t)m);
+  o[0] = make_uint4(enc[0], enc[1], enc[2], enc[3]);
+  o[1] = make_uint4(enc[4], enc[5], enc[6], enc[7]);
+}
+
 // ---- group checks ---------------------------------------------------------------------
 // A group of transactions whose equations E_t are weighted by independent random rho's (k_transcript)
 // sums to the identity iff every one of them does (up to probability ~2^-250), and the generator

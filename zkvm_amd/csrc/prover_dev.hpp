@@ -88,7 +88,7 @@ struct PvStrobe {
   ZK_HD void xor_in(unsigned i, uint32_t b) { w[i >> 2] ^= b << (8 * (i & 3)); }
   ZK_HD uint32_t get(unsigned i) const { return (w[i >> 2] >> (8 * (i & 3))) & 0xffu; }
   ZK_HD void clear(unsigned i) { w[i >> 2] &= ~(0xffu << (8 * (i & 3))); }
-  ZK_HD void permute() {
+  ZK_HD_NOINLINE void permute() {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t lo[25], hi[25];
 #pragma unroll
@@ -103,7 +103,7 @@ struct PvStrobe {
     for (int i = 0; i < 25; ++i) { w[2 * i] = (uint32_t)s[i]; w[2 * i + 1] = (uint32_t)(s[i] >> 32); }
 #endif
   }
-  ZK_HD void run_f() {
+  ZK_HD_NOINLINE void run_f() {
     xor_in(w[50], w[51] & 0xffu);
     xor_in(w[50] + 1, 0x04);
     xor_in(kRate + 1, 0x80);
@@ -123,19 +123,19 @@ struct PvStrobe {
     if ((flags & (4u | 32u)) && w[50] != 0) run_f();
   }
   // flags: I 1, A 2, C 4, T 8, M 16, K 32
-  ZK_HD void meta_ad(const uint8_t* d, unsigned n, bool more) { if (!more) begin_op(16u | 2u); for (unsigned i = 0; i < n; ++i) absorb_byte(d[i]); }
-  ZK_HD void ad(const uint8_t* d, unsigned n) { begin_op(2u); for (unsigned i = 0; i < n; ++i) absorb_byte(d[i]); }
-  ZK_HD void key(const uint8_t* d, unsigned n) {
+  ZK_HD_NOINLINE void meta_ad(const uint8_t* d, unsigned n, bool more) { if (!more) begin_op(16u | 2u); for (unsigned i = 0; i < n; ++i) absorb_byte(d[i]); }
+  ZK_HD_NOINLINE void ad(const uint8_t* d, unsigned n) { begin_op(2u); for (unsigned i = 0; i < n; ++i) absorb_byte(d[i]); }
+  ZK_HD_NOINLINE void key(const uint8_t* d, unsigned n) {
     begin_op(2u | 4u);
     for (unsigned i = 0; i < n; ++i) { clear(w[50]); xor_in(w[50], d[i]); if (++w[50] == kRate) run_f(); }
   }
-  ZK_HD void prf(uint8_t* out, unsigned n) {
+  ZK_HD_NOINLINE void prf(uint8_t* out, unsigned n) {
     begin_op(1u | 2u | 4u);
     for (unsigned i = 0; i < n; ++i) { out[i] = (uint8_t)get(w[50]); clear(w[50]); if (++w[50] == kRate) run_f(); }
   }
   // Merlin
   ZK_HD void le32(uint8_t b[4], uint32_t n) { b[0] = (uint8_t)n; b[1] = (uint8_t)(n >> 8); b[2] = (uint8_t)(n >> 16); b[3] = (uint8_t)(n >> 24); }
-  ZK_HD void append_message(const char* label, unsigned label_len, const uint8_t* msg, unsigned n) {
+  ZK_HD_NOINLINE void append_message(const char* label, unsigned label_len, const uint8_t* msg, unsigned n) {
     uint8_t len[4];
     le32(len, n);
     meta_ad((const uint8_t*)label, label_len, false);
@@ -159,7 +159,7 @@ struct PvStrobe {
     prf(b, 64);
     for (int i = 0; i < 16; ++i) out[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
   }
-  ZK_HD scm challenge_scalar(const char* label, unsigned label_len) {
+  ZK_HD_NOINLINE scm challenge_scalar(const char* label, unsigned label_len) {
     uint32_t wd[16];
     challenge_wide(label, label_len, wd);
     return scm_from_wide(wd);
@@ -179,7 +179,7 @@ struct PvStrobe {
     meta_ad((const uint8_t*)"rng", 3, false);
     key(b, 32);
   }
-  ZK_HD scm rng_scalar() {
+  ZK_HD_NOINLINE scm rng_scalar() {
     uint8_t len[4], b[64];
     uint32_t wd[16];
     le32(len, 64);
@@ -189,15 +189,84 @@ struct PvStrobe {
     return scm_from_wide(wd);
   }
 };
+// The TranscriptRng's draws, word-wise: once the generator is keyed every rng_fill(64) is the same STROBE sequence --
+// meta-AD(LE32(64)), PRF(64) -- which XORs ten fixed bytes into the state at the current position (32 right after the
+// keying, 64 from then on), pads, runs Keccak-f and hands out (and zeroes) the first 64 bytes.  With the state in
+// registers a draw is one permutation and a reduction mod l: what the serial byte machine above needs ~200 LDS
+// round trips for.  One lane per proof (k_pv_rng).
+struct PvRng {
+  uint32_t lo[25], hi[25];
+  uint32_t pos, pos_begin;
+  ZK_HD void load(const uint32_t* w) {
+    ZK_UNROLL for (int i = 0; i < 25; ++i) { lo[i] = w[2 * i]; hi[i] = w[2 * i + 1]; }
+    pos = w[50]; pos_begin = w[51];
+  }
+  ZK_HD void store(uint32_t* w) const {
+    ZK_UNROLL for (int i = 0; i < 25; ++i) { w[2 * i] = lo[i]; w[2 * i + 1] = hi[i]; }
+    w[50] = pos; w[51] = pos_begin;
+  }
+  ZK_HD bool fast() const { return pos_begin == 0 && (pos == 32 || pos == 64); }
+  // bytes at pos: 00 12 | 40 00 00 00 | (pos + 1) 07 | then the padding (pos + 7) 04 at pos + 8, 80 at byte 167
+  ZK_HD scm draw() {
+    if (pos == 32) {          // bytes 32..41: words 8, 9, 10  = (lo[4], hi[4], lo[5])
+      lo[4] ^= 0x00401200u; hi[4] ^= 0x07210000u; lo[5] ^= 0x00000427u;
+    } else {                  // bytes 64..73: words 16, 17, 18 = (lo[8], hi[8], lo[9])
+      lo[8] ^= 0x00401200u; hi[8] ^= 0x07410000u; lo[9] ^= 0x00000447u;
+    }
+    hi[20] ^= 0x80000000u;    // byte 167 = word 41, top byte
+#if defined(__HIP_DEVICE_COMPILE__)
+    keccak_f1600_halves(lo, hi);
+#else
+    uint64_t st[25];
+    for (int i = 0; i < 25; ++i) st[i] = (uint64_t)lo[i] | ((uint64_t)hi[i] << 32);
+    keccak_f1600(st);
+    for (int i = 0; i < 25; ++i) { lo[i] = (uint32_t)st[i]; hi[i] = (uint32_t)(st[i] >> 32); }
+#endif
+    uint32_t wd[16];
+    ZK_UNROLL for (int i = 0; i < 8; ++i) { wd[2 * i] = lo[i]; wd[2 * i + 1] = hi[i]; lo[i] = 0; hi[i] = 0; }
+    pos = 64;
+    pos_begin = 0;
+    return scm_from_wide(wd);
+  }
+};
 #define PV_LBL(s) (s), (unsigned)(sizeof(s) - 1)
 
 // ---- helpers ---------------------------------------------------------------------------------------------
 ZK_HD void pv_ld(scm& s, const uint32_t* p) { ZK_UNROLL for (int i = 0; i < 8; ++i) s.v[i] = p[i]; }
 ZK_HD void pv_st(uint32_t* p, const scm& s) { ZK_UNROLL for (int i = 0; i < 8; ++i) p[i] = s.v[i]; }
+// The building blocks are CALLED, not inlined: a phase is long straight-line code run by one lane per workgroup, and
+// with every product and every Keccak-f inlined it outgrows the instruction cache many times over (50 000
+// instructions per kernel, and the kernels ran at the speed of instruction fetches).
+ZK_HD_NOINLINE scl pv_mul(scl a, scl b) { return scl_mul(a, b); }
+// a^(l-2) by fixed 4-bit windows in the lazy form: 252 squarings + 14 (table) + at most 32 products (the 127 bits
+// below the top one of l - 2 = 2^252 + c - 2 are zero) -- against 378 canonical products of scm_invert
+ZK_HD_NOINLINE scm pv_invert(scm am) {
+  const uint32_t e[8] = ZK_SC_LM2;
+  const scl a = scl_from_scm(am);
+  scl tbl[16];
+  tbl[0] = scl_one();
+  tbl[1] = a;
+  ZK_NOUNROLL for (int i = 2; i < 16; ++i) tbl[i] = pv_mul(tbl[i - 1], a);
+  scl acc = a;                                     // nibble 63 of the exponent is 1
+  ZK_NOUNROLL for (int i = 62; i >= 0; --i) {
+    ZK_NOUNROLL for (int k = 0; k < 4; ++k) acc = pv_mul(acc, acc);
+    uint32_t word = 0;
+    ZK_UNROLL for (int k = 0; k < 8; ++k) word = (k == (i >> 3)) ? e[k] : word;
+    const uint32_t nib = (word >> (4 * (i & 7))) & 15u;
+    if (nib) {
+      scl f = tbl[1];
+      ZK_NOUNROLL for (uint32_t t = 2; t < 16; ++t) {
+        ZK_UNROLL for (int q = 0; q < 10; ++q) f.v[q] = (t == nib) ? tbl[t].v[q] : f.v[q];
+      }
+      acc = pv_mul(acc, f);
+    }
+  }
+  return scl_to_scm(acc);
+}
 ZK_HD scl pv_ldl(const uint32_t* p) { return scl_from_words(p); }                 // same value, limb form
-ZK_HD void pv_stl(uint32_t* p, const scl& a) { scl_canon_words(p, a); }           // same value, canonical words
-ZK_HD void pv_st_plain(uint32_t* p, const scl& mont) { scl_canon_words(p, scl_mul(mont, scl_plain_one())); }   // Montgomery -> the integer's words
-ZK_HD scl pv_from_plain(const uint32_t* p) { return scl_mul(scl_from_words(p), scl_r2()); }                   // canonical integer -> Montgomery
+ZK_HD_NOINLINE void pv_stl(uint32_t* p, scl a) { scl_canon_words(p, a); }         // same value, canonical words
+ZK_HD void pv_st_plain(uint32_t* p, const scl& mont) { pv_stl(p, pv_mul(mont, scl_plain_one())); }   // Montgomery -> the integer's words
+ZK_HD scl pv_from_plain(const uint32_t* p) { return pv_mul(scl_from_words(p), scl_r2()); }           // canonical integer -> Montgomery
 
 struct PvView {   // the state of one proof
   const PvShape& sh;
@@ -224,11 +293,11 @@ ZK_HD bool pv_solve(const PvView& V, const PvPlan& P, uint32_t con, uint32_t kin
   for (uint32_t e = P.con_off[con]; e < P.con_off[con + 1]; ++e) {
     scl c = pv_ldl(P.t_coef + 8 * (uint64_t)e);
     const uint32_t mi = P.t_mono[e];
-    if (mi) c = scl_mul(c, pv_ldl(V.at(V.sh.o_sym, mi)));
+    if (mi) c = pv_mul(c, pv_ldl(V.at(V.sh.o_sym, mi)));
     const uint32_t tk = P.t_kind[e], ti = P.t_idx[e];
     if (tk == kind && ti == i) { own = scl_weak(scl_add(own, c)); continue; }
     if ((tk >= 1 && tk <= 3 && ti >= have) || (tk == 0 && ti >= V.sh.m)) return false;
-    acc = scl_add(acc, tk == 4 ? scl_weak(c) : scl_mul(c, pv_var(V, tk, ti)));
+    acc = scl_add(acc, tk == 4 ? scl_weak(c) : pv_mul(c, pv_var(V, tk, ti)));
     if (++cnt == 8) { acc = scl_weak(acc); cnt = 1; }
   }
   const scm own_c = scl_to_scm(own), minus_one = scm_neg(scm_one());
@@ -236,7 +305,7 @@ ZK_HD bool pv_solve(const PvView& V, const PvPlan& P, uint32_t con, uint32_t kin
   for (int q = 0; q < 8; ++q) { zero &= own_c.v[q] == 0; is_m1 &= own_c.v[q] == minus_one.v[q]; }
   if (zero) return false;
   acc = scl_weak(acc);
-  if (!is_m1) acc = scl_mul(acc, scl_from_scm(scm_invert(scm_neg(own_c))));
+  if (!is_m1) acc = pv_mul(acc, scl_from_scm(pv_invert(scm_neg(own_c))));
   out = acc;
   return true;
 }
@@ -252,7 +321,7 @@ ZK_HD void pv_assign(Env& env, const PvView& V, const PvPlan& P, const PvBatch& 
     const scl l = pv_from_plain(g), r = pv_from_plain(g + 8);
     pv_stl(V.at(sh.o_aL, i), l);
     pv_stl(V.at(sh.o_aR, i), r);
-    pv_stl(V.at(sh.o_aO, i), scl_mul(l, r));
+    pv_stl(V.at(sh.o_aO, i), pv_mul(l, r));
   }
   env.sync();
   if (env.tid() == 0) {
@@ -263,34 +332,49 @@ ZK_HD void pv_assign(Env& env, const PvView& V, const PvPlan& P, const PvBatch& 
       if (!ok) V.s[sh.o_flag] = 1;
       pv_stl(V.at(sh.o_aL, i), l);
       pv_stl(V.at(sh.o_aR, i), r);
-      pv_stl(V.at(sh.o_aO, i), scl_mul(l, r));
+      pv_stl(V.at(sh.o_aO, i), pv_mul(l, r));
     }
   }
   env.sync();
 }
 
 // rows of a Pedersen vector commitment phase over multipliers [first, last): A_I = [i_bl | aL.. | aR..],
-// A_O = [o_bl | aO..], S = [s_bl | sL.. | sR..]  as plain canonical words
+// A_O = [o_bl | aO..], S = [s_bl | sL.. | sR..]  as plain canonical words.  The witness part (all threads):
 template <class Env>
-ZK_HD void pv_commit_rows(Env& env, const PvView& V, uint32_t* rows, uint32_t first, uint32_t last, uint32_t bl_slot) {
+ZK_HD void pv_commit_rows(Env& env, const PvView& V, uint32_t* rows, uint32_t first, uint32_t last) {
   const PvShape& sh = V.sh;
   const uint32_t cnt = last - first;
   uint32_t* rI = rows;
   uint32_t* rO = rI + 8 * (1 + 2 * cnt);
-  uint32_t* rS = rO + 8 * (1 + cnt);
-  if (env.tid() == 0) {
-    pv_st_plain(rI, pv_ldl(V.at(sh.o_blind, bl_slot)));
-    pv_st_plain(rO, pv_ldl(V.at(sh.o_blind, bl_slot + 1)));
-    pv_st_plain(rS, pv_ldl(V.at(sh.o_blind, bl_slot + 2)));
-  }
   for (uint32_t j = env.tid(); j < cnt; j += env.nt()) {
     const uint32_t i = first + j;
     pv_st_plain(rI + 8 * (1 + j), pv_ldl(V.at(sh.o_aL, i)));
     pv_st_plain(rI + 8 * (1 + cnt + j), pv_ldl(V.at(sh.o_aR, i)));
     pv_st_plain(rO + 8 * (1 + j), pv_ldl(V.at(sh.o_aO, i)));
-    pv_st_plain(rS + 8 * (1 + j), pv_ldl(V.at(sh.o_sL, i)));
-    pv_st_plain(rS + 8 * (1 + cnt + j), pv_ldl(V.at(sh.o_sR, i)));
   }
+}
+// ... and the part drawn from the TranscriptRng, in the reference's order: i_bl, o_bl, s_bl, sL.., sR.. (ONE thread per
+// proof: k_pv_rng runs it one lane per proof).  Values go to the state (Montgomery) and to the rows (plain).
+ZK_HD void pv_rng_draw(const PvShape& sh, uint32_t* state, uint32_t* rows, uint32_t first, uint32_t last, uint32_t bl_slot) {
+  PvView V{sh, state};
+  const uint32_t cnt = last - first;
+  uint32_t* rI = rows;
+  uint32_t* rO = rI + 8 * (1 + 2 * cnt);
+  uint32_t* rS = rO + 8 * (1 + cnt);
+  PvRng rng;
+  rng.load(state + sh.o_rng);
+  if (!rng.fast()) { state[sh.o_flag] = 2; return; }   // cannot happen: the generator was keyed just before
+  auto one = [&](uint32_t* st_slot, uint32_t* row_slot) {
+    const scm v = rng.draw();
+    pv_st(st_slot, v);
+    pv_st_plain(row_slot, scl_from_scm(v));
+  };
+  one(V.at(sh.o_blind, bl_slot), rI);
+  one(V.at(sh.o_blind, bl_slot + 1), rO);
+  one(V.at(sh.o_blind, bl_slot + 2), rS);
+  for (uint32_t j = 0; j < cnt; ++j) one(V.at(sh.o_sL, first + j), rS + 8 * (1 + j));
+  for (uint32_t j = 0; j < cnt; ++j) one(V.at(sh.o_sR, first + j), rS + 8 * (1 + cnt + j));
+  rng.store(state + sh.o_rng);
 }
 
 // ---- phase 0: the value commitments' rows (no transcript yet) ----------------------------------------------
@@ -323,17 +407,12 @@ ZK_HD void pv_phase1(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
     // TranscriptRng: a fork of the transcript, keyed with the blinding factors and the external randomness
     for (uint32_t j = 0; j < sh.m; ++j) tr.rekey_with_witness(PV_LBL("v_blinding"), B.rows0 + ((uint64_t)proof * sh.m + j) * 16 + 8);
     tr.finalize_rng(B.rng_seed + (uint64_t)proof * 8);
-    pv_st(V.at(sh.o_blind, PV_IBL1), tr.rng_scalar());
-    pv_st(V.at(sh.o_blind, PV_OBL1), tr.rng_scalar());
-    pv_st(V.at(sh.o_blind, PV_SBL1), tr.rng_scalar());
-    for (uint32_t i = 0; i < sh.n1; ++i) pv_st(V.at(sh.o_sL, i), tr.rng_scalar());
-    for (uint32_t i = 0; i < sh.n1; ++i) pv_st(V.at(sh.o_sR, i), tr.rng_scalar());
-    for (int i = 0; i < 52; ++i) V.s[sh.o_rng + i] = tr.w[i];
+    for (int i = 0; i < 52; ++i) V.s[sh.o_rng + i] = tr.w[i];   // the draws follow in pv_rng_draw
     pv_st(V.at(sh.o_sym, 0), scm_one());
   }
   env.sync();
   pv_assign(env, V, P, B, proof, 0, sh.n1);
-  pv_commit_rows(env, V, B.rows1 + (uint64_t)proof * sh.r1_terms * 8, 0, sh.n1, PV_IBL1);
+  pv_commit_rows(env, V, B.rows1 + (uint64_t)proof * sh.r1_terms * 8, 0, sh.n1);
 }
 
 // ---- phase 2: A_I1 A_O1 S1 in; second-phase challenges and witness; rows of A_I2 A_O2 S2 ----------------------
@@ -360,7 +439,7 @@ ZK_HD void pv_phase2(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
       for (uint32_t mi = 1; mi < sh.n_mono; ++mi) {   // monomials c^p of the second-phase challenges
         const scl base = pv_ldl(V.at(sh.o_c2, P.mono_chal[mi]));
         scl acc = base;
-        for (uint32_t e = 1; e < P.mono_pow[mi]; ++e) acc = scl_mul(acc, base);
+        for (uint32_t e = 1; e < P.mono_pow[mi]; ++e) acc = pv_mul(acc, base);
         pv_stl(V.at(sh.o_sym, mi), acc);
       }
     }
@@ -373,18 +452,7 @@ ZK_HD void pv_phase2(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
     return;
   }
   pv_assign(env, V, P, B, proof, sh.n1, sh.n);
-  if (env.tid() == 0) {
-    PvStrobe rng{env.strobe()};
-    for (int i = 0; i < 52; ++i) rng.w[i] = V.s[sh.o_rng + i];
-    pv_st(V.at(sh.o_blind, PV_IBL2), rng.rng_scalar());
-    pv_st(V.at(sh.o_blind, PV_OBL2), rng.rng_scalar());
-    pv_st(V.at(sh.o_blind, PV_SBL2), rng.rng_scalar());
-    for (uint32_t i = sh.n1; i < sh.n; ++i) pv_st(V.at(sh.o_sL, i), rng.rng_scalar());
-    for (uint32_t i = sh.n1; i < sh.n; ++i) pv_st(V.at(sh.o_sR, i), rng.rng_scalar());
-    for (int i = 0; i < 52; ++i) V.s[sh.o_rng + i] = rng.w[i];
-  }
-  env.sync();
-  pv_commit_rows(env, V, B.rows2 + (uint64_t)proof * sh.r2_terms * 8, sh.n1, sh.n, PV_IBL2);
+  pv_commit_rows(env, V, B.rows2 + (uint64_t)proof * sh.r2_terms * 8, sh.n1, sh.n);   // the drawn part: pv_rng_draw
 }
 
 // ---- phase 3: A_I2 A_O2 S2 in; y, z; flattening, t(x) coefficients; rows of T_1 T_3 T_4 T_5 T_6 ----------------
@@ -395,12 +463,12 @@ ZK_HD PvPoly pv_poly(const PvView& V, uint32_t i) {
   const PvShape& sh = V.sh;
   const scl yp = pv_ldl(V.at(sh.o_ypow, i)), yi = pv_ldl(V.at(sh.o_yinv, i));
   PvPoly p;
-  p.l1 = scl_add(pv_ldl(V.at(sh.o_aL, i)), scl_mul(yi, pv_ldl(V.at(sh.o_wR, i))));
+  p.l1 = scl_add(pv_ldl(V.at(sh.o_aL, i)), pv_mul(yi, pv_ldl(V.at(sh.o_wR, i))));
   p.l2 = pv_ldl(V.at(sh.o_aO, i));
   p.l3 = pv_ldl(V.at(sh.o_sL, i));
   p.r0 = scl_sub(pv_ldl(V.at(sh.o_wO, i)), yp);
-  p.r1 = scl_add(scl_mul(yp, pv_ldl(V.at(sh.o_aR, i))), pv_ldl(V.at(sh.o_wL, i)));
-  p.r3 = scl_mul(yp, pv_ldl(V.at(sh.o_sR, i)));
+  p.r1 = scl_add(pv_mul(yp, pv_ldl(V.at(sh.o_aR, i))), pv_ldl(V.at(sh.o_wL, i)));
+  p.r3 = pv_mul(yp, pv_ldl(V.at(sh.o_sR, i)));
   return p;
 }
 
@@ -412,9 +480,9 @@ ZK_HD void pv_powers(Env& env, uint32_t* table, const scl& base, uint32_t count)
   scl stride = base;
   for (uint32_t half = 1; half < count; half <<= 1) {
     const uint32_t end = 2 * half < count ? 2 * half : count;
-    for (uint32_t q = half + env.tid(); q < end; q += env.nt()) pv_stl(table + 8 * q, scl_mul(pv_ldl(table + 8 * (q - half)), stride));
+    for (uint32_t q = half + env.tid(); q < end; q += env.nt()) pv_stl(table + 8 * q, pv_mul(pv_ldl(table + 8 * (q - half)), stride));
     env.sync();
-    stride = scl_mul(stride, stride);
+    stride = pv_mul(stride, stride);
   }
 }
 
@@ -432,7 +500,7 @@ ZK_HD void pv_phase3(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
     const scm y = tr.challenge_scalar(PV_LBL("y")), z = tr.challenge_scalar(PV_LBL("z"));
     pv_st(V.at(sh.o_chal, PV_Y), y);
     pv_st(V.at(sh.o_chal, PV_Z), z);
-    pv_st(V.at(sh.o_chal, PV_YINV), scm_invert(y));
+    pv_st(V.at(sh.o_chal, PV_YINV), pv_invert(y));
     for (int i = 0; i < 52; ++i) V.s[sh.o_tr + i] = tr.w[i];
   }
   env.sync();
@@ -455,8 +523,8 @@ ZK_HD void pv_phase3(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
         const uint32_t p = info & 0x00ffffffu, q = P.prod_qm[2 * p], mi = P.prod_qm[2 * p + 1];
         scl c;
         for (int k = 0; k < 10; ++k) c.v[k] = P.prod_coef[10 * (uint64_t)p + k];
-        if (mi) c = scl_mul(c, pv_ldl(V.at(sh.o_sym, mi)));
-        v = scl_mul(c, pv_ldl(V.at(sh.o_zpow, q + 1)));
+        if (mi) c = pv_mul(c, pv_ldl(V.at(sh.o_sym, mi)));
+        v = pv_mul(c, pv_ldl(V.at(sh.o_zpow, q + 1)));
       }
       acc = scl_add(acc, scl_cneg(v, (info & 0x40000000u) != 0));
       if (++cnt == 16) { acc = scl_weak(acc); cnt = 1; }
@@ -472,24 +540,25 @@ ZK_HD void pv_phase3(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
   for (uint32_t i = env.tid(); i < sh.n; i += env.nt()) {
     const PvPoly p = pv_poly(V, i);
     // operands of a product: limbs < 2^28 each (sums of two tight values or a difference)
-    t[0] = scl_add(t[0], scl_mul(p.l1, p.r0));
-    t[1] = scl_add(t[1], scl_add(scl_mul(p.l1, p.r1), scl_mul(p.l2, p.r0)));
-    t[2] = scl_add(t[2], scl_add(scl_mul(p.l2, p.r1), scl_mul(p.l3, p.r0)));
-    t[3] = scl_add(t[3], scl_add(scl_mul(p.l1, p.r3), scl_mul(p.l3, p.r1)));
-    t[4] = scl_add(t[4], scl_mul(p.l2, p.r3));
-    t[5] = scl_add(t[5], scl_mul(p.l3, p.r3));
+    t[0] = scl_add(t[0], pv_mul(p.l1, p.r0));
+    t[1] = scl_add(t[1], scl_add(pv_mul(p.l1, p.r1), pv_mul(p.l2, p.r0)));
+    t[2] = scl_add(t[2], scl_add(pv_mul(p.l2, p.r1), pv_mul(p.l3, p.r0)));
+    t[3] = scl_add(t[3], scl_add(pv_mul(p.l1, p.r3), pv_mul(p.l3, p.r1)));
+    t[4] = scl_add(t[4], pv_mul(p.l2, p.r3));
+    t[5] = scl_add(t[5], pv_mul(p.l3, p.r3));
     if (++cnt == 8) { for (int k = 0; k < 6; ++k) t[k] = scl_weak(t[k]); cnt = 1; }
   }
   for (int k = 0; k < 6; ++k) t[k] = scl_weak(t[k]);
   env.sum(t, 6);                      // thread 0 holds the sums
   if (env.tid() == 0) {
     for (int k = 0; k < 6; ++k) pv_stl(V.at(sh.o_t, k + 1), t[k]);
-    PvStrobe rng{env.strobe()};
-    for (int i = 0; i < 52; ++i) rng.w[i] = V.s[sh.o_rng + i];
+    PvRng rng;
+    rng.load(V.s + sh.o_rng);
+    if (!rng.fast()) V.s[sh.o_flag] = 2;
     const int order[5] = {1, 3, 4, 5, 6};
     pv_st(V.at(sh.o_tb, 2), scm_zero());
-    for (int k = 0; k < 5; ++k) pv_st(V.at(sh.o_tb, order[k]), rng.rng_scalar());
-    for (int i = 0; i < 52; ++i) V.s[sh.o_rng + i] = rng.w[i];
+    for (int k = 0; k < 5; ++k) pv_st(V.at(sh.o_tb, order[k]), rng.draw());
+    rng.store(V.s + sh.o_rng);
     uint32_t* rows = B.rows3 + (uint64_t)proof * 5 * 16;
     for (int k = 0; k < 5; ++k) {
       pv_st_plain(rows + 16 * k, pv_ldl(V.at(sh.o_t, order[k])));
@@ -520,22 +589,22 @@ ZK_HD void pv_phase4(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
     scl tb2 = scl_zero();
     uint32_t cnt = 0;
     for (uint32_t j = 0; j < sh.m; ++j) {
-      tb2 = scl_add(tb2, scl_mul(pv_ldl(V.at(sh.o_wV, j)), pv_ldl(V.at(sh.o_vbl, j))));
+      tb2 = scl_add(tb2, pv_mul(pv_ldl(V.at(sh.o_wV, j)), pv_ldl(V.at(sh.o_vbl, j))));
       if (++cnt == 16) { tb2 = scl_weak(tb2); cnt = 1; }
     }
     tb2 = scl_weak(tb2);
     pv_stl(V.at(sh.o_tb, 2), tb2);
     scl xp = scl_one(), t_x = scl_zero(), t_x_bl = scl_zero();
     for (int i = 1; i <= 6; ++i) {
-      xp = scl_mul(xp, x);
-      t_x = scl_add(t_x, scl_mul(pv_ldl(V.at(sh.o_t, i)), xp));
-      t_x_bl = scl_add(t_x_bl, scl_mul(pv_ldl(V.at(sh.o_tb, i)), xp));
+      xp = pv_mul(xp, x);
+      t_x = scl_add(t_x, pv_mul(pv_ldl(V.at(sh.o_t, i)), xp));
+      t_x_bl = scl_add(t_x_bl, pv_mul(pv_ldl(V.at(sh.o_tb, i)), xp));
     }
-    const scl i_bl = scl_add(pv_ldl(V.at(sh.o_blind, PV_IBL1)), scl_mul(u, pv_ldl(V.at(sh.o_blind, PV_IBL2))));
-    const scl o_bl = scl_add(pv_ldl(V.at(sh.o_blind, PV_OBL1)), scl_mul(u, pv_ldl(V.at(sh.o_blind, PV_OBL2))));
-    const scl s_bl = scl_add(pv_ldl(V.at(sh.o_blind, PV_SBL1)), scl_mul(u, pv_ldl(V.at(sh.o_blind, PV_SBL2))));
-    scl e_bl = scl_mul(scl_add(scl_mul(x, s_bl), o_bl), x);
-    e_bl = scl_mul(scl_add(e_bl, i_bl), x);
+    const scl i_bl = scl_add(pv_ldl(V.at(sh.o_blind, PV_IBL1)), pv_mul(u, pv_ldl(V.at(sh.o_blind, PV_IBL2))));
+    const scl o_bl = scl_add(pv_ldl(V.at(sh.o_blind, PV_OBL1)), pv_mul(u, pv_ldl(V.at(sh.o_blind, PV_OBL2))));
+    const scl s_bl = scl_add(pv_ldl(V.at(sh.o_blind, PV_SBL1)), pv_mul(u, pv_ldl(V.at(sh.o_blind, PV_SBL2))));
+    scl e_bl = pv_mul(scl_add(pv_mul(x, s_bl), o_bl), x);
+    e_bl = pv_mul(scl_add(e_bl, i_bl), x);
     uint32_t w3[24];
     pv_st_plain(w3, t_x);
     pv_st_plain(w3 + 8, t_x_bl);
@@ -553,7 +622,7 @@ ZK_HD void pv_phase4(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
   }
   env.sync();
   const scl x = pv_ldl(V.at(sh.o_chal, PV_X)), u = pv_ldl(V.at(sh.o_chal, PV_U));
-  const scl x2 = scl_mul(x, x), x3 = scl_mul(x2, x);
+  const scl x2 = pv_mul(x, x), x3 = pv_mul(x2, x);
   uint32_t* lv = B.ipa_lv + (uint64_t)proof * sh.pn * 8;
   uint32_t* rv = B.ipa_rv + (uint64_t)proof * sh.pn * 8;
   uint32_t* cg = B.ipa_cg + (uint64_t)proof * sh.pn * 8;
@@ -562,8 +631,8 @@ ZK_HD void pv_phase4(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
     scl l = scl_zero(), r;
     if (i < sh.n) {
       const PvPoly p = pv_poly(V, i);
-      l = scl_add(scl_add(scl_mul(p.l1, x), scl_mul(p.l2, x2)), scl_mul(p.l3, x3));
-      r = scl_add(scl_add(p.r0, scl_mul(p.r1, x)), scl_mul(p.r3, x3));
+      l = scl_add(scl_add(pv_mul(p.l1, x), pv_mul(p.l2, x2)), pv_mul(p.l3, x3));
+      r = scl_add(scl_add(p.r0, pv_mul(p.r1, x)), pv_mul(p.r3, x3));
     } else {
       r = scl_neg(pv_ldl(V.at(sh.o_ypow, i)));
     }
@@ -571,7 +640,7 @@ ZK_HD void pv_phase4(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
     pv_stl(rv + 8 * i, r);
     const scl g = i < sh.n1 ? scl_one() : u;
     pv_st_plain(cg + 8 * i, g);         // generator coefficients as plain words
-    pv_st_plain(ch + 8 * i, scl_mul(pv_ldl(V.at(sh.o_yinv, i)), g));
+    pv_st_plain(ch + 8 * i, pv_mul(pv_ldl(V.at(sh.o_yinv, i)), g));
   }
 }
 
@@ -589,7 +658,7 @@ ZK_HD void pv_ipa_round(Env& env, const PvShape& sh, const PvBatch& B, uint32_t 
   const scm u = tr.challenge_scalar(PV_LBL("u"));
   uint32_t* out = B.ipa_u + (uint64_t)proof * 16;
   pv_st_plain(out, scl_from_scm(u));
-  pv_st_plain(out + 8, scl_from_scm(scm_invert(u)));
+  pv_st_plain(out + 8, scl_from_scm(pv_invert(u)));
   for (int i = 0; i < 52; ++i) V.s[sh.o_tr + i] = tr.w[i];
 }
 

@@ -51,6 +51,15 @@ k_pv_phase1(PvShape sh, PvPlan P, PvBatch B, const uint32_t* __restrict__ points
   PvDevEnv env{lds};
   pv_phase1(env, sh, P, B, blockIdx.x, points + (uint64_t)blockIdx.x * sh.m * 8);
 }
+// the TranscriptRng's draws of a commitment phase, one LANE per proof (state in registers, one Keccak-f per draw)
+__global__ void __launch_bounds__(64)
+k_pv_rng(PvShape sh, PvBatch B, uint32_t batch, uint32_t phase) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= batch) return;
+  uint32_t* state = B.state + (uint64_t)p * sh.state_words;
+  if (phase == 1) pv_rng_draw(sh, state, B.rows1 + (uint64_t)p * sh.r1_terms * 8, 0, sh.n1, PV_IBL1);
+  else pv_rng_draw(sh, state, B.rows2 + (uint64_t)p * sh.r2_terms * 8, sh.n1, sh.n, PV_IBL2);
+}
 __global__ void __launch_bounds__(256)
 k_pv_phase2(PvShape sh, PvPlan P, PvBatch B, const uint32_t* __restrict__ points) {
   __shared__ uint32_t lds[PV_LDS_WORDS];
@@ -80,7 +89,8 @@ k_pv_finish(PvShape sh, PvBatch B, const uint32_t* __restrict__ ab, uint32_t bat
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= batch) return;
   pv_finish(sh, B, p, ab + (uint64_t)p * 16);
-  if (B.state[(uint64_t)p * sh.state_words + sh.o_flag]) atomicOr(status, 1u);
+  const uint32_t flag = B.state[(uint64_t)p * sh.state_words + sh.o_flag];
+  if (flag) atomicOr(status, flag == 2 ? 2u : 1u);
 }
 
 }  // namespace zk

@@ -1711,9 +1711,15 @@ int msm_ps_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t rows, uint64_t n, 
                        d_index, (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)rows, n,
                        (uint32_t*)c->st_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
   }
+  TRY(ensure(c, c->rechk_pts, rows * EXT_WORDS * 4));       // (free while a prover runs: the verifier's re-check sums)
   {
-    Launch l(c, "k_static_values");
-    hipLaunchKernelGGL(k_static_values, dim3((unsigned)rows), dim3(64), 0, s, (const uint32_t*)c->st_partials.p, (uint32_t)(W * P), d_out);
+    Launch l(c, "k_static_row_sums");
+    hipLaunchKernelGGL(k_static_row_sums, dim3((unsigned)rows), dim3(64), 0, s, (const uint32_t*)c->st_partials.p, (uint32_t)(W * P),
+                       (uint32_t*)c->rechk_pts.p);
+  }
+  {
+    Launch l(c, "k_encode_rows");
+    hipLaunchKernelGGL(k_encode_rows, dim3(blocks_for(rows, 64)), dim3(64), 0, s, (const uint32_t*)c->rechk_pts.p, (uint32_t)rows, d_out);
   }
   HIP_TRY(c, hipGetLastError());
   return ZKGPU_OK;
@@ -1729,6 +1735,9 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   DeviceGuard g(c->device);
   hipStream_t s = c->stream;
+  const bool timing = getenv("ZKGPU_PROVER_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now();
   // constant tables: one blob
   std::vector<uint32_t> blob;
   auto put = [&blob](const std::vector<uint32_t>& v) { const size_t at = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); while (blob.size() & 3) blob.push_back(0); return at; };
@@ -1800,11 +1809,14 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
                       (const uint64_t*)(lb + o_off[which]), out);
   };
   const unsigned nb = (unsigned)batch;
+  const double t_setup = now();
   { Launch l(c, "k_pv_phase0"); hipLaunchKernelGGL(k_pv_phase0, dim3(nb), dim3(64), 0, s, sh, B); }
   if (sh.m) TRY(msm(0, B.rows0, (uint32_t*)c->pv_com.p));
   { Launch l(c, "k_pv_phase1"); hipLaunchKernelGGL(k_pv_phase1, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)c->pv_com.p); }
+  { Launch l(c, "k_pv_rng"); hipLaunchKernelGGL(k_pv_rng, dim3(blocks_for(batch, 64)), dim3(64), 0, s, sh, B, nb, 1u); }
   TRY(msm(1, B.rows1, pts));
   { Launch l(c, "k_pv_phase2"); hipLaunchKernelGGL(k_pv_phase2, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)pts); }
+  if (sh.n > sh.n1) { Launch l(c, "k_pv_rng"); hipLaunchKernelGGL(k_pv_rng, dim3(blocks_for(batch, 64)), dim3(64), 0, s, sh, B, nb, 2u); }
   TRY(msm(2, B.rows2, pts));
   { Launch l(c, "k_pv_phase3"); hipLaunchKernelGGL(k_pv_phase3, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)pts); }
   TRY(msm(3, B.rows3, pts));
@@ -1831,10 +1843,13 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
   HIP_TRY(c, hipMemcpyAsync(h_proofs.data(), c->pv_proofs.p, h_proofs.size(), hipMemcpyDeviceToHost, s));
   if (sh.m) HIP_TRY(c, hipMemcpyAsync(commitments, c->pv_com.p, batch * sh.m * 32, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipMemcpyAsync(st, c->status.p, 8, hipMemcpyDeviceToHost, s));
+  const double t_queued = now();
   HIP_TRY(c, hipStreamSynchronize(s));
+  if (timing) fprintf(stderr, "device prover: setup + uploads %.1f ms, queueing %.1f ms, waiting for the device %.1f ms (%zu proofs)\n",
+                      (t_setup - t_start) * 1e3, (t_queued - t_setup) * 1e3, (now() - t_queued) * 1e3, batch);
   if (c->profiling) prof_collect(c);
   if (st[0] & 1u) { c->last_error = "prover: inconsistent witness (a multiplier's defining constraint cannot be solved)"; return ZKGPU_EINVAL; }
-  if (st[0] & 2u) { c->last_error = "prover: scalar out of range"; return ZKGPU_EHIP; }
+  if (st[0] & 2u) { c->last_error = "prover: scalar out of range or TranscriptRng out of step"; return ZKGPU_EHIP; }
   for (size_t i = 0; i < batch; ++i) memcpy(proofs + proof_stride * i, h_proofs.data() + (size_t)sh.proof_stride * i, sh.proof_len);
   *proof_len = sh.proof_len;
   return ZKGPU_OK;
@@ -1934,10 +1949,12 @@ int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_
   R1csDesc desc;
   std::vector<uint32_t> md;
   PvHostPlan hp;
+  const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   try {
     PvCloakTrace::trace(n_in, n_out, desc, md);
     hp = pv_build(desc, md, gens_capacity);
   } catch (const std::exception& e) { c->last_error = e.what(); return ZKGPU_EINVAL; }
+  const double t1 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   const size_t m = 2 * nv;
   std::vector<uint8_t> vals(batch * m * 32), bl(batch * m * 32), giv(batch * (size_t)hp.sh.n_given * 64), rs(batch * 32);
   std::atomic<bool> bad{false};
@@ -1956,6 +1973,9 @@ int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_
     R1csProver::derive(seed, "rng", 0, &rs[32 * i], 32);
   });
   if (bad) { c->last_error = "prover: the cloak witness does not fit the traced gadget"; return ZKGPU_EINVAL; }
+  if (getenv("ZKGPU_PROVER_TIMING"))
+    fprintf(stderr, "device prover: tracing the gadget + tables %.1f ms, blinding factors + witness queues %.1f ms\n", (t1 - t0) * 1e3,
+            (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t1) * 1e3);
   return prove_device(c, ps, hp, batch, vals.data(), bl.data(), giv.data(), rs.data(), commitments, proofs, proof_stride, proof_len);
 }
 

@@ -55,8 +55,8 @@ class BulletproofGens:
 
 
 class Prover:
-    """Batch prover for cloak statements (zkgpu_cloak_prove_batch): host threads drive the provers in
-    lockstep, every multiscalar multiplication of every phase runs on the generator tables."""
+    """Batch prover for cloak statements (zkgpu_cloak_prove_batch): the whole proof on the device (Context.set_prover_mode(1):
+    host threads drive the provers in lockstep), every multiscalar multiplication on the generator tables."""
 
     def __init__(self, ctx: Context, bp_gens: BulletproofGens, host_threads: int = 0):
         self.ctx = ctx
@@ -73,9 +73,14 @@ class Prover:
         stride = 1 + 32 * (16 + 2 * 16)
         proofs = C.create_string_buffer(max(stride * batch, 1))
         plen = C.c_size_t(0)
-        self.ctx._check(self.ctx.lib.zkgpu_cloak_prove_batch(
-            self.ctx.h, self.bp_gens.points.h, self.bp_gens.gens_capacity, batch, n_in, n_out, qa, fl, b"".join(seeds),
-            self.host_threads, com, proofs, stride, C.byref(plen)))
+        import time
+        sd = b"".join(seeds)
+        t0 = time.perf_counter()
+        rc = self.ctx.lib.zkgpu_cloak_prove_batch(
+            self.ctx.h, self.bp_gens.points.h, self.bp_gens.gens_capacity, batch, n_in, n_out, qa, fl, sd,
+            self.host_threads, com, proofs, stride, C.byref(plen))
+        self.last_call_s = time.perf_counter() - t0          # the library call alone (bench.py)
+        self.ctx._check(rc)
         return [CloakTx(n_in, n_out, com.raw[64 * nv * i: 64 * nv * (i + 1)], proofs.raw[stride * i: stride * i + plen.value])
                 for i in range(batch)]
 
@@ -226,9 +231,14 @@ class R1csProver:
         stride = 1 + 32 * (16 + 2 * 16)
         proofs = C.create_string_buffer(max(stride * batch, 1))
         plen = C.c_size_t(0)
-        self.ctx._check(self.ctx.lib.zkgpu_r1cs_prove_batch(
+        import time
+        sd = b"".join(seeds)
+        t0 = time.perf_counter()
+        rc = self.ctx.lib.zkgpu_r1cs_prove_batch(
             self.ctx.h, self.bp_gens.points.h, C.byref(self.desc.struct), self.mult_def, self.bp_gens.gens_capacity, batch, vb, None,
-            gb, n_given, b"".join(seeds), self.host_threads, com, proofs, stride, C.byref(plen)))
+            gb, n_given, sd, self.host_threads, com, proofs, stride, C.byref(plen))
+        self.last_call_s = time.perf_counter() - t0          # the library call alone (bench.py)
+        self.ctx._check(rc)
         return ([com.raw[32 * m * i: 32 * m * (i + 1)] for i in range(batch)],
                 [proofs.raw[stride * i: stride * i + plen.value] for i in range(batch)])
 
