@@ -293,9 +293,9 @@ long long zkgpu_debug_force_regroup(zkgpu_ctx* ctx, int on);
 int zkgpu_set_locate_mode(zkgpu_ctx* ctx, int mode);
 /* The Horner chains over the windows of the proof-point sums (the longest dependent chain of a batch): 2 = one chain
  * per GROUP over the summed windows of its transactions, then one per transaction of the groups that failed (a third
- * less point arithmetic when few groups fail, two chains in a row for those that do); 1 = one chain per transaction up
- * front; 0 (default) = chosen per batch from the share of failed groups in the batch the context family finished last
- * (1 % or more: mode 1).  Same verdicts in every mode.  Forks inherit the setting. */
+ * less point arithmetic, but two chains in a row as soon as one group fails); 1 = one chain per transaction up front;
+ * 0 (default) = per group as long as the batch the context family finished last had no failed group, else per
+ * transaction.  Same verdicts in every mode.  Forks inherit the setting. */
 int zkgpu_set_horner_mode(zkgpu_ctx* ctx, int mode);
 
 /* Transcript replay of the whole-proof paths: 0 automatic (default: one WAVEFRONT per transaction --

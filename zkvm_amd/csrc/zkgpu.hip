@@ -104,7 +104,7 @@ struct zkgpu_ctx {
   int group_size = 16;             // transactions per group check (1 = every transaction on its own)
   bool serial = false;             // measurement aid: the whole DAG of a batch on one stream
   int horner_mode = 0;             // 0 automatic, 1 one chain per transaction, 2 one per group (+ the failed groups' transactions)
-  std::atomic<uint32_t> fail_permille{0};   // root context: share of failed groups in the batch finished last (any fork)
+  std::atomic<uint32_t> last_failed_groups{0};   // root context: failed groups in the batch finished last (any fork)
   hipEvent_t ev_dig = nullptr, ev_u = nullptr;
   Buffer prep_com, prep_proofs, prep_r, prep_pw, prep_ch, prep_wf, prep_dyn_sc, prep_dyn_pt, prep_st_sc;
   Buffer coal_com, coal_proofs, coal_r;  // merged inputs of the batches a zkgpu_verifier runs as one (session.hpp, tickets)
@@ -247,7 +247,6 @@ inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + pe
 // multiplexes them in software (measured: 100-200 ms per step beyond that)
 constexpr int STREAM_SETS = 2;
 constexpr int MAX_FORKS = 9;
-constexpr uint32_t HORNER_PER_TX_PERMILLE = 10;   // share of failed groups beyond which every transaction gets its own Horner chain up front
 constexpr size_t LOCATE_MIN_BATCH = 2048;      // transactions per batch from which failed groups are located instead of re-checked in full
 constexpr size_t COOP_TRANSCRIPT_MAX = 1536;   // transactions per batch up to which the transcript runs one wavefront each
 
@@ -690,13 +689,6 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
   if (c->profiling) prof_collect(c);
   uint32_t st;
   memcpy(&st, h + nbytes, 4);
-  if (c->group_size > 1) {             // the share of failed groups steers the next batches' Horner arrangement
-    uint32_t n_fail;
-    memcpy(&n_fail, h + nbytes + 36, 4);
-    const uint64_t n_groups = (c->pending_batch + c->group_size - 1) / c->group_size;
-    zkgpu_ctx* root = c->parent ? c->parent : c;
-    root->fail_permille.store(n_groups ? (uint32_t)std::min<uint64_t>(1000, (1000ull * n_fail) / n_groups) : 0u);
-  }
   if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
   memcpy(accept_bitmap, h, nbytes);
   return ZKGPU_OK;
@@ -901,11 +893,12 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   HIP_TRY(c, hipStreamWaitEvent(L, c->ev_sm, 0));
   // Horner chains (the longest dependent chain of a batch): one per GROUP over the summed windows of its transactions,
   // the transactions of a failed group getting theirs after k_group_combine has named the group -- a third less point
-  // arithmetic when few groups fail, but two chains in a row for the groups that do.  When many fail (the share of
-  // failed groups in the batch this context family finished last, root->fail_permille), one chain per transaction
-  // up front is faster.  Same verdicts either way.
+  // arithmetic, but a batch in which ANY group fails walks two chains in a row, and the chain is latency, not work
+  // (measured: +2 % without failures, -3 % with 1 bad transaction in 64).  So: per group while the batch this context
+  // family finished last had no failed group at all (root->last_failed_groups), else one chain per transaction up
+  // front.  Same verdicts either way.
   zkgpu_ctx* root = c->parent ? c->parent : c;
-  const bool group_first = group > 1 && (c->horner_mode == 2 || (c->horner_mode == 0 && root->fail_permille.load() < HORNER_PER_TX_PERMILLE));
+  const bool group_first = group > 1 && (c->horner_mode == 2 || (c->horner_mode == 0 && root->last_failed_groups.load() == 0));
   if (group_first) {
     {
       Launch l(c, "k_group_windows", L);
@@ -1040,6 +1033,11 @@ int pipe_wait(zkgpu_ctx* c, uint8_t* accept_bitmap) {
   const char* h = (const char*)c->pinned;
   uint32_t st;
   memcpy(&st, h + nbytes, 4);
+  if (c->group_size > 1) {             // failed groups steer the next batches' Horner arrangement (pipe_enqueue)
+    uint32_t n_fail;
+    memcpy(&n_fail, h + nbytes + 36, 4);
+    (c->parent ? c->parent : c)->last_failed_groups.store(n_fail);
+  }
   if ((st & 4u) && c->last.valid && c->group_size > 1) {
     // a located transaction did not account for its group's sum (probability ~2^-248, or the test hook): verdicts
     // must not rest on it -- run the same batch again with every transaction checked on its own
