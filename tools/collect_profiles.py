@@ -4,6 +4,7 @@
   profiles/<tag>_bench_kernel_trace_summary.txt    per-kernel durations of the last dispatches (= timed steps)
   profiles/<tag>_solo_kernel_stats.csv             rocprofv3 --stats table of `bench.py --solo` (each kernel alone on the chip)
   profiles/<tag>_msm_kernel_stats.csv              ... of the 2^20 MSM pipeline (tools/msm_bench.py)
+  profiles/<tag>_prover_kernel_stats.csv           ... of the device prover (tools/prover_profile.py: 2048 cloak proofs per call)
   profiles/<tag>_{bench,solo,msm}.json             the JSON records those commands printed
   profiles/<tag>_pmc_<PASS>.txt, <tag>_pmcmsm_<PASS>.txt   per kernel and counter: dispatches, last value, mean
   profiles/pmc_traffic.json                        HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B)
@@ -21,8 +22,8 @@ def short(name):
     return name.split("(")[0].replace("zk::", "")
 
 
-for kind in ("prof", "solo", "msm"):
-    label = {"prof": "bench", "solo": "solo", "msm": "msm"}[kind]
+for kind in ("prof", "solo", "msm", "prover"):
+    label = {"prof": "bench", "solo": "solo", "msm": "msm", "prover": "prover"}[kind]
     stats = glob.glob(os.path.join(go, "%s_%s" % (kind, tag), "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, label)))
