@@ -161,7 +161,11 @@ int zkgpu_cloak_verify_batch(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t ge
  * equation (one workgroup per transaction) and evaluates it, all on the GPU: the only PCIe
  * traffic is commitments + proof bytes + 64 bytes of verifier randomness per transaction.
  * Every statement of the batch has the plan's shape and `proof_len` bytes of proof
- * (fixed stride).  Verdicts are identical to zkgpu_cloak_verify_batch. */
+ * (fixed stride): the two-phase wire format (version byte 1, 16 + 2k elements) or, for a whole batch, the one-phase
+ * one (version byte 0, A_I2 A_O2 S2 left out: 13 + 2k elements -- what upstream's R1CSProof::to_bytes writes for a
+ * statement without a second phase; read as the identity for the three points).  A version byte that disagrees with the
+ * length rejects that proof.  Blocks of mixed shapes (zkgpu_verifier_*) may mix the two forms freely.
+ * Verdicts are identical to zkgpu_cloak_verify_batch. */
 typedef struct zkgpu_cloak_plan zkgpu_cloak_plan;
 int zkgpu_cloak_plan_create(zkgpu_ctx *ctx, uint32_t n_in, uint32_t n_out, size_t gens_capacity,
                             zkgpu_cloak_plan **out);

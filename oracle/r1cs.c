@@ -521,6 +521,17 @@ int r1cs_verify_prepare(r1cs_cs *cs, const uint8_t *proof, size_t proof_len, con
   if (cs->is_prover) return -1;
   merlin_transcript *tr = &cs->tr;
   memset(out, 0, sizeof *out);
+  /* the one-phase wire format (version byte 0: A_I2, A_O2, S2 left out, 13 + 2k elements) is the two-phase one with
+   * the identity in their place (upstream R1CSProof::from_bytes) */
+  uint8_t expanded[1 + 32 * (16 + 2 * 32)];
+  if (proof_len >= 1 + 32 * 13 && proof[0] == 0 && (proof_len - 1) % 32 == 0 && proof_len + 96 <= sizeof expanded) {
+    expanded[0] = 1;
+    memcpy(expanded + 1, proof + 1, 96);
+    memset(expanded + 97, 0, 96);
+    memcpy(expanded + 193, proof + 97, proof_len - 97);
+    proof = expanded;
+    proof_len += 96;
+  }
   if (proof_len < 1 + 32 * 16 || proof[0] != 1) return -2;
   if ((proof_len - 1) % 32) return -2;
   size_t words = (proof_len - 1) / 32;

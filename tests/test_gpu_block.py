@@ -63,6 +63,49 @@ def test_mixed_arity_shard_8192_vs_oracle(ctx, gens512, oracle):
         bv.close()
 
 
+def test_one_phase_wire_format_on_the_device(ctx, gens512, oracle):
+    """Proofs in the one-phase wire format (version byte 0, A_I2 A_O2 S2 left out: what upstream writes for a statement
+    without a second phase, here the 1x1 cloak) through every device path -- a uniform batch, and a block mixing both
+    forms and shapes -- against the oracle, which reads the short form as the long one with identities."""
+    from zkvm_amd.verifier import Verifier, BlockVerifier
+    fix = load_mixed_fixture()
+    one = fix[(1, 1)][:48]
+    short = []
+    for i, (com, proof) in enumerate(one):
+        assert proof[0] == 1 and proof[97:193] == bytes(96)
+        sp = bytearray(b"\x00" + proof[1:97] + proof[193:])
+        if i % 7 == 3:
+            sp[1 + 32 * 8 + 5] ^= 2                               # t_x: only the multiscalar multiplication can tell
+        if i % 11 == 5:
+            sp[0] = 1                                            # version byte disagrees with the length
+        short.append((com, bytes(sp)))
+    n = len(short)
+    r = hashlib.shake_256(b"one phase device").digest(64 * n)
+    plen = len(short[0][1])
+    want = list(oracle.cloak_verify_batch(b"".join(c for c, _ in short), 1, 1, b"".join(p for _, p in short), plen, r, threads=8))
+    assert 0 < sum(want) < n
+    v = Verifier(ctx, gens512)
+    try:
+        for group in (16, 1):
+            ctx.set_group_size(group)
+            assert bits(v.verify_packed_gpu(1, 1, n, b"".join(c for c, _ in short), b"".join(p for _, p in short), plen, r), n) == want
+    finally:
+        ctx.set_group_size(16)
+        v.close()
+    # a block: long and short 1x1 proofs, 2x2 proofs, and a 2x2 proof cut down to the short form (parsed, then rejected)
+    two = fix[(2, 2)][:20]
+    txs = [(1, 1, c, p) for c, p in one[:10]] + [(1, 1, c, p) for c, p in short[:30]] + [(2, 2, c, p) for c, p in two]
+    txs.append((2, 2, two[0][0], b"\x00" + two[0][1][1:97] + two[0][1][193:]))
+    rb = hashlib.shake_256(b"one phase block").digest(64 * len(txs))
+    want_b = oracle_block_bits(oracle, txs, rb)
+    assert want_b[-1] == 0 and sum(want_b) > 40
+    bv = BlockVerifier(ctx, gens512)
+    try:
+        assert bits(bv.verify(_cloak(txs), rb), len(txs)) == want_b
+    finally:
+        bv.close()
+
+
 def test_block_rejects_unverifiable_shapes_one_by_one(ctx, oracle):
     """Too few generators for a shape, a statement with no values, a proof of the wrong length: that transaction is
     rejected (InvalidGeneratorsLength / malformed proof in the reference), its neighbours are verified, and the

@@ -107,6 +107,37 @@ def test_verifier_prepare_rejects_malformed(host, oracle):
     assert _prepare(host, com, 1, 1, proof, r, 256) is None                        # k does not match the statement
 
 
+def compact_proof(proof: bytes) -> bytes:
+    """the one-phase wire format of a proof whose A_I2, A_O2, S2 are the identity: version byte 0, the three points left out"""
+    assert proof[0] == 1 and proof[97:193] == bytes(96)
+    return b"\x00" + proof[1:97] + proof[193:]
+
+
+def test_one_phase_wire_format_equals_two_phase_with_identities(host, oracle):
+    """upstream R1CSProof::to_bytes writes 13 + 2k elements under version byte 0 when the statement has no second phase
+    (from_bytes restores the identity for A_I2, A_O2, S2): oracle and host verifier produce the same multiscalar
+    multiplication from either form (1x1 cloak: one phase), and reject a version byte that disagrees with the length."""
+    com, proofs = oracle.cloak_prove_batch(2, 1, 1, b"\x21" * 32)
+    for i, proof in enumerate(proofs):
+        c = com[128 * i: 128 * (i + 1)]
+        r = hashlib.shake_256(b"one phase %d" % i).digest(64)
+        short = compact_proof(proof)
+        assert len(short) == len(proof) - 96
+        want = oracle.cloak_verify_prepare(c, 1, 1, proof, r)
+        assert want is not None and oracle.cloak_verify_prepare(c, 1, 1, short, r) == want
+        assert oracle.cloak_verify(c, 1, 1, short, r)
+        assert _prepare(host, c, 1, 1, short, r, 64) == _prepare(host, c, 1, 1, proof, r, 64) != None
+        assert _prepare(host, c, 1, 1, b"\x01" + short[1:], r, 64) is None          # two-phase tag on the short form
+        assert _prepare(host, c, 1, 1, b"\x00" + proof[1:], r, 64) is None          # one-phase tag on the long form
+        assert oracle.cloak_verify_prepare(c, 1, 1, b"\x00" + proof[1:], r) is None
+        bad = bytearray(short); bad[40] ^= 1
+        assert not oracle.cloak_verify(c, 1, 1, bytes(bad), r)
+    # a two-phase statement sent in the short form is a proof with identities where points were: parsed, then rejected
+    com2, proofs2 = oracle.cloak_prove_batch(1, 2, 2, b"\x22" * 32)
+    short2 = b"\x00" + proofs2[0][1:97] + proofs2[0][193:]
+    assert not oracle.cloak_verify(com2, 2, 2, short2, bytes(64))
+
+
 def _golden_cloak():
     import struct
     raw = open(os.path.join(ROOT, "tests", "golden", "cloak_2x2_proofs.bin"), "rb").read()

@@ -62,16 +62,22 @@ __device__ inline scm scm_pow_u32(const scm& base, uint32_t e) {
 }
 
 // ---- k_proof_unpack -------------------------------------------------------------------
+// compact != 0: the one-phase wire format (version byte 0; A_I2, A_O2, S2 left out, proof_stride = 1 + 4 (proof_words - 24)):
+// the identity -- 32 zero bytes -- stands in for the three points, as upstream's R1CSProof::from_bytes has it
 __global__ void __launch_bounds__(256)
 k_proof_unpack(const uint8_t* __restrict__ proofs, uint64_t proof_stride, uint32_t* __restrict__ pw,
-               uint32_t proof_words, uint32_t batch, uint32_t* __restrict__ wellformed) {
+               uint32_t proof_words, uint32_t batch, uint32_t* __restrict__ wellformed, uint32_t compact) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (uint64_t)batch * proof_words) return;
   const uint32_t tx = (uint32_t)(g / proof_words), j = (uint32_t)(g % proof_words);
   const uint8_t* p = proofs + (uint64_t)tx * proof_stride;
-  const uint8_t* b = p + 1 + 4 * (uint64_t)j;
-  pw[g] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
-  if (j == 0 && p[0] != 1) atomicAnd(&wellformed[tx], 0u);   // wrong wire-format version
+  uint32_t v = 0;
+  if (!compact || j < 24 || j >= 48) {
+    const uint8_t* b = p + 1 + 4 * (uint64_t)((compact && j >= 48) ? j - 24 : j);
+    v = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+  }
+  pw[g] = v;
+  if (j == 0 && p[0] != (compact ? 0 : 1)) atomicAnd(&wellformed[tx], 0u);   // version byte and length must agree
 }
 
 // ---- k_transcript -----------------------------------------------------------------------

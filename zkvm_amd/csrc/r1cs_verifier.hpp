@@ -112,6 +112,17 @@ class R1csVerifier : public ConstraintSystemT<Scalar> {
   // pairs in the generator set (static index of H_i is 2 + gens_capacity + i).
   // r = verifier's random weight.  false: malformed proof (the reference returns Err).
   bool prepare(const uint8_t* proof, size_t len, const Scalar& r, size_t gens_capacity, VerifierMsm& out) {
+    // the one-phase wire format (version byte 0: A_I2, A_O2, S2 left out, 13 + 2k elements) is the two-phase one with
+    // the identity in their place (upstream R1CSProof::from_bytes)
+    std::vector<uint8_t> expanded;
+    if (len >= 1 + 32 * 13 && proof[0] == 0 && (len - 1) % 32 == 0) {
+      expanded.assign(len + 96, 0);
+      expanded[0] = 1;
+      std::memcpy(&expanded[1], proof + 1, 96);
+      std::memcpy(&expanded[193], proof + 97, len - 97);
+      proof = expanded.data();
+      len += 96;
+    }
     if (len < 1 + 32 * 16 || proof[0] != 1 || (len - 1) % 32) return false;
     const size_t words = (len - 1) / 32;
     if ((words - 16) % 2) return false;

@@ -232,7 +232,7 @@ int zkgpu_txblock_create(zkgpu_verifier* v, size_t batch, const uint32_t* n_in, 
       zkgpu_txblock::Group g;
       g.n_in = n_in[i]; g.n_out = n_out[i]; g.proof_len = (size_t)plen;
       g.plan = verifier_plan(v, n_in[i], n_out[i]);
-      if (g.plan && plen != 1 + 4ull * g.plan->shape.proof_words) g.plan = nullptr;   // wrong length for the statement
+      if (g.plan && !proof_len_fits(g.plan->shape, plen)) g.plan = nullptr;   // wrong length for the statement
       g.com_off = g.proof_off = g.r_off = 0;
       it = where.emplace(key, b->groups.size()).first;
       b->groups.push_back(std::move(g));
@@ -395,7 +395,7 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
     zkgpu_cloak_plan* plan = verifier_plan(v, head->n_in, head->n_out);
     int rc = ZKGPU_OK;
     const void *p_com = pick[0]->d_com, *p_proofs = pick[0]->d_proofs, *p_r = pick[0]->d_r;
-    if (plan && head->proof_len == 1 + 4ull * plan->shape.proof_words && pick.size() > 1) {
+    if (plan && proof_len_fits(plan->shape, head->proof_len) && pick.size() > 1) {
       std::lock_guard<std::recursive_mutex> lk(L->mu);
       DeviceGuard g(L->device);
       const size_t wcom = (size_t)plan->shape.m * 32;

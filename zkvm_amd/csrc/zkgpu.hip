@@ -719,6 +719,10 @@ struct PrepLaunch {
   size_t proof_len;
 };
 
+// proof bytes of a statement shape: the two-phase wire format, or the one-phase one (three points fewer)
+inline bool proof_len_fits(const PrepShape& sh, size_t len) { return len == 1 + 4ull * sh.proof_words || len + 96 == 1 + 4ull * sh.proof_words; }
+inline uint32_t proof_is_compact(const PrepShape& sh, size_t len) { return len + 96 == 1 + 4ull * sh.proof_words ? 1u : 0u; }
+
 bool pipe_eligible(const zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps) {
   return ps && ps->table && job.n_static && job.n_dyn && !c->forced_w && job.n_dyn <= 128ull * job.n_msm;
 }
@@ -791,7 +795,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
       Launch l(c, "k_proof_unpack", L);
       hipLaunchKernelGGL(k_proof_unpack, dim3(blocks_for((uint64_t)B * sh.proof_words, 256)), dim3(256), 0, L,
                          prep->d_proofs, (uint64_t)prep->proof_len, (uint32_t*)c->prep_pw.p, sh.proof_words,
-                         (uint32_t)B, (uint32_t*)c->prep_wf.p);
+                         (uint32_t)B, (uint32_t*)c->prep_wf.p, proof_is_compact(sh, prep->proof_len));
     }
     // the proof-specific points need the proof bytes only: gather, decompress and build their small
     // tables on the shared stream while the transcript is replayed
@@ -2388,7 +2392,7 @@ int zkgpu_cloak_verify_submit(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloa
   {
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->pending) return ZKGPU_EINVAL;
-    if (proof_len != 1 + 4ull * sh.proof_words) {     // wrong length for this statement: every proof is Err
+    if (!proof_len_fits(sh, proof_len)) {     // wrong length for this statement: every proof is Err
       std::vector<uint8_t> z((batch + 7) / 8, 0);
       park_sync_result(c, ZKGPU_OK, z.data(), batch);
       return ZKGPU_OK;
@@ -2425,7 +2429,7 @@ int zkgpu_cloak_verify_batch_gpu_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, zkg
   memset(accept_bitmap, 0, (batch + 7) / 8);
   if (batch == 0) return ZKGPU_OK;
   if (!d_commitments || !d_proofs || !d_r || batch >= (1ull << 24)) return ZKGPU_EINVAL;
-  if (proof_len != 1 + 4ull * plan->shape.proof_words) return ZKGPU_OK;
+  if (!proof_len_fits(plan->shape, proof_len)) return ZKGPU_OK;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   DeviceGuard g(c->device);
   return cloak_verify_gpu_body(c, ps, plan, batch, (const uint32_t*)d_commitments, (const uint8_t*)d_proofs,
@@ -2513,7 +2517,7 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
     Launch l(c, "k_proof_unpack");
     hipLaunchKernelGGL(k_proof_unpack, dim3(blocks_for((uint64_t)B * sh.proof_words, 256)), dim3(256), 0, s,
                        d_proofs, (uint64_t)proof_len, (uint32_t*)c->prep_pw.p, sh.proof_words, B,
-                       (uint32_t*)c->prep_wf.p);
+                       (uint32_t*)c->prep_wf.p, proof_is_compact(sh, proof_len));
   }
   {
     Launch l(c, "k_transcript");
@@ -2559,7 +2563,7 @@ int zkgpu_cloak_verify_submit_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_
   {
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->pending) return ZKGPU_EINVAL;
-    if (proof_len != 1 + 4ull * plan->shape.proof_words) {     // wrong length for this statement: every proof is Err
+    if (!proof_len_fits(plan->shape, proof_len)) {     // wrong length for this statement: every proof is Err
       std::vector<uint8_t> z((batch + 7) / 8, 0);
       park_sync_result(c, ZKGPU_OK, z.data(), batch);
       return ZKGPU_OK;
