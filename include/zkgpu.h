@@ -428,6 +428,20 @@ int zkgpu_verifier_submit_dev(zkgpu_verifier *v, uint32_t n_in, uint32_t n_out, 
                               const void *d_proofs, size_t proof_len, const void *d_r, uint64_t *ticket);
 int zkgpu_verifier_wait(zkgpu_verifier *v, uint64_t ticket, uint8_t *accept_bitmap);
 
+/* ---- serialized transactions (replaces Tx::verify / Verifier::verify_tx for the PAYMENT SUBSET) --
+ * txs: the transactions back to back, tx_offsets[batch + 1].  Per transaction, on host threads: wire format
+ *     version u64 | mintime_ms u64 | maxtime_ms u64 | n u32 program[n] | R 32 s 32 | n u32 R1CSProof[n]      (little endian)
+ * and the VM over the instructions  push:n:x  drop  dup:k  roll:k  var  cloak:m:n  input  output:k  signtx  (one cloak per
+ * transaction), giving the transaction ID (Merkle root of the transaction log), the keys the signature must cover and the
+ * cloak's statement; then, for the whole batch on the device: the MuSig-aggregated keys, the Schnorr equations
+ * s B = R + c X as multiscalar multiplications == identity, and the cloak proofs through zkgpu_verifier_verify.
+ * accept bit i = all of it holds.  status (optional, batch bytes): 0 accepted, 1 rejected, 2 OUTSIDE THE SUBSET (another
+ * instruction, another version, no or several cloaks): the caller's own VM must decide -- such a transaction is never
+ * reported as invalid.  UNPINNED: format, opcodes and labels follow a recollection of the public ZkVM design notes
+ * (DESIGN.md sec 4.5); nothing under /root/reference defines them. */
+int zkgpu_tx_verify_batch(zkgpu_verifier *v, size_t batch, const uint8_t *txs, const uint64_t *tx_offsets, int host_threads,
+                          uint8_t *accept_bitmap, uint8_t *status);
+
 /* ---- one process per GPU: sharding and the RCCL exchange ------------------
  * Transactions are independent, so a block is cut into `world` contiguous shards balanced by the
  * number of multiscalar-multiplication terms (zkgpu_cloak_msm_terms of each shape; zkgpu_shard_cuts

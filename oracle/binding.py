@@ -382,3 +382,33 @@ def gadget_verify_prepare(kind: int, param: int, commitments: bytes, proof: byte
            [int.from_bytes(buf.raw[32 * i: 32 * i + 32], "little") for i in range(n.value)])
     lib.r1cs_msm_free(C.byref(m))
     return out
+
+
+# ---- ZkVM transactions of the payment subset (zkvm_tx.c) --------------------------------
+def tx_build_payment(n_in: int, n_out: int, quantities: Sequence[int], flavors: Sequence[bytes], seed: bytes,
+                     mintime: int = 0, maxtime: int = 2 ** 63) -> bytes:
+    """a signed transaction: n_in unspent contracts -> cloak -> n_out contracts (b"" when it cannot be built)"""
+    lib = load()
+    lib.zko_tx_build_payment.restype = C.c_size_t
+    nv = n_in + n_out
+    assert len(quantities) == nv and len(flavors) == nv and len(seed) == 32
+    q = (C.c_uint64 * nv)(*quantities)
+    cap = 65536
+    out = C.create_string_buffer(cap)
+    n = lib.zko_tx_build_payment(C.c_size_t(n_in), C.c_size_t(n_out), q, b"".join(flavors), seed, C.c_uint64(mintime),
+                                 C.c_uint64(maxtime), out, C.c_size_t(cap))
+    return out.raw[:n]
+
+
+def tx_id(tx: bytes):
+    """-> (status, txid, n_in, n_out); status 0 ok, 1 invalid, 2 outside the subset"""
+    txid = C.create_string_buffer(32)
+    a, b = C.c_size_t(0), C.c_size_t(0)
+    rc = load().zko_tx_id(tx, C.c_size_t(len(tx)), txid, C.byref(a), C.byref(b))
+    return rc, txid.raw, a.value, b.value
+
+
+def tx_verify(tx: bytes, r_bytes: bytes) -> int:
+    """Tx::verify: 0 accepted, 1 rejected, 2 outside the subset"""
+    assert len(r_bytes) == 64
+    return int(load().zko_tx_verify(tx, C.c_size_t(len(tx)), r_bytes))

@@ -1,0 +1,147 @@
+"""ZkVM transactions of the payment subset: the product's host half of
+Tx::verify (zkvm_tx.hpp: wire format, VM, transaction ID, signature equation) against the oracle's independent
+restatement (oracle/zkvm_tx.c), on transactions the oracle builds and signs."""
+import ctypes as C
+import hashlib
+import os
+import random
+import struct
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host():
+    from zkvm_amd.build import build, HOST_OUT
+    build()
+    return C.CDLL(HOST_OUT)
+
+
+def payment(oracle, n_in, n_out, seed, two_flavors=False, mintime=0, maxtime=2 ** 40):
+    rng = random.Random(seed)
+    fl = [rng.randrange(2 ** 250).to_bytes(32, "little") for _ in range(2)]
+    q_in = [rng.randrange(1, 2 ** 40) for _ in range(n_in)]
+    f_in = [fl[j & 1] if two_flavors else fl[0] for j in range(n_in)]
+    tot = [0, 0]
+    for a, f in zip(q_in, f_in):
+        tot[fl.index(f)] += a
+    q_out, f_out = [], []
+    for j in range(n_out):
+        fi = (j & 1) if two_flavors else 0
+        last = all(((jj & 1) if two_flavors else 0) != fi for jj in range(j + 1, n_out))
+        a = tot[fi] if last else tot[fi] // 3
+        tot[fi] -= a
+        q_out.append(a); f_out.append(fl[fi])
+    assert tot == [0, 0]
+    tx = oracle.tx_build_payment(n_in, n_out, q_in + q_out, f_in + f_out, hashlib.sha256(b"tx %d" % seed).digest(), mintime, maxtime)
+    assert tx
+    return tx
+
+
+def prepare(host, tx):
+    txid = C.create_string_buffer(32)
+    n_in, n_out = C.c_uint32(0), C.c_uint32(0)
+    com = C.create_string_buffer(64 * 128)
+    ss, sp = C.create_string_buffer(32 * 80), C.create_string_buffer(32 * 80)
+    n_sig, po, pl = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    rc = host.zkhost_tx_prepare(tx, C.c_size_t(len(tx)), txid, C.byref(n_in), C.byref(n_out), com, C.c_size_t(64 * 128), ss, sp,
+                                C.c_size_t(80), C.byref(n_sig), C.byref(po), C.byref(pl))
+    return rc, txid.raw, n_in.value, n_out.value, com.raw[: 64 * (n_in.value + n_out.value)], ss.raw[: 32 * n_sig.value], \
+        sp.raw[: 32 * n_sig.value], po.value, pl.value
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 2), (3, 2), (1, 2)])
+def test_transaction_statement_equals_oracle(host, oracle, shape):
+    """Same transaction ID, same cloak statement, and a signature equation that the oracle's multiscalar multiplication
+    finds to be the identity -- for a valid transaction; the same verdict for damaged ones."""
+    n_in, n_out = shape
+    tx = payment(oracle, n_in, n_out, 100 * n_in + n_out, two_flavors=n_in >= 2 and n_out >= 2)
+    rc, txid, a, b, com, ss, sp, po, pl = prepare(host, tx)
+    want_rc, want_id, wa, wb = oracle.tx_id(tx)
+    assert (rc, txid, a, b) == (0, want_id, n_in, n_out) == (want_rc, want_id, wa, wb)
+    proof = tx[po: po + pl]
+    assert po + pl == len(tx)
+    r = hashlib.shake_256(b"tx r").digest(64)
+    assert oracle.cloak_verify(com, n_in, n_out, proof, r)          # the statement the VM extracted is the one that was proved
+    n_terms = len(ss) // 32
+    assert n_terms == 2 + n_in
+    assert oracle.verify_batch(ss, sp, [0, n_terms]) == bytes([1])   # s B - R - sum c a_i X_i == identity
+    assert oracle.tx_verify(tx, r) == 0
+    # damage, one byte at a time: header, program (a contract), signature R, signature s, proof
+    sig_at = po - 4 - 64
+    for at in (8, 16, 40, 28 + 40, sig_at + 3, sig_at + 35, po + 50, len(tx) - 1):
+        bad = bytearray(tx); bad[at] ^= 1
+        bad = bytes(bad)
+        want = oracle.tx_verify(bad, r)
+        assert want == 1, at
+        rc2, txid2, a2, b2, com2, ss2, sp2, po2, pl2 = prepare(host, bad)
+        if rc2 != 0:
+            assert rc2 == 1
+            continue
+        sig_ok = oracle.verify_batch(ss2, sp2, [0, len(ss2) // 32]) == bytes([1])
+        proof_ok = oracle.cloak_verify(com2, a2, b2, bad[po2: po2 + pl2], r)
+        assert not (sig_ok and proof_ok), at
+
+
+def test_transactions_outside_the_subset_are_reported_not_rejected(host, oracle):
+    tx = payment(oracle, 2, 2, 7)
+    plen = struct.unpack("<I", tx[24:28])[0]
+    prog = tx[28: 28 + plen]
+    rest = tx[28 + plen:]
+
+    def with_program(p, version=1):
+        return struct.pack("<QQQ", version, 0, 2 ** 40) + struct.pack("<I", len(p)) + p + rest
+
+    for bad, want in ((with_program(prog + b"\x15"), 2),                 # an instruction of the full VM (issue)
+                      (with_program(prog, version=2), 2),                 # a later transaction version
+                      (with_program(prog + b"\x02"), 1),                  # drop on an empty stack: invalid
+                      (with_program(prog[:-5]), 1),                       # an output missing: a value left on the stack
+                      (with_program(b""), 2),                             # no cloak at all: nothing for the proof system
+                      (tx[:-1], 1), (tx + b"\x00", 1), (tx[:20], 1)):
+        assert oracle.tx_id(bad)[0] == want
+        assert prepare(host, bad)[0] == want
+
+
+@pytest.mark.gpu
+def test_transactions_verified_on_the_device_equal_oracle():
+    """zkgpu_tx_verify_batch: a batch of serialized transactions of several shapes, some damaged in every part, some outside
+    the subset -- accept bits and status bytes against the oracle's Tx::verify."""
+    import oracle.binding as oracle
+    from zkvm_amd import Context
+    from zkvm_amd.verifier import BulletproofGens, BlockVerifier
+    ctx = Context(0)
+    gens = BulletproofGens(ctx, 256, table_bits=8)
+    bv = BlockVerifier(ctx, gens)
+    try:
+        txs = []
+        for i in range(40):
+            shape = [(1, 1), (2, 2), (3, 2), (1, 2), (2, 1)][i % 5]
+            txs.append(payment(oracle, shape[0], shape[1], 1000 + i, two_flavors=(i % 3 == 0) and min(shape) >= 2))
+        for i, at in ((3, 8), (7, 40), (11, -1), (13, None), (17, "s"), (19, "R"), (23, "v2"), (29, "op")):
+            t = bytearray(txs[i])
+            plen = struct.unpack("<I", t[24:28])[0]
+            if at == "s":
+                t[28 + plen + 40] ^= 4
+            elif at == "R":
+                t[28 + plen + 2] ^= 4
+            elif at == "v2":
+                t[0] = 2
+            elif at == "op":
+                t = bytearray(struct.pack("<QQQ", 1, 0, 2 ** 40) + struct.pack("<I", plen + 1) + bytes(t[28: 28 + plen]) + b"\x15" + bytes(t[28 + plen:]))
+            elif at is None:
+                t = t[:-7]
+            else:
+                t[at] ^= 1
+            txs[i] = bytes(t)
+        r = hashlib.shake_256(b"tx device r").digest(64)
+        want = [oracle.tx_verify(t, r) for t in txs]
+        assert want.count(0) == 32 and want.count(2) == 2
+        bm, st = bv.verify_txs(txs, host_threads=4)
+        assert list(st) == want
+        assert [(bm[i // 8] >> (i % 8)) & 1 for i in range(len(txs))] == [1 if w == 0 else 0 for w in want]
+    finally:
+        bv.close()
+        gens.close()
+        ctx.close()

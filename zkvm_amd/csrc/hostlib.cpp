@@ -8,6 +8,7 @@
 #include "transcript_tape.hpp"
 #include "keccak_coop.hpp"
 #include "prover_plan.hpp"
+#include "zkvm_tx.hpp"
 
 #include <array>
 #include <map>
@@ -594,3 +595,44 @@ int zkhost_prove_dev_r1cs(const char* label, uint32_t m, uint32_t n1, uint32_t n
   return pv_emulate(d, md, vw, bw, gw, seed, generators, gens_capacity, commitments, proof, proof_cap, proof_len_out);
 }
 }  // extern "C"
+
+// ---- ZkVM transactions (zkvm_tx.hpp): the host half of Tx::verify, with this library's reference group arithmetic for
+// the aggregated key.  Out: status (0 ok, 1 invalid, 2 outside the subset), txid, the cloak's shape and commitments,
+// the terms of the signature equation (scalars | points, 32 bytes each; *n_sig of them).
+extern "C" int zkhost_tx_prepare(const uint8_t* tx, size_t len, uint8_t txid[32], uint32_t* n_in, uint32_t* n_out, uint8_t* commitments,
+                                 size_t com_cap, uint8_t* sig_scalars, uint8_t* sig_points, size_t sig_cap, size_t* n_sig,
+                                 size_t* proof_offset, size_t* proof_len) {
+  using namespace zk::zkvm;
+  TxStatement st = tx_prepare(tx, len);
+  *n_sig = 0;
+  if (st.status != TX_OK) return (int)st.status;
+  const size_t n_terms = st.sig_scalars.size() / 32, n_keys = n_terms - 2;
+  if (st.commitments.size() > com_cap || n_terms > sig_cap) return -1;
+  // aggregated key X = sum a_i X_i with the reference multiscalar multiplication
+  std::vector<ge> pts(n_keys);
+  MsmRow row;
+  for (size_t i = 0; i < n_keys; ++i) {
+    uint32_t w[8];
+    std::memcpy(w, &st.sig_points[32 * (2 + i)], 32);
+    if (!ristretto_decode(pts[i], w)) return (int)TX_INVALID;
+    Scalar a;
+    Scalar::from_canonical(&st.sig_scalars[32 * (2 + i)], a);
+    row.add(a, (uint32_t)i);
+  }
+  std::vector<uint8_t> agg;
+  host_rows(pts, {row}, agg);
+  ge B;
+  B.X = fe_BASE_X(); B.Y = fe_BASE_Y(); B.Z = fe_one(); B.T = fe_BASE_T();
+  uint32_t benc[8];
+  ristretto_encode(benc, B);
+  tx_finish_signature(st, (const uint8_t*)benc, agg.data());
+  std::memcpy(txid, st.txid, 32);
+  *n_in = st.n_in; *n_out = st.n_out;
+  std::memcpy(commitments, st.commitments.data(), st.commitments.size());
+  std::memcpy(sig_scalars, st.sig_scalars.data(), st.sig_scalars.size());
+  std::memcpy(sig_points, st.sig_points.data(), st.sig_points.size());
+  *n_sig = n_terms;
+  *proof_offset = (size_t)(st.proof - tx);
+  *proof_len = st.proof_len;
+  return 0;
+}

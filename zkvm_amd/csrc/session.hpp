@@ -12,6 +12,7 @@
 // RCCL is bound at run time (dlopen of librccl.so.1, the soname torch's bundled copy also carries), so
 // the library loads and every single-GPU entry point works on a machine without it.
 #pragma once
+#include "zkvm_tx.hpp"
 
 #include <deque>
 #include <dlfcn.h>
@@ -639,6 +640,81 @@ int zkgpu_verifier_verify_sharded(zkgpu_verifier* v, zkgpu_comm* cm, size_t batc
                                po.data(), r_bytes ? r_bytes + 64 * lo : nullptr, local.data());
   }
   return zkgpu_comm_allgather_bitmap(cm, cuts.data(), local.data(), rc, accept_bitmap);
+}
+
+// ---- serialized transactions (Tx::verify / Verifier::verify_tx on transaction bytes) ------
+// Per transaction on host threads (zkvm_tx.hpp): wire format, the VM of the payment subset, transaction ID, the terms
+// of the signature equation; then for the whole batch on the device: the aggregated keys (one small multiscalar
+// multiplication each), the signature equations (multiscalar multiplication == identity), and the cloak proofs as a
+// block of mixed shapes.  status[i] (optional): 0 accepted, 1 rejected, 2 outside the subset (the caller's own VM must
+// decide; the accept bit is 0).
+int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, const uint64_t* tx_offsets, int host_threads,
+                          uint8_t* accept_bitmap, uint8_t* status) {
+  using namespace zk::zkvm;
+  if (!v || !accept_bitmap) return ZKGPU_EINVAL;
+  memset(accept_bitmap, 0, (batch + 7) / 8);
+  if (status) memset(status, TX_INVALID, batch);
+  if (batch == 0) return ZKGPU_OK;
+  if (!txs || !tx_offsets || batch >= (1ull << 31)) return ZKGPU_EINVAL;
+  for (size_t i = 0; i < batch; ++i) if (tx_offsets[i + 1] < tx_offsets[i]) return ZKGPU_EINVAL;
+  std::vector<TxStatement> st(batch);
+  host_parallel(batch, host_threads, [&](size_t i) { st[i] = tx_prepare(txs + tx_offsets[i], (size_t)(tx_offsets[i + 1] - tx_offsets[i])); });
+  std::vector<size_t> live;
+  for (size_t i = 0; i < batch; ++i) {
+    if (status) status[i] = (uint8_t)st[i].status;
+    if (st[i].status == TX_OK) live.push_back(i);
+  }
+  if (live.empty()) return ZKGPU_OK;
+  zkgpu_ctx* c = v->root;
+  // 1. aggregated keys X = sum a_i X_i
+  std::vector<uint8_t> sc, pt, agg(32 * live.size()), okb((live.size() + 7) / 8);
+  std::vector<uint64_t> off(1, 0);
+  for (size_t i : live) {
+    sc.insert(sc.end(), st[i].sig_scalars.begin() + 64, st[i].sig_scalars.end());
+    pt.insert(pt.end(), st[i].sig_points.begin() + 64, st[i].sig_points.end());
+    off.push_back(sc.size() / 32);
+  }
+  TRY(zkgpu_msm_batch(c, sc.data(), pt.data(), off.data(), live.size(), agg.data(), okb.data()));
+  uint8_t B[32], Bb[32];
+  TRY(zkgpu_pedersen_gens(c, B, Bb));
+  // 2. the signature equations  s B - R - sum (c a_i) X_i == identity
+  std::vector<size_t> signed_ok;
+  sc.clear(); pt.clear(); off.assign(1, 0);
+  for (size_t j = 0; j < live.size(); ++j) {
+    const size_t i = live[j];
+    if (!((okb[j / 8] >> (j % 8)) & 1)) { if (status) status[i] = TX_INVALID; continue; }   // a key that is no point
+    tx_finish_signature(st[i], B, &agg[32 * j]);
+    sc.insert(sc.end(), st[i].sig_scalars.begin(), st[i].sig_scalars.end());
+    pt.insert(pt.end(), st[i].sig_points.begin(), st[i].sig_points.end());
+    off.push_back(sc.size() / 32);
+    signed_ok.push_back(i);
+  }
+  std::vector<uint8_t> sig_bits((signed_ok.size() + 7) / 8 + 1, 0);
+  if (!signed_ok.empty()) TRY(zkgpu_verify_batch(c, sc.data(), pt.data(), off.data(), signed_ok.size(), sig_bits.data()));
+  // 3. the cloak proofs of the transactions whose signature holds
+  std::vector<size_t> proved;
+  std::vector<uint32_t> n_in, n_out;
+  std::vector<uint8_t> com, proofs;
+  std::vector<uint64_t> po(1, 0);
+  for (size_t j = 0; j < signed_ok.size(); ++j) {
+    const size_t i = signed_ok[j];
+    if (!((sig_bits[j / 8] >> (j % 8)) & 1)) { if (status) status[i] = TX_INVALID; continue; }
+    proved.push_back(i);
+    n_in.push_back(st[i].n_in); n_out.push_back(st[i].n_out);
+    com.insert(com.end(), st[i].commitments.begin(), st[i].commitments.end());
+    proofs.insert(proofs.end(), st[i].proof, st[i].proof + st[i].proof_len);
+    po.push_back(proofs.size());
+  }
+  if (proved.empty()) return ZKGPU_OK;
+  std::vector<uint8_t> bits((proved.size() + 7) / 8, 0);
+  TRY(zkgpu_verifier_verify(v, proved.size(), n_in.data(), n_out.data(), com.data(), proofs.data(), po.data(), nullptr, bits.data()));
+  for (size_t j = 0; j < proved.size(); ++j) {
+    const size_t i = proved[j];
+    const bool ok = (bits[j / 8] >> (j % 8)) & 1;
+    if (ok) accept_bitmap[i / 8] |= (uint8_t)(1u << (i % 8));
+    if (status) status[i] = ok ? TX_OK : TX_INVALID;
+  }
+  return ZKGPU_OK;
 }
 
 }  // extern "C"

@@ -34,6 +34,7 @@
 #include "ipa_kernels.hpp"
 #include "prover_plan.hpp"
 #include "prover_kernels.hpp"
+#include "zkvm_tx.hpp"
 
 using namespace zk;
 

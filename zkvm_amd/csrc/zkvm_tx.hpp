@@ -1,0 +1,348 @@
+// zkvm_tx.hpp -- the caller's side of the hot path (second half): a serialized ZkVM
+// transaction -> what `Tx::verify` / `Verifier::verify_tx` hands to the proof system: the transaction ID, the keys the
+// transaction signature must cover, and the statement + proof of its `cloak`.  Host code, as upstream's VM is.
+//
+// UNPINNED RECOLLECTION.  /root/reference holds no source and no specification: the wire format, the
+// opcodes, the labels and the hashing below restate what the survey's appendix and the public ZkVM design notes
+// describe, as far as they could be recalled; they are self-consistent across this file and the oracle
+// (oracle/zkvm_tx.c, written separately) and NOT checkable against upstream here.  DESIGN.md sec 4.5 is the normative
+// description of what this subset is; everything outside it is reported as "unsupported", never as "invalid".
+//
+//   Tx       := version:u64 | mintime_ms:u64 | maxtime_ms:u64 | n:u32 program[n] | R:32 s:32 | n:u32 proof[n]
+//   program  := instruction*          (subset: a payment)
+//       0x00 push:n:x   0x02 drop   0x03 dup:k   0x04 roll:k   0x06 var   0x18 cloak:m:n
+//       0x1b input      0x1c output:k            0x20 signtx           (immediates: u32 little-endian)
+//   Contract := anchor:32 | predicate:32 | k:u32 | item*      item := 0x00 n:u32 bytes[n]  |  0x02 qty:32 flavor:32
+#pragma once
+#include "merlin.hpp"
+#include "scalar.hpp"
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace zk {
+namespace zkvm {
+
+enum TxStatus : uint8_t { TX_OK = 0, TX_INVALID = 1, TX_UNSUPPORTED = 2 };
+
+struct TxStatement {
+  TxStatus status = TX_INVALID;
+  const char* why = "";
+  uint64_t version = 0, mintime = 0, maxtime = 0;
+  uint8_t txid[32] = {0};
+  // the one cloak of the transaction: m inputs, n outputs, 64 bytes (qty, flavor commitments) per value, inputs first
+  uint32_t n_in = 0, n_out = 0;
+  std::vector<uint8_t> commitments;
+  const uint8_t* proof = nullptr;
+  size_t proof_len = 0;
+  // the signature check  s B - R - sum_i (c a_i) X_i == identity  as terms of a multiscalar multiplication
+  std::vector<uint8_t> sig_scalars, sig_points;   // 32 bytes each, same count
+};
+
+struct Item {
+  enum Kind : uint8_t { Data, Variable, Value, Contract } kind = Data;
+  std::vector<uint8_t> bytes;          // Data: the string; Variable: 32-byte commitment; Value: qty | flavor; Contract: its serialization
+};
+
+inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint64_t rd64(const uint8_t* p) { return (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
+
+inline void contract_id(const uint8_t* ser, size_t n, uint8_t id[32]) {
+  Transcript t("ZkVM.contractid");
+  t.append_message("contract", ser, n);
+  t.challenge_bytes("id", id, 32);
+}
+inline void ratchet_anchor(const uint8_t old_anchor[32], uint8_t fresh[32]) {
+  Transcript t("ZkVM.ratchet-anchor");
+  t.append_message("old", old_anchor, 32);
+  t.challenge_bytes("new", fresh, 32);
+}
+
+// Merkle root over the log entries (RFC 6962 split: the largest power of two below the count goes left), every hash a
+// Merlin transcript: leaf = entry's own messages then "merkle.leaf"; node = "L", "R" then "merkle.node"
+struct LogEntry {
+  enum Kind : uint8_t { Header, Input, Output } kind;
+  uint64_t a = 0, b = 0, c = 0;
+  uint8_t id[32] = {0};
+};
+inline void merkle_root(const char* label, const LogEntry* e, size_t n, uint8_t out[32]) {
+  Transcript t(label);
+  if (n == 0) { t.challenge_bytes("merkle.empty", out, 32); return; }
+  if (n == 1) {
+    switch (e->kind) {
+      case LogEntry::Header: t.append_u64("tx.version", e->a); t.append_u64("tx.mintime", e->b); t.append_u64("tx.maxtime", e->c); break;
+      case LogEntry::Input: t.append_message("input", e->id, 32); break;
+      case LogEntry::Output: t.append_message("output", e->id, 32); break;
+    }
+    t.challenge_bytes("merkle.leaf", out, 32);
+    return;
+  }
+  size_t k = 1;
+  while (2 * k < n) k *= 2;
+  uint8_t l[32], r[32];
+  merkle_root(label, e, k, l);
+  merkle_root(label, e + k, n - k, r);
+  t.append_message("L", l, 32);
+  t.append_message("R", r, 32);
+  t.challenge_bytes("merkle.node", out, 32);
+}
+
+// parses a serialized contract; false: malformed.  items: Data or Value
+inline bool parse_contract(const uint8_t* p, size_t n, uint8_t anchor[32], uint8_t predicate[32], std::vector<Item>& items, bool& unsupported) {
+  if (n < 68) return false;
+  std::memcpy(anchor, p, 32);
+  std::memcpy(predicate, p + 32, 32);
+  const uint32_t k = rd32(p + 64);
+  size_t pos = 68;
+  for (uint32_t i = 0; i < k; ++i) {
+    if (pos >= n) return false;
+    const uint8_t type = p[pos++];
+    Item it;
+    if (type == 0x00) {
+      if (n - pos < 4) return false;
+      const uint32_t len = rd32(p + pos);
+      pos += 4;
+      if (n - pos < len) return false;
+      it.kind = Item::Data;
+      it.bytes.assign(p + pos, p + pos + len);
+      pos += len;
+    } else if (type == 0x02) {
+      if (n - pos < 64) return false;
+      it.kind = Item::Value;
+      it.bytes.assign(p + pos, p + pos + 64);
+      pos += 64;
+    } else if (type == 0x01) {
+      unsupported = true;      // a program item: outside the subset
+      return false;
+    } else {
+      return false;
+    }
+    items.push_back(std::move(it));
+  }
+  return pos == n;
+}
+
+inline void serialize_contract(const uint8_t anchor[32], const uint8_t predicate[32], const std::vector<Item>& items, std::vector<uint8_t>& out) {
+  out.assign(anchor, anchor + 32);
+  out.insert(out.end(), predicate, predicate + 32);
+  const uint32_t k = (uint32_t)items.size();
+  for (int b = 0; b < 4; ++b) out.push_back((uint8_t)(k >> (8 * b)));
+  for (const Item& it : items) {
+    if (it.kind == Item::Value) {
+      out.push_back(0x02);
+      out.insert(out.end(), it.bytes.begin(), it.bytes.end());
+    } else {
+      out.push_back(0x00);
+      const uint32_t len = (uint32_t)it.bytes.size();
+      for (int b = 0; b < 4; ++b) out.push_back((uint8_t)(len >> (8 * b)));
+      out.insert(out.end(), it.bytes.begin(), it.bytes.end());
+    }
+  }
+}
+
+// Runs the transaction: parse, VM, transaction ID, signature equation.  The statement refers into `tx` (proof bytes).
+inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
+  TxStatement st;
+  auto fail = [&st](TxStatus s, const char* why) { st.status = s; st.why = why; return st; };
+  if (len < 24 + 4) return fail(TX_INVALID, "truncated header");
+  st.version = rd64(tx); st.mintime = rd64(tx + 8); st.maxtime = rd64(tx + 16);
+  size_t pos = 24;
+  const uint32_t prog_len = rd32(tx + pos);
+  pos += 4;
+  if (len - pos < prog_len) return fail(TX_INVALID, "truncated program");
+  const uint8_t* prog = tx + pos;
+  pos += prog_len;
+  if (len - pos < 64 + 4) return fail(TX_INVALID, "truncated signature");
+  const uint8_t* sig = tx + pos;
+  pos += 64;
+  const uint32_t proof_len = rd32(tx + pos);
+  pos += 4;
+  if (len - pos != proof_len) return fail(TX_INVALID, "proof length does not match the transaction's");
+  st.proof = tx + pos;
+  st.proof_len = proof_len;
+  if (st.version != 1) return fail(TX_UNSUPPORTED, "transaction version");
+  if (st.mintime > st.maxtime) return fail(TX_INVALID, "mintime after maxtime");
+
+  std::vector<Item> stack;
+  std::vector<LogEntry> log;
+  std::vector<std::vector<uint8_t>> keys;
+  LogEntry hdr; hdr.kind = LogEntry::Header; hdr.a = st.version; hdr.b = st.mintime; hdr.c = st.maxtime;
+  log.push_back(hdr);
+  bool have_anchor = false, cloaked = false;
+  uint8_t last_anchor[32] = {0};
+  size_t pc = 0;
+  auto imm32 = [&](uint32_t& v) { if (prog_len - pc < 4) return false; v = rd32(prog + pc); pc += 4; return true; };
+  while (pc < prog_len) {
+    const uint8_t op = prog[pc++];
+    switch (op) {
+      case 0x00: {   // push:n:x
+        uint32_t n;
+        if (!imm32(n) || prog_len - pc < n) return fail(TX_INVALID, "push runs past the program");
+        Item it; it.kind = Item::Data; it.bytes.assign(prog + pc, prog + pc + n);
+        pc += n;
+        stack.push_back(std::move(it));
+        break;
+      }
+      case 0x02:     // drop
+        if (stack.empty()) return fail(TX_INVALID, "stack underflow");
+        if (stack.back().kind == Item::Value || stack.back().kind == Item::Contract) return fail(TX_INVALID, "drop of a value or a contract");
+        stack.pop_back();
+        break;
+      case 0x03: {   // dup:k
+        uint32_t k;
+        if (!imm32(k) || k >= stack.size()) return fail(TX_INVALID, "dup out of range");
+        const Item& src = stack[stack.size() - 1 - k];
+        if (src.kind == Item::Value || src.kind == Item::Contract) return fail(TX_INVALID, "dup of a value or a contract");
+        stack.push_back(src);
+        break;
+      }
+      case 0x04: {   // roll:k
+        uint32_t k;
+        if (!imm32(k) || k >= stack.size()) return fail(TX_INVALID, "roll out of range");
+        Item it = std::move(stack[stack.size() - 1 - k]);
+        stack.erase(stack.end() - 1 - k);
+        stack.push_back(std::move(it));
+        break;
+      }
+      case 0x06: {   // var
+        if (stack.empty() || stack.back().kind != Item::Data || stack.back().bytes.size() != 32) return fail(TX_INVALID, "var needs a 32-byte commitment");
+        stack.back().kind = Item::Variable;
+        break;
+      }
+      case 0x18: {   // cloak:m:n
+        uint32_t m, n;
+        if (!imm32(m) || !imm32(n)) return fail(TX_INVALID, "cloak immediates");
+        if (cloaked) return fail(TX_UNSUPPORTED, "more than one cloak per transaction");
+        if (m == 0 || n == 0 || m > 64 || n > 64) return fail(TX_UNSUPPORTED, "cloak arity");
+        if (stack.size() < (size_t)m + 2 * (size_t)n) return fail(TX_INVALID, "stack underflow");
+        std::vector<uint8_t> outs(64 * (size_t)n), ins(64 * (size_t)m);
+        for (uint32_t j = n; j-- > 0;) {     // .. q_j f_j on top
+          for (int half = 1; half >= 0; --half) {
+            if (stack.back().kind != Item::Variable) return fail(TX_INVALID, "cloak outputs must be variables");
+            std::memcpy(&outs[64 * j + 32 * half], stack.back().bytes.data(), 32);
+            stack.pop_back();
+          }
+        }
+        for (uint32_t i = m; i-- > 0;) {
+          if (stack.back().kind != Item::Value) return fail(TX_INVALID, "cloak inputs must be values");
+          std::memcpy(&ins[64 * i], stack.back().bytes.data(), 64);
+          stack.pop_back();
+        }
+        st.n_in = m; st.n_out = n;
+        st.commitments = ins;
+        st.commitments.insert(st.commitments.end(), outs.begin(), outs.end());
+        for (uint32_t j = 0; j < n; ++j) { Item v; v.kind = Item::Value; v.bytes.assign(&outs[64 * j], &outs[64 * j] + 64); stack.push_back(std::move(v)); }
+        cloaked = true;
+        break;
+      }
+      case 0x1b: {   // input
+        if (stack.empty() || stack.back().kind != Item::Data) return fail(TX_INVALID, "input needs a serialized contract");
+        uint8_t anchor[32], pred[32];
+        std::vector<Item> payload;
+        bool unsupported = false;
+        const std::vector<uint8_t> ser = std::move(stack.back().bytes);
+        stack.pop_back();
+        if (!parse_contract(ser.data(), ser.size(), anchor, pred, payload, unsupported))
+          return fail(unsupported ? TX_UNSUPPORTED : TX_INVALID, "malformed contract");
+        LogEntry e; e.kind = LogEntry::Input;
+        contract_id(ser.data(), ser.size(), e.id);
+        log.push_back(e);
+        std::memcpy(last_anchor, e.id, 32);
+        have_anchor = true;
+        Item c; c.kind = Item::Contract; c.bytes = ser;
+        stack.push_back(std::move(c));
+        break;
+      }
+      case 0x1c: {   // output:k
+        uint32_t k;
+        if (!imm32(k)) return fail(TX_INVALID, "output immediate");
+        if (stack.size() < (size_t)k + 1) return fail(TX_INVALID, "stack underflow");
+        if (stack.back().kind != Item::Data || stack.back().bytes.size() != 32) return fail(TX_INVALID, "output needs a 32-byte predicate");
+        if (!have_anchor) return fail(TX_INVALID, "output before any input: no anchor");
+        uint8_t pred[32];
+        std::memcpy(pred, stack.back().bytes.data(), 32);
+        stack.pop_back();
+        std::vector<Item> items(stack.end() - k, stack.end());
+        stack.erase(stack.end() - k, stack.end());
+        for (const Item& it : items) if (it.kind != Item::Data && it.kind != Item::Value) return fail(TX_INVALID, "output payload must be data or values");
+        uint8_t anchor[32];
+        ratchet_anchor(last_anchor, anchor);
+        std::memcpy(last_anchor, anchor, 32);
+        std::vector<uint8_t> ser;
+        serialize_contract(anchor, pred, items, ser);
+        LogEntry e; e.kind = LogEntry::Output;
+        contract_id(ser.data(), ser.size(), e.id);
+        log.push_back(e);
+        break;
+      }
+      case 0x20: {   // signtx
+        if (stack.empty() || stack.back().kind != Item::Contract) return fail(TX_INVALID, "signtx needs a contract");
+        uint8_t anchor[32], pred[32];
+        std::vector<Item> payload;
+        bool unsupported = false;
+        const std::vector<uint8_t> ser = std::move(stack.back().bytes);
+        stack.pop_back();
+        if (!parse_contract(ser.data(), ser.size(), anchor, pred, payload, unsupported)) return fail(TX_INVALID, "malformed contract");
+        keys.emplace_back(pred, pred + 32);
+        for (Item& it : payload) stack.push_back(std::move(it));
+        break;
+      }
+      default:
+        return fail(TX_UNSUPPORTED, "instruction outside the payment subset");
+    }
+  }
+  if (!stack.empty()) return fail(TX_INVALID, "stack not empty at the end");
+  if (!cloaked) return fail(TX_UNSUPPORTED, "no cloak: nothing for the proof system");
+  if (keys.empty()) return fail(TX_INVALID, "no key signs the transaction");
+  merkle_root("ZkVM.txid", log.data(), log.size(), st.txid);
+
+  // signature: X = sum a_i X_i (MuSig key aggregation), c = H(txid, X, R);  s B == R + c X
+  Scalar s;
+  if (!Scalar::from_canonical(sig + 32, s)) return fail(TX_INVALID, "signature scalar not canonical");
+  Transcript agg("Musig.aggregated-key");
+  agg.append_u64("n", keys.size());
+  for (const auto& k : keys) agg.append_point("X", k.data());
+  std::vector<Scalar> a(keys.size());
+  for (size_t i = 0; i < keys.size(); ++i) {
+    Transcript ti = agg;
+    ti.append_u64("i", i);
+    a[i] = ti.challenge_scalar("a_i");
+  }
+  // the aggregated key as an encoding is not needed by the equation, but it is what the challenge binds: it has to be
+  // computed, which needs the group -- the caller (device or test library) supplies it through `aggregate`
+  st.sig_scalars.resize(32 * (2 + keys.size()));
+  st.sig_points.resize(32 * (2 + keys.size()));
+  st.status = TX_OK;
+  // slots: [0] B (filled by the caller: scalar s), [1] R (scalar -1), [2 + i] X_i (scalar -c a_i, c filled in by finish_signature)
+  s.to_bytes(&st.sig_scalars[0]);
+  (-Scalar::one()).to_bytes(&st.sig_scalars[32]);
+  std::memcpy(&st.sig_points[32], sig, 32);
+  for (size_t i = 0; i < keys.size(); ++i) {
+    a[i].to_bytes(&st.sig_scalars[32 * (2 + i)]);          // a_i for now
+    std::memcpy(&st.sig_points[32 * (2 + i)], keys[i].data(), 32);
+  }
+  return st;
+}
+
+// second half of the signature preparation, once the aggregated key X = sum a_i X_i is known as an encoding
+// (one small multiscalar multiplication per transaction: zkgpu_msm_batch on the device, host_rows in the CPU tests)
+inline void tx_finish_signature(TxStatement& st, const uint8_t basepoint[32], const uint8_t agg_key[32]) {
+  Transcript t("ZkVM.signtx");
+  t.append_message("txid", st.txid, 32);
+  t.append_message("dom-sep", (const uint8_t*)"schnorr-signature v1", 20);
+  t.append_point("X", agg_key);
+  t.append_point("R", &st.sig_points[32]);
+  const Scalar c = t.challenge_scalar("c");
+  std::memcpy(&st.sig_points[0], basepoint, 32);
+  const size_t n_keys = st.sig_scalars.size() / 32 - 2;
+  for (size_t i = 0; i < n_keys; ++i) {
+    Scalar ai;
+    Scalar::from_canonical(&st.sig_scalars[32 * (2 + i)], ai);
+    (-(c * ai)).to_bytes(&st.sig_scalars[32 * (2 + i)]);
+  }
+}
+
+}  // namespace zkvm
+}  // namespace zk

@@ -192,6 +192,18 @@ class BlockVerifier:
         self._check(self.lib.zkgpu_verifier_verify_block(self.h, block.h, bm))
         return bm.raw[: (block.n + 7) // 8]
 
+    def verify_txs(self, txs: Sequence[bytes], host_threads: int = 0):
+        """zkgpu_tx_verify_batch: serialized ZkVM transactions (payment subset) -> (accept bitmap, status bytes:
+        0 accepted, 1 rejected, 2 outside the subset)"""
+        batch = len(txs)
+        offs = [0]
+        for t in txs:
+            offs.append(offs[-1] + len(t))
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        st = C.create_string_buffer(max(batch, 1))
+        self._check(self.lib.zkgpu_tx_verify_batch(self.h, batch, b"".join(txs), (C.c_uint64 * (batch + 1))(*offs), host_threads, bm, st))
+        return bm.raw[: (batch + 7) // 8], st.raw[:batch]
+
     def verify_sharded(self, comm, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None) -> bytes:
         """zkgpu_verifier_verify_sharded: every rank passes the whole block and receives the whole bitmap."""
         batch = len(txs)
