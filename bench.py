@@ -319,6 +319,33 @@ def prover_program_microbench(ctx, host_threads: int, batch: int = 1024):
                     "the algebra on host threads (zkgpu_set_prover_mode 1, batch 256)"}
 
 
+def tx_verify_microbench(ctx, gens, host_threads: int):
+    """SURVEY.md sec 8 row f-3: Tx::verify on SERIALIZED transactions (payment subset) -- the 1024 committed transactions
+    (tests/golden/tx_2x2_1024_wrappers.bin around the committed cloak proofs): wire format + VM + transaction ID on host
+    threads, aggregated keys, Schnorr equations and cloak proofs on the device.  Host buffers in, PCIe included."""
+    import ctypes as C
+    from gpu_util import load_tx_fixture
+    from zkvm_amd.verifier import BlockVerifier
+    txs = load_tx_fixture()
+    bv = BlockVerifier(ctx, gens)
+    try:
+        bm, st = bv.verify_txs(txs[:64], host_threads)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            bm, st = bv.verify_txs(txs, host_threads)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        assert bm == bitmap_of([1] * len(txs)) and not any(st), "a committed transaction was not accepted"
+    finally:
+        bv.close()
+    return {"tx_per_s": round(len(txs) / best, 1), "batch": len(txs), "ms": round(best * 1e3, 3), "host_threads": host_threads,
+            "tx_bytes": len(txs[0]),
+            "note": "zkgpu_tx_verify_batch on 1024 serialized 2-in/2-out payment transactions (host memory in): VM and "
+                    "transaction IDs on host threads; key aggregation, signature equations and cloak proofs on the device; "
+                    "one call at a time (no batches in flight), Python marshalling included"}
+
+
 def prover_microbench(ctx, gens, host_threads: int, batch: int = 2048):
     """BASELINE configs[4] (prover side): `batch` 2-in/2-out cloak proofs; every proof verified by the device verifier."""
     import random
@@ -667,6 +694,7 @@ def run_config2(args, W):
             if world == 1 and not args.no_msm:
                 line["prover"] = prover_microbench(ctx, gens, host_threads)
                 line["prover_1024_constraints"] = prover_program_microbench(ctx, host_threads)
+                line["tx_verify"] = tx_verify_microbench(ctx, gens, host_threads)
                 line["msm_2p20"] = msm_microbench(ctx, torch, dev)
         emit(line)
     W.close()

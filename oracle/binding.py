@@ -400,6 +400,19 @@ def tx_build_payment(n_in: int, n_out: int, quantities: Sequence[int], flavors: 
     return out.raw[:n]
 
 
+def tx_wrap_payment(n_in: int, n_out: int, commitments: bytes, proof: bytes, seed: bytes, mintime: int = 0,
+                    maxtime: int = 2 ** 63) -> bytes:
+    """a signed transaction around an existing cloak proof (no proving)"""
+    lib = load()
+    lib.zko_tx_wrap_payment.restype = C.c_size_t
+    assert len(commitments) == 64 * (n_in + n_out) and len(seed) == 32
+    cap = 65536
+    out = C.create_string_buffer(cap)
+    n = lib.zko_tx_wrap_payment(C.c_size_t(n_in), C.c_size_t(n_out), commitments, proof, C.c_size_t(len(proof)), seed,
+                                C.c_uint64(mintime), C.c_uint64(maxtime), out, C.c_size_t(cap))
+    return out.raw[:n]
+
+
 def tx_id(tx: bytes):
     """-> (status, txid, n_in, n_out); status 0 ok, 1 invalid, 2 outside the subset"""
     txid = C.create_string_buffer(32)

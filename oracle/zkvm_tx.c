@@ -354,17 +354,13 @@ static void derive3(const uint8_t seed[32], const char *tag, uint64_t i, uint8_t
   shake256_squeeze(&c, out, n);
 }
 
-/* A payment: n_in unspent contracts (one value each, a key each) -> one cloak -> n_out contracts (one value each).
- * quantities / flavors: inputs first, as zko_cloak_prove takes them; keys, anchors, blinding factors and the nonce are
- * derived from the seed.  Writes the transaction, returns its length (0: does not fit / proving failed). */
-size_t zko_tx_build_payment(size_t n_in, size_t n_out, const uint64_t *quantities, const uint8_t *flavors, const uint8_t seed[32],
-                            uint64_t mintime, uint64_t maxtime, uint8_t *out, size_t cap) {
+/* A payment around an EXISTING cloak proof: n_in unspent contracts (one value each, a key each) -> one cloak -> n_out
+ * contracts (one value each).  commitments: 64 bytes per value, inputs first, as the proof commits to them; keys,
+ * anchors, recipients and the nonce are derived from the seed.  Writes the signed transaction, returns its length
+ * (0: does not fit). */
+size_t zko_tx_wrap_payment(size_t n_in, size_t n_out, const uint8_t *com, const uint8_t *proof, size_t proof_len,
+                           const uint8_t seed[32], uint64_t mintime, uint64_t maxtime, uint8_t *out, size_t cap) {
   if (n_in == 0 || n_out == 0 || n_in > 16 || n_out > 16) return 0;
-  size_t nv = n_in + n_out;
-  uint8_t *com = malloc(64 * nv), *proof = malloc(4096);
-  size_t proof_len = 0;
-  if (zko_cloak_prove(quantities, flavors, n_in, n_out, seed, com, proof, 4096, &proof_len, NULL)) { free(com); free(proof); return 0; }
-  /* program */
   uint8_t *prog = malloc(16384);
   size_t pl = 0;
   sc x[16];
@@ -403,7 +399,7 @@ size_t zko_tx_build_payment(size_t n_in, size_t n_out, const uint64_t *quantitie
     prog[pl++] = 0x1c; put32(prog + pl, 1); pl += 4;
   }
   size_t total = 24 + 4 + pl + 64 + 4 + proof_len;
-  if (total > cap) { free(com); free(proof); free(prog); return 0; }
+  if (total > cap) { free(prog); return 0; }
   put64(out, 1); put64(out + 8, mintime); put64(out + 16, maxtime);
   put32(out + 24, (uint32_t)pl);
   memcpy(out + 28, prog, pl);
@@ -433,6 +429,20 @@ size_t zko_tx_build_payment(size_t n_in, size_t n_out, const uint64_t *quantitie
       ret = total;
     }
   }
-  free(run); free(com); free(proof); free(prog);
+  free(run); free(prog);
+  return ret;
+}
+
+/* The same with the cloak proved here: quantities / flavors, inputs first, as zko_cloak_prove takes them; blinding
+ * factors derived from the seed (0: proving failed / does not fit). */
+size_t zko_tx_build_payment(size_t n_in, size_t n_out, const uint64_t *quantities, const uint8_t *flavors, const uint8_t seed[32],
+                            uint64_t mintime, uint64_t maxtime, uint8_t *out, size_t cap) {
+  if (n_in == 0 || n_out == 0 || n_in > 16 || n_out > 16) return 0;
+  size_t nv = n_in + n_out;
+  uint8_t *com = malloc(64 * nv), *proof = malloc(4096);
+  size_t proof_len = 0, ret = 0;
+  if (zko_cloak_prove(quantities, flavors, n_in, n_out, seed, com, proof, 4096, &proof_len, NULL) == 0)
+    ret = zko_tx_wrap_payment(n_in, n_out, com, proof, proof_len, seed, mintime, maxtime, out, cap);
+  free(com); free(proof);
   return ret;
 }

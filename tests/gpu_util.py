@@ -200,3 +200,23 @@ def gadget_witness(kind: int, param: int, values):
     for i in range(n):
         mult_def += [2 * i, 2 * i + 1]
     return mult_def, []
+
+
+# ---- serialized ZkVM transactions (tests/golden/gen_tx_fixture.py) -----------------------------------------
+def load_tx_fixture():
+    """-> list of signed payment transactions (bytes): the wrappers of tx_2x2_1024_wrappers.bin around the proofs of
+    cloak_2x2_1024.bin"""
+    import os
+    import struct
+    recs, n_in, n_out, plen = load_cloak_fixture()
+    raw = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tx_2x2_1024_wrappers.bin"), "rb").read()
+    assert raw[:8] == b"ZKVMTXW1"
+    count, a, b, c = struct.unpack("<IIII", raw[8:24])
+    assert (count, a, b, c) == (len(recs), n_in, n_out, plen)
+    pos, txs = 24, []
+    for _, proof in recs:
+        (n,) = struct.unpack("<I", raw[pos: pos + 4])
+        txs.append(raw[pos + 4: pos + 4 + n] + struct.pack("<I", plen) + proof)
+        pos += 4 + n
+    assert pos == len(raw)
+    return txs

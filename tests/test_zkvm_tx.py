@@ -104,6 +104,22 @@ def test_transactions_outside_the_subset_are_reported_not_rejected(host, oracle)
         assert prepare(host, bad)[0] == want
 
 
+def test_committed_transaction_fixture_is_what_the_oracle_accepts(host, oracle):
+    """tests/golden/tx_2x2_1024_wrappers.bin (+ the committed cloak proofs): a sample verifies under the oracle, and the
+    product's host half reads the same transaction IDs out of all 1024."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from gpu_util import load_tx_fixture
+    txs = load_tx_fixture()
+    assert len(txs) == 1024 and len(set(txs)) == 1024
+    for i in (0, 1, 511, 1023):
+        assert oracle.tx_verify(txs[i], hashlib.shake_256(b"fixture %d" % i).digest(64)) == 0
+    for i in range(0, 1024, 37):
+        rc, txid, a, b = oracle.tx_id(txs[i])
+        got = prepare(host, txs[i])
+        assert rc == 0 and got[0] == 0 and got[1] == txid and (got[2], got[3]) == (a, b) == (2, 2)
+
+
 @pytest.mark.gpu
 def test_transactions_verified_on_the_device_equal_oracle():
     """zkgpu_tx_verify_batch: a batch of serialized transactions of several shapes, some damaged in every part, some outside
@@ -141,6 +157,34 @@ def test_transactions_verified_on_the_device_equal_oracle():
         bm, st = bv.verify_txs(txs, host_threads=4)
         assert list(st) == want
         assert [(bm[i // 8] >> (i % 8)) & 1 for i in range(len(txs))] == [1 if w == 0 else 0 for w in want]
+    finally:
+        bv.close()
+        gens.close()
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_the_1024_fixture_transactions_on_the_device():
+    """the benched input of bench.py's tx_verify leg: all 1024 committed transactions accepted, and a damaged copy of
+    every 16th rejected, alone"""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from gpu_util import load_tx_fixture
+    from zkvm_amd import Context
+    from zkvm_amd.verifier import BulletproofGens, BlockVerifier
+    txs = load_tx_fixture()
+    for i in range(5, 1024, 16):
+        t = bytearray(txs[i])
+        t[(97 * i) % len(t)] ^= 1 << (i % 8)
+        txs[i] = bytes(t)
+    ctx = Context(0)
+    gens = BulletproofGens(ctx, 256, table_bits=12)
+    bv = BlockVerifier(ctx, gens)
+    try:
+        bm, st = bv.verify_txs(txs)
+        bad = set(range(5, 1024, 16))
+        assert [i for i in range(1024) if not (bm[i // 8] >> (i % 8)) & 1] == sorted(bad)
+        assert all((st[i] != 0) == (i in bad) for i in range(1024))
     finally:
         bv.close()
         gens.close()
