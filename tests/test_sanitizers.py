@@ -52,6 +52,43 @@ DRIVER = textwrap.dedent(r"""
     out = C.create_string_buffer(32)
     for op in range(6):
         assert host.zkhost_scalar_op(op, bytes([255]) * 64, bytes(range(64)), out) == 0
+    # the device prover's phase functions (prover_dev.hpp) run on the host: same proof as the oracle's
+    class Ge(C.Structure):
+        _fields_ = [("v", C.c_uint64 * 20)]
+    def enc(g):
+        o = C.create_string_buffer(32); orc.ristretto_encode(o, C.byref(g)); return o.raw
+    b_, bb_ = Ge(), Ge()
+    orc.pedersen_gens(C.byref(b_), C.byref(bb_))
+    gs, hs = (Ge * 64)(), (Ge * 64)()
+    orc.bulletproof_gens_chain(gs, C.c_size_t(64), C.c_char(b"G"), C.c_uint32(0))
+    orc.bulletproof_gens_chain(hs, C.c_size_t(64), C.c_char(b"H"), C.c_uint32(0))
+    gens = enc(b_) + enc(bb_) + b"".join(enc(gs[i]) for i in range(64)) + b"".join(enc(hs[i]) for i in range(64))
+    com2 = C.create_string_buffer(64 * 2); pr2 = C.create_string_buffer(4096); plen2 = C.c_size_t(0)
+    assert host.zkhost_prove_dev_cloak(1, 1, q, fl, bytes(32), gens, C.c_size_t(64), com2, pr2, C.c_size_t(4096), C.byref(plen2)) == 0
+    assert com2.raw == com.raw and pr2.raw[:plen2.value] == pr.raw[:plen.value]
+    # serialized transactions: the oracle builds one, both sides read it, then every truncation and a byte flip every 13 bytes
+    orc.zko_tx_build_payment.restype = C.c_size_t
+    txb = C.create_string_buffer(65536)
+    q4 = (C.c_uint64 * 4)(5, 9, 4, 10)
+    n = orc.zko_tx_build_payment(C.c_size_t(2), C.c_size_t(2), q4, bytes([1] + [0] * 31) * 4, bytes(range(32)), C.c_uint64(1), C.c_uint64(9), txb, C.c_size_t(65536))
+    tx = txb.raw[:n]
+    assert n > 1000 and orc.zko_tx_verify(tx, C.c_size_t(n), r) == 0
+    def host_tx(t):
+        txid = C.create_string_buffer(32); a, b = C.c_uint32(0), C.c_uint32(0); cm = C.create_string_buffer(64 * 128)
+        ss, sp = C.create_string_buffer(32 * 80), C.create_string_buffer(32 * 80)
+        ns, po, pl = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        return host.zkhost_tx_prepare(t, C.c_size_t(len(t)), txid, C.byref(a), C.byref(b), cm, C.c_size_t(64 * 128), ss, sp, C.c_size_t(80),
+                                      C.byref(ns), C.byref(po), C.byref(pl)), txid.raw
+    tid = C.create_string_buffer(32)
+    assert orc.zko_tx_id(tx, C.c_size_t(n), tid, None, None) == 0
+    assert host_tx(tx) == (0, tid.raw)
+    for cut in list(range(0, n, 41)) + [n - 1]:
+        assert host_tx(tx[:cut])[0] != 0 and orc.zko_tx_verify(tx[:cut], C.c_size_t(cut), r) != 0
+    for at in range(24, n - 1100, 13):                                     # header, program and signature bytes
+        bad = bytearray(tx); bad[at] ^= 0x81
+        bad = bytes(bad)
+        assert orc.zko_tx_verify(bad, C.c_size_t(n), r) != 0
+        host_tx(bad)
     print("sanitized run ok")
 """)
 
