@@ -844,11 +844,11 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="transactions per GPU (config 4: default 8192)")
     ap.add_argument("--table-bits", type=int, default=16, help="window width of the fixed-base generator tables")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="device batches in flight per GPU (contexts): default 3 with --tickets, 6 without, 6 for config 4")
+                    help="device batches in flight per GPU (contexts): default 5 with --tickets, 6 without, 6 for config 4")
     ap.add_argument("--group", type=int, default=16, help="transactions per group check (1 = every transaction on its own)")
     ap.add_argument("--chunk", type=int, default=0, help="config 4: transactions per batch in flight (0 = library default)")
     ap.add_argument("--bad-every", type=int, default=64, help="config 2: one transaction in this many is corrupted (0 = none)")
-    ap.add_argument("--tickets", type=int, default=32,
+    ap.add_argument("--tickets", type=int, default=64,
                     help="config 2: batches kept in flight as tickets of a zkgpu_verifier, which merges them into device batches of --merge tx (0 = plain contexts)")
     ap.add_argument("--merge", type=int, default=8192, help="config 2 with --tickets: transactions per merged device batch")
     ap.add_argument("--locate-mode", type=int, default=0, choices=(0, 1, 2), help="zkgpu_set_locate_mode")
@@ -867,7 +867,7 @@ def main():
     if args.config == 4:
         args.tickets = 0
     if args.inflight <= 0:
-        args.inflight = 3 if args.tickets > 0 else 6
+        args.inflight = 5 if args.tickets > 0 else 6    # measured (r02k sweep): 32 / 3: 2.87 M, 64 / 5: 3.05 M, 128 / 9: 3.08 M tx/s
     W = World(args)
     (run_config2 if args.config == 2 else run_config4)(args, W)
 
