@@ -114,6 +114,8 @@ struct zkgpu_ctx {
   // multiplications with their offsets / generator indices, the points coming back, the proofs
   Buffer pv_plan, pv_state, pv_in, pv_rows0, pv_rows1, pv_rows2, pv_rows3, pv_lay, pv_pts, pv_com, pv_ab, pv_proofs;
   int prover_mode = 0;             // 0: everything between the multiplications on the device, 1: host threads in lockstep
+  std::vector<uint32_t> pv_plan_host;   // the tables pv_plan holds (compared before uploading again)
+  size_t pv_lay_batch = 0;              // batch size the scaffolding in pv_lay was built for (0: none)
   Buffer prep_absorb, prep_raw;    // cooperative transcript: absorbed words per segment, raw challenge bytes
   int locate_mode = 0;             // failed groups: 0 automatic, 1 always re-check every transaction, 2 always locate the culprit
   int transcript_mode = 0;         // 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction
@@ -1750,7 +1752,12 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
   std::vector<uint32_t> labels((hp.chal_labels.size() + 3) / 4, 0);
   memcpy(labels.data(), hp.chal_labels.data(), hp.chal_labels.size());
   const size_t o_lab = put(labels);
-  TRY(upload(c, c->pv_plan, blob.data(), blob.size() * 4));
+  (void)put({sh.m, sh.n1, sh.n, sh.pn, sh.gens_capacity});   // part of the key the cached scaffolding goes by
+  if (blob != c->pv_plan_host) {        // the same statement as in the last call: the tables are already there
+    TRY(upload(c, c->pv_plan, blob.data(), blob.size() * 4));
+    c->pv_plan_host = blob;
+    c->pv_lay_batch = 0;
+  }
   const uint32_t* base = (const uint32_t*)c->pv_plan.p;
   PvPlan P;
   P.init = base + o_init; P.chal_labels = (const uint8_t*)(base + o_lab); P.mono_chal = base + o_mc; P.mono_pow = base + o_mp;
@@ -1767,20 +1774,30 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
   }
   if (b_giv) HIP_TRY(c, hipMemcpyAsync(in + 2 * b_val, given, b_giv, hipMemcpyHostToDevice, s));
   HIP_TRY(c, hipMemcpyAsync(in + 2 * b_val + b_giv, rng_seeds, b_seed, hipMemcpyHostToDevice, s));
-  // rows and their scaffolding
+  // rows and their scaffolding (offsets and generator indices: kept on the device from call to call while statement and
+  // batch size stay the same)
   const size_t cap = sh.gens_capacity;
-  const PvRows l0 = pv_rows_pairs(batch * sh.m), l1 = pv_rows_commit(batch, 0, sh.n1, cap, false),
-               l2 = pv_rows_commit(batch, sh.n1, sh.n, cap, true), l3 = pv_rows_pairs(batch * 5);
   const size_t row_len = (size_t)sh.pn + 1, n_ipa_rows = 2 * batch;
-  std::vector<uint64_t> ipa_offs(n_ipa_rows + 1);
-  for (size_t r = 0; r <= n_ipa_rows; ++r) ipa_offs[r] = r * row_len;
-  std::vector<uint8_t> lay;
-  auto put_lay = [&lay](const void* p, size_t bytes) { const size_t at = lay.size(); lay.insert(lay.end(), (const uint8_t*)p, (const uint8_t*)p + bytes); while (lay.size() & 15) lay.push_back(0); return at; };
-  const PvRows* lays[4] = {&l0, &l1, &l2, &l3};
-  size_t o_off[4], o_idx[4];
-  for (int i = 0; i < 4; ++i) { o_off[i] = put_lay(lays[i]->offsets.data(), lays[i]->offsets.size() * 8); o_idx[i] = put_lay(lays[i]->index.data(), lays[i]->index.size() * 4); }
-  const size_t o_ipa = put_lay(ipa_offs.data(), ipa_offs.size() * 8);
-  TRY(upload(c, c->pv_lay, lay.data(), lay.size()));
+  const size_t lay_rows[4] = {batch * sh.m, 3 * batch, 3 * batch, 5 * batch};
+  const size_t lay_terms[4] = {2 * batch * sh.m, batch * (size_t)sh.r1_terms, batch * (size_t)sh.r2_terms, 10 * batch};
+  size_t o_off[4], o_idx[4], o_ipa, lay_bytes = 0;
+  auto place = [&lay_bytes](size_t bytes) { const size_t at = lay_bytes; lay_bytes = (lay_bytes + bytes + 15) & ~(size_t)15; return at; };
+  for (int i = 0; i < 4; ++i) { o_off[i] = place((lay_rows[i] + 1) * 8); o_idx[i] = place(lay_terms[i] * 4); }
+  o_ipa = place((n_ipa_rows + 1) * 8);
+  if (c->pv_lay_batch != batch) {
+    const PvRows l0 = pv_rows_pairs(batch * sh.m), l1 = pv_rows_commit(batch, 0, sh.n1, cap, false),
+                 l2 = pv_rows_commit(batch, sh.n1, sh.n, cap, true), l3 = pv_rows_pairs(batch * 5);
+    const PvRows* lays[4] = {&l0, &l1, &l2, &l3};
+    std::vector<uint8_t> lay(lay_bytes, 0);
+    for (int i = 0; i < 4; ++i) {
+      if (lays[i]->offsets.size() != lay_rows[i] + 1 || lays[i]->index.size() != lay_terms[i]) { c->last_error = "prover: row scaffolding out of step"; return ZKGPU_EINVAL; }
+      memcpy(&lay[o_off[i]], lays[i]->offsets.data(), lays[i]->offsets.size() * 8);
+      memcpy(&lay[o_idx[i]], lays[i]->index.data(), lays[i]->index.size() * 4);
+    }
+    for (size_t r = 0; r <= n_ipa_rows; ++r) { const uint64_t v = r * row_len; memcpy(&lay[o_ipa + 8 * r], &v, 8); }
+    TRY(upload(c, c->pv_lay, lay.data(), lay.size()));
+    c->pv_lay_batch = batch;
+  }
   const char* lb = (const char*)c->pv_lay.p;
   TRY(ensure(c, c->pv_state, batch * (size_t)sh.state_words * 4));
   TRY(ensure(c, c->pv_rows0, std::max<size_t>(batch * sh.m, 1) * 64));
@@ -1808,7 +1825,7 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
   B.ipa_w = (uint32_t*)c->ipa_w.p; B.ipa_u = (uint32_t*)c->ipa_u.p;
   uint32_t* pts = (uint32_t*)c->pv_pts.p;
   auto msm = [&](int which, const uint32_t* rows, uint32_t* out) {
-    return msm_ps_dev(c, ps, lays[which]->offsets.size() - 1, lays[which]->index.size(), rows, (const uint32_t*)(lb + o_idx[which]),
+    return msm_ps_dev(c, ps, lay_rows[which], lay_terms[which], rows, (const uint32_t*)(lb + o_idx[which]),
                       (const uint64_t*)(lb + o_off[which]), out);
   };
   const unsigned nb = (unsigned)batch;

@@ -63,6 +63,24 @@ class Prover:
         self.bp_gens = bp_gens
         self.host_threads = host_threads
 
+    def prove_packed(self, n_in: int, n_out: int, batch: int, quantities, flavors: bytes, seeds: bytes):
+        """zkgpu_cloak_prove_batch on contiguous inputs (quantities: ctypes array of batch x (n_in + n_out) u64; flavors 32 B
+        per value; seeds 32 B per statement) -> (commitments, proofs with stride 1569, proof_len); no per-proof Python work"""
+        nv = n_in + n_out
+        if len(flavors) != 32 * nv * batch or len(seeds) != 32 * batch or len(quantities) != nv * batch:
+            raise ValueError("quantities: one per value; flavors: 32 bytes per value; seeds: 32 bytes per statement")
+        import time
+        com = C.create_string_buffer(max(64 * nv * batch, 1))
+        stride = 1 + 32 * (16 + 2 * 16)
+        proofs = C.create_string_buffer(max(stride * batch, 1))
+        plen = C.c_size_t(0)
+        t0 = time.perf_counter()
+        rc = self.ctx.lib.zkgpu_cloak_prove_batch(self.ctx.h, self.bp_gens.points.h, self.bp_gens.gens_capacity, batch, n_in, n_out,
+                                                  quantities, flavors, seeds, self.host_threads, com, proofs, stride, C.byref(plen))
+        self.last_call_s = time.perf_counter() - t0
+        self.ctx._check(rc)
+        return com, proofs, plen.value
+
     def prove(self, n_in: int, n_out: int, quantities: Sequence[Sequence[int]], flavors: Sequence[Sequence[bytes]],
               seeds: Sequence[bytes]) -> List[CloakTx]:
         batch, nv = len(seeds), n_in + n_out
