@@ -1,0 +1,17 @@
+"""zkgpu_tx_verify_batch on the committed 1024 transactions (per-stage times with ZKGPU_PROVER_TIMING=1)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from gpu_util import load_tx_fixture
+from zkvm_amd import Context
+from zkvm_amd.verifier import BulletproofGens, BlockVerifier
+txs = load_tx_fixture()
+ctx = Context(0)
+gens = BulletproofGens(ctx, 256, table_bits=16)
+bv = BlockVerifier(ctx, gens)
+bv.verify_txs(txs[:64])
+for _ in range(4):
+    t0 = time.perf_counter()
+    bm, st = bv.verify_txs(txs)
+    print("%.2f ms" % ((time.perf_counter() - t0) * 1e3), file=sys.stderr)
+assert not any(st)

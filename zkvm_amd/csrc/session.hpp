@@ -658,7 +658,11 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   if (!txs || !tx_offsets || batch >= (1ull << 31)) return ZKGPU_EINVAL;
   for (size_t i = 0; i < batch; ++i) if (tx_offsets[i + 1] < tx_offsets[i]) return ZKGPU_EINVAL;
   std::vector<TxStatement> st(batch);
+  const bool timing = getenv("ZKGPU_PROVER_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   host_parallel(batch, host_threads, [&](size_t i) { st[i] = tx_prepare(txs + tx_offsets[i], (size_t)(tx_offsets[i + 1] - tx_offsets[i])); });
+  const double t1 = now();
   std::vector<size_t> live;
   for (size_t i = 0; i < batch; ++i) {
     if (status) status[i] = (uint8_t)st[i].status;
@@ -675,22 +679,32 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     off.push_back(sc.size() / 32);
   }
   TRY(zkgpu_msm_batch(c, sc.data(), pt.data(), off.data(), live.size(), agg.data(), okb.data()));
+  const double t2 = now();
   uint8_t B[32], Bb[32];
   TRY(zkgpu_pedersen_gens(c, B, Bb));
-  // 2. the signature equations  s B - R - sum (c a_i) X_i == identity
+  // 2. the signature equations  s B - R - sum (c a_i) X_i == identity: B is generator 0 of the resident set (its term
+  //    comes out of the fixed-base tables), R and the keys are the proof-specific points of the row
   std::vector<size_t> signed_ok;
+  std::vector<uint8_t> ssc;
+  std::vector<uint32_t> sidx;
+  std::vector<uint64_t> soff(1, 0);
   sc.clear(); pt.clear(); off.assign(1, 0);
   for (size_t j = 0; j < live.size(); ++j) {
     const size_t i = live[j];
     if (!((okb[j / 8] >> (j % 8)) & 1)) { if (status) status[i] = TX_INVALID; continue; }   // a key that is no point
     tx_finish_signature(st[i], B, &agg[32 * j]);
-    sc.insert(sc.end(), st[i].sig_scalars.begin(), st[i].sig_scalars.end());
-    pt.insert(pt.end(), st[i].sig_points.begin(), st[i].sig_points.end());
+    ssc.insert(ssc.end(), st[i].sig_scalars.begin(), st[i].sig_scalars.begin() + 32);
+    sidx.push_back(0);
+    soff.push_back(sidx.size());
+    sc.insert(sc.end(), st[i].sig_scalars.begin() + 32, st[i].sig_scalars.end());
+    pt.insert(pt.end(), st[i].sig_points.begin() + 32, st[i].sig_points.end());
     off.push_back(sc.size() / 32);
     signed_ok.push_back(i);
   }
   std::vector<uint8_t> sig_bits((signed_ok.size() + 7) / 8 + 1, 0);
-  if (!signed_ok.empty()) TRY(zkgpu_verify_batch(c, sc.data(), pt.data(), off.data(), signed_ok.size(), sig_bits.data()));
+  if (!signed_ok.empty())
+    TRY(zkgpu_verify_batch_ps(c, v->ps, signed_ok.size(), sc.data(), pt.data(), off.data(), ssc.data(), sidx.data(), soff.data(), sig_bits.data()));
+  const double t3 = now();
   // 3. the cloak proofs of the transactions whose signature holds
   std::vector<size_t> proved;
   std::vector<uint32_t> n_in, n_out;
@@ -708,6 +722,8 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   if (proved.empty()) return ZKGPU_OK;
   std::vector<uint8_t> bits((proved.size() + 7) / 8, 0);
   TRY(zkgpu_verifier_verify(v, proved.size(), n_in.data(), n_out.data(), com.data(), proofs.data(), po.data(), nullptr, bits.data()));
+  if (timing) fprintf(stderr, "tx verify: VM + ids %.2f ms, aggregated keys %.2f ms, signature equations %.2f ms, cloak proofs %.2f ms (%zu transactions)\n",
+                      (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (now() - t3) * 1e3, batch);
   for (size_t j = 0; j < proved.size(); ++j) {
     const size_t i = proved[j];
     const bool ok = (bits[j / 8] >> (j % 8)) & 1;
