@@ -314,6 +314,13 @@ int zkgpu_set_horner_mode(zkgpu_ctx* ctx, int mode);
 int zkgpu_set_transcript_mode(zkgpu_ctx* ctx, int mode);
 int zkgpu_debug_coop_selftest(zkgpu_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t* states, size_t n_states);
 
+/* Test hook: the arithmetic layers on their own, one lane per element (a, b, out: n x 32 bytes).  op 0 field product,
+ * 1 square, 2 inverse, 3 a + b - b + a, 4 x^((p-5)/8)  (GF(2^255-19): 32 little-endian bytes, canonical out);
+ * 10 product mod l (canonical Montgomery form), 11 the same in the lazy limb form, 12 a lazy chain
+ * (a-b)(a+b) + 16ab - b, 13 / 14 inverse mod l (canonical / windowed lazy), 15 a + b - a  (scalars: canonical words out,
+ * inputs reduced mod l). */
+int zkgpu_debug_arith(zkgpu_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
+
 /* Measurement aid: with on != 0 the kernels of a batch run one after another on a single stream
  * (no overlap), so that the profile hooks report each kernel's duration alone on the chip. */
 int zkgpu_set_serial(zkgpu_ctx* ctx, int on);

@@ -93,4 +93,52 @@ k_pv_finish(PvShape sh, PvBatch B, const uint32_t* __restrict__ ab, uint32_t bat
   if (flag) atomicOr(status, flag == 2 ? 2u : 1u);
 }
 
+
+// ---- test hook: the arithmetic layers alone (zkgpu_debug_arith), one lane per element ------------------------
+// op: 0 fe_mul  1 fe_sq  2 fe_invert  3 fe_add then fe_sub (a + b - b + a)  4 fe_pow22523
+//     10 scm product  11 scl product  12 scl chain ((a - b) (a + b) + 16 a b - b, lazily)  13 inverse mod l (scm_invert)
+//     14 inverse mod l (pv_invert: windows, lazy form)  15 scm sum / difference (a + b, then - a)
+// field elements travel as 32 little-endian bytes (bit 255 ignored on input, canonical on output), scalars as
+// canonical words (inputs are reduced mod l first).
+__global__ void __launch_bounds__(64)
+k_debug_arith(uint32_t op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t wa[8], wb[8], wo[8];
+  for (int q = 0; q < 8; ++q) { wa[q] = a[8 * i + q]; wb[q] = b[8 * i + q]; wo[q] = 0; }
+  if (op < 10) {
+    fe x, y, r;
+    fe_from_words(x, wa);
+    fe_from_words(y, wb);
+    switch (op) {
+      case 0: fe_mul(r, x, y); break;
+      case 1: fe_sq(r, x); break;
+      case 2: fe_invert(r, x); break;
+      case 3: { fe t; fe_add(t, x, y); fe_carry(t); fe_sub(r, t, y); fe_carry(r); fe_add(r, r, x); fe_carry(r); break; }
+      default: fe_pow22523(r, x); break;
+    }
+    fe_to_words(wo, r);
+  } else {
+    const scm x = scm_from_words(wa), y = scm_from_words(wb);
+    scm r = scm_zero();
+    switch (op) {
+      case 10: r = scm_mul(x, y); break;
+      case 11: r = scl_to_scm(scl_mul(scl_from_scm(x), scl_from_scm(y))); break;
+      case 12: {
+        const scl lx = scl_from_scm(x), ly = scl_from_scm(y);
+        scl acc = scl_mul(scl_sub(lx, ly), scl_add(lx, ly));
+        const scl xy = scl_mul(lx, ly);
+        for (int k = 0; k < 16; ++k) acc = scl_add(acc, xy);
+        r = scl_to_scm(scl_sub(acc, ly));
+        break;
+      }
+      case 13: r = scm_invert(x); break;
+      case 14: r = pv_invert(x); break;
+      default: r = scm_sub(scm_add(x, y), x); break;
+    }
+    scm_to_words(wo, r);
+  }
+  for (int q = 0; q < 8; ++q) out[8 * i + q] = wo[q];
+}
+
 }  // namespace zk

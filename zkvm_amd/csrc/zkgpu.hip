@@ -1462,6 +1462,22 @@ int zkgpu_debug_coop_selftest(zkgpu_ctx* c, const uint32_t* in, uint32_t* out, u
   return ZKGPU_OK;
 }
 
+// Test hook: one arithmetic operation of the field / scalar layers on n elements (prover_kernels.hpp, k_debug_arith)
+int zkgpu_debug_arith(zkgpu_ctx* c, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+  if (!c || !a || !b || !out || n == 0 || n >= (1u << 24)) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  TRY(upload(c, c->in_scalars, a, 32 * n));
+  TRY(upload(c, c->in_points, b, 32 * n));
+  TRY(ensure(c, c->values, 32 * n));
+  hipLaunchKernelGGL(k_debug_arith, dim3(blocks_for(n, 64)), dim3(64), 0, c->stream, (uint32_t)op, (const uint32_t*)c->in_scalars.p,
+                     (const uint32_t*)c->in_points.p, (uint32_t*)c->values.p, (uint32_t)n);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out, c->values.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ZKGPU_OK;
+}
+
 // Failed groups: 0 automatic (locate the culprit from LOCATE_MIN_BATCH transactions per batch on), 1 always re-check
 // every transaction of a failed group, 2 always locate.  Same verdicts either way.
 int zkgpu_set_locate_mode(zkgpu_ctx* c, int mode) {

@@ -156,6 +156,7 @@ def load_library():
     lib.zkgpu_set_locate_mode.argtypes = [vp, C.c_int]
     lib.zkgpu_set_horner_mode.argtypes = [vp, C.c_int]
     lib.zkgpu_set_prover_mode.argtypes = [vp, C.c_int]
+    lib.zkgpu_debug_arith.argtypes = [vp, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
     lib.zkgpu_debug_force_regroup.argtypes = [vp, C.c_int]
     lib.zkgpu_debug_force_regroup.restype = C.c_longlong
     lib.zkgpu_debug_coop_selftest.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), sz]
@@ -251,6 +252,14 @@ class Context:
         st = (C.c_uint64 * max(len(flat), 1))(*flat)
         self._check(self.lib.zkgpu_debug_coop_selftest(self.h, inp, out, st, len(states)))
         return [list(out[64 * i: 64 * i + 64]) for i in range(8)], [list(st[25 * i: 25 * i + 25]) for i in range(len(states))]
+
+    def debug_arith(self, op: int, a: bytes, b: bytes) -> bytes:
+        """zkgpu_debug_arith: one operation of the field / scalar layers on len(a) / 32 elements"""
+        n = len(a) // 32
+        assert len(a) == len(b) == 32 * n and n > 0
+        out = C.create_string_buffer(32 * n)
+        self._check(self.lib.zkgpu_debug_arith(self.h, op, a, b, out, n))
+        return out.raw
 
     def set_prover_mode(self, mode: int) -> None:
         """zkgpu_set_prover_mode: 0 the whole proof on the device, 1 host threads in lockstep."""
