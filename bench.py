@@ -181,10 +181,13 @@ def roofline_object(solo, launches_per_step, in_flight_ms, alg_bytes_step, units
     alg_per_launch = alg_bytes_step / max(launches_per_step.get(dom, 1.0), 1e-9)
     achieved = alg_per_launch / (solo[dom] * 1e-3) / 1e9
     step_traffic = step_valu = None
+    # the counters were collected for launches of `_units_per_launch` transactions: scaled to this run's device batch
     if traffic_tbl:
-        step_traffic = int(sum(traffic_tbl.get(k, 0) * launches_per_step.get(k, 1.0) for k in solo))
+        scale = units_step / float(traffic_tbl.get("_units_per_launch", units_step))
+        step_traffic = int(scale * sum(traffic_tbl.get(k, 0) * launches_per_step.get(k, 1.0) for k in solo))
     if valu_tbl:
-        step_valu = int(sum(valu_tbl.get(k, 0) * launches_per_step.get(k, 1.0) for k in solo))
+        scale = units_step / float(valu_tbl.get("_units_per_launch", units_step))
+        step_valu = int(scale * sum(valu_tbl.get(k, 0) * launches_per_step.get(k, 1.0) for k in solo))
     step = {"algorithmic_bytes": int(alg_bytes_step), "achieved": round(alg_bytes_step / (ms_per_step * 1e-3) / 1e9, 3),
             "frac": round(alg_bytes_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": step_traffic,
             "traffic_over_algorithmic": round(step_traffic / alg_bytes_step, 1) if step_traffic else None,
@@ -193,7 +196,10 @@ def roofline_object(solo, launches_per_step, in_flight_ms, alg_bytes_step, units
             "valu_issue_frac": round(step_valu * 64 / (ms_per_step * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if step_valu else None,
             "solo_kernel_ms_sum": round(sum(per_step.values()), 4)}
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": (traffic_tbl or {}).get(dom),
+            "frac": round(achieved / HBM_PEAK_GBS, 6),
+            "traffic": (int((traffic_tbl or {}).get(dom) * units_step / max(launches_per_step.get(dom, 1.0), 1e-9) /
+                            float((traffic_tbl or {}).get("_units_per_launch", units_step / max(launches_per_step.get(dom, 1.0), 1e-9))))
+                        if (traffic_tbl or {}).get(dom) else None),
             "algorithmic_bytes_per_launch": int(alg_per_launch),
             "units_per_launch": round(units_step / max(launches_per_step.get(dom, 1.0), 1e-9), 1),
             "avg_launch_ms": round(solo[dom], 4), "launches_per_step": round(launches_per_step.get(dom, 1.0), 2),
@@ -564,6 +570,9 @@ def run_config2(args, W):
             host_time["n"] += 1
         while q:
             bm = bv.wait(q.pop(0))
+            if world > 1:                                     # every step's bitmap is exchanged, the drained ones too
+                d_bm.copy_(torch.frombuffer(bytearray(bm), dtype=torch.uint8))
+                W.dist.all_gather_into_tensor(d_all, d_bm)
             assert bm == want_bm
         return bm
 
@@ -873,9 +882,9 @@ def main():
     ap.add_argument("--group", type=int, default=16, help="transactions per group check (1 = every transaction on its own)")
     ap.add_argument("--chunk", type=int, default=0, help="config 4: transactions per batch in flight (0 = library default)")
     ap.add_argument("--bad-every", type=int, default=64, help="config 2: one transaction in this many is corrupted (0 = none)")
-    ap.add_argument("--tickets", type=int, default=64,
+    ap.add_argument("--tickets", type=int, default=-1,
                     help="config 2: batches kept in flight as tickets of a zkgpu_verifier, which merges them into device batches of --merge tx (0 = plain contexts)")
-    ap.add_argument("--merge", type=int, default=8192, help="config 2 with --tickets: transactions per merged device batch")
+    ap.add_argument("--merge", type=int, default=0, help="config 2 with --tickets: transactions per merged device batch (0: chosen from --steps, see below)")
     ap.add_argument("--locate-mode", type=int, default=0, choices=(0, 1, 2), help="zkgpu_set_locate_mode")
     ap.add_argument("--horner-mode", type=int, default=0, choices=(0, 1, 2), help="zkgpu_set_horner_mode")
     ap.add_argument("--transcript-mode", type=int, default=0, choices=(0, 1, 2),
@@ -891,8 +900,22 @@ def main():
         args.warmup = 10 if args.config == 2 else 3
     if args.config == 4:
         args.tickets = 0
+    if args.tickets < 0:
+        # Batching for the offered load.  The timed region starts and ends with an idle device, so K steps are K batches
+        # arriving at once: a short run (the driver's --steps 20) is best served as TWO equal device batches side by side
+        # (measured at K = 20: 2 x 10240 tx: 2.65 M tx/s; 8192 per device batch with 3 / 5 in flight: 2.30 / 2.33 M; one
+        # batch of 20480: 2.47 M); a long run settles into a steady state in which 64 queued batches, merged 8 at a time,
+        # 5 device batches in flight do best (sweep r02k: 32 / 3: 2.87 M, 64 / 5: 3.05 M, 128 / 9: 3.08 M tx/s).
+        if args.steps * args.batch <= 40960 and args.merge <= 0 and args.inflight <= 0:
+            args.tickets = max(args.steps, 2)
+            args.merge = ((args.steps + 1) // 2) * args.batch
+            args.inflight = 2
+        else:
+            args.tickets = 64
+    if args.merge <= 0:
+        args.merge = 8192
     if args.inflight <= 0:
-        args.inflight = 5 if args.tickets > 0 else 6    # measured (r02k sweep): 32 / 3: 2.87 M, 64 / 5: 3.05 M, 128 / 9: 3.08 M tx/s
+        args.inflight = 5 if args.tickets > 0 else 6
     W = World(args)
     (run_config2 if args.config == 2 else run_config4)(args, W)
 

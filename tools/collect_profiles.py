@@ -63,11 +63,18 @@ traffic = {"_note": "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> 
                     "(tools/profile_bench.sh %s: bench.py --solo and tools/msm_bench.py), mean over the last <= 8 dispatches of "
                     "each kernel.  Kernels that run more than once per batch (k_static_accumulate: the group launch and the "
                     "re-check of failed groups) show the mean of their launches." % tag}
+units = 8192
+try:
+    units = int(json.loads(open(os.path.join(out, "%s_solo.json" % tag)).readline()).get("batch", 8192))
+except Exception:
+    pass
+traffic["_units_per_launch"] = units      # transactions per device batch of the profiled `bench.py --solo` run
 for k in sorted(set(fetch) | set(write)):
     traffic[k] = int(1024 * (2 * fetch.get(k, 0.0) + write.get(k, 0.0)))
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 v = {"_note": "SQ_INSTS_VALU per launch (wave instructions; x 64 lanes for thread instructions), rocprofv3 --pmc pass of "
               "tools/profile_bench.sh %s, mean over the last <= 8 dispatches of each kernel" % tag}
+v["_units_per_launch"] = units
 v.update({k: int(x) for k, x in sorted(valu.items())})
 json.dump(v, open(os.path.join(out, "pmc_valu.json"), "w"), indent=1, sort_keys=True)
 print("wrote", sorted(f for f in os.listdir(out) if f.startswith(tag) or f.startswith("pmc_")))
