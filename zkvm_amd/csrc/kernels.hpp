@@ -1256,6 +1256,44 @@ k_encode_rows(const uint32_t* __restrict__ ext, uint32_t n_rows, uint32_t* __res
   o[1] = make_uint4(enc[4], enc[5], enc[6], enc[7]);
 }
 
+// ---- merging queued batches (session.hpp, tickets): ONE launch copies the three input buffers of up to 16 batches side
+// by side into a context's workspace (instead of three device-to-device copies per batch: the host time of those calls
+// is what delays the launch of a merged batch)
+struct MergeSources {
+  const uint4* com[16];
+  const uint8_t* proofs[16];
+  const uint4* r[16];
+  uint32_t first[17];        // first transaction of each source in the merged batch; first[n] = total
+  uint32_t n;
+};
+__global__ void __launch_bounds__(256)
+k_merge_inputs(MergeSources src, uint32_t com_vec /*uint4 per transaction*/, uint32_t proof_len, uint4* __restrict__ com,
+               uint8_t* __restrict__ proofs, uint4* __restrict__ r) {
+  const uint32_t total = src.first[src.n];
+  const uint64_t n_com = (uint64_t)total * com_vec, n_r = (uint64_t)total * 4, n_pw = ((uint64_t)total * proof_len + 3) / 4;
+  const uint64_t g0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+  auto source_of = [&src](uint32_t tx) { uint32_t k = 0; while (k + 1 < src.n && tx >= src.first[k + 1]) ++k; return k; };
+  for (uint64_t g = g0; g < n_com; g += stride) {
+    const uint32_t tx = (uint32_t)(g / com_vec), k = source_of(tx);
+    com[g] = src.com[k][g - (uint64_t)src.first[k] * com_vec];
+  }
+  for (uint64_t g = g0; g < n_r; g += stride) {
+    const uint32_t tx = (uint32_t)(g / 4), k = source_of(tx);
+    r[g] = src.r[k][g - (uint64_t)src.first[k] * 4];
+  }
+  // proofs: byte-aligned sources (a proof is 1 + 32 k bytes): four bytes per lane of the destination
+  for (uint64_t g = g0; g < n_pw; g += stride) {
+    uint32_t w = 0;
+    for (int b = 0; b < 4; ++b) {
+      const uint64_t at = 4 * g + b;
+      if (at >= (uint64_t)total * proof_len) break;
+      const uint32_t tx = (uint32_t)(at / proof_len), k = source_of(tx);
+      w |= (uint32_t)src.proofs[k][at - (uint64_t)src.first[k] * proof_len] << (8 * b);
+    }
+    reinterpret_cast<uint32_t*>(proofs)[g] = w;
+  }
+}
+
 // ---- group checks ---------------------------------------------------------------------
 // A group of transactions whose equations E_t are weighted by independent random rho's (k_transcript)
 // sums to the identity iff every one of them does (up to probability ~2^-250), and the generator

@@ -401,16 +401,42 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
       DeviceGuard g(L->device);
       const size_t wcom = (size_t)plan->shape.m * 32;
       rc = ensure(L, L->coal_com, total * wcom);
-      if (rc == ZKGPU_OK) rc = ensure(L, L->coal_proofs, total * head->proof_len);
+      if (rc == ZKGPU_OK) rc = ensure(L, L->coal_proofs, total * head->proof_len + 16);   // (k_merge_inputs writes whole words)
       if (rc == ZKGPU_OK) rc = ensure(L, L->coal_r, total * 64);
-      size_t off = 0;
-      for (zkgpu_request* r : pick) {
-        if (rc != ZKGPU_OK) break;
-        hipError_t e = hipMemcpyAsync((char*)L->coal_com.p + off * wcom, r->d_com, r->batch * wcom, hipMemcpyDeviceToDevice, L->stream_l);
-        if (e == hipSuccess) e = hipMemcpyAsync((char*)L->coal_proofs.p + off * head->proof_len, r->d_proofs, r->batch * head->proof_len, hipMemcpyDeviceToDevice, L->stream_l);
-        if (e == hipSuccess) e = hipMemcpyAsync((char*)L->coal_r.p + off * 64, r->d_r, r->batch * 64, hipMemcpyDeviceToDevice, L->stream_l);
-        if (e != hipSuccess) { L->last_error = hipGetErrorString(e); rc = ZKGPU_EHIP; }
-        off += r->batch;
+      // one gather launch per 16 queued batches (commitments and randomness as 16-byte vectors; buffers that are not
+      // 16-byte aligned go through plain copies)
+      size_t off = 0, at = 0;
+      while (rc == ZKGPU_OK && at < pick.size()) {
+        MergeSources ms;
+        ms.n = 0;
+        bool aligned = true;
+        const size_t base = off;
+        while (at < pick.size() && ms.n < 16) {
+          zkgpu_request* r = pick[at];
+          aligned = aligned && ((uintptr_t)r->d_com % 16 == 0) && ((uintptr_t)r->d_r % 16 == 0);
+          ms.com[ms.n] = (const uint4*)r->d_com; ms.proofs[ms.n] = (const uint8_t*)r->d_proofs; ms.r[ms.n] = (const uint4*)r->d_r;
+          ms.first[ms.n] = (uint32_t)(off - base);
+          off += r->batch;
+          ++ms.n; ++at;
+        }
+        ms.first[ms.n] = (uint32_t)(off - base);
+        if (aligned && (base * head->proof_len) % 4 == 0) {
+          const uint32_t span = ms.first[ms.n];
+          hipLaunchKernelGGL(k_merge_inputs, dim3(blocks_for((uint64_t)span * (head->proof_len / 4 + 1), 256)), dim3(256), 0, L->stream_l, ms,
+                             (uint32_t)(wcom / 16), (uint32_t)head->proof_len, (uint4*)((char*)L->coal_com.p + base * wcom),
+                             (uint8_t*)L->coal_proofs.p + base * head->proof_len, (uint4*)((char*)L->coal_r.p + base * 64));
+          if (hipGetLastError() != hipSuccess) { L->last_error = "k_merge_inputs"; rc = ZKGPU_EHIP; }
+        } else {
+          size_t o2 = base;
+          for (uint32_t k = 0; k < ms.n && rc == ZKGPU_OK; ++k) {
+            const size_t nb = ms.first[k + 1] - ms.first[k];
+            hipError_t e = hipMemcpyAsync((char*)L->coal_com.p + o2 * wcom, ms.com[k], nb * wcom, hipMemcpyDeviceToDevice, L->stream_l);
+            if (e == hipSuccess) e = hipMemcpyAsync((char*)L->coal_proofs.p + o2 * head->proof_len, ms.proofs[k], nb * head->proof_len, hipMemcpyDeviceToDevice, L->stream_l);
+            if (e == hipSuccess) e = hipMemcpyAsync((char*)L->coal_r.p + o2 * 64, ms.r[k], nb * 64, hipMemcpyDeviceToDevice, L->stream_l);
+            if (e != hipSuccess) { L->last_error = hipGetErrorString(e); rc = ZKGPU_EHIP; }
+            o2 += nb;
+          }
+        }
       }
       p_com = L->coal_com.p; p_proofs = L->coal_proofs.p; p_r = L->coal_r.p;
     }
