@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from gpu_util import load_tx_fixture
 from zkvm_amd import Context
 from zkvm_amd.verifier import BulletproofGens, BlockVerifier
-txs = load_tx_fixture()
+rep = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+txs = load_tx_fixture() * rep
 ctx = Context(0)
 gens = BulletproofGens(ctx, 256, table_bits=16)
 bv = BlockVerifier(ctx, gens)
@@ -13,5 +14,6 @@ bv.verify_txs(txs[:64])
 for _ in range(4):
     t0 = time.perf_counter()
     bm, st = bv.verify_txs(txs)
-    print("%.2f ms" % ((time.perf_counter() - t0) * 1e3), file=sys.stderr)
+    dt = time.perf_counter() - t0
+    print("%.2f ms, %.0f tx/s (%d transactions per call)" % (dt * 1e3, len(txs) / dt, len(txs)), file=sys.stderr)
 assert not any(st)

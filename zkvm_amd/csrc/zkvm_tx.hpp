@@ -49,13 +49,15 @@ struct Item {
 inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline uint64_t rd64(const uint8_t* p) { return (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
 
+// every hash below starts from a copy of its label's freshly initialised transcript (two Keccak-f saved per hash)
+#define ZK_TX_TRANSCRIPT(var, label) static const Transcript var##_proto(label); Transcript var = var##_proto
 inline void contract_id(const uint8_t* ser, size_t n, uint8_t id[32]) {
-  Transcript t("ZkVM.contractid");
+  ZK_TX_TRANSCRIPT(t, "ZkVM.contractid");
   t.append_message("contract", ser, n);
   t.challenge_bytes("id", id, 32);
 }
 inline void ratchet_anchor(const uint8_t old_anchor[32], uint8_t fresh[32]) {
-  Transcript t("ZkVM.ratchet-anchor");
+  ZK_TX_TRANSCRIPT(t, "ZkVM.ratchet-anchor");
   t.append_message("old", old_anchor, 32);
   t.challenge_bytes("new", fresh, 32);
 }
@@ -67,8 +69,8 @@ struct LogEntry {
   uint64_t a = 0, b = 0, c = 0;
   uint8_t id[32] = {0};
 };
-inline void merkle_root(const char* label, const LogEntry* e, size_t n, uint8_t out[32]) {
-  Transcript t(label);
+inline void merkle_root(const Transcript& fresh, const LogEntry* e, size_t n, uint8_t out[32]) {
+  Transcript t = fresh;
   if (n == 0) { t.challenge_bytes("merkle.empty", out, 32); return; }
   if (n == 1) {
     switch (e->kind) {
@@ -82,8 +84,8 @@ inline void merkle_root(const char* label, const LogEntry* e, size_t n, uint8_t 
   size_t k = 1;
   while (2 * k < n) k *= 2;
   uint8_t l[32], r[32];
-  merkle_root(label, e, k, l);
-  merkle_root(label, e + k, n - k, r);
+  merkle_root(fresh, e, k, l);
+  merkle_root(fresh, e + k, n - k, r);
   t.append_message("L", l, 32);
   t.append_message("R", r, 32);
   t.challenge_bytes("merkle.node", out, 32);
@@ -296,12 +298,13 @@ inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
   if (!stack.empty()) return fail(TX_INVALID, "stack not empty at the end");
   if (!cloaked) return fail(TX_UNSUPPORTED, "no cloak: nothing for the proof system");
   if (keys.empty()) return fail(TX_INVALID, "no key signs the transaction");
-  merkle_root("ZkVM.txid", log.data(), log.size(), st.txid);
+  static const Transcript txid_proto("ZkVM.txid");
+  merkle_root(txid_proto, log.data(), log.size(), st.txid);
 
   // signature: X = sum a_i X_i (MuSig key aggregation), c = H(txid, X, R);  s B == R + c X
   Scalar s;
   if (!Scalar::from_canonical(sig + 32, s)) return fail(TX_INVALID, "signature scalar not canonical");
-  Transcript agg("Musig.aggregated-key");
+  ZK_TX_TRANSCRIPT(agg, "Musig.aggregated-key");
   agg.append_u64("n", keys.size());
   for (const auto& k : keys) agg.append_point("X", k.data());
   std::vector<Scalar> a(keys.size());
@@ -329,7 +332,7 @@ inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
 // second half of the signature preparation, once the aggregated key X = sum a_i X_i is known as an encoding
 // (one small multiscalar multiplication per transaction: zkgpu_msm_batch on the device, host_rows in the CPU tests)
 inline void tx_finish_signature(TxStatement& st, const uint8_t basepoint[32], const uint8_t agg_key[32]) {
-  Transcript t("ZkVM.signtx");
+  ZK_TX_TRANSCRIPT(t, "ZkVM.signtx");
   t.append_message("txid", st.txid, 32);
   t.append_message("dom-sep", (const uint8_t*)"schnorr-signature v1", 20);
   t.append_point("X", agg_key);
