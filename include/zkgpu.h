@@ -433,6 +433,10 @@ int zkgpu_verifier_verify_block(zkgpu_verifier *v, const zkgpu_txblock *block, u
 int zkgpu_verifier_set_merge(zkgpu_verifier *v, size_t transactions);
 int zkgpu_verifier_submit_dev(zkgpu_verifier *v, uint32_t n_in, uint32_t n_out, size_t batch, const void *d_commitments,
                               const void *d_proofs, size_t proof_len, const void *d_r, uint64_t *ticket);
+/* the same for `count` batches of one shape and size at once (arrays of count device pointers; tickets[count]) */
+int zkgpu_verifier_submit_many_dev(zkgpu_verifier *v, uint32_t n_in, uint32_t n_out, size_t count, size_t batch_each,
+                                   const void *const *d_commitments, const void *const *d_proofs, size_t proof_len,
+                                   const void *const *d_r, uint64_t *tickets);
 int zkgpu_verifier_wait(zkgpu_verifier *v, uint64_t ticket, uint8_t *accept_bitmap);
 
 /* ---- serialized transactions (replaces Tx::verify / Verifier::verify_tx for the PAYMENT SUBSET) --

@@ -562,6 +562,13 @@ def test_tickets_merge_small_batches_and_return_each_its_own_bitmap(ctx, oracle)
         tickets += [bv.submit_dev(s[0], s[1], n, dc, dp, plen, dr) for (s, n, dc, dp, dr, plen, _) in jobs[10:]]
         for k in order[4:] + list(range(10, 15)):
             assert bits(bv.wait(tickets[k]), jobs[k][1]) == jobs[k][6], k
+        # zkgpu_verifier_submit_many_dev: 20 equal batches in one call (17 merged by the first gather launch, 3 by the next)
+        shape, n, dc, dp, dr, plen, want = next(j for j in jobs if j[0] == (2, 2) and j[1] == 37) if any(j[0] == (2, 2) and j[1] == 37 for j in jobs) else jobs[0]
+        bv.set_merge(20 * n)
+        many = bv.submit_many_dev(shape[0], shape[1], n, [dc] * 20, [dp] * 20, plen, [dr] * 20)
+        assert len(set(many)) == 20
+        for t in reversed(many):
+            assert bits(bv.wait(t), n) == want
         for (_, _, dc, dp, dr, _, _) in jobs:
             for d in (dc, dp, dr):
                 ctx.free_device(d)

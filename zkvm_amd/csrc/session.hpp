@@ -477,6 +477,25 @@ int zkgpu_verifier_submit_dev(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, 
   return ticket_dispatch(v, false);
 }
 
+// `count` batches of one shape and size in one call (what a caller holding a queue of them would do): tickets[count]
+int zkgpu_verifier_submit_many_dev(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, size_t count, size_t batch_each,
+                                   const void* const* d_commitments, const void* const* d_proofs, size_t proof_len,
+                                   const void* const* d_r, uint64_t* tickets) {
+  if (!v || !tickets || !d_commitments || !d_proofs || !d_r || batch_each == 0 || batch_each >= (1ull << 24)) return ZKGPU_EINVAL;
+  for (size_t i = 0; i < count; ++i) if (!d_commitments[i] || !d_proofs[i] || !d_r[i]) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  for (size_t i = 0; i < count; ++i) {
+    zkgpu_request* r = new zkgpu_request();
+    r->id = v->next_id++;
+    r->n_in = n_in; r->n_out = n_out; r->batch = batch_each; r->proof_len = proof_len;
+    r->d_com = d_commitments[i]; r->d_proofs = d_proofs[i]; r->d_r = d_r[i];
+    v->requests[r->id] = r;
+    v->queue.push_back(r);
+    tickets[i] = r->id;
+  }
+  return ticket_dispatch(v, false);
+}
+
 int zkgpu_verifier_wait(zkgpu_verifier* v, uint64_t ticket, uint8_t* accept_bitmap) {
   if (!v || !accept_bitmap) return ZKGPU_EINVAL;
   std::lock_guard<std::mutex> lk(v->mu);

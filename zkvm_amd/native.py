@@ -143,6 +143,7 @@ def load_library():
     lib.zkgpu_comm_allgather_bitmap.argtypes = [vp, u64p, u8p, C.c_int, u8p]
     lib.zkgpu_verifier_verify_sharded.argtypes = [vp, vp, sz, u32p, u32p, u8p, u8p, u64p, u8p, u8p]
     lib.zkgpu_tx_verify_batch.argtypes = [vp, sz, u8p, u64p, C.c_int, u8p, u8p]
+    lib.zkgpu_verifier_submit_many_dev.argtypes = [vp, C.c_uint32, C.c_uint32, sz, sz, vp, vp, sz, vp, vp]
     lib.zkgpu_r1cs_plan_create.argtypes = [vp, vp, sz, C.POINTER(vp)]
     lib.zkgpu_r1cs_plan_destroy.argtypes = [vp]
     lib.zkgpu_r1cs_plan_destroy.restype = None

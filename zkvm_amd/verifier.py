@@ -195,6 +195,20 @@ class BlockVerifier:
         self.__dict__.setdefault("_ticket_batch", {})[t.value] = batch
         return int(t.value)
 
+    def submit_many_dev(self, n_in: int, n_out: int, batch_each: int, d_commitments: Sequence, d_proofs: Sequence, proof_len: int,
+                        d_r: Sequence) -> List[int]:
+        """zkgpu_verifier_submit_many_dev: queue len(d_commitments) uniform batches in one call; -> tickets"""
+        from .native import _ptr
+        count = len(d_commitments)
+        assert len(d_proofs) == count and len(d_r) == count
+        arr = lambda xs: (C.c_void_p * max(count, 1))(*[_ptr(x) for x in xs])
+        t = (C.c_uint64 * max(count, 1))()
+        self._check(self.lib.zkgpu_verifier_submit_many_dev(self.h, n_in, n_out, count, batch_each, arr(d_commitments), arr(d_proofs),
+                                                            proof_len, arr(d_r), t))
+        for i in range(count):
+            self.__dict__.setdefault("_ticket_batch", {})[t[i]] = batch_each
+        return [int(t[i]) for i in range(count)]
+
     def wait(self, ticket: int) -> bytes:
         """zkgpu_verifier_wait: the accept bitmap of that ticket's batch"""
         batch = self.__dict__["_ticket_batch"].pop(ticket)
