@@ -352,7 +352,7 @@ def tx_verify_microbench(ctx, gens, host_threads: int):
                     "one call at a time (no batches in flight), Python marshalling included"}
 
 
-def prover_microbench(ctx, gens, host_threads: int, batch: int = 2048):
+def prover_microbench(ctx, gens, host_threads: int, batch: int = 2048, ctx2=None):
     """BASELINE configs[4] (prover side): `batch` 2-in/2-out cloak proofs per call; every proof verified by the device verifier."""
     import ctypes as C
     import random
@@ -380,7 +380,7 @@ def prover_microbench(ctx, gens, host_threads: int, batch: int = 2048):
         com, proofs, plen = pr.prove_packed(2, 2, batch, qa, fl, sd)
         best = pr.last_call_s if best is None else min(best, pr.last_call_s)
     # two calls in flight: two host threads, each on a context of its own (a fork: same tables)
-    second = Prover(ctx.fork(), gens, host_threads=max(1, host_threads // 2))
+    second = Prover(ctx2 if ctx2 is not None else ctx.fork(), gens, host_threads=max(1, host_threads // 2))   # (forks are a limited resource)
     pr.host_threads = max(1, host_threads // 2)
     second.prove_packed(2, 2, batch, qa, fl, sd)
     rounds = 4
@@ -731,10 +731,18 @@ def run_config2(args, W):
             if world == 1 and not args.no_cpu:
                 line["cpu_baseline"] = cpu_baseline(txs, r_bytes, bits_of(bm, batch))
             if world == 1 and not args.no_msm:
-                line["prover"] = prover_microbench(ctx, gens, host_threads)
-                line["prover_1024_constraints"] = prover_program_microbench(ctx, host_threads)
-                line["tx_verify"] = tx_verify_microbench(ctx, gens, host_threads)
-                line["msm_2p20"] = msm_microbench(ctx, torch, dev)
+                # side legs: a failure of one of them is reported in its field, it does not take the headline line with it
+                # (a wrong RESULT in a leg is an AssertionError and does)
+                for key, leg in (("prover", lambda: prover_microbench(ctx, gens, host_threads, ctx2=ctxs[1])),
+                                 ("prover_1024_constraints", lambda: prover_program_microbench(ctx, host_threads)),
+                                 ("tx_verify", lambda: tx_verify_microbench(ctx, gens, host_threads)),
+                                 ("msm_2p20", lambda: msm_microbench(ctx, torch, dev))):
+                    try:
+                        line[key] = leg()
+                    except AssertionError:
+                        raise
+                    except Exception as e:                     # noqa: BLE001
+                        line[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         emit(line)
     W.close()
     if bv is not None:
