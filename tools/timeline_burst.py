@@ -10,8 +10,9 @@ import torch
 import bench
 from zkvm_amd import Context
 from zkvm_amd.verifier import BulletproofGens, Verifier
-rep = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-nctx = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+reps = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "10,10").split(",")]   # batches of 1024 per context
+nctx = len(reps)
+rep = max(reps)
 ctx = Context(0)
 txs, expected = bench.workload_2x2(1024, 0)
 gens = BulletproofGens(ctx, 256, table_bits=16)
@@ -27,7 +28,7 @@ sub_ms = []
 def burst():
     for c in ctxs:
         ts = time.perf_counter()
-        v.submit_packed_gpu_dev(2, 2, 1024 * rep, d_com, d_pr, plen, d_r, ctx=c)
+        v.submit_packed_gpu_dev(2, 2, 1024 * reps[ctxs.index(c)], d_com, d_pr, plen, d_r, ctx=c)
         sub_ms.append((time.perf_counter() - ts) * 1e3)
     for c in ctxs:
         c.verify_wait()
@@ -37,7 +38,7 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 burst()
 dt = time.perf_counter() - t0
-print("burst of %d x %d tx: %.3f ms (%.0f tx/s); host time of the submits: %s ms" % (nctx, 1024 * rep, dt * 1e3, nctx * 1024 * rep / dt, ["%.3f" % x for x in sub_ms[-nctx:]]))
+print("burst of %s x 1024 tx: %.3f ms (%.0f tx/s); host time of the submits: %s ms" % (reps, dt * 1e3, 1024 * sum(reps) / dt, ["%.3f" % x for x in sub_ms[-nctx:]]))
 for c in ctxs:
     c.profile(True)
 if os.path.exists(path):
