@@ -189,3 +189,62 @@ def test_the_1024_fixture_transactions_on_the_device():
         bv.close()
         gens.close()
         ctx.close()
+
+
+def test_random_programs_get_the_same_verdict_from_both_implementations(host, oracle):
+    """Differential fuzzing of the two independently written VMs (zkvm_tx.hpp, oracle/zkvm_tx.c): random instruction
+    sequences over the subset's opcodes (and a few outside it), random immediates, spliced fragments of a valid program --
+    status and, when the program runs, transaction ID and cloak shape must agree."""
+    rng = random.Random(20240)
+    base = payment(oracle, 2, 2, 4242)
+    plen = struct.unpack("<I", base[24:28])[0]
+    prog, rest = base[28: 28 + plen], base[28 + plen:]
+    contract = prog[5: 5 + 133]                                   # the first pushed contract
+    com = [prog[o: o + 32] for o in range(5 + 133 + 2 + 5 + 133 + 2 + 5, 5 + 133 + 2 + 5 + 133 + 2 + 5 + 4 * 38, 38)]
+
+    def u32(x):
+        return struct.pack("<I", x)
+
+    def fragment():
+        k = rng.randrange(14)
+        if k == 0: return b"\x00" + u32(len(contract)) + contract + b"\x1b"
+        if k == 1: return b"\x20"
+        if k == 2: return b"\x00" + u32(32) + rng.choice(com) + b"\x06"
+        if k == 3: return b"\x18" + u32(rng.choice([1, 2, 2, 3])) + u32(rng.choice([1, 2, 2, 65]))
+        if k == 4: return b"\x00" + u32(32) + bytes(rng.getrandbits(8) for _ in range(32)) + b"\x1c" + u32(rng.choice([0, 1, 1, 2]))
+        if k == 5: return b"\x02"
+        if k == 6: return b"\x03" + u32(rng.randrange(4))
+        if k == 7: return b"\x04" + u32(rng.randrange(4))
+        if k == 8: return b"\x00" + u32(rng.choice([0, 1, 31, 32, 33, 2 ** 31])) + bytes(rng.getrandbits(8) for _ in range(rng.randrange(40)))
+        if k == 9: return bytes([rng.choice([0x01, 0x05, 0x15, 0x1f, 0x21, 0xff])])
+        if k == 10: return b"\x1b"
+        if k == 11: return b"\x06"
+        if k == 12:                                                # a damaged contract
+            c = bytearray(contract); c[rng.randrange(64, len(c))] ^= 1 << rng.randrange(8)
+            return b"\x00" + u32(len(c)) + bytes(c) + b"\x1b"
+        a = rng.randrange(len(prog)); return prog[a: a + rng.randrange(1, 200)]
+
+    seen = {0: 0, 1: 0, 2: 0}
+    for case in range(6000):
+        if case % 5 == 0:                                          # mutate the valid program
+            p = bytearray(prog)
+            for _ in range(rng.randrange(1, 4)):
+                at = rng.randrange(len(p))
+                p[at: at + rng.randrange(0, 3)] = fragment() if rng.random() < 0.5 else bytes([rng.getrandbits(8)])
+            p = bytes(p)
+        else:
+            p = b"".join(fragment() for _ in range(rng.randrange(1, 12)))
+        tx = struct.pack("<QQQ", rng.choice([1, 1, 1, 2]), 5, rng.choice([5, 9, 4])) + u32(len(p)) + p + rest
+        want = oracle.tx_id(tx)
+        got = prepare(host, tx)
+        if (got[0], want[0]) == (1, 0):
+            # the product's preparation also decodes the signing keys (it aggregates them); the oracle does that when it
+            # verifies: a key that is no point is "invalid" on both sides, just at different stages
+            assert oracle.tx_verify(tx, bytes(64)) == 1, (case, p.hex())
+            seen[1] += 1
+            continue
+        assert got[0] == want[0], (case, p.hex())
+        seen[want[0]] += 1
+        if want[0] == 0:
+            assert got[1] == want[1] and (got[2], got[3]) == (want[2], want[3]), (case, p.hex())
+    assert seen[1] > 1200 and seen[2] > 400 and seen[0] > 20, seen
