@@ -230,6 +230,16 @@ def test_lazy_scalar_form_equals_canonical(host):
         assert host.zkhost_scl_selftest(seed, 1500) == 0
 
 
+def test_cooperative_transcript_rng_draws_equal_the_serial_generator(host):
+    """PvRngCoop (prover_dev.hpp: the TranscriptRng's draws on a Keccak state spread over a wavefront -- k_pv_rng_coop --
+    here through the emulated cross-lane primitives) against PvRng (one lane, word-wise), which the prover tests tie to
+    the byte-wise STROBE of the oracle: same scalars, same final state, starting right after the keying (position 32)."""
+    host.zkhost_rng_coop_selftest.restype = C.c_uint64
+    host.zkhost_rng_coop_selftest.argtypes = [C.c_uint64, C.c_uint32]
+    for seed, n in ((1, 3), (0x5a6b564d, 275), (2 ** 63 + 9, 1027)):
+        assert host.zkhost_rng_coop_selftest(seed, n) == 0
+
+
 def test_cooperative_keccak_emulation_equals_keccak(host, oracle):
     """keccak_coop.hpp -- one Keccak state spread over a wavefront (DPP row shifts, row swaps, ds_bpermute),
     run on the host with emulated cross-lane primitives -- against the oracle's Keccak-f[1600]."""

@@ -636,3 +636,52 @@ extern "C" int zkhost_tx_prepare(const uint8_t* tx, size_t len, uint8_t txid[32]
   *proof_len = st.proof_len;
   return 0;
 }
+
+// PvRngCoop (the TranscriptRng's draws on a state spread over an emulated wavefront) against PvRng (one lane, state in
+// registers) and thereby against the byte-wise STROBE: n draws from a keyed generator; returns mismatches.
+extern "C" uint64_t zkhost_rng_coop_selftest(uint64_t seed, uint32_t n_draws) {
+  using namespace zk::coop;
+  uint32_t w[52];
+  {
+    Transcript t("rng selftest");
+    uint8_t sd[32];
+    for (int i = 0; i < 32; ++i) sd[i] = (uint8_t)(seed >> (8 * (i & 7))) ^ (uint8_t)i;
+    t.rekey_with_witness("v_blinding", sd, 32);
+    t.finalize_rng(sd);
+    t.export_state(w);
+  }
+  PvRng a;
+  a.load(w);
+  if (!a.fast()) return ~0ull;
+  LaneVec lo, hi;
+  PvRngCoop<HostTraits>::Masks m;
+  for (uint32_t i = 0; i < 64; ++i) {
+    const KcLane k = kc_lane(i);
+    lo.l[i] = k.live ? w[2 * k.q] : 0;
+    hi.l[i] = k.live ? w[2 * k.q + 1] : 0;
+    auto holds = [&k](uint32_t q) { return (k.live && k.q == q) ? ~0u : 0u; };
+    m.w4.l[i] = holds(4); m.w5.l[i] = holds(5); m.w8.l[i] = holds(8); m.w9.l[i] = holds(9); m.w20.l[i] = holds(20);
+    m.keep.l[i] = (k.live && k.q < 8) ? 0u : ~0u;
+  }
+  const auto c = host_consts();
+  uint64_t bad = 0;
+  for (uint32_t d = 0; d < n_draws; ++d) {
+    const scm want = a.draw();
+    PvRngCoop<HostTraits>::draw(lo, hi, c, m, d == 0 && w[50] == 32);
+    uint32_t wd[16];
+    for (uint32_t i = 0; i < 64; ++i) {
+      const KcLane k = kc_lane(i);
+      if (k.primary && k.q < 8) { wd[2 * k.q] = lo.l[i]; wd[2 * k.q + 1] = hi.l[i]; }
+    }
+    PvRngCoop<HostTraits>::taken(lo, hi, m);
+    const scm got = scm_from_wide(wd);
+    for (int q = 0; q < 8; ++q) if (got.v[q] != want.v[q]) { ++bad; break; }
+  }
+  uint32_t wa[52];
+  a.store(wa);
+  for (uint32_t i = 0; i < 64; ++i) {
+    const KcLane k = kc_lane(i);
+    if (k.primary && (lo.l[i] != wa[2 * k.q] || hi.l[i] != wa[2 * k.q + 1])) ++bad;
+  }
+  return bad;
+}

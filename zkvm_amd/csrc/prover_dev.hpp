@@ -25,6 +25,7 @@
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include "keccak.hpp"
 #endif
+#include "keccak_coop.hpp"
 
 namespace zk {
 
@@ -229,6 +230,29 @@ struct PvRng {
     return scm_from_wide(wd);
   }
 };
+// The same draws with the generator's state spread over the lanes of a wavefront (keccak_coop.hpp): one wavefront per
+// proof, ~55 instructions per Keccak round instead of ~180 dependent ones on a single lane, which shortens the chain of
+// 3 + 2 n dependent permutations a commitment phase waits for.  T: the cross-lane traits (device: DevKcTraits, host
+// emulation: coop::HostTraits); masks select the lanes (copies included) that hold the state words a draw touches.
+template <class T>
+struct PvRngCoop {
+  using V = typename T::V;
+  struct Masks { V w4, w5, w8, w9, w20, keep; };           // holders of words 4, 5, 8, 9, 20; everything but words 0..7
+  static ZK_HD_INL void draw(V& lo, V& hi, const typename coop::KeccakCoop<T>::Consts& c, const Masks& m, bool at32) {
+    if (at32) {
+      lo = T::xor_and(lo, T::splat(0x00401200u), m.w4); hi = T::xor_and(hi, T::splat(0x07210000u), m.w4);
+      lo = T::xor_and(lo, T::splat(0x00000427u), m.w5);
+    } else {
+      lo = T::xor_and(lo, T::splat(0x00401200u), m.w8); hi = T::xor_and(hi, T::splat(0x07410000u), m.w8);
+      lo = T::xor_and(lo, T::splat(0x00000447u), m.w9);
+    }
+    hi = T::xor_and(hi, T::splat(0x80000000u), m.w20);
+    coop::KeccakCoop<T>::permute(lo, hi, c);
+    // the caller reads words 0..7 (the 64 bytes of the draw) and then calls taken()
+  }
+  static ZK_HD_INL void taken(V& lo, V& hi, const Masks& m) { lo = T::and_(lo, m.keep); hi = T::and_(hi, m.keep); }
+};
+
 #define PV_LBL(s) (s), (unsigned)(sizeof(s) - 1)
 
 // ---- helpers ---------------------------------------------------------------------------------------------

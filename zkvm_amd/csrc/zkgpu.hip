@@ -1849,10 +1849,16 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
   { Launch l(c, "k_pv_phase0"); hipLaunchKernelGGL(k_pv_phase0, dim3(nb), dim3(64), 0, s, sh, B); }
   if (sh.m) TRY(msm(0, B.rows0, (uint32_t*)c->pv_com.p));
   { Launch l(c, "k_pv_phase1"); hipLaunchKernelGGL(k_pv_phase1, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)c->pv_com.p); }
-  { Launch l(c, "k_pv_rng"); hipLaunchKernelGGL(k_pv_rng, dim3(blocks_for(batch, 64)), dim3(64), 0, s, sh, B, nb, 1u); }
+  // the TranscriptRng's draws: one wavefront per proof on the spread Keccak state while the outputs fit LDS, else one lane
+  auto rng_launch = [&](uint32_t phase, uint32_t cnt) {
+    const size_t lds = (size_t)(3 + 2 * cnt) * 64;
+    if (lds <= 48 * 1024) { Launch l(c, "k_pv_rng_coop"); hipLaunchKernelGGL(k_pv_rng_coop, dim3(nb), dim3(64), lds, s, sh, B, nb, phase); }
+    else { Launch l(c, "k_pv_rng"); hipLaunchKernelGGL(k_pv_rng, dim3(blocks_for(batch, 64)), dim3(64), 0, s, sh, B, nb, phase); }
+  };
+  rng_launch(1u, sh.n1);
   TRY(msm(1, B.rows1, pts));
   { Launch l(c, "k_pv_phase2"); hipLaunchKernelGGL(k_pv_phase2, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)pts); }
-  if (sh.n > sh.n1) { Launch l(c, "k_pv_rng"); hipLaunchKernelGGL(k_pv_rng, dim3(blocks_for(batch, 64)), dim3(64), 0, s, sh, B, nb, 2u); }
+  if (sh.n > sh.n1) rng_launch(2u, sh.n - sh.n1);
   TRY(msm(2, B.rows2, pts));
   { Launch l(c, "k_pv_phase3"); hipLaunchKernelGGL(k_pv_phase3, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)pts); }
   TRY(msm(3, B.rows3, pts));
