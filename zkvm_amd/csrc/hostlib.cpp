@@ -141,6 +141,11 @@ uint64_t zkhost_scl_selftest(uint64_t seed, uint32_t rounds) {
     if (!same(acc, lacc)) ++bad;
     if (!same(acc, scl_weak(lacc))) ++bad;
     if (!same(scm_mul(acc, a), scl_mul(lacc, la))) ++bad;
+    // the Euclidean inverse of the device prover against Fermat's
+    {
+      const scm inv_f = scm_invert(a), inv_e = pv_invert(a);
+      for (int i = 0; i < 8; ++i) if (inv_f.v[i] != inv_e.v[i]) { ++bad; break; }
+    }
     // plain <-> Montgomery
     uint32_t plain[8];
     scm_to_words(plain, a);
