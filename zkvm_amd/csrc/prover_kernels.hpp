@@ -60,11 +60,12 @@ k_pv_rng(PvShape sh, PvBatch B, uint32_t batch, uint32_t phase) {
   if (phase == 1) pv_rng_draw(sh, state, B.rows1 + (uint64_t)p * sh.r1_terms * 8, 0, sh.n1, PV_IBL1);
   else pv_rng_draw(sh, state, B.rows2 + (uint64_t)p * sh.r2_terms * 8, sh.n1, sh.n, PV_IBL2);
 }
-// ... and one WAVEFRONT per proof (PvRngCoop): the permutations on the spread state, the 64-byte outputs parked in LDS,
-// then the reductions mod l and the stores one lane per draw.  LDS: (3 + 2 count) x 16 words.
+// ... and one WAVEFRONT per proof (PvRngCoop): the permutations on the spread state, 256 draws at a time: their 64-byte
+// outputs parked in LDS (16 KB), then the reductions mod l and the stores one lane per draw.
+constexpr uint32_t PV_RNG_CHUNK = 256;
 __global__ void __launch_bounds__(64)
 k_pv_rng_coop(PvShape sh, PvBatch B, uint32_t batch, uint32_t phase) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t wide[];
+  __shared__ __attribute__((aligned(16))) uint32_t wide[PV_RNG_CHUNK * 16];
   const uint32_t p = blockIdx.x, lane = threadIdx.x;
   if (p >= batch) return;
   uint32_t* state = B.state + (uint64_t)p * sh.state_words;
@@ -78,30 +79,35 @@ k_pv_rng_coop(PvShape sh, PvBatch B, uint32_t batch, uint32_t phase) {
   uint32_t lo = k.live ? state[sh.o_rng + 2 * k.q] : 0, hi = k.live ? state[sh.o_rng + 2 * k.q + 1] : 0;
   const uint32_t pos = state[sh.o_rng + 50], pos_begin = state[sh.o_rng + 51];
   if (pos_begin != 0 || (pos != 32 && pos != 64)) { if (lane == 0) state[sh.o_flag] = 2; return; }
-#pragma unroll 1
-  for (uint32_t d = 0; d < n_draws; ++d) {
-    PvRngCoop<DevKcTraits>::draw(lo, hi, c, m, d == 0 && pos == 32);
-    if (k.primary && k.q < 8) { wide[16 * d + 2 * k.q] = lo; wide[16 * d + 2 * k.q + 1] = hi; }
-    PvRngCoop<DevKcTraits>::taken(lo, hi, m);
-  }
-  __syncthreads();
   PvView V{sh, state};
   uint32_t* rI = rows;
   uint32_t* rO = rI + 8 * (1 + 2 * cnt);
   uint32_t* rS = rO + 8 * (1 + cnt);
-  for (uint32_t d = lane; d < n_draws; d += 64) {
-    uint32_t wd[16];
+#pragma unroll 1
+  for (uint32_t d0 = 0; d0 < n_draws; d0 += PV_RNG_CHUNK) {
+    const uint32_t d1 = min(d0 + PV_RNG_CHUNK, n_draws);
+#pragma unroll 1
+    for (uint32_t d = d0; d < d1; ++d) {
+      PvRngCoop<DevKcTraits>::draw(lo, hi, c, m, d == 0 && pos == 32);
+      if (k.primary && k.q < 8) { wide[16 * (d - d0) + 2 * k.q] = lo; wide[16 * (d - d0) + 2 * k.q + 1] = hi; }
+      PvRngCoop<DevKcTraits>::taken(lo, hi, m);
+    }
+    __syncthreads();
+    for (uint32_t d = d0 + lane; d < d1; d += 64) {
+      uint32_t wd[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) wd[q] = wide[16 * d + q];
-    const scm v = scm_from_wide(wd);
-    uint32_t *st_slot, *row_slot;
-    if (d == 0) { st_slot = V.at(sh.o_blind, bl_slot); row_slot = rI; }
-    else if (d == 1) { st_slot = V.at(sh.o_blind, bl_slot + 1); row_slot = rO; }
-    else if (d == 2) { st_slot = V.at(sh.o_blind, bl_slot + 2); row_slot = rS; }
-    else if (d < 3 + cnt) { st_slot = V.at(sh.o_sL, first + (d - 3)); row_slot = rS + 8 * (1 + (d - 3)); }
-    else { st_slot = V.at(sh.o_sR, first + (d - 3 - cnt)); row_slot = rS + 8 * (1 + cnt + (d - 3 - cnt)); }
-    pv_st(st_slot, v);
-    pv_st_plain(row_slot, scl_from_scm(v));
+      for (int q = 0; q < 16; ++q) wd[q] = wide[16 * (d - d0) + q];
+      const scm v = scm_from_wide(wd);
+      uint32_t *st_slot, *row_slot;
+      if (d == 0) { st_slot = V.at(sh.o_blind, bl_slot); row_slot = rI; }
+      else if (d == 1) { st_slot = V.at(sh.o_blind, bl_slot + 1); row_slot = rO; }
+      else if (d == 2) { st_slot = V.at(sh.o_blind, bl_slot + 2); row_slot = rS; }
+      else if (d < 3 + cnt) { st_slot = V.at(sh.o_sL, first + (d - 3)); row_slot = rS + 8 * (1 + (d - 3)); }
+      else { st_slot = V.at(sh.o_sR, first + (d - 3 - cnt)); row_slot = rS + 8 * (1 + cnt + (d - 3 - cnt)); }
+      pv_st(st_slot, v);
+      pv_st_plain(row_slot, scl_from_scm(v));
+    }
+    __syncthreads();
   }
   if (k.primary) { state[sh.o_rng + 2 * k.q] = lo; state[sh.o_rng + 2 * k.q + 1] = hi; }
   if (lane == 0) { state[sh.o_rng + 50] = 64; state[sh.o_rng + 51] = 0; }

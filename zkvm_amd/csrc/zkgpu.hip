@@ -1849,11 +1849,11 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
   { Launch l(c, "k_pv_phase0"); hipLaunchKernelGGL(k_pv_phase0, dim3(nb), dim3(64), 0, s, sh, B); }
   if (sh.m) TRY(msm(0, B.rows0, (uint32_t*)c->pv_com.p));
   { Launch l(c, "k_pv_phase1"); hipLaunchKernelGGL(k_pv_phase1, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)c->pv_com.p); }
-  // the TranscriptRng's draws: one wavefront per proof on the spread Keccak state while the outputs fit LDS, else one lane
-  auto rng_launch = [&](uint32_t phase, uint32_t cnt) {
-    const size_t lds = (size_t)(3 + 2 * cnt) * 64;
-    if (lds <= 48 * 1024) { Launch l(c, "k_pv_rng_coop"); hipLaunchKernelGGL(k_pv_rng_coop, dim3(nb), dim3(64), lds, s, sh, B, nb, phase); }
-    else { Launch l(c, "k_pv_rng"); hipLaunchKernelGGL(k_pv_rng, dim3(blocks_for(batch, 64)), dim3(64), 0, s, sh, B, nb, phase); }
+  // the TranscriptRng's draws: one wavefront per proof on the spread Keccak state (k_pv_rng, one lane per proof, is the
+  // form the host emulation and the first device version ran; kept for comparison)
+  auto rng_launch = [&](uint32_t phase, uint32_t) {
+    Launch l(c, "k_pv_rng_coop");
+    hipLaunchKernelGGL(k_pv_rng_coop, dim3(nb), dim3(64), 0, s, sh, B, nb, phase);
   };
   rng_launch(1u, sh.n1);
   TRY(msm(1, B.rows1, pts));
