@@ -202,6 +202,69 @@ def gadget_witness(kind: int, param: int, values):
     return mult_def, []
 
 
+# ---- random constraint systems as data (differential tests of the generic R1CS path) ----------------------------
+def random_system(rng, m, n1, n2, n_chal):
+    """A random satisfiable constraint system with its witness: m committed values; n1 first-phase multipliers (some with
+    given assignments, some defined by two constraints over earlier variables); n2 second-phase multipliers defined with
+    coefficients in the challenges; extra linear constraints that the witness satisfies for EVERY challenge value (each
+    monomial's terms balance on their own).  -> (description tuple, mult_def, values, given)"""
+    K_COMMITTED, K_LEFT, K_RIGHT, K_OUT, K_ONE = range(5)
+    values = [rng.randrange(L) for _ in range(m)]
+    cons, mult_def, given = [], [], []
+    known = [((K_COMMITTED, j), values[j]) for j in range(m)]          # variables whose value is known here (no challenge in it)
+
+    def lc(count, chal=False):
+        terms = []
+        for _ in range(count):
+            (kind, idx), _v = rng.choice(known)
+            c = rng.randrange(1, L) if rng.random() < 0.7 else rng.choice([1, L - 1, 2])
+            ch, pw = (rng.randrange(n_chal), rng.randrange(1, 4)) if (chal and rng.random() < 0.6) else (-1, 0)
+            terms.append((kind, idx, c, ch, pw))
+        if rng.random() < 0.5:
+            terms.append((K_ONE, 0, rng.randrange(L), -1, 0))
+        return terms
+
+    def value_of(terms):
+        acc = 0
+        for kind, idx, c, ch, pw in terms:
+            assert ch < 0
+            v = 1 if kind == K_ONE else next(val for (k, i), val in known if (k, i) == (kind, idx))
+            acc = (acc + c * v) % L
+        return acc
+
+    for i in range(n1):
+        if rng.random() < 0.4:
+            l, r = rng.randrange(L), rng.randrange(L)
+            given.append((l, r))
+            mult_def += [0xFFFFFFFF, 0xFFFFFFFF]
+        else:
+            left, right = lc(rng.randrange(1, 4)), lc(rng.randrange(1, 4))
+            l, r = value_of(left), value_of(right)
+            mult_def += [len(cons), len(cons) + 1]
+            cons.append(left + [(K_LEFT, i, L - 1, -1, 0)])
+            cons.append(right + [(K_RIGHT, i, L - 1, -1, 0)])
+        known += [((K_LEFT, i), l), ((K_RIGHT, i), r), ((K_OUT, i), l * r % L)]
+    first_phase_known = list(known)
+    for i in range(n1, n1 + n2):                                   # their values depend on the challenges: never reused below
+        mult_def += [len(cons), len(cons) + 1]
+        cons.append(lc(rng.randrange(1, 4), chal=True) + [(K_LEFT, i, L - 1, -1, 0)])
+        cons.append(lc(rng.randrange(1, 3), chal=True) + [(K_RIGHT, i, L - 1, -1, 0)])
+    known = first_phase_known
+    for _ in range(rng.randrange(2, 6)):                           # balanced constraints: sum over each monomial = 0
+        terms = []
+        for _g in range(rng.randrange(1, 4)):
+            ch, pw = (rng.randrange(n_chal), rng.randrange(1, 3)) if (n_chal and rng.random() < 0.5) else (-1, 0)
+            group = lc(rng.randrange(1, 4))
+            total = value_of(group)
+            (kb, ib), vb = rng.choice([kv for kv in known if kv[1] % L != 0])
+            group.append((kb, ib, (-total * pow(vb, -1, L)) % L, -1, 0))
+            terms += [(k, i, c, ch, pw) for (k, i, c, _c, _p) in group]
+        cons.append(terms)
+    labels = [b"challenge %d" % j for j in range(n_chal)]
+    return (m, n1, n1 + n2, labels, cons), mult_def, values, given
+
+
+
 # ---- serialized ZkVM transactions (tests/golden/gen_tx_fixture.py) -----------------------------------------
 def load_tx_fixture():
     """-> list of signed payment transactions (bytes): the wrappers of tx_2x2_1024_wrappers.bin around the proofs of

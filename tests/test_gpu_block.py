@@ -7,7 +7,7 @@ import os
 
 import pytest
 
-from gpu_util import L, bits, load_cloak_fixture, load_mixed_fixture, mixed_block, msm_2p20_inputs, oracle_block_bits
+from gpu_util import L, bits, load_cloak_fixture, load_mixed_fixture, mixed_block, msm_2p20_inputs, oracle_block_bits, random_system
 
 pytestmark = pytest.mark.gpu
 R260_INV = pow(pow(2, 260, L), -1, L)
@@ -574,4 +574,47 @@ def test_tickets_merge_small_batches_and_return_each_its_own_bitmap(ctx, oracle)
                 ctx.free_device(d)
     finally:
         bv.close()
+        gens.close()
+
+
+@pytest.mark.parametrize("seed,shape", [(1, None), (2, None), (3, None), (4, None), (5, (1, 0, 0)), (6, (2, 1, 0)), (7, (3, 0, 2)),
+                                        (8, (4, 8, 4)), (9, (2, 3, 1)), (10, (3, 13, 3))])
+def test_random_described_systems_all_provers_and_verifiers_agree(ctx, seed, shape):
+    """Random constraint systems handed over as data (no code anywhere knows them): the device prover and the lockstep
+    prover produce byte-identical proofs, the device verifier and the host-prepared verifier both accept them and both
+    reject a proof made for other values -- four implementations of the R1CS layer against each other."""
+    import random
+    from zkvm_amd.native import R1csDescription
+    from zkvm_amd.verifier import BulletproofGens, R1csProver, R1csVerifier
+    rng = random.Random(9000 + seed)
+    m, n1, n2 = shape if shape else (rng.randrange(1, 5), rng.randrange(0, 9), rng.randrange(0, 5) if seed != 2 else 0)
+    n_chal = rng.randrange(1, 3) if n2 else 0
+    (m, n1, n, labels, cons), mult_def, values, given = random_system(rng, m, n1, n2, n_chal)
+    desc = R1csDescription(b"random system", m, n1, n, labels, cons)
+    gens = BulletproofGens(ctx, 16, table_bits=8)
+    batch = 5
+    vals, givens, seeds = [values] * batch, [given] * batch, [hashlib.sha256(b"rs %d %d" % (seed, i)).digest() for i in range(batch)]
+    try:
+        out = {}
+        for mode in (1, 0):
+            ctx.set_prover_mode(mode)
+            out[mode] = R1csProver(ctx, gens, desc, mult_def, host_threads=2).prove(vals, givens, seeds)
+        assert out[0] == out[1]
+        coms, proofs = out[0]
+        assert len(set(proofs)) == batch                            # different seeds, different proofs
+        bad = bytearray(proofs[2]); bad[1 + 32 * 11 + 3] ^= 1       # t_x
+        proofs_t = list(proofs); proofs_t[2] = bytes(bad)
+        coms_t = list(coms); coms_t[4] = coms[4][:-32] + coms[3][:32] if m > 1 else coms[4]
+        r = hashlib.shake_256(b"random system r").digest(64 * batch)
+        want = [1, 1, 0, 1, 0 if (m > 1 and coms_t[4] != coms[4]) else 1]
+        v = R1csVerifier(ctx, gens, desc)
+        try:
+            plen = len(proofs[0])
+            assert bits(v.verify_gpu(batch, b"".join(coms), b"".join(proofs), plen, r), batch) == [1] * batch
+            assert bits(v.verify_gpu(batch, b"".join(coms_t), b"".join(proofs_t), plen, r), batch) == want
+            assert bits(v.verify_host_prepared(batch, b"".join(coms_t), b"".join(proofs_t), plen, r), batch) == want
+        finally:
+            v.close()
+    finally:
+        ctx.set_prover_mode(0)
         gens.close()

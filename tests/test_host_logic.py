@@ -386,3 +386,39 @@ def test_described_prover_equals_oracle_gadget_prover(host, oracle, kind, param)
                                     C.c_size_t(cap), com2, proof2, C.c_size_t(4096), C.byref(plen2))
     assert rc == 0
     assert com2.raw == want_com and proof2.raw[: plen2.value] == want_proof
+
+
+@pytest.mark.parametrize("seed,shape", [(11, (1, 0, 0)), (12, (2, 1, 0)), (13, (3, 0, 2)), (14, (3, 6, 3)), (15, (2, 9, 2))])
+def test_random_described_systems_device_prover_functions_equal_host_prover(host, oracle, seed, shape):
+    """Random satisfiable constraint systems as data (tests/gpu_util.py: random_system): the device prover's phase functions
+    run on the host (prover_dev.hpp) and the host prover (r1cs_prover.hpp: desc_prover) produce the same bytes."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from gpu_util import random_system
+    rng = random.Random(seed)
+    m, n1, n2 = shape
+    (m, n1, n, labels, cons), mult_def, values, given = random_system(rng, m, n1, n2, 1 if n2 else 0)
+    cap = 1
+    while cap < max(n, 1):
+        cap *= 2
+    gens = _gens_bytes(oracle, cap)
+    offs, kinds, idx, coeff, chal, power = [0], [], [], b"", [], []
+    for con in cons:
+        for (k_, i_, c_, ch_, pw_) in con:
+            kinds.append(k_); idx.append(i_); coeff += (c_ % L).to_bytes(32, "little"); chal.append(ch_); power.append(pw_)
+        offs.append(len(kinds))
+    nt = max(len(kinds), 1)
+    lab = (C.c_char_p * max(len(labels), 1))(*labels)
+    gv = b"".join(a.to_bytes(32, "little") + b.to_bytes(32, "little") for a, b in given)
+    vb = b"".join(v.to_bytes(32, "little") for v in values)
+    seed_b = hashlib.sha256(b"random system %d" % seed).digest()
+    outs = []
+    for fn in (host.zkhost_r1cs_prove, host.zkhost_prove_dev_r1cs):
+        com, proof, plen = C.create_string_buffer(32 * m), C.create_string_buffer(4096), C.c_size_t(0)
+        rc = fn(b"random system", m, n1, n, len(labels), lab, len(cons), (C.c_uint64 * len(offs))(*offs), (C.c_uint8 * nt)(*kinds),
+                (C.c_uint32 * nt)(*idx), coeff, (C.c_int32 * nt)(*chal), (C.c_uint32 * nt)(*power),
+                (C.c_uint32 * max(len(mult_def), 1))(*mult_def), vb, gv, C.c_size_t(len(given)), seed_b, gens, C.c_size_t(cap), com, proof,
+                C.c_size_t(4096), C.byref(plen))
+        assert rc == 0
+        outs.append((com.raw, proof.raw[: plen.value]))
+    assert outs[0] == outs[1] and len(outs[0][1]) > 400
