@@ -17,3 +17,8 @@ for _ in range(4):
     dt = time.perf_counter() - t0
     print("%.2f ms, %.0f tx/s (%d transactions per call)" % (dt * 1e3, len(txs) / dt, len(txs)), file=sys.stderr)
 assert not any(st)
+ctx.profile(True); ctx.profile_reset()
+bm, st = bv.verify_txs(txs)
+ctx.profile(False)
+for name, (n, ms) in sorted(ctx.profile_read().items(), key=lambda kv: -kv[1][1])[:14]:
+    print('%-24s %4d launches %9.3f ms' % (name, n, ms), file=sys.stderr)
