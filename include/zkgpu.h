@@ -486,7 +486,7 @@ int zkgpu_verifier_verify_sharded(zkgpu_verifier *v, zkgpu_comm *comm, size_t ba
 /* ---- measurement hooks (used by bench.py; not part of the reference API) ----
  * Environment variables read by the library, none of which changes a result:
  *   ZKGPU_TIMELINE=<file>     with profiling on, every launch as "ctx kernel start_ms end_ms"
- *   ZKGPU_PROVER_TIMING=1     zkgpu_cloak_prove_batch prints per-phase host / device times to stderr
+ *   ZKGPU_PROVER_TIMING=1     the provers and zkgpu_tx_verify_batch print per-phase host / device times to stderr
  * and GPU_MAX_HW_QUEUES (a HIP runtime variable): zkgpu_init sets it to 24 if it is unset and the
  * runtime has not started; batches in flight need a hardware queue per context. */
 /* When enabled, every kernel launch of this context is bracketed by HIP events
