@@ -898,7 +898,7 @@ def main():
     ap.add_argument("--tickets", type=int, default=-1,
                     help="config 2: batches kept in flight as tickets of a zkgpu_verifier, which merges them into device batches of --merge tx (0 = plain contexts)")
     ap.add_argument("--merge", type=int, default=0, help="config 2 with --tickets: transactions per merged device batch (0: chosen from --steps, see below)")
-    ap.add_argument("--locate-mode", type=int, default=0, choices=(0, 1, 2), help="zkgpu_set_locate_mode")
+    ap.add_argument("--locate-mode", type=int, default=0, choices=(0, 1, 2, 3), help="zkgpu_set_locate_mode")
     ap.add_argument("--horner-mode", type=int, default=0, choices=(0, 1, 2), help="zkgpu_set_horner_mode")
     ap.add_argument("--transcript-mode", type=int, default=0, choices=(0, 1, 2),
                     help="zkgpu_set_transcript_mode: 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction")

@@ -293,7 +293,9 @@ int zkgpu_set_group_size(zkgpu_ctx* ctx, int group);
 long long zkgpu_debug_force_regroup(zkgpu_ctx* ctx, int on);
 /* 0 automatic (default: locate from 2048 transactions per batch on -- below that the two extra dependent stages cost
  * more latency than the saved work is worth, and a failed group is simply re-checked transaction by transaction),
- * 1 never locate, 2 always locate.  Forks inherit the setting. */
+ * 1 never locate, 2 always locate, 3 always locate with the locating sums of ALL groups formed beside the group sums (the
+ * culprit is then named two dependent launches earlier, for ~3 % more point arithmetic per batch: measured slower, kept for
+ * comparison).  Forks inherit the setting. */
 int zkgpu_set_locate_mode(zkgpu_ctx* ctx, int mode);
 /* The Horner chains over the windows of the proof-point sums (the longest dependent chain of a batch): 2 = one chain
  * per GROUP over the summed windows of its transactions, then one per transaction of the groups that failed (a third

@@ -371,7 +371,7 @@ def test_failed_groups_are_located_and_every_pattern_of_bad_transactions_resolve
         before = ctx.force_regroup(False)
         for horner in (1, 2, 0):                                # Horner chains per transaction / per group / automatic
             ctx.set_horner_mode(horner)
-            for mode in (1, 2, 2):                              # re-check in full; locate (the default from 2048 per batch on)
+            for mode in (1, 2, 2, 3, 3):                        # re-check in full; locate (the default from 2048 per batch on); locating sums formed up front
                 ctx.set_locate_mode(mode)
                 assert bits(v.verify_packed_gpu(n_in, n_out, n, com_b, proof_b, plen, r), n) == want, (horner, mode)
         assert ctx.force_regroup(True) == before               # nothing above needed the ungrouped re-run

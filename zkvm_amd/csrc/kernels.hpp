@@ -1379,6 +1379,13 @@ k_group_windows(const uint32_t* __restrict__ window_sums, const uint32_t* __rest
   if (have) store_ext(out_sums + (uint64_t)g * EXT_WORDS, acc);
 }
 
+__device__ inline void locate_group(const uint32_t* __restrict__ partials2, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
+                                    const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
+                                    uint32_t group, uint32_t G, uint32_t f, const uint32_t* __restrict__ fail_sum,
+                                    uint32_t* __restrict__ row_map, uint32_t* __restrict__ n_recheck, uint32_t* __restrict__ cand,
+                                    const uint32_t* __restrict__ st_scalars, uint32_t n_static, int16_t* __restrict__ digits, int w, int W,
+                                    unsigned long long* sh_queue);
+
 // one wave per group: generator partials of the group + the proof-point sums of its transactions
 // blockDim = 256: wavefront 0 sums the points; a failed group's locating scalars are then spread over all four.
 // locate == 0 (small batches, where the extra stage costs more latency than it saves work): a failed group queues
@@ -1389,9 +1396,11 @@ k_group_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, cons
                 uint32_t group, uint8_t* __restrict__ accept, uint32_t* __restrict__ grp_state /*[n_groups]: 0 passed, f + 1 failed*/,
                 uint32_t* __restrict__ fail_list, uint32_t* __restrict__ fail_sum /*[n_groups][40]*/, uint32_t* __restrict__ n_fail,
                 const uint32_t* __restrict__ st_scalars, uint32_t n_static, uint32_t* __restrict__ loc_sc /*[n_groups][n_static][8]*/,
-                int16_t* __restrict__ loc_digits, int w, int W, uint32_t locate, uint32_t* __restrict__ row_map,
-                uint32_t* __restrict__ n_recheck, uint32_t* __restrict__ cand) {
+                int16_t* __restrict__ loc_digits, int w, int W, uint32_t locate /*0 no, 1 by a multiplication to come, 2 its rows are there*/,
+                uint32_t* __restrict__ row_map, uint32_t* __restrict__ n_recheck, uint32_t* __restrict__ cand,
+                int16_t* __restrict__ rechk_digits /*locate == 2: [W][n_msm * n_static]*/) {
   __shared__ uint32_t sh_fail;           // 0: the group passed, else f + 1
+  __shared__ unsigned long long sh_queue;
   const uint32_t G = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63;
   const uint32_t in_group = min(group, n_msm - G * group);
@@ -1459,6 +1468,14 @@ k_group_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, cons
   if (f1 == 0) return;
   const uint32_t f = f1 - 1;
   if (!locate) { if (t == 0) cand[f] = LOCATE_NONE; return; }
+  if (locate == 2) {
+    // the locating sums of ALL groups were formed beside the group sums (rows n_groups + G of the same multiplication):
+    // the culprit is named right here, two dependent launches earlier
+    const uint32_t n_groups2 = (n_msm + group - 1) / group;
+    locate_group(partials + (uint64_t)(n_groups2 + G) * n_partials * EXT_WORDS, n_partials, dyn_sum, msm_fail, wellformed, n_msm, group, G, f,
+                 fail_sum, row_map, n_recheck, cand, st_scalars, n_static, rechk_digits, w, W, &sh_queue);
+    return;
+  }
   // failed: the generator scalars of the group's LOCATING sum, sum_t i_t s_(t,j) (i_t = 1, 2, .. the position in the
   // group), and their digits, stored at the group's place in the failed list
   const uint32_t n_groups = (n_msm + group - 1) / group;
@@ -1486,27 +1503,23 @@ k_group_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, cons
   }
 }
 
-// one wave per failed group f: S2 = generator partials of the locating sum + sum_t i_t dyn_t; the position i
-// with i S1 = S2 names the one bad transaction, which alone is queued for the individual check (cand[f] =
-// its slot in row_map); no such i: every transaction of the group is queued (cand[f] = LOCATE_NONE)
-__global__ void __launch_bounds__(256)
-k_locate_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
-                 const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
-                 uint32_t group, const uint32_t* __restrict__ fail_list, const uint32_t* __restrict__ n_fail,
-                 const uint32_t* __restrict__ fail_sum, uint32_t* __restrict__ row_map, uint32_t* __restrict__ n_recheck,
-                 uint32_t* __restrict__ cand, const uint32_t* __restrict__ st_scalars, uint32_t n_static,
-                 int16_t* __restrict__ digits /*[W][n_msm * n_static], as k_static_digits writes them*/, int w, int W) {
-  __shared__ unsigned long long sh_queue;    // bit i: transaction i of the group is queued for the individual check
-  const uint32_t f = blockIdx.x;
-  if (f >= *n_fail) return;
-  const uint32_t G = fail_list[f];
+// Failed group f (= group G): S2 = generator partials of the locating sum (`partials2`: its n_partials rows) + sum_t i_t dyn_t;
+// the position i with i S1 = S2 names the one bad transaction, which alone is queued for the individual check (cand[f] = its
+// slot in row_map); no such i: every transaction of the group is queued (cand[f] = LOCATE_NONE).  Called by all 256 threads of
+// a workgroup: wavefront 0 locates, then everybody writes the digits of the queued transactions' generator scalars.
+__device__ inline void locate_group(const uint32_t* __restrict__ partials2, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
+                                    const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
+                                    uint32_t group, uint32_t G, uint32_t f, const uint32_t* __restrict__ fail_sum,
+                                    uint32_t* __restrict__ row_map, uint32_t* __restrict__ n_recheck, uint32_t* __restrict__ cand,
+                                    const uint32_t* __restrict__ st_scalars, uint32_t n_static, int16_t* __restrict__ digits, int w, int W,
+                                    unsigned long long* sh_queue) {
   const int t = threadIdx.x, lane = t & 63;
   if (t < 64) {
     ge acc;
     ge_identity(acc);
     for (uint32_t c = lane; c < n_partials; c += 64) {
       ge p;
-      load_ext(p, partials + ((uint64_t)f * n_partials + c) * EXT_WORDS);
+      load_ext(p, partials2 + (uint64_t)c * EXT_WORDS);
       ge_add(acc, acc, p);
     }
     const uint32_t tx = G * group + (uint32_t)lane;
@@ -1547,17 +1560,17 @@ k_locate_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, con
         const uint32_t slot = atomicAdd(n_recheck, 1u);
         row_map[slot] = G * group + (uint32_t)b;
         cand[f] = slot;
-        sh_queue = 1ull << b;
+        *sh_queue = 1ull << b;
       }
     } else {
       uint32_t base = 0;
-      if (lane == 0) { base = atomicAdd(n_recheck, (uint32_t)__popcll(lives)); cand[f] = LOCATE_NONE; sh_queue = lives; }
+      if (lane == 0) { base = atomicAdd(n_recheck, (uint32_t)__popcll(lives)); cand[f] = LOCATE_NONE; *sh_queue = lives; }
       base = __shfl(base, 0);
       if (live) row_map[base + (uint32_t)__popcll(lives & ((1ull << lane) - 1))] = tx;
     }
   }
   __syncthreads();
-  const unsigned long long queue = sh_queue;
+  const unsigned long long queue = *sh_queue;
   for (uint32_t i = 0; i < group && i < 64; ++i) {
     if (!((queue >> i) & 1)) continue;
     const uint32_t ti = G * group + i;
@@ -1567,6 +1580,21 @@ k_locate_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, con
       for_each_digit(st_scalars + 8 * g, w, W, [&](int tt, int dd) { digits[(uint64_t)tt * n_msm * n_static + g] = (int16_t)dd; });
     }
   }
+}
+
+// one workgroup per failed group f, after the locating multiscalar multiplication (rows indexed by f)
+__global__ void __launch_bounds__(256)
+k_locate_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
+                 const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
+                 uint32_t group, const uint32_t* __restrict__ fail_list, const uint32_t* __restrict__ n_fail,
+                 const uint32_t* __restrict__ fail_sum, uint32_t* __restrict__ row_map, uint32_t* __restrict__ n_recheck,
+                 uint32_t* __restrict__ cand, const uint32_t* __restrict__ st_scalars, uint32_t n_static,
+                 int16_t* __restrict__ digits /*[W][n_msm * n_static], as k_static_digits writes them*/, int w, int W) {
+  __shared__ unsigned long long sh_queue;    // bit i: transaction i of the group is queued for the individual check
+  const uint32_t f = blockIdx.x;
+  if (f >= *n_fail) return;
+  locate_group(partials + (uint64_t)f * n_partials * EXT_WORDS, n_partials, dyn_sum, msm_fail, wellformed, n_msm, group, fail_list[f], f,
+               fail_sum, row_map, n_recheck, cand, st_scalars, n_static, digits, w, W, &sh_queue);
 }
 
 // Final verdicts of a batch checked in groups, packed into the bitmap (byte i / 8, bit i % 8):

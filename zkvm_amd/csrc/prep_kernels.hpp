@@ -893,35 +893,43 @@ k_points_tables(PrepShape sh, const uint32_t* __restrict__ com, const uint32_t* 
   }
 }
 
-// generator scalars of a group: sum over its transactions (canonical words in and out)
+// generator scalars of a group: sum over its transactions (canonical words in and out).  both != 0: also the LOCATING sum
+// sum_t i_t s_t (i_t = 1, 2, .. the position in the group) as rows n_groups + G of the same multiscalar multiplication:
+// outputs and digits then hold 2 n_groups rows
 __global__ void __launch_bounds__(256)
 k_group_scalars(const uint32_t* __restrict__ st_scalars /*[B][n_static][8]*/, uint32_t n_msm, uint32_t n_static,
-                uint32_t group, uint32_t* __restrict__ out /*[groups][n_static][8]*/,
-                int16_t* __restrict__ digits /*optional: [W][groups * n_static], as k_static_digits writes them*/,
-                int w, int W, const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed) {
+                uint32_t group, uint32_t* __restrict__ out /*[groups (x 2)][n_static][8]*/,
+                int16_t* __restrict__ digits /*optional: [W][rows * n_static], as k_static_digits writes them*/,
+                int w, int W, const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t both) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n_groups = (n_msm + group - 1) / group;
-  const uint64_t total = (uint64_t)n_groups * n_static;
+  const uint64_t total = (uint64_t)n_groups * n_static, stride = both ? 2 * total : total;
   if (g >= total) return;
   const uint32_t G = (uint32_t)(g / n_static), j = (uint32_t)(g % n_static);
-  scm acc = scm_zero();
-  for (uint32_t i = 0; i < group; ++i) {
+  scm acc = scm_zero(), sum2 = scm_zero();
+  const uint32_t in_group = min(group, n_msm - G * group);
+  for (uint32_t i = in_group; i-- > 0;) {         // acc: running sum from the last transaction down; sum_k (sum_{t >= k} s_t) = sum_t (t + 1) s_t
     const uint32_t tx = G * group + i;
-    if (tx >= n_msm) break;
-    if (tx_excluded(msm_fail, wellformed, tx)) continue;   // known bad already: left out of the group, rejected on the spot
-    const uint4* src = reinterpret_cast<const uint4*>(st_scalars + ((uint64_t)tx * n_static + j) * 8);
-    const uint4 a = src[0], b = src[1];
-    scm v;
-    v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w; v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
-    acc = scm_add(acc, v);
+    if (!tx_excluded(msm_fail, wellformed, tx)) {   // known bad already: left out of the group, rejected on the spot
+      const uint4* src = reinterpret_cast<const uint4*>(st_scalars + ((uint64_t)tx * n_static + j) * 8);
+      const uint4 a = src[0], b = src[1];
+      scm v;
+      v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w; v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w;
+      acc = scm_add(acc, v);
+    }
+    if (both) sum2 = scm_add(sum2, acc);
   }
-  uint4* dst = reinterpret_cast<uint4*>(out + g * 8);
-  dst[0] = make_uint4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]);
-  dst[1] = make_uint4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
-  if (digits) {   // the sum is < l: no range flag to raise; digits straight from the registers' copy
-    for (int t = 0; t < W; ++t) digits[(uint64_t)t * total + g] = 0;
-    for_each_digit(out + g * 8, w, W, [&](int t, int d) { digits[(uint64_t)t * total + g] = (int16_t)d; });
-  }
+  auto emit = [&](uint64_t at, const scm& val) {
+    uint4* dst = reinterpret_cast<uint4*>(out + at * 8);
+    dst[0] = make_uint4(val.v[0], val.v[1], val.v[2], val.v[3]);
+    dst[1] = make_uint4(val.v[4], val.v[5], val.v[6], val.v[7]);
+    if (digits) {   // the sum is < l: no range flag to raise
+      for (int t = 0; t < W; ++t) digits[(uint64_t)t * stride + at] = 0;
+      for_each_digit(out + at * 8, w, W, [&](int t, int d) { digits[(uint64_t)t * stride + at] = (int16_t)d; });
+    }
+  };
+  emit(g, acc);
+  if (both) emit(total + g, sum2);
 }
 
 }  // namespace zk

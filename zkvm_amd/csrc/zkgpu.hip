@@ -754,15 +754,22 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   const uint32_t group = (prep && c->group_size > 1) ? (uint32_t)std::min<size_t>(c->group_size, B) : 1;
   const uint32_t n_groups = (uint32_t)((B + group - 1) / group);
   const uint32_t ns = prep ? prep->sh.n_static : 0;
+  // locating the culprit of a failed group saves work (one multiscalar multiplication instead of `group`) at the
+  // price of two more dependent stages: worth it once the batch is large enough for the work to matter.  Mode 3 forms the
+  // locating sums of ALL groups beside the group sums (twice the rows in the same multiplication), so that a failed group's
+  // culprit is named by k_group_combine itself: no extra stage, ~3 % more point arithmetic per batch.
+  const bool locate = group > 1 && (c->locate_mode >= 2 || (c->locate_mode == 0 && B >= LOCATE_MIN_BATCH));
+  const bool spec = locate && c->locate_mode == 3;
+  const uint32_t grp_rows = spec ? 2 * n_groups : n_groups;
   // parts per (check, window) of the group launch and of the individual re-check (few checks each:
   // short chains of additions per lane keep their latency down)
   int Pg = 1;
   const int Pf = 32;
   if (group > 1) {
-    Pg = (int)std::max<uint64_t>(1, std::min<uint64_t>(32, (65536 + (uint64_t)n_groups * W - 1) / ((uint64_t)n_groups * W)));
-    TRY(ensure(c, c->grp_sc, (size_t)n_groups * ns * 32));
-    TRY(ensure(c, c->grp_digits, (size_t)n_groups * ns * W * 2));
-    TRY(ensure(c, c->grp_partials, (size_t)n_groups * W * Pg * EXT_WORDS * 4));
+    Pg = (int)std::max<uint64_t>(1, std::min<uint64_t>(32, (65536 + (uint64_t)grp_rows * W - 1) / ((uint64_t)grp_rows * W)));
+    TRY(ensure(c, c->grp_sc, (size_t)grp_rows * ns * 32));
+    TRY(ensure(c, c->grp_digits, (size_t)grp_rows * ns * W * 2));
+    TRY(ensure(c, c->grp_partials, (size_t)grp_rows * W * Pg * EXT_WORDS * 4));
     TRY(ensure(c, c->grp_ok, n_groups));
     TRY(ensure(c, c->row_map, B * 4));
     TRY(ensure(c, c->grp_fail, (size_t)n_groups * 12));
@@ -859,13 +866,13 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
       Launch l(c, "k_group_scalars", H2);     // sums and their digits in one launch
       hipLaunchKernelGGL(k_group_scalars, dim3(blocks_for((uint64_t)n_groups * ns, 256)), dim3(256), 0, H2,
                          job.d_st_scalars, (uint32_t)B, ns, group, (uint32_t*)c->grp_sc.p, (int16_t*)c->grp_digits.p,
-                         ps->tbl_w, W, (const uint32_t*)c->msm_fail.p, job.d_wellformed);
+                         ps->tbl_w, W, (const uint32_t*)c->msm_fail.p, job.d_wellformed, spec ? 1u : 0u);
     }
     {
       Launch l(c, "k_static_accumulate", H2);
-      hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)n_groups * W * Pg, 256)), dim3(256), 0, H2,
+      hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)grp_rows * W * Pg, 256)), dim3(256), 0, H2,
                          (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
-                         (uint32_t)ps->n, ps->tbl_H, W, Pg, n_groups, (uint64_t)n_groups * ns,
+                         (uint32_t)ps->n, ps->tbl_H, W, Pg, grp_rows, (uint64_t)grp_rows * ns,
                          (uint32_t*)c->grp_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     }
     HIP_TRY(c, hipEventRecord(c->ev_sa, H2));
@@ -905,7 +912,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   // family finished last had no failed group at all (root->last_failed_groups), else one chain per transaction up
   // front.  Same verdicts either way.
   zkgpu_ctx* root = c->parent ? c->parent : c;
-  const bool group_first = group > 1 && (c->horner_mode == 2 || (c->horner_mode == 0 && root->last_failed_groups.load() == 0));
+  const bool group_first = group > 1 && !spec && (c->horner_mode == 2 || (c->horner_mode == 0 && root->last_failed_groups.load() == 0));
   if (group_first) {
     {
       Launch l(c, "k_group_windows", L);
@@ -930,9 +937,6 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     uint32_t* fail_list = (uint32_t*)c->grp_fail.p;
     uint32_t* cand = fail_list + n_groups;
     uint32_t* grp_state = cand + n_groups;
-    // locating the culprit of a failed group saves work (one multiscalar multiplication instead of `group`) at the
-    // price of two more dependent stages: worth it once the batch is large enough for the work to matter
-    const bool locate = c->locate_mode == 2 || (c->locate_mode == 0 && B >= LOCATE_MIN_BATCH);
     {
       Launch l(c, "k_group_combine", L);        // verdicts of the groups; a failed group also gets its locating scalars
       hipLaunchKernelGGL(k_group_combine, dim3(n_groups), dim3(256), 0, L, (const uint32_t*)c->grp_partials.p,
@@ -940,7 +944,8 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
                          (const uint32_t*)c->dynsum.p, (const uint32_t*)c->msm_fail.p,
                          job.d_wellformed, (uint32_t)B, group, (uint8_t*)c->accept2.p, grp_state, fail_list,
                          (uint32_t*)c->grp_fail_sum.p, n_fail, job.d_st_scalars, ns, (uint32_t*)c->grp_sc.p,
-                         (int16_t*)c->grp_digits.p, ps->tbl_w, W, locate ? 1u : 0u, (uint32_t*)c->row_map.p, n_recheck, cand);
+                         (int16_t*)c->grp_digits.p, ps->tbl_w, W, spec ? 2u : locate ? 1u : 0u, (uint32_t*)c->row_map.p, n_recheck, cand,
+                         (int16_t*)c->digits.p);
     }
     if (group_first) {
       Launch l(c, "k_msm_finish_quad", L);      // Horner chains of the transactions of the failed groups only
@@ -952,7 +957,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     // failed groups (kernels.hpp, "group checks"): one more multiscalar multiplication each LOCATES the bad
     // transaction, which alone is then checked on its own.  Grids are sized for the worst case; lanes beyond the
     // device-side counts leave at once (no failed group: four near-empty launches).
-    if (locate) {
+    if (locate && !spec) {
       Launch l(c, "k_static_accumulate", L);
       hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)n_groups * W * Pg, 256)), dim3(256), 0, L,
                          (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
@@ -964,7 +969,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
       hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, L, job.d_st_scalars,
                          (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p,
                          (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, ns);
-    } else {
+    } else if (!spec) {
       Launch l(c, "k_locate_combine", L);       // names the culprit (or queues the whole group) and writes the digits of the queued
       hipLaunchKernelGGL(k_locate_combine, dim3(n_groups), dim3(256), 0, L, (const uint32_t*)c->grp_partials.p,
                          (uint32_t)(W * Pg), (const uint32_t*)c->dynsum.p, (const uint32_t*)c->msm_fail.p, job.d_wellformed,
@@ -1481,7 +1486,7 @@ int zkgpu_debug_arith(zkgpu_ctx* c, int op, const uint8_t* a, const uint8_t* b, 
 // Failed groups: 0 automatic (locate the culprit from LOCATE_MIN_BATCH transactions per batch on), 1 always re-check
 // every transaction of a failed group, 2 always locate.  Same verdicts either way.
 int zkgpu_set_locate_mode(zkgpu_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 2) return ZKGPU_EINVAL;
+  if (!c || mode < 0 || mode > 3) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   c->locate_mode = mode;
   return ZKGPU_OK;

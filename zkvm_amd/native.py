@@ -271,7 +271,7 @@ class Context:
         self._check(self.lib.zkgpu_set_horner_mode(self.h, mode))
 
     def set_locate_mode(self, mode: int) -> None:
-        """zkgpu_set_locate_mode: failed groups -- 0 automatic, 1 re-check every transaction, 2 locate the culprit."""
+        """zkgpu_set_locate_mode: failed groups -- 0 automatic, 1 re-check every transaction, 2 locate the culprit, 3 locate with the locating sums formed up front."""
         self._check(self.lib.zkgpu_set_locate_mode(self.h, mode))
 
     def force_regroup(self, on: bool) -> int:
