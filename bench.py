@@ -919,7 +919,7 @@ def main():
         # (measured at K = 20: 2 x 10240 tx: 2.65 M tx/s; 8192 per device batch with 3 / 5 in flight: 2.30 / 2.33 M; one
         # batch of 20480: 2.47 M); a long run settles into a steady state in which 64 queued batches, merged 8 at a time,
         # 5 device batches in flight do best (sweep r02k: 32 / 3: 2.87 M, 64 / 5: 3.05 M, 128 / 9: 3.08 M tx/s).
-        if args.steps * args.batch <= 40960 and args.merge <= 0 and args.inflight <= 0:
+        if args.steps * args.batch <= 40960 and args.merge <= 0 and args.inflight <= 0 and not args.solo:   # (--solo: always 8192 per launch)
             args.tickets = max(args.steps, 2)
             args.merge = ((args.steps + 1) // 2) * args.batch
             args.inflight = 2
