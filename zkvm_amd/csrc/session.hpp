@@ -209,36 +209,42 @@ void zkgpu_txblock_destroy(zkgpu_txblock* b) {
 size_t zkgpu_txblock_size(const zkgpu_txblock* b) { return b ? b->batch : 0; }
 size_t zkgpu_txblock_shapes(const zkgpu_txblock* b) { return b ? b->groups.size() : 0; }
 
-int zkgpu_txblock_create(zkgpu_verifier* v, size_t batch, const uint32_t* n_in, const uint32_t* n_out,
-                         const uint8_t* commitments, const uint8_t* proofs, const uint64_t* proof_offsets,
-                         const uint8_t* r_bytes, zkgpu_txblock** out) {
-  if (!v || !out) return ZKGPU_EINVAL;
-  *out = nullptr;
-  if (batch && (!n_in || !n_out || !commitments || !proofs || !proof_offsets)) return ZKGPU_EINVAL;
-  if (batch >= (1ull << 31)) return ZKGPU_EINVAL;
-  for (size_t i = 0; i < batch; ++i) if (proof_offsets[i + 1] < proof_offsets[i]) return ZKGPU_EINVAL;
+namespace {
+
+// One transaction of a block being staged: where its commitments (64 (n_in + n_out) bytes) and its proof lie in host memory
+struct TxSource { uint32_t n_in, n_out; const uint8_t* com; const uint8_t* proof; uint64_t proof_len; };
+
+// groups the transactions by (inputs, outputs, proof length), lays the groups out, gathers them on host threads and
+// copies the block to HBM
+int txblock_build(zkgpu_verifier* v, size_t batch, const TxSource* src, const uint8_t* r_bytes, int host_threads, zkgpu_txblock** out) {
   std::lock_guard<std::mutex> lk(v->mu);
   zkgpu_ctx* c = v->root;
   std::unique_ptr<zkgpu_txblock> b(new zkgpu_txblock());
   b->v = v; b->batch = batch;
-  // group by (inputs, outputs, proof length): one uniform device batch per group
   std::map<std::tuple<uint32_t, uint32_t, uint64_t>, size_t> where;
-  std::vector<uint64_t> com_off(batch + 1, 0);
+  std::vector<uint32_t> slot(batch);                  // position inside its group
+  std::vector<uint32_t> group_of(batch);
+  size_t last = (size_t)-1;
+  std::tuple<uint32_t, uint32_t, uint64_t> last_key{0, 0, 0};
   for (size_t i = 0; i < batch; ++i) {
-    com_off[i + 1] = com_off[i] + 64ull * ((uint64_t)n_in[i] + n_out[i]);
-    const uint64_t plen = proof_offsets[i + 1] - proof_offsets[i];
-    const auto key = std::make_tuple(n_in[i], n_out[i], plen);
-    auto it = where.find(key);
-    if (it == where.end()) {
-      zkgpu_txblock::Group g;
-      g.n_in = n_in[i]; g.n_out = n_out[i]; g.proof_len = (size_t)plen;
-      g.plan = verifier_plan(v, n_in[i], n_out[i]);
-      if (g.plan && !proof_len_fits(g.plan->shape, plen)) g.plan = nullptr;   // wrong length for the statement
-      g.com_off = g.proof_off = g.r_off = 0;
-      it = where.emplace(key, b->groups.size()).first;
-      b->groups.push_back(std::move(g));
+    const auto key = std::make_tuple(src[i].n_in, src[i].n_out, src[i].proof_len);
+    if (last == (size_t)-1 || key != last_key) {      // blocks are mostly runs of one shape: the map is asked once per run
+      auto it = where.find(key);
+      if (it == where.end()) {
+        zkgpu_txblock::Group g;
+        g.n_in = src[i].n_in; g.n_out = src[i].n_out; g.proof_len = (size_t)src[i].proof_len;
+        g.plan = verifier_plan(v, g.n_in, g.n_out);
+        if (g.plan && !proof_len_fits(g.plan->shape, g.proof_len)) g.plan = nullptr;   // wrong length for the statement
+        g.com_off = g.proof_off = g.r_off = 0;
+        it = where.emplace(key, b->groups.size()).first;
+        b->groups.push_back(std::move(g));
+      }
+      last = it->second;
+      last_key = key;
     }
-    b->groups[it->second].idx.push_back((uint32_t)i);
+    group_of[i] = (uint32_t)last;
+    slot[i] = (uint32_t)b->groups[last].idx.size();
+    b->groups[last].idx.push_back((uint32_t)i);
   }
   // layout in HBM (256-byte aligned pieces), only for the groups that will run
   size_t total = 0;
@@ -250,45 +256,75 @@ int zkgpu_txblock_create(zkgpu_verifier* v, size_t batch, const uint32_t* n_in, 
     g.proof_off = total; total = align(total + n * g.proof_len);
     g.r_off = total; total = align(total + n * 64);
   }
+  const bool timing = getenv("ZKGPU_PROVER_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tb0 = now();
+  double tb1 = 0, tb2 = 0;
   if (total) {
     DeviceGuard dg(c->device);
-    std::vector<uint8_t> host(total);
-    for (auto& g : b->groups) {
-      if (!g.plan) continue;
-      const size_t wcom = 64 * ((size_t)g.n_in + g.n_out);
-      for (size_t j = 0; j < g.idx.size(); ++j) {
-        const size_t i = g.idx[j];
-        memcpy(&host[g.com_off + j * wcom], commitments + com_off[i], wcom);
-        memcpy(&host[g.proof_off + j * g.proof_len], proofs + proof_offsets[i], g.proof_len);
-        if (r_bytes) memcpy(&host[g.r_off + j * 64], r_bytes + 64 * i, 64);
-      }
-      if (!r_bytes && !os_random(&host[g.r_off], g.idx.size() * 64)) { v->last_error = "getrandom failed"; return ZKGPU_EINVAL; }
-    }
+    std::unique_ptr<uint8_t[]> host(new uint8_t[total]);
+    host_parallel(batch, host_threads, [&](size_t i) {
+      const zkgpu_txblock::Group& g = b->groups[group_of[i]];
+      if (!g.plan) return;
+      const size_t wcom = 64 * ((size_t)g.n_in + g.n_out), j = slot[i];
+      memcpy(&host[g.com_off + j * wcom], src[i].com, wcom);
+      memcpy(&host[g.proof_off + j * g.proof_len], src[i].proof, g.proof_len);
+      if (r_bytes) memcpy(&host[g.r_off + j * 64], r_bytes + 64 * i, 64);
+    });
+    tb1 = now();
+    if (!r_bytes)
+      for (auto& g : b->groups)
+        if (g.plan && !os_random(&host[g.r_off], g.idx.size() * 64)) { v->last_error = "getrandom failed"; return ZKGPU_EINVAL; }
+    tb2 = now();
     hipError_t e = hipMalloc((void**)&b->dev, total);
     if (e != hipSuccess) { v->last_error = std::string("hipMalloc: ") + hipGetErrorString(e); b->dev = nullptr; return ZKGPU_ENOMEM; }
     b->dev_bytes = total;
-    e = hipMemcpy(b->dev, host.data(), total, hipMemcpyHostToDevice);
+    e = hipMemcpy(b->dev, host.get(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) { v->last_error = hipGetErrorString(e); (void)hipFree(b->dev); b->dev = nullptr; return ZKGPU_EHIP; }
   }
+  if (timing && total) fprintf(stderr, "txblock: gather %.2f ms, randomness %.2f ms, allocation + copy %.2f ms (%zu bytes)\n",
+                               (tb1 - tb0) * 1e3, (tb2 - tb1) * 1e3, (now() - tb2) * 1e3, total);
   *out = b.release();
   return ZKGPU_OK;
+}
+
+}  // namespace
+
+int zkgpu_txblock_create(zkgpu_verifier* v, size_t batch, const uint32_t* n_in, const uint32_t* n_out,
+                         const uint8_t* commitments, const uint8_t* proofs, const uint64_t* proof_offsets,
+                         const uint8_t* r_bytes, zkgpu_txblock** out) {
+  if (!v || !out) return ZKGPU_EINVAL;
+  *out = nullptr;
+  if (batch && (!n_in || !n_out || !commitments || !proofs || !proof_offsets)) return ZKGPU_EINVAL;
+  if (batch >= (1ull << 31)) return ZKGPU_EINVAL;
+  for (size_t i = 0; i < batch; ++i) if (proof_offsets[i + 1] < proof_offsets[i]) return ZKGPU_EINVAL;
+  std::vector<TxSource> src(batch);
+  uint64_t com_off = 0;
+  for (size_t i = 0; i < batch; ++i) {
+    src[i] = TxSource{n_in[i], n_out[i], commitments + com_off, proofs + proof_offsets[i], proof_offsets[i + 1] - proof_offsets[i]};
+    com_off += 64ull * ((uint64_t)n_in[i] + n_out[i]);
+  }
+  return txblock_build(v, batch, src.data(), r_bytes, 0, out);
 }
 
 // Verifies every transaction of a resident block: the groups are cut into batches of at most `chunk`
 // transactions, which go round the verifier's lanes (one batch in flight on each); bit i of
 // accept_bitmap is the verdict of transaction i of the block.  Any device error: all bits zero.
-int zkgpu_verifier_verify_block(zkgpu_verifier* v, const zkgpu_txblock* b, uint8_t* accept_bitmap) {
-  if (!v || !b || b->v != v || !accept_bitmap) return ZKGPU_EINVAL;
-  const size_t nbytes = (b->batch + 7) / 8;
-  memset(accept_bitmap, 0, nbytes);
-  std::lock_guard<std::mutex> lk(v->mu);
-  (void)ticket_dispatch(v, true);                      // tickets in flight use the same lanes: finish them first
-  while (!v->busy.empty()) ticket_collect(v, v->busy.front());
+namespace {
+
+// the batches of one resident block going round the verifier's lanes (v->mu held by the caller from start to finish)
+struct BlockRun {
+  zkgpu_verifier* v;
+  const zkgpu_txblock* b;
+  uint8_t* accept_bitmap;
   struct InFlight { const zkgpu_txblock::Group* g; size_t off, n; };
-  std::vector<InFlight> on_lane(v->lanes.size(), InFlight{nullptr, 0, 0});
+  std::vector<InFlight> on_lane;
   std::vector<uint8_t> bm;
   int rc = ZKGPU_OK;
-  auto collect = [&](size_t lane) -> int {
+
+  BlockRun(zkgpu_verifier* v_, const zkgpu_txblock* b_, uint8_t* bits) : v(v_), b(b_), accept_bitmap(bits), on_lane(v_->lanes.size(), InFlight{nullptr, 0, 0}) {}
+
+  int collect(size_t lane) {
     InFlight& f = on_lane[lane];
     if (!f.g) return ZKGPU_OK;
     bm.assign((f.n + 7) / 8, 0);
@@ -298,28 +334,46 @@ int zkgpu_verifier_verify_block(zkgpu_verifier* v, const zkgpu_txblock* b, uint8
         if ((bm[j / 8] >> (j % 8)) & 1) { const uint32_t i = f.g->idx[f.off + j]; accept_bitmap[i / 8] |= (uint8_t)(1u << (i % 8)); }
     f.g = nullptr;
     return r;
-  };
-  size_t turn = 0;
-  for (const auto& g : b->groups) {
-    if (!g.plan || rc != ZKGPU_OK) continue;
-    const size_t wcom = 64 * ((size_t)g.n_in + g.n_out);
-    for (size_t off = 0; off < g.idx.size() && rc == ZKGPU_OK; off += v->chunk) {
-      const size_t n = std::min(v->chunk, g.idx.size() - off);
-      const size_t lane = turn++ % v->lanes.size();
-      rc = collect(lane);
-      if (rc != ZKGPU_OK) break;
-      rc = zkgpu_cloak_verify_submit_dev(v->lanes[lane], v->ps, g.plan, n, b->dev + g.com_off + off * wcom,
-                                         b->dev + g.proof_off + off * g.proof_len, g.proof_len, b->dev + g.r_off + off * 64);
-      if (rc == ZKGPU_OK) on_lane[lane] = InFlight{&g, off, n};
-      else v->last_error = zkgpu_last_error(v->lanes[lane]);
+  }
+  // queues every batch; a lane that is still busy with an earlier batch of the block is collected first
+  void start() {
+    (void)ticket_dispatch(v, true);                      // tickets in flight use the same lanes: finish them first
+    while (!v->busy.empty()) ticket_collect(v, v->busy.front());
+    size_t turn = 0;
+    for (const auto& g : b->groups) {
+      if (!g.plan || rc != ZKGPU_OK) continue;
+      const size_t wcom = 64 * ((size_t)g.n_in + g.n_out);
+      for (size_t off = 0; off < g.idx.size() && rc == ZKGPU_OK; off += v->chunk) {
+        const size_t n = std::min(v->chunk, g.idx.size() - off);
+        const size_t lane = turn++ % v->lanes.size();
+        rc = collect(lane);
+        if (rc != ZKGPU_OK) break;
+        rc = zkgpu_cloak_verify_submit_dev(v->lanes[lane], v->ps, g.plan, n, b->dev + g.com_off + off * wcom,
+                                           b->dev + g.proof_off + off * g.proof_len, g.proof_len, b->dev + g.r_off + off * 64);
+        if (rc == ZKGPU_OK) on_lane[lane] = InFlight{&g, off, n};
+        else v->last_error = zkgpu_last_error(v->lanes[lane]);
+      }
     }
   }
-  for (size_t lane = 0; lane < v->lanes.size(); ++lane) {
-    const int r = collect(lane);          // always drains: no lane is left pending after an error
-    if (r != ZKGPU_OK && rc == ZKGPU_OK) { rc = r; v->last_error = zkgpu_last_error(v->lanes[lane]); }
+  int finish() {
+    for (size_t lane = 0; lane < v->lanes.size(); ++lane) {
+      const int r = collect(lane);          // always drains: no lane is left pending after an error
+      if (r != ZKGPU_OK && rc == ZKGPU_OK) { rc = r; v->last_error = zkgpu_last_error(v->lanes[lane]); }
+    }
+    if (rc != ZKGPU_OK) memset(accept_bitmap, 0, (b->batch + 7) / 8);
+    return rc;
   }
-  if (rc != ZKGPU_OK) memset(accept_bitmap, 0, nbytes);
-  return rc;
+};
+
+}  // namespace
+
+int zkgpu_verifier_verify_block(zkgpu_verifier* v, const zkgpu_txblock* b, uint8_t* accept_bitmap) {
+  if (!v || !b || b->v != v || !accept_bitmap) return ZKGPU_EINVAL;
+  memset(accept_bitmap, 0, (b->batch + 7) / 8);
+  std::lock_guard<std::mutex> lk(v->mu);
+  BlockRun run(v, b, accept_bitmap);
+  run.start();
+  return run.finish();
 }
 
 // Host-memory form: block -> HBM -> verdicts (PCIe copies included).
@@ -697,6 +751,7 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
                           uint8_t* accept_bitmap, uint8_t* status) {
   using namespace zk::zkvm;
   if (!v || !accept_bitmap) return ZKGPU_EINVAL;
+  const double t00 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   memset(accept_bitmap, 0, (batch + 7) / 8);
   if (status) memset(status, TX_INVALID, batch);
   if (batch == 0) return ZKGPU_OK;
@@ -715,63 +770,75 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   }
   if (live.empty()) return ZKGPU_OK;
   zkgpu_ctx* c = v->root;
+  auto par = [&](size_t n, const std::function<void(size_t)>& f) { host_parallel(n, host_threads, f); };
+  const size_t nl = live.size();
   // 1. aggregated keys X = sum a_i X_i
-  std::vector<uint8_t> sc, pt, agg(32 * live.size()), okb((live.size() + 7) / 8);
-  std::vector<uint64_t> off(1, 0);
-  for (size_t i : live) {
-    sc.insert(sc.end(), st[i].sig_scalars.begin() + 64, st[i].sig_scalars.end());
-    pt.insert(pt.end(), st[i].sig_points.begin() + 64, st[i].sig_points.end());
-    off.push_back(sc.size() / 32);
-  }
-  TRY(zkgpu_msm_batch(c, sc.data(), pt.data(), off.data(), live.size(), agg.data(), okb.data()));
+  std::vector<uint64_t> off(nl + 1, 0);
+  for (size_t j = 0; j < nl; ++j) off[j + 1] = off[j] + st[live[j]].sig_scalars.size() / 32 - 2;
+  std::vector<uint8_t> sc(32 * off.back()), pt(32 * off.back()), agg(32 * nl), okb((nl + 7) / 8);
+  par(nl, [&](size_t j) {
+    const TxStatement& t = st[live[j]];
+    memcpy(sc.data() + 32 * off[j], t.sig_scalars.data() + 64, t.sig_scalars.size() - 64);
+    memcpy(pt.data() + 32 * off[j], t.sig_points.data() + 64, t.sig_points.size() - 64);
+  });
+  TRY(zkgpu_msm_batch(c, sc.data(), pt.data(), off.data(), nl, agg.data(), okb.data()));
   const double t2 = now();
   uint8_t B[32], Bb[32];
   TRY(zkgpu_pedersen_gens(c, B, Bb));
   // 2. the signature equations  s B - R - sum (c a_i) X_i == identity: B is generator 0 of the resident set (its term
   //    comes out of the fixed-base tables), R and the keys are the proof-specific points of the row
-  std::vector<size_t> signed_ok;
-  std::vector<uint8_t> ssc;
-  std::vector<uint32_t> sidx;
-  std::vector<uint64_t> soff(1, 0);
-  sc.clear(); pt.clear(); off.assign(1, 0);
-  for (size_t j = 0; j < live.size(); ++j) {
-    const size_t i = live[j];
-    if (!((okb[j / 8] >> (j % 8)) & 1)) { if (status) status[i] = TX_INVALID; continue; }   // a key that is no point
-    tx_finish_signature(st[i], B, &agg[32 * j]);
-    ssc.insert(ssc.end(), st[i].sig_scalars.begin(), st[i].sig_scalars.begin() + 32);
-    sidx.push_back(0);
-    soff.push_back(sidx.size());
-    sc.insert(sc.end(), st[i].sig_scalars.begin() + 32, st[i].sig_scalars.end());
-    pt.insert(pt.end(), st[i].sig_points.begin() + 32, st[i].sig_points.end());
-    off.push_back(sc.size() / 32);
-    signed_ok.push_back(i);
+  std::vector<size_t> keyed;                           // positions in `live` whose keys all decode
+  for (size_t j = 0; j < nl; ++j) {
+    if ((okb[j / 8] >> (j % 8)) & 1) keyed.push_back(j);
+    else if (status) status[live[j]] = TX_INVALID;
   }
-  std::vector<uint8_t> sig_bits((signed_ok.size() + 7) / 8 + 1, 0);
-  if (!signed_ok.empty())
-    TRY(zkgpu_verify_batch_ps(c, v->ps, signed_ok.size(), sc.data(), pt.data(), off.data(), ssc.data(), sidx.data(), soff.data(), sig_bits.data()));
+  const size_t ns = keyed.size();
+  off.assign(ns + 1, 0);
+  for (size_t q = 0; q < ns; ++q) off[q + 1] = off[q] + st[live[keyed[q]]].sig_scalars.size() / 32 - 1;
+  sc.resize(32 * off.back()); pt.resize(32 * off.back());
+  std::vector<uint8_t> ssc(32 * ns);
+  std::vector<uint32_t> sidx(ns, 0);
+  std::vector<uint64_t> soff(ns + 1);
+  for (size_t q = 0; q <= ns; ++q) soff[q] = q;
+  par(ns, [&](size_t q) {
+    TxStatement& t = st[live[keyed[q]]];
+    tx_finish_signature(t, B, &agg[32 * keyed[q]]);
+    memcpy(&ssc[32 * q], t.sig_scalars.data(), 32);
+    memcpy(sc.data() + 32 * off[q], t.sig_scalars.data() + 32, t.sig_scalars.size() - 32);
+    memcpy(pt.data() + 32 * off[q], t.sig_points.data() + 32, t.sig_points.size() - 32);
+  });
+  std::vector<uint8_t> sig_bits((ns + 7) / 8 + 1, 0);
+  if (ns) TRY(zkgpu_verify_batch_ps(c, v->ps, ns, sc.data(), pt.data(), off.data(), ssc.data(), sidx.data(), soff.data(), sig_bits.data()));
   const double t3 = now();
-  // 3. the cloak proofs of the transactions whose signature holds
+  // 3. the cloak proofs of the transactions whose signature holds, staged straight from the statements (no second copy).
+  //    (Queueing them on the lanes BEFORE the signature stages, to run underneath, was measured slower: the short kernels
+  //    of the signature stages then wait for CU slots behind the proofs' long ones.)
   std::vector<size_t> proved;
-  std::vector<uint32_t> n_in, n_out;
-  std::vector<uint8_t> com, proofs;
-  std::vector<uint64_t> po(1, 0);
-  for (size_t j = 0; j < signed_ok.size(); ++j) {
-    const size_t i = signed_ok[j];
-    if (!((sig_bits[j / 8] >> (j % 8)) & 1)) { if (status) status[i] = TX_INVALID; continue; }
-    proved.push_back(i);
-    n_in.push_back(st[i].n_in); n_out.push_back(st[i].n_out);
-    com.insert(com.end(), st[i].commitments.begin(), st[i].commitments.end());
-    proofs.insert(proofs.end(), st[i].proof, st[i].proof + st[i].proof_len);
-    po.push_back(proofs.size());
+  for (size_t q = 0; q < ns; ++q) {
+    const size_t i = live[keyed[q]];
+    if ((sig_bits[q / 8] >> (q % 8)) & 1) proved.push_back(i);
+    else if (status) status[i] = TX_INVALID;
   }
   if (proved.empty()) return ZKGPU_OK;
-  std::vector<uint8_t> bits((proved.size() + 7) / 8, 0);
-  TRY(zkgpu_verifier_verify(v, proved.size(), n_in.data(), n_out.data(), com.data(), proofs.data(), po.data(), nullptr, bits.data()));
-  if (timing) fprintf(stderr, "tx verify: VM + ids %.2f ms, aggregated keys %.2f ms, signature equations %.2f ms, cloak proofs %.2f ms (%zu transactions)\n",
-                      (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (now() - t3) * 1e3, batch);
-  for (size_t j = 0; j < proved.size(); ++j) {
-    const size_t i = proved[j];
-    const bool ok = (bits[j / 8] >> (j % 8)) & 1;
+  const size_t np = proved.size();
+  std::vector<TxSource> src(np);
+  for (size_t q = 0; q < np; ++q) {
+    const TxStatement& t = st[proved[q]];
+    src[q] = TxSource{t.n_in, t.n_out, t.commitments.data(), t.proof, t.proof_len};
+  }
+  std::vector<uint8_t> bits((np + 7) / 8, 0);
+  zkgpu_txblock* blk = nullptr;
+  TRY(txblock_build(v, np, src.data(), nullptr, host_threads, &blk));
+  const double t4 = now();
+  const int rc = zkgpu_verifier_verify_block(v, blk, bits.data());
+  zkgpu_txblock_destroy(blk);
+  if (rc != ZKGPU_OK) return rc;
+  if (timing) fprintf(stderr, "tx verify: VM + ids %.2f ms, aggregated keys %.2f ms, signature equations %.2f ms, cloak proofs %.2f ms (of which staging %.2f ms), "
+                              "%.2f ms in all (%zu transactions)\n",
+                      (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (now() - t3) * 1e3, (t4 - t3) * 1e3, (now() - t00) * 1e3, batch);
+  for (size_t q = 0; q < np; ++q) {
+    const size_t i = proved[q];
+    const bool ok = (bits[q / 8] >> (q % 8)) & 1;
     if (ok) accept_bitmap[i / 8] |= (uint8_t)(1u << (i % 8));
     if (status) status[i] = ok ? TX_OK : TX_INVALID;
   }

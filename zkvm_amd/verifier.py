@@ -16,6 +16,7 @@ device-resident generator set (and its fixed-base tables) instead of a Vec<Ristr
 from __future__ import annotations
 
 import ctypes as C
+import numpy as np
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -227,13 +228,16 @@ class BlockVerifier:
     def verify_txs(self, txs: Sequence[bytes], host_threads: int = 0):
         """zkgpu_tx_verify_batch: serialized ZkVM transactions (payment subset) -> (accept bitmap, status bytes:
         0 accepted, 1 rejected, 2 outside the subset)"""
-        batch = len(txs)
-        offs = [0]
-        for t in txs:
-            offs.append(offs[-1] + len(t))
+        return self.verify_txs_packed(b"".join(txs), [len(t) for t in txs], host_threads)
+
+    def verify_txs_packed(self, blob: bytes, lengths, host_threads: int = 0):
+        """the same over one buffer of concatenated transactions and their lengths"""
+        batch = len(lengths)
+        offs = np.zeros(batch + 1, dtype=np.uint64)
+        np.cumsum(np.asarray(lengths, dtype=np.uint64), out=offs[1:])
         bm = C.create_string_buffer(max((batch + 7) // 8, 1))
         st = C.create_string_buffer(max(batch, 1))
-        self._check(self.lib.zkgpu_tx_verify_batch(self.h, batch, b"".join(txs), (C.c_uint64 * (batch + 1))(*offs), host_threads, bm, st))
+        self._check(self.lib.zkgpu_tx_verify_batch(self.h, batch, blob, offs.ctypes.data_as(C.POINTER(C.c_uint64)), host_threads, bm, st))
         return bm.raw[: (batch + 7) // 8], st.raw[:batch]
 
     def verify_sharded(self, comm, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None) -> bytes:
