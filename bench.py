@@ -51,6 +51,7 @@ _JSON_OUT = os.fdopen(os.dup(1), "w")
 os.dup2(2, 1)
 
 import argparse
+import collections
 import hashlib
 import json
 import sys
@@ -343,9 +344,21 @@ def tx_verify_microbench(ctx, gens, host_threads: int):
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         assert bm == bitmap_of([1] * len(txs)) and not any(st), "a committed transaction was not accepted"
+        # the same transactions eight times over in one call (one buffer + lengths, as a node would hand a block over)
+        big = txs * 8
+        blob, lens = b"".join(big), [len(t) for t in big]
+        bv.verify_txs_packed(blob, lens, host_threads)
+        best8 = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            bm8, st8 = bv.verify_txs_packed(blob, lens, host_threads)
+            dt = time.perf_counter() - t0
+            best8 = dt if best8 is None else min(best8, dt)
+        assert bm8 == bitmap_of([1] * len(big)) and not any(st8), "a committed transaction was not accepted"
     finally:
         bv.close()
     return {"tx_per_s": round(len(txs) / best, 1), "batch": len(txs), "ms": round(best * 1e3, 3), "host_threads": host_threads,
+            "tx_per_s_8192_per_call": round(len(big) / best8, 1), "ms_8192_per_call": round(best8 * 1e3, 3),
             "tx_bytes": len(txs[0]),
             "note": "zkgpu_tx_verify_batch on 1024 serialized 2-in/2-out payment transactions (host memory in): VM and "
                     "transaction IDs on host threads; key aggregation, signature equations and cloak proofs on the device; "
@@ -791,29 +804,55 @@ def run_config4(args, W):
         comm = Comm(ctx, rank, world, uid)
     parts = [(cuts[i], cuts[i + 1]) for i in range(world)]
 
-    def step():
-        status, local = 0, b""
+    # a step = one whole block: its batches queued on the lanes (zkgpu_verifier_block_start), its verdicts waited for
+    # (zkgpu_verifier_block_finish) and exchanged.  --blocks-in-flight 2 queues block k+1 before block k is waited for,
+    # as a node verifying a stream of blocks could.  Measured (8192 mixed tx per block): no gain with the default 6
+    # lanes (1.96 vs 1.97 M tx/s: the second block waits for lanes), +5-7 % with 7 or 9 lanes, and with 8 or 10 lanes the
+    # run falls off the hardware-queue cliff of DESIGN.md sec 7 (0.72 / 0.20 M tx/s) -- so the default stays one block
+    # at a time.
+    depth = max(1, args.blocks_in_flight)
+
+    def start():
         try:
-            local = bv.verify_block(block)
+            return bv.block_start(block), 0
         except ZkGpuError as e:
-            status = e.code
+            return None, e.code
+
+    def finish(handle):
+        run, status = handle
+        local = b""
+        if run is not None:
+            try:
+                local = bv.block_finish(run, hi - lo)
+            except ZkGpuError as e:
+                status = e.code
         if comm is not None:
             return comm.allgather_bitmap(cuts, local, status)
         return gather_bitmaps(parts, local, status != 0, W.dist, None) if W.dist else local
 
-    whole = None
-    for _ in range(max(args.warmup, 1)):
-        whole = step()
-    W.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        whole = step()
-    W.barrier()
-    elapsed = W.max_over_ranks(time.perf_counter() - t0)
+    def steps(k):
+        inflight, out = collections.deque(), None
+        for _ in range(k):
+            inflight.append(start())
+            while len(inflight) >= depth:
+                out = finish(inflight.popleft())
+                assert out == want, "whole-batch accept bitmap differs from the constructed expectation (rank %d)" % rank
+        while inflight:
+            out = finish(inflight.popleft())
+            assert out == want, "whole-batch accept bitmap differs from the constructed expectation (rank %d)" % rank
+        return out
+
     # expectation by construction: the corruptions of mixed_block reject, everything else is a valid proof;
     # the -m gpu test compares the same construction bit by bit with the oracle
     expected = [0 if i % 61 == 3 else 1 for i in range(total)]
-    assert whole == bitmap_of(expected), "whole-batch accept bitmap differs from the constructed expectation (rank %d)" % rank
+    want = bitmap_of(expected)
+    whole = steps(max(args.warmup, 1))
+    W.barrier()
+    t0 = time.perf_counter()
+    whole = steps(args.steps)
+    W.barrier()
+    elapsed = W.max_over_ranks(time.perf_counter() - t0)
+    assert whole == want
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -850,7 +889,7 @@ def run_config4(args, W):
                                         "the C ABI, whole bitmap checked on every rank" % (total, per_gpu, world),
                             "tx_total": total, "tx_per_gpu": per_gpu, "per_shape": counts,
                             "shard_tx": [b - a for a, b in parts], "shard_terms": shard_terms,
-                            "generator_table_bits": args.table_bits, "gens_capacity": 512, "calls_in_flight": bv.lanes(),
+                            "generator_table_bits": args.table_bits, "gens_capacity": 512, "calls_in_flight": bv.lanes(), "blocks_in_flight": depth,
                             "chunk": args.chunk or 2048, "group_size": args.group,
                             "exchange": "gloo (ranks share one GPU)" if W.share_gpu else "ncclAllGather via zkgpu_comm_allgather_bitmap",
                             "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
@@ -894,6 +933,7 @@ def main():
                     help="device batches in flight per GPU (contexts): default 5 with --tickets, 6 without, 6 for config 4")
     ap.add_argument("--group", type=int, default=16, help="transactions per group check (1 = every transaction on its own)")
     ap.add_argument("--chunk", type=int, default=0, help="config 4: transactions per batch in flight (0 = library default)")
+    ap.add_argument("--blocks-in-flight", type=int, default=1, help="config 4: blocks whose batches are on the lanes at once (default 1: one block at a time)")
     ap.add_argument("--bad-every", type=int, default=64, help="config 2: one transaction in this many is corrupted (0 = none)")
     ap.add_argument("--tickets", type=int, default=-1,
                     help="config 2: batches kept in flight as tickets of a zkgpu_verifier, which merges them into device batches of --merge tx (0 = plain contexts)")
@@ -928,7 +968,7 @@ def main():
     if args.merge <= 0:
         args.merge = 8192
     if args.inflight <= 0:
-        args.inflight = 5 if args.tickets > 0 else 6
+        args.inflight = 5 if args.tickets > 0 else (10 if args.config == 4 and args.blocks_in_flight > 1 else 6)
     W = World(args)
     (run_config2 if args.config == 2 else run_config4)(args, W)
 

@@ -421,6 +421,14 @@ void zkgpu_txblock_destroy(zkgpu_txblock *block);
 size_t zkgpu_txblock_size(const zkgpu_txblock *block);
 size_t zkgpu_txblock_shapes(const zkgpu_txblock *block);
 int zkgpu_verifier_verify_block(zkgpu_verifier *v, const zkgpu_txblock *block, uint8_t *accept_bitmap);
+/* The same in two halves: zkgpu_verifier_block_start queues every batch of the block on the verifier's contexts and
+ * returns a run id at once; zkgpu_verifier_block_finish waits for that run and writes the block's accept bitmap.  A
+ * node that verifies a stream of blocks starts block k+1 before it finishes block k, so the chip does not drain between
+ * blocks (bench.py --config 4 keeps two in flight).  When every context is busy, starting waits for the oldest batch in
+ * flight first; its verdicts are kept with its run.  The block must stay alive until its run has been finished; runs are
+ * finished in any order; an unknown or already finished run id: ZKGPU_EINVAL. */
+int zkgpu_verifier_block_start(zkgpu_verifier *v, const zkgpu_txblock *block, uint64_t *run_id);
+int zkgpu_verifier_block_finish(zkgpu_verifier *v, uint64_t run_id, uint8_t *accept_bitmap);
 /* Tickets: many small batches in flight, few large device batches.  zkgpu_verifier_submit_dev QUEUES one uniform batch
  * (inputs resident in HBM, as zkgpu_cloak_verify_submit_dev) and returns a ticket at once; queued batches of one shape
  * are merged, up to `merge` transactions (zkgpu_verifier_set_merge, default 4096), copied side by side into the

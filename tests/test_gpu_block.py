@@ -63,6 +63,42 @@ def test_mixed_arity_shard_8192_vs_oracle(ctx, gens512, oracle):
         bv.close()
 
 
+def test_blocks_in_flight_equal_the_oracle(ctx, gens512, oracle):
+    """zkgpu_verifier_block_start / _finish: three different blocks started before any is finished, on a verifier with
+    fewer lanes than batches (starting has to wait for the oldest batch, whose verdicts must stay with its own run),
+    finished out of order; every accept bit equals the oracle's, a run id cannot be
+    finished twice."""
+    from zkvm_amd import ZkGpuError
+    from zkvm_amd.verifier import BlockVerifier
+    blocks = []
+    for k, n in enumerate((700, 900, 400)):
+        txs = mixed_block(n, seed=20 + k)
+        r = hashlib.shake_256(b"blocks in flight %d" % k).digest(64 * n)
+        want = oracle_block_bits(oracle, txs, r, threads=16)
+        assert 0 < sum(want) < n
+        blocks.append((txs, r, want))
+    for lanes, chunk in ((3, 64), (10, 0)):
+        bv = BlockVerifier(ctx, gens512, batches_in_flight=lanes, chunk=chunk)
+        try:
+            resident = [bv.block(_cloak(txs), r) for txs, r, _ in blocks]
+            for _ in range(2):
+                runs = [bv.block_start(b) for b in resident]
+                assert len(set(runs)) == 3
+                for k in (1, 0, 2):
+                    assert bits(bv.block_finish(runs[k], len(blocks[k][0])), len(blocks[k][0])) == blocks[k][2]
+                with pytest.raises(ZkGpuError):
+                    bv.block_finish(runs[1], len(blocks[1][0]))
+            # the same block twice in flight, and the plain call while a run is open
+            a, b = bv.block_start(resident[0]), bv.block_start(resident[0])
+            assert bits(bv.verify_block(resident[2]), len(blocks[2][0])) == blocks[2][2]
+            assert bits(bv.block_finish(b, len(blocks[0][0])), len(blocks[0][0])) == blocks[0][2]
+            assert bits(bv.block_finish(a, len(blocks[0][0])), len(blocks[0][0])) == blocks[0][2]
+            for blk in resident:
+                blk.close()
+        finally:
+            bv.close()
+
+
 def test_one_phase_wire_format_on_the_device(ctx, gens512, oracle):
     """Proofs in the one-phase wire format (version byte 0, A_I2 A_O2 S2 left out: what upstream writes for a statement
     without a second phase, here the 1x1 cloak) through every device path -- a uniform batch, and a block mixing both

@@ -9,7 +9,8 @@ rep = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 txs = load_tx_fixture() * rep
 ctx = Context(0)
 gens = BulletproofGens(ctx, 256, table_bits=16)
-bv = BlockVerifier(ctx, gens)
+chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bv = BlockVerifier(ctx, gens, chunk=chunk)
 bv.verify_txs(txs[:64])
 blob, lens = b"".join(txs), [len(t) for t in txs]
 for _ in range(4):

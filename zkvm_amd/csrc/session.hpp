@@ -43,6 +43,19 @@ struct zkgpu_verifier {
   std::map<std::pair<uint32_t, uint32_t>, zkgpu_cloak_plan*> plans;   // nullptr: the shape cannot be verified here
   std::map<std::pair<uint32_t, uint32_t>, uint64_t> costs;
   size_t chunk = 2048;                                // transactions per batch in flight
+  // ---- blocks in flight (zkgpu_verifier_block_start / _finish): which batch of which block a lane is running
+  struct BlockRun {
+    const struct zkgpu_txblock* b = nullptr;
+    std::vector<uint8_t> bits;                          // verdicts gathered so far, by position in the block
+    size_t pending = 0;                                 // batches of the block still on a lane
+    int rc = 0;
+    uint64_t id = 0;
+  };
+  struct LaneJob { BlockRun* run = nullptr; size_t group = 0, off = 0, n = 0; };
+  std::vector<LaneJob> lane_job;                        // per lane
+  std::deque<int> block_busy;                           // lanes running a block's batch, oldest first
+  std::map<uint64_t, std::unique_ptr<BlockRun>> block_runs;
+  uint64_t next_run = 1;
   std::mutex mu;
   std::string last_error;
 };
@@ -76,6 +89,7 @@ struct zkgpu_comm {
 namespace {
 void ticket_collect(zkgpu_verifier* v, int lane);
 int ticket_dispatch(zkgpu_verifier* v, bool force);
+void block_collect(zkgpu_verifier* v, int lane);
 
 // ---- RCCL, bound on first use -------------------------------------------------------------
 struct RcclApi {
@@ -167,6 +181,7 @@ int zkgpu_verifier_create(zkgpu_ctx* ctx, const zkgpu_pointset* ps, size_t gens_
     v->lanes.push_back(f);
   }
   v->running.resize(v->lanes.size());
+  v->lane_job.resize(v->lanes.size());
   *out = v;
   return ZKGPU_OK;
 }
@@ -312,58 +327,75 @@ int zkgpu_txblock_create(zkgpu_verifier* v, size_t batch, const uint32_t* n_in, 
 // accept_bitmap is the verdict of transaction i of the block.  Any device error: all bits zero.
 namespace {
 
-// the batches of one resident block going round the verifier's lanes (v->mu held by the caller from start to finish)
-struct BlockRun {
-  zkgpu_verifier* v;
-  const zkgpu_txblock* b;
-  uint8_t* accept_bitmap;
-  struct InFlight { const zkgpu_txblock::Group* g; size_t off, n; };
-  std::vector<InFlight> on_lane;
-  std::vector<uint8_t> bm;
-  int rc = ZKGPU_OK;
-
-  BlockRun(zkgpu_verifier* v_, const zkgpu_txblock* b_, uint8_t* bits) : v(v_), b(b_), accept_bitmap(bits), on_lane(v_->lanes.size(), InFlight{nullptr, 0, 0}) {}
-
-  int collect(size_t lane) {
-    InFlight& f = on_lane[lane];
-    if (!f.g) return ZKGPU_OK;
-    bm.assign((f.n + 7) / 8, 0);
-    const int r = zkgpu_verify_wait(v->lanes[lane], bm.data());
-    if (r == ZKGPU_OK)
-      for (size_t j = 0; j < f.n; ++j)
-        if ((bm[j / 8] >> (j % 8)) & 1) { const uint32_t i = f.g->idx[f.off + j]; accept_bitmap[i / 8] |= (uint8_t)(1u << (i % 8)); }
-    f.g = nullptr;
-    return r;
+// the verdicts of the block batch on `lane` into its run (v->mu held)
+void block_collect(zkgpu_verifier* v, int lane) {
+  zkgpu_verifier::LaneJob job = v->lane_job[(size_t)lane];
+  v->lane_job[(size_t)lane] = zkgpu_verifier::LaneJob{};
+  for (auto it = v->block_busy.begin(); it != v->block_busy.end(); ++it) if (*it == lane) { v->block_busy.erase(it); break; }
+  if (!job.run) return;
+  std::vector<uint8_t> bm((job.n + 7) / 8, 0);
+  const int r = zkgpu_verify_wait(v->lanes[(size_t)lane], bm.data());
+  if (r == ZKGPU_OK) {
+    const auto& idx = job.run->b->groups[job.group].idx;
+    for (size_t j = 0; j < job.n; ++j)
+      if ((bm[j / 8] >> (j % 8)) & 1) { const uint32_t i = idx[job.off + j]; job.run->bits[i / 8] |= (uint8_t)(1u << (i % 8)); }
+  } else if (job.run->rc == ZKGPU_OK) {
+    job.run->rc = r;
+    v->last_error = zkgpu_last_error(v->lanes[(size_t)lane]);
   }
-  // queues every batch; a lane that is still busy with an earlier batch of the block is collected first
-  void start() {
-    (void)ticket_dispatch(v, true);                      // tickets in flight use the same lanes: finish them first
-    while (!v->busy.empty()) ticket_collect(v, v->busy.front());
-    size_t turn = 0;
-    for (const auto& g : b->groups) {
-      if (!g.plan || rc != ZKGPU_OK) continue;
-      const size_t wcom = 64 * ((size_t)g.n_in + g.n_out);
-      for (size_t off = 0; off < g.idx.size() && rc == ZKGPU_OK; off += v->chunk) {
-        const size_t n = std::min(v->chunk, g.idx.size() - off);
-        const size_t lane = turn++ % v->lanes.size();
-        rc = collect(lane);
-        if (rc != ZKGPU_OK) break;
-        rc = zkgpu_cloak_verify_submit_dev(v->lanes[lane], v->ps, g.plan, n, b->dev + g.com_off + off * wcom,
-                                           b->dev + g.proof_off + off * g.proof_len, g.proof_len, b->dev + g.r_off + off * 64);
-        if (rc == ZKGPU_OK) on_lane[lane] = InFlight{&g, off, n};
-        else v->last_error = zkgpu_last_error(v->lanes[lane]);
-      }
+  --job.run->pending;
+}
+
+// a lane with nothing in flight; if there is none, the oldest batch of a block (else of the tickets) is waited for
+int free_lane(zkgpu_verifier* v) {
+  for (;;) {
+    for (size_t i = 0; i < v->lanes.size(); ++i) if (v->running[i].empty() && !v->lane_job[i].run) return (int)i;
+    if (!v->block_busy.empty()) block_collect(v, v->block_busy.front());
+    else ticket_collect(v, v->busy.front());
+  }
+}
+
+// queues every batch of the block (v->mu held)
+zkgpu_verifier::BlockRun* block_start(zkgpu_verifier* v, const zkgpu_txblock* b) {
+  (void)ticket_dispatch(v, true);                      // queued tickets go first
+  std::unique_ptr<zkgpu_verifier::BlockRun> owned(new zkgpu_verifier::BlockRun());
+  zkgpu_verifier::BlockRun* run = owned.get();
+  run->b = b;
+  run->bits.assign((b->batch + 7) / 8, 0);
+  for (size_t gi = 0; gi < b->groups.size() && run->rc == ZKGPU_OK; ++gi) {
+    const auto& g = b->groups[gi];
+    if (!g.plan) continue;
+    const size_t wcom = 64 * ((size_t)g.n_in + g.n_out);
+    for (size_t off = 0; off < g.idx.size(); off += v->chunk) {
+      const size_t n = std::min(v->chunk, g.idx.size() - off);
+      const int lane = free_lane(v);
+      const int rc = zkgpu_cloak_verify_submit_dev(v->lanes[(size_t)lane], v->ps, g.plan, n, b->dev + g.com_off + off * wcom,
+                                                   b->dev + g.proof_off + off * g.proof_len, g.proof_len, b->dev + g.r_off + off * 64);
+      if (rc != ZKGPU_OK) { run->rc = rc; v->last_error = zkgpu_last_error(v->lanes[(size_t)lane]); break; }
+      v->lane_job[(size_t)lane] = zkgpu_verifier::LaneJob{run, gi, off, n};
+      v->block_busy.push_back(lane);
+      ++run->pending;
     }
   }
-  int finish() {
-    for (size_t lane = 0; lane < v->lanes.size(); ++lane) {
-      const int r = collect(lane);          // always drains: no lane is left pending after an error
-      if (r != ZKGPU_OK && rc == ZKGPU_OK) { rc = r; v->last_error = zkgpu_last_error(v->lanes[lane]); }
-    }
-    if (rc != ZKGPU_OK) memset(accept_bitmap, 0, (b->batch + 7) / 8);
-    return rc;
+  run->id = v->next_run++;
+  v->block_runs[run->id] = std::move(owned);
+  return run;
+}
+
+// waits for the block's batches (always all of them: no lane is left pending after an error); v->mu held
+int block_finish(zkgpu_verifier* v, zkgpu_verifier::BlockRun* run, uint8_t* accept_bitmap) {
+  while (run->pending) {
+    int lane = -1;
+    for (int l : v->block_busy) if (v->lane_job[(size_t)l].run == run) { lane = l; break; }
+    if (lane < 0) { run->pending = 0; break; }          // (cannot happen: every pending batch is on a lane)
+    block_collect(v, lane);
   }
-};
+  const int rc = run->rc;
+  const size_t nbytes = (run->b->batch + 7) / 8;
+  if (rc == ZKGPU_OK) memcpy(accept_bitmap, run->bits.data(), nbytes); else memset(accept_bitmap, 0, nbytes);
+  v->block_runs.erase(run->id);
+  return rc;
+}
 
 }  // namespace
 
@@ -371,9 +403,25 @@ int zkgpu_verifier_verify_block(zkgpu_verifier* v, const zkgpu_txblock* b, uint8
   if (!v || !b || b->v != v || !accept_bitmap) return ZKGPU_EINVAL;
   memset(accept_bitmap, 0, (b->batch + 7) / 8);
   std::lock_guard<std::mutex> lk(v->mu);
-  BlockRun run(v, b, accept_bitmap);
-  run.start();
-  return run.finish();
+  return block_finish(v, block_start(v, b), accept_bitmap);
+}
+
+// The same in two halves, so that the next block's batches are on the lanes before the last one's verdicts are waited
+// for (a node verifying a stream of blocks).  The block must stay alive until its run has been finished; a run that is
+// never finished is drained when the verifier is destroyed.
+int zkgpu_verifier_block_start(zkgpu_verifier* v, const zkgpu_txblock* b, uint64_t* run_id) {
+  if (!v || !b || b->v != v || !run_id) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  *run_id = block_start(v, b)->id;
+  return ZKGPU_OK;
+}
+
+int zkgpu_verifier_block_finish(zkgpu_verifier* v, uint64_t run_id, uint8_t* accept_bitmap) {
+  if (!v || !accept_bitmap) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  auto it = v->block_runs.find(run_id);
+  if (it == v->block_runs.end()) return ZKGPU_EINVAL;
+  return block_finish(v, it->second.get(), accept_bitmap);
 }
 
 // Host-memory form: block -> HBM -> verdicts (PCIe copies included).
@@ -440,10 +488,10 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
     }
     if (total < v->merge_target && !force) return ZKGPU_OK;
     int lane = -1;
-    for (size_t i = 0; i < v->lanes.size(); ++i) if (v->running[i].empty()) { lane = (int)i; break; }
+    for (size_t i = 0; i < v->lanes.size(); ++i) if (v->running[i].empty() && !v->lane_job[i].run) { lane = (int)i; break; }
     if (lane < 0) {
       if (!force) return ZKGPU_OK;
-      ticket_collect(v, v->busy.front());
+      if (!v->busy.empty()) ticket_collect(v, v->busy.front()); else block_collect(v, v->block_busy.front());
       continue;
     }
     zkgpu_ctx* L = v->lanes[(size_t)lane];

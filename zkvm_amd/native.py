@@ -130,6 +130,8 @@ def load_library():
     lib.zkgpu_txblock_shapes.argtypes = [vp]
     lib.zkgpu_txblock_shapes.restype = sz
     lib.zkgpu_verifier_verify_block.argtypes = [vp, vp, u8p]
+    lib.zkgpu_verifier_block_start.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
+    lib.zkgpu_verifier_block_finish.argtypes = [vp, C.c_uint64, u8p]
     lib.zkgpu_cloak_msm_terms.argtypes = [C.c_uint32, C.c_uint32]
     lib.zkgpu_cloak_msm_terms.restype = C.c_uint64
     lib.zkgpu_shard_cuts.argtypes = [sz, u32p, u32p, C.c_int, u64p]

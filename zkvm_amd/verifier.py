@@ -225,6 +225,18 @@ class BlockVerifier:
         self._check(self.lib.zkgpu_verifier_verify_block(self.h, block.h, bm))
         return bm.raw[: (block.n + 7) // 8]
 
+    def block_start(self, block: TxBlock) -> int:
+        """zkgpu_verifier_block_start: the block's batches queued, a run id back at once"""
+        run = C.c_uint64()
+        self._check(self.lib.zkgpu_verifier_block_start(self.h, block.h, C.byref(run)))
+        return int(run.value)
+
+    def block_finish(self, run: int, n: int) -> bytes:
+        """zkgpu_verifier_block_finish: the accept bitmap of the run's block (n transactions)"""
+        bm = C.create_string_buffer(max((n + 7) // 8, 1))
+        self._check(self.lib.zkgpu_verifier_block_finish(self.h, run, bm))
+        return bm.raw[: (n + 7) // 8]
+
     def verify_txs(self, txs: Sequence[bytes], host_threads: int = 0):
         """zkgpu_tx_verify_batch: serialized ZkVM transactions (payment subset) -> (accept bitmap, status bytes:
         0 accepted, 1 rejected, 2 outside the subset)"""
