@@ -823,7 +823,7 @@ def run_config4(args, W):
         local = b""
         if run is not None:
             try:
-                local = bv.block_finish(run, hi - lo)
+                local = bv.block_finish(run)
             except ZkGpuError as e:
                 status = e.code
         if comm is not None:

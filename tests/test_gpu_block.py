@@ -85,14 +85,17 @@ def test_blocks_in_flight_equal_the_oracle(ctx, gens512, oracle):
                 runs = [bv.block_start(b) for b in resident]
                 assert len(set(runs)) == 3
                 for k in (1, 0, 2):
-                    assert bits(bv.block_finish(runs[k], len(blocks[k][0])), len(blocks[k][0])) == blocks[k][2]
+                    assert bits(bv.block_finish(runs[k]), len(blocks[k][0])) == blocks[k][2]
                 with pytest.raises(ZkGpuError):
-                    bv.block_finish(runs[1], len(blocks[1][0]))
+                    bv.block_finish(runs[1])
+                import ctypes
+                scratch = ctypes.create_string_buffer(1024)
+                assert bv.lib.zkgpu_verifier_block_finish(bv.h, runs[1], scratch) == -1       # ZKGPU_EINVAL, at the C ABI too
             # the same block twice in flight, and the plain call while a run is open
             a, b = bv.block_start(resident[0]), bv.block_start(resident[0])
             assert bits(bv.verify_block(resident[2]), len(blocks[2][0])) == blocks[2][2]
-            assert bits(bv.block_finish(b, len(blocks[0][0])), len(blocks[0][0])) == blocks[0][2]
-            assert bits(bv.block_finish(a, len(blocks[0][0])), len(blocks[0][0])) == blocks[0][2]
+            assert bits(bv.block_finish(b), len(blocks[0][0])) == blocks[0][2]
+            assert bits(bv.block_finish(a), len(blocks[0][0])) == blocks[0][2]
             for blk in resident:
                 blk.close()
         finally:

@@ -162,6 +162,7 @@ class BlockVerifier:
         self.h = C.c_void_p()
         ctx._check(self.lib.zkgpu_verifier_create(ctx.h, bp_gens.points.h, bp_gens.gens_capacity, batches_in_flight,
                                                   C.byref(self.h)))
+        self._runs = {}
         if chunk:
             self._check(self.lib.zkgpu_verifier_set_chunk(self.h, chunk))
 
@@ -229,10 +230,14 @@ class BlockVerifier:
         """zkgpu_verifier_block_start: the block's batches queued, a run id back at once"""
         run = C.c_uint64()
         self._check(self.lib.zkgpu_verifier_block_start(self.h, block.h, C.byref(run)))
+        self._runs[int(run.value)] = block.n
         return int(run.value)
 
-    def block_finish(self, run: int, n: int) -> bytes:
-        """zkgpu_verifier_block_finish: the accept bitmap of the run's block (n transactions)"""
+    def block_finish(self, run: int) -> bytes:
+        """zkgpu_verifier_block_finish: the accept bitmap of the run's block"""
+        n = self._runs.pop(run, None)
+        if n is None:
+            raise ZkGpuError(-1, "no such run in flight")
         bm = C.create_string_buffer(max((n + 7) // 8, 1))
         self._check(self.lib.zkgpu_verifier_block_finish(self.h, run, bm))
         return bm.raw[: (n + 7) // 8]
@@ -247,6 +252,8 @@ class BlockVerifier:
         batch = len(lengths)
         offs = np.zeros(batch + 1, dtype=np.uint64)
         np.cumsum(np.asarray(lengths, dtype=np.uint64), out=offs[1:])
+        if int(offs[-1]) != len(blob):
+            raise ValueError("the lengths add up to %d bytes, the buffer holds %d" % (int(offs[-1]), len(blob)))
         bm = C.create_string_buffer(max((batch + 7) // 8, 1))
         st = C.create_string_buffer(max(batch, 1))
         self._check(self.lib.zkgpu_tx_verify_batch(self.h, batch, blob, offs.ctypes.data_as(C.POINTER(C.c_uint64)), host_threads, bm, st))
