@@ -515,6 +515,10 @@ uint64_t zkgpu_last_bucket_adds(const zkgpu_ctx *ctx);
 int zkgpu_set_window_bits(zkgpu_ctx *ctx, int w);
 /* Override how many lanes share one (check, window) in the fixed-base kernel (0 = automatic). */
 int zkgpu_set_static_parts(zkgpu_ctx *ctx, int parts);
+/* Lanes per (failed group, window) of the locating multiplication of zkgpu_set_locate_mode (0 = the default, 32:
+ * it runs for the failed groups only, on the tail of a batch, so short chains matter more than few partial sums).
+ * Forks take the value their parent has when they are made.  Same verdicts whatever the value. */
+int zkgpu_set_locate_parts(zkgpu_ctx *ctx, int parts);
 
 #ifdef __cplusplus
 }

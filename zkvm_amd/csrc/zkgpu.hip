@@ -121,6 +121,7 @@ struct zkgpu_ctx {
   int locate_mode = 0;             // failed groups: 0 automatic, 1 always re-check every transaction, 2 always locate the culprit
   int transcript_mode = 0;         // 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction
   int forced_parts = 0;
+  int locate_parts = 0;            // lanes per (failed group, window) of the locating multiplication (0: 32)
   void* pinned = nullptr;   // host staging for results
   size_t pinned_cap = 0;
   void* pinned_in = nullptr;   // host staging for inputs handed over in host memory
@@ -766,11 +767,14 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   // short chains of additions per lane keep their latency down)
   int Pg = 1;
   const int Pf = 32;
+  // the locating multiplication runs for the failed groups only, on the tail of the batch: many short chains (its grid is
+  // sized for every group failing; lanes beyond the device-side count leave at once)
+  const int Pl = c->locate_parts > 0 ? c->locate_parts : 32;
   if (group > 1) {
     Pg = (int)std::max<uint64_t>(1, std::min<uint64_t>(32, (65536 + (uint64_t)grp_rows * W - 1) / ((uint64_t)grp_rows * W)));
     TRY(ensure(c, c->grp_sc, (size_t)grp_rows * ns * 32));
     TRY(ensure(c, c->grp_digits, (size_t)grp_rows * ns * W * 2));
-    TRY(ensure(c, c->grp_partials, (size_t)grp_rows * W * Pg * EXT_WORDS * 4));
+    TRY(ensure(c, c->grp_partials, (size_t)grp_rows * W * std::max(Pg, locate && !spec ? Pl : 0) * EXT_WORDS * 4));
     TRY(ensure(c, c->grp_ok, n_groups));
     TRY(ensure(c, c->row_map, B * 4));
     TRY(ensure(c, c->grp_fail, (size_t)n_groups * 12));
@@ -960,9 +964,9 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     // device-side counts leave at once (no failed group: four near-empty launches).
     if (locate && !spec) {
       Launch l(c, "k_static_accumulate", L);
-      hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)n_groups * W * Pg, 256)), dim3(256), 0, L,
+      hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)n_groups * W * Pl, 256)), dim3(256), 0, L,
                          (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
-                         (uint32_t)ps->n, ps->tbl_H, W, Pg, n_groups, (uint64_t)n_groups * ns,
+                         (uint32_t)ps->n, ps->tbl_H, W, Pl, n_groups, (uint64_t)n_groups * ns,
                          (uint32_t*)c->grp_partials.p, (const uint32_t*)nullptr, (const uint32_t*)n_fail);
     }
     if (!locate) {
@@ -973,7 +977,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     } else if (!spec) {
       Launch l(c, "k_locate_combine", L);       // names the culprit (or queues the whole group) and writes the digits of the queued
       hipLaunchKernelGGL(k_locate_combine, dim3(n_groups), dim3(256), 0, L, (const uint32_t*)c->grp_partials.p,
-                         (uint32_t)(W * Pg), (const uint32_t*)c->dynsum.p, (const uint32_t*)c->msm_fail.p, job.d_wellformed,
+                         (uint32_t)(W * Pl), (const uint32_t*)c->dynsum.p, (const uint32_t*)c->msm_fail.p, job.d_wellformed,
                          (uint32_t)B, group, (const uint32_t*)fail_list, (const uint32_t*)n_fail,
                          (const uint32_t*)c->grp_fail_sum.p, (uint32_t*)c->row_map.p, n_recheck, cand, job.d_st_scalars, ns,
                          (int16_t*)c->digits.p, ps->tbl_w, W);
@@ -1149,6 +1153,7 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
     c->group_size = parent->group_size;
     c->transcript_mode = parent->transcript_mode;
     c->locate_mode = parent->locate_mode;
+    c->locate_parts = parent->locate_parts;
     c->horner_mode = parent->horner_mode;
   } else {
     ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
@@ -1512,6 +1517,13 @@ int zkgpu_set_group_size(zkgpu_ctx* c, int group) {
 int zkgpu_set_static_parts(zkgpu_ctx* c, int parts) {
   if (!c || parts < 0 || parts > 64) return ZKGPU_EINVAL;
   c->forced_parts = parts;
+  return ZKGPU_OK;
+}
+
+int zkgpu_set_locate_parts(zkgpu_ctx* c, int parts) {
+  if (!c || parts < 0 || parts > 64) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->locate_parts = parts;
   return ZKGPU_OK;
 }
 
