@@ -389,7 +389,9 @@ int zkgpu_decode_check(zkgpu_ctx *ctx, const uint8_t *points, size_t n, uint8_t 
 
 /* ---- whole blocks of transactions of mixed shapes (BASELINE configs[3]) -----------------------
  * zkgpu_verifier mirrors the reference's `Verifier` for a block: it owns up to `batches_in_flight`
- * contexts (the given one and forks of it; 0 = default 6) and one device plan per statement shape,
+ * contexts (the given one and forks of it; 0 = default 6, at most 10.  More than 7 is not recommended: every
+ * context brings a stream of its own, and on MI355X runs with 8 and with 10 contexts were measured 3x and 10x slower
+ * than with 6, 7 or 9 -- the hardware-queue effect of DESIGN.md sec 7) and one device plan per statement shape,
  * created on first use.  zkgpu_verifier_verify takes the block as Tx::verify sees it -- per
  * transaction (n_in, n_out), its 64 (n_in + n_out) commitment bytes back to back, its R1CSProof bytes
  * (CSR) and 64 bytes of verifier randomness (NULL: getrandom(2)) -- groups the transactions by shape,
