@@ -115,3 +115,22 @@ def test_host_logic_and_oracle_under_asan_ubsan(tmp_path):
     p = subprocess.run([sys.executable, "-c", DRIVER, ROOT, host_so, os.path.join(OUT, "liboracle_asan.so")], env=env,
                        capture_output=True, text=True, timeout=500)
     assert p.returncode == 0 and "sanitized run ok" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+
+
+@pytest.mark.timeout(600)
+def test_host_worker_pool_under_tsan(tmp_path):
+    """host_pool.hpp under ThreadSanitizer: its selftest (hostlib.cpp, zkhost_pool_selftest: four callers at once, every size
+    and thread count) as a standalone program -- the race-detection tier for the one piece of the product that shares
+    state between host threads without going through a context's mutex."""
+    tsan = subprocess.run(["gcc", "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip()
+    if not (os.path.isabs(tsan) and os.path.exists(tsan)):
+        pytest.skip("gcc has no libtsan here")
+    main = tmp_path / "main.cpp"
+    main.write_text('extern "C" unsigned long long zkhost_pool_selftest(unsigned, unsigned);\n'
+                    'int main() { return zkhost_pool_selftest(2, 4) ? 1 : 0; }\n')
+    exe = tmp_path / "pool_tsan"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", str(main),
+                    os.path.join(ROOT, "zkvm_amd", "csrc", "hostlib.cpp"), "-o", str(exe)], check=True)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert p.returncode == 0 and "ThreadSanitizer" not in p.stderr, p.stderr[-4000:]

@@ -33,7 +33,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     subprocess.run(cmd, check=True)
     # host-only logic (scalars, Merlin, R1CS verifier preparation) for the CPU test tier
     cxx = os.environ.get("CXX", "g++")
-    subprocess.run([cxx, "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-o", HOST_OUT, HOST_SRC], check=True)
+    subprocess.run([cxx, "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-pthread", "-o", HOST_OUT, HOST_SRC], check=True)
     return OUT
 
 

@@ -690,3 +690,36 @@ extern "C" uint64_t zkhost_rng_coop_selftest(uint64_t seed, uint32_t n_draws) {
   }
   return bad;
 }
+
+// HostPool (host_pool.hpp, the workers behind every host stage of the product): every index of every call visited exactly
+// once for a range of sizes and thread counts, calls from `callers` threads at once (one gets the pool, the others are
+// told to use threads of their own), and repeated use of the sleeping workers.  Returns the number of violations.
+#include "host_pool.hpp"
+extern "C" uint64_t zkhost_pool_selftest(uint32_t rounds, uint32_t callers) {
+  std::atomic<uint64_t> bad{0}, took{0}, refused{0};
+  auto one = [&](uint32_t salt) {
+    static const size_t sizes[] = {0, 1, 2, 15, 16, 17, 255, 1000, 4097};
+    static const int threads[] = {2, 3, 8, 32, 100};
+    for (uint32_t r = 0; r < rounds; ++r)
+      for (size_t n : sizes)
+        for (int nt : threads) {
+          std::vector<std::atomic<uint32_t>> hits(n);
+          for (auto& h : hits) h.store(0);
+          const std::function<void(size_t)> f = [&](size_t i) { (void)salt; hits[i].fetch_add(1); };
+          if (zk::HostPool::get().run(n, std::min(nt, zk::HostPool::MAX_WORKERS + 1), f)) {
+            ++took;
+            for (auto& h : hits) if (h.load() != 1) ++bad;
+          } else {
+            ++refused;
+            for (auto& h : hits) if (h.load() != 0) ++bad;   // a refused call must not have touched anything
+          }
+        }
+  };
+  std::vector<std::thread> th;
+  for (uint32_t c = 1; c < callers; ++c) th.emplace_back(one, c);
+  one(0);
+  for (auto& t : th) t.join();
+  if (took.load() == 0) ++bad;
+  if (callers <= 1 && refused.load() != 0) ++bad;
+  return bad.load();
+}
