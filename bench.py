@@ -171,12 +171,14 @@ def pmc_tables():
     return out
 
 
-def roofline_object(solo, launches_per_step, in_flight_ms, alg_bytes_step, units_step, ms_per_step, table_bytes, note):
+def roofline_object(solo, launches_per_step, in_flight_ms, alg_bytes_step, units_step, ms_per_step, table_bytes, note, counters=True):
     """solo: kernel -> mean ms alone on the chip (HIP events, measured live after the timed region);
-    launches_per_step: kernel -> launches per step; dominant = largest summed solo time per step."""
+    launches_per_step: kernel -> launches per step; dominant = largest summed solo time per step.
+    counters=False: the committed PMC tables (collected on uniform 2-in/2-out launches) do not describe this workload:
+    the traffic / VALU fields are null."""
     per_step = {k: solo[k] * launches_per_step.get(k, 1.0) for k in solo}
     dom = max(per_step, key=per_step.get)
-    pmc = pmc_tables()
+    pmc = pmc_tables() if counters else {"pmc_traffic": None, "pmc_valu": None}
     traffic_tbl, valu_tbl = pmc["pmc_traffic"], pmc["pmc_valu"]
     # the dominant kernel processes every unit of the step in its launches
     alg_per_launch = alg_bytes_step / max(launches_per_step.get(dom, 1.0), 1e-9)
@@ -204,7 +206,7 @@ def roofline_object(solo, launches_per_step, in_flight_ms, alg_bytes_step, units
             "algorithmic_bytes_per_launch": int(alg_per_launch),
             "units_per_launch": round(units_step / max(launches_per_step.get(dom, 1.0), 1e-9), 1),
             "avg_launch_ms": round(solo[dom], 4), "launches_per_step": round(launches_per_step.get(dom, 1.0), 2),
-            "avg_launch_ms_in_flight": round(in_flight_ms.get(dom, float("nan")), 4),
+            "avg_launch_ms_in_flight": round(in_flight_ms[dom], 4) if dom in in_flight_ms else None,
             "dominant_by": "largest summed solo duration per step (HIP events around each kernel alone on the chip, same "
                            "process, after the timed region; `bench.py --solo` under rocprofv3 --stats gives the same averages)",
             "step": step,
@@ -898,7 +900,9 @@ def run_config4(args, W):
                             "parallelism": "tx-sharded x%d" % world})
         line["roofline"] = roofline_object(solo, launches, {}, alg_step, hi - lo, ms_per_step, table_bytes,
                                            "rank 0's shard: %d transactions, %d algorithmic bytes (64 B per proof-specific term + 32 B "
-                                           "per generator scalar, per shape)" % (hi - lo, alg_step))
+                                           "per generator scalar, per shape); the committed counter tables were collected on uniform "
+                                           "2-in/2-out launches and are not applied to mixed shapes (traffic / VALU fields null)"
+                                           % (hi - lo, alg_step), counters=False)
         line["setup"] = {"table_build_ms": round(table_s * 1e3, 1), "table_bytes": table_bytes,
                          "note": "one table set for every shape up to 4x4 (512 + 512 generators); not in `value`"}
         line["kernel_ms_solo"] = {k: round(x, 4) for k, x in sorted(solo.items())}
