@@ -854,7 +854,10 @@ k_gather_dyn_points(PrepShape sh, const uint32_t* __restrict__ com, const uint32
 // The same gather fused with the RFC 9496 DECODE and the per-point tables of the small-MSM path
 // (kernels.hpp, k_small_tables): one launch instead of three on the shared stream -- under load every
 // small kernel there waits for CU slots behind the long ones, and the waits add up along the chain.
-__global__ void __launch_bounds__(256)
+// (two wavefronts per SIMD: left to itself the compiler takes 315 registers -- ONE wavefront per SIMD, and the decoding is a
+// chain of 254 dependent squarings; capped at 256 registers (24 spilled) the kernel runs 0.53 -> 0.43 ms per 8192
+// transactions; three wavefronts (168 registers, 118 spilled): 0.44 ms)
+__global__ void __launch_bounds__(256, 2)
 k_points_tables(PrepShape sh, const uint32_t* __restrict__ com, const uint32_t* __restrict__ pw, uint32_t batch,
                 uint32_t* __restrict__ tbl /*[B n_dyn][8][40]*/, uint32_t* __restrict__ msm_fail,
                 unsigned long long* __restrict__ bad_index) {
