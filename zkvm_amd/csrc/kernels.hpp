@@ -1390,6 +1390,9 @@ __device__ inline void locate_group(const uint32_t* __restrict__ partials2, uint
 // blockDim = 256: wavefront 0 sums the points; a failed group's locating scalars are then spread over all four.
 // locate == 0 (small batches, where the extra stage costs more latency than it saves work): a failed group queues
 // all of its transactions for the individual re-check right here (cand = LOCATE_NONE).
+// kSpec: the instantiation that also knows how to locate (locate == 2); kept apart because the locating code triples the
+// kernel's registers (463 against ~150: one wavefront per SIMD, a whole CU per group) for a mode that is off by default
+template <bool kSpec>
 __global__ void __launch_bounds__(256)
 k_group_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ grp_dyn /*[n_groups][40], or null: sum dyn_sum over the group*/,
                 const uint32_t* __restrict__ dyn_sum, const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
@@ -1468,7 +1471,7 @@ k_group_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, cons
   if (f1 == 0) return;
   const uint32_t f = f1 - 1;
   if (!locate) { if (t == 0) cand[f] = LOCATE_NONE; return; }
-  if (locate == 2) {
+  if (kSpec && locate == 2) {
     // the locating sums of ALL groups were formed beside the group sums (rows n_groups + G of the same multiplication):
     // the culprit is named right here, two dependent launches earlier
     const uint32_t n_groups2 = (n_msm + group - 1) / group;

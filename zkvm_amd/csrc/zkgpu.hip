@@ -944,7 +944,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     uint32_t* grp_state = cand + n_groups;
     {
       Launch l(c, "k_group_combine", L);        // verdicts of the groups; a failed group also gets its locating scalars
-      hipLaunchKernelGGL(k_group_combine, dim3(n_groups), dim3(256), 0, L, (const uint32_t*)c->grp_partials.p,
+      hipLaunchKernelGGL(spec ? k_group_combine<true> : k_group_combine<false>, dim3(n_groups), dim3(256), 0, L, (const uint32_t*)c->grp_partials.p,
                          (uint32_t)(W * Pg), group_first ? (const uint32_t*)c->grp_dyn.p : (const uint32_t*)nullptr,
                          (const uint32_t*)c->dynsum.p, (const uint32_t*)c->msm_fail.p,
                          job.d_wellformed, (uint32_t)B, group, (uint8_t*)c->accept2.p, grp_state, fail_list,
