@@ -19,7 +19,10 @@ go = os.path.join(ROOT, "gpurun_out")
 
 
 def short(name):
-    return name.split("(")[0].replace("zk::", "")
+    n = name.split("(")[0].replace("zk::", "")
+    if n.startswith("void "):           # template instantiations are printed with their return type: void k_group_combine<false>
+        n = n[5:]
+    return n.split("<")[0]
 
 
 for kind in ("prof", "solo", "msm", "prover"):

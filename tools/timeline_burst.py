@@ -14,7 +14,7 @@ reps = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "10,10").split(",
 nctx = len(reps)
 rep = max(reps)
 ctx = Context(0)
-txs, expected = bench.workload_2x2(1024, 0)
+txs, expected = bench.workload_2x2(1024, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 gens = BulletproofGens(ctx, 256, table_bits=16)
 r = bench.shake(b"verifier-r|0", 64 * 1024)
 dev = torch.device("cuda", 0)
