@@ -182,6 +182,9 @@ def test_the_1024_fixture_transactions_on_the_device():
     bv = BlockVerifier(ctx, gens)
     try:
         bm, st = bv.verify_txs(txs)
+        with pytest.raises(ValueError):                        # lengths that do not add up to the buffer: refused before the C call
+            bv.verify_txs_packed(b"".join(txs), [len(t) for t in txs[:-1]])
+        assert bv.verify_txs_packed(b"".join(txs), [len(t) for t in txs]) == (bm, st)
         bad = set(range(5, 1024, 16))
         assert [i for i in range(1024) if not (bm[i // 8] >> (i % 8)) & 1] == sorted(bad)
         assert all((st[i] != 0) == (i in bad) for i in range(1024))
