@@ -427,7 +427,7 @@ def test_random_described_systems_device_prover_functions_equal_host_prover(host
 def test_host_worker_pool(host):
     """host_pool.hpp (the persistent workers behind the VM stage of zkgpu_tx_verify_batch and the prover's witness rows):
     every index exactly once for sizes 0 .. 4097 and 2 .. 100 requested threads, also with four callers at once (one
-    at a time gets the pool, a refused call has run nothing), and across repeated calls on the sleeping workers."""
+    at a time gets the pool, the others wait), and across repeated calls on the sleeping workers."""
     host.zkhost_pool_selftest.restype = C.c_uint64
     host.zkhost_pool_selftest.argtypes = [C.c_uint32, C.c_uint32]
     assert host.zkhost_pool_selftest(3, 1) == 0

@@ -4,7 +4,8 @@
 // device prover) are short -- a millisecond or two per call -- and creating and joining a dozen threads per call
 // costs a good part of that.  The workers are created on first use, sleep on a condition variable between calls and
 // are joined when the library is unloaded.  One call uses the pool at a time; a second caller arriving meanwhile (two
-// prover calls in flight on two contexts), or a process forked after the pool was made, runs with threads of its own.
+// prover calls in flight on two contexts) waits for its turn; a process forked after the pool was made runs with
+// threads of its own.
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -24,11 +25,11 @@ class HostPool {
   }
   static constexpr int MAX_WORKERS = 31;
 
-  // f(i) for i < n on the caller and up to nt - 1 workers; false when the pool cannot take the call
+  // f(i) for i < n on the caller and up to nt - 1 workers; false when the pool cannot take the call (forked process)
   bool run(size_t n, int nt, const std::function<void(size_t)>& f) {
     if (getpid() != owner_) return false;
-    std::unique_lock<std::mutex> busy(run_mu_, std::try_to_lock);
-    if (!busy.owns_lock()) return false;
+    std::unique_lock<std::mutex> busy(run_mu_);      // a second caller waits its turn: the stages are short, and a dozen
+                                                     // more threads beside a full pool would only take its cores away
     {
       std::lock_guard<std::mutex> lk(mu_);
       grow(nt - 1);
