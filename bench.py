@@ -523,6 +523,7 @@ def run_config2(args, W):
     ctx.set_transcript_mode(args.transcript_mode)
     ctx.set_locate_mode(args.locate_mode)
     ctx.set_locate_parts(args.locate_parts)
+    ctx.set_tail_mode(args.tail_mode)
     ctx.set_horner_mode(args.horner_mode)
     ctxs = [ctx] + [ctx.fork() for _ in range((min(max(1, args.inflight), 10) if args.tickets <= 0 else 6) - 1)]
     d_com = to_dev(b"".join(t[2] for t in txs))
@@ -798,6 +799,7 @@ def run_config4(args, W):
         bv.lane(i).set_transcript_mode(args.transcript_mode)
         bv.lane(i).set_locate_mode(args.locate_mode)
         bv.lane(i).set_locate_parts(args.locate_parts)
+        bv.lane(i).set_tail_mode(args.tail_mode)
         bv.lane(i).set_horner_mode(args.horner_mode)
     mine = [CloakTx(*t) for t in txs[lo:hi]]
     block = bv.block(mine, r_bytes[64 * lo: 64 * hi])          # this rank's shard, resident in HBM, grouped by shape
@@ -946,6 +948,7 @@ def main():
     ap.add_argument("--merge", type=int, default=0, help="config 2 with --tickets: transactions per merged device batch (0: chosen from --steps, see below)")
     ap.add_argument("--locate-mode", type=int, default=0, choices=(0, 1, 2, 3), help="zkgpu_set_locate_mode")
     ap.add_argument("--locate-parts", type=int, default=0, help="zkgpu_set_locate_parts (0 = the library's default)")
+    ap.add_argument("--tail-mode", type=int, default=0, choices=(0, 1), help="zkgpu_set_tail_mode")
     ap.add_argument("--horner-mode", type=int, default=0, choices=(0, 1, 2), help="zkgpu_set_horner_mode")
     ap.add_argument("--transcript-mode", type=int, default=0, choices=(0, 1, 2),
                     help="zkgpu_set_transcript_mode: 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction")

@@ -521,6 +521,11 @@ int zkgpu_set_static_parts(zkgpu_ctx *ctx, int parts);
  * it runs for the failed groups only, on the tail of a batch, so short chains matter more than few partial sums).
  * Forks take the value their parent has when they are made.  Same verdicts whatever the value. */
 int zkgpu_set_locate_parts(zkgpu_ctx *ctx, int parts);
+/* The sums on the tail of a batch checked in groups (the locating multiplication of the failed groups, the individual
+ * re-check of the queued transactions): 0 (default) each inside the kernel that consumes it, one workgroup per row
+ * (k_locate_fused, k_recheck_fused: two dependent launches fewer per batch); 1: launches of their own, many lanes per
+ * row (k_static_accumulate + k_locate_combine / k_static_combine).  Same verdicts either way; a measurement hook. */
+int zkgpu_set_tail_mode(zkgpu_ctx *ctx, int mode);
 
 #ifdef __cplusplus
 }

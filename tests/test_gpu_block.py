@@ -413,10 +413,15 @@ def test_failed_groups_are_located_and_every_pattern_of_bad_transactions_resolve
             for mode in (1, 2, 2, 3, 3):                        # re-check in full; locate (the default from 2048 per batch on); locating sums formed up front
                 ctx.set_locate_mode(mode)
                 assert bits(v.verify_packed_gpu(n_in, n_out, n, com_b, proof_b, plen, r), n) == want, (horner, mode)
+        ctx.set_tail_mode(1)                                    # the tail's sums as launches of their own
+        for mode in (1, 2, 3):
+            ctx.set_locate_mode(mode)
+            assert bits(v.verify_packed_gpu(n_in, n_out, n, com_b, proof_b, plen, r), n) == want, mode
         ctx.set_locate_mode(2)
         for parts in (1, 5, 64, 0):                             # lanes per (failed group, window) of the locating multiplication
             ctx.set_locate_parts(parts)
             assert bits(v.verify_packed_gpu(n_in, n_out, n, com_b, proof_b, plen, r), n) == want, parts
+        ctx.set_tail_mode(0)
         assert ctx.force_regroup(True) == before               # nothing above needed the ungrouped re-run
         assert bits(v.verify_packed_gpu(n_in, n_out, n, com_b, proof_b, plen, r), n) == want
         assert ctx.force_regroup(False) == before + 1          # ... and here it was taken
@@ -427,6 +432,7 @@ def test_failed_groups_are_located_and_every_pattern_of_bad_transactions_resolve
         ctx.set_group_size(16)
         ctx.set_locate_mode(0)
         ctx.set_locate_parts(0)
+        ctx.set_tail_mode(0)
         ctx.set_horner_mode(0)
         ctx.force_regroup(False)
         v.close()

@@ -1157,15 +1157,10 @@ k_static_accumulate(const int16_t* __restrict__ digits, const uint64_t* __restri
 // the ristretto identity test.  Lane sums are folded with wavefront shuffles.
 // With row_map / n_active (the per-transaction re-check of failed groups) block b handles
 // MSM row_map[b]; its partials sit at slot b.
-__global__ void __launch_bounds__(64)
-k_static_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
-                 const uint8_t* __restrict__ dyn_ok, const uint32_t* __restrict__ row_map,
-                 const uint32_t* __restrict__ n_active, uint8_t* __restrict__ accept,
-                 uint32_t* __restrict__ out_points /*optional: the sum of slot b, extended, for k_locate_finish*/) {
-  if (n_active && blockIdx.x >= *n_active) return;
-  const uint32_t slot = blockIdx.x;
-  const uint32_t tx = row_map ? row_map[slot] : slot;
-  const int lane = threadIdx.x;
+// (one wavefront; `lane` = its lane)
+__device__ inline void static_combine_slot(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
+                                           const uint8_t* __restrict__ dyn_ok, uint32_t slot, uint32_t tx, int lane,
+                                           uint8_t* __restrict__ accept, uint32_t* __restrict__ out_points) {
   ge acc;
   ge_identity(acc);
   for (uint32_t c = lane; c < n_partials; c += 64) {
@@ -1188,6 +1183,70 @@ k_static_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, con
     accept[tx] = (ge_is_identity(acc) && (!dyn_ok || dyn_ok[tx])) ? 1 : 0;
     if (out_points) store_ext(out_points + (uint64_t)slot * EXT_WORDS, acc);
   }
+}
+
+__global__ void __launch_bounds__(64)
+k_static_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
+                 const uint8_t* __restrict__ dyn_ok, const uint32_t* __restrict__ row_map,
+                 const uint32_t* __restrict__ n_active, uint8_t* __restrict__ accept,
+                 uint32_t* __restrict__ out_points /*optional: the sum of slot b, extended, for k_locate_finish*/) {
+  if (n_active && blockIdx.x >= *n_active) return;
+  const uint32_t slot = blockIdx.x;
+  static_combine_slot(partials, n_partials, dyn_sum, dyn_ok, slot, row_map ? row_map[slot] : slot, (int)threadIdx.x, accept, out_points);
+}
+
+// One thread's share of ONE row's fixed-base sum: the (window, term) pairs i = tid, tid + n_threads, .. of the W x ns
+// pairs of the row whose terms start at k0 -- the next table row is fetched while the current addition runs.  For the rows
+// that are summed on the tail of a batch by a single workgroup (k_locate_fused, k_recheck_fused), where a launch of its own
+// for the partial sums costs more than the sums.
+__device__ inline void static_row_share(ge& acc, const int16_t* __restrict__ digits, uint64_t n_static_total, uint64_t k0, uint32_t ns,
+                                        const uint32_t* __restrict__ st_index, const uint32_t* __restrict__ table, uint32_t n_set,
+                                        uint32_t H, int W, uint32_t tid, uint32_t n_threads) {
+  ge_identity(acc);
+  const uint32_t items = (uint32_t)W * ns;
+  auto fetch = [&](uint32_t i, ge_niels& q, bool& neg) {
+    const uint32_t t = i / ns, j = i - t * ns;
+    const uint64_t k = k0 + j;
+    int d = digits[(uint64_t)t * n_static_total + k];
+    d = (d == -32768) ? 32768 : d;
+    const uint32_t idx = st_index ? st_index[k] : j;
+    const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+    load_table_row(q, table + (((uint64_t)t * n_set + idx) * H + (mag ? mag - 1 : 0)) * TABLE_WORDS);
+    if (d == 0) niels_identity(q);
+    neg = d < 0;
+  };
+  uint32_t i = tid;
+  ge_niels cur, nxt;
+  bool cur_neg = false, nxt_neg = false;
+  if (i < items) fetch(i, cur, cur_neg);
+  while (i < items) {
+    const uint32_t in = i + n_threads;
+    if (in < items) fetch(in, nxt, nxt_neg);
+    ge_madd(acc, acc, cur, cur_neg);
+    cur = nxt; cur_neg = nxt_neg;
+    i = in;
+  }
+}
+
+// The individual re-check of the queued transactions in ONE launch: workgroup `slot` sums the generator terms of
+// transaction row_map[slot] (256 shares), then its first wavefront adds the proof-point sum and tests for the identity --
+// k_static_accumulate (row_map) + k_static_combine in one, for the tail of a batch.
+__global__ void __launch_bounds__(256)
+k_recheck_fused(const int16_t* __restrict__ digits, const uint64_t* __restrict__ st_offsets, const uint32_t* __restrict__ st_index,
+                const uint32_t* __restrict__ table, uint32_t n_set, uint32_t H, int W, uint64_t n_static_total,
+                uint32_t* __restrict__ partials /*[slots][256][40]*/, const uint32_t* __restrict__ dyn_sum,
+                const uint8_t* __restrict__ dyn_ok, const uint32_t* __restrict__ row_map, const uint32_t* __restrict__ n_active,
+                uint8_t* __restrict__ accept, uint32_t* __restrict__ out_points) {
+  const uint32_t slot = blockIdx.x;
+  if (slot >= *n_active) return;
+  const uint32_t tx = row_map[slot];
+  const uint64_t k0 = st_offsets[tx];
+  ge acc;
+  static_row_share(acc, digits, n_static_total, k0, (uint32_t)(st_offsets[tx + 1] - k0), st_index, table, n_set, H, W, threadIdx.x, 256u);
+  store_ext(partials + ((uint64_t)slot * 256 + threadIdx.x) * EXT_WORDS, acc);
+  __threadfence_block();
+  __syncthreads();
+  if (threadIdx.x < 64) static_combine_slot(partials, 256u, dyn_sum, dyn_ok, slot, tx, (int)threadIdx.x, accept, out_points);
 }
 
 // one wave per MSM over the resident set: sum of its W*P table partials -> canonical ristretto
@@ -1597,6 +1656,31 @@ k_locate_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, con
   const uint32_t f = blockIdx.x;
   if (f >= *n_fail) return;
   locate_group(partials + (uint64_t)f * n_partials * EXT_WORDS, n_partials, dyn_sum, msm_fail, wellformed, n_msm, group, fail_list[f], f,
+               fail_sum, row_map, n_recheck, cand, st_scalars, n_static, digits, w, W, &sh_queue);
+}
+
+// The locating multiplication and k_locate_combine in ONE launch: workgroup f sums the locating scalars' generator terms
+// itself (256 shares, digits at the group's place f in the failed list) and goes on to name the culprit.
+__global__ void __launch_bounds__(256)
+k_locate_fused(const int16_t* __restrict__ loc_digits, const uint64_t* __restrict__ st_offsets, const uint32_t* __restrict__ st_index,
+               const uint32_t* __restrict__ table, uint32_t n_set, uint32_t H, uint32_t n_groups,
+               uint32_t* __restrict__ partials /*[n_groups][256][40]*/, const uint32_t* __restrict__ dyn_sum,
+               const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
+               uint32_t group, const uint32_t* __restrict__ fail_list, const uint32_t* __restrict__ n_fail,
+               const uint32_t* __restrict__ fail_sum, uint32_t* __restrict__ row_map, uint32_t* __restrict__ n_recheck,
+               uint32_t* __restrict__ cand, const uint32_t* __restrict__ st_scalars, uint32_t n_static,
+               int16_t* __restrict__ digits, int w, int W) {
+  __shared__ unsigned long long sh_queue;
+  const uint32_t f = blockIdx.x;
+  if (f >= *n_fail) return;
+  {
+    ge acc;
+    static_row_share(acc, loc_digits, (uint64_t)n_groups * n_static, st_offsets[f], n_static, st_index, table, n_set, H, W, threadIdx.x, 256u);
+    store_ext(partials + ((uint64_t)f * 256 + threadIdx.x) * EXT_WORDS, acc);
+  }
+  __threadfence_block();
+  __syncthreads();
+  locate_group(partials + (uint64_t)f * 256 * EXT_WORDS, 256u, dyn_sum, msm_fail, wellformed, n_msm, group, fail_list[f], f,
                fail_sum, row_map, n_recheck, cand, st_scalars, n_static, digits, w, W, &sh_queue);
 }
 

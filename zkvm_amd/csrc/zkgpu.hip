@@ -122,6 +122,7 @@ struct zkgpu_ctx {
   int transcript_mode = 0;         // 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction
   int forced_parts = 0;
   int locate_parts = 0;            // lanes per (failed group, window) of the locating multiplication (0: 32)
+  int tail_mode = 0;               // 0: the tail's sums inside k_locate_fused / k_recheck_fused; 1: launches of their own
   void* pinned = nullptr;   // host staging for results
   size_t pinned_cap = 0;
   void* pinned_in = nullptr;   // host staging for inputs handed over in host memory
@@ -774,7 +775,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     Pg = (int)std::max<uint64_t>(1, std::min<uint64_t>(32, (65536 + (uint64_t)grp_rows * W - 1) / ((uint64_t)grp_rows * W)));
     TRY(ensure(c, c->grp_sc, (size_t)grp_rows * ns * 32));
     TRY(ensure(c, c->grp_digits, (size_t)grp_rows * ns * W * 2));
-    TRY(ensure(c, c->grp_partials, (size_t)grp_rows * W * std::max(Pg, locate && !spec ? Pl : 0) * EXT_WORDS * 4));
+    TRY(ensure(c, c->grp_partials, (size_t)grp_rows * std::max<size_t>((size_t)W * std::max(Pg, locate && !spec ? Pl : 0), 256) * EXT_WORDS * 4));
     TRY(ensure(c, c->grp_ok, n_groups));
     TRY(ensure(c, c->row_map, B * 4));
     TRY(ensure(c, c->grp_fail, (size_t)n_groups * 12));
@@ -790,7 +791,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   TRY(ensure_pinned(c, nbytes + 64));
   TRY(ensure(c, c->status, 64));
   TRY(ensure(c, c->digits, std::max<uint64_t>(job.n_static, 1) * W * 2));
-  TRY(ensure(c, c->st_partials, std::max<uint64_t>(n_lanes, group > 1 ? (uint64_t)B * W * Pf : 0) * EXT_WORDS * 4));
+  TRY(ensure(c, c->st_partials, std::max<uint64_t>(n_lanes, group > 1 ? (uint64_t)B * std::max(W * Pf, 256) : 0) * EXT_WORDS * 4));
   TRY(ensure(c, c->dynsum, B * EXT_WORDS * 4));
   TRY(ensure(c, c->dyn_rows, std::max<uint64_t>(job.n_dyn, 1) * NIELS_WORDS * 4));
   TRY(ensure(c, c->window_sums, (size_t)B * 64 * EXT_WORDS * 4));
@@ -962,7 +963,16 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     // failed groups (kernels.hpp, "group checks"): one more multiscalar multiplication each LOCATES the bad
     // transaction, which alone is then checked on its own.  Grids are sized for the worst case; lanes beyond the
     // device-side counts leave at once (no failed group: four near-empty launches).
-    if (locate && !spec) {
+    const bool fused_tail = c->tail_mode == 0;
+    if (locate && !spec && fused_tail) {
+      Launch l(c, "k_locate_fused", L);
+      hipLaunchKernelGGL(k_locate_fused, dim3(n_groups), dim3(256), 0, L, (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index,
+                         (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, n_groups, (uint32_t*)c->grp_partials.p,
+                         (const uint32_t*)c->dynsum.p, (const uint32_t*)c->msm_fail.p, job.d_wellformed, (uint32_t)B, group,
+                         (const uint32_t*)fail_list, (const uint32_t*)n_fail, (const uint32_t*)c->grp_fail_sum.p,
+                         (uint32_t*)c->row_map.p, n_recheck, cand, job.d_st_scalars, ns, (int16_t*)c->digits.p, ps->tbl_w, W);
+    }
+    if (locate && !spec && !fused_tail) {
       Launch l(c, "k_static_accumulate", L);
       hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)n_groups * W * Pl, 256)), dim3(256), 0, L,
                          (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
@@ -974,7 +984,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
       hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, L, job.d_st_scalars,
                          (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p,
                          (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, ns);
-    } else if (!spec) {
+    } else if (!spec && !fused_tail) {
       Launch l(c, "k_locate_combine", L);       // names the culprit (or queues the whole group) and writes the digits of the queued
       hipLaunchKernelGGL(k_locate_combine, dim3(n_groups), dim3(256), 0, L, (const uint32_t*)c->grp_partials.p,
                          (uint32_t)(W * Pl), (const uint32_t*)c->dynsum.p, (const uint32_t*)c->msm_fail.p, job.d_wellformed,
@@ -982,7 +992,14 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
                          (const uint32_t*)c->grp_fail_sum.p, (uint32_t*)c->row_map.p, n_recheck, cand, job.d_st_scalars, ns,
                          (int16_t*)c->digits.p, ps->tbl_w, W);
     }
-    {
+    if (fused_tail) {
+      Launch l(c, "k_recheck_fused", L);
+      hipLaunchKernelGGL(k_recheck_fused, dim3((unsigned)B), dim3(256), 0, L, (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index,
+                         (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, W, (uint64_t)job.n_static, (uint32_t*)c->st_partials.p,
+                         (const uint32_t*)c->dynsum.p, (const uint8_t*)c->accept.p, (const uint32_t*)c->row_map.p,
+                         (const uint32_t*)n_recheck, (uint8_t*)c->accept2.p, (uint32_t*)c->rechk_pts.p);
+    } else {
+      {
       Launch l(c, "k_static_accumulate", L);
       hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)B * W * Pf, 256)), dim3(256), 0, L,
                          (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
@@ -995,6 +1012,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
                          (uint32_t)(W * Pf), (const uint32_t*)c->dynsum.p, (const uint8_t*)c->accept.p,
                          (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, (uint8_t*)c->accept2.p,
                          (uint32_t*)c->rechk_pts.p);
+    }
     }
     {
       Launch l(c, "k_pack_bitmap_groups", L);   // with the verdict of the located groups' other transactions: S1 - E_b
@@ -1154,6 +1172,7 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
     c->transcript_mode = parent->transcript_mode;
     c->locate_mode = parent->locate_mode;
     c->locate_parts = parent->locate_parts;
+    c->tail_mode = parent->tail_mode;
     c->horner_mode = parent->horner_mode;
   } else {
     ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
@@ -1517,6 +1536,13 @@ int zkgpu_set_group_size(zkgpu_ctx* c, int group) {
 int zkgpu_set_static_parts(zkgpu_ctx* c, int parts) {
   if (!c || parts < 0 || parts > 64) return ZKGPU_EINVAL;
   c->forced_parts = parts;
+  return ZKGPU_OK;
+}
+
+int zkgpu_set_tail_mode(zkgpu_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 1) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->tail_mode = mode;
   return ZKGPU_OK;
 }
 

@@ -74,6 +74,7 @@ def load_library():
     lib.zkgpu_msm_ps_batch.argtypes = [vp, vp, sz, u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), u8p]
     lib.zkgpu_set_static_parts.argtypes = [vp, C.c_int]
     lib.zkgpu_set_locate_parts.argtypes = [vp, C.c_int]
+    lib.zkgpu_set_tail_mode.argtypes = [vp, C.c_int]
     lib.zkgpu_decode_check.argtypes = [vp, u8p, sz, u8p]
     lib.zkgpu_cloak_verify_batch.argtypes = [vp, vp, sz, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p, u8p,
                                              C.POINTER(C.c_uint64), u8p, u8p, C.c_int]
@@ -450,6 +451,9 @@ class Context:
 
     def set_locate_parts(self, parts: int) -> None:
         self._check(self.lib.zkgpu_set_locate_parts(self.h, parts))
+
+    def set_tail_mode(self, mode: int) -> None:
+        self._check(self.lib.zkgpu_set_tail_mode(self.h, mode))
 
     def set_window_bits(self, w: int) -> None:
         self._check(self.lib.zkgpu_set_window_bits(self.h, w))
