@@ -1231,10 +1231,10 @@ __device__ inline void static_row_share(ge& acc, const int16_t* __restrict__ dig
 // The individual re-check of the queued transactions in ONE launch: workgroup `slot` sums the generator terms of
 // transaction row_map[slot] (256 shares), then its first wavefront adds the proof-point sum and tests for the identity --
 // k_static_accumulate (row_map) + k_static_combine in one, for the tail of a batch.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_recheck_fused(const int16_t* __restrict__ digits, const uint64_t* __restrict__ st_offsets, const uint32_t* __restrict__ st_index,
                 const uint32_t* __restrict__ table, uint32_t n_set, uint32_t H, int W, uint64_t n_static_total,
-                uint32_t* __restrict__ partials /*[slots][256][40]*/, const uint32_t* __restrict__ dyn_sum,
+                uint32_t* __restrict__ partials /*[slots][blockDim][40]*/, const uint32_t* __restrict__ dyn_sum,
                 const uint8_t* __restrict__ dyn_ok, const uint32_t* __restrict__ row_map, const uint32_t* __restrict__ n_active,
                 uint8_t* __restrict__ accept, uint32_t* __restrict__ out_points) {
   const uint32_t slot = blockIdx.x;
@@ -1242,11 +1242,11 @@ k_recheck_fused(const int16_t* __restrict__ digits, const uint64_t* __restrict__
   const uint32_t tx = row_map[slot];
   const uint64_t k0 = st_offsets[tx];
   ge acc;
-  static_row_share(acc, digits, n_static_total, k0, (uint32_t)(st_offsets[tx + 1] - k0), st_index, table, n_set, H, W, threadIdx.x, 256u);
-  store_ext(partials + ((uint64_t)slot * 256 + threadIdx.x) * EXT_WORDS, acc);
+  static_row_share(acc, digits, n_static_total, k0, (uint32_t)(st_offsets[tx + 1] - k0), st_index, table, n_set, H, W, threadIdx.x, blockDim.x);
+  store_ext(partials + ((uint64_t)slot * blockDim.x + threadIdx.x) * EXT_WORDS, acc);
   __threadfence_block();
   __syncthreads();
-  if (threadIdx.x < 64) static_combine_slot(partials, 256u, dyn_sum, dyn_ok, slot, tx, (int)threadIdx.x, accept, out_points);
+  if (threadIdx.x < 64) static_combine_slot(partials, blockDim.x, dyn_sum, dyn_ok, slot, tx, (int)threadIdx.x, accept, out_points);
 }
 
 // one wave per MSM over the resident set: sum of its W*P table partials -> canonical ristretto
@@ -1661,10 +1661,10 @@ k_locate_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, con
 
 // The locating multiplication and k_locate_combine in ONE launch: workgroup f sums the locating scalars' generator terms
 // itself (256 shares, digits at the group's place f in the failed list) and goes on to name the culprit.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_locate_fused(const int16_t* __restrict__ loc_digits, const uint64_t* __restrict__ st_offsets, const uint32_t* __restrict__ st_index,
                const uint32_t* __restrict__ table, uint32_t n_set, uint32_t H, uint32_t n_groups,
-               uint32_t* __restrict__ partials /*[n_groups][256][40]*/, const uint32_t* __restrict__ dyn_sum,
+               uint32_t* __restrict__ partials /*[n_groups][blockDim][40]*/, const uint32_t* __restrict__ dyn_sum,
                const uint32_t* __restrict__ msm_fail, const uint32_t* __restrict__ wellformed, uint32_t n_msm,
                uint32_t group, const uint32_t* __restrict__ fail_list, const uint32_t* __restrict__ n_fail,
                const uint32_t* __restrict__ fail_sum, uint32_t* __restrict__ row_map, uint32_t* __restrict__ n_recheck,
@@ -1675,12 +1675,12 @@ k_locate_fused(const int16_t* __restrict__ loc_digits, const uint64_t* __restric
   if (f >= *n_fail) return;
   {
     ge acc;
-    static_row_share(acc, loc_digits, (uint64_t)n_groups * n_static, st_offsets[f], n_static, st_index, table, n_set, H, W, threadIdx.x, 256u);
-    store_ext(partials + ((uint64_t)f * 256 + threadIdx.x) * EXT_WORDS, acc);
+    static_row_share(acc, loc_digits, (uint64_t)n_groups * n_static, st_offsets[f], n_static, st_index, table, n_set, H, W, threadIdx.x, blockDim.x);
+    store_ext(partials + ((uint64_t)f * blockDim.x + threadIdx.x) * EXT_WORDS, acc);
   }
   __threadfence_block();
   __syncthreads();
-  locate_group(partials + (uint64_t)f * 256 * EXT_WORDS, 256u, dyn_sum, msm_fail, wellformed, n_msm, group, fail_list[f], f,
+  locate_group(partials + (uint64_t)f * blockDim.x * EXT_WORDS, blockDim.x, dyn_sum, msm_fail, wellformed, n_msm, group, fail_list[f], f,
                fail_sum, row_map, n_recheck, cand, st_scalars, n_static, digits, w, W, &sh_queue);
 }
 

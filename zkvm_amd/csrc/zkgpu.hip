@@ -251,6 +251,7 @@ inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + pe
 // sets of shared chip-filling streams per parent context (consecutive forks alternate between them) and the
 // fork limit that keeps the process under the ~22 hardware queues the runtime hands out before it
 // multiplexes them in software (measured: 100-200 ms per step beyond that)
+constexpr int TAIL_THREADS = 512;   // threads per row in k_locate_fused / k_recheck_fused (shares of the row's generator sum)
 constexpr int STREAM_SETS = 2;
 constexpr int MAX_FORKS = 9;
 constexpr size_t LOCATE_MIN_BATCH = 2048;      // transactions per batch from which failed groups are located instead of re-checked in full
@@ -775,7 +776,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     Pg = (int)std::max<uint64_t>(1, std::min<uint64_t>(32, (65536 + (uint64_t)grp_rows * W - 1) / ((uint64_t)grp_rows * W)));
     TRY(ensure(c, c->grp_sc, (size_t)grp_rows * ns * 32));
     TRY(ensure(c, c->grp_digits, (size_t)grp_rows * ns * W * 2));
-    TRY(ensure(c, c->grp_partials, (size_t)grp_rows * std::max<size_t>((size_t)W * std::max(Pg, locate && !spec ? Pl : 0), 256) * EXT_WORDS * 4));
+    TRY(ensure(c, c->grp_partials, (size_t)grp_rows * std::max<size_t>((size_t)W * std::max(Pg, locate && !spec ? Pl : 0), TAIL_THREADS) * EXT_WORDS * 4));
     TRY(ensure(c, c->grp_ok, n_groups));
     TRY(ensure(c, c->row_map, B * 4));
     TRY(ensure(c, c->grp_fail, (size_t)n_groups * 12));
@@ -791,7 +792,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   TRY(ensure_pinned(c, nbytes + 64));
   TRY(ensure(c, c->status, 64));
   TRY(ensure(c, c->digits, std::max<uint64_t>(job.n_static, 1) * W * 2));
-  TRY(ensure(c, c->st_partials, std::max<uint64_t>(n_lanes, group > 1 ? (uint64_t)B * std::max(W * Pf, 256) : 0) * EXT_WORDS * 4));
+  TRY(ensure(c, c->st_partials, std::max<uint64_t>(n_lanes, group > 1 ? (uint64_t)B * std::max(W * Pf, TAIL_THREADS) : 0) * EXT_WORDS * 4));
   TRY(ensure(c, c->dynsum, B * EXT_WORDS * 4));
   TRY(ensure(c, c->dyn_rows, std::max<uint64_t>(job.n_dyn, 1) * NIELS_WORDS * 4));
   TRY(ensure(c, c->window_sums, (size_t)B * 64 * EXT_WORDS * 4));
@@ -966,7 +967,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     const bool fused_tail = c->tail_mode == 0;
     if (locate && !spec && fused_tail) {
       Launch l(c, "k_locate_fused", L);
-      hipLaunchKernelGGL(k_locate_fused, dim3(n_groups), dim3(256), 0, L, (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index,
+      hipLaunchKernelGGL(k_locate_fused, dim3(n_groups), dim3(TAIL_THREADS), 0, L, (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index,
                          (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, n_groups, (uint32_t*)c->grp_partials.p,
                          (const uint32_t*)c->dynsum.p, (const uint32_t*)c->msm_fail.p, job.d_wellformed, (uint32_t)B, group,
                          (const uint32_t*)fail_list, (const uint32_t*)n_fail, (const uint32_t*)c->grp_fail_sum.p,
@@ -994,7 +995,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     }
     if (fused_tail) {
       Launch l(c, "k_recheck_fused", L);
-      hipLaunchKernelGGL(k_recheck_fused, dim3((unsigned)B), dim3(256), 0, L, (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index,
+      hipLaunchKernelGGL(k_recheck_fused, dim3((unsigned)B), dim3(TAIL_THREADS), 0, L, (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index,
                          (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, W, (uint64_t)job.n_static, (uint32_t*)c->st_partials.p,
                          (const uint32_t*)c->dynsum.p, (const uint8_t*)c->accept.p, (const uint32_t*)c->row_map.p,
                          (const uint32_t*)n_recheck, (uint8_t*)c->accept2.p, (uint32_t*)c->rechk_pts.p);
