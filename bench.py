@@ -69,6 +69,7 @@ MAD_PEAK_GOPS = 33864.9                      # measured v_mad_u64_u32 rate, prof
 VALU_PEAK_GINST = 1024 * 2.4 / 4 * 64        # 1024 SIMDs x 2.4 GHz / 4 cycles per wave instruction x 64 lanes
 BAD_POINT = bytes.fromhex("01" + "00" * 31)
 SHAPE_TERMS = {}                             # (n_in, n_out) -> (n_dyn, n_static), filled from the library
+DEFAULT_MERGE = 10240                        # transactions per merged device batch (config 2), whatever --steps
 
 
 def emit(record) -> None:
@@ -126,27 +127,10 @@ def algorithmic_bytes(lib, shapes) -> int:
 
 
 # ---- workloads ---------------------------------------------------------------------------------
-def workload_2x2(batch: int, rank: int, bad_every: int = 64):
-    """configs[1]: the committed distinct proofs, ~1.5 % corrupted -> (txs, expected bits)"""
-    from gpu_util import load_cloak_fixture
-    fixture, n_in, n_out, _ = load_cloak_fixture("cloak_2x2_1024.bin")
-    txs, expected = [], []
-    for i in range(batch):
-        com, proof = fixture[(i + 37 * rank) % len(fixture)]
-        ok = 1
-        if bad_every and i % bad_every == 7 % bad_every:
-            ok = 0
-            c = (i // bad_every) % 3
-            if c == 0:      # commitment that is not a ristretto255 encoding
-                com = com[:96] + BAD_POINT + com[128:]
-            elif c == 1:    # IPA scalar a off by one (still canonical)
-                a = (int.from_bytes(proof[-64:-32], "little") + 1) % L
-                proof = proof[:-64] + a.to_bytes(32, "little") + proof[-32:]
-            else:           # a valid proof of a different statement
-                proof = fixture[(i + 37 * rank + 1) % len(fixture)][1]
-        txs.append((n_in, n_out, com, proof))
-        expected.append(ok)
-    return txs, expected
+def workload_2x2(batch: int, rank: int, bad_every: int = 64, step: int = 0):
+    """configs[1], one step: tests/gpu_util.py benched_step (shared with the -m gpu test of this very arrangement)"""
+    from gpu_util import benched_step
+    return benched_step(batch, rank, bad_every, step)
 
 
 def profile_lanes(ctxs):
@@ -273,18 +257,36 @@ def msm_microbench(ctx, torch, dev):
     assert r == r0
     prof = ctx.profile_read()
     kern = {k: round(v[1] / v[0], 4) for k, v in prof.items() if v[0]}
-    acc_ms = kern.get("k_bucket_accumulate", 0.0)
     n_win = 255 // ctx.last_window_bits() + 1
     out = {"terms": n, "pairs_per_s": round(n / dt, 1), "ms": round(dt * 1e3, 3), "window_bits": ctx.last_window_bits(),
-           "result": r.hex(), "equals_committed_expected_value": True, "kernel_ms": kern}
-    if acc_ms:
-        madds = n * n_win                      # one mixed addition per term and window (bucket accumulation)
-        out["roofline"] = {"bound": "hbm", "kernel": "k_bucket_accumulate", "algorithmic_bytes_per_launch": 64 * n,
-                           "achieved": round(64 * n / (acc_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(64 * n / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "avg_launch_ms": acc_ms,
-                           "whole_call_GBps": round(64 * n / dt / 1e9, 2),
-                           "valu_int": {"achieved_Gmad_s": round(madds * 700 / (acc_ms * 1e-3) / 1e9, 1), "peak_Gmad_s": MAD_PEAK_GOPS,
-                                        "frac": round(madds * 700 / (acc_ms * 1e-3) / 1e9 / MAD_PEAK_GOPS, 4)}}
+           "result": r.hex(), "equals_committed_expected_value": True, "kernel_ms": kern,
+           "kernel_ms_sum": round(sum(kern.values()), 4),
+           "streams": "decompression on a stream of its own beside the digit sort (explicit fork / join events); the call's "
+                      "time against kernel_ms_sum shows whether the two overlapped on this box"}
+    if kern:
+        dom = max(kern, key=kern.get)                  # the dominant kernel BY MEASURED DURATION (HIP events, this run)
+        dom_ms = kern[dom]
+        madds = n * n_win                              # one mixed addition per term and window (bucket accumulation)
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "algorithmic_bytes_per_launch": 64 * n,
+                           "achieved": round(64 * n / (dom_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(64 * n / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "avg_launch_ms": dom_ms,
+                           "whole_call_GBps": round(64 * n / dt / 1e9, 2), "whole_call_frac": round(64 * n / dt / 1e9 / HBM_PEAK_GBS, 6)}
+        acc_ms = kern.get("k_bucket_accumulate", 0.0)
+        if acc_ms:
+            out["roofline"]["bucket_accumulate_valu_int"] = {"achieved_Gmad_s": round(madds * 700 / (acc_ms * 1e-3) / 1e9, 1), "peak_Gmad_s": MAD_PEAK_GOPS,
+                                                             "frac": round(madds * 700 / (acc_ms * 1e-3) / 1e9 / MAD_PEAK_GOPS, 4)}
+        valu_tbl = pmc_tables()["pmc_valu"]
+        if valu_tbl:
+            # wave instructions of the whole call from the committed --pmc pass of tools/msm_bench.py (same pipeline, same size)
+            launches = {k: v[0] / iters for k, v in prof.items() if v[0]}
+            alias = {"k_decompress": ("k_decompress_pre", "k_pow22523", "k_decompress_post", "k_decompress_fused"),
+                     "k_scan": ("k_scan_reduce", "k_scan_blocksums", "k_scan_apply"), "k_bin_order": ("k_bin_classes", "k_class_scan", "k_bin_order")}
+            tot = 0
+            for k in kern:
+                for name in alias.get(k, (k,)):
+                    tot += valu_tbl.get(name, 0) * (launches.get(k, 1.0) if name == k else 1.0)
+            out["valu_wave_instructions"] = int(tot)
+            out["valu_issue_frac"] = round(tot * 64 / dt / 1e9 / VALU_PEAK_GINST, 4)
     return out
 
 
@@ -337,6 +339,7 @@ def tx_verify_microbench(ctx, gens, host_threads: int):
     from zkvm_amd.verifier import BlockVerifier
     txs = load_tx_fixture()
     bv = BlockVerifier(ctx, gens)
+    bv.set_tx_format(bv.TXFORMAT_RECOLLECTED_V1)               # opt-in: the format is an unpinned recollection
     try:
         bm, st = bv.verify_txs(txs[:64], host_threads)
         best = None
@@ -475,6 +478,24 @@ class World:
         self.dist.broadcast(t, src=0)
         return bytes(t.cpu().numpy().tobytes())
 
+    def describe_ranks(self):
+        """per rank: the device it runs on, and the collective library's version -- so that a multi-GPU record says by
+        itself what it ran on (collective: every rank calls this)"""
+        torch = self.torch
+        p = torch.cuda.get_device_properties(self.local)
+        mine = {"rank": self.rank, "device": self.local, "name": p.name, "gcn_arch": getattr(p, "gcnArchName", ""),
+                "pci_bus_id": "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0)),
+                "hbm_GiB": round(p.total_memory / 2**30, 1), "pid": os.getpid()}
+        try:
+            mine["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:                                  # noqa: BLE001
+            mine["rccl_version"] = "unknown (%s)" % type(e).__name__
+        if not self.dist:
+            return [mine]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, mine)
+        return out
+
     def close(self):
         if self.dist:
             self.dist.barrier()
@@ -489,144 +510,189 @@ def common_line(args, W, value, elapsed, data, config):
 
 
 # ---- config 2: the headline --------------------------------------------------------------------
+class StepSet:
+    """One step's batch resident in HBM: commitments, proofs, verifier randomness (torch tensors) and the accept bitmap
+    the construction implies."""
+    __slots__ = ("com", "proofs", "r", "want", "bits", "txs", "r_bytes")
+
+
+def make_exchange(W, ctx, cuts, always_comm=False):
+    """The one exchange step of the sharded path -- rank r's accept bitmap of [cuts[r], cuts[r+1]) in, the bitmap of the
+    whole batch out on every rank -- through the C ABI (zkgpu_comm_allgather_bitmap: ncclAllGather over xGMI) in both
+    configs; gloo only when several ranks share one GPU (ZKGPU_BENCH_SHARE_GPU, the 1-GPU rehearsal: RCCL refuses two
+    ranks on one device).  -> (exchange(local_bitmap, status) -> whole bitmap, close())"""
+    if W.world == 1 and not always_comm:
+        def alone(local, status=0):
+            if status:
+                raise RuntimeError("verification failed with status %d" % status)
+            return local
+        return alone, (lambda: None), "none (one rank)"
+    parts = [(cuts[i], cuts[i + 1]) for i in range(W.world)]
+    if W.share_gpu:
+        from zkvm_amd.sharded import gather_bitmaps
+        return (lambda local, status=0: gather_bitmaps(parts, local, status != 0, W.dist, None)), (lambda: None), "gloo (ranks share one GPU)"
+    from zkvm_amd.native import Comm
+    uid = W.broadcast_bytes(Comm.unique_id() if W.rank == 0 else b"", 128)
+    comm = Comm(ctx, W.rank, W.world, uid)
+    return (lambda local, status=0: comm.allgather_bitmap(cuts, local, status)), comm.close, "ncclAllGather via zkgpu_comm_allgather_bitmap"
+
+
 def run_config2(args, W):
     torch, dev, rank, world = W.torch, W.dev, W.rank, W.world
+    from gpu_util import benched_randomness
     from zkvm_amd import Context
-    from zkvm_amd.verifier import BulletproofGens, CloakTx, Verifier
+    from zkvm_amd.verifier import BlockVerifier, BulletproofGens, CloakTx, Verifier
     ctx = Context(W.local)
     lib = ctx.lib
     batch = args.batch
     host_threads = max(1, usable_cores(os.cpu_count() or 1) // max(1, world))
-    txs, expected = workload_2x2(batch, rank, args.bad_every)
-    n_in, n_out = txs[0][0], txs[0][1]
-    n_dyn, n_static = shape_terms(lib, n_in, n_out)
     t0 = time.perf_counter()
     gens = BulletproofGens(ctx, 256, table_bits=args.table_bits)
     table_s = time.perf_counter() - t0
     table_bytes = int(lib.zkgpu_pointset_table_bytes(gens.points.h))
-    r_bytes = shake(b"verifier-r|%d" % rank, 64 * batch)
-    ctxs_txs = [CloakTx(*t) for t in txs]
-    proof_len = len(txs[0][3])
 
     def to_dev(b, dtype=torch.uint8):
         return torch.frombuffer(bytearray(b), dtype=dtype).to(dev)
 
+    # Every step is a batch of its own (workload_2x2): distinct proofs order, distinct corruptions, distinct verifier
+    # randomness.  The ring is as long as the longest run of this process, so no batch is ever submitted twice while
+    # anything that met it could still sit in a cache: 1.35 MB per step in HBM.
+    steady_steps = 0 if (args.lean or args.solo or args.no_steady or world > 1) else 200
+    n_sets = max(args.steps + max(args.warmup, 1), steady_steps, 2 * args.merge // batch + 2, 24)
+    sets = []
+    for sidx in range(n_sets):
+        txs, expected = workload_2x2(batch, rank, args.bad_every, sidx)
+        r_bytes = benched_randomness(rank, sidx, batch)
+        S = StepSet()
+        S.com, S.proofs, S.r = to_dev(b"".join(t[2] for t in txs)), to_dev(b"".join(t[3] for t in txs)), to_dev(r_bytes)
+        S.bits, S.want = expected, bitmap_of(expected)
+        S.txs, S.r_bytes = (txs, r_bytes) if sidx == 0 else (None, None)
+        sets.append(S)
+    txs, r_bytes = sets[0].txs, sets[0].r_bytes
+    n_in, n_out = txs[0][0], txs[0][1]
+    n_dyn, n_static = shape_terms(lib, n_in, n_out)
+    ctxs_txs = [CloakTx(*t) for t in txs]
+    proof_len = len(txs[0][3])
     nbytes = (batch + 7) // 8
-    d_bm = torch.zeros(nbytes, dtype=torch.uint8, device=W.coll_dev)
-    d_all = torch.zeros(nbytes * world, dtype=torch.uint8, device=W.coll_dev) if world > 1 else None
+    cuts = [batch * i for i in range(world + 1)]
+    exchange, close_exchange, exchange_name = make_exchange(W, ctx, cuts)
 
-    # `--inflight M`: M batches in flight.  Each has its own forked context (workspace + a light stream for its
+    # `--inflight M`: M device batches in flight.  Each has its own forked context (workspace + a light stream for its
     # latency-bound kernels); the chip-filling kernels of all of them go first-in first-out through the parent's
-    # shared streams (zkgpu_ctx_fork).  One host thread submits step i + M only after collecting step i.  Every step
-    # is one complete, independent verification of the whole batch; K steps are timed as a whole.
+    # shared streams (zkgpu_ctx_fork).  Every step is one complete, independent verification of a whole batch.
     ctx.set_group_size(args.group)               # forks inherit it
     ctx.set_transcript_mode(args.transcript_mode)
     ctx.set_locate_mode(args.locate_mode)
     ctx.set_locate_parts(args.locate_parts)
     ctx.set_tail_mode(args.tail_mode)
     ctx.set_horner_mode(args.horner_mode)
-    ctxs = [ctx] + [ctx.fork() for _ in range((min(max(1, args.inflight), 10) if args.tickets <= 0 else 6) - 1)]
-    d_com = to_dev(b"".join(t[2] for t in txs))
-    d_proofs = to_dev(b"".join(t[3] for t in txs))
-    d_r = to_dev(r_bytes)
+    ctxs = [ctx] + [ctx.fork() for _ in range((min(max(1, args.inflight), 10) if args.tickets <= 0 else 5) - 1)]
     gv = Verifier(ctx, gens)
     torch.cuda.synchronize()
+    host_time = {"submit": 0.0, "n": 0}
+    whole_last = [None]
 
-    def submit_verify(c):
-        gv.submit_packed_gpu_dev(n_in, n_out, batch, d_com, d_proofs, proof_len, d_r, ctx=c)
-
-    def collect(c, gather=True):
-        bm = c.verify_wait()
-        if world > 1 and gather:
-            d_bm.copy_(torch.frombuffer(bytearray(bm), dtype=torch.uint8))
-            W.dist.all_gather_into_tensor(d_all, d_bm)    # RCCL over xGMI: the per-shard accept bitmaps
+    def checked(bm, j, gather=True):
+        assert bm == sets[j].want, "accept bitmap of step set %d differs from the constructed expectation" % j
+        if gather and world > 1:
+            whole_last[0] = exchange(bm, 0)
+            assert whole_last[0][rank * nbytes:(rank + 1) * nbytes] == bm
         return bm
 
-    host_time = {"submit": 0.0, "n": 0}
-
-    def run_steps(n, submit=None, gather=True, lanes=None):
-        # gather=False: the rank-0-only extra legs (no collective: the other ranks are not in them)
-        submit = submit or submit_verify
+    def run_steps(n, base=0, submit=None, gather=True, lanes=None):
+        # plain contexts (no tickets): step base + i on lane i mod depth; gather=False: the rank-0-only extra legs
         lanes = lanes or ctxs
         depth = len(lanes)
+        pend = collections.deque()
         bm = None
         for i in range(n):
             c = lanes[i % depth]
-            if i >= depth:
-                bm = collect(c, gather)
+            if len(pend) >= depth:
+                cc, j = pend.popleft()
+                bm = checked(cc.verify_wait(), j, gather)
+            j = (base + i) % n_sets
             ts = time.perf_counter()
-            submit(c)
+            if submit is not None:
+                submit(c, j)
+            else:
+                gv.submit_packed_gpu_dev(n_in, n_out, batch, sets[j].com, sets[j].proofs, proof_len, sets[j].r, ctx=c)
             host_time["submit"] += time.perf_counter() - ts
             host_time["n"] += 1
-        for i in range(max(n - depth, 0), n):
-            bm = collect(lanes[i % depth], gather)
+            pend.append((c, j))
+        while pend:
+            cc, j = pend.popleft()
+            bm = checked(cc.verify_wait(), j, gather)
         return bm
 
     bv = None
     if args.tickets > 0:
-        from zkvm_amd.verifier import BlockVerifier
         bv = BlockVerifier(ctx, gens, batches_in_flight=args.inflight)
         bv.set_merge(args.merge)
         for i in range(bv.lanes()):
             bv.lane(i).set_group_size(args.group)
 
-    def run_tickets(n):
-        # `--tickets D`: D batches in flight as tickets; the verifier merges them into device batches of --merge transactions
-        depth = args.tickets
-        q, bm = [], None
-        first = min(n, depth)                                 # the batches that arrive together: one call queues them all
+    def run_tickets(n, base=0, depth=None, gather=True):
+        # `--tickets D`: up to D batches in flight as tickets; the verifier merges them into device batches of --merge
+        # transactions.  The batches that arrive together are queued by ONE call.
+        depth = depth or args.tickets
+        q, bm = collections.deque(), None
+        first = min(n, depth)
+        idx = [(base + i) % n_sets for i in range(first)]
         ts = time.perf_counter()
-        q.extend(bv.submit_many_dev(n_in, n_out, batch, [d_com] * first, [d_proofs] * first, proof_len, [d_r] * first))
+        tk = bv.submit_many_dev(n_in, n_out, batch, [sets[j].com for j in idx], [sets[j].proofs for j in idx], proof_len,
+                                [sets[j].r for j in idx])
         host_time["submit"] += time.perf_counter() - ts
         host_time["n"] += first
+        q.extend(zip(tk, idx))
         for i in range(first, n):
             if len(q) >= depth:
-                bm = bv.wait(q.pop(0))
-                if world > 1:
-                    d_bm.copy_(torch.frombuffer(bytearray(bm), dtype=torch.uint8))
-                    W.dist.all_gather_into_tensor(d_all, d_bm)
-                assert bm == want_bm
+                t, j = q.popleft()
+                bm = checked(bv.wait(t), j, gather)
+            j = (base + i) % n_sets
             ts = time.perf_counter()
-            q.append(bv.submit_dev(n_in, n_out, batch, d_com, d_proofs, proof_len, d_r))
+            q.append((bv.submit_dev(n_in, n_out, batch, sets[j].com, sets[j].proofs, proof_len, sets[j].r), j))
             host_time["submit"] += time.perf_counter() - ts
             host_time["n"] += 1
-        while q:
-            bm = bv.wait(q.pop(0))
-            if world > 1:                                     # every step's bitmap is exchanged, the drained ones too
-                d_bm.copy_(torch.frombuffer(bytearray(bm), dtype=torch.uint8))
-                W.dist.all_gather_into_tensor(d_all, d_bm)
-            assert bm == want_bm
+        while q:                                              # every step's bitmap is checked and exchanged, the drained ones too
+            t, j = q.popleft()
+            bm = checked(bv.wait(t), j, gather)
         return bm
 
-    want_bm = bitmap_of(expected)
+    # what the device executes are merged batches of --merge transactions: the per-kernel figures (solo pass, PMC passes)
+    # are taken on such a batch, made of `rep` DISTINCT steps side by side, exactly what the verifier's merge produces
+    rep = max(1, args.merge // batch) if bv is not None else 1
+    dev_batch = rep * batch
 
-    dev_batch = batch
-    d_com_s, d_proofs_s, d_r_s, want_solo = d_com, d_proofs, d_r, want_bm
-    if bv is not None and args.merge > batch:
-        # the device executes merged batches of --merge transactions: that is what the per-kernel figures describe
-        rep = max(1, args.merge // batch)
-        dev_batch = rep * batch
-        d_com_s, d_proofs_s, d_r_s = d_com.repeat(rep), d_proofs.repeat(rep), d_r.repeat(rep)
-        want_solo = bitmap_of(expected * rep)
+    def merged_inputs(first_set):
+        js = [(first_set + q) % n_sets for q in range(rep)]
+        if rep == 1:
+            S = sets[js[0]]
+            return S.com, S.proofs, S.r, S.want
+        return (torch.cat([sets[j].com for j in js]), torch.cat([sets[j].proofs for j in js]), torch.cat([sets[j].r for j in js]),
+                bitmap_of([b for j in js for b in sets[j].bits]))
 
     def solo_pass(reps=5):
         ctx.profile_reset()
         ctx.set_serial(True)
         ctx.profile(True)
-        for _ in range(reps):
-            gv.submit_packed_gpu_dev(n_in, n_out, dev_batch, d_com_s, d_proofs_s, proof_len, d_r_s, ctx=ctx)
-            assert ctx.verify_wait() == want_solo
+        for k in range(reps):
+            d_c, d_p, d_r, want = merged_inputs(k * rep)      # a different device batch every repetition
+            gv.submit_packed_gpu_dev(n_in, n_out, dev_batch, d_c, d_p, proof_len, d_r, ctx=ctx)
+            assert ctx.verify_wait() == want
         ctx.profile(False)
         ctx.set_serial(False)
         prof = ctx.profile_read()
         return {k: v[1] / v[0] for k, v in prof.items() if v[0]}, {k: v[0] / reps for k, v in prof.items() if v[0]}
 
-    if args.solo:      # what tools/profile_bench.sh runs under rocprofv3 --stats: every kernel alone on the chip
+    if args.solo:      # what tools/profile_bench.sh runs under rocprofv3 --stats / --pmc: every kernel alone on the chip
         solo_pass(2)
         solo, launches = solo_pass(max(args.steps, 5))
         if rank == 0:
-            emit({"solo_kernel_ms": {k: round(v, 4) for k, v in sorted(solo.items())}, "launches_per_step": launches, "batch": dev_batch})
+            emit({"solo_kernel_ms": {k: round(v, 4) for k, v in sorted(solo.items())}, "launches_per_step": launches, "batch": dev_batch,
+                  "inputs": "%d distinct steps per device batch, a different device batch every repetition" % rep})
         gv.close()
+        if bv is not None:
+            bv.close()
         for c in ctxs[1:]:
             c.close()
         gens.close()
@@ -634,8 +700,9 @@ def run_config2(args, W):
         return
 
     timed = run_tickets if bv is not None else run_steps
-    bm = timed(max(args.warmup, len(ctxs), args.tickets))
-    # HIP events around every launch of ONE of the contexts in flight (every len(ctxs)-th step)
+    n_warm = max(args.warmup, 1)
+    timed(n_warm, base=args.steps)                            # warm-up on sets the timed steps do not use
+    # HIP events around every launch of the contexts in flight
     prof_ctxs = [bv.lane(i) for i in range(bv.lanes())] if bv is not None else ctxs[:1]
     for c in prof_ctxs:
         c.profile_reset()
@@ -643,17 +710,14 @@ def run_config2(args, W):
     W.barrier()
     t0 = time.perf_counter()
     host_time.update(submit=0.0, n=0)
-    bm = timed(args.steps)
+    bm = timed(args.steps, base=0)
     W.barrier()
     elapsed = time.perf_counter() - t0
     submit_ms = host_time["submit"] / max(host_time["n"], 1) * 1e3
     for c in prof_ctxs:
         c.profile(False)
     elapsed = W.max_over_ranks(elapsed)
-    if world > 1:
-        gathered = bytes(d_all.cpu().numpy().tobytes())
-        assert gathered[rank * nbytes:(rank + 1) * nbytes] == bm
-    assert bm == bitmap_of(expected), "accept bitmap differs from the constructed expectation"
+    ranks_info = W.describe_ranks()
 
     if rank == 0:
         prof = profile_lanes(prof_ctxs)
@@ -665,15 +729,18 @@ def run_config2(args, W):
         ms_per_dev_batch = ms_per_step * (dev_batch // batch)
         line = common_line(args, W, batch * world * args.steps / elapsed, elapsed,
                            "synthetic: 1024 distinct real R1CS proofs of the 2-in/2-out cloak statement (committed fixture, oracle "
-                           "prover), each verified under per-transaction verifier randomness; ~1.5% corrupted",
+                           "prover); every step is a batch of its own -- the fixture rotated, its own ~1.5% corruptions, its own "
+                           "64 bytes of verifier randomness per transaction (SHAKE256 of rank and step): no two batches in flight, "
+                           "and no two merged into one device batch, share scalars or table rows",
                            {"workload": "BASELINE configs[1]: batch of %d 2-in/2-out cloak tx per GPU, complete r1cs::Verifier::verify "
                                         "on the device from commitments + R1CSProof bytes + verifier randomness resident in HBM: "
                                         "Merlin replay, verification scalars (IPA s vector, constraint flattening), decompression, "
                                         "the %d-term mega_check MSM (n=256, k=8, m=8; %d terms on shared generators), identity "
                                         "test -> accept bitmap" % (batch, n_dyn + n_static, n_static),
                             "tx_per_gpu": batch, "terms_per_tx": n_dyn + n_static, "generator_table_bits": args.table_bits,
-                            "calls_in_flight": args.tickets if bv is not None else len(ctxs), "group_size": args.group,
-                            "merged_device_batches": ({"transactions": args.merge, "in_flight": bv.lanes()} if bv is not None else None),
+                            "calls_in_flight": min(args.tickets, args.steps) if bv is not None else len(ctxs), "group_size": args.group,
+                            "merged_device_batches": ({"transactions": args.merge, "lanes": bv.lanes()} if bv is not None else None),
+                            "distinct_step_inputs": n_sets, "exchange": exchange_name, "ranks": ranks_info,
                             "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "hw_queues_set_by": "caller" if _HWQ_PRESET else "bench.py, before the HIP runtime started",
                             "parallelism": "tx-sharded x%d, RCCL all-gather of accept bitmaps" % world})
         line["roofline"] = roofline_object(solo, launches, in_flight_ms, alg_dev, dev_batch, ms_per_dev_batch, table_bytes,
@@ -685,7 +752,37 @@ def run_config2(args, W):
         line["kernel_ms_in_flight"] = {k: round(x, 4) for k, x in sorted(in_flight_ms.items())}
         line["kernel_ms_solo"] = {k: round(x, 4) for k, x in sorted(solo.items())}
         line["host_submit_ms_per_step"] = round(submit_ms, 4)
+        if bv is not None and not args.lean:
+            # ONE batch of 1024 with nothing else in flight (configs[1] read literally): submit, wait, repeat
+            lat = []
+            for k in range(12):
+                j = (args.steps + k) % n_sets
+                t1 = time.perf_counter()
+                t = bv.submit_dev(n_in, n_out, batch, sets[j].com, sets[j].proofs, proof_len, sets[j].r)
+                got = bv.wait(t)
+                lat.append(time.perf_counter() - t1)
+                assert got == sets[j].want
+            lat.sort()
+            line["latency_one_batch_ms"] = round(lat[len(lat) // 2] * 1e3, 4)
+            line["latency_one_batch"] = {"ms_median": round(lat[len(lat) // 2] * 1e3, 4), "ms_min": round(lat[0] * 1e3, 4),
+                                         "tx_per_s": round(batch / lat[len(lat) // 2], 1),
+                                         "note": "one %d-transaction batch, nothing else in flight: zkgpu_verifier_submit_dev + "
+                                                 "zkgpu_verifier_wait, 12 distinct batches" % batch}
+        if bv is not None and steady_steps:
+            # the same arrangement under sustained load: 200 steps, up to 64 tickets in flight (never `value` unless the
+            # run itself is that long)
+            run_tickets(24, base=0, depth=64, gather=False)
+            t1 = time.perf_counter()
+            run_tickets(steady_steps, base=0, depth=64, gather=False)
+            dt = time.perf_counter() - t1
+            line["steady_state"] = {"tx_per_s": round(batch * steady_steps / dt, 1), "ms_per_step": round(dt / steady_steps * 1e3, 4),
+                                    "steps": steady_steps, "tickets_in_flight": 64,
+                                    "note": "same verifier, same merge target, 200 distinct steps with up to 64 tickets in flight"}
         if not args.lean:
+            line["hbm_copy"] = hbm_copy_leg(ctx)
+            line["cpu2"] = ("omitted: BASELINE.md's second CPU line (libsodium naive sum of crypto_scalarmult_ristretto255) needs "
+                            "libsodium on the GPU box; it exists only in the build container (/opt/conda/lib), where the golden vectors "
+                            "were made, and nothing outside /root/repo travels")
             ps = gens.points
             # the multiscalar-multiplication boundary alone: scalars prepared beforehand by the product's host verifier
             hv = Verifier(ctx, gens, host_threads=host_threads)
@@ -697,43 +794,53 @@ def run_config2(args, W):
             d_dyn_off = torch.tensor(prep["dyn_off"], dtype=torch.int64, device=dev)
             d_st_off = torch.tensor(prep["st_off"], dtype=torch.int64, device=dev)
 
-            def submit_msm_only(c):
+            def submit_msm_only(c, j):
                 c.verify_batch_ps_submit_dev(ps, batch, d_dyn_sc, d_dyn_pt, d_dyn_off, batch * n_dyn,
                                              d_st_sc, d_st_idx, d_st_off, batch * n_static)
-            wf = [int(x) for x in prep["wellformed"]]
-            want_msm = bitmap_of([e for e in expected])
-            assert all(wf)
-            assert run_steps(len(ctxs), submit_msm_only, gather=False) == want_msm
+            assert all(int(x) for x in prep["wellformed"])
+
+            def run_set0(n, submit):
+                depth, bm0 = len(ctxs), None
+                for i in range(n + depth):
+                    c = ctxs[i % depth]
+                    if i >= depth:
+                        bm0 = c.verify_wait()
+                        assert bm0 == sets[0].want
+                    if i < n:
+                        submit(c, 0)
+                return bm0
+            run_set0(len(ctxs), submit_msm_only)
             t0 = time.perf_counter()
-            run_steps(args.steps, submit_msm_only, gather=False)
+            run_set0(args.steps, submit_msm_only)
             msm_only_s = (time.perf_counter() - t0) / args.steps
             # proof bytes -> accept bits with the verifier head on host threads
             t0 = time.perf_counter()
             bm_e2e = hv.verify_bitmap(ctxs_txs, r_bytes)
             e2e_s = time.perf_counter() - t0
-            assert bm_e2e == bm
+            assert bm_e2e == sets[0].want
             # the device path fed from HOST memory (PCIe copies + python marshalling included)
             packed_com = b"".join(t[2] for t in txs)
             packed_proofs = b"".join(t[3] for t in txs)
             n_e2e = 6 * len(ctxs)
 
-            def submit_host(c):
+            def submit_host(c, j):
                 gv.submit_packed_gpu(n_in, n_out, batch, packed_com, packed_proofs, proof_len, r_bytes, ctx=c)
-            assert run_steps(len(ctxs), submit_host, gather=False) == bm
+            run_set0(len(ctxs), submit_host)
             t0 = time.perf_counter()
-            assert run_steps(n_e2e, submit_host, gather=False) == bm
+            run_set0(n_e2e, submit_host)
             e2e_gpu_s = (time.perf_counter() - t0) / n_e2e
             # the same complete verification with every transaction checked on its own (no group checks)
             for c in ctxs:
                 c.set_group_size(1)
-            assert run_steps(len(ctxs), gather=False) == bm
+            run_steps(len(ctxs), base=0, gather=False)
             t0 = time.perf_counter()
-            run_steps(args.steps, gather=False)
+            run_steps(args.steps, base=0, gather=False)
             per_tx_s = (time.perf_counter() - t0) / args.steps
             for c in ctxs:
                 c.set_group_size(args.group)
             line["per_tx_checks"] = {"tx_per_s": round(batch / per_tx_s, 1), "ms_per_step": round(per_tx_s * 1e3, 4),
-                                     "note": "the same step with zkgpu_set_group_size(1): every transaction's MSM on its own"}
+                                     "note": "the same steps on plain contexts (%d batches of %d in flight, no merging) with "
+                                             "zkgpu_set_group_size(1): every transaction's MSM on its own" % (len(ctxs), batch)}
             line["msm_boundary"] = {"tx_per_s": round(batch / msm_only_s, 1), "ms_per_step": round(msm_only_s * 1e3, 4),
                                     "note": "zkgpu_verify_batch_ps_submit_dev alone: decompress + MSM + identity test on scalars "
                                             "prepared beforehand (the argument list of dalek's mega_check resident in HBM)"}
@@ -746,7 +853,9 @@ def run_config2(args, W):
                                            "`value`." % host_threads}
             hv.close()
             if world == 1 and not args.no_cpu:
-                line["cpu_baseline"] = cpu_baseline(txs, r_bytes, bits_of(bm, batch))
+                line["cpu_baseline"] = cpu_baseline(txs, r_bytes, bits_of(sets[0].want, batch))
+            if world == 1 and not args.no_sweep:
+                line["setup"]["table_bits_sweep"] = table_bits_sweep(args, ctx, ctxs, sets, n_in, n_out, proof_len, batch, gens, torch)
             if world == 1 and not args.no_msm:
                 # side legs: a failure of one of them is reported in its field, it does not take the headline line with it
                 # (a wrong RESULT in a leg is an AssertionError and does)
@@ -761,6 +870,7 @@ def run_config2(args, W):
                     except Exception as e:                     # noqa: BLE001
                         line[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         emit(line)
+    close_exchange()
     W.close()
     if bv is not None:
         bv.close()
@@ -771,13 +881,63 @@ def run_config2(args, W):
     ctx.close()
 
 
+def hbm_copy_leg(ctx):
+    """'measure achievable HBM with a copy kernel and report both' -- the library's own streaming
+    copy kernel (k_hbm_copy: 16 B per lane, grid-stride) over 2 x 1 GiB, bytes read + bytes written per second."""
+    gbs = ctx.measure_hbm_copy(1 << 30, 10)
+    return {"measured_copy_GBps": round(gbs, 1), "spec_GBps": HBM_PEAK_GBS, "measured_over_spec": round(gbs / HBM_PEAK_GBS, 4),
+            "note": "zkgpu_measure_hbm_copy: 1 GiB read + 1 GiB written per launch, best of 10 launches (HIP events); `roofline.peak` "
+                    "stays the 8 TB/s spec the north-star names; divide `roofline.frac` by measured_over_spec for the fraction of "
+                    "what a copy achieves"}
+
+
+def table_bits_sweep(args, ctx, lanes, sets, n_in, n_out, proof_len, batch, gens16, torch):
+    """Throughput of the same verification over generator tables of 13 .. 16 bits (what zkgpu_pointset_build_tables(.., 0)
+    chooses between by capacity and free HBM): device batches of 8192 distinct transactions, 5 in flight on plain contexts."""
+    from zkvm_amd.verifier import BulletproofGens, Verifier
+    rep, out = 8, {}
+    n_big = min(6, len(sets) // rep)
+    big = []
+    for k in range(n_big):
+        js = range(k * rep, (k + 1) * rep)
+        big.append((torch.cat([sets[j].com for j in js]), torch.cat([sets[j].proofs for j in js]), torch.cat([sets[j].r for j in js]),
+                    bitmap_of([b for j in js for b in sets[j].bits])))
+    for w in (13, 14, 15, 16):
+        t0 = time.perf_counter()
+        g = gens16 if w == args.table_bits else BulletproofGens(ctx, 256, table_bits=w)
+        build_s = time.perf_counter() - t0
+        v = Verifier(ctx, g)
+        try:
+            def run(n):
+                depth = len(lanes)
+                for i in range(n + depth):
+                    c = lanes[i % depth]
+                    if i >= depth:
+                        assert c.verify_wait() == big[(i - depth) % n_big][3]
+                    if i < n:
+                        d_c, d_p, d_r, _ = big[i % n_big]
+                        v.submit_packed_gpu_dev(n_in, n_out, rep * batch, d_c, d_p, proof_len, d_r, ctx=c)
+            run(len(lanes))
+            t0 = time.perf_counter()
+            n = 15
+            run(n)
+            dt = time.perf_counter() - t0
+            out[str(w)] = {"tx_per_s": round(n * rep * batch / dt, 1), "table_bytes": int(ctx.lib.zkgpu_pointset_table_bytes(g.points.h)),
+                           "table_build_ms": None if g is gens16 else round(build_s * 1e3, 1)}
+        finally:
+            v.close()
+            if g is not gens16:
+                g.close()
+    out["note"] = "device batches of %d distinct transactions, %d in flight on plain contexts (no tickets), groups of %d" % (rep * batch, len(lanes), args.group)
+    return out
+
+
 # ---- config 4: mixed-arity blocks sharded over the node -------------------------------------------
 def run_config4(args, W):
     torch, rank, world = W.torch, W.rank, W.world
     from gpu_util import mixed_block
     from zkvm_amd import Context, ZkGpuError
-    from zkvm_amd.native import Comm, shard_cuts
-    from zkvm_amd.sharded import gather_bitmaps
+    from zkvm_amd.native import shard_cuts
     from zkvm_amd.verifier import BlockVerifier, BulletproofGens, CloakTx
     ctx = Context(W.local)
     lib = ctx.lib
@@ -803,11 +963,8 @@ def run_config4(args, W):
         bv.lane(i).set_horner_mode(args.horner_mode)
     mine = [CloakTx(*t) for t in txs[lo:hi]]
     block = bv.block(mine, r_bytes[64 * lo: 64 * hi])          # this rank's shard, resident in HBM, grouped by shape
-    # the exchange step: RCCL behind the C ABI (zkgpu_comm); gloo when several ranks share one GPU
-    comm = None
-    if not W.share_gpu:
-        uid = W.broadcast_bytes(Comm.unique_id() if rank == 0 else b"", 128)
-        comm = Comm(ctx, rank, world, uid)
+    # the exchange step: RCCL behind the C ABI (zkgpu_comm), the same function config 2 uses; gloo when several ranks share one GPU
+    exchange, close_exchange, exchange_name = make_exchange(W, ctx, cuts, always_comm=True)   # (a world of one too: through RCCL)
     parts = [(cuts[i], cuts[i + 1]) for i in range(world)]
 
     # a step = one whole block: its batches queued on the lanes (zkgpu_verifier_block_start), its verdicts waited for
@@ -832,9 +989,7 @@ def run_config4(args, W):
                 local = bv.block_finish(run)
             except ZkGpuError as e:
                 status = e.code
-        if comm is not None:
-            return comm.allgather_bitmap(cuts, local, status)
-        return gather_bitmaps(parts, local, status != 0, W.dist, None) if W.dist else local
+        return exchange(local, status)
 
     def steps(k):
         inflight, out = collections.deque(), None
@@ -859,6 +1014,7 @@ def run_config4(args, W):
     W.barrier()
     elapsed = W.max_over_ranks(time.perf_counter() - t0)
     assert whole == want
+    ranks_info = W.describe_ranks()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -897,7 +1053,7 @@ def run_config4(args, W):
                             "shard_tx": [b - a for a, b in parts], "shard_terms": shard_terms,
                             "generator_table_bits": args.table_bits, "gens_capacity": 512, "calls_in_flight": bv.lanes(), "blocks_in_flight": depth,
                             "chunk": args.chunk or 2048, "group_size": args.group,
-                            "exchange": "gloo (ranks share one GPU)" if W.share_gpu else "ncclAllGather via zkgpu_comm_allgather_bitmap",
+                            "exchange": exchange_name, "ranks": ranks_info,
                             "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                             "parallelism": "tx-sharded x%d" % world})
         line["roofline"] = roofline_object(solo, launches, {}, alg_step, hi - lo, ms_per_step, table_bytes,
@@ -919,10 +1075,9 @@ def run_config4(args, W):
             if world == 1 and not args.no_cpu:
                 line["cpu_baseline"] = cpu_baseline(txs[lo:hi], r_bytes[64 * lo: 64 * hi], bits_of(whole, total)[lo:hi])
         emit(line)
+    close_exchange()
     W.close()
     block.close()
-    if comm is not None:
-        comm.close()
     bv.close()
     gens.close()
     ctx.close()
@@ -945,7 +1100,7 @@ def main():
     ap.add_argument("--bad-every", type=int, default=64, help="config 2: one transaction in this many is corrupted (0 = none)")
     ap.add_argument("--tickets", type=int, default=-1,
                     help="config 2: batches kept in flight as tickets of a zkgpu_verifier, which merges them into device batches of --merge tx (0 = plain contexts)")
-    ap.add_argument("--merge", type=int, default=0, help="config 2 with --tickets: transactions per merged device batch (0: chosen from --steps, see below)")
+    ap.add_argument("--merge", type=int, default=0, help="config 2 with --tickets: transactions per merged device batch (0: %d)" % DEFAULT_MERGE)
     ap.add_argument("--locate-mode", type=int, default=0, choices=(0, 1, 2, 3), help="zkgpu_set_locate_mode")
     ap.add_argument("--locate-parts", type=int, default=0, help="zkgpu_set_locate_parts (0 = the library's default)")
     ap.add_argument("--tail-mode", type=int, default=0, choices=(0, 1), help="zkgpu_set_tail_mode")
@@ -954,6 +1109,8 @@ def main():
                     help="zkgpu_set_transcript_mode: 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction")
     ap.add_argument("--lean", action="store_true", help="the timed steps and the solo pass only (what tools/profile_bench.sh profiles)")
     ap.add_argument("--solo", action="store_true", help="config 2: only serial steps, every kernel alone on the chip (for rocprofv3 --stats)")
+    ap.add_argument("--no-steady", action="store_true", help="config 2: skip the 200-step steady-state leg")
+    ap.add_argument("--no-sweep", action="store_true", help="config 2: skip the generator-table width sweep")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-msm", action="store_true", help="skip the prover and 2^20 MSM legs")
     args = ap.parse_args()
@@ -963,20 +1120,14 @@ def main():
         args.warmup = 10 if args.config == 2 else 3
     if args.config == 4:
         args.tickets = 0
+    # ONE arrangement whatever the flags: up to 64 batches of 1024 in flight as tickets, merged by the verifier into device
+    # batches of --merge transactions on 5 lanes.  (Until round 2 a short run -- the driver's --steps 20 -- was reshaped
+    # into two device batches of steps / 2 batches each; the arrangement no longer looks at --steps: a run shorter than 64
+    # steps simply has fewer tickets in flight, and its last device batch is as large as what is left.)
     if args.tickets < 0:
-        # Batching for the offered load.  The timed region starts and ends with an idle device, so K steps are K batches
-        # arriving at once: a short run (the driver's --steps 20) is best served as TWO equal device batches side by side
-        # (measured at K = 20: 2 x 10240 tx: 2.65 M tx/s; 8192 per device batch with 3 / 5 in flight: 2.30 / 2.33 M; one
-        # batch of 20480: 2.47 M); a long run settles into a steady state in which 64 queued batches, merged 8 at a time,
-        # 5 device batches in flight do best (sweep r02k: 32 / 3: 2.87 M, 64 / 5: 3.05 M, 128 / 9: 3.08 M tx/s).
-        if args.steps * args.batch <= 40960 and args.merge <= 0 and args.inflight <= 0 and not args.solo:   # (--solo: always 8192 per launch)
-            args.tickets = max(args.steps, 2)
-            args.merge = ((args.steps + 1) // 2) * args.batch
-            args.inflight = 2
-        else:
-            args.tickets = 64
+        args.tickets = 64
     if args.merge <= 0:
-        args.merge = 8192
+        args.merge = DEFAULT_MERGE
     if args.inflight <= 0:
         args.inflight = 5 if args.tickets > 0 else (10 if args.config == 4 and args.blocks_in_flight > 1 else 6)
     W = World(args)

@@ -27,7 +27,10 @@
  *     its forks, and a light one of its own) and serialises its own calls; use one context per
  *     thread, one process per GPU (zkgpu_comm joins the processes of a node over RCCL);
  *   - `*_dev` variants take device pointers (inputs already resident in HBM) and
- *     are what bench.py times; host-pointer variants add the PCIe copies.
+ *     are what bench.py times; host-pointer variants add the PCIe copies;
+ *   - a context with a SUBMITTED batch (zkgpu_*_submit*, not yet collected by zkgpu_verify_wait) owns its
+ *     workspace and result buffers on behalf of that batch: until then every synchronous entry point called
+ *     on it returns ZKGPU_EINVAL with its outputs zeroed (it never runs over the batch in flight).
  */
 #ifndef ZKGPU_H
 #define ZKGPU_H
@@ -461,7 +464,15 @@ int zkgpu_verifier_wait(zkgpu_verifier *v, uint64_t ticket, uint8_t *accept_bitm
  * accept bit i = all of it holds.  status (optional, batch bytes): 0 accepted, 1 rejected, 2 OUTSIDE THE SUBSET (another
  * instruction, another version, no or several cloaks): the caller's own VM must decide -- such a transaction is never
  * reported as invalid.  UNPINNED: format, opcodes and labels follow a recollection of the public ZkVM design notes
- * (DESIGN.md sec 4.5); nothing under /root/reference defines them. */
+ * (DESIGN.md sec 4.5); nothing under /root/reference defines them.
+ * EXPERIMENTAL, OPT-IN: because the format is unpinned the entry point is inert by default -- every transaction is
+ * reported as OUTSIDE THE SUBSET (status 2, accept bit 0: "ask your own VM") until the caller names the format with
+ * zkgpu_verifier_set_tx_format(v, ZKGPU_TXFORMAT_RECOLLECTED_V1).  Both outputs are fail-closed: status 0 is written
+ * only beside an accept bit of 1, after every stage has passed; on any error every transaction inside the subset reads
+ * "rejected" and the bitmap is zero.  The call holds the verifier for its whole length and first collects whatever its
+ * lanes have in flight (tickets and blocks keep their verdicts). */
+#define ZKGPU_TXFORMAT_RECOLLECTED_V1 1
+int zkgpu_verifier_set_tx_format(zkgpu_verifier *v, int format);
 int zkgpu_tx_verify_batch(zkgpu_verifier *v, size_t batch, const uint8_t *txs, const uint64_t *tx_offsets, int host_threads,
                           uint8_t *accept_bitmap, uint8_t *status);
 
@@ -477,8 +488,16 @@ int zkgpu_tx_verify_batch(zkgpu_verifier *v, size_t batch, const uint8_t *txs, c
  * a world of one needs no RCCL (id == NULL).
  * zkgpu_comm_allgather_bitmap is fail-closed ACROSS ranks: if any rank passes a non-zero local_status
  * every rank gets an all-zero bitmap and an error (its own, or ZKGPU_EREMOTE) -- and no rank is left
- * waiting in the collective.  zkgpu_verifier_verify_sharded = cuts + verify own shard + that gather,
- * with the whole block in host memory on every rank. */
+ * waiting in the collective: a communicator owns fixed exchange buffers from its creation (a rank contributes at most
+ * 1 MiB per call: a status word and the bitmap of 8 M transactions), so nothing that can fail on ONE rank stands between
+ * a call and its collective; a local fault (the caller's status, a missing bitmap, a failed copy to the device) travels
+ * through the gather as that rank's status word.  Arguments that are the same on every rank (the cuts) are checked
+ * before it.  Framing: csrc/comm_frame.hpp.  zkgpu_verifier_verify_sharded = cuts + verify own shard + that gather,
+ * with the whole block in host memory on every rank.
+ * zkgpu_debug_comm_mock: test hook -- world > 0 replaces the collective function table by an in-process mock of a world
+ * of `world` ranks whose other ranks contribute peer_slots (world x slot_bytes bytes), so that the exchange step can be
+ * exercised at world 2 .. 8 on one GPU; world = 0 restores RCCL.  Returns the all-gathers the mock has served. */
+long long zkgpu_debug_comm_mock(zkgpu_ctx *ctx, int world, const uint8_t *peer_slots, size_t slot_bytes);
 #define ZKGPU_COMM_ID_BYTES 128
 typedef struct zkgpu_comm zkgpu_comm;
 uint64_t zkgpu_cloak_msm_terms(uint32_t n_in, uint32_t n_out);
@@ -501,6 +520,9 @@ int zkgpu_verifier_verify_sharded(zkgpu_verifier *v, zkgpu_comm *comm, size_t ba
  *   ZKGPU_PROVER_TIMING=1     the provers and zkgpu_tx_verify_batch print per-phase host / device times to stderr
  * and GPU_MAX_HW_QUEUES (a HIP runtime variable): zkgpu_init sets it to 24 if it is unset and the
  * runtime has not started; batches in flight need a hardware queue per context. */
+/* "measure achievable HBM with a copy kernel and report both" -- a streaming copy of `bytes` bytes
+ * (16 B per lane, grid-stride), best of `iters` launches by HIP events: *gbytes_per_s = (bytes read + bytes written) / time. */
+int zkgpu_measure_hbm_copy(zkgpu_ctx *ctx, size_t bytes, int iters, double *gbytes_per_s);
 /* When enabled, every kernel launch of this context is bracketed by HIP events
  * on the context's own stream. */
 int zkgpu_profile_enable(zkgpu_ctx *ctx, int on);

@@ -3,6 +3,7 @@ import hashlib
 
 L = 2**252 + 27742317777372353535851937790883648493
 BAD_POINT = bytes.fromhex("01" + "00" * 31)          # s = 1 is negative: rejected by RFC 9496 DECODE
+_FIXTURE_CACHE = {}
 
 
 def stream(tag: str, n: int) -> bytes:
@@ -31,12 +32,48 @@ def load_cloak_fixture(name: str = "cloak_2x2_1024.bin"):
     """-> ([(commitments, proof), ...], n_in, n_out, proof_len)"""
     import os
     import struct
+    if name in _FIXTURE_CACHE:
+        return _FIXTURE_CACHE[name]
     raw = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name), "rb").read()
     assert raw[:8] == b"ZKCLOAK1"
     count, n_in, n_out, plen = struct.unpack("<IIII", raw[8:24])
     w = 64 * (n_in + n_out)
     rec = w + plen
-    return [(raw[24 + rec * i: 24 + rec * i + w], raw[24 + rec * i + w: 24 + rec * (i + 1)]) for i in range(count)], n_in, n_out, plen
+    out = [(raw[24 + rec * i: 24 + rec * i + w], raw[24 + rec * i + w: 24 + rec * (i + 1)]) for i in range(count)], n_in, n_out, plen
+    _FIXTURE_CACHE[name] = out
+    return out
+
+
+# ---- the headline bench's input (bench.py config 2), shared with the GPU test of that arrangement ---------------------
+def benched_step(batch: int, rank: int, bad_every: int = 64, step: int = 0):
+    """BASELINE configs[1], one step of bench.py: the committed distinct proofs, ~1.5 % corrupted -> (txs, expected bits).
+    Every STEP is a batch of its own: the fixture rotated by 31 per step (37 per rank), its own corrupted positions and
+    kinds -- and its own verifier randomness (benched_randomness) -- so that no two batches in flight, and no two merged
+    into one device batch, repeat each other's scalars, table rows or verdict pattern."""
+    fixture, n_in, n_out, _ = load_cloak_fixture("cloak_2x2_1024.bin")
+    txs, expected = [], []
+    rot = 37 * rank + 31 * step
+    for i in range(batch):
+        com, proof = fixture[(i + rot) % len(fixture)]
+        ok = 1
+        if bad_every and (i + 5 * step) % bad_every == 7 % bad_every:
+            ok = 0
+            c = ((i + 5 * step) // bad_every + step) % 3
+            if c == 0:      # commitment that is not a ristretto255 encoding
+                com = com[:96] + BAD_POINT + com[128:]
+            elif c == 1:    # IPA scalar a off by one (still canonical)
+                a = (int.from_bytes(proof[-64:-32], "little") + 1) % L
+                proof = proof[:-64] + a.to_bytes(32, "little") + proof[-32:]
+            else:           # a valid proof of a different statement
+                proof = fixture[(i + rot + 1) % len(fixture)][1]
+        txs.append((n_in, n_out, com, proof))
+        expected.append(ok)
+    return txs, expected
+
+
+def benched_randomness(rank: int, step: int, batch: int) -> bytes:
+    """64 bytes of verifier randomness per transaction of one step: SHAKE256 of the bench seed, the rank and the step"""
+    return hashlib.shake_256((0x5A6B564D).to_bytes(4, "little") + b"verifier-r|%d|%d" % (rank, step)).digest(64 * batch)
 
 
 def load_mixed_fixture():

@@ -29,7 +29,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.zkgpu_abi_version() == 2
+    assert lib.zkgpu_abi_version() == 3
     assert lib.zkgpu_strerror(0) == b"ok"
     assert b"ristretto" in lib.zkgpu_strerror(-2)
 

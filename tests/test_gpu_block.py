@@ -203,6 +203,149 @@ def test_exchange_step_behind_the_abi(ctx, oracle):
         gens.close()
 
 
+def _slot(cuts, rank, bitmap, status=0):
+    """one rank's contribution to the gather, framed as csrc/comm_frame.hpp frames it (written down independently here)"""
+    width = max((cuts[i + 1] - cuts[i] + 7) // 8 for i in range(len(cuts) - 1))
+    slot = 8 + (width + 7) // 8 * 8
+    n = cuts[rank + 1] - cuts[rank]
+    body = bitmap[: (n + 7) // 8] if status == 0 else b""
+    return (status & 0xFFFFFFFF).to_bytes(4, "little") + bytes(4) + body + bytes(slot - 8 - len(body))
+
+
+@pytest.mark.parametrize("world,rank", [(2, 1), (3, 0), (8, 5)])
+def test_exchange_step_in_a_mocked_world_of_n_ranks(ctx, oracle, world, rank):
+    """zkgpu_comm_* at world 2 / 3 / 8 on ONE GPU: the collective function table replaced by an in-process mock whose other
+    ranks contribute what the test supplies (zkgpu_debug_comm_mock), everything else -- buffers, stream, copies, framing,
+    statuses, zkgpu_verifier_verify_sharded with its cuts -- the product's own path.  Every rank's bits land at their
+    cuts; a peer's error, or the poison word of a peer whose copy failed, gives an error and an all-zero bitmap here; this
+    rank's own fault is reported as its own code; and the sharded verification of a mixed block verifies exactly
+    [cuts[rank], cuts[rank + 1]) on this GPU, the oracle's verdicts for the other shards arriving through the gather."""
+    import ctypes as C
+    from zkvm_amd import ZkGpuError
+    from zkvm_amd.native import Comm, shard_cuts
+    from zkvm_amd.verifier import BlockVerifier, BulletproofGens
+    lib = ctx.lib
+    txs = [t for t in mixed_block(40 * world, seed=20 + world, bad_every=7) if (t[0], t[1]) != (4, 4)]
+    n = len(txs)
+    r = hashlib.shake_256(b"mock world %d" % world).digest(64 * n)
+    want = oracle_block_bits(oracle, txs, r)
+    cuts = shard_cuts([(t[0], t[1]) for t in txs], world)
+    assert cuts[0] == 0 and cuts[-1] == n and all(a <= b for a, b in zip(cuts, cuts[1:]))
+
+    def shard_bitmap(k):
+        b = bytearray((cuts[k + 1] - cuts[k] + 7) // 8)
+        for j, i in enumerate(range(cuts[k], cuts[k + 1])):
+            b[j // 8] |= want[i] << (j % 8)
+        return bytes(b)
+
+    def install(peers):
+        blob = b"".join(peers)
+        assert lib.zkgpu_debug_comm_mock(ctx.h, world, blob, len(peers[0])) >= 0
+
+    whole = bytearray((n + 7) // 8)
+    for i, v in enumerate(want):
+        whole[i // 8] |= v << (i % 8)
+    gens = BulletproofGens(ctx, 256, table_bits=8)
+    bv = BlockVerifier(ctx, gens, batches_in_flight=2)
+    comm = None
+    try:
+        good = [_slot(cuts, k, shard_bitmap(k)) for k in range(world)]
+        junk = list(good)
+        junk[rank] = b"\xff" * len(good[0])                   # the mock overwrites this rank's place with what it really sends
+        install(junk)
+        comm = Comm(ctx, rank, world, bytes(128))
+        before = lib.zkgpu_debug_comm_mock(ctx.h, world, b"".join(junk), len(junk[0]))
+        assert comm.allgather_bitmap(cuts, shard_bitmap(rank)) == bytes(whole)
+        assert bits(bv.verify_sharded(comm, _cloak(txs), r), n) == want
+        assert lib.zkgpu_debug_comm_mock(ctx.h, world, b"".join(junk), len(junk[0])) == before + 2
+        # this rank's own fault: its code, zeros; and the collective was still entered (the peers are not left waiting)
+        with pytest.raises(ZkGpuError) as e:
+            comm.allgather_bitmap(cuts, shard_bitmap(rank), local_status=-4)
+        assert e.value.code == -4
+        assert lib.zkgpu_debug_comm_mock(ctx.h, world, b"".join(junk), len(junk[0])) == before + 3
+        peer = (rank + 1) % world
+        for status in (-3, 0x80000001 - (1 << 32)):          # a peer's error code; a peer's poison word
+            bad = list(junk)
+            bad[peer] = _slot(cuts, peer, b"", status)
+            install(bad)
+            out = C.create_string_buffer(len(whole))
+            rc = lib.zkgpu_comm_allgather_bitmap(comm.h, (C.c_uint64 * (world + 1))(*cuts), shard_bitmap(rank), 0, out)
+            assert rc == -7 and out.raw == bytes(len(whole))
+            with pytest.raises(ZkGpuError):
+                bv.verify_sharded(comm, _cloak(txs), r)
+        # cuts that go backwards are refused before the collective (the same answer on every rank)
+        back = list(cuts)
+        if world >= 2:
+            back[1] = back[2] + 1 if world > 2 else n + 1
+            rc = lib.zkgpu_comm_allgather_bitmap(comm.h, (C.c_uint64 * (world + 1))(*back), shard_bitmap(rank), 0, C.create_string_buffer(len(whole) + 8))
+            assert rc == -1
+    finally:
+        if comm is not None:
+            comm.close()
+        lib.zkgpu_debug_comm_mock(ctx.h, 0, None, 0)
+        bv.close()
+        gens.close()
+
+
+def test_synchronous_calls_never_run_over_a_batch_in_flight(ctx, oracle):
+    """A context with a submitted batch refuses every synchronous entry point (they share its status words and pinned
+    result buffer), and the batch's verdicts are untouched; zkgpu_tx_verify_batch -- whose key and signature stages are
+    synchronous calls on the verifier's root context = lane 0 -- first collects what the lanes have in flight: a block
+    of all-bad proofs started before it must still finish as all zeros, tickets keep their own bits."""
+    from gpu_util import load_tx_fixture
+    from zkvm_amd import ZkGpuError
+    from zkvm_amd.verifier import BlockVerifier, BulletproofGens, Verifier
+    fix, n_in, n_out, plen = load_cloak_fixture()
+    gens = BulletproofGens(ctx, 256, table_bits=10)
+    v = Verifier(ctx, gens)
+    n = 300
+    com = b"".join(fix[i][0] for i in range(n))
+    proofs = bytearray(b"".join(fix[i][1] for i in range(n)))
+    for i in range(0, n, 7):
+        proofs[i * plen + 1 + 32 * 11 + 5] ^= 1
+    r = hashlib.shake_256(b"pending guard").digest(64 * n)
+    want = list(oracle.cloak_verify_batch(com, n_in, n_out, bytes(proofs), plen, r, threads=8))
+    d = [ctx.to_device(x) for x in (com, bytes(proofs), r)]
+    bv = None
+    try:
+        v.submit_packed_gpu_dev(n_in, n_out, n, d[0], d[1], plen, d[2])
+        sc = (5).to_bytes(32, "little")
+        pt = oracle.encode(oracle.basepoint())
+        for call in (lambda: ctx.msm(sc, pt), lambda: ctx.verify_batch(sc, pt, [0, 1]), lambda: ctx.hash_to_points(bytes(64)),
+                     lambda: ctx.decode_check(pt)):
+            with pytest.raises(ZkGpuError) as e:
+                call()
+            assert e.value.code == -1
+        assert bits(ctx.verify_wait(), n) == want
+        assert ctx.msm(sc, pt) == oracle.encode(oracle.scalarmult(5, oracle.basepoint()))       # and works again afterwards
+        # the transaction path beside a block and tickets in flight on the same verifier
+        bv = BlockVerifier(ctx, gens, batches_in_flight=3)
+        bv.set_tx_format(bv.TXFORMAT_RECOLLECTED_V1)
+        txs = load_tx_fixture()[:200]
+        all_bad = []
+        for i in range(256):
+            p = bytearray(fix[i][1]); p[1 + 32 * 12 + (i % 30)] ^= 1 << (i % 8)
+            all_bad.append((n_in, n_out, fix[i][0], bytes(p)))
+        rb = hashlib.shake_256(b"all bad").digest(64 * 256)
+        assert oracle_block_bits(oracle, all_bad[:16], rb[: 64 * 16]) == [0] * 16
+        blk = bv.block(_cloak(all_bad), rb)
+        for _ in range(3):
+            run = bv.block_start(blk)
+            ticket = bv.submit_dev(n_in, n_out, n, d[0], d[1], plen, d[2])
+            bm, st = bv.verify_txs(txs)
+            assert bm == bytes([0xFF]) * 25 and not any(st)
+            assert bv.block_finish(run) == bytes(32)
+            assert bits(bv.wait(ticket), n) == want
+        blk.close()
+    finally:
+        if bv is not None:
+            bv.close()
+        v.close()
+        for x in d:
+            ctx.free_device(x)
+        gens.close()
+
+
 def test_cooperative_keccak_primitives_and_permutation(ctx, oracle):
     """keccak_coop.hpp on the hardware: every cross-lane primitive (DPP row_ror:8 / row_shr:1 / row_shl:1,
     v_permlane16_swap, v_permlane32_swap, ds_bpermute) behaves as the host emulation assumes, and Keccak-f[1600] with
@@ -353,6 +496,56 @@ def test_benched_configuration_full_size_vs_oracle(ctx, oracle):
         v.close()
         for c in lanes[1:]:
             c.close()
+        gens.close()
+
+
+def test_benched_arrangement_tickets_merged_into_device_batches_vs_oracle(ctx, oracle):
+    """EXACTLY what bench.py times with the driver's flags (--steps 20): 20 batches of 1024 transactions -- bench.py's own
+    input construction (gpu_util.benched_step / benched_randomness: every batch its own rotation of the 1024 distinct
+    golden proofs, its own corruptions, its own verifier randomness) -- queued by ONE zkgpu_verifier_submit_many_dev on a
+    verifier with 5 lanes, merged into device batches of 10 240 transactions over 16-bit generator tables (25.9 GB),
+    groups of 16, inputs resident in HBM: every accept bit of every ticket against the oracle's full verifier (and against
+    the constructed expectation bench.py asserts); then the steady-state form: 40 more tickets, 64 in flight at most,
+    submitted one by one as earlier ones are waited for."""
+    import torch
+    from gpu_util import benched_randomness, benched_step
+    from zkvm_amd.verifier import BlockVerifier, BulletproofGens
+    n_steps, batch, merge = 20, 1024, 10240
+    gens = BulletproofGens(ctx, 256, table_bits=16)
+    bv = BlockVerifier(ctx, gens, batches_in_flight=5)
+    bv.set_merge(merge)
+    assert bv.lanes() == 5
+    dev = torch.device("cuda", 0)
+    sets = []
+    try:
+        for s in range(n_steps + 40):
+            txs, expected = benched_step(batch, 0, 64, s)
+            r = benched_randomness(0, s, batch)
+            n_in, n_out, plen = txs[0][0], txs[0][1], len(txs[0][3])
+            com, proofs = b"".join(t[2] for t in txs), b"".join(t[3] for t in txs)
+            if s < n_steps or s % 8 == 0:
+                want = list(oracle.cloak_verify_batch(com, n_in, n_out, proofs, plen, r, threads=16))
+                assert want == expected, s                          # the bench's constructed expectation IS the oracle's verdict
+            t = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (com, proofs, r)]
+            sets.append((t, expected))
+        assert len({bytes(e) for _, e in sets[:n_steps]}) > 10      # the verdict pattern differs from step to step
+        torch.cuda.synchronize()
+        for _ in range(2):                                          # twice: cold and warm workspace
+            tickets = bv.submit_many_dev(n_in, n_out, batch, [t[0] for t, _ in sets[:n_steps]], [t[1] for t, _ in sets[:n_steps]], plen,
+                                         [t[2] for t, _ in sets[:n_steps]])
+            for k, tk in enumerate(tickets):
+                assert bits(bv.wait(tk), batch) == sets[k][1], k
+        q = []
+        for s in range(n_steps, n_steps + 40):
+            if len(q) >= 16:
+                k, tk = q.pop(0)
+                assert bits(bv.wait(tk), batch) == sets[k][1], k
+            t = sets[s][0]
+            q.append((s, bv.submit_dev(n_in, n_out, batch, t[0], t[1], plen, t[2])))
+        for k, tk in q:
+            assert bits(bv.wait(tk), batch) == sets[k][1], k
+    finally:
+        bv.close()
         gens.close()
 
 

@@ -155,3 +155,93 @@ def test_shard_cuts_of_the_library_equal_the_python_partition():
             if n >= 1000:
                 loads = [offs[cuts[i + 1]] - offs[cuts[i]] for i in range(world)]
                 assert max(loads) - min(loads) <= 2 * 1071
+
+
+# ---- the framing of the exchange (zkvm_amd/csrc/comm_frame.hpp through libzkhost.so): any world size on CPU -------------
+def _frame_lib():
+    import ctypes as C
+    from zkvm_amd import build
+    build.build()
+    lib = C.CDLL(os.path.join(ROOT, "zkvm_amd", "lib", "libzkhost.so"))
+    u64p = C.POINTER(C.c_uint64)
+    lib.zkhost_comm_slot_bytes.argtypes = [u64p, C.c_int]
+    lib.zkhost_comm_slot_bytes.restype = C.c_size_t
+    lib.zkhost_comm_pack.argtypes = [C.c_char_p, C.c_size_t, u64p, C.c_int, C.c_char_p, C.c_int]
+    lib.zkhost_comm_pack.restype = None
+    lib.zkhost_comm_unpack.argtypes = [C.c_char_p, C.c_size_t, u64p, C.c_int, C.c_int, C.c_char_p]
+    return lib
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_exchange_framing_status_word_padding_and_cuts(world):
+    """What zkgpu_comm_allgather_bitmap puts around the collective, with the collective itself replaced by concatenation:
+    ragged shards (empty ones too) land at their cuts bit by bit, the slot is a status word + the widest bitmap padded
+    to 8 bytes, ANY rank's non-zero status (its own code, the poison word of a failed copy) gives EVERY rank an error
+    and an all-zero bitmap -- its own code on the faulty rank, EREMOTE on the others -- a missing bitmap is a fault that
+    travels, and cuts that go backwards are refused identically everywhere."""
+    import ctypes as C
+    lib = _frame_lib()
+    rng = random.Random(100 + world)
+    for trial in range(12):
+        sizes = [rng.choice([0, 1, 7, 8, 9, 63, 64, 65, 1000, 8192]) for _ in range(world)]
+        if trial == 0:
+            sizes = [0] * world
+        cuts = [0]
+        for s in sizes:
+            cuts.append(cuts[-1] + s)
+        c_cuts = (C.c_uint64 * (world + 1))(*cuts)
+        slot = lib.zkhost_comm_slot_bytes(c_cuts, world)
+        assert slot == 8 + ((max((s + 7) // 8 for s in sizes) + 7) // 8) * 8
+        bits = [rng.getrandbits(1) for _ in range(cuts[-1])]
+        local = []
+        for r in range(world):
+            b = bytearray((sizes[r] + 7) // 8 + 3)                  # trailing garbage beyond the shard must not travel
+            for j in range(sizes[r]):
+                b[j // 8] |= bits[cuts[r] + j] << (j % 8)
+            b[(sizes[r] + 7) // 8:] = b"\xff\xff\xff"
+            if sizes[r] % 8:
+                b[sizes[r] // 8] |= (0xFF << (sizes[r] % 8)) & 0xFF  # ... nor the spare bits of its last byte
+            local.append(bytes(b))
+        want = bytearray((cuts[-1] + 7) // 8)
+        for i, v in enumerate(bits):
+            want[i // 8] |= v << (i % 8)
+
+        def gather(statuses, missing=()):
+            buf = b""
+            for r in range(world):
+                out = C.create_string_buffer(slot)
+                lib.zkhost_comm_pack(out, slot, c_cuts, r, None if r in missing else local[r], statuses[r])
+                buf += out.raw
+            return buf
+
+        def unpack(buf, rank):
+            whole = C.create_string_buffer(max(len(want), 1))
+            rc = lib.zkhost_comm_unpack(buf, slot, c_cuts, world, rank, whole)
+            return rc, whole.raw[: len(want)]
+
+        ok = gather([0] * world)
+        for r in range(world):
+            assert int.from_bytes(ok[slot * r: slot * r + 4], "little") == 0 and ok[slot * r + 4: slot * r + 8] == bytes(4)
+            assert unpack(ok, r) == (0, bytes(want))
+        bad_rank = rng.randrange(world)
+        for code in (-3, -4, -6):
+            st = [0] * world
+            st[bad_rank] = code
+            buf = gather(st)
+            for r in range(world):
+                rc, whole = unpack(buf, r)
+                assert rc == (code if r == bad_rank else -7) and whole == bytes(len(want))
+        # the poison word a rank's send buffer holds between calls (its copy to the device failed): an error everywhere
+        poisoned = bytearray(ok)
+        poisoned[slot * bad_rank: slot * bad_rank + 4] = (0x80000001).to_bytes(4, "little")
+        for r in range(world):
+            rc, whole = unpack(bytes(poisoned), r)
+            assert rc != 0 and whole == bytes(len(want))
+        if sizes[bad_rank]:
+            buf = gather([0] * world, missing=(bad_rank,))
+            for r in range(world):
+                rc, whole = unpack(buf, r)
+                assert rc == (-1 if r == bad_rank else -7) and whole == bytes(len(want))
+    if world >= 2:
+        back = (C.c_uint64 * (world + 1))(*([0, 5, 3] + [9] * (world - 2)))
+        assert lib.zkhost_comm_slot_bytes(back, world) == 0

@@ -154,6 +154,10 @@ def test_transactions_verified_on_the_device_equal_oracle():
         r = hashlib.shake_256(b"tx device r").digest(64)
         want = [oracle.tx_verify(t, r) for t in txs]
         assert want.count(0) == 32 and want.count(2) == 2
+        # inert until a format is named: everything "outside the subset", nothing accepted
+        bm0, st0 = bv.verify_txs(txs, host_threads=4)
+        assert bm0 == bytes(len(bm0)) and list(st0) == [2] * len(txs)
+        bv.set_tx_format(bv.TXFORMAT_RECOLLECTED_V1)
         bm, st = bv.verify_txs(txs, host_threads=4)
         assert list(st) == want
         assert [(bm[i // 8] >> (i % 8)) & 1 for i in range(len(txs))] == [1 if w == 0 else 0 for w in want]
@@ -180,6 +184,7 @@ def test_the_1024_fixture_transactions_on_the_device():
     ctx = Context(0)
     gens = BulletproofGens(ctx, 256, table_bits=12)
     bv = BlockVerifier(ctx, gens)
+    bv.set_tx_format(bv.TXFORMAT_RECOLLECTED_V1)
     try:
         bm, st = bv.verify_txs(txs)
         with pytest.raises(ValueError):                        # lengths that do not add up to the buffer: refused before the C call

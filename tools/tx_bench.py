@@ -11,6 +11,7 @@ ctx = Context(0)
 gens = BulletproofGens(ctx, 256, table_bits=16)
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bv = BlockVerifier(ctx, gens, chunk=chunk)
+bv.set_tx_format(bv.TXFORMAT_RECOLLECTED_V1)
 bv.verify_txs(txs[:64])
 blob, lens = b"".join(txs), [len(t) for t in txs]
 for _ in range(4):

@@ -15,6 +15,7 @@ gens = BulletproofGens(ctx, 256, table_bits=16)
 ctxs = [ctx, ctx.fork()]
 bvs = [BlockVerifier(c, gens, batches_in_flight=lanes) for c in ctxs]
 for bv in bvs:
+    bv.set_tx_format(bv.TXFORMAT_RECOLLECTED_V1)
     bv.verify_txs_packed(blob, lens)
 calls = 6
 def one(bv, out):

@@ -723,3 +723,14 @@ extern "C" uint64_t zkhost_pool_selftest(uint32_t rounds, uint32_t callers) {
   if (refused.load() != 0) ++bad;                     // only a forked process is refused
   return bad.load();
 }
+
+// ---- the framing of the sharded verification's one exchange (comm_frame.hpp), for the CPU tests: a world of any size is
+// ---- the test concatenating the slots its "ranks" packed
+#include "comm_frame.hpp"
+extern "C" size_t zkhost_comm_slot_bytes(const uint64_t* cuts, int world) { return commframe::slot_bytes(cuts, world); }
+extern "C" void zkhost_comm_pack(uint8_t* out, size_t slot, const uint64_t* cuts, int rank, const uint8_t* local_bitmap, int local_status) {
+  commframe::pack(out, slot, cuts, rank, local_bitmap, local_status);
+}
+extern "C" int zkhost_comm_unpack(const uint8_t* all, size_t slot, const uint64_t* cuts, int world, int rank, uint8_t* whole) {
+  return commframe::unpack(all, slot, cuts, world, rank, whole);
+}

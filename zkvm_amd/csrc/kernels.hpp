@@ -982,6 +982,20 @@ k_from_uniform(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint
   o[1] = make_uint4(enc[4], enc[5], enc[6], enc[7]);
 }
 
+// ---- k_hbm_copy -----------------------------------------------------------------
+// The achievable-HBM yardstick of SURVEY.md sec 8(d) ("measure achievable HBM with a copy kernel and report both"): 16 bytes
+// per lane, consecutive lanes on consecutive vectors, four independent loads in flight per lane, grid-stride over the buffer.
+__global__ void __launch_bounds__(256)
+k_hbm_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n_vec) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n_vec; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n_vec; i += stride) dst[i] = src[i];
+}
+
 // per-batch scratch state in one launch (instead of five fills): status words, per-MSM failure
 // flags, per-transaction wellformed flags
 __global__ void __launch_bounds__(256)

@@ -12,6 +12,7 @@
 // RCCL is bound at run time (dlopen of librccl.so.1, the soname torch's bundled copy also carries), so
 // the library loads and every single-GPU entry point works on a machine without it.
 #pragma once
+#include "comm_frame.hpp"
 #include "zkvm_tx.hpp"
 
 #include <deque>
@@ -56,6 +57,7 @@ struct zkgpu_verifier {
   std::deque<int> block_busy;                           // lanes running a block's batch, oldest first
   std::map<uint64_t, std::unique_ptr<BlockRun>> block_runs;
   uint64_t next_run = 1;
+  int tx_format = 0;                                    // zkgpu_verifier_set_tx_format: 0 = no serialized-transaction format enabled
   std::mutex mu;
   std::string last_error;
 };
@@ -80,11 +82,15 @@ struct zkgpu_comm {
   int rank = 0, world = 1;
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;
-  void* d_send = nullptr; void* d_recv = nullptr; size_t d_cap = 0;
-  void* h_pin = nullptr; size_t h_cap = 0;
+  // exchange buffers of a fixed size, made with the communicator: no allocation -- nothing that can fail on ONE rank --
+  // stands between a call and its collective (slot = bytes one rank contributes, at most COMM_MAX_SLOT)
+  void* d_send = nullptr; void* d_recv = nullptr;
+  void* h_pin = nullptr;                                // [slot | world * slot]
   std::mutex mu;
   std::string last_error;
 };
+constexpr size_t COMM_MAX_SLOT = 1u << 20;             // bytes per rank and call: a status word + the bitmap of 8 M transactions
+constexpr uint32_t COMM_POISON = 0x80000001u;          // what d_send's first word holds between calls: "this rank failed"
 
 namespace {
 void ticket_collect(zkgpu_verifier* v, int lane);
@@ -103,9 +109,52 @@ struct RcclApi {
   bool ok() const { return handle && GetUniqueId && CommInitRank && AllGather && CommDestroy && GetErrorString; }
 };
 
+// Test hook (zkgpu_debug_comm_mock): an in-process stand-in for a world of N ranks behind the same function table, so
+// that the exchange step -- buffers, stream, framing, fail-closed statuses, the poison word -- can run at world 2 .. 8 on
+// ONE GPU (RCCL refuses two ranks on one device).  The mock's all-gather puts this rank's bytes at its place and fills the
+// other ranks' places from the slots the test supplied.
+struct CommMock {
+  bool on = false;
+  int world = 1, rank = 0;
+  size_t slot = 0;
+  std::vector<uint8_t> peers;                     // world x slot bytes
+  void* d_peers = nullptr;
+  uint64_t gathers = 0;
+};
+CommMock g_comm_mock;
+std::mutex g_comm_mock_mu;
+
+ncclResult_t mock_get_unique_id(ncclUniqueId* id) { memset(id, 0x5a, sizeof *id); return ncclSuccess; }
+ncclResult_t mock_comm_init_rank(ncclComm_t* comm, int world, ncclUniqueId, int rank) {
+  std::lock_guard<std::mutex> lk(g_comm_mock_mu);
+  if (world != g_comm_mock.world) return ncclInvalidArgument;
+  g_comm_mock.rank = rank;
+  *comm = (ncclComm_t)&g_comm_mock;
+  return ncclSuccess;
+}
+ncclResult_t mock_all_gather(const void* send, void* recv, size_t bytes, ncclDataType_t, ncclComm_t, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_comm_mock_mu);
+  CommMock& m = g_comm_mock;
+  ++m.gathers;
+  if (bytes != m.slot) return ncclInvalidArgument;
+  if (hipMemcpyAsync(recv, m.d_peers, bytes * (size_t)m.world, hipMemcpyDeviceToDevice, st) != hipSuccess) return ncclUnhandledCudaError;
+  if (hipMemcpyAsync((char*)recv + bytes * (size_t)m.rank, send, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return ncclUnhandledCudaError;
+  return ncclSuccess;
+}
+ncclResult_t mock_comm_destroy(ncclComm_t) { return ncclSuccess; }
+const char* mock_error_string(ncclResult_t) { return "mock collective error"; }
+
 RcclApi& rccl() {
-  static RcclApi api;
-  static std::once_flag once;
+  static RcclApi api, mock;
+  static std::once_flag once, once_mock;
+  if (g_comm_mock.on) {
+    std::call_once(once_mock, [] {
+      mock.handle = (void*)&g_comm_mock;
+      mock.GetUniqueId = mock_get_unique_id; mock.CommInitRank = mock_comm_init_rank; mock.AllGather = mock_all_gather;
+      mock.CommDestroy = mock_comm_destroy; mock.GetErrorString = mock_error_string;
+    });
+    return mock;
+  }
   std::call_once(once, [] {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -134,16 +183,20 @@ uint64_t cloak_msm_terms(uint32_t n_in, uint32_t n_out) {
   }
 }
 
-// plan of a shape, created on first use; shapes the generator set cannot serve (more multipliers than
-// generators, no values, more than 64 inputs / outputs) map to nullptr: the reference rejects exactly
-// those transactions (InvalidGeneratorsLength / a VM error) and so does the caller, one by one
-zkgpu_cloak_plan* verifier_plan(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out) {
+// plan of a shape, created on first use.  *rc = ZKGPU_OK and nullptr: a shape the generator set can NEVER serve (more
+// multipliers than generators, no values, more than 64 inputs / outputs) -- the reference rejects exactly those
+// transactions (InvalidGeneratorsLength / a VM error) and so does the caller, one by one; that answer is cached.
+// *rc != ZKGPU_OK: the plan could not be made THIS time (out of device memory, a HIP error): nothing is cached, and the
+// caller fails its block or ticket with that error -- a transient fault must not turn into "the proof is invalid".
+zkgpu_cloak_plan* verifier_plan(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, int* rc) {
+  *rc = ZKGPU_OK;
   const auto key = std::make_pair(n_in, n_out);
   auto it = v->plans.find(key);
   if (it != v->plans.end()) return it->second;
   zkgpu_cloak_plan* p = nullptr;
-  const int rc = zkgpu_cloak_plan_create(v->root, n_in, n_out, v->gens_capacity, &p);
-  if (rc != ZKGPU_OK) p = nullptr;
+  const int r = zkgpu_cloak_plan_create(v->root, n_in, n_out, v->gens_capacity, &p);
+  if (r != ZKGPU_OK && r != ZKGPU_EINVAL) { *rc = r; v->last_error = zkgpu_last_error(v->root); return nullptr; }
+  if (r != ZKGPU_OK) p = nullptr;
   v->plans[key] = p;
   return p;
 }
@@ -231,8 +284,8 @@ struct TxSource { uint32_t n_in, n_out; const uint8_t* com; const uint8_t* proof
 
 // groups the transactions by (inputs, outputs, proof length), lays the groups out, gathers them on host threads and
 // copies the block to HBM
-int txblock_build(zkgpu_verifier* v, size_t batch, const TxSource* src, const uint8_t* r_bytes, int host_threads, zkgpu_txblock** out) {
-  std::lock_guard<std::mutex> lk(v->mu);
+// (v->mu held: the plans and last_error are the verifier's)
+int txblock_build_locked(zkgpu_verifier* v, size_t batch, const TxSource* src, const uint8_t* r_bytes, int host_threads, zkgpu_txblock** out) {
   zkgpu_ctx* c = v->root;
   std::unique_ptr<zkgpu_txblock> b(new zkgpu_txblock());
   b->v = v; b->batch = batch;
@@ -248,7 +301,9 @@ int txblock_build(zkgpu_verifier* v, size_t batch, const TxSource* src, const ui
       if (it == where.end()) {
         zkgpu_txblock::Group g;
         g.n_in = src[i].n_in; g.n_out = src[i].n_out; g.proof_len = (size_t)src[i].proof_len;
-        g.plan = verifier_plan(v, g.n_in, g.n_out);
+        int prc = ZKGPU_OK;
+        g.plan = verifier_plan(v, g.n_in, g.n_out, &prc);
+        if (prc != ZKGPU_OK) return prc;
         if (g.plan && !proof_len_fits(g.plan->shape, g.proof_len)) g.plan = nullptr;   // wrong length for the statement
         g.com_off = g.proof_off = g.r_off = 0;
         it = where.emplace(key, b->groups.size()).first;
@@ -301,6 +356,11 @@ int txblock_build(zkgpu_verifier* v, size_t batch, const TxSource* src, const ui
                                (tb1 - tb0) * 1e3, (tb2 - tb1) * 1e3, (now() - tb2) * 1e3, total);
   *out = b.release();
   return ZKGPU_OK;
+}
+
+int txblock_build(zkgpu_verifier* v, size_t batch, const TxSource* src, const uint8_t* r_bytes, int host_threads, zkgpu_txblock** out) {
+  std::lock_guard<std::mutex> lk(v->mu);
+  return txblock_build_locked(v, batch, src, r_bytes, host_threads, out);
 }
 
 }  // namespace
@@ -495,8 +555,8 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
       continue;
     }
     zkgpu_ctx* L = v->lanes[(size_t)lane];
-    zkgpu_cloak_plan* plan = verifier_plan(v, head->n_in, head->n_out);
     int rc = ZKGPU_OK;
+    zkgpu_cloak_plan* plan = verifier_plan(v, head->n_in, head->n_out, &rc);   // rc != OK: no plan THIS time -> the tickets fail with it
     const void *p_com = pick[0]->d_com, *p_proofs = pick[0]->d_proofs, *p_r = pick[0]->d_r;
     if (plan && proof_len_fits(plan->shape, head->proof_len) && pick.size() > 1) {
       std::lock_guard<std::recursive_mutex> lk(L->mu);
@@ -548,10 +608,10 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
       for (auto it = v->queue.begin(); it != v->queue.end(); ++it) if (*it == r) { v->queue.erase(it); break; }
       r->bit_off = off; off += r->batch;
       if (rc == ZKGPU_OK && plan) { r->state = 1; r->lane = lane; }
-      else { r->state = 2; r->rc = plan ? rc : ZKGPU_OK; r->bits.assign((r->batch + 7) / 8, 0); }   // no plan: every proof is Err
+      else { r->state = 2; r->rc = rc; r->bits.assign((r->batch + 7) / 8, 0); }   // rc OK and no plan: every proof is Err
     }
     if (rc == ZKGPU_OK && plan) { v->running[(size_t)lane] = pick; v->busy.push_back(lane); }
-    else if (rc != ZKGPU_OK) v->last_error = zkgpu_last_error(L);
+    else if (rc != ZKGPU_OK && plan) v->last_error = zkgpu_last_error(L);
   }
   return ZKGPU_OK;
 }
@@ -643,6 +703,23 @@ int zkgpu_shard_cuts(size_t batch, const uint32_t* n_in, const uint32_t* n_out, 
   return ZKGPU_OK;
 }
 
+// Test hook: world > 0 switches the collective function table to the in-process mock of a world of `world` ranks whose
+// OTHER ranks contribute `peer_slots` (world x slot_bytes bytes, rank-major; the place of the rank the communicator is
+// then created with is overwritten by what that rank really sends); world = 0 switches back to RCCL.  Returns the number
+// of all-gathers the mock has served so far.
+long long zkgpu_debug_comm_mock(zkgpu_ctx* ctx, int world, const uint8_t* peer_slots, size_t slot_bytes) {
+  std::lock_guard<std::mutex> lk(g_comm_mock_mu);
+  CommMock& m = g_comm_mock;
+  if (world <= 0) { m.on = false; return (long long)m.gathers; }
+  if (!ctx || !peer_slots || slot_bytes == 0 || slot_bytes > COMM_MAX_SLOT) return ZKGPU_EINVAL;
+  DeviceGuard g(ctx->device);
+  if (m.d_peers) { (void)hipFree(m.d_peers); m.d_peers = nullptr; }
+  if (hipMalloc(&m.d_peers, slot_bytes * (size_t)world) != hipSuccess) return ZKGPU_ENOMEM;
+  if (hipMemcpy(m.d_peers, peer_slots, slot_bytes * (size_t)world, hipMemcpyHostToDevice) != hipSuccess) return ZKGPU_EHIP;
+  m.world = world; m.slot = slot_bytes; m.on = true;
+  return (long long)m.gathers;
+}
+
 int zkgpu_comm_unique_id(uint8_t id[ZKGPU_COMM_ID_BYTES]) {
   if (!id) return ZKGPU_EINVAL;
   static_assert(sizeof(ncclUniqueId) == ZKGPU_COMM_ID_BYTES, "unique id size");
@@ -665,12 +742,24 @@ int zkgpu_comm_create(zkgpu_ctx* ctx, int rank, int world, const uint8_t id[ZKGP
     DeviceGuard g(ctx->device);
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking));
-    const ncclResult_t r = api.CommInitRank(&cm->comm, world, uid, rank);
-    if (r != ncclSuccess) {
-      ctx->last_error = std::string("ncclCommInitRank: ") + api.GetErrorString(r);
-      (void)hipStreamDestroy(cm->stream);
-      return ZKGPU_ENOCOMM;
+    hipError_t e = hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&cm->d_send, COMM_MAX_SLOT);
+    if (e == hipSuccess) e = hipMalloc(&cm->d_recv, COMM_MAX_SLOT * (size_t)world);
+    if (e == hipSuccess) e = hipHostMalloc(&cm->h_pin, COMM_MAX_SLOT * ((size_t)world + 1), hipHostMallocDefault);
+    if (e == hipSuccess) {
+      const uint32_t poison = COMM_POISON;
+      e = hipMemcpy(cm->d_send, &poison, 4, hipMemcpyHostToDevice);
+    }
+    ncclResult_t r = ncclSuccess;
+    if (e == hipSuccess) r = api.CommInitRank(&cm->comm, world, uid, rank);
+    if (e != hipSuccess || r != ncclSuccess) {
+      ctx->last_error = e != hipSuccess ? std::string("zkgpu_comm_create: ") + hipGetErrorString(e)
+                                        : std::string("ncclCommInitRank: ") + api.GetErrorString(r);
+      if (cm->stream) (void)hipStreamDestroy(cm->stream);
+      if (cm->d_send) (void)hipFree(cm->d_send);
+      if (cm->d_recv) (void)hipFree(cm->d_recv);
+      if (cm->h_pin) (void)hipHostFree(cm->h_pin);
+      return e != hipSuccess ? (e == hipErrorOutOfMemory ? ZKGPU_ENOMEM : ZKGPU_EHIP) : ZKGPU_ENOCOMM;
     }
   }
   *out = cm.release();
@@ -692,8 +781,12 @@ int zkgpu_comm_rank(const zkgpu_comm* cm) { return cm ? cm->rank : -1; }
 int zkgpu_comm_world(const zkgpu_comm* cm) { return cm ? cm->world : 0; }
 
 // Every rank contributes `bytes` bytes; `all` receives world * bytes (rank-major), in host memory.
+// Once the arguments are accepted (they are the same on every rank: `bytes` must be), this rank ENTERS the collective
+// whatever happens locally, so that no peer is left waiting in it: the buffers exist since zkgpu_comm_create, and if
+// the copy of this rank's contribution to the device fails, what the peers receive from it starts with the poison word
+// every call leaves behind in d_send -- a non-zero status to zkgpu_comm_allgather_bitmap.
 int zkgpu_comm_allgather(zkgpu_comm* cm, const uint8_t* local, size_t bytes, uint8_t* all) {
-  if (!cm || !all || (bytes && !local)) return ZKGPU_EINVAL;
+  if (!cm || !all || (bytes && !local) || bytes > COMM_MAX_SLOT) return ZKGPU_EINVAL;
   std::lock_guard<std::mutex> lk(cm->mu);
   if (bytes == 0) return ZKGPU_OK;
   if (!cm->comm) {                      // a world of one without RCCL
@@ -704,23 +797,23 @@ int zkgpu_comm_allgather(zkgpu_comm* cm, const uint8_t* local, size_t bytes, uin
   zkgpu_ctx* c = cm->ctx;
   DeviceGuard g(c->device);
   const size_t total = bytes * (size_t)cm->world;
-  if (cm->d_cap < total) {
-    if (cm->d_send) { (void)hipFree(cm->d_send); (void)hipFree(cm->d_recv); (void)hipHostFree(cm->h_pin); }
-    cm->d_send = cm->d_recv = cm->h_pin = nullptr; cm->d_cap = 0;
-    const size_t cap = std::max<size_t>(2 * total, 4096);
-    HIP_TRY(c, hipMalloc(&cm->d_send, cap));
-    HIP_TRY(c, hipMalloc(&cm->d_recv, cap));
-    HIP_TRY(c, hipHostMalloc(&cm->h_pin, 2 * cap, hipHostMallocDefault));
-    cm->d_cap = cap;
-  }
   char* h = (char*)cm->h_pin;
   memcpy(h, local, bytes);
-  HIP_TRY(c, hipMemcpyAsync(cm->d_send, h, bytes, hipMemcpyHostToDevice, cm->stream));
+  int rc = ZKGPU_OK;
+  auto note = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == ZKGPU_OK) { c->last_error = std::string(what) + ": " + hipGetErrorString(e); rc = ZKGPU_EHIP; }
+  };
+  note(hipMemcpyAsync(cm->d_send, h, bytes, hipMemcpyHostToDevice, cm->stream), "zkgpu_comm_allgather: copy in");
   const ncclResult_t r = rccl().AllGather(cm->d_send, cm->d_recv, bytes, ncclUint8, cm->comm, cm->stream);
-  if (r != ncclSuccess) { c->last_error = std::string("ncclAllGather: ") + rccl().GetErrorString(r); return ZKGPU_ENOCOMM; }
-  HIP_TRY(c, hipMemcpyAsync(h + cm->d_cap, cm->d_recv, total, hipMemcpyDeviceToHost, cm->stream));
-  HIP_TRY(c, hipStreamSynchronize(cm->stream));
-  memcpy(all, h + cm->d_cap, total);
+  if (r != ncclSuccess && rc == ZKGPU_OK) { c->last_error = std::string("ncclAllGather: ") + rccl().GetErrorString(r); rc = ZKGPU_ENOCOMM; }
+  note(hipMemcpyAsync(h + COMM_MAX_SLOT, cm->d_recv, total, hipMemcpyDeviceToHost, cm->stream), "zkgpu_comm_allgather: copy out");
+  {
+    static const uint32_t poison = COMM_POISON;        // (pageable source of an async copy: staged by the runtime)
+    note(hipMemcpyAsync(cm->d_send, &poison, 4, hipMemcpyHostToDevice, cm->stream), "zkgpu_comm_allgather: poison");
+  }
+  note(hipStreamSynchronize(cm->stream), "zkgpu_comm_allgather: synchronize");
+  if (rc != ZKGPU_OK) { memset(all, 0, total); return rc; }
+  memcpy(all, h + COMM_MAX_SLOT, total);
   return ZKGPU_OK;
 }
 
@@ -732,36 +825,16 @@ int zkgpu_comm_allgather_bitmap(zkgpu_comm* cm, const uint64_t* cuts, const uint
                                 uint8_t* whole_bitmap) {
   if (!cm || !cuts || !whole_bitmap) return ZKGPU_EINVAL;
   const int world = cm->world;
-  const uint64_t batch = cuts[world];
-  memset(whole_bitmap, 0, (size_t)((batch + 7) / 8));
-  size_t width = 0;
-  for (int r = 0; r < world; ++r) {
-    if (cuts[r + 1] < cuts[r]) return ZKGPU_EINVAL;
-    width = std::max<size_t>(width, (size_t)((cuts[r + 1] - cuts[r] + 7) / 8));
-  }
-  const size_t slot = 8 + ((width + 7) & ~(size_t)7);      // status word, then the bitmap
-  std::vector<uint8_t> mine(slot, 0), all(slot * (size_t)world, 0);
-  const uint64_t mine_n = cuts[cm->rank + 1] - cuts[cm->rank];
-  const int32_t st = local_status;
-  memcpy(mine.data(), &st, 4);
-  if (local_status == ZKGPU_OK && mine_n) {
-    if (!local_bitmap) return ZKGPU_EINVAL;
-    memcpy(mine.data() + 8, local_bitmap, (size_t)((mine_n + 7) / 8));
-  }
+  memset(whole_bitmap, 0, (size_t)((cuts[world] + 7) / 8));
+  // (the cuts are the same on every rank, and so are the two answers below: no rank goes on into the collective alone)
+  const size_t slot = commframe::slot_bytes(cuts, world);
+  if (slot == 0 || slot > COMM_MAX_SLOT) return ZKGPU_EINVAL;
+  std::vector<uint8_t> mine(slot), all(slot * (size_t)world, 0);
+  // a local fault -- the caller's status, or a missing bitmap -- travels THROUGH the gather as this rank's status word:
+  // returning here would leave the peers waiting in the collective
+  commframe::pack(mine.data(), slot, cuts, cm->rank, local_bitmap, local_status);
   TRY(zkgpu_comm_allgather(cm, mine.data(), slot, all.data()));
-  int rc = ZKGPU_OK;
-  for (int r = 0; r < world; ++r) {
-    int32_t s;
-    memcpy(&s, &all[slot * (size_t)r], 4);
-    if (s != ZKGPU_OK && rc == ZKGPU_OK) rc = (r == cm->rank) ? s : ZKGPU_EREMOTE;
-  }
-  if (rc != ZKGPU_OK) return rc;
-  for (int r = 0; r < world; ++r) {
-    const uint8_t* bmr = &all[slot * (size_t)r + 8];
-    for (uint64_t j = 0, i = cuts[r]; i < cuts[r + 1]; ++j, ++i)
-      if ((bmr[j / 8] >> (j % 8)) & 1) whole_bitmap[i / 8] |= (uint8_t)(1u << (i % 8));
-  }
-  return ZKGPU_OK;
+  return commframe::unpack(all.data(), slot, cuts, world, cm->rank, whole_bitmap);
 }
 
 // Whole batch in host memory on every rank (a block of transactions as every node of the network
@@ -790,11 +863,27 @@ int zkgpu_verifier_verify_sharded(zkgpu_verifier* v, zkgpu_comm* cm, size_t batc
 }
 
 // ---- serialized transactions (Tx::verify / Verifier::verify_tx on transaction bytes) ------
+// UNPINNED: the wire format, opcodes and labels are a recollection (zkvm_tx.hpp); nothing under
+// /root/reference defines them.  The entry point therefore does nothing until the caller names the format it wants
+// (zkgpu_verifier_set_tx_format): by default every transaction is reported as "outside the subset" (status 2), which
+// is the answer that sends it to the caller's own VM.
 // Per transaction on host threads (zkvm_tx.hpp): wire format, the VM of the payment subset, transaction ID, the terms
 // of the signature equation; then for the whole batch on the device: the aggregated keys (one small multiscalar
 // multiplication each), the signature equations (multiscalar multiplication == identity), and the cloak proofs as a
 // block of mixed shapes.  status[i] (optional): 0 accepted, 1 rejected, 2 outside the subset (the caller's own VM must
-// decide; the accept bit is 0).
+// decide; the accept bit is 0).  Fail-closed in BOTH outputs: a status of 0 is written only beside an accept bit of 1,
+// at the very end; on any error every live transaction reads "rejected".
+// The key and signature stages run synchronously on the verifier's root context, which is also lane 0 of its tickets
+// and blocks: the whole call holds the verifier's mutex, and whatever is in flight on the lanes is collected first
+// (the verdicts stay with their tickets / runs) -- a synchronous call on a context with a batch in flight would
+// overwrite that batch's status words and pinned result buffer (and is refused by the context: refuse_if_pending).
+int zkgpu_verifier_set_tx_format(zkgpu_verifier* v, int format) {
+  if (!v || (format != 0 && format != ZKGPU_TXFORMAT_RECOLLECTED_V1)) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  v->tx_format = format;
+  return ZKGPU_OK;
+}
+
 int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, const uint64_t* tx_offsets, int host_threads,
                           uint8_t* accept_bitmap, uint8_t* status) {
   using namespace zk::zkvm;
@@ -805,6 +894,11 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   if (batch == 0) return ZKGPU_OK;
   if (!txs || !tx_offsets || batch >= (1ull << 31)) return ZKGPU_EINVAL;
   for (size_t i = 0; i < batch; ++i) if (tx_offsets[i + 1] < tx_offsets[i]) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> vlk(v->mu);
+  if (v->tx_format != ZKGPU_TXFORMAT_RECOLLECTED_V1) {            // no format enabled: nothing is inside the subset
+    if (status) memset(status, TX_UNSUPPORTED, batch);
+    return ZKGPU_OK;
+  }
   std::vector<TxStatement> st(batch);
   const bool timing = getenv("ZKGPU_PROVER_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -813,10 +907,13 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   const double t1 = now();
   std::vector<size_t> live;
   for (size_t i = 0; i < batch; ++i) {
-    if (status) status[i] = (uint8_t)st[i].status;
+    if (status && st[i].status == TX_UNSUPPORTED) status[i] = TX_UNSUPPORTED;     // (TX_OK is written at the very end only)
     if (st[i].status == TX_OK) live.push_back(i);
   }
   if (live.empty()) return ZKGPU_OK;
+  // the lanes' batches in flight are collected before the root context is used synchronously
+  while (!v->block_busy.empty()) block_collect(v, v->block_busy.front());
+  while (!v->busy.empty()) ticket_collect(v, v->busy.front());
   zkgpu_ctx* c = v->root;
   auto par = [&](size_t n, const std::function<void(size_t)>& f) { host_parallel(n, host_threads, f); };
   const size_t nl = live.size();
@@ -829,17 +926,15 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     memcpy(sc.data() + 32 * off[j], t.sig_scalars.data() + 64, t.sig_scalars.size() - 64);
     memcpy(pt.data() + 32 * off[j], t.sig_points.data() + 64, t.sig_points.size() - 64);
   });
-  TRY(zkgpu_msm_batch(c, sc.data(), pt.data(), off.data(), nl, agg.data(), okb.data()));
+  auto fail = [&](int rc) { v->last_error = zkgpu_last_error(c); return rc; };
+  { const int rc = zkgpu_msm_batch(c, sc.data(), pt.data(), off.data(), nl, agg.data(), okb.data()); if (rc != ZKGPU_OK) return fail(rc); }
   const double t2 = now();
   uint8_t B[32], Bb[32];
-  TRY(zkgpu_pedersen_gens(c, B, Bb));
+  { const int rc = zkgpu_pedersen_gens(c, B, Bb); if (rc != ZKGPU_OK) return fail(rc); }
   // 2. the signature equations  s B - R - sum (c a_i) X_i == identity: B is generator 0 of the resident set (its term
   //    comes out of the fixed-base tables), R and the keys are the proof-specific points of the row
   std::vector<size_t> keyed;                           // positions in `live` whose keys all decode
-  for (size_t j = 0; j < nl; ++j) {
-    if ((okb[j / 8] >> (j % 8)) & 1) keyed.push_back(j);
-    else if (status) status[live[j]] = TX_INVALID;
-  }
+  for (size_t j = 0; j < nl; ++j) if ((okb[j / 8] >> (j % 8)) & 1) keyed.push_back(j);
   const size_t ns = keyed.size();
   off.assign(ns + 1, 0);
   for (size_t q = 0; q < ns; ++q) off[q + 1] = off[q] + st[live[keyed[q]]].sig_scalars.size() / 32 - 1;
@@ -856,17 +951,16 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     memcpy(pt.data() + 32 * off[q], t.sig_points.data() + 32, t.sig_points.size() - 32);
   });
   std::vector<uint8_t> sig_bits((ns + 7) / 8 + 1, 0);
-  if (ns) TRY(zkgpu_verify_batch_ps(c, v->ps, ns, sc.data(), pt.data(), off.data(), ssc.data(), sidx.data(), soff.data(), sig_bits.data()));
+  if (ns) {
+    const int rc = zkgpu_verify_batch_ps(c, v->ps, ns, sc.data(), pt.data(), off.data(), ssc.data(), sidx.data(), soff.data(), sig_bits.data());
+    if (rc != ZKGPU_OK) return fail(rc);
+  }
   const double t3 = now();
   // 3. the cloak proofs of the transactions whose signature holds, staged straight from the statements (no second copy).
   //    (Queueing them on the lanes BEFORE the signature stages, to run underneath, was measured slower: the short kernels
   //    of the signature stages then wait for CU slots behind the proofs' long ones.)
   std::vector<size_t> proved;
-  for (size_t q = 0; q < ns; ++q) {
-    const size_t i = live[keyed[q]];
-    if ((sig_bits[q / 8] >> (q % 8)) & 1) proved.push_back(i);
-    else if (status) status[i] = TX_INVALID;
-  }
+  for (size_t q = 0; q < ns; ++q) if ((sig_bits[q / 8] >> (q % 8)) & 1) proved.push_back(live[keyed[q]]);
   if (proved.empty()) return ZKGPU_OK;
   const size_t np = proved.size();
   std::vector<TxSource> src(np);
@@ -876,9 +970,9 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   }
   std::vector<uint8_t> bits((np + 7) / 8, 0);
   zkgpu_txblock* blk = nullptr;
-  TRY(txblock_build(v, np, src.data(), nullptr, host_threads, &blk));
+  TRY(txblock_build_locked(v, np, src.data(), nullptr, host_threads, &blk));
   const double t4 = now();
-  const int rc = zkgpu_verifier_verify_block(v, blk, bits.data());
+  const int rc = block_finish(v, block_start(v, blk), bits.data());
   zkgpu_txblock_destroy(blk);
   if (rc != ZKGPU_OK) return rc;
   if (timing) fprintf(stderr, "tx verify: VM + ids %.2f ms, aggregated keys %.2f ms, signature equations %.2f ms, cloak proofs %.2f ms (of which staging %.2f ms), "
@@ -886,9 +980,10 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
                       (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (now() - t3) * 1e3, (t4 - t3) * 1e3, (now() - t00) * 1e3, batch);
   for (size_t q = 0; q < np; ++q) {
     const size_t i = proved[q];
-    const bool ok = (bits[q / 8] >> (q % 8)) & 1;
-    if (ok) accept_bitmap[i / 8] |= (uint8_t)(1u << (i % 8));
-    if (status) status[i] = ok ? TX_OK : TX_INVALID;
+    if ((bits[q / 8] >> (q % 8)) & 1) {
+      accept_bitmap[i / 8] |= (uint8_t)(1u << (i % 8));
+      if (status) status[i] = TX_OK;
+    }
   }
   return ZKGPU_OK;
 }

@@ -173,6 +173,15 @@ int ensure_pinned(zkgpu_ctx* c, size_t bytes) {
 
 #define TRY(expr) do { int rc__ = (expr); if (rc__ != ZKGPU_OK) return rc__; } while (0)
 
+// A context with a submitted batch still to be waited for owns its workspace, its status words and its pinned result
+// buffer on behalf of that batch: every synchronous entry point refuses to run on it (it would overwrite them, and the
+// batch's verdicts with them) until zkgpu_verify_wait has collected the batch.  Call with c->mu held.
+int refuse_if_pending(zkgpu_ctx* c) {
+  if (!c->pending) return ZKGPU_OK;
+  c->last_error = "a submitted batch is still waiting for zkgpu_verify_wait on this context";
+  return ZKGPU_EINVAL;
+}
+
 // Verifier randomness (the weight r of each proof's two equation halves and of a transaction inside
 // a group check is the soundness parameter): from the kernel's CSPRNG, getrandom(2).  false = no
 // randomness available: the caller fails closed.
@@ -1121,7 +1130,7 @@ struct DeviceGuard {
 // =============================== C ABI =========================================
 extern "C" {
 
-int zkgpu_abi_version(void) { return 2; }
+int zkgpu_abi_version(void) { return 3; }
 
 const char* zkgpu_strerror(int code) {
   switch (code) {
@@ -1280,6 +1289,8 @@ int zkgpu_msm_dev(zkgpu_ctx* c, const void* d_scalars, const void* d_points, siz
                   size_t* bad_index) {
   if (!c || !out || (n && (!d_scalars || !d_points))) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  memset(out, 0, 32);
+  TRY(refuse_if_pending(c));
   DeviceGuard g(c->device);
   int rc = msm_device(c, d_scalars, d_points, n, out, bad_index);
   if (rc != ZKGPU_OK) memset(out, 0, 32);
@@ -1292,6 +1303,7 @@ int zkgpu_msm(zkgpu_ctx* c, const uint8_t* scalars, const uint8_t* points, size_
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   DeviceGuard g(c->device);
   memset(out, 0, 32);
+  TRY(refuse_if_pending(c));
   TRY(upload(c, c->in_scalars, scalars, n * 32));
   TRY(upload(c, c->in_points, points, n * 32));
   int rc = msm_device(c, c->in_scalars.p, c->in_points.p, n, out, bad_index);
@@ -1304,6 +1316,8 @@ int zkgpu_verify_batch_dev(zkgpu_ctx* c, const void* d_scalars, const void* d_po
   if (!c || !accept_bitmap || (batch && !d_offsets) || (n_terms && (!d_scalars || !d_points))) return ZKGPU_EINVAL;
   if (batch >= (1ull << 31)) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  memset(accept_bitmap, 0, (batch + 7) / 8);
+  TRY(refuse_if_pending(c));
   DeviceGuard g(c->device);
   Job job;
   job.d_dyn_scalars = (const uint32_t*)d_scalars;
@@ -1323,6 +1337,7 @@ int zkgpu_verify_batch(zkgpu_ctx* c, const uint8_t* scalars, const uint8_t* poin
   uint64_t n = 0;
   if (!offsets_ok(offsets, batch, &n) || (n && (!scalars || !points)) || batch >= (1ull << 31)) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  TRY(refuse_if_pending(c));
   DeviceGuard g(c->device);
   TRY(upload(c, c->in_scalars, scalars, n * 32));
   TRY(upload(c, c->in_points, points, n * 32));
@@ -1342,6 +1357,7 @@ int zkgpu_pointset_create(zkgpu_ctx* c, const uint8_t* points, size_t n, zkgpu_p
   if (!c || !out || (n && !points) || n >= (1ull << 30)) return ZKGPU_EINVAL;
   *out = nullptr;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  TRY(refuse_if_pending(c));
   DeviceGuard g(c->device);
   TRY(upload(c, c->in_points, points, n * 32));
   TRY(ensure(c, c->status, 64));
@@ -1563,6 +1579,8 @@ int zkgpu_verify_batch_ps_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t bat
   if (batch && (!d_dyn_offsets || !d_static_offsets)) return ZKGPU_EINVAL;
   if ((n_dyn && (!d_dyn_scalars || !d_dyn_points)) || (n_static && !d_static_scalars)) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  memset(accept_bitmap, 0, (batch + 7) / 8);
+  TRY(refuse_if_pending(c));
   DeviceGuard g(c->device);
   Job job;
   job.d_dyn_scalars = (const uint32_t*)d_dyn_scalars;
@@ -1595,6 +1613,7 @@ int zkgpu_verify_batch_ps(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, 
     for (size_t i = 0; i < batch; ++i) if (static_offsets[i + 1] - static_offsets[i] > ps->n) return ZKGPU_EINVAL;
   }
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  TRY(refuse_if_pending(c));
   {
     DeviceGuard g(c->device);
     TRY(upload(c, c->in_scalars, dyn_scalars, nd * 32));
@@ -1674,6 +1693,7 @@ int zkgpu_msm_ps_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, con
     for (size_t i = 0; i < batch; ++i) if (offsets[i + 1] - offsets[i] > ps->n) return ZKGPU_EINVAL;
   }
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  TRY(refuse_if_pending(c));
   DeviceGuard g(c->device);
   TRY(upload(c, c->in_st_scalars, scalars, n * 32));
   if (index) TRY(upload(c, c->in_st_index, index, n * 4));
@@ -1700,6 +1720,7 @@ int ipa_on_device(zkgpu_ctx* c, const zkgpu_pointset* ps, std::vector<std::uniqu
   for (size_t i = 0; i < batch; ++i)
     if (!pr[i]->at_ipa() || pr[i]->ipa_len() != pn) { c->last_error = "prover: statements of one batch must share one shape"; return ZKGPU_EINVAL; }
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  TRY(refuse_if_pending(c));
   DeviceGuard g(c->device);
   hipStream_t s = c->stream;
   const size_t vec = pn * 32, row_len = pn + 1, n_rows = 2 * batch;
@@ -1800,6 +1821,7 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
   const PvShape& sh = hp.sh;
   if (sh.proof_len > proof_stride) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  TRY(refuse_if_pending(c));
   DeviceGuard g(c->device);
   hipStream_t s = c->stream;
   const bool timing = getenv("ZKGPU_PROVER_TIMING") != nullptr;
@@ -2119,6 +2141,7 @@ int zkgpu_decode_check(zkgpu_ctx* c, const uint8_t* points, size_t n, uint8_t* o
   if (n == 0) return ZKGPU_OK;
   memset(ok, 0, n);
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  TRY(refuse_if_pending(c));
   DeviceGuard g(c->device);
   TRY(upload(c, c->in_points, points, n * 32));
   TRY(ensure(c, c->ok_bytes, n));
@@ -2245,7 +2268,10 @@ struct zkgpu_cloak_plan {
 
 namespace {
 int plan_upload_bytes(zkgpu_ctx* c, void** dst, const void* src, size_t bytes) {
-  HIP_TRY(c, hipMalloc(dst, std::max<size_t>(bytes, 16)));
+  {
+    const hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
+    if (e != hipSuccess) { *dst = nullptr; c->last_error = std::string("hipMalloc (plan): ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? ZKGPU_ENOMEM : ZKGPU_EHIP; }
+  }
   if (bytes) HIP_TRY(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
   return ZKGPU_OK;
 }
@@ -2254,10 +2280,12 @@ int plan_upload_bytes(zkgpu_ctx* c, void** dst, const void* src, size_t bytes) {
 
 namespace {
 bool desc_from_c(zkgpu_ctx* c, const zkgpu_r1cs_desc* d, R1csDesc& desc);
-// common tail of plan creation: p->host is set
-int plan_finish(zkgpu_ctx* c, zkgpu_cloak_plan* p, size_t gens_capacity, zkgpu_cloak_plan** out) {
+// common tail of plan creation: p->host is set.  Error codes matter to the callers that cache plans per shape
+// (session.hpp, verifier_plan): ZKGPU_EINVAL = this statement can never be verified over this generator set (what the
+// reference answers with InvalidGeneratorsLength); anything else (ZKGPU_ENOMEM, ZKGPU_EHIP) is transient.
+int plan_finish_inner(zkgpu_ctx* c, zkgpu_cloak_plan* p, size_t gens_capacity) {
   const CloakPlan& h = p->host;
-  if (h.pn > gens_capacity || h.k > 16) { delete p; c->last_error = "statement needs more generators than the set holds"; return ZKGPU_EINVAL; }
+  if (h.pn > gens_capacity || h.k > 16) { c->last_error = "statement needs more generators than the set holds"; return ZKGPU_EINVAL; }
   PrepShape& s = p->shape;
   s.m = h.m; s.n1 = h.n1; s.n = h.n; s.pn = h.pn; s.k = h.k; s.n_cons = h.n_cons;
   s.n_chal2 = (uint32_t)h.chal_names.size();
@@ -2297,7 +2325,7 @@ int plan_finish(zkgpu_ctx* c, zkgpu_cloak_plan* p, size_t gens_capacity, zkgpu_c
   }
   s = best;
   p->lds_bytes = best_bytes;
-  if (p->lds_bytes > 160 * 1024) { delete p; c->last_error = "plan does not fit the 160 KiB LDS of a CU"; return ZKGPU_EINVAL; }
+  if (p->lds_bytes > 160 * 1024) { c->last_error = "plan does not fit the 160 KiB LDS of a CU"; return ZKGPU_EINVAL; }
   // STROBE state after Transcript::new("ZkVM.r1cs") + r1cs_domain_sep()
   Transcript tr(h.label.c_str());
   tr.append_message("dom-sep", (const uint8_t*)"r1cs v1", 7);
@@ -2327,6 +2355,12 @@ int plan_finish(zkgpu_ctx* c, zkgpu_cloak_plan* p, size_t gens_capacity, zkgpu_c
     TRY(plan_upload(c, &p->d_term_coef, h.prod_coef));    //             prod_coef
   }
   HIP_TRY(c, hipFuncSetAttribute((const void*)k_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+  return ZKGPU_OK;
+}
+
+int plan_finish(zkgpu_ctx* c, zkgpu_cloak_plan* p, size_t gens_capacity, zkgpu_cloak_plan** out) {
+  const int rc = plan_finish_inner(c, p, gens_capacity);
+  if (rc != ZKGPU_OK) { zkgpu_cloak_plan_destroy(p); return rc; }     // whatever was uploaded so far goes with it
   *out = p;
   return ZKGPU_OK;
 }
@@ -2809,6 +2843,7 @@ int zkgpu_msm_batch(zkgpu_ctx* c, const uint8_t* scalars, const uint8_t* points,
   uint64_t n = 0;
   if (!offsets_ok(offsets, batch, &n) || (n && (!scalars || !points)) || batch >= (1ull << 31)) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  TRY(refuse_if_pending(c));
   DeviceGuard g(c->device);
   TRY(upload(c, c->in_scalars, scalars, n * 32));
   TRY(upload(c, c->in_points, points, n * 32));
@@ -2828,6 +2863,7 @@ int zkgpu_hash_to_points(zkgpu_ctx* c, const uint8_t* uniform, size_t n, uint8_t
   if (!c || (n && (!uniform || !out))) return ZKGPU_EINVAL;
   if (n == 0) return ZKGPU_OK;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  TRY(refuse_if_pending(c));
   DeviceGuard g(c->device);
   TRY(upload(c, c->uniform, uniform, 64 * n));
   TRY(ensure(c, c->values, 32 * n));
@@ -2872,6 +2908,42 @@ int zkgpu_bulletproof_gens(zkgpu_ctx* c, size_t capacity, uint32_t party, uint8_
     sp.squeeze(stream.data(), stream.size());
     TRY(zkgpu_hash_to_points(c, stream.data(), capacity, side ? H : G));
   }
+  return ZKGPU_OK;
+}
+
+// Achievable HBM bandwidth by a streaming copy of `bytes` bytes (read + written: 2 x bytes per launch), best of `iters`
+// launches timed with HIP events on the context's stream; *gbytes_per_s = 2 * bytes / time / 1e9.
+int zkgpu_measure_hbm_copy(zkgpu_ctx* c, size_t bytes, int iters, double* gbytes_per_s) {
+  if (!c || !gbytes_per_s || bytes < (1u << 20) || iters < 1 || iters > 1000) return ZKGPU_EINVAL;
+  *gbytes_per_s = 0;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  bytes &= ~(size_t)15;
+  void *a = nullptr, *b = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc(&a, bytes);
+  if (e == hipSuccess) e = hipMalloc(&b, bytes);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = hipMemsetAsync(a, 0x5a, bytes, c->stream);
+  float best = 0;
+  // enough workgroups for every CU to hold its full complement of wavefronts several times over
+  const unsigned blocks = 256 * 32;
+  for (int it = 0; e == hipSuccess && it <= iters; ++it) {        // (the first launch warms up and is not counted)
+    (void)hipEventRecord(e0, c->stream);
+    hipLaunchKernelGGL(k_hbm_copy, dim3(blocks), dim3(256), 0, c->stream, (const uint4*)(it & 1 ? b : a), (uint4*)(it & 1 ? a : b), (uint64_t)(bytes / 16));
+    (void)hipEventRecord(e1, c->stream);
+    e = hipEventSynchronize(e1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess && it > 0 && (best == 0 || ms < best)) best = ms;
+  }
+  if (a) (void)hipFree(a);
+  if (b) (void)hipFree(b);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (e != hipSuccess) { c->last_error = std::string("zkgpu_measure_hbm_copy: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? ZKGPU_ENOMEM : ZKGPU_EHIP; }
+  *gbytes_per_s = best > 0 ? 2.0 * (double)bytes / (best * 1e-3) / 1e9 : 0.0;
   return ZKGPU_OK;
 }
 

@@ -147,6 +147,10 @@ def load_library():
     lib.zkgpu_comm_allgather_bitmap.argtypes = [vp, u64p, u8p, C.c_int, u8p]
     lib.zkgpu_verifier_verify_sharded.argtypes = [vp, vp, sz, u32p, u32p, u8p, u8p, u64p, u8p, u8p]
     lib.zkgpu_tx_verify_batch.argtypes = [vp, sz, u8p, u64p, C.c_int, u8p, u8p]
+    lib.zkgpu_verifier_set_tx_format.argtypes = [vp, C.c_int]
+    lib.zkgpu_measure_hbm_copy.argtypes = [vp, sz, C.c_int, C.POINTER(C.c_double)]
+    lib.zkgpu_debug_comm_mock.argtypes = [vp, C.c_int, u8p, sz]
+    lib.zkgpu_debug_comm_mock.restype = C.c_longlong
     lib.zkgpu_verifier_submit_many_dev.argtypes = [vp, C.c_uint32, C.c_uint32, sz, sz, vp, vp, sz, vp, vp]
     lib.zkgpu_r1cs_plan_create.argtypes = [vp, vp, sz, C.POINTER(vp)]
     lib.zkgpu_r1cs_plan_destroy.argtypes = [vp]
@@ -240,6 +244,12 @@ class Context:
 
     def free_device(self, d_ptr: int) -> None:
         self._check(self.lib.zkgpu_free(self.h, C.c_void_p(d_ptr)))
+
+    def measure_hbm_copy(self, nbytes: int = 1 << 30, iters: int = 10) -> float:
+        """zkgpu_measure_hbm_copy: achievable HBM bandwidth of a streaming copy, GB/s (read + written)"""
+        out = C.c_double(0.0)
+        self._check(self.lib.zkgpu_measure_hbm_copy(self.h, nbytes, iters, C.byref(out)))
+        return float(out.value)
 
     def set_group_size(self, group: int) -> None:
         """zkgpu_set_group_size: transactions per group check of the whole-proof paths (1 = none)."""

@@ -242,9 +242,17 @@ class BlockVerifier:
         self._check(self.lib.zkgpu_verifier_block_finish(self.h, run, bm))
         return bm.raw[: (n + 7) // 8]
 
+    TXFORMAT_RECOLLECTED_V1 = 1
+
+    def set_tx_format(self, fmt: int) -> None:
+        """zkgpu_verifier_set_tx_format: the serialized-transaction format zkgpu_tx_verify_batch reads.  0 (the default):
+        none -- every transaction is reported as outside the subset; TXFORMAT_RECOLLECTED_V1: the payment subset of
+        DESIGN.md sec 4.5, an UNPINNED recollection of the ZkVM wire format (opt-in for exactly that reason)."""
+        self._check(self.lib.zkgpu_verifier_set_tx_format(self.h, fmt))
+
     def verify_txs(self, txs: Sequence[bytes], host_threads: int = 0):
         """zkgpu_tx_verify_batch: serialized ZkVM transactions (payment subset) -> (accept bitmap, status bytes:
-        0 accepted, 1 rejected, 2 outside the subset)"""
+        0 accepted, 1 rejected, 2 outside the subset).  Inert until set_tx_format names a format."""
         return self.verify_txs_packed(b"".join(txs), [len(t) for t in txs], host_threads)
 
     def verify_txs_packed(self, blob: bytes, lengths, host_threads: int = 0):
