@@ -558,7 +558,8 @@ def run_config2(args, W):
     # randomness.  The ring is as long as the longest run of this process, so no batch is ever submitted twice while
     # anything that met it could still sit in a cache: 1.35 MB per step in HBM.
     steady_steps = 0 if (args.lean or args.solo or args.no_steady or world > 1) else 200
-    n_sets = max(args.steps + max(args.warmup, 1), steady_steps, 2 * args.merge // batch + 2, 24)
+    lanes_planned = args.inflight if args.tickets > 0 else 1
+    n_sets = max(args.steps + max(args.warmup, 1, lanes_planned * (args.merge // batch)), steady_steps, 2 * args.merge // batch + 2, 24)
     sets = []
     for sidx in range(n_sets):
         txs, expected = workload_2x2(batch, rank, args.bad_every, sidx)
@@ -701,6 +702,11 @@ def run_config2(args, W):
 
     timed = run_tickets if bv is not None else run_steps
     n_warm = max(args.warmup, 1)
+    # Workspace priming (setup, untimed, as the table build is): every lane executes one device batch of the size the
+    # timed steps will give it, so that its workspace exists -- the library never allocates in steady state, but a lane's
+    # FIRST batch of a new size does (hipMalloc synchronises the device).  Then the W warm-up steps proper.
+    n_prime = (bv.lanes() * rep if bv is not None else len(ctxs))
+    timed(n_prime, base=args.steps, gather=False)
     timed(n_warm, base=args.steps)                            # warm-up on sets the timed steps do not use
     # HIP events around every launch of the contexts in flight
     prof_ctxs = [bv.lane(i) for i in range(bv.lanes())] if bv is not None else ctxs[:1]

@@ -507,7 +507,6 @@ def test_benched_arrangement_tickets_merged_into_device_batches_vs_oracle(ctx, o
     groups of 16, inputs resident in HBM: every accept bit of every ticket against the oracle's full verifier (and against
     the constructed expectation bench.py asserts); then the steady-state form: 40 more tickets, 64 in flight at most,
     submitted one by one as earlier ones are waited for."""
-    import torch
     from gpu_util import benched_randomness, benched_step
     from zkvm_amd.verifier import BlockVerifier, BulletproofGens
     n_steps, batch, merge = 20, 1024, 10240
@@ -515,7 +514,6 @@ def test_benched_arrangement_tickets_merged_into_device_batches_vs_oracle(ctx, o
     bv = BlockVerifier(ctx, gens, batches_in_flight=5)
     bv.set_merge(merge)
     assert bv.lanes() == 5
-    dev = torch.device("cuda", 0)
     sets = []
     try:
         for s in range(n_steps + 40):
@@ -526,10 +524,9 @@ def test_benched_arrangement_tickets_merged_into_device_batches_vs_oracle(ctx, o
             if s < n_steps or s % 8 == 0:
                 want = list(oracle.cloak_verify_batch(com, n_in, n_out, proofs, plen, r, threads=16))
                 assert want == expected, s                          # the bench's constructed expectation IS the oracle's verdict
-            t = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (com, proofs, r)]
+            t = [ctx.to_device(b) for b in (com, proofs, r)]        # (zkgpu_malloc + zkgpu_upload: device pointers)
             sets.append((t, expected))
         assert len({bytes(e) for _, e in sets[:n_steps]}) > 10      # the verdict pattern differs from step to step
-        torch.cuda.synchronize()
         for _ in range(2):                                          # twice: cold and warm workspace
             tickets = bv.submit_many_dev(n_in, n_out, batch, [t[0] for t, _ in sets[:n_steps]], [t[1] for t, _ in sets[:n_steps]], plen,
                                          [t[2] for t, _ in sets[:n_steps]])
@@ -546,6 +543,9 @@ def test_benched_arrangement_tickets_merged_into_device_batches_vs_oracle(ctx, o
             assert bits(bv.wait(tk), batch) == sets[k][1], k
     finally:
         bv.close()
+        for t, _ in sets:
+            for d in t:
+                ctx.free_device(d)
         gens.close()
 
 
