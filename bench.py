@@ -550,6 +550,7 @@ def run_config2(args, W):
     gens = BulletproofGens(ctx, 256, table_bits=args.table_bits)
     table_s = time.perf_counter() - t0
     table_bytes = int(lib.zkgpu_pointset_table_bytes(gens.points.h))
+    args.table_bits = gens.points.table_bits()           # (-1: what the library chose)
 
     def to_dev(b, dtype=torch.uint8):
         return torch.frombuffer(bytearray(b), dtype=dtype).to(dev)
@@ -959,6 +960,7 @@ def run_config4(args, W):
     gens = BulletproofGens(ctx, 512, table_bits=args.table_bits)
     table_s = time.perf_counter() - t0
     table_bytes = int(lib.zkgpu_pointset_table_bytes(gens.points.h))
+    args.table_bits = gens.points.table_bits()
     bv = BlockVerifier(ctx, gens, batches_in_flight=args.inflight, chunk=args.chunk)
     for i in range(bv.lanes()):
         bv.lane(i).set_group_size(args.group)
@@ -1097,7 +1099,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=(2, 4),
                     help="2: BASELINE configs[1], 1024 2x2 tx per GPU (default, the headline); 4: configs[3], mixed arity, sharded")
     ap.add_argument("--batch", type=int, default=1024, help="transactions per GPU (config 4: default 8192)")
-    ap.add_argument("--table-bits", type=int, default=16, help="window width of the fixed-base generator tables")
+    ap.add_argument("--table-bits", type=int, default=-1, help="window width of the fixed-base generator tables (-1: the library chooses by capacity and free HBM: 16 on an MI355X)")
     ap.add_argument("--inflight", type=int, default=0,
                     help="device batches in flight per GPU (contexts): default 5 with --tickets, 6 without, 6 for config 4")
     ap.add_argument("--group", type=int, default=16, help="transactions per group check (1 = every transaction on its own)")

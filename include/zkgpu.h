@@ -96,8 +96,13 @@ size_t zkgpu_pointset_size(const zkgpu_pointset *ps);
  * entry point sum static terms straight out of them: one mixed addition per term and window,
  * no doublings, no sorting.  One-time cost: ~0.2 s at 16 bits and 514 points (50 MB per point),
  * milliseconds at 8-12 bits; results are identical with or without tables.
- * 2 <= window_bits <= 16. */
+ * 2 <= window_bits <= 16, or 0: the library chooses -- the widest width, at most 16, whose tables take no more than a quarter
+ * of the device's memory and whose construction (the tables + 1.7x scratch) fits in 60 % of what is free at the time of the
+ * call (zkgpu_choose_table_bits answers the same question without building; zkgpu_pointset_table_bits: the width in use, 0
+ * without tables).  Fewer bits cost throughput gently (bench.py, setup.table_bits_sweep: 13 .. 16 bits measured). */
 int zkgpu_pointset_build_tables(zkgpu_ctx *ctx, zkgpu_pointset *ps, int window_bits);
+int zkgpu_choose_table_bits(zkgpu_ctx *ctx, size_t n_points);
+int zkgpu_pointset_table_bits(const zkgpu_pointset *ps);
 size_t zkgpu_pointset_table_bytes(const zkgpu_pointset *ps);
 
 /* Values of `batch` multiscalar multiplications over a resident set with tables:

@@ -354,3 +354,35 @@ def test_msm_values_over_resident_set(ctx, oracle, w):
     val = ctx.msm_ps_batch(ps2, b"".join(k.to_bytes(32, "little") for k in ks), [0, len(ks)])
     assert val == oracle.encode(oracle.msm_points("vartime", ks, [oracle.decode(allp[32 * j: 32 * j + 32]) for j in range(130)]))
     ps2.close()
+
+
+def test_table_width_is_chosen_by_capacity_and_free_memory(ctx, oracle):
+    """zkgpu_pointset_build_tables(.., 0): the library picks the window width -- 16 bits for the 514 generators of the
+    2-in/2-out statement on a 288 GB MI355X, fewer for sets whose tables would not fit a quarter of the device -- and the
+    verdicts are the same whatever the width (here against a set built at 9 bits)."""
+    import ctypes as C
+    lib = ctx.lib
+    assert lib.zkgpu_choose_table_bits(ctx.h, 514) == 16
+    assert lib.zkgpu_choose_table_bits(ctx.h, 1026) == 16
+    w_big = lib.zkgpu_choose_table_bits(ctx.h, 200000)
+    assert 4 <= w_big < 14
+    assert lib.zkgpu_choose_table_bits(ctx.h, 0) == -1
+    from zkvm_amd.verifier import BulletproofGens, CloakTx, Verifier
+    auto = BulletproofGens(ctx, 64, table_bits=-1)
+    nine = BulletproofGens(ctx, 64, table_bits=9)
+    try:
+        assert auto.points.table_bits() == 16 and nine.points.table_bits() == 9
+        assert lib.zkgpu_pointset_table_bytes(auto.points.h) == 16 * 130 * 32768 * 96
+        com, proofs = oracle.cloak_prove_batch(3, 1, 1, b"auto width".ljust(32, b"\0"), threads=3)      # 1-in/1-out: 64 generators
+        bad = bytearray(proofs[1]); bad[-40] ^= 1
+        txs = [CloakTx(1, 1, com[128 * i: 128 * (i + 1)], bytes(bad) if i == 1 else proofs[i]) for i in range(3)]
+        r = bytes(range(192))
+        got = []
+        for g in (auto, nine):
+            v = Verifier(ctx, g)
+            got.append(bits(v.verify_bitmap_gpu(txs, r), 3))
+            v.close()
+        assert got[0] == got[1] == [1, 0, 1]
+    finally:
+        auto.close()
+        nine.close()

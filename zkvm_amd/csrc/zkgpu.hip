@@ -1392,8 +1392,37 @@ void zkgpu_pointset_destroy(zkgpu_pointset* ps) {
 
 size_t zkgpu_pointset_size(const zkgpu_pointset* ps) { return ps ? ps->n : 0; }
 
+// bytes of the tables of n points at w bits, and of the scratch their construction needs beside them
+static inline uint64_t table_bytes_for(uint64_t n, int w) { return (uint64_t)(255 / w + 1) * n * (1ull << (w - 1)) * TABLE_WORDS * 4; }
+static inline uint64_t table_build_bytes_for(uint64_t n, int w) {
+  const uint64_t lanes = (uint64_t)(255 / w + 1) * n;
+  return table_bytes_for(n, w) + lanes * (1ull << (w - 1)) * EXT_WORDS * 4 + lanes * EXT_WORDS * 4;
+}
+
+// window_bits == 0: the library chooses.  Wider windows mean fewer mixed additions per generator term (255/w + 1 of them:
+// 16 at 16 bits, 20 at 13) and exponentially more table: the widest width, at most 16, whose tables take no more than a
+// quarter of the device's memory and whose construction (tables + 1.7x scratch) fits in 60 % of what is free right now.
+// On a 288 GB MI355X: 16 bits up to ~1400 points (two sets of 514 / 1026 points fit side by side), 15 bits up to ~2800, ...
+// Measured throughput by width: bench.py, setup.table_bits_sweep.
+int zkgpu_choose_table_bits(zkgpu_ctx* c, size_t n_points) {
+  if (!c || n_points == 0) return ZKGPU_EINVAL;
+  DeviceGuard g(c->device);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return ZKGPU_EHIP;
+  for (int w = 16; w >= 4; --w)
+    if (table_bytes_for(n_points, w) <= total_b / 4 && table_build_bytes_for(n_points, w) <= free_b / 10 * 6) return w;
+  return 4;
+}
+
+int zkgpu_pointset_table_bits(const zkgpu_pointset* ps) { return (ps && ps->table) ? ps->tbl_w : 0; }
+
 int zkgpu_pointset_build_tables(zkgpu_ctx* c, zkgpu_pointset* ps, int window_bits) {
-  if (!c || !ps || ps->ctx != c || window_bits < 2 || window_bits > 16 || ps->n == 0) return ZKGPU_EINVAL;  // digits are int16
+  if (!c || !ps || ps->ctx != c || ps->n == 0) return ZKGPU_EINVAL;
+  if (window_bits == 0) {
+    window_bits = zkgpu_choose_table_bits(c, ps->n);
+    if (window_bits < 0) return window_bits;
+  }
+  if (window_bits < 2 || window_bits > 16) return ZKGPU_EINVAL;  // digits are int16
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   DeviceGuard g(c->device);
   if (ps->table) { HIP_TRY(c, hipFree(ps->table)); ps->table = nullptr; }

@@ -68,6 +68,8 @@ def load_library():
     lib.zkgpu_verify_batch_ps_dev.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, sz, u8p]
     lib.zkgpu_pointset_build_tables.argtypes = [vp, vp, C.c_int]
     lib.zkgpu_pointset_table_bytes.argtypes = [vp]
+    lib.zkgpu_choose_table_bits.argtypes = [vp, sz]
+    lib.zkgpu_pointset_table_bits.argtypes = [vp]
     lib.zkgpu_pointset_table_bytes.restype = sz
     lib.zkgpu_cloak_prove_batch.argtypes = [vp, vp, sz, sz, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), u8p, u8p, C.c_int,
                                             u8p, u8p, sz, C.POINTER(sz)]
@@ -198,8 +200,12 @@ class PointSet:
     def __len__(self) -> int:
         return int(self.ctx.lib.zkgpu_pointset_size(self.h))
 
+    def table_bits(self) -> int:
+        """zkgpu_pointset_table_bits: the window width of the tables in use (0: none)"""
+        return int(self.ctx.lib.zkgpu_pointset_table_bits(self.h))
+
     def build_tables(self, window_bits: int) -> int:
-        """Fixed-base window tables (one-time); returns their size in bytes."""
+        """Fixed-base window tables (one-time; window_bits 0: the library chooses by capacity and free HBM); returns their size in bytes."""
         self.ctx._check(self.ctx.lib.zkgpu_pointset_build_tables(self.ctx.h, self.h, window_bits))
         return int(self.ctx.lib.zkgpu_pointset_table_bytes(self.h))
 

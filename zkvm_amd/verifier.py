@@ -48,8 +48,8 @@ class BulletproofGens:
         b, bb = ctx.pedersen_gens()
         g, h = ctx.bulletproof_gens(gens_capacity)
         self.points = PointSet(ctx, b + bb + g + h)
-        if table_bits:
-            self.points.build_tables(table_bits)
+        if table_bits:                 # -1: the library chooses the width (zkgpu_pointset_build_tables(.., 0)); 0: no tables
+            self.points.build_tables(0 if table_bits < 0 else table_bits)
 
     def close(self) -> None:
         self.points.close()
