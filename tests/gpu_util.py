@@ -49,16 +49,27 @@ def benched_step(batch: int, rank: int, bad_every: int = 64, step: int = 0):
     """BASELINE configs[1], one step of bench.py: the committed distinct proofs, ~1.5 % corrupted -> (txs, expected bits).
     Every STEP is a batch of its own: the fixture rotated by 31 per step (37 per rank), its own corrupted positions and
     kinds -- and its own verifier randomness (benched_randomness) -- so that no two batches in flight, and no two merged
-    into one device batch, repeat each other's scalars, table rows or verdict pattern."""
+    into one device batch, repeat each other's scalars, table rows or verdict pattern.  The batch / bad_every corrupted
+    positions are DRAWN (SHAKE256 of rank and step), not spaced evenly: the verifier checks transactions in groups, and
+    what a failed group costs depends on how many bad transactions it holds -- evenly spaced ones would never share a
+    group."""
     fixture, n_in, n_out, _ = load_cloak_fixture("cloak_2x2_1024.bin")
     txs, expected = [], []
     rot = 37 * rank + 31 * step
+    bad = {}
+    if bad_every:
+        raw = hashlib.shake_256(b"zkvm_amd bench corruptions|%d|%d" % (rank, step)).digest(8 * batch)
+        k = 0
+        while len(bad) < max(1, batch // bad_every) and k < batch:
+            pos = int.from_bytes(raw[8 * k: 8 * k + 4], "little") % batch
+            bad.setdefault(pos, raw[8 * k + 4] % 3)
+            k += 1
     for i in range(batch):
         com, proof = fixture[(i + rot) % len(fixture)]
         ok = 1
-        if bad_every and (i + 5 * step) % bad_every == 7 % bad_every:
+        if i in bad:
             ok = 0
-            c = ((i + 5 * step) // bad_every + step) % 3
+            c = bad[i]
             if c == 0:      # commitment that is not a ristretto255 encoding
                 com = com[:96] + BAD_POINT + com[128:]
             elif c == 1:    # IPA scalar a off by one (still canonical)
