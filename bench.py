@@ -351,7 +351,8 @@ def tx_verify_microbench(ctx, gens, host_threads: int):
         assert bm == bitmap_of([1] * len(txs)) and not any(st), "a committed transaction was not accepted"
         # the same transactions eight times over in one call (one buffer + lengths, as a node would hand a block over)
         big = txs * 8
-        blob, lens = b"".join(big), [len(t) for t in big]
+        import numpy as np
+        blob, lens = b"".join(big), np.asarray([len(t) for t in big], dtype=np.uint64)
         bv.verify_txs_packed(blob, lens, host_threads)
         best8 = None
         for _ in range(3):

@@ -475,9 +475,14 @@ int zkgpu_verifier_wait(zkgpu_verifier *v, uint64_t ticket, uint8_t *accept_bitm
  * zkgpu_verifier_set_tx_format(v, ZKGPU_TXFORMAT_RECOLLECTED_V1).  Both outputs are fail-closed: status 0 is written
  * only beside an accept bit of 1, after every stage has passed; on any error every transaction inside the subset reads
  * "rejected" and the bitmap is zero.  The call holds the verifier for its whole length and first collects whatever its
- * lanes have in flight (tickets and blocks keep their verdicts). */
+ * lanes have in flight (tickets and blocks keep their verdicts).
+ * Inside, the call is cut into chunks (default ~3000 transactions; zkgpu_verifier_set_tx_chunk, 0 = automatic) that travel
+ * through four stages -- VM on the host threads; the cloak proofs staged through pinned memory and queued on the lanes;
+ * the aggregated keys, then the signature equations, on two contexts of their own -- so that the host's share of one
+ * chunk runs beside the device's share of the others, from ONE calling thread. */
 #define ZKGPU_TXFORMAT_RECOLLECTED_V1 1
 int zkgpu_verifier_set_tx_format(zkgpu_verifier *v, int format);
+int zkgpu_verifier_set_tx_chunk(zkgpu_verifier *v, size_t transactions);
 int zkgpu_tx_verify_batch(zkgpu_verifier *v, size_t batch, const uint8_t *txs, const uint64_t *tx_offsets, int host_threads,
                           uint8_t *accept_bitmap, uint8_t *status);
 

@@ -199,6 +199,64 @@ def test_the_1024_fixture_transactions_on_the_device():
         ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tx_chunk", [0, 1000])
+def test_a_long_call_travels_through_the_stages_in_chunks(tx_chunk):
+    """zkgpu_tx_verify_batch on 7168 transactions in ONE call: the call is cut into chunks whose host stages (VM, signature
+    transcripts) run beside the device stages of the others (aggregated keys, signature equations, cloak proofs on the
+    lanes) -- with the default chunking (three chunks, the last one short) and with chunks of 1000 (eight chunks: the
+    staging ring of four is reused).  Sixty transactions are damaged in every part, in every chunk: their verdicts are the
+    oracle's Tx::verify, everybody else's is "accepted"; and status 0 appears exactly beside accept bits of 1."""
+    import random
+    import sys
+    import oracle.binding as oracle
+    sys.path.insert(0, os.path.dirname(__file__))
+    from gpu_util import load_tx_fixture
+    from zkvm_amd import Context
+    from zkvm_amd.verifier import BulletproofGens, BlockVerifier
+    base = load_tx_fixture()
+    txs = [base[i % 1024] for i in range(7168)]
+    rng = random.Random(77 + tx_chunk)
+    damaged = {}
+    for i in sorted(rng.sample(range(len(txs)), 60)):
+        t = bytearray(txs[i])
+        plen = struct.unpack("<I", t[24:28])[0]
+        kind = len(damaged) % 6
+        if kind == 0:
+            t[28 + plen + 32 + rng.randrange(31)] ^= 1 << rng.randrange(8)      # signature scalar s
+        elif kind == 1:
+            t[28 + plen + rng.randrange(32)] ^= 1 << rng.randrange(8)           # signature point R
+        elif kind == 2:
+            t[28 + rng.randrange(plen)] ^= 1 << rng.randrange(8)                # somewhere in the program
+        elif kind == 3:
+            t[len(t) - 1 - rng.randrange(900)] ^= 1 << rng.randrange(8)         # somewhere in the proof
+        elif kind == 4:
+            t[0] = 2                                                            # another version: outside the subset
+        else:
+            t = t[: len(t) - 1 - rng.randrange(40)]                             # truncated
+        txs[i] = bytes(t)
+        damaged[i] = None
+    r = hashlib.shake_256(b"long call").digest(64)
+    for i in damaged:
+        damaged[i] = oracle.tx_verify(txs[i], r)
+    assert set(damaged.values()) == {1, 2} or set(damaged.values()) == {0, 1, 2}       # (a flipped bit may land in dead bytes)
+    ctx = Context(0)
+    gens = BulletproofGens(ctx, 256, table_bits=12)
+    bv = BlockVerifier(ctx, gens)
+    bv.set_tx_format(bv.TXFORMAT_RECOLLECTED_V1)
+    bv.set_tx_chunk(tx_chunk)
+    try:
+        for _ in range(2):
+            bm, st = bv.verify_txs(txs, host_threads=8)
+            want_status = [damaged.get(i, 0) for i in range(len(txs))]
+            assert list(st) == want_status
+            assert [(bm[i // 8] >> (i % 8)) & 1 for i in range(len(txs))] == [1 if w == 0 else 0 for w in want_status]
+    finally:
+        bv.close()
+        gens.close()
+        ctx.close()
+
+
 def test_random_programs_get_the_same_verdict_from_both_implementations(host, oracle):
     """Differential fuzzing of the two independently written VMs (zkvm_tx.hpp, oracle/zkvm_tx.c): random instruction
     sequences over the subset's opcodes (and a few outside it), random immediates, spliced fragments of a valid program --

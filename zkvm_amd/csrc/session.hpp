@@ -58,6 +58,17 @@ struct zkgpu_verifier {
   std::map<uint64_t, std::unique_ptr<BlockRun>> block_runs;
   uint64_t next_run = 1;
   int tx_format = 0;                                    // zkgpu_verifier_set_tx_format: 0 = no serialized-transaction format enabled
+  // zkgpu_tx_verify_batch: two contexts of their own for the key and the signature stages (each a pair of streams beside
+  // the lanes'), and a ring of staging areas (pinned host + device, grow-only) for the cloak statements of the chunks in
+  // flight -- nothing on that path allocates or frees device memory once the sizes have been seen (hipFree synchronises)
+  zkgpu_ctx* aux_keys = nullptr;
+  zkgpu_ctx* aux_sigs = nullptr;
+  struct TxArena { void* h_pin = nullptr; size_t h_cap = 0; char* dev = nullptr; size_t d_cap = 0; hipEvent_t copied = nullptr; };
+  hipStream_t copy_stream = nullptr;                    // staging copies run here; the lanes wait for TxArena::copied
+  std::vector<TxArena> tx_arenas;
+  size_t tx_chunk = 0;                                  // transactions per chunk of zkgpu_tx_verify_batch (0: automatic)
+  uint8_t basepoint[32] = {0};                          // encoding of B, computed once (the signature equations name it)
+  bool have_basepoint = false;
   std::mutex mu;
   std::string last_error;
 };
@@ -65,6 +76,8 @@ struct zkgpu_verifier {
 struct zkgpu_txblock {
   zkgpu_verifier* v = nullptr;
   size_t batch = 0;
+  bool owns_dev = true;                                 // false: `dev` is a staging area of the verifier (tx path)
+  hipEvent_t ready = nullptr;                           // set: the copy to `dev` is still queued; batches wait for this event
   struct Group {
     uint32_t n_in, n_out;
     size_t proof_len;
@@ -245,6 +258,13 @@ void zkgpu_verifier_destroy(zkgpu_verifier* v) {
   (void)drain(v, scratch);
   for (auto& kv : v->requests) delete kv.second;
   for (size_t i = 1; i < v->lanes.size(); ++i) zkgpu_destroy(v->lanes[i]);
+  if (v->aux_keys) zkgpu_destroy(v->aux_keys);
+  if (v->aux_sigs) zkgpu_destroy(v->aux_sigs);
+  {
+    DeviceGuard g(v->root->device);
+    for (auto& a : v->tx_arenas) { if (a.h_pin) (void)hipHostFree(a.h_pin); if (a.dev) (void)hipFree(a.dev); if (a.copied) (void)hipEventDestroy(a.copied); }
+    if (v->copy_stream) (void)hipStreamDestroy(v->copy_stream);
+  }
   for (auto& kv : v->plans) if (kv.second) zkgpu_cloak_plan_destroy(kv.second);
   delete v;
 }
@@ -270,7 +290,7 @@ uint64_t zkgpu_cloak_msm_terms(uint32_t n_in, uint32_t n_out) { return cloak_msm
 
 void zkgpu_txblock_destroy(zkgpu_txblock* b) {
   if (!b) return;
-  if (b->dev) { DeviceGuard g(b->v->root->device); (void)hipFree(b->dev); }
+  if (b->dev && b->owns_dev) { DeviceGuard g(b->v->root->device); (void)hipFree(b->dev); }
   delete b;
 }
 
@@ -285,7 +305,8 @@ struct TxSource { uint32_t n_in, n_out; const uint8_t* com; const uint8_t* proof
 // groups the transactions by (inputs, outputs, proof length), lays the groups out, gathers them on host threads and
 // copies the block to HBM
 // (v->mu held: the plans and last_error are the verifier's)
-int txblock_build_locked(zkgpu_verifier* v, size_t batch, const TxSource* src, const uint8_t* r_bytes, int host_threads, zkgpu_txblock** out) {
+int txblock_build_locked(zkgpu_verifier* v, size_t batch, const TxSource* src, const uint8_t* r_bytes, int host_threads, zkgpu_txblock** out,
+                         zkgpu_verifier::TxArena* arena = nullptr) {
   zkgpu_ctx* c = v->root;
   std::unique_ptr<zkgpu_txblock> b(new zkgpu_txblock());
   b->v = v; b->batch = batch;
@@ -332,25 +353,71 @@ int txblock_build_locked(zkgpu_verifier* v, size_t batch, const TxSource* src, c
   double tb1 = 0, tb2 = 0;
   if (total) {
     DeviceGuard dg(c->device);
-    std::unique_ptr<uint8_t[]> host(new uint8_t[total]);
+    std::unique_ptr<uint8_t[]> owned;
+    uint8_t* host = nullptr;
+    if (arena) {                                        // the verifier's staging area: pinned host memory, device memory kept
+      if (arena->h_cap < total) {
+        if (arena->h_pin) (void)hipHostFree(arena->h_pin);
+        arena->h_pin = nullptr; arena->h_cap = 0;
+        const size_t want = total + total / 4 + 4096;
+        if (hipHostMalloc(&arena->h_pin, want, hipHostMallocDefault) != hipSuccess) { v->last_error = "hipHostMalloc (transaction staging)"; return ZKGPU_ENOMEM; }
+        arena->h_cap = want;
+      }
+      if (arena->d_cap < total) {
+        if (arena->dev) (void)hipFree(arena->dev);
+        arena->dev = nullptr; arena->d_cap = 0;
+        const size_t want = total + total / 4 + 4096;
+        if (hipMalloc((void**)&arena->dev, want) != hipSuccess) { v->last_error = "hipMalloc (transaction staging)"; return ZKGPU_ENOMEM; }
+        arena->d_cap = want;
+      }
+      host = (uint8_t*)arena->h_pin;
+    } else {
+      owned.reset(new uint8_t[total]);
+      host = owned.get();
+    }
+    // verifier randomness when the caller gives none: 32 bytes from the OS (getrandom(2)) per block, expanded per
+    // transaction with SHAKE256(seed || position) on the gathering threads -- getrandom itself delivers ~0.35 GB/s on one
+    // thread, which for 64 bytes per transaction would be a quarter of this stage's time
+    uint8_t seed[40] = {0};
+    if (!r_bytes && !os_random(seed, 32)) { v->last_error = "getrandom failed"; return ZKGPU_EINVAL; }
     host_parallel(batch, host_threads, [&](size_t i) {
       const zkgpu_txblock::Group& g = b->groups[group_of[i]];
       if (!g.plan) return;
       const size_t wcom = 64 * ((size_t)g.n_in + g.n_out), j = slot[i];
       memcpy(&host[g.com_off + j * wcom], src[i].com, wcom);
       memcpy(&host[g.proof_off + j * g.proof_len], src[i].proof, g.proof_len);
-      if (r_bytes) memcpy(&host[g.r_off + j * 64], r_bytes + 64 * i, 64);
+      if (r_bytes) {
+        memcpy(&host[g.r_off + j * 64], r_bytes + 64 * i, 64);
+      } else {
+        uint8_t in[40];
+        memcpy(in, seed, 32);
+        for (int q = 0; q < 8; ++q) in[32 + q] = (uint8_t)((uint64_t)i >> (8 * q));
+        Sponge sp = shake256_sponge();
+        sp.absorb(in, 40);
+        sp.squeeze(&host[g.r_off + j * 64], 64);
+      }
     });
     tb1 = now();
-    if (!r_bytes)
-      for (auto& g : b->groups)
-        if (g.plan && !os_random(&host[g.r_off], g.idx.size() * 64)) { v->last_error = "getrandom failed"; return ZKGPU_EINVAL; }
     tb2 = now();
-    hipError_t e = hipMalloc((void**)&b->dev, total);
-    if (e != hipSuccess) { v->last_error = std::string("hipMalloc: ") + hipGetErrorString(e); b->dev = nullptr; return ZKGPU_ENOMEM; }
+    if (arena) {
+      b->dev = arena->dev;
+      b->owns_dev = false;
+    } else {
+      hipError_t e = hipMalloc((void**)&b->dev, total);
+      if (e != hipSuccess) { v->last_error = std::string("hipMalloc: ") + hipGetErrorString(e); b->dev = nullptr; return ZKGPU_ENOMEM; }
+    }
     b->dev_bytes = total;
-    e = hipMemcpy(b->dev, host.get(), total, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { v->last_error = hipGetErrorString(e); (void)hipFree(b->dev); b->dev = nullptr; return ZKGPU_EHIP; }
+    hipError_t e;
+    if (arena) {                                        // queued on the copy stream: the host goes on, the lanes wait for the event
+      e = v->copy_stream ? hipSuccess : hipStreamCreateWithFlags(&v->copy_stream, hipStreamNonBlocking);
+      if (e == hipSuccess && !arena->copied) e = hipEventCreateWithFlags(&arena->copied, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipMemcpyAsync(b->dev, host, total, hipMemcpyHostToDevice, v->copy_stream);
+      if (e == hipSuccess) e = hipEventRecord(arena->copied, v->copy_stream);
+      if (e == hipSuccess) b->ready = arena->copied;
+    } else {
+      e = hipMemcpy(b->dev, host, total, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { v->last_error = hipGetErrorString(e); if (b->owns_dev) (void)hipFree(b->dev); b->dev = nullptr; return ZKGPU_EHIP; }
   }
   if (timing && total) fprintf(stderr, "txblock: gather %.2f ms, randomness %.2f ms, allocation + copy %.2f ms (%zu bytes)\n",
                                (tb1 - tb0) * 1e3, (tb2 - tb1) * 1e3, (now() - tb2) * 1e3, total);
@@ -429,6 +496,7 @@ zkgpu_verifier::BlockRun* block_start(zkgpu_verifier* v, const zkgpu_txblock* b)
     for (size_t off = 0; off < g.idx.size(); off += v->chunk) {
       const size_t n = std::min(v->chunk, g.idx.size() - off);
       const int lane = free_lane(v);
+      v->lanes[(size_t)lane]->dep_event = b->ready;
       const int rc = zkgpu_cloak_verify_submit_dev(v->lanes[(size_t)lane], v->ps, g.plan, n, b->dev + g.com_off + off * wcom,
                                                    b->dev + g.proof_off + off * g.proof_len, g.proof_len, b->dev + g.r_off + off * 64);
       if (rc != ZKGPU_OK) { run->rc = rc; v->last_error = zkgpu_last_error(v->lanes[(size_t)lane]); break; }
@@ -884,11 +952,110 @@ int zkgpu_verifier_set_tx_format(zkgpu_verifier* v, int format) {
   return ZKGPU_OK;
 }
 
+namespace {
+
+// One chunk of a zkgpu_tx_verify_batch call on its way through the stages (see below)
+struct TxChunk {
+  size_t lo = 0, n = 0;                                 // transactions [lo, lo + n) of the call
+  std::vector<zk::zkvm::TxStatement> st;
+  std::vector<size_t> live;                             // positions in the chunk the VM accepted
+  // aggregated keys: rows of (a_i, X_i)
+  std::vector<uint64_t> koff;
+  std::vector<uint8_t> ksc, kpt, agg, kok;
+  // signature equations of the transactions whose keys all decode
+  std::vector<size_t> keyed;                            // positions in `live`
+  std::vector<uint64_t> soff, sst_off;
+  std::vector<uint8_t> ssc, spt, sst, sig_bits;
+  std::vector<uint32_t> sidx;
+  // cloak proofs (every live transaction: the signature verdict is ANDed in at the end)
+  zkgpu_txblock* blk = nullptr;
+  zkgpu_verifier::BlockRun* run = nullptr;
+  std::vector<uint8_t> pbits;
+  bool keys_pending = false, sigs_pending = false;
+};
+
+// host arrays -> the context's input buffers -> kernels and result copy queued (batch_device_enqueue, value mode);
+// msm_values_collect finishes.  The arrays must stay alive until then; the context is marked busy meanwhile.
+int msm_values_enqueue(zkgpu_ctx* c, const uint8_t* scalars, const uint8_t* points, const uint64_t* offsets, size_t batch) {
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  TRY(refuse_if_pending(c));
+  DeviceGuard g(c->device);
+  const uint64_t n = offsets[batch];
+  TRY(upload(c, c->in_scalars, scalars, n * 32));
+  TRY(upload(c, c->in_points, points, n * 32));
+  TRY(upload(c, c->in_offsets, offsets, (batch + 1) * 8));
+  Job job;
+  job.d_dyn_scalars = (const uint32_t*)c->in_scalars.p;
+  job.d_dyn_points = (const uint32_t*)c->in_points.p;
+  job.d_dyn_offsets = (const uint64_t*)c->in_offsets.p;
+  job.n_dyn = n;
+  job.n_msm = (uint32_t)batch;
+  const int rc = batch_device_enqueue(c, job, true);
+  if (rc != ZKGPU_OK) { c->split = zkgpu_ctx::SplitOp{}; return rc; }
+  c->pending = true; c->pending_batch = batch;
+  return ZKGPU_OK;
+}
+
+int split_collect(zkgpu_ctx* c, uint8_t* bitmap, uint8_t* values) {
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  c->pending = false;
+  return batch_collect(c, bitmap, values);
+}
+
+// the same for rows of dynamic terms + terms on the resident set's tables (the signature equations)
+int verify_ps_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, const uint8_t* dyn_scalars, const uint8_t* dyn_points,
+                      const uint64_t* dyn_offsets, const uint8_t* static_scalars, const uint32_t* static_index, const uint64_t* static_offsets) {
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  TRY(refuse_if_pending(c));
+  DeviceGuard g(c->device);
+  const uint64_t nd = dyn_offsets[batch], ns = static_offsets[batch];
+  TRY(upload(c, c->in_scalars, dyn_scalars, nd * 32));
+  TRY(upload(c, c->in_points, dyn_points, nd * 32));
+  TRY(upload(c, c->in_offsets, dyn_offsets, (batch + 1) * 8));
+  TRY(upload(c, c->in_st_scalars, static_scalars, ns * 32));
+  TRY(upload(c, c->in_st_index, static_index, ns * 4));
+  TRY(upload(c, c->in_st_offsets, static_offsets, (batch + 1) * 8));
+  Job job;
+  job.d_dyn_scalars = (const uint32_t*)c->in_scalars.p;
+  job.d_dyn_points = (const uint32_t*)c->in_points.p;
+  job.d_dyn_offsets = (const uint64_t*)c->in_offsets.p;
+  job.n_dyn = nd;
+  job.d_st_scalars = (const uint32_t*)c->in_st_scalars.p;
+  job.d_st_index = (const uint32_t*)c->in_st_index.p;
+  job.d_st_offsets = (const uint64_t*)c->in_st_offsets.p;
+  job.n_static = ns;
+  job.d_static_rows = ps->rows;
+  job.n_msm = (uint32_t)batch;
+  const int rc = (ps->table && ns) ? batch_device_tables_enqueue(c, job, ps) : batch_device_enqueue(c, job, false);
+  if (rc != ZKGPU_OK) { c->split = zkgpu_ctx::SplitOp{}; return rc; }
+  c->pending = true; c->pending_batch = batch;
+  return ZKGPU_OK;
+}
+
+}  // namespace
+
+int zkgpu_verifier_set_tx_chunk(zkgpu_verifier* v, size_t transactions) {
+  if (!v || transactions >= (1u << 24)) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  v->tx_chunk = transactions;
+  return ZKGPU_OK;
+}
+
+// The call is cut into chunks of ~3000 transactions that travel through four stages, the host's share of one chunk
+// beside the device's share of the others (ONE calling thread: every device stage is queued asynchronously):
+//   VM        host pool: wire format, the VM, contract ids, transaction ID, the (a_i, X_i) rows and s, R of the signature
+//   proofs    host pool gathers the cloak statements of the chunk's live transactions into a pinned staging area, one
+//             copy to HBM, and the chunk's batches are queued on the verifier's lanes (block_start)          [lanes]
+//   keys      X = sum a_i X_i per transaction, as encodings: queued on a context of its own                  [aux_keys]
+//   sigs      host pool: c = H(txid, X, R); the equations s B - R - sum (c a_i) X_i == identity queued       [aux_sigs]
+// and the verdicts are collected at the end: accept = the VM accepted & the keys decode & the signature holds & the
+// proof verifies.  (The proofs of a chunk do not wait for its signatures: a transaction whose signature fails has its
+// proof verified for nothing -- that is the rare case -- and in exchange nothing on the device waits for a host round trip.)
 int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, const uint64_t* tx_offsets, int host_threads,
                           uint8_t* accept_bitmap, uint8_t* status) {
   using namespace zk::zkvm;
   if (!v || !accept_bitmap) return ZKGPU_EINVAL;
-  const double t00 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   memset(accept_bitmap, 0, (batch + 7) / 8);
   if (status) memset(status, TX_INVALID, batch);
   if (batch == 0) return ZKGPU_OK;
@@ -899,88 +1066,186 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     if (status) memset(status, TX_UNSUPPORTED, batch);
     return ZKGPU_OK;
   }
-  std::vector<TxStatement> st(batch);
   const bool timing = getenv("ZKGPU_PROVER_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t0 = now();
-  host_parallel(batch, host_threads, [&](size_t i) { st[i] = tx_prepare(txs + tx_offsets[i], (size_t)(tx_offsets[i + 1] - tx_offsets[i])); });
-  const double t1 = now();
-  std::vector<size_t> live;
-  for (size_t i = 0; i < batch; ++i) {
-    if (status && st[i].status == TX_UNSUPPORTED) status[i] = TX_UNSUPPORTED;     // (TX_OK is written at the very end only)
-    if (st[i].status == TX_OK) live.push_back(i);
-  }
-  if (live.empty()) return ZKGPU_OK;
-  // the lanes' batches in flight are collected before the root context is used synchronously
+  const double t00 = now();
+  double t_vm = 0, t_stage = 0, t_keys = 0, t_sigs = 0, t_wait = 0;
+  zkgpu_ctx* c = v->root;
+  // the lanes' batches in flight are collected first: the call owns the verifier (tickets and runs keep their verdicts)
   while (!v->block_busy.empty()) block_collect(v, v->block_busy.front());
   while (!v->busy.empty()) ticket_collect(v, v->busy.front());
-  zkgpu_ctx* c = v->root;
+  {
+    DeviceGuard g(c->device);
+    if (!v->aux_keys && ctx_create(c->device, nullptr, &v->aux_keys, true) != ZKGPU_OK) { v->aux_keys = nullptr; v->last_error = "no context for the key stage"; return ZKGPU_EHIP; }
+    if (!v->aux_sigs && ctx_create(c->device, nullptr, &v->aux_sigs, true) != ZKGPU_OK) { v->aux_sigs = nullptr; v->last_error = "no context for the signature stage"; return ZKGPU_EHIP; }
+  }
+  if (!v->have_basepoint) {
+    uint8_t Bb[32];
+    const int rc = zkgpu_pedersen_gens(v->aux_keys, v->basepoint, Bb);
+    if (rc != ZKGPU_OK) { v->last_error = zkgpu_last_error(v->aux_keys); return rc; }
+    v->have_basepoint = true;
+  }
+  const uint8_t* B = v->basepoint;
+  constexpr size_t RING = 4;
+  if (v->tx_arenas.size() < RING) v->tx_arenas.resize(RING);
+  // chunk boundaries: ~3000 transactions each (zkgpu_verifier_set_tx_chunk overrides), the LAST one half as long -- what
+  // follows the last chunk's VM stage (its keys -> signatures chain, its proofs) is the tail of the call
+  std::vector<size_t> cuts{0};
+  {
+    const size_t chunk = v->tx_chunk ? v->tx_chunk : 3072;
+    const size_t full = std::max<size_t>(1, (batch + chunk / 2) / chunk);           // chunks if all were equal
+    if (full == 1 || v->tx_chunk) {
+      for (size_t at = 0; at < batch; at += chunk) cuts.push_back(std::min(batch, at + chunk));
+    } else {
+      const double unit = (double)batch / ((double)full - 0.5);                     // full - 1 whole chunks and a half one
+      for (size_t q = 1; q < full; ++q) cuts.push_back(std::min(batch, (size_t)(unit * (double)q)));
+      cuts.push_back(batch);
+    }
+  }
+  const size_t n_chunks = cuts.size() - 1;
+  std::vector<std::unique_ptr<TxChunk>> ck(n_chunks);
   auto par = [&](size_t n, const std::function<void(size_t)>& f) { host_parallel(n, host_threads, f); };
-  const size_t nl = live.size();
-  // 1. aggregated keys X = sum a_i X_i
-  std::vector<uint64_t> off(nl + 1, 0);
-  for (size_t j = 0; j < nl; ++j) off[j + 1] = off[j] + st[live[j]].sig_scalars.size() / 32 - 2;
-  std::vector<uint8_t> sc(32 * off.back()), pt(32 * off.back()), agg(32 * nl), okb((nl + 7) / 8);
-  par(nl, [&](size_t j) {
-    const TxStatement& t = st[live[j]];
-    memcpy(sc.data() + 32 * off[j], t.sig_scalars.data() + 64, t.sig_scalars.size() - 64);
-    memcpy(pt.data() + 32 * off[j], t.sig_points.data() + 64, t.sig_points.size() - 64);
-  });
-  auto fail = [&](int rc) { v->last_error = zkgpu_last_error(c); return rc; };
-  { const int rc = zkgpu_msm_batch(c, sc.data(), pt.data(), off.data(), nl, agg.data(), okb.data()); if (rc != ZKGPU_OK) return fail(rc); }
-  const double t2 = now();
-  uint8_t B[32], Bb[32];
-  { const int rc = zkgpu_pedersen_gens(c, B, Bb); if (rc != ZKGPU_OK) return fail(rc); }
-  // 2. the signature equations  s B - R - sum (c a_i) X_i == identity: B is generator 0 of the resident set (its term
-  //    comes out of the fixed-base tables), R and the keys are the proof-specific points of the row
-  std::vector<size_t> keyed;                           // positions in `live` whose keys all decode
-  for (size_t j = 0; j < nl; ++j) if ((okb[j / 8] >> (j % 8)) & 1) keyed.push_back(j);
-  const size_t ns = keyed.size();
-  off.assign(ns + 1, 0);
-  for (size_t q = 0; q < ns; ++q) off[q + 1] = off[q] + st[live[keyed[q]]].sig_scalars.size() / 32 - 1;
-  sc.resize(32 * off.back()); pt.resize(32 * off.back());
-  std::vector<uint8_t> ssc(32 * ns);
-  std::vector<uint32_t> sidx(ns, 0);
-  std::vector<uint64_t> soff(ns + 1);
-  for (size_t q = 0; q <= ns; ++q) soff[q] = q;
-  par(ns, [&](size_t q) {
-    TxStatement& t = st[live[keyed[q]]];
-    tx_finish_signature(t, B, &agg[32 * keyed[q]]);
-    memcpy(&ssc[32 * q], t.sig_scalars.data(), 32);
-    memcpy(sc.data() + 32 * off[q], t.sig_scalars.data() + 32, t.sig_scalars.size() - 32);
-    memcpy(pt.data() + 32 * off[q], t.sig_points.data() + 32, t.sig_points.size() - 32);
-  });
-  std::vector<uint8_t> sig_bits((ns + 7) / 8 + 1, 0);
-  if (ns) {
-    const int rc = zkgpu_verify_batch_ps(c, v->ps, ns, sc.data(), pt.data(), off.data(), ssc.data(), sidx.data(), soff.data(), sig_bits.data());
-    if (rc != ZKGPU_OK) return fail(rc);
+  int first_rc = ZKGPU_OK;
+  auto note = [&](int rc, zkgpu_ctx* where) { if (rc != ZKGPU_OK && first_rc == ZKGPU_OK) { first_rc = rc; if (where) v->last_error = zkgpu_last_error(where); } return rc; };
+
+  auto keys_collect = [&](TxChunk& k) {
+    if (!k.keys_pending) return;
+    k.keys_pending = false;
+    const double t0 = now();
+    note(split_collect(v->aux_keys, k.kok.data(), k.agg.data()), v->aux_keys);
+    t_wait += now() - t0;
+  };
+  auto sigs_collect = [&](TxChunk& k) {
+    if (!k.sigs_pending) return;
+    k.sigs_pending = false;
+    const double t0 = now();
+    note(split_collect(v->aux_sigs, k.sig_bits.data(), nullptr), v->aux_sigs);
+    t_wait += now() - t0;
+  };
+  auto proofs_collect = [&](TxChunk& k) {
+    if (!k.run) return;
+    const double t0 = now();
+    const int rc = block_finish(v, k.run, k.pbits.data());
+    k.run = nullptr;
+    if (rc != ZKGPU_OK && first_rc == ZKGPU_OK) first_rc = rc;
+    if (k.blk) { zkgpu_txblock_destroy(k.blk); k.blk = nullptr; }
+    t_wait += now() - t0;
+  };
+  // signature stage of a chunk whose aggregated keys have arrived
+  auto sigs_start = [&](TxChunk& k) {
+    const double t0 = now();
+    const size_t nl = k.live.size();
+    k.keyed.clear();
+    for (size_t j = 0; j < nl; ++j) if ((k.kok[j / 8] >> (j % 8)) & 1) k.keyed.push_back(j);
+    const size_t ns = k.keyed.size();
+    k.sig_bits.assign((ns + 7) / 8 + 1, 0);
+    if (ns == 0 || first_rc != ZKGPU_OK) return;
+    k.soff.assign(ns + 1, 0);
+    for (size_t q = 0; q < ns; ++q) k.soff[q + 1] = k.soff[q] + k.st[k.live[k.keyed[q]]].sig_scalars.size() / 32 - 1;
+    k.ssc.resize(32 * k.soff.back()); k.spt.resize(32 * k.soff.back());
+    k.sst.resize(32 * ns);
+    k.sidx.assign(ns, 0);
+    k.sst_off.resize(ns + 1);
+    for (size_t q = 0; q <= ns; ++q) k.sst_off[q] = q;
+    par(ns, [&](size_t q) {
+      TxStatement& t = k.st[k.live[k.keyed[q]]];
+      tx_finish_signature(t, B, &k.agg[32 * k.keyed[q]]);
+      memcpy(&k.sst[32 * q], t.sig_scalars.data(), 32);
+      memcpy(k.ssc.data() + 32 * k.soff[q], t.sig_scalars.data() + 32, t.sig_scalars.size() - 32);
+      memcpy(k.spt.data() + 32 * k.soff[q], t.sig_points.data() + 32, t.sig_points.size() - 32);
+    });
+    if (note(verify_ps_enqueue(v->aux_sigs, v->ps, ns, k.ssc.data(), k.spt.data(), k.soff.data(), k.sst.data(), k.sidx.data(), k.sst_off.data()),
+             v->aux_sigs) == ZKGPU_OK)
+      k.sigs_pending = true;
+    t_sigs += now() - t0;
+  };
+
+  for (size_t ci = 0; ci < n_chunks && first_rc == ZKGPU_OK; ++ci) {
+    ck[ci].reset(new TxChunk());
+    TxChunk& k = *ck[ci];
+    k.lo = cuts[ci]; k.n = cuts[ci + 1] - cuts[ci];
+    // ---- VM
+    double t0 = now();
+    k.st.resize(k.n);
+    par(k.n, [&](size_t i) { k.st[i] = tx_prepare(txs + tx_offsets[k.lo + i], (size_t)(tx_offsets[k.lo + i + 1] - tx_offsets[k.lo + i])); });
+    for (size_t i = 0; i < k.n; ++i) {
+      if (status && k.st[i].status == TX_UNSUPPORTED) status[k.lo + i] = TX_UNSUPPORTED;     // (TX_OK is written at the very end only)
+      if (k.st[i].status == TX_OK) k.live.push_back(i);
+    }
+    t_vm += now() - t0;
+    const size_t nl = k.live.size();
+    k.pbits.assign((nl + 7) / 8 + 1, 0);
+    k.kok.assign((nl + 7) / 8 + 1, 0);
+    k.agg.assign(32 * std::max<size_t>(nl, 1), 0);
+    // ---- keys: the previous chunk's have had this chunk's VM stage to finish in and are collected first (one operation at
+    //      a time on aux_keys); then this chunk's rows go out, BEFORE its proofs: what follows them is a chain (keys -> host
+    //      transcripts -> equations), and queued behind the proofs' chip-filling kernels its short kernels would wait for CUs
+    t0 = now();
+    if (ci > 0) keys_collect(*ck[ci - 1]);
+    if (nl) {
+      k.koff.assign(nl + 1, 0);
+      for (size_t j = 0; j < nl; ++j) k.koff[j + 1] = k.koff[j] + k.st[k.live[j]].sig_scalars.size() / 32 - 2;
+      k.ksc.resize(32 * k.koff.back()); k.kpt.resize(32 * k.koff.back());
+      par(nl, [&](size_t j) {
+        const TxStatement& t = k.st[k.live[j]];
+        memcpy(k.ksc.data() + 32 * k.koff[j], t.sig_scalars.data() + 64, t.sig_scalars.size() - 64);
+        memcpy(k.kpt.data() + 32 * k.koff[j], t.sig_points.data() + 64, t.sig_points.size() - 64);
+      });
+      if (first_rc == ZKGPU_OK && note(msm_values_enqueue(v->aux_keys, k.ksc.data(), k.kpt.data(), k.koff.data(), nl), v->aux_keys) == ZKGPU_OK)
+        k.keys_pending = true;
+    }
+    t_keys += now() - t0;
+    // ---- signatures of the previous chunk (its keys have just arrived); the one before that is collected first
+    if (ci > 0 && !ck[ci - 1]->live.empty()) {
+      if (ci > 1) sigs_collect(*ck[ci - 2]);
+      sigs_start(*ck[ci - 1]);
+    }
+    if (nl) {
+      // ---- proofs: staged and queued on the lanes (the ring slot's previous user is finished first)
+      t0 = now();
+      if (ci >= RING) proofs_collect(*ck[ci - RING]);
+      std::vector<TxSource> src(nl);
+      for (size_t q = 0; q < nl; ++q) {
+        const TxStatement& t = k.st[k.live[q]];
+        src[q] = TxSource{t.n_in, t.n_out, t.commitments.data(), t.proof, t.proof_len};
+      }
+      if (first_rc == ZKGPU_OK && note(txblock_build_locked(v, nl, src.data(), nullptr, host_threads, &k.blk, &v->tx_arenas[ci % RING]), nullptr) == ZKGPU_OK) {
+        // the chunk goes to the lanes in batches short enough for the one-wavefront-per-transaction transcript: this path is
+        // bound by the host and by the length of a batch's dependent chain (the last chunk's is the tail of the call),
+        // not by how well a batch fills the chip
+        const size_t saved_chunk = v->chunk;
+        v->chunk = std::max<size_t>(saved_chunk, 4096);
+        k.run = block_start(v, k.blk);
+        v->chunk = saved_chunk;
+        if (k.run->rc != ZKGPU_OK) note(k.run->rc, nullptr);
+      }
+      t_stage += now() - t0;
+    }
   }
-  const double t3 = now();
-  // 3. the cloak proofs of the transactions whose signature holds, staged straight from the statements (no second copy).
-  //    (Queueing them on the lanes BEFORE the signature stages, to run underneath, was measured slower: the short kernels
-  //    of the signature stages then wait for CU slots behind the proofs' long ones.)
-  std::vector<size_t> proved;
-  for (size_t q = 0; q < ns; ++q) if ((sig_bits[q / 8] >> (q % 8)) & 1) proved.push_back(live[keyed[q]]);
-  if (proved.empty()) return ZKGPU_OK;
-  const size_t np = proved.size();
-  std::vector<TxSource> src(np);
-  for (size_t q = 0; q < np; ++q) {
-    const TxStatement& t = st[proved[q]];
-    src[q] = TxSource{t.n_in, t.n_out, t.commitments.data(), t.proof, t.proof_len};
+  // drain: the last chunk's keys and signatures, then every verdict
+  if (n_chunks > 0 && ck[n_chunks - 1]) {
+    TxChunk& last = *ck[n_chunks - 1];
+    keys_collect(last);
+    if (n_chunks > 1 && ck[n_chunks - 2]) sigs_collect(*ck[n_chunks - 2]);
+    if (!last.live.empty() && first_rc == ZKGPU_OK) sigs_start(last);
   }
-  std::vector<uint8_t> bits((np + 7) / 8, 0);
-  zkgpu_txblock* blk = nullptr;
-  TRY(txblock_build_locked(v, np, src.data(), nullptr, host_threads, &blk));
-  const double t4 = now();
-  const int rc = block_finish(v, block_start(v, blk), bits.data());
-  zkgpu_txblock_destroy(blk);
-  if (rc != ZKGPU_OK) return rc;
-  if (timing) fprintf(stderr, "tx verify: VM + ids %.2f ms, aggregated keys %.2f ms, signature equations %.2f ms, cloak proofs %.2f ms (of which staging %.2f ms), "
-                              "%.2f ms in all (%zu transactions)\n",
-                      (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (now() - t3) * 1e3, (t4 - t3) * 1e3, (now() - t00) * 1e3, batch);
-  for (size_t q = 0; q < np; ++q) {
-    const size_t i = proved[q];
-    if ((bits[q / 8] >> (q % 8)) & 1) {
+  for (size_t ci = 0; ci < n_chunks; ++ci) {
+    if (!ck[ci]) continue;
+    keys_collect(*ck[ci]);                              // (only after an error: nothing is left pending on the contexts)
+    sigs_collect(*ck[ci]);
+    proofs_collect(*ck[ci]);
+  }
+  if (timing) fprintf(stderr, "tx verify: %zu transactions in %zu chunks: VM + ids %.2f ms, staging + queueing the proofs %.2f ms, key rows %.2f ms, "
+                              "signature transcripts + rows %.2f ms, waiting for the device %.2f ms, %.2f ms in all\n",
+                      batch, n_chunks, t_vm * 1e3, t_stage * 1e3, t_keys * 1e3, t_sigs * 1e3, t_wait * 1e3, (now() - t00) * 1e3);
+  if (first_rc != ZKGPU_OK) return first_rc;             // both outputs still read "nothing accepted"
+  for (size_t ci = 0; ci < n_chunks; ++ci) {
+    const TxChunk& k = *ck[ci];
+    std::vector<uint8_t> sig_ok(k.live.size(), 0);
+    for (size_t q = 0; q < k.keyed.size(); ++q) if ((k.sig_bits[q / 8] >> (q % 8)) & 1) sig_ok[k.keyed[q]] = 1;
+    for (size_t j = 0; j < k.live.size(); ++j) {
+      if (!sig_ok[j] || !((k.pbits[j / 8] >> (j % 8)) & 1)) continue;
+      const size_t i = k.lo + k.live[j];
       accept_bitmap[i / 8] |= (uint8_t)(1u << (i % 8));
       if (status) status[i] = TX_OK;
     }

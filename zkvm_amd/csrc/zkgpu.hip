@@ -85,6 +85,11 @@ struct zkgpu_ctx {
   hipEvent_t ev_t = nullptr, ev_p = nullptr, ev_sm = nullptr, ev_sa = nullptr, ev_done = nullptr;
   bool pending = false;            // a submitted batch has not been waited for yet
   size_t pending_batch = 0;
+  // the general (non-pipelined) batch paths in two halves -- batch_device_enqueue / batch_device_tables_enqueue queue the
+  // kernels and the copy of the results to the pinned buffer, batch_collect waits and reads them -- so that the key and
+  // signature stages of zkgpu_tx_verify_batch can run beside the host's work on the next chunk (session.hpp)
+  struct SplitOp { int kind = 0; size_t batch = 0; bool values = false; hipStream_t stream = nullptr; } split;
+  hipEvent_t dep_event = nullptr;  // the next whole-proof submit on this context waits for it first (its inputs are still being copied)
   std::vector<uint8_t> sync_result; // result of a submit that had to run synchronously
   bool sync_result_valid = false;
   int sync_rc = 0;
@@ -542,14 +547,40 @@ int msm_device(zkgpu_ctx* c, const void* d_scalars, const void* d_points, size_t
 // ---- batch ------------------------------------------------------------------------
 // values != nullptr: "value mode" -- write the 32-byte encoding of every MSM to
 // values[32 * i] (host) and make bit i mean "all points of MSM i decoded".
-int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap, uint8_t* values = nullptr) {
+int small_msm_launch(zkgpu_ctx* c, const Job& job, hipStream_t st);
+
+int batch_device_enqueue(zkgpu_ctx* c, const Job& job, bool values) {
   const size_t B = job.n_msm;
   const size_t nbytes = (B + 7) / 8;
-  memset(accept_bitmap, 0, nbytes);
-  if (values) memset(values, 0, 32 * B);
+  c->split = zkgpu_ctx::SplitOp{1, B, values, c->stream};
   if (B == 0) return ZKGPU_OK;
   JobDesc jd;
-  TRY(run_to_windows(c, job, jd));
+  if (!c->forced_w && job.n_static == 0 && job.n_dyn && job.n_dyn <= 64ull * B && B >= 64) {
+    // many SMALL multiscalar multiplications (a few terms each: aggregated keys, signature equations): per-point tables
+    // and one wavefront per row -- four launches, no global sort, no atomics -- instead of the bucket pipeline's seventeen
+    hipStream_t s = c->stream;
+    jd.w = 4; jd.n_windows = 64;
+    c->last_w = 4;
+    TRY(ensure(c, c->dyn_rows, std::max<uint64_t>(job.n_dyn, 1) * NIELS_WORDS * 4));
+    TRY(ensure(c, c->window_sums, (size_t)B * 64 * EXT_WORDS * 4));
+    TRY(ensure(c, c->window_flags, (size_t)B * 64 * 4));
+    TRY(ensure(c, c->msm_fail, (size_t)B * 4));
+    TRY(ensure(c, c->status, 64));
+    {
+      Launch l(c, "k_batch_init", s);
+      hipLaunchKernelGGL(k_batch_init, dim3(blocks_for(B, 256)), dim3(256), 0, s, (uint32_t*)c->status.p, (uint32_t*)c->msm_fail.p,
+                         (uint32_t*)nullptr, (uint32_t)B);
+    }
+    {
+      Launch l(c, "k_decompress", s);
+      hipLaunchKernelGGL(k_decompress, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, s, job.d_dyn_points,
+                         (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, (uint32_t)B,
+                         (uint32_t*)c->msm_fail.p, (unsigned long long*)((char*)c->status.p + 8), (uint8_t*)nullptr);
+    }
+    TRY(small_msm_launch(c, job, s));
+  } else {
+    TRY(run_to_windows(c, job, jd));
+  }
   TRY(ensure(c, c->accept, B));
   TRY(ensure(c, c->bitmap, nbytes));
   TRY(ensure_pinned(c, nbytes + 64 + (values ? 32 * B : 0)));
@@ -572,15 +603,38 @@ int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap, uint8_t* 
   HIP_TRY(c, hipMemcpyAsync(h, c->bitmap.p, nbytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(h + nbytes, c->status.p, 16, hipMemcpyDeviceToHost, c->stream));
   if (values) HIP_TRY(c, hipMemcpyAsync(h + nbytes + 64, c->values.p, 32 * B, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ZKGPU_OK;
+}
+
+// second half of batch_device_enqueue / batch_device_tables_enqueue: wait for the stream, read the results
+int batch_collect(zkgpu_ctx* c, uint8_t* accept_bitmap, uint8_t* values) {
+  const zkgpu_ctx::SplitOp op = c->split;
+  c->split = zkgpu_ctx::SplitOp{};
+  const size_t B = op.batch, nbytes = (B + 7) / 8;
+  memset(accept_bitmap, 0, nbytes);
+  if (values) memset(values, 0, 32 * B);
+  if (op.kind == 0) return ZKGPU_EINVAL;
+  if (B == 0) return ZKGPU_OK;
+  HIP_TRY(c, hipStreamSynchronize(op.stream));
   if (c->profiling) prof_collect(c);
-  const uint32_t* hs = (const uint32_t*)(h + nbytes);
+  const char* h = (const char*)c->pinned;
   uint32_t st;
-  memcpy(&st, hs, 4);
+  memcpy(&st, h + nbytes, 4);
   if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
   memcpy(accept_bitmap, h, nbytes);
-  if (values) memcpy(values, h + nbytes + 64, 32 * B);
+  if (values && op.values) memcpy(values, h + nbytes + 64, 32 * B);
   return ZKGPU_OK;
+}
+
+// values != nullptr: "value mode" -- write the 32-byte encoding of every MSM to
+// values[32 * i] (host) and make bit i mean "all points of MSM i decoded".
+int batch_device(zkgpu_ctx* c, const Job& job, uint8_t* accept_bitmap, uint8_t* values = nullptr) {
+  const size_t B = job.n_msm;
+  memset(accept_bitmap, 0, (B + 7) / 8);
+  if (values) memset(values, 0, 32 * B);
+  const int rc = batch_device_enqueue(c, job, values != nullptr);
+  if (rc != ZKGPU_OK) { c->split = zkgpu_ctx::SplitOp{}; return rc; }
+  return batch_collect(c, accept_bitmap, values);
 }
 
 // window sums of many small MSMs (few proof-specific points each): see kernels.hpp, k_small_tables.
@@ -613,10 +667,10 @@ int small_msm_launch(zkgpu_ctx* c, const Job& job, hipStream_t st) {
 // Batch path when the point set carries fixed-base tables: generator terms are
 // summed straight out of the tables (no sort, no buckets, no doublings); only
 // the proof-specific terms go through the Pippenger pipeline.
-int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, uint8_t* accept_bitmap) {
+int batch_device_tables_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps) {
   const size_t B = job.n_msm;
   const size_t nbytes = (B + 7) / 8;
-  memset(accept_bitmap, 0, nbytes);
+  c->split = zkgpu_ctx::SplitOp{2, B, false, c->stream};
   if (B == 0) return ZKGPU_OK;
   hipStream_t s = c->stream, s2 = c->stream2;
   const bool has_dyn = job.n_dyn > 0;
@@ -701,13 +755,14 @@ int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, 
   char* h = (char*)c->pinned;
   HIP_TRY(c, hipMemcpyAsync(h, c->bitmap.p, nbytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipMemcpyAsync(h + nbytes, c->status.p, 16, hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipStreamSynchronize(s));
-  if (c->profiling) prof_collect(c);
-  uint32_t st;
-  memcpy(&st, h + nbytes, 4);
-  if (st & 2u) { c->last_error = "scalar with bit 255 set"; return ZKGPU_EINVAL; }
-  memcpy(accept_bitmap, h, nbytes);
   return ZKGPU_OK;
+}
+
+int batch_device_tables(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, uint8_t* accept_bitmap) {
+  memset(accept_bitmap, 0, ((size_t)job.n_msm + 7) / 8);
+  const int rc = batch_device_tables_enqueue(c, job, ps);
+  if (rc != ZKGPU_OK) { c->split = zkgpu_ctx::SplitOp{}; return rc; }
+  return batch_collect(c, accept_bitmap, nullptr);
 }
 
 // ---- pipelined submit / wait ---------------------------------------------------------------
@@ -1149,7 +1204,9 @@ const char* zkgpu_strerror(int code) {
 const char* zkgpu_last_error(const zkgpu_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 namespace {
-int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
+// aux: a context for the general (one-stream-pair) paths only -- two streams of its own, no light stream, no third one:
+// what the key and signature stages of zkgpu_tx_verify_batch run on beside the verifier's lanes (session.hpp)
+int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out, bool aux = false) {
   zkgpu_ctx* c = new zkgpu_ctx();
   c->device = device;
   // main stream: the proof-point pipeline, high priority; stream2: the chip-filling generator
@@ -1184,12 +1241,15 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out) {
     c->locate_parts = parent->locate_parts;
     c->tail_mode = parent->tail_mode;
     c->horner_mode = parent->horner_mode;
+  } else if (aux) {
+    ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+         hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   } else {
     ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
          hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
          hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   }
-  ok = ok && hipStreamCreateWithPriority(&c->stream_l, hipStreamNonBlocking, prio_greatest) == hipSuccess;
+  if (!aux) ok = ok && hipStreamCreateWithPriority(&c->stream_l, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   hipEvent_t* evs[] = {&c->ev_fork, &c->ev_join, &c->ev_t, &c->ev_p, &c->ev_sm, &c->ev_sa, &c->ev_done, &c->ev_dig, &c->ev_u};
   for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   if (!ok) { if (parent) --parent->n_forks; delete c; return ZKGPU_EHIP; }
@@ -1256,7 +1316,7 @@ int zkgpu_ctx_fork(zkgpu_ctx* parent, zkgpu_ctx** out) {
 void zkgpu_destroy(zkgpu_ctx* c) {
   if (!c) return;
   DeviceGuard g(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->stream_l) (void)hipStreamSynchronize(c->stream_l);
@@ -1273,7 +1333,7 @@ void zkgpu_destroy(zkgpu_ctx* c) {
   if (c->pinned_in) (void)hipHostFree(c->pinned_in);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->owns_streams) {
-    (void)hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     for (hipStream_t st : c->lane_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
@@ -2592,6 +2652,11 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
                              const uint32_t* d_com, const uint8_t* d_proofs, const uint32_t* d_r, size_t proof_len) {
   if (ps->n < 2 + 2 * plan->gens_capacity) return ZKGPU_EINVAL;
   if (c->pending) { c->last_error = "a submitted batch is still waiting for zkgpu_verify_wait"; return ZKGPU_EINVAL; }
+  if (c->dep_event) {            // inputs on their way to HBM on another stream (session.hpp, staged transactions)
+    const hipEvent_t ev = c->dep_event;
+    c->dep_event = nullptr;
+    HIP_TRY(c, hipStreamWaitEvent(c->stream_l, ev, 0));
+  }
   const PrepShape& sh = plan->shape;
   const uint32_t B = (uint32_t)batch;
   TRY(ensure(c, c->prep_pw, (size_t)B * sh.proof_words * 4));
@@ -2714,6 +2779,7 @@ int zkgpu_cloak_verify_submit_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_
     if (c->pending) return ZKGPU_EINVAL;
     if (!proof_len_fits(plan->shape, proof_len)) {     // wrong length for this statement: every proof is Err
       std::vector<uint8_t> z((batch + 7) / 8, 0);
+      c->dep_event = nullptr;
       park_sync_result(c, ZKGPU_OK, z.data(), batch);
       return ZKGPU_OK;
     }

@@ -27,6 +27,40 @@ namespace zkvm {
 
 enum TxStatus : uint8_t { TX_OK = 0, TX_INVALID = 1, TX_UNSUPPORTED = 2 };
 
+// Bytes with inline room for the common case (a payment's four values, its few keys) and a heap fallback beyond: the
+// statements of a chunk are then ONE allocation of the calling thread, instead of three small ones per transaction made
+// on the worker threads and freed on the caller's (cross-thread frees: 2.5 ms of an 8192-transaction call).
+template <size_t N>
+class SmallBytes {
+ public:
+  SmallBytes() = default;
+  SmallBytes(const SmallBytes& o) { assign(o.data(), o.size()); }
+  SmallBytes& operator=(const SmallBytes& o) { if (this != &o) assign(o.data(), o.size()); return *this; }
+  SmallBytes(SmallBytes&& o) noexcept : n_(o.n_), heap_(std::move(o.heap_)) { if (heap_.empty() && n_) std::memcpy(inl_, o.inl_, n_); o.n_ = 0; }
+  SmallBytes& operator=(SmallBytes&& o) noexcept {
+    if (this != &o) { n_ = o.n_; heap_ = std::move(o.heap_); if (heap_.empty() && n_) std::memcpy(inl_, o.inl_, n_); o.n_ = 0; }
+    return *this;
+  }
+  void resize(size_t n) {                       // contents beyond the old size are zero
+    if (n <= N && heap_.empty()) { if (n > n_) std::memset(inl_ + n_, 0, n - n_); n_ = n; return; }
+    if (heap_.empty()) { heap_.assign(inl_, inl_ + n_); }
+    heap_.resize(n, 0);
+    n_ = n;
+  }
+  void assign(const uint8_t* p, size_t n) { heap_.clear(); n_ = 0; resize(n); if (n) std::memcpy(data(), p, n); }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  uint8_t* data() { return heap_.empty() ? inl_ : heap_.data(); }
+  const uint8_t* data() const { return heap_.empty() ? inl_ : heap_.data(); }
+  uint8_t& operator[](size_t i) { return data()[i]; }
+  const uint8_t& operator[](size_t i) const { return data()[i]; }
+
+ private:
+  size_t n_ = 0;
+  uint8_t inl_[N];
+  std::vector<uint8_t> heap_;
+};
+
 struct TxStatement {
   TxStatus status = TX_INVALID;
   const char* why = "";
@@ -34,16 +68,20 @@ struct TxStatement {
   uint8_t txid[32] = {0};
   // the one cloak of the transaction: m inputs, n outputs, 64 bytes (qty, flavor commitments) per value, inputs first
   uint32_t n_in = 0, n_out = 0;
-  std::vector<uint8_t> commitments;
+  SmallBytes<256> commitments;
   const uint8_t* proof = nullptr;
   size_t proof_len = 0;
   // the signature check  s B - R - sum_i (c a_i) X_i == identity  as terms of a multiscalar multiplication
-  std::vector<uint8_t> sig_scalars, sig_points;   // 32 bytes each, same count
+  SmallBytes<160> sig_scalars, sig_points;        // 32 bytes each, same count
 };
 
+// A stack item REFERS to its bytes -- inside the transaction (pushed strings, and the contracts and payloads parsed out of
+// them) or inside the statement's commitment buffer (the values a cloak leaves) -- and owns nothing: the VM of a payment
+// moves a few dozen items around, and with owning items it spent a third of its time in the allocator.
 struct Item {
   enum Kind : uint8_t { Data, Variable, Value, Contract } kind = Data;
-  std::vector<uint8_t> bytes;          // Data: the string; Variable: 32-byte commitment; Value: qty | flavor; Contract: its serialization
+  const uint8_t* p = nullptr;          // Data: the string; Variable: 32-byte commitment; Value: qty | flavor; Contract: its serialization
+  size_t n = 0;
 };
 
 inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -91,11 +129,10 @@ inline void merkle_root(const Transcript& fresh, const LogEntry* e, size_t n, ui
   t.challenge_bytes("merkle.node", out, 32);
 }
 
-// parses a serialized contract; false: malformed.  items: Data or Value
-inline bool parse_contract(const uint8_t* p, size_t n, uint8_t anchor[32], uint8_t predicate[32], std::vector<Item>& items, bool& unsupported) {
+// parses a serialized contract; false: malformed.  items (Data or Value) refer into `p`
+inline bool parse_contract(const uint8_t* p, size_t n, const uint8_t*& predicate, std::vector<Item>* items, bool& unsupported) {
   if (n < 68) return false;
-  std::memcpy(anchor, p, 32);
-  std::memcpy(predicate, p + 32, 32);
+  predicate = p + 32;
   const uint32_t k = rd32(p + 64);
   size_t pos = 68;
   for (uint32_t i = 0; i < k; ++i) {
@@ -108,12 +145,12 @@ inline bool parse_contract(const uint8_t* p, size_t n, uint8_t anchor[32], uint8
       pos += 4;
       if (n - pos < len) return false;
       it.kind = Item::Data;
-      it.bytes.assign(p + pos, p + pos + len);
+      it.p = p + pos; it.n = len;
       pos += len;
     } else if (type == 0x02) {
       if (n - pos < 64) return false;
       it.kind = Item::Value;
-      it.bytes.assign(p + pos, p + pos + 64);
+      it.p = p + pos; it.n = 64;
       pos += 64;
     } else if (type == 0x01) {
       unsupported = true;      // a program item: outside the subset
@@ -121,25 +158,26 @@ inline bool parse_contract(const uint8_t* p, size_t n, uint8_t anchor[32], uint8
     } else {
       return false;
     }
-    items.push_back(std::move(it));
+    if (items) items->push_back(it);
   }
   return pos == n;
 }
 
-inline void serialize_contract(const uint8_t anchor[32], const uint8_t predicate[32], const std::vector<Item>& items, std::vector<uint8_t>& out) {
+inline void serialize_contract(const uint8_t anchor[32], const uint8_t predicate[32], const Item* items, size_t n_items, std::vector<uint8_t>& out) {
   out.assign(anchor, anchor + 32);
   out.insert(out.end(), predicate, predicate + 32);
-  const uint32_t k = (uint32_t)items.size();
+  const uint32_t k = (uint32_t)n_items;
   for (int b = 0; b < 4; ++b) out.push_back((uint8_t)(k >> (8 * b)));
-  for (const Item& it : items) {
+  for (size_t q = 0; q < n_items; ++q) {
+    const Item& it = items[q];
     if (it.kind == Item::Value) {
       out.push_back(0x02);
-      out.insert(out.end(), it.bytes.begin(), it.bytes.end());
+      out.insert(out.end(), it.p, it.p + it.n);
     } else {
       out.push_back(0x00);
-      const uint32_t len = (uint32_t)it.bytes.size();
+      const uint32_t len = (uint32_t)it.n;
       for (int b = 0; b < 4; ++b) out.push_back((uint8_t)(len >> (8 * b)));
-      out.insert(out.end(), it.bytes.begin(), it.bytes.end());
+      out.insert(out.end(), it.p, it.p + it.n);
     }
   }
 }
@@ -167,9 +205,12 @@ inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
   if (st.version != 1) return fail(TX_UNSUPPORTED, "transaction version");
   if (st.mintime > st.maxtime) return fail(TX_INVALID, "mintime after maxtime");
 
-  std::vector<Item> stack;
-  std::vector<LogEntry> log;
-  std::vector<std::vector<uint8_t>> keys;
+  // scratch of the calling thread, reused from transaction to transaction
+  static thread_local std::vector<Item> stack, payload;
+  static thread_local std::vector<LogEntry> log;
+  static thread_local std::vector<const uint8_t*> keys;
+  static thread_local std::vector<uint8_t> ser;
+  stack.clear(); log.clear(); keys.clear();
   LogEntry hdr; hdr.kind = LogEntry::Header; hdr.a = st.version; hdr.b = st.mintime; hdr.c = st.maxtime;
   log.push_back(hdr);
   bool have_anchor = false, cloaked = false;
@@ -182,9 +223,9 @@ inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
       case 0x00: {   // push:n:x
         uint32_t n;
         if (!imm32(n) || prog_len - pc < n) return fail(TX_INVALID, "push runs past the program");
-        Item it; it.kind = Item::Data; it.bytes.assign(prog + pc, prog + pc + n);
+        Item it; it.kind = Item::Data; it.p = prog + pc; it.n = n;
         pc += n;
-        stack.push_back(std::move(it));
+        stack.push_back(it);
         break;
       }
       case 0x02:     // drop
@@ -195,7 +236,7 @@ inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
       case 0x03: {   // dup:k
         uint32_t k;
         if (!imm32(k) || k >= stack.size()) return fail(TX_INVALID, "dup out of range");
-        const Item& src = stack[stack.size() - 1 - k];
+        const Item src = stack[stack.size() - 1 - k];
         if (src.kind == Item::Value || src.kind == Item::Contract) return fail(TX_INVALID, "dup of a value or a contract");
         stack.push_back(src);
         break;
@@ -203,13 +244,13 @@ inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
       case 0x04: {   // roll:k
         uint32_t k;
         if (!imm32(k) || k >= stack.size()) return fail(TX_INVALID, "roll out of range");
-        Item it = std::move(stack[stack.size() - 1 - k]);
+        const Item it = stack[stack.size() - 1 - k];
         stack.erase(stack.end() - 1 - k);
-        stack.push_back(std::move(it));
+        stack.push_back(it);
         break;
       }
       case 0x06: {   // var
-        if (stack.empty() || stack.back().kind != Item::Data || stack.back().bytes.size() != 32) return fail(TX_INVALID, "var needs a 32-byte commitment");
+        if (stack.empty() || stack.back().kind != Item::Data || stack.back().n != 32) return fail(TX_INVALID, "var needs a 32-byte commitment");
         stack.back().kind = Item::Variable;
         break;
       }
@@ -219,61 +260,58 @@ inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
         if (cloaked) return fail(TX_UNSUPPORTED, "more than one cloak per transaction");
         if (m == 0 || n == 0 || m > 64 || n > 64) return fail(TX_UNSUPPORTED, "cloak arity");
         if (stack.size() < (size_t)m + 2 * (size_t)n) return fail(TX_INVALID, "stack underflow");
-        std::vector<uint8_t> outs(64 * (size_t)n), ins(64 * (size_t)m);
+        st.commitments.resize(64 * ((size_t)m + n));      // inputs, then outputs (the values pushed below refer into it)
+        uint8_t* ins = st.commitments.data();
+        uint8_t* outs = ins + 64 * (size_t)m;
         for (uint32_t j = n; j-- > 0;) {     // .. q_j f_j on top
           for (int half = 1; half >= 0; --half) {
             if (stack.back().kind != Item::Variable) return fail(TX_INVALID, "cloak outputs must be variables");
-            std::memcpy(&outs[64 * j + 32 * half], stack.back().bytes.data(), 32);
+            std::memcpy(&outs[64 * j + 32 * half], stack.back().p, 32);
             stack.pop_back();
           }
         }
         for (uint32_t i = m; i-- > 0;) {
           if (stack.back().kind != Item::Value) return fail(TX_INVALID, "cloak inputs must be values");
-          std::memcpy(&ins[64 * i], stack.back().bytes.data(), 64);
+          std::memcpy(&ins[64 * i], stack.back().p, 64);
           stack.pop_back();
         }
         st.n_in = m; st.n_out = n;
-        st.commitments = ins;
-        st.commitments.insert(st.commitments.end(), outs.begin(), outs.end());
-        for (uint32_t j = 0; j < n; ++j) { Item v; v.kind = Item::Value; v.bytes.assign(&outs[64 * j], &outs[64 * j] + 64); stack.push_back(std::move(v)); }
+        for (uint32_t j = 0; j < n; ++j) { Item v; v.kind = Item::Value; v.p = &outs[64 * j]; v.n = 64; stack.push_back(v); }
         cloaked = true;
         break;
       }
       case 0x1b: {   // input
         if (stack.empty() || stack.back().kind != Item::Data) return fail(TX_INVALID, "input needs a serialized contract");
-        uint8_t anchor[32], pred[32];
-        std::vector<Item> payload;
+        const uint8_t* pred;
         bool unsupported = false;
-        const std::vector<uint8_t> ser = std::move(stack.back().bytes);
+        const Item c_ser = stack.back();
         stack.pop_back();
-        if (!parse_contract(ser.data(), ser.size(), anchor, pred, payload, unsupported))
+        if (!parse_contract(c_ser.p, c_ser.n, pred, nullptr, unsupported))
           return fail(unsupported ? TX_UNSUPPORTED : TX_INVALID, "malformed contract");
         LogEntry e; e.kind = LogEntry::Input;
-        contract_id(ser.data(), ser.size(), e.id);
+        contract_id(c_ser.p, c_ser.n, e.id);
         log.push_back(e);
         std::memcpy(last_anchor, e.id, 32);
         have_anchor = true;
-        Item c; c.kind = Item::Contract; c.bytes = ser;
-        stack.push_back(std::move(c));
+        Item c = c_ser; c.kind = Item::Contract;
+        stack.push_back(c);
         break;
       }
       case 0x1c: {   // output:k
         uint32_t k;
         if (!imm32(k)) return fail(TX_INVALID, "output immediate");
         if (stack.size() < (size_t)k + 1) return fail(TX_INVALID, "stack underflow");
-        if (stack.back().kind != Item::Data || stack.back().bytes.size() != 32) return fail(TX_INVALID, "output needs a 32-byte predicate");
+        if (stack.back().kind != Item::Data || stack.back().n != 32) return fail(TX_INVALID, "output needs a 32-byte predicate");
         if (!have_anchor) return fail(TX_INVALID, "output before any input: no anchor");
-        uint8_t pred[32];
-        std::memcpy(pred, stack.back().bytes.data(), 32);
+        const uint8_t* pred = stack.back().p;
         stack.pop_back();
-        std::vector<Item> items(stack.end() - k, stack.end());
-        stack.erase(stack.end() - k, stack.end());
-        for (const Item& it : items) if (it.kind != Item::Data && it.kind != Item::Value) return fail(TX_INVALID, "output payload must be data or values");
+        const Item* items = stack.data() + (stack.size() - k);
+        for (uint32_t q = 0; q < k; ++q) if (items[q].kind != Item::Data && items[q].kind != Item::Value) return fail(TX_INVALID, "output payload must be data or values");
         uint8_t anchor[32];
         ratchet_anchor(last_anchor, anchor);
         std::memcpy(last_anchor, anchor, 32);
-        std::vector<uint8_t> ser;
-        serialize_contract(anchor, pred, items, ser);
+        serialize_contract(anchor, pred, items, k, ser);
+        stack.resize(stack.size() - k);
         LogEntry e; e.kind = LogEntry::Output;
         contract_id(ser.data(), ser.size(), e.id);
         log.push_back(e);
@@ -281,14 +319,14 @@ inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
       }
       case 0x20: {   // signtx
         if (stack.empty() || stack.back().kind != Item::Contract) return fail(TX_INVALID, "signtx needs a contract");
-        uint8_t anchor[32], pred[32];
-        std::vector<Item> payload;
+        const uint8_t* pred;
         bool unsupported = false;
-        const std::vector<uint8_t> ser = std::move(stack.back().bytes);
+        const Item c_ser = stack.back();
         stack.pop_back();
-        if (!parse_contract(ser.data(), ser.size(), anchor, pred, payload, unsupported)) return fail(TX_INVALID, "malformed contract");
-        keys.emplace_back(pred, pred + 32);
-        for (Item& it : payload) stack.push_back(std::move(it));
+        payload.clear();
+        if (!parse_contract(c_ser.p, c_ser.n, pred, &payload, unsupported)) return fail(TX_INVALID, "malformed contract");
+        keys.push_back(pred);
+        for (const Item& it : payload) stack.push_back(it);
         break;
       }
       default:
@@ -306,8 +344,9 @@ inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
   if (!Scalar::from_canonical(sig + 32, s)) return fail(TX_INVALID, "signature scalar not canonical");
   ZK_TX_TRANSCRIPT(agg, "Musig.aggregated-key");
   agg.append_u64("n", keys.size());
-  for (const auto& k : keys) agg.append_point("X", k.data());
-  std::vector<Scalar> a(keys.size());
+  for (const uint8_t* k : keys) agg.append_point("X", k);
+  static thread_local std::vector<Scalar> a;
+  a.resize(keys.size());
   for (size_t i = 0; i < keys.size(); ++i) {
     Transcript ti = agg;
     ti.append_u64("i", i);
@@ -324,7 +363,7 @@ inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
   std::memcpy(&st.sig_points[32], sig, 32);
   for (size_t i = 0; i < keys.size(); ++i) {
     a[i].to_bytes(&st.sig_scalars[32 * (2 + i)]);          // a_i for now
-    std::memcpy(&st.sig_points[32 * (2 + i)], keys[i].data(), 32);
+    std::memcpy(&st.sig_points[32 * (2 + i)], keys[i], 32);
   }
   return st;
 }

@@ -150,6 +150,7 @@ def load_library():
     lib.zkgpu_verifier_verify_sharded.argtypes = [vp, vp, sz, u32p, u32p, u8p, u8p, u64p, u8p, u8p]
     lib.zkgpu_tx_verify_batch.argtypes = [vp, sz, u8p, u64p, C.c_int, u8p, u8p]
     lib.zkgpu_verifier_set_tx_format.argtypes = [vp, C.c_int]
+    lib.zkgpu_verifier_set_tx_chunk.argtypes = [vp, sz]
     lib.zkgpu_measure_hbm_copy.argtypes = [vp, sz, C.c_int, C.POINTER(C.c_double)]
     lib.zkgpu_debug_comm_mock.argtypes = [vp, C.c_int, u8p, sz]
     lib.zkgpu_debug_comm_mock.restype = C.c_longlong

@@ -250,6 +250,10 @@ class BlockVerifier:
         DESIGN.md sec 4.5, an UNPINNED recollection of the ZkVM wire format (opt-in for exactly that reason)."""
         self._check(self.lib.zkgpu_verifier_set_tx_format(self.h, fmt))
 
+    def set_tx_chunk(self, transactions: int) -> None:
+        """zkgpu_verifier_set_tx_chunk: transactions per chunk of the staged pipeline inside verify_txs (0 = automatic)"""
+        self._check(self.lib.zkgpu_verifier_set_tx_chunk(self.h, transactions))
+
     def verify_txs(self, txs: Sequence[bytes], host_threads: int = 0):
         """zkgpu_tx_verify_batch: serialized ZkVM transactions (payment subset) -> (accept bitmap, status bytes:
         0 accepted, 1 rejected, 2 outside the subset).  Inert until set_tx_format names a format."""
@@ -259,7 +263,7 @@ class BlockVerifier:
         """the same over one buffer of concatenated transactions and their lengths"""
         batch = len(lengths)
         offs = np.zeros(batch + 1, dtype=np.uint64)
-        np.cumsum(np.asarray(lengths, dtype=np.uint64), out=offs[1:])
+        np.cumsum(lengths if isinstance(lengths, np.ndarray) and lengths.dtype == np.uint64 else np.asarray(lengths, dtype=np.uint64), out=offs[1:])
         if int(offs[-1]) != len(blob):
             raise ValueError("the lengths add up to %d bytes, the buffer holds %d" % (int(offs[-1]), len(blob)))
         bm = C.create_string_buffer(max((batch + 7) // 8, 1))
