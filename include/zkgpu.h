@@ -417,6 +417,23 @@ int zkgpu_verifier_create(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t gens_
 void zkgpu_verifier_destroy(zkgpu_verifier *v);
 int zkgpu_verifier_set_chunk(zkgpu_verifier *v, size_t transactions);
 int zkgpu_verifier_lanes(const zkgpu_verifier *v);
+/* Hardware queues.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES queues (default 4; read ONCE, when the runtime
+ * starts: zkgpu_init sets it to 24 if unset, which only counts when no HIP call came before -- an embedding application
+ * that touches HIP first must export it itself).  Measured on MI355X (profiles/r03_hw_queues.txt): on 4 - 8 queues every
+ * pair of streams still overlaps, but batches in flight that wait for each other's events take turns (a mixed block: 1.3
+ * instead of 2.0 M tx/s); from 12 queues on that is gone, but the device runs fewer queues side by side than the runtime
+ * hands out, and a lane whose light stream lands on a queue that is not co-scheduled with another lane's alternates with
+ * it (the 3x - 10x cliff of round 2 at 8 and 10 lanes).  The library therefore does not trust the variable, it PROBES what
+ * it got: every lane of a new verifier is checked against the lanes kept so far (two spinning wavefronts, ~0.2 ms per
+ * pair, idle device assumed) and dropped when it would serialise with one of them -- fewer lanes, every one of them real;
+ * verdicts are the same with any number of lanes.
+ * zkgpu_verifier_queue_info: out[0] lanes in use, out[1] lanes asked for, out[2] lanes dropped, out[3] 1 when the
+ * process's HIP runtime had started before GPU_MAX_HW_QUEUES was set (zkgpu_verifier_last_error names the cause).
+ * zkgpu_ctx_queue_info: out[0] whether the context's two pipeline streams run side by side (1 / 0 / -1 probe failed;
+ * zkgpu_init asks for another stream up to six times when they do not), out[1] GPU_MAX_HW_QUEUES as the process sees it
+ * (0 = unset), out[2] the same late-start flag. */
+int zkgpu_verifier_queue_info(const zkgpu_verifier *v, int out[4]);
+int zkgpu_ctx_queue_info(zkgpu_ctx *ctx, int out[3]);
 /* context of lane i (0 = the one given to zkgpu_verifier_create), for zkgpu_set_group_size and the
  * measurement hooks below; owned by the verifier */
 zkgpu_ctx *zkgpu_verifier_lane(zkgpu_verifier *v, int i);

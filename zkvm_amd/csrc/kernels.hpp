@@ -982,6 +982,18 @@ k_from_uniform(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint
   o[1] = make_uint4(enc[4], enc[5], enc[6], enc[7]);
 }
 
+// ---- k_spin ----------------------------------------------------------------------
+// One wavefront that does nothing for `cycles` shader cycles: the probe of whether two streams really run side by side
+// (zkgpu.hip, streams_overlap) -- the runtime maps streams onto a limited set of hardware queues, and two streams that
+// share one take turns.
+__global__ void __launch_bounds__(64)
+k_spin(unsigned long long cycles, uint32_t* __restrict__ sink) {
+  const unsigned long long t0 = clock64();
+  unsigned long long spins = 0;
+  while ((unsigned long long)clock64() - t0 < cycles) ++spins;
+  if (sink && spins == ~0ull) *sink = 1;
+}
+
 // ---- k_hbm_copy -----------------------------------------------------------------
 // The achievable-HBM yardstick of SURVEY.md sec 8(d) ("measure achievable HBM with a copy kernel and report both"): 16 bytes
 // per lane, consecutive lanes on consecutive vectors, four independent loads in flight per lane, grid-stride over the buffer.

@@ -57,6 +57,7 @@ struct zkgpu_verifier {
   std::deque<int> block_busy;                           // lanes running a block's batch, oldest first
   std::map<uint64_t, std::unique_ptr<BlockRun>> block_runs;
   uint64_t next_run = 1;
+  int lanes_requested = 0, lanes_dropped = 0;           // lanes whose light stream shared a hardware queue with an earlier lane's were not kept
   int tx_format = 0;                                    // zkgpu_verifier_set_tx_format: 0 = no serialized-transaction format enabled
   // zkgpu_tx_verify_batch: two contexts of their own for the key and the signature stages (each a pair of streams beside
   // the lanes'), and a ring of staging areas (pinned host + device, grow-only) for the cloak statements of the chunks in
@@ -241,10 +242,35 @@ int zkgpu_verifier_create(zkgpu_ctx* ctx, const zkgpu_pointset* ps, size_t gens_
   zkgpu_verifier* v = new zkgpu_verifier();
   v->root = ctx; v->ps = ps; v->gens_capacity = gens_capacity;
   v->lanes.push_back(ctx);
-  for (int i = 1; i < batches_in_flight; ++i) {
-    zkgpu_ctx* f = nullptr;
-    if (zkgpu_ctx_fork(ctx, &f) != ZKGPU_OK) break;     // fewer lanes than asked for: still correct
-    v->lanes.push_back(f);
+  v->lanes_requested = batches_in_flight;
+  // A lane is worth having only if its light stream -- the latency-bound kernels of its batch: transcript, Horner chains,
+  // verdicts -- really runs beside the other lanes'.  The runtime hands out a limited number of hardware queues
+  // (GPU_MAX_HW_QUEUES, read once when HIP starts: 4 unless the process exported more BEFORE its first HIP call; zkgpu_init
+  // sets 24 when it is the first), and streams beyond that share queues: two lanes on one queue take turns, and when they
+  // also wait for each other's events they crawl (measured in round 2: 3x - 10x slower with 8 and 10 lanes than with 7 and
+  // 9).  So every new lane is probed against the lanes kept so far (two spinning wavefronts, ~0.2 ms per pair, idle
+  // device assumed) and dropped if it serialises with one of them: fewer lanes, every one of them real.
+  {
+    DeviceGuard g(ctx->device);
+    for (int i = 1; i < batches_in_flight; ++i) {
+      zkgpu_ctx* f = nullptr;
+      if (zkgpu_ctx_fork(ctx, &f) != ZKGPU_OK) break;     // fewer lanes than asked for: still correct
+      bool alone = true;
+      for (zkgpu_ctx* kept : v->lanes)
+        if (streams_overlap(kept->stream_l, f->stream_l) == 0) { alone = false; break; }
+      if (alone) { v->lanes.push_back(f); continue; }
+      ++v->lanes_dropped;
+      zkgpu_destroy(f);
+    }
+  }
+  if (g_hw_queues_late) {
+    v->last_error = "the HIP runtime of this process started before GPU_MAX_HW_QUEUES was set: it runs on its default of 4 hardware "
+                    "queues, on which batches in flight take turns -- export GPU_MAX_HW_QUEUES=24 before the process's first HIP call";
+  } else if (v->lanes_dropped) {
+    char msg[256];
+    snprintf(msg, sizeof msg, "%d of %d lanes not kept: their streams share a hardware queue with another lane's (GPU_MAX_HW_QUEUES=%s; "
+             "export it before the process's first HIP call)", v->lanes_dropped, batches_in_flight, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "unset");
+    v->last_error = msg;
   }
   v->running.resize(v->lanes.size());
   v->lane_job.resize(v->lanes.size());
@@ -277,6 +303,15 @@ int zkgpu_verifier_set_chunk(zkgpu_verifier* v, size_t transactions) {
 }
 
 int zkgpu_verifier_lanes(const zkgpu_verifier* v) { return v ? (int)v->lanes.size() : 0; }
+
+// out[0] lanes in use, out[1] lanes asked for, out[2] lanes dropped at creation because their stream did not run beside
+// another lane's, out[3] 1 when the process's HIP runtime started before GPU_MAX_HW_QUEUES was set (zkgpu_verifier_last_error
+// says which)
+int zkgpu_verifier_queue_info(const zkgpu_verifier* v, int out[4]) {
+  if (!v || !out) return ZKGPU_EINVAL;
+  out[0] = (int)v->lanes.size(); out[1] = v->lanes_requested; out[2] = v->lanes_dropped; out[3] = g_hw_queues_late ? 1 : 0;
+  return ZKGPU_OK;
+}
 
 // the context of lane i (0 = the one the verifier was created on): for the measurement hooks
 // (zkgpu_profile_*, zkgpu_set_serial, zkgpu_set_group_size); owned by the verifier

@@ -22,7 +22,9 @@
 #include <string>
 #include <map>
 #include <atomic>
+#include <dirent.h>
 #include <sys/random.h>
+#include <unistd.h>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -89,6 +91,7 @@ struct zkgpu_ctx {
   // kernels and the copy of the results to the pinned buffer, batch_collect waits and reads them -- so that the key and
   // signature stages of zkgpu_tx_verify_batch can run beside the host's work on the next chunk (session.hpp)
   struct SplitOp { int kind = 0; size_t batch = 0; bool values = false; hipStream_t stream = nullptr; } split;
+  int pair_overlaps = -1;          // root contexts: do stream and stream2 run side by side (streams_overlap at creation; -1 not probed)
   hipEvent_t dep_event = nullptr;  // the next whole-proof submit on this context waits for it first (its inputs are still being copied)
   std::vector<uint8_t> sync_result; // result of a submit that had to run synchronously
   bool sync_result_valid = false;
@@ -1204,6 +1207,52 @@ const char* zkgpu_strerror(int code) {
 const char* zkgpu_last_error(const zkgpu_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 namespace {
+bool g_hw_queues_late = false;     // GPU_MAX_HW_QUEUES was unset when the HIP runtime started, before the first zkgpu_init
+
+// is the compute driver's device node open in this process (= has the HIP / HSA runtime started)?
+bool kfd_is_open() {
+  DIR* d = opendir("/proc/self/fd");
+  if (!d) return false;
+  bool found = false;
+  while (struct dirent* e = readdir(d)) {
+    char path[64], target[64];
+    snprintf(path, sizeof path, "/proc/self/fd/%s", e->d_name);
+    const ssize_t n = readlink(path, target, sizeof target - 1);
+    if (n > 0) { target[n] = 0; if (strcmp(target, "/dev/kfd") == 0) { found = true; break; } }
+  }
+  closedir(d);
+  return found;
+}
+
+// Do kernels queued on `a` and on `b` run at the same time?  Two ~80 us spinning wavefronts, one per stream, released
+// together: side by side both finish after ~one spin, on a shared hardware queue the second finishes after two.
+// -1: the probe itself failed.  (Idle device assumed: called at creation time.)
+int streams_overlap(hipStream_t a, hipStream_t b) {
+  if (a == b) return 0;
+  hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) return -1;
+  const unsigned long long cycles = 200000;
+  int verdict = -1;
+  for (int attempt = 0; attempt < 2; ++attempt) {               // the first round also pays both streams' first launch
+    hipError_t e = hipEventRecord(e0, a);
+    if (e == hipSuccess) e = hipStreamWaitEvent(b, e0, 0);
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, cycles, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, cycles, (uint32_t*)nullptr);
+    if (e == hipSuccess) e = hipEventRecord(ea, a);
+    if (e == hipSuccess) e = hipEventRecord(eb, b);
+    if (e == hipSuccess) e = hipEventSynchronize(ea);
+    if (e == hipSuccess) e = hipEventSynchronize(eb);
+    float ta = 0, tb = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ta, e0, ea);
+    if (e == hipSuccess) e = hipEventElapsedTime(&tb, e0, eb);
+    if (e != hipSuccess) { verdict = -1; break; }
+    const float lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+    verdict = hi < 1.6f * lo ? 1 : 0;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+  return verdict;
+}
+
 // aux: a context for the general (one-stream-pair) paths only -- two streams of its own, no light stream, no third one:
 // what the key and signature stages of zkgpu_tx_verify_batch run on beside the verifier's lanes (session.hpp)
 int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out, bool aux = false) {
@@ -1248,6 +1297,20 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out, bool aux = false)
     ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
          hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
          hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest) == hipSuccess;
+    // stream and stream2 carry the two halves of every pipeline that forks (decompression beside the digit sort of a large
+    // multiscalar multiplication; the generator terms beside the proof points): if the runtime put them on one hardware
+    // queue they would take turns.  Probe, and ask for another stream2 a few times if so (each new stream lands on the next
+    // queue of the runtime's round robin).
+    std::vector<hipStream_t> rejected;
+    for (int attempt = 0; ok && attempt < 6; ++attempt) {
+      const int ov = streams_overlap(c->stream, c->stream2);
+      c->pair_overlaps = ov;
+      if (ov != 0) break;
+      rejected.push_back(c->stream2);
+      c->stream2 = nullptr;
+      ok = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess;
+    }
+    for (hipStream_t st : rejected) (void)hipStreamDestroy(st);
   }
   if (!aux) ok = ok && hipStreamCreateWithPriority(&c->stream_l, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   hipEvent_t* evs[] = {&c->ev_fork, &c->ev_join, &c->ev_t, &c->ev_p, &c->ev_sm, &c->ev_sa, &c->ev_done, &c->ev_dig, &c->ev_u};
@@ -1265,7 +1328,19 @@ int zkgpu_init(int device, zkgpu_ctx** out) {
   // hardware queues unless told otherwise, and streams that share a queue while waiting on each
   // other's events crawl.  Only effective if the HIP runtime has not started yet in this process
   // (otherwise the embedding application must export it itself); never overrides the caller.
-  setenv("GPU_MAX_HW_QUEUES", "24", 0);
+  {
+    // The variable is read ONCE, when the HIP runtime starts.  Unset and the runtime not yet started (the kernel driver's
+    // device node not yet open in this process): set it, it will count.  Unset and the runtime already up -- an embedding
+    // application that touched HIP first: setting it changes nothing, the process runs on the runtime's default of 4
+    // queues, on which batches in flight that wait for each other's events take turns (measured: a mixed block at 1.3
+    // instead of 2.0 M tx/s) -- remembered, and reported by zkgpu_ctx_queue_info and zkgpu_verifier_create.
+    static std::once_flag once;
+    std::call_once(once, [] {
+      if (getenv("GPU_MAX_HW_QUEUES")) return;
+      g_hw_queues_late = kfd_is_open();
+      setenv("GPU_MAX_HW_QUEUES", "24", 0);
+    });
+  }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ZKGPU_ENODEVICE;
   if (hipSetDevice(device) != hipSuccess) return ZKGPU_ENODEVICE;
@@ -3003,6 +3078,25 @@ int zkgpu_bulletproof_gens(zkgpu_ctx* c, size_t capacity, uint32_t party, uint8_
     sp.squeeze(stream.data(), stream.size());
     TRY(zkgpu_hash_to_points(c, stream.data(), capacity, side ? H : G));
   }
+  return ZKGPU_OK;
+}
+
+// Diagnostics of the stream -> hardware-queue mapping (idle device assumed).  out[0]: do this context's two pipeline
+// streams run side by side (1 / 0; -1: the probe failed) -- probed afresh; out[1]: GPU_MAX_HW_QUEUES as the process sees
+// it (0: unset); out[2]: 1 when that value came too late -- the HIP runtime had started, with the variable unset, before
+// the first zkgpu_init of the process.  The variable is read by the HIP runtime ONCE, when it starts: zkgpu_init sets it to 24 if it is unset,
+// which only helps when no HIP call came before -- an embedding application that touched HIP first gets the runtime's
+// default of 4 queues unless it exported the variable itself.  The library does not trust the variable: it probes what it
+// got (here, and per lane in zkgpu_verifier_create).
+int zkgpu_ctx_queue_info(zkgpu_ctx* c, int out[3]) {
+  if (!c || !out) return ZKGPU_EINVAL;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  TRY(refuse_if_pending(c));
+  DeviceGuard g(c->device);
+  out[0] = (c->stream && c->stream2) ? streams_overlap(c->stream, c->stream2) : -1;
+  const char* q = getenv("GPU_MAX_HW_QUEUES");
+  out[1] = q ? atoi(q) : 0;
+  out[2] = g_hw_queues_late ? 1 : 0;
   return ZKGPU_OK;
 }
 

@@ -150,6 +150,8 @@ def load_library():
     lib.zkgpu_verifier_verify_sharded.argtypes = [vp, vp, sz, u32p, u32p, u8p, u8p, u64p, u8p, u8p]
     lib.zkgpu_tx_verify_batch.argtypes = [vp, sz, u8p, u64p, C.c_int, u8p, u8p]
     lib.zkgpu_verifier_set_tx_format.argtypes = [vp, C.c_int]
+    lib.zkgpu_verifier_queue_info.argtypes = [vp, C.POINTER(C.c_int)]
+    lib.zkgpu_ctx_queue_info.argtypes = [vp, C.POINTER(C.c_int)]
     lib.zkgpu_verifier_set_tx_chunk.argtypes = [vp, sz]
     lib.zkgpu_measure_hbm_copy.argtypes = [vp, sz, C.c_int, C.POINTER(C.c_double)]
     lib.zkgpu_debug_comm_mock.argtypes = [vp, C.c_int, u8p, sz]
@@ -251,6 +253,13 @@ class Context:
 
     def free_device(self, d_ptr: int) -> None:
         self._check(self.lib.zkgpu_free(self.h, C.c_void_p(d_ptr)))
+
+    def queue_info(self):
+        """zkgpu_ctx_queue_info -> (the two pipeline streams run side by side: 1 / 0 / -1, GPU_MAX_HW_QUEUES or 0,
+        1 when the HIP runtime had started before the variable was set)"""
+        out = (C.c_int * 3)()
+        self._check(self.lib.zkgpu_ctx_queue_info(self.h, out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def measure_hbm_copy(self, nbytes: int = 1 << 30, iters: int = 10) -> float:
         """zkgpu_measure_hbm_copy: achievable HBM bandwidth of a streaming copy, GB/s (read + written)"""

@@ -174,6 +174,13 @@ class BlockVerifier:
     def lanes(self) -> int:
         return int(self.lib.zkgpu_verifier_lanes(self.h))
 
+    def queue_info(self):
+        """zkgpu_verifier_queue_info -> (lanes in use, lanes asked for, lanes dropped because they would not run beside the
+        others, 1 when the HIP runtime had started before GPU_MAX_HW_QUEUES was set)"""
+        out = (C.c_int * 4)()
+        self._check(self.lib.zkgpu_verifier_queue_info(self.h, out))
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
+
     def lane(self, i: int) -> Context:
         """zkgpu_verifier_lane: lane i's context (owned by the verifier) for set_group_size / the profile hooks."""
         return Context(_borrowed=int(self.lib.zkgpu_verifier_lane(self.h, i)))
