@@ -6,11 +6,10 @@ this package is the thin host-side mirror used by tests and bench.py.  There is
 no CPU fallback: importing works anywhere, but creating a `Context` without the
 built library or without a GPU raises.
 """
-import os as _os
-
-# batches in flight use one light stream each (zkgpu_ctx_fork): let the HIP runtime give them hardware
-# queues of their own (default 4).  Only effective when set before the runtime initialises.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# GPU_MAX_HW_QUEUES (the HIP runtime's number of hardware queues, read once when it starts) is the library's business:
+# zkgpu_init sets it when it is unset and the runtime has not started yet, and remembers when it came too late
+# (Context.queue_info, BlockVerifier.queue_info).  A process that uses HIP before its first Context -- torch.cuda, say --
+# exports the variable itself, before that (bench.py does, at its very top).
 
 from .native import Context, PointSet, ZkGpuError, lib_path, load_library  # noqa: F401
 
