@@ -517,7 +517,7 @@ class StepSet:
     __slots__ = ("com", "proofs", "r", "want", "bits", "txs", "r_bytes")
 
 
-def make_exchange(W, ctx, cuts, always_comm=False):
+def make_exchange(W, ctx, cuts, always_comm=False, comm=None):
     """The one exchange step of the sharded path -- rank r's accept bitmap of [cuts[r], cuts[r+1]) in, the bitmap of the
     whole batch out on every rank -- through the C ABI (zkgpu_comm_allgather_bitmap: ncclAllGather over xGMI) in both
     configs; gloo only when several ranks share one GPU (ZKGPU_BENCH_SHARE_GPU, the 1-GPU rehearsal: RCCL refuses two
@@ -527,15 +527,18 @@ def make_exchange(W, ctx, cuts, always_comm=False):
             if status:
                 raise RuntimeError("verification failed with status %d" % status)
             return local
-        return alone, (lambda: None), "none (one rank)"
+        return alone, (lambda: None), "none (one rank)", None
     parts = [(cuts[i], cuts[i + 1]) for i in range(W.world)]
     if W.share_gpu:
         from zkvm_amd.sharded import gather_bitmaps
-        return (lambda local, status=0: gather_bitmaps(parts, local, status != 0, W.dist, None)), (lambda: None), "gloo (ranks share one GPU)"
+        return (lambda local, status=0: gather_bitmaps(parts, local, status != 0, W.dist, None)), (lambda: None), "gloo (ranks share one GPU)", None
     from zkvm_amd.native import Comm
-    uid = W.broadcast_bytes(Comm.unique_id() if W.rank == 0 else b"", 128)
-    comm = Comm(ctx, W.rank, W.world, uid)
-    return (lambda local, status=0: comm.allgather_bitmap(cuts, local, status)), comm.close, "ncclAllGather via zkgpu_comm_allgather_bitmap"
+    own = comm is None
+    if own:
+        uid = W.broadcast_bytes(Comm.unique_id() if W.rank == 0 else b"", 128)
+        comm = Comm(ctx, W.rank, W.world, uid)
+    ex = (lambda local, status=0: comm.allgather_bitmap(cuts, local, status)), (comm.close if own else (lambda: None)), "ncclAllGather via zkgpu_comm_allgather_bitmap"
+    return ex + (comm,)
 
 
 def run_config2(args, W):
@@ -578,7 +581,8 @@ def run_config2(args, W):
     proof_len = len(txs[0][3])
     nbytes = (batch + 7) // 8
     cuts = [batch * i for i in range(world + 1)]
-    exchange, close_exchange, exchange_name = make_exchange(W, ctx, cuts)
+    exchange, close_exchange, exchange_name, comm0 = make_exchange(W, ctx, cuts)
+    exchanges, shared_comm = {1: (exchange, close_exchange, exchange_name, comm0)}, [comm0]
 
     # `--inflight M`: M device batches in flight.  Each has its own forked context (workspace + a light stream for its
     # latency-bound kernels); the chip-filling kernels of all of them go first-in first-out through the parent's
@@ -595,11 +599,32 @@ def run_config2(args, W):
     host_time = {"submit": 0.0, "n": 0}
     whole_last = [None]
 
+    # N > 1: every step's accept bitmap is exchanged (zkgpu_comm_allgather_bitmap: ncclAllGather over xGMI) and the whole
+    # bitmap checked on every rank -- the bitmaps of the steps that one merged device batch finished together travel in ONE
+    # collective (a status word + 128 bytes per step and rank: latency-bound either way), not in one collective per step
+    gather_every = max(1, args.merge // batch) if args.tickets > 0 else 1
+    pend_x = []
+
+    def flush_exchange():
+        if not pend_x:
+            return
+        g = len(pend_x)
+        cuts_g = [batch * g * i for i in range(world + 1)]
+        ex = exchanges.get(g)
+        if ex is None:
+            ex = exchanges[g] = make_exchange(W, ctx, cuts_g, comm=shared_comm[0])
+        whole = ex[0](b"".join(bm for bm, _ in pend_x), 0)
+        mine = whole[rank * nbytes * g:(rank + 1) * nbytes * g]
+        assert mine == b"".join(bm for bm, _ in pend_x)
+        whole_last[0] = whole
+        pend_x.clear()
+
     def checked(bm, j, gather=True):
         assert bm == sets[j].want, "accept bitmap of step set %d differs from the constructed expectation" % j
         if gather and world > 1:
-            whole_last[0] = exchange(bm, 0)
-            assert whole_last[0][rank * nbytes:(rank + 1) * nbytes] == bm
+            pend_x.append((bm, j))
+            if len(pend_x) >= gather_every:
+                flush_exchange()
         return bm
 
     def run_steps(n, base=0, submit=None, gather=True, lanes=None):
@@ -625,6 +650,7 @@ def run_config2(args, W):
         while pend:
             cc, j = pend.popleft()
             bm = checked(cc.verify_wait(), j, gather)
+        flush_exchange()
         return bm
 
     bv = None
@@ -659,6 +685,7 @@ def run_config2(args, W):
         while q:                                              # every step's bitmap is checked and exchanged, the drained ones too
             t, j = q.popleft()
             bm = checked(bv.wait(t), j, gather)
+        flush_exchange()
         return bm
 
     # what the device executes are merged batches of --merge transactions: the per-kernel figures (solo pass, PMC passes)
@@ -671,8 +698,10 @@ def run_config2(args, W):
         if rep == 1:
             S = sets[js[0]]
             return S.com, S.proofs, S.r, S.want
-        return (torch.cat([sets[j].com for j in js]), torch.cat([sets[j].proofs for j in js]), torch.cat([sets[j].r for j in js]),
-                bitmap_of([b for j in js for b in sets[j].bits]))
+        out = (torch.cat([sets[j].com for j in js]), torch.cat([sets[j].proofs for j in js]), torch.cat([sets[j].r for j in js]),
+               bitmap_of([b for j in js for b in sets[j].bits]))
+        torch.cuda.synchronize()      # (torch.cat runs on torch's stream; the library's streams do not wait for it)
+        return out
 
     def solo_pass(reps=5):
         ctx.profile_reset()
@@ -748,7 +777,8 @@ def run_config2(args, W):
                             "tx_per_gpu": batch, "terms_per_tx": n_dyn + n_static, "generator_table_bits": args.table_bits,
                             "calls_in_flight": min(args.tickets, args.steps) if bv is not None else len(ctxs), "group_size": args.group,
                             "merged_device_batches": ({"transactions": args.merge, "lanes": bv.lanes()} if bv is not None else None),
-                            "distinct_step_inputs": n_sets, "exchange": exchange_name, "ranks": ranks_info,
+                            "distinct_step_inputs": n_sets, "exchange": exchange_name, "steps_per_exchange": gather_every if world > 1 else None,
+                            "ranks": ranks_info,
                             "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "hw_queues_set_by": "caller" if _HWQ_PRESET else "bench.py, before the HIP runtime started",
                             "parallelism": "tx-sharded x%d, RCCL all-gather of accept bitmaps" % world})
         line["roofline"] = roofline_object(solo, launches, in_flight_ms, alg_dev, dev_batch, ms_per_dev_batch, table_bytes,
@@ -910,6 +940,7 @@ def table_bits_sweep(args, ctx, lanes, sets, n_in, n_out, proof_len, batch, gens
         js = range(k * rep, (k + 1) * rep)
         big.append((torch.cat([sets[j].com for j in js]), torch.cat([sets[j].proofs for j in js]), torch.cat([sets[j].r for j in js]),
                     bitmap_of([b for j in js for b in sets[j].bits])))
+    torch.cuda.synchronize()          # (torch.cat runs on torch's stream; the library's streams do not wait for it)
     for w in (13, 14, 15, 16):
         t0 = time.perf_counter()
         g = gens16 if w == args.table_bits else BulletproofGens(ctx, 256, table_bits=w)
@@ -973,7 +1004,7 @@ def run_config4(args, W):
     mine = [CloakTx(*t) for t in txs[lo:hi]]
     block = bv.block(mine, r_bytes[64 * lo: 64 * hi])          # this rank's shard, resident in HBM, grouped by shape
     # the exchange step: RCCL behind the C ABI (zkgpu_comm), the same function config 2 uses; gloo when several ranks share one GPU
-    exchange, close_exchange, exchange_name = make_exchange(W, ctx, cuts, always_comm=True)   # (a world of one too: through RCCL)
+    exchange, close_exchange, exchange_name, _comm = make_exchange(W, ctx, cuts, always_comm=True)   # (a world of one too: through RCCL)
     parts = [(cuts[i], cuts[i + 1]) for i in range(world)]
 
     # a step = one whole block: its batches queued on the lanes (zkgpu_verifier_block_start), its verdicts waited for

@@ -165,7 +165,9 @@ k_decompress(const uint32_t* __restrict__ pts, uint32_t* __restrict__ rows, uint
 // shares its registers with everything live around it and the kernel runs one wave per
 // SIMD; split in three, the chain runs alone in a ~100-register kernel at full occupancy
 // and the ends trade 280 B/point of scratch traffic for it.
-//   scratch row (72 words): s[10] u1[10] u2[10] v[10] w[10] r[10] flags pad  (w = v * u2^2, r = w^((p-5)/8))
+//   scratch, word-major (word k of point i at scratch[k n + i]: every load and store of a wavefront is one contiguous
+//   256-byte run -- point-major rows of 64 words cost four times the traffic): s[10] u1[10] u2[10] v[10] w[10] r[10] flags
+//   (w = v * u2^2, r = w^((p-5)/8))
 constexpr int DEC_WORDS = 64;
 
 __global__ void __launch_bounds__(256)
@@ -200,12 +202,13 @@ k_decompress_pre(const uint32_t* __restrict__ pts, uint32_t* __restrict__ scratc
   fe_mul(w3, w2, t);
   fe_sq(w7, w3);
   fe_mul(w7, w7, t);
-  uint32_t* row = scratch + i * DEC_WORDS;
+  uint32_t* col = scratch + i;
 #pragma unroll
-  for (int k = 0; k < 10; ++k) { row[k] = s.v[k]; row[10 + k] = u1.v[k]; row[20 + k] = u2.v[k]; row[30 + k] = v.v[k]; row[40 + k] = t.v[k]; row[50 + k] = w7.v[k]; }
-  row[60] = pre_ok ? 1u : 0u;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) row[61 + k] = 0;
+  for (int k = 0; k < 10; ++k) {
+    col[(uint64_t)k * n] = s.v[k]; col[(uint64_t)(10 + k) * n] = u1.v[k]; col[(uint64_t)(20 + k) * n] = u2.v[k];
+    col[(uint64_t)(30 + k) * n] = v.v[k]; col[(uint64_t)(40 + k) * n] = t.v[k]; col[(uint64_t)(50 + k) * n] = w7.v[k];
+  }
+  col[(uint64_t)60 * n] = pre_ok ? 1u : 0u;
   (void)w3;
 }
 
@@ -214,13 +217,13 @@ __global__ void __launch_bounds__(256, 4)
 k_pow22523(uint32_t* __restrict__ scratch, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint32_t* row = scratch + i * DEC_WORDS + 50;
+  uint32_t* col = scratch + (uint64_t)50 * n + i;
   fe x, r;
 #pragma unroll
-  for (int k = 0; k < 10; ++k) x.v[k] = row[k];
+  for (int k = 0; k < 10; ++k) x.v[k] = col[(uint64_t)k * n];
   fe_pow22523(r, x);
 #pragma unroll
-  for (int k = 0; k < 10; ++k) row[k] = r.v[k];
+  for (int k = 0; k < 10; ++k) col[(uint64_t)k * n] = r.v[k];
 }
 
 __global__ void __launch_bounds__(256)
@@ -229,11 +232,14 @@ k_decompress_post(const uint32_t* __restrict__ scratch, uint32_t* __restrict__ r
                   unsigned long long* __restrict__ bad_index) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t* row = scratch + i * DEC_WORDS;
+  const uint32_t* col = scratch + i;
   fe s, u1, u2, v, w, pw;
 #pragma unroll
-  for (int k = 0; k < 10; ++k) { s.v[k] = row[k]; u1.v[k] = row[10 + k]; u2.v[k] = row[20 + k]; v.v[k] = row[30 + k]; w.v[k] = row[40 + k]; pw.v[k] = row[50 + k]; }
-  const bool pre_ok = row[60] != 0;
+  for (int k = 0; k < 10; ++k) {
+    s.v[k] = col[(uint64_t)k * n]; u1.v[k] = col[(uint64_t)(10 + k) * n]; u2.v[k] = col[(uint64_t)(20 + k) * n];
+    v.v[k] = col[(uint64_t)(30 + k) * n]; w.v[k] = col[(uint64_t)(40 + k) * n]; pw.v[k] = col[(uint64_t)(50 + k) * n];
+  }
+  const bool pre_ok = col[(uint64_t)60 * n] != 0;
   // SQRT_RATIO_M1(1, w): r = w^3 * (w^7)^((p-5)/8); check = w r^2
   fe w3, r, t, check, r_prime, neg_r;
   fe_sq(t, w);
