@@ -52,7 +52,7 @@ def prepare(host, tx):
         sp.raw[: 32 * n_sig.value], po.value, pl.value
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (2, 2), (3, 2), (1, 2)])
+@pytest.mark.parametrize("shape", [(1, 1), (2, 2), (3, 2), (1, 2), (6, 3)])     # (6, 3): more values and keys than a statement keeps inline
 def test_transaction_statement_equals_oracle(host, oracle, shape):
     """Same transaction ID, same cloak statement, and a signature equation that the oracle's multiscalar multiplication
     finds to be the identity -- for a valid transaction; the same verdict for damaged ones."""

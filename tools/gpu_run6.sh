@@ -1,10 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for Q in 4 6 8 12 16 24; do
-  export GPU_MAX_HW_QUEUES=$Q
-  A=$(python bench.py --lean --steps 200 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['config']['merged_device_batches']['lanes'])")
-  B=$(python bench.py --lean --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'])")
-  C=$(python bench.py --config 4 --lean --steps 10 --warmup 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['config']['calls_in_flight'])")
-  D=$(python tools/msm_bench.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['pairs_per_s'], d['ms'], d['kernel_ms_sum'])")
-  echo "hwq $Q | config2 200: $A | 20: $B | config4: $C | msm: $D"
-done
+python -m pytest tests -m gpu -x -q -k "zkvm_tx or never_run_over" 2>&1 | tail -8
+ZKGPU_PROVER_TIMING=1 python tools/tx_bench.py 8 2>&1 | grep -E "library call|tx verify" | tail -4
+python tools/tx_bench.py 1 2>&1 | grep -E "library call" | tail -2
+python tools/tx_bench.py 16 2>&1 | grep -E "library call" | tail -2
+python tools/tx_bench.py 32 2>&1 | grep -E "library call" | tail -2
