@@ -120,6 +120,51 @@ def test_committed_transaction_fixture_is_what_the_oracle_accepts(host, oracle):
         assert rc == 0 and got[0] == 0 and got[1] == txid and (got[2], got[3]) == (a, b) == (2, 2)
 
 
+def test_lockstep_hashing_of_eight_transactions_equals_one_at_a_time(host, oracle):
+    """merlin_x8.hpp: the payment VM's hashing with eight Keccak states per AVX-512 register against the same plans run one
+    transaction at a time -- status, transaction ID, MuSig coefficients and signature terms (after the challenge) byte
+    for byte: uniform groups (the committed transactions), groups with a damaged or foreign transaction in them (the
+    rest still runs in lockstep), groups of other shapes side by side (one at a time), ragged last groups; and the
+    one-at-a-time form is the one every other test holds against the oracle."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from gpu_util import load_tx_fixture
+    rng = random.Random(808)
+    base = load_tx_fixture()
+    txs = list(base[:203])                                                     # ragged: 25 groups of eight and one of three
+    for i in rng.sample(range(len(txs)), 30):
+        t = bytearray(txs[i])
+        kind = rng.randrange(4)
+        if kind == 0:
+            t[rng.randrange(len(t))] ^= 1 << rng.randrange(8)
+        elif kind == 1:
+            t[0] = 2
+        elif kind == 2:
+            t = t[: len(t) - 1 - rng.randrange(50)]
+        else:
+            t = bytearray(payment(oracle, rng.choice([1, 3]), rng.choice([1, 2]), 5000 + i))      # another shape in the group
+        txs[i] = bytes(t)
+    txs += [payment(oracle, 3, 2, 6000 + i, two_flavors=True) for i in range(9)]                    # a uniform run of another shape
+    txs += [payment(oracle, 6, 3, 7000 + i) for i in range(8)]                                     # more keys than fit inline
+    blob = b"".join(txs)
+    offs = (C.c_uint64 * (len(txs) + 1))()
+    for i, t in enumerate(txs):
+        offs[i + 1] = offs[i] + len(t)
+    agg = hashlib.shake_256(b"aggregated keys").digest(32 * len(txs))
+    out = {}
+    for mode in (0, 1):
+        st, ids, dig = C.create_string_buffer(len(txs)), C.create_string_buffer(32 * len(txs)), C.create_string_buffer(64 * len(txs))
+        have = host.zkhost_tx_prepare_group(blob, offs, C.c_size_t(len(txs)), mode, agg, st, ids, dig)
+        out[mode] = (st.raw, ids.raw, dig.raw)
+    assert out[0] == out[1]
+    assert out[0][0].count(b"\x00") >= 190 and out[0][0].count(b"\x02") >= 3
+    if not have:
+        pytest.skip("no AVX-512 on this CPU: both modes ran one transaction at a time")
+    for i in (0, 7, 100, 202, 203, 211, 212, 219):                              # and the one-at-a-time form is the oracle's
+        rc, txid, a, b = oracle.tx_id(txs[i])
+        assert rc == out[1][0][i] and (rc != 0 or txid == out[1][1][32 * i: 32 * i + 32])
+
+
 @pytest.mark.gpu
 def test_transactions_verified_on_the_device_equal_oracle():
     """zkgpu_tx_verify_batch: a batch of serialized transactions of several shapes, some damaged in every part, some outside

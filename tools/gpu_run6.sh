@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q -k "zkvm_tx or never_run_over" 2>&1 | tail -8
-ZKGPU_PROVER_TIMING=1 python tools/tx_bench.py 8 2>&1 | grep -E "library call|tx verify" | tail -4
-python tools/tx_bench.py 1 2>&1 | grep -E "library call" | tail -2
-python tools/tx_bench.py 16 2>&1 | grep -E "library call" | tail -2
-python tools/tx_bench.py 32 2>&1 | grep -E "library call" | tail -2
+R=$GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/txtr -- python3 $R/tools/tx_bench.py 8 > /dev/null 2> $R/gpurun_out/txtr.err)
+python tools/tx_trace.py $(ls gpurun_out/txtr/*/*_kernel_trace.csv | head -1) 14 > gpurun_out/txtr_summary.txt
+grep -v "fillBuffer\|copyBuffer" gpurun_out/txtr_summary.txt | awk '$2 > 0.05 || /last burst/' | head -90

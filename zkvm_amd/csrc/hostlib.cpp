@@ -734,3 +734,37 @@ extern "C" void zkhost_comm_pack(uint8_t* out, size_t slot, const uint64_t* cuts
 extern "C" int zkhost_comm_unpack(const uint8_t* all, size_t slot, const uint64_t* cuts, int world, int rank, uint8_t* whole) {
   return commframe::unpack(all, slot, cuts, world, rank, whole);
 }
+
+// ---- the lockstep (AVX-512, eight transactions at a time) form of the payment VM's hashing against the one-at-a-time
+// ---- form: for the CPU tests.  Per transaction out: status | txid (32) | then, for accepted ones, the statement's
+// ---- commitments, signature scalars and points (after the challenge has been applied with the given aggregated keys)
+// ---- folded into a SHA3-512 digest (64).  Returns 1 when AVX-512 is available (0: both modes ran one at a time).
+extern "C" int zkhost_tx_prepare_group(const uint8_t* txs, const uint64_t* offs, size_t count, int lockstep, const uint8_t* agg_keys /*32 per tx*/,
+                                       uint8_t* status, uint8_t* txid /*32 per tx*/, uint8_t* digest /*64 per tx*/) {
+  using namespace zk::zkvm;
+  uint8_t base[32];
+  for (int i = 0; i < 32; ++i) base[i] = (uint8_t)(0xB0 + i);
+  for (size_t g = 0; g < count; g += 8) {
+    const size_t n = std::min<size_t>(8, count - g);
+    const uint8_t* p[8]; size_t l[8];
+    TxStatement st[8];
+    for (size_t i = 0; i < n; ++i) { p[i] = txs + offs[g + i]; l[i] = (size_t)(offs[g + i + 1] - offs[g + i]); }
+    tx_prepare_many(p, l, st, n, lockstep != 0);
+    TxStatement* live[8]; const uint8_t* keys[8]; size_t nl = 0;
+    for (size_t i = 0; i < n; ++i) if (st[i].status == TX_OK) { live[nl] = &st[i]; keys[nl] = agg_keys + 32 * (g + i); ++nl; }
+    if (lockstep) tx_finish_signature_many(live, keys, base, nl);
+    else for (size_t i = 0; i < nl; ++i) tx_finish_signature(*live[i], base, keys[i]);
+    for (size_t i = 0; i < n; ++i) {
+      status[g + i] = (uint8_t)st[i].status;
+      std::memcpy(txid + 32 * (g + i), st[i].txid, 32);
+      Sponge sp = sha3_512_sponge();
+      if (st[i].status == TX_OK) {
+        sp.absorb(st[i].commitments.data(), st[i].commitments.size());
+        sp.absorb(st[i].sig_scalars.data(), st[i].sig_scalars.size());
+        sp.absorb(st[i].sig_points.data(), st[i].sig_points.size());
+      }
+      sp.squeeze(digest + 64 * (g + i), 64);
+    }
+  }
+  return x8_available() ? 1 : 0;
+}

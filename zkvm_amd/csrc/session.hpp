@@ -1182,12 +1182,18 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     k.sidx.assign(ns, 0);
     k.sst_off.resize(ns + 1);
     for (size_t q = 0; q <= ns; ++q) k.sst_off[q] = q;
-    par(ns, [&](size_t q) {
-      TxStatement& t = k.st[k.live[k.keyed[q]]];
-      tx_finish_signature(t, B, &k.agg[32 * k.keyed[q]]);
-      memcpy(&k.sst[32 * q], t.sig_scalars.data(), 32);
-      memcpy(k.ssc.data() + 32 * k.soff[q], t.sig_scalars.data() + 32, t.sig_scalars.size() - 32);
-      memcpy(k.spt.data() + 32 * k.soff[q], t.sig_points.data() + 32, t.sig_points.size() - 32);
+    par((ns + 7) / 8, [&](size_t g) {              // eight challenges c = H(txid, X, R) at a time
+      TxStatement* tp[8];
+      const uint8_t* ap[8];
+      const size_t first = 8 * g, cnt = std::min<size_t>(8, ns - first);
+      for (size_t q = 0; q < cnt; ++q) { tp[q] = &k.st[k.live[k.keyed[first + q]]]; ap[q] = &k.agg[32 * k.keyed[first + q]]; }
+      tx_finish_signature_many(tp, ap, B, cnt);
+      for (size_t q = first; q < first + cnt; ++q) {
+        const TxStatement& t = *tp[q - first];
+        memcpy(&k.sst[32 * q], t.sig_scalars.data(), 32);
+        memcpy(k.ssc.data() + 32 * k.soff[q], t.sig_scalars.data() + 32, t.sig_scalars.size() - 32);
+        memcpy(k.spt.data() + 32 * k.soff[q], t.sig_points.data() + 32, t.sig_points.size() - 32);
+      }
     });
     if (note(verify_ps_enqueue(v->aux_sigs, v->ps, ns, k.ssc.data(), k.spt.data(), k.soff.data(), k.sst.data(), k.sidx.data(), k.sst_off.data()),
              v->aux_sigs) == ZKGPU_OK)
@@ -1202,7 +1208,15 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     // ---- VM
     double t0 = now();
     k.st.resize(k.n);
-    par(k.n, [&](size_t i) { k.st[i] = tx_prepare(txs + tx_offsets[k.lo + i], (size_t)(tx_offsets[k.lo + i + 1] - tx_offsets[k.lo + i])); });
+    // eight transactions per task: the hashing of transactions of one shape runs in lockstep on AVX-512 (zkvm_tx.hpp,
+    // tx_prepare_many; merlin_x8.hpp)
+    par((k.n + 7) / 8, [&](size_t g) {
+      const uint8_t* p[8];
+      size_t l[8];
+      const size_t first = 8 * g, cnt = std::min<size_t>(8, k.n - first);
+      for (size_t q = 0; q < cnt; ++q) { p[q] = txs + tx_offsets[k.lo + first + q]; l[q] = (size_t)(tx_offsets[k.lo + first + q + 1] - tx_offsets[k.lo + first + q]); }
+      tx_prepare_many(p, l, &k.st[first], cnt);
+    });
     for (size_t i = 0; i < k.n; ++i) {
       if (status && k.st[i].status == TX_UNSUPPORTED) status[k.lo + i] = TX_UNSUPPORTED;     // (TX_OK is written at the very end only)
       if (k.st[i].status == TX_OK) k.live.push_back(i);
@@ -1245,11 +1259,11 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
         src[q] = TxSource{t.n_in, t.n_out, t.commitments.data(), t.proof, t.proof_len};
       }
       if (first_rc == ZKGPU_OK && note(txblock_build_locked(v, nl, src.data(), nullptr, host_threads, &k.blk, &v->tx_arenas[ci % RING]), nullptr) == ZKGPU_OK) {
-        // the chunk goes to the lanes in batches short enough for the one-wavefront-per-transaction transcript: this path is
-        // bound by the host and by the length of a batch's dependent chain (the last chunk's is the tail of the call),
-        // not by how well a batch fills the chip
+        // a chunk of one shape goes to the device as few, large batches -- except the LAST chunk of a longer call: what
+        // remains after it is the tail of the call, as long as its batches' dependent chains, and batches short enough for
+        // the one-wavefront-per-transaction transcript have the shortest
         const size_t saved_chunk = v->chunk;
-        v->chunk = std::max<size_t>(saved_chunk, 4096);
+        v->chunk = (n_chunks > 1 && ci + 1 == n_chunks) ? COOP_TRANSCRIPT_MAX : std::max<size_t>(saved_chunk, 4096);
         k.run = block_start(v, k.blk);
         v->chunk = saved_chunk;
         if (k.run->rc != ZKGPU_OK) note(k.run->rc, nullptr);

@@ -15,6 +15,7 @@
 //   Contract := anchor:32 | predicate:32 | k:u32 | item*      item := 0x00 n:u32 bytes[n]  |  0x02 qty:32 flavor:32
 #pragma once
 #include "merlin.hpp"
+#include "merlin_x8.hpp"
 #include "scalar.hpp"
 
 #include <cstdint>
@@ -87,46 +88,151 @@ struct Item {
 inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline uint64_t rd64(const uint8_t* p) { return (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
 
-// every hash below starts from a copy of its label's freshly initialised transcript (two Keccak-f saved per hash)
-#define ZK_TX_TRANSCRIPT(var, label) static const Transcript var##_proto(label); Transcript var = var##_proto
-inline void contract_id(const uint8_t* ser, size_t n, uint8_t id[32]) {
-  ZK_TX_TRANSCRIPT(t, "ZkVM.contractid");
-  t.append_message("contract", ser, n);
-  t.challenge_bytes("id", id, 32);
+// ---- hashing as a PLAN ------------------------------------------------------------------------------------------------
+// The VM below does not hash while it runs: it writes down WHAT is to be hashed -- a list of Merlin transcripts ("jobs":
+// contract ids, anchors, the leaves and nodes of the transaction-ID Merkle tree, the MuSig coefficients), each a list of
+// messages given as pieces (bytes of the transaction, bytes of the statement's commitment buffer, small immediates, or
+// the 32-byte result of an earlier job: a "slot") -- and the plan is executed afterwards: one transaction at a time
+// (run_plan), or EIGHT transactions of the same plan shape in lockstep on AVX-512 (run_plans_x8, merlin_x8.hpp).  Every
+// hash starts from a copy of its label's freshly initialised transcript (two Keccak-f saved per hash).
+enum Proto : uint8_t { P_CONTRACTID = 0, P_RATCHET, P_TXID, P_MUSIG, P_SIGNTX, N_PROTO };
+enum Label : uint8_t { L_CONT = 0 /* more bytes of the message in progress */, L_contract, L_id, L_old, L_new, L_tx_version, L_tx_mintime,
+                       L_tx_maxtime, L_merkle_leaf, L_input, L_output, L_L, L_R, L_merkle_node, L_merkle_empty, L_n, L_X, L_i, L_a_i,
+                       L_txid, L_dom_sep, L_c, N_LABEL };
+inline const char* label_text(uint8_t l) {
+  static const char* const t[N_LABEL] = {"", "contract", "id", "old", "new", "tx.version", "tx.mintime", "tx.maxtime", "merkle.leaf", "input",
+                                         "output", "L", "R", "merkle.node", "merkle.empty", "n", "X", "i", "a_i", "txid", "dom-sep", "c"};
+  return t[l];
 }
-inline void ratchet_anchor(const uint8_t old_anchor[32], uint8_t fresh[32]) {
-  ZK_TX_TRANSCRIPT(t, "ZkVM.ratchet-anchor");
-  t.append_message("old", old_anchor, 32);
-  t.challenge_bytes("new", fresh, 32);
+inline const Transcript& proto_transcript(uint8_t p) {
+  static const Transcript t[N_PROTO] = {Transcript("ZkVM.contractid"), Transcript("ZkVM.ratchet-anchor"), Transcript("ZkVM.txid"),
+                                        Transcript("Musig.aggregated-key"), Transcript("ZkVM.signtx")};
+  return t[p];
 }
 
+struct HashPiece {
+  enum Kind : uint8_t { Bytes = 0, Slot = 1, Imm = 2 };
+  uint8_t label = L_CONT;        // != L_CONT: this piece opens a message of msg_len bytes in all
+  uint8_t kind = Bytes;
+  uint16_t slot = 0;             // Slot: which
+  uint32_t len = 0, msg_len = 0;
+  uint32_t off = 0;              // Imm: offset into the plan's immediate pool
+  const uint8_t* p = nullptr;    // Bytes: where
+};
+struct HashJob { uint8_t proto, chal_label, out_len; uint16_t out_slot; uint32_t first, count; };
+struct TxPlan {
+  std::vector<HashJob> jobs;
+  std::vector<HashPiece> pieces;
+  std::vector<uint8_t> imm;
+  std::vector<uint32_t> shape;   // everything that must agree for two plans to run in lockstep (no pointers, no contents)
+  uint16_t n_slots = 0;
+  void clear() { jobs.clear(); pieces.clear(); imm.clear(); shape.clear(); n_slots = 0; }
+  void begin(uint8_t proto) { jobs.push_back(HashJob{proto, 0, 0, 0, (uint32_t)pieces.size(), 0}); shape.push_back(0x4a000000u | proto); }
+  void piece(uint8_t label, uint8_t kind, const uint8_t* p, uint32_t len, uint32_t msg_len, uint16_t slot = 0, uint32_t off = 0) {
+    HashPiece h; h.label = label; h.kind = kind; h.p = p; h.len = len; h.msg_len = msg_len; h.slot = slot; h.off = off;
+    pieces.push_back(h);
+    shape.push_back(((uint32_t)label << 24) | ((uint32_t)kind << 16) | slot);
+    shape.push_back(len);
+    shape.push_back(msg_len);
+  }
+  void bytes(uint8_t label, const uint8_t* p, uint32_t len, uint32_t msg_len) { piece(label, HashPiece::Bytes, p, len, msg_len); }
+  void slot(uint8_t label, uint16_t s, uint32_t msg_len = 32) { piece(label, HashPiece::Slot, nullptr, 32, msg_len, s); }
+  void immediate(uint8_t label, const uint8_t* b, uint32_t len, uint32_t msg_len) {
+    const uint32_t off = (uint32_t)imm.size();
+    imm.insert(imm.end(), b, b + len);
+    piece(label, HashPiece::Imm, nullptr, len, msg_len, 0, off);
+  }
+  void u64(uint8_t label, uint64_t x) {
+    uint8_t b[8];
+    for (int i = 0; i < 8; ++i) b[i] = (uint8_t)(x >> (8 * i));
+    immediate(label, b, 8, 8);
+  }
+  // closes the job: its challenge (32 bytes, or 64 bytes reduced to a canonical scalar) goes to a new slot
+  uint16_t end(uint8_t chal_label, uint8_t out_len) {
+    HashJob& j = jobs.back();
+    j.chal_label = chal_label; j.out_len = out_len; j.out_slot = n_slots++;
+    j.count = (uint32_t)pieces.size() - j.first;
+    shape.push_back(0x4b000000u | ((uint32_t)chal_label << 8) | out_len);
+    return j.out_slot;
+  }
+  bool same_shape(const TxPlan& o) const { return shape.size() == o.shape.size() && std::memcmp(shape.data(), o.shape.data(), 4 * shape.size()) == 0; }
+};
+
+inline const uint8_t* piece_bytes(const TxPlan& P, const HashPiece& h, const uint8_t* slots) {
+  return h.kind == HashPiece::Bytes ? h.p : h.kind == HashPiece::Slot ? slots + 32 * (size_t)h.slot : P.imm.data() + h.off;
+}
+
+// slots: 32 bytes per slot.  One transaction.
+inline void run_plan(const TxPlan& P, uint8_t* slots) {
+  static thread_local std::vector<uint8_t> msg;
+  for (const HashJob& j : P.jobs) {
+    Transcript t = proto_transcript(j.proto);
+    for (uint32_t q = j.first; q < j.first + j.count;) {
+      const HashPiece& h = P.pieces[q];
+      if (h.len == h.msg_len) { t.append_message(label_text(h.label), piece_bytes(P, h, slots), h.len); ++q; continue; }
+      msg.clear();                                        // a message in several pieces: assembled first
+      uint32_t q2 = q;
+      do { const HashPiece& g = P.pieces[q2]; const uint8_t* b = piece_bytes(P, g, slots); msg.insert(msg.end(), b, b + g.len); ++q2; }
+      while (q2 < j.first + j.count && P.pieces[q2].label == L_CONT);
+      t.append_message(label_text(h.label), msg.data(), msg.size());
+      q = q2;
+    }
+    uint8_t out[64];
+    t.challenge_bytes(label_text(j.chal_label), out, j.out_len);
+    if (j.out_len == 64) Scalar::from_wide(out).to_bytes(slots + 32 * (size_t)j.out_slot);
+    else std::memcpy(slots + 32 * (size_t)j.out_slot, out, 32);
+  }
+}
+
+#if ZK_HAVE_X8
+// Eight plans of one shape in lockstep (lanes may repeat a plan: padding).  slots[l]: lane l's slot memory.
+ZK_X8 inline void run_plans_x8(const TxPlan* const P[8], uint8_t* const slots[8]) {
+  const TxPlan& P0 = *P[0];
+  for (size_t ji = 0; ji < P0.jobs.size(); ++ji) {
+    const HashJob& j = P0.jobs[ji];
+    TranscriptX8 t(proto_transcript(j.proto));
+    for (uint32_t q = j.first; q < j.first + j.count; ++q) {
+      const HashPiece& h = P0.pieces[q];
+      if (h.label != L_CONT) t.begin_message(label_text(h.label), h.msg_len);
+      const uint8_t* d[8];
+      for (int l = 0; l < 8; ++l) d[l] = piece_bytes(*P[l], P[l]->pieces[q], slots[l]);
+      t.data(d, h.len);
+    }
+    uint8_t wide[8][64];
+    uint8_t* out[8];
+    for (int l = 0; l < 8; ++l) out[l] = j.out_len == 64 ? wide[l] : slots[l] + 32 * (size_t)j.out_slot;
+    t.challenge(label_text(j.chal_label), out, j.out_len);
+    if (j.out_len == 64)
+      for (int l = 0; l < 8; ++l) Scalar::from_wide(wide[l]).to_bytes(slots[l] + 32 * (size_t)j.out_slot);
+  }
+}
+#endif
+
 // Merkle root over the log entries (RFC 6962 split: the largest power of two below the count goes left), every hash a
-// Merlin transcript: leaf = entry's own messages then "merkle.leaf"; node = "L", "R" then "merkle.node"
+// Merlin transcript: leaf = entry's own messages then "merkle.leaf"; node = "L", "R" then "merkle.node".  -> slot of the root
 struct LogEntry {
   enum Kind : uint8_t { Header, Input, Output } kind;
   uint64_t a = 0, b = 0, c = 0;
-  uint8_t id[32] = {0};
+  uint16_t id_slot = 0;
 };
-inline void merkle_root(const Transcript& fresh, const LogEntry* e, size_t n, uint8_t out[32]) {
-  Transcript t = fresh;
-  if (n == 0) { t.challenge_bytes("merkle.empty", out, 32); return; }
+inline uint16_t plan_merkle(TxPlan& P, const LogEntry* e, size_t n) {
+  if (n == 0) { P.begin(P_TXID); return P.end(L_merkle_empty, 32); }
   if (n == 1) {
+    P.begin(P_TXID);
     switch (e->kind) {
-      case LogEntry::Header: t.append_u64("tx.version", e->a); t.append_u64("tx.mintime", e->b); t.append_u64("tx.maxtime", e->c); break;
-      case LogEntry::Input: t.append_message("input", e->id, 32); break;
-      case LogEntry::Output: t.append_message("output", e->id, 32); break;
+      case LogEntry::Header: P.u64(L_tx_version, e->a); P.u64(L_tx_mintime, e->b); P.u64(L_tx_maxtime, e->c); break;
+      case LogEntry::Input: P.slot(L_input, e->id_slot); break;
+      case LogEntry::Output: P.slot(L_output, e->id_slot); break;
     }
-    t.challenge_bytes("merkle.leaf", out, 32);
-    return;
+    return P.end(L_merkle_leaf, 32);
   }
   size_t k = 1;
   while (2 * k < n) k *= 2;
-  uint8_t l[32], r[32];
-  merkle_root(fresh, e, k, l);
-  merkle_root(fresh, e + k, n - k, r);
-  t.append_message("L", l, 32);
-  t.append_message("R", r, 32);
-  t.challenge_bytes("merkle.node", out, 32);
+  const uint16_t l = plan_merkle(P, e, k), r = plan_merkle(P, e + k, n - k);
+  P.begin(P_TXID);
+  P.slot(L_L, l);
+  P.slot(L_R, r);
+  return P.end(L_merkle_node, 32);
 }
 
 // parses a serialized contract; false: malformed.  items (Data or Value) refer into `p`
@@ -163,58 +269,43 @@ inline bool parse_contract(const uint8_t* p, size_t n, const uint8_t*& predicate
   return pos == n;
 }
 
-inline void serialize_contract(const uint8_t anchor[32], const uint8_t predicate[32], const Item* items, size_t n_items, std::vector<uint8_t>& out) {
-  out.assign(anchor, anchor + 32);
-  out.insert(out.end(), predicate, predicate + 32);
-  const uint32_t k = (uint32_t)n_items;
-  for (int b = 0; b < 4; ++b) out.push_back((uint8_t)(k >> (8 * b)));
-  for (size_t q = 0; q < n_items; ++q) {
-    const Item& it = items[q];
-    if (it.kind == Item::Value) {
-      out.push_back(0x02);
-      out.insert(out.end(), it.p, it.p + it.n);
-    } else {
-      out.push_back(0x00);
-      const uint32_t len = (uint32_t)it.n;
-      for (int b = 0; b < 4; ++b) out.push_back((uint8_t)(len >> (8 * b)));
-      out.insert(out.end(), it.p, it.p + it.n);
-    }
-  }
-}
-
-// Runs the transaction: parse, VM, transaction ID, signature equation.  The statement refers into `tx` (proof bytes).
-inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
-  TxStatement st;
-  auto fail = [&st](TxStatus s, const char* why) { st.status = s; st.why = why; return st; };
-  if (len < 24 + 4) return fail(TX_INVALID, "truncated header");
+// First half: parse, VM, and the PLAN of everything there is to hash (nothing is hashed yet).  The statement refers into
+// `tx` (proof bytes), the plan into `tx` and into st.commitments: neither may move until the plan has run.
+// txid_slot / a_slots: where the transaction ID and the MuSig coefficients will be found.
+struct TxSlots { uint16_t txid = 0; std::vector<uint16_t> a; std::vector<const uint8_t*> keys; const uint8_t* sig = nullptr; };
+inline void tx_structure(const uint8_t* tx, size_t len, TxStatement& st, TxPlan& P, TxSlots& out) {
+  st = TxStatement();
+  P.clear();
+  out.a.clear(); out.keys.clear();
+  auto fail = [&st](TxStatus s, const char* why) { st.status = s; st.why = why; };
+  if (len < 24 + 4) { fail(TX_INVALID, "truncated header"); return; }
   st.version = rd64(tx); st.mintime = rd64(tx + 8); st.maxtime = rd64(tx + 16);
   size_t pos = 24;
   const uint32_t prog_len = rd32(tx + pos);
   pos += 4;
-  if (len - pos < prog_len) return fail(TX_INVALID, "truncated program");
+  if (len - pos < prog_len) { fail(TX_INVALID, "truncated program"); return; }
   const uint8_t* prog = tx + pos;
   pos += prog_len;
-  if (len - pos < 64 + 4) return fail(TX_INVALID, "truncated signature");
+  if (len - pos < 64 + 4) { fail(TX_INVALID, "truncated signature"); return; }
   const uint8_t* sig = tx + pos;
   pos += 64;
   const uint32_t proof_len = rd32(tx + pos);
   pos += 4;
-  if (len - pos != proof_len) return fail(TX_INVALID, "proof length does not match the transaction's");
+  if (len - pos != proof_len) { fail(TX_INVALID, "proof length does not match the transaction's"); return; }
   st.proof = tx + pos;
   st.proof_len = proof_len;
-  if (st.version != 1) return fail(TX_UNSUPPORTED, "transaction version");
-  if (st.mintime > st.maxtime) return fail(TX_INVALID, "mintime after maxtime");
+  if (st.version != 1) { fail(TX_UNSUPPORTED, "transaction version"); return; }
+  if (st.mintime > st.maxtime) { fail(TX_INVALID, "mintime after maxtime"); return; }
 
   // scratch of the calling thread, reused from transaction to transaction
   static thread_local std::vector<Item> stack, payload;
   static thread_local std::vector<LogEntry> log;
-  static thread_local std::vector<const uint8_t*> keys;
-  static thread_local std::vector<uint8_t> ser;
-  stack.clear(); log.clear(); keys.clear();
+  std::vector<const uint8_t*>& keys = out.keys;
+  stack.clear(); log.clear();
   LogEntry hdr; hdr.kind = LogEntry::Header; hdr.a = st.version; hdr.b = st.mintime; hdr.c = st.maxtime;
   log.push_back(hdr);
   bool have_anchor = false, cloaked = false;
-  uint8_t last_anchor[32] = {0};
+  uint16_t last_anchor = 0;              // slot
   size_t pc = 0;
   auto imm32 = [&](uint32_t& v) { if (prog_len - pc < 4) return false; v = rd32(prog + pc); pc += 4; return true; };
   while (pc < prog_len) {
@@ -222,56 +313,56 @@ inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
     switch (op) {
       case 0x00: {   // push:n:x
         uint32_t n;
-        if (!imm32(n) || prog_len - pc < n) return fail(TX_INVALID, "push runs past the program");
+        if (!imm32(n) || prog_len - pc < n) { fail(TX_INVALID, "push runs past the program"); return; }
         Item it; it.kind = Item::Data; it.p = prog + pc; it.n = n;
         pc += n;
         stack.push_back(it);
         break;
       }
       case 0x02:     // drop
-        if (stack.empty()) return fail(TX_INVALID, "stack underflow");
-        if (stack.back().kind == Item::Value || stack.back().kind == Item::Contract) return fail(TX_INVALID, "drop of a value or a contract");
+        if (stack.empty()) { fail(TX_INVALID, "stack underflow"); return; }
+        if (stack.back().kind == Item::Value || stack.back().kind == Item::Contract) { fail(TX_INVALID, "drop of a value or a contract"); return; }
         stack.pop_back();
         break;
       case 0x03: {   // dup:k
         uint32_t k;
-        if (!imm32(k) || k >= stack.size()) return fail(TX_INVALID, "dup out of range");
+        if (!imm32(k) || k >= stack.size()) { fail(TX_INVALID, "dup out of range"); return; }
         const Item src = stack[stack.size() - 1 - k];
-        if (src.kind == Item::Value || src.kind == Item::Contract) return fail(TX_INVALID, "dup of a value or a contract");
+        if (src.kind == Item::Value || src.kind == Item::Contract) { fail(TX_INVALID, "dup of a value or a contract"); return; }
         stack.push_back(src);
         break;
       }
       case 0x04: {   // roll:k
         uint32_t k;
-        if (!imm32(k) || k >= stack.size()) return fail(TX_INVALID, "roll out of range");
+        if (!imm32(k) || k >= stack.size()) { fail(TX_INVALID, "roll out of range"); return; }
         const Item it = stack[stack.size() - 1 - k];
         stack.erase(stack.end() - 1 - k);
         stack.push_back(it);
         break;
       }
       case 0x06: {   // var
-        if (stack.empty() || stack.back().kind != Item::Data || stack.back().n != 32) return fail(TX_INVALID, "var needs a 32-byte commitment");
+        if (stack.empty() || stack.back().kind != Item::Data || stack.back().n != 32) { fail(TX_INVALID, "var needs a 32-byte commitment"); return; }
         stack.back().kind = Item::Variable;
         break;
       }
       case 0x18: {   // cloak:m:n
         uint32_t m, n;
-        if (!imm32(m) || !imm32(n)) return fail(TX_INVALID, "cloak immediates");
-        if (cloaked) return fail(TX_UNSUPPORTED, "more than one cloak per transaction");
-        if (m == 0 || n == 0 || m > 64 || n > 64) return fail(TX_UNSUPPORTED, "cloak arity");
-        if (stack.size() < (size_t)m + 2 * (size_t)n) return fail(TX_INVALID, "stack underflow");
+        if (!imm32(m) || !imm32(n)) { fail(TX_INVALID, "cloak immediates"); return; }
+        if (cloaked) { fail(TX_UNSUPPORTED, "more than one cloak per transaction"); return; }
+        if (m == 0 || n == 0 || m > 64 || n > 64) { fail(TX_UNSUPPORTED, "cloak arity"); return; }
+        if (stack.size() < (size_t)m + 2 * (size_t)n) { fail(TX_INVALID, "stack underflow"); return; }
         st.commitments.resize(64 * ((size_t)m + n));      // inputs, then outputs (the values pushed below refer into it)
         uint8_t* ins = st.commitments.data();
         uint8_t* outs = ins + 64 * (size_t)m;
         for (uint32_t j = n; j-- > 0;) {     // .. q_j f_j on top
           for (int half = 1; half >= 0; --half) {
-            if (stack.back().kind != Item::Variable) return fail(TX_INVALID, "cloak outputs must be variables");
+            if (stack.back().kind != Item::Variable) { fail(TX_INVALID, "cloak outputs must be variables"); return; }
             std::memcpy(&outs[64 * j + 32 * half], stack.back().p, 32);
             stack.pop_back();
           }
         }
         for (uint32_t i = m; i-- > 0;) {
-          if (stack.back().kind != Item::Value) return fail(TX_INVALID, "cloak inputs must be values");
+          if (stack.back().kind != Item::Value) { fail(TX_INVALID, "cloak inputs must be values"); return; }
           std::memcpy(&ins[64 * i], stack.back().p, 64);
           stack.pop_back();
         }
@@ -281,17 +372,19 @@ inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
         break;
       }
       case 0x1b: {   // input
-        if (stack.empty() || stack.back().kind != Item::Data) return fail(TX_INVALID, "input needs a serialized contract");
+        if (stack.empty() || stack.back().kind != Item::Data) { fail(TX_INVALID, "input needs a serialized contract"); return; }
         const uint8_t* pred;
         bool unsupported = false;
         const Item c_ser = stack.back();
         stack.pop_back();
         if (!parse_contract(c_ser.p, c_ser.n, pred, nullptr, unsupported))
-          return fail(unsupported ? TX_UNSUPPORTED : TX_INVALID, "malformed contract");
+          { fail(unsupported ? TX_UNSUPPORTED : TX_INVALID, "malformed contract"); return; }
         LogEntry e; e.kind = LogEntry::Input;
-        contract_id(c_ser.p, c_ser.n, e.id);
+        P.begin(P_CONTRACTID);
+        P.bytes(L_contract, c_ser.p, (uint32_t)c_ser.n, (uint32_t)c_ser.n);
+        e.id_slot = P.end(L_id, 32);
         log.push_back(e);
-        std::memcpy(last_anchor, e.id, 32);
+        last_anchor = e.id_slot;
         have_anchor = true;
         Item c = c_ser; c.kind = Item::Contract;
         stack.push_back(c);
@@ -299,84 +392,138 @@ inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
       }
       case 0x1c: {   // output:k
         uint32_t k;
-        if (!imm32(k)) return fail(TX_INVALID, "output immediate");
-        if (stack.size() < (size_t)k + 1) return fail(TX_INVALID, "stack underflow");
-        if (stack.back().kind != Item::Data || stack.back().n != 32) return fail(TX_INVALID, "output needs a 32-byte predicate");
-        if (!have_anchor) return fail(TX_INVALID, "output before any input: no anchor");
+        if (!imm32(k)) { fail(TX_INVALID, "output immediate"); return; }
+        if (stack.size() < (size_t)k + 1) { fail(TX_INVALID, "stack underflow"); return; }
+        if (stack.back().kind != Item::Data || stack.back().n != 32) { fail(TX_INVALID, "output needs a 32-byte predicate"); return; }
+        if (!have_anchor) { fail(TX_INVALID, "output before any input: no anchor"); return; }
         const uint8_t* pred = stack.back().p;
         stack.pop_back();
         const Item* items = stack.data() + (stack.size() - k);
-        for (uint32_t q = 0; q < k; ++q) if (items[q].kind != Item::Data && items[q].kind != Item::Value) return fail(TX_INVALID, "output payload must be data or values");
-        uint8_t anchor[32];
-        ratchet_anchor(last_anchor, anchor);
-        std::memcpy(last_anchor, anchor, 32);
-        serialize_contract(anchor, pred, items, k, ser);
+        for (uint32_t q = 0; q < k; ++q) if (items[q].kind != Item::Data && items[q].kind != Item::Value) { fail(TX_INVALID, "output payload must be data or values"); return; }
+        P.begin(P_RATCHET);
+        P.slot(L_old, last_anchor);
+        last_anchor = P.end(L_new, 32);
+        // the new contract, serialized as the message "contract": anchor | predicate | k | items
+        uint32_t ser_len = 68;
+        for (uint32_t q = 0; q < k; ++q) ser_len += items[q].kind == Item::Value ? 1 + 64 : 1 + 4 + (uint32_t)items[q].n;
+        P.begin(P_CONTRACTID);
+        P.slot(L_contract, last_anchor, ser_len);
+        P.bytes(L_CONT, pred, 32, ser_len);
+        { const uint8_t kb[4] = {(uint8_t)k, (uint8_t)(k >> 8), (uint8_t)(k >> 16), (uint8_t)(k >> 24)}; P.immediate(L_CONT, kb, 4, ser_len); }
+        for (uint32_t q = 0; q < k; ++q) {
+          const Item& it = items[q];
+          if (it.kind == Item::Value) {
+            const uint8_t ty = 0x02;
+            P.immediate(L_CONT, &ty, 1, ser_len);
+          } else {
+            const uint32_t n = (uint32_t)it.n;
+            const uint8_t hd[5] = {0x00, (uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
+            P.immediate(L_CONT, hd, 5, ser_len);
+          }
+          if (it.n) P.bytes(L_CONT, it.p, (uint32_t)it.n, ser_len);
+        }
         stack.resize(stack.size() - k);
         LogEntry e; e.kind = LogEntry::Output;
-        contract_id(ser.data(), ser.size(), e.id);
+        e.id_slot = P.end(L_id, 32);
         log.push_back(e);
         break;
       }
       case 0x20: {   // signtx
-        if (stack.empty() || stack.back().kind != Item::Contract) return fail(TX_INVALID, "signtx needs a contract");
+        if (stack.empty() || stack.back().kind != Item::Contract) { fail(TX_INVALID, "signtx needs a contract"); return; }
         const uint8_t* pred;
         bool unsupported = false;
         const Item c_ser = stack.back();
         stack.pop_back();
         payload.clear();
-        if (!parse_contract(c_ser.p, c_ser.n, pred, &payload, unsupported)) return fail(TX_INVALID, "malformed contract");
+        if (!parse_contract(c_ser.p, c_ser.n, pred, &payload, unsupported)) { fail(TX_INVALID, "malformed contract"); return; }
         keys.push_back(pred);
         for (const Item& it : payload) stack.push_back(it);
         break;
       }
       default:
-        return fail(TX_UNSUPPORTED, "instruction outside the payment subset");
+        { fail(TX_UNSUPPORTED, "instruction outside the payment subset"); return; }
     }
   }
-  if (!stack.empty()) return fail(TX_INVALID, "stack not empty at the end");
-  if (!cloaked) return fail(TX_UNSUPPORTED, "no cloak: nothing for the proof system");
-  if (keys.empty()) return fail(TX_INVALID, "no key signs the transaction");
-  static const Transcript txid_proto("ZkVM.txid");
-  merkle_root(txid_proto, log.data(), log.size(), st.txid);
+  if (!stack.empty()) { fail(TX_INVALID, "stack not empty at the end"); return; }
+  if (!cloaked) { fail(TX_UNSUPPORTED, "no cloak: nothing for the proof system"); return; }
+  if (keys.empty()) { fail(TX_INVALID, "no key signs the transaction"); return; }
+  out.txid = plan_merkle(P, log.data(), log.size());
 
   // signature: X = sum a_i X_i (MuSig key aggregation), c = H(txid, X, R);  s B == R + c X
   Scalar s;
-  if (!Scalar::from_canonical(sig + 32, s)) return fail(TX_INVALID, "signature scalar not canonical");
-  ZK_TX_TRANSCRIPT(agg, "Musig.aggregated-key");
-  agg.append_u64("n", keys.size());
-  for (const uint8_t* k : keys) agg.append_point("X", k);
-  static thread_local std::vector<Scalar> a;
-  a.resize(keys.size());
+  if (!Scalar::from_canonical(sig + 32, s)) { fail(TX_INVALID, "signature scalar not canonical"); return; }
+  // a_i = H("Musig.aggregated-key": n, X_0 .. X_{n-1}, then i): one transcript per key (the common prefix is absorbed again:
+  // a permutation at most for a handful of keys)
   for (size_t i = 0; i < keys.size(); ++i) {
-    Transcript ti = agg;
-    ti.append_u64("i", i);
-    a[i] = ti.challenge_scalar("a_i");
+    P.begin(P_MUSIG);
+    P.u64(L_n, keys.size());
+    for (const uint8_t* k : keys) P.bytes(L_X, k, 32, 32);
+    P.u64(L_i, i);
+    out.a.push_back(P.end(L_a_i, 64));
   }
-  // the aggregated key as an encoding is not needed by the equation, but it is what the challenge binds: it has to be
-  // computed, which needs the group -- the caller (device or test library) supplies it through `aggregate`
+  out.sig = sig;
   st.sig_scalars.resize(32 * (2 + keys.size()));
   st.sig_points.resize(32 * (2 + keys.size()));
   st.status = TX_OK;
-  // slots: [0] B (filled by the caller: scalar s), [1] R (scalar -1), [2 + i] X_i (scalar -c a_i, c filled in by finish_signature)
+  // terms: [0] B (filled by the caller: scalar s), [1] R (scalar -1), [2 + i] X_i (scalar a_i for now -- tx_finish_hashes --,
+  // -c a_i once tx_finish_signature knows the aggregated key)
   s.to_bytes(&st.sig_scalars[0]);
   (-Scalar::one()).to_bytes(&st.sig_scalars[32]);
   std::memcpy(&st.sig_points[32], sig, 32);
-  for (size_t i = 0; i < keys.size(); ++i) {
-    a[i].to_bytes(&st.sig_scalars[32 * (2 + i)]);          // a_i for now
-    std::memcpy(&st.sig_points[32 * (2 + i)], keys[i], 32);
+  for (size_t i = 0; i < keys.size(); ++i) std::memcpy(&st.sig_points[32 * (2 + i)], keys[i], 32);
+}
+
+// after the plan has run: the transaction ID and the MuSig coefficients move from the slots into the statement
+inline void tx_finish_hashes(TxStatement& st, const TxSlots& out, const uint8_t* slots) {
+  std::memcpy(st.txid, slots + 32 * (size_t)out.txid, 32);
+  for (size_t i = 0; i < out.a.size(); ++i) std::memcpy(&st.sig_scalars[32 * (2 + i)], slots + 32 * (size_t)out.a[i], 32);
+}
+
+// Runs up to eight transactions: parse, VM, transaction ID, signature terms.  Transactions whose plans have one shape
+// (payments of the same arity and payload sizes, as a block mostly holds) are hashed in lockstep, eight Keccak states per
+// AVX-512 register; anything else -- other shapes side by side, a CPU without AVX-512 -- one at a time.  Same results.
+inline void tx_prepare_many(const uint8_t* const* tx, const size_t* len, TxStatement* st, size_t count, bool allow_x8 = true) {
+  static thread_local TxPlan plans[8];
+  static thread_local TxSlots outs[8];
+  static thread_local std::vector<uint8_t> slot_mem[8];
+  int live[8], n_live = 0;
+  for (size_t i = 0; i < count && i < 8; ++i) {
+    tx_structure(tx[i], len[i], st[i], plans[i], outs[i]);
+    if (st[i].status != TX_OK) continue;
+    slot_mem[i].resize(32 * (size_t)plans[i].n_slots + 32);
+    live[n_live++] = (int)i;
   }
+  bool lockstep = false;
+#if ZK_HAVE_X8
+  lockstep = allow_x8 && n_live >= 3 && x8_available();
+  for (int q = 1; lockstep && q < n_live; ++q) lockstep = plans[live[q]].same_shape(plans[live[0]]);
+  if (lockstep) {
+    static thread_local std::vector<uint8_t> spare[8];
+    const TxPlan* P[8];
+    uint8_t* S[8];
+    for (int l = 0; l < 8; ++l) {
+      if (l < n_live) { P[l] = &plans[live[l]]; S[l] = slot_mem[live[l]].data(); }
+      else { P[l] = &plans[live[0]]; spare[l].resize(slot_mem[live[0]].size()); S[l] = spare[l].data(); }     // padding: lane 0's work again
+    }
+    run_plans_x8(P, S);
+  }
+#endif
+  for (int q = 0; q < n_live; ++q) {
+    const int i = live[q];
+    if (!lockstep) run_plan(plans[i], slot_mem[i].data());
+    tx_finish_hashes(st[i], outs[i], slot_mem[i].data());
+  }
+}
+
+inline TxStatement tx_prepare(const uint8_t* tx, size_t len) {
+  TxStatement st;
+  tx_prepare_many(&tx, &len, &st, 1);
   return st;
 }
 
 // second half of the signature preparation, once the aggregated key X = sum a_i X_i is known as an encoding
 // (one small multiscalar multiplication per transaction: zkgpu_msm_batch on the device, host_rows in the CPU tests)
-inline void tx_finish_signature(TxStatement& st, const uint8_t basepoint[32], const uint8_t agg_key[32]) {
-  ZK_TX_TRANSCRIPT(t, "ZkVM.signtx");
-  t.append_message("txid", st.txid, 32);
-  t.append_message("dom-sep", (const uint8_t*)"schnorr-signature v1", 20);
-  t.append_point("X", agg_key);
-  t.append_point("R", &st.sig_points[32]);
-  const Scalar c = t.challenge_scalar("c");
+inline void tx_apply_challenge(TxStatement& st, const uint8_t basepoint[32], const Scalar& c) {
   std::memcpy(&st.sig_points[0], basepoint, 32);
   const size_t n_keys = st.sig_scalars.size() / 32 - 2;
   for (size_t i = 0; i < n_keys; ++i) {
@@ -384,6 +531,44 @@ inline void tx_finish_signature(TxStatement& st, const uint8_t basepoint[32], co
     Scalar::from_canonical(&st.sig_scalars[32 * (2 + i)], ai);
     (-(c * ai)).to_bytes(&st.sig_scalars[32 * (2 + i)]);
   }
+}
+inline void tx_finish_signature(TxStatement& st, const uint8_t basepoint[32], const uint8_t agg_key[32]) {
+  Transcript t = proto_transcript(P_SIGNTX);
+  t.append_message("txid", st.txid, 32);
+  t.append_message("dom-sep", (const uint8_t*)"schnorr-signature v1", 20);
+  t.append_point("X", agg_key);
+  t.append_point("R", &st.sig_points[32]);
+  tx_apply_challenge(st, basepoint, t.challenge_scalar("c"));
+}
+// the same for up to eight transactions (the transcript has one shape whatever the transaction: always in lockstep)
+inline void tx_finish_signature_many(TxStatement* const* st, const uint8_t* const* agg_key, const uint8_t basepoint[32], size_t count) {
+#if ZK_HAVE_X8
+  if (count >= 3 && count <= 8 && x8_available()) {
+    [&]() ZK_X8 {
+      TranscriptX8 t(proto_transcript(P_SIGNTX));
+      const uint8_t* d[8];
+      auto lane = [&](int l) { return (size_t)l < count ? (size_t)l : 0; };
+      t.begin_message("txid", 32);
+      for (int l = 0; l < 8; ++l) d[l] = st[lane(l)]->txid;
+      t.data(d, 32);
+      t.begin_message("dom-sep", 20);
+      t.data_same((const uint8_t*)"schnorr-signature v1", 20);
+      t.begin_message("X", 32);
+      for (int l = 0; l < 8; ++l) d[l] = agg_key[lane(l)];
+      t.data(d, 32);
+      t.begin_message("R", 32);
+      for (int l = 0; l < 8; ++l) d[l] = &st[lane(l)]->sig_points[32];
+      t.data(d, 32);
+      uint8_t wide[8][64];
+      uint8_t* out[8];
+      for (int l = 0; l < 8; ++l) out[l] = wide[l];
+      t.challenge("c", out, 64);
+      for (size_t l = 0; l < count; ++l) tx_apply_challenge(*st[l], basepoint, Scalar::from_wide(wide[l]));
+    }();
+    return;
+  }
+#endif
+  for (size_t l = 0; l < count; ++l) tx_finish_signature(*st[l], basepoint, agg_key[l]);
 }
 
 }  // namespace zkvm
