@@ -1,7 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-R=$GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/txtr -- python3 $R/tools/tx_bench.py 8 > /dev/null 2> $R/gpurun_out/txtr.err)
-python tools/tx_trace.py $(ls gpurun_out/txtr/*/*_kernel_trace.csv | head -1) 14 > gpurun_out/txtr_summary.txt
-grep -v "fillBuffer\|copyBuffer" gpurun_out/txtr_summary.txt | awk '$2 > 0.05 || /last burst/' | head -90
+ZKGPU_PROVER_TIMING=1 python tools/tx_bench.py 8 0 0 16 2>&1 | grep -E "library call|tx verify" | tail -2
+ZKGPU_TX_TAIL_SPLIT=1 ZKGPU_PROVER_TIMING=1 python tools/tx_bench.py 8 0 0 16 2>&1 | grep -E "library call|tx verify" | tail -2
+for TC in 1536 2048 4096; do ZKGPU_PROVER_TIMING=1 python tools/tx_bench.py 8 0 $TC 16 2>&1 | grep -E "library call" | tail -1; done

@@ -1259,11 +1259,10 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
         src[q] = TxSource{t.n_in, t.n_out, t.commitments.data(), t.proof, t.proof_len};
       }
       if (first_rc == ZKGPU_OK && note(txblock_build_locked(v, nl, src.data(), nullptr, host_threads, &k.blk, &v->tx_arenas[ci % RING]), nullptr) == ZKGPU_OK) {
-        // a chunk of one shape goes to the device as few, large batches -- except the LAST chunk of a longer call: what
-        // remains after it is the tail of the call, as long as its batches' dependent chains, and batches short enough for
-        // the one-wavefront-per-transaction transcript have the shortest
+        // a chunk of one shape goes to the device as few, large batches (measured: the last chunk in batches short enough for
+        // the one-wavefront-per-transaction transcript, or cut in two, does not shorten the tail of the call)
         const size_t saved_chunk = v->chunk;
-        v->chunk = (n_chunks > 1 && ci + 1 == n_chunks) ? COOP_TRANSCRIPT_MAX : std::max<size_t>(saved_chunk, 4096);
+        v->chunk = std::max<size_t>(saved_chunk, 4096);
         k.run = block_start(v, k.blk);
         v->chunk = saved_chunk;
         if (k.run->rc != ZKGPU_OK) note(k.run->rc, nullptr);
