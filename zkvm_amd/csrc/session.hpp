@@ -63,7 +63,7 @@ struct zkgpu_verifier {
   // the lanes'), and a ring of staging areas (pinned host + device, grow-only) for the cloak statements of the chunks in
   // flight -- nothing on that path allocates or frees device memory once the sizes have been seen (hipFree synchronises)
   zkgpu_ctx* aux_keys = nullptr;
-  zkgpu_ctx* aux_sigs = nullptr;
+  zkgpu_ctx* aux_sigs[2] = {nullptr, nullptr};           // signature equations of the chunks, in turn: a stage may still run when the next is queued
   struct TxArena { void* h_pin = nullptr; size_t h_cap = 0; char* dev = nullptr; size_t d_cap = 0; hipEvent_t copied = nullptr; };
   hipStream_t copy_stream = nullptr;                    // staging copies run here; the lanes wait for TxArena::copied
   std::vector<TxArena> tx_arenas;
@@ -285,7 +285,7 @@ void zkgpu_verifier_destroy(zkgpu_verifier* v) {
   for (auto& kv : v->requests) delete kv.second;
   for (size_t i = 1; i < v->lanes.size(); ++i) zkgpu_destroy(v->lanes[i]);
   if (v->aux_keys) zkgpu_destroy(v->aux_keys);
-  if (v->aux_sigs) zkgpu_destroy(v->aux_sigs);
+  for (zkgpu_ctx* a : v->aux_sigs) if (a) zkgpu_destroy(a);
   {
     DeviceGuard g(v->root->device);
     for (auto& a : v->tx_arenas) { if (a.h_pin) (void)hipHostFree(a.h_pin); if (a.dev) (void)hipFree(a.dev); if (a.copied) (void)hipEventDestroy(a.copied); }
@@ -991,7 +991,7 @@ namespace {
 
 // One chunk of a zkgpu_tx_verify_batch call on its way through the stages (see below)
 struct TxChunk {
-  size_t lo = 0, n = 0;                                 // transactions [lo, lo + n) of the call
+  size_t lo = 0, n = 0, index = 0;                      // transactions [lo, lo + n) of the call; which chunk
   std::vector<zk::zkvm::TxStatement> st;
   std::vector<size_t> live;                             // positions in the chunk the VM accepted
   // aggregated keys: rows of (a_i, X_i)
@@ -1112,7 +1112,8 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   {
     DeviceGuard g(c->device);
     if (!v->aux_keys && ctx_create(c->device, nullptr, &v->aux_keys, true) != ZKGPU_OK) { v->aux_keys = nullptr; v->last_error = "no context for the key stage"; return ZKGPU_EHIP; }
-    if (!v->aux_sigs && ctx_create(c->device, nullptr, &v->aux_sigs, true) != ZKGPU_OK) { v->aux_sigs = nullptr; v->last_error = "no context for the signature stage"; return ZKGPU_EHIP; }
+    for (zkgpu_ctx*& a : v->aux_sigs)
+      if (!a && ctx_create(c->device, nullptr, &a, true) != ZKGPU_OK) { a = nullptr; v->last_error = "no context for the signature stage"; return ZKGPU_EHIP; }
   }
   if (!v->have_basepoint) {
     uint8_t Bb[32];
@@ -1143,19 +1144,22 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   int first_rc = ZKGPU_OK;
   auto note = [&](int rc, zkgpu_ctx* where) { if (rc != ZKGPU_OK && first_rc == ZKGPU_OK) { first_rc = rc; if (where) v->last_error = zkgpu_last_error(where); } return rc; };
 
+  auto mark = [&](const char* what, size_t ci) { if (timing) fprintf(stderr, "    %7.3f ms  %s %zu\n", (now() - t00) * 1e3, what, ci); };
   auto keys_collect = [&](TxChunk& k) {
     if (!k.keys_pending) return;
     k.keys_pending = false;
     const double t0 = now();
     note(split_collect(v->aux_keys, k.kok.data(), k.agg.data()), v->aux_keys);
     t_wait += now() - t0;
+    mark("keys collected, chunk at", k.lo);
   };
   auto sigs_collect = [&](TxChunk& k) {
     if (!k.sigs_pending) return;
     k.sigs_pending = false;
     const double t0 = now();
-    note(split_collect(v->aux_sigs, k.sig_bits.data(), nullptr), v->aux_sigs);
+    note(split_collect(v->aux_sigs[k.index & 1], k.sig_bits.data(), nullptr), v->aux_sigs[k.index & 1]);
     t_wait += now() - t0;
+    mark("signatures collected, chunk at", k.lo);
   };
   auto proofs_collect = [&](TxChunk& k) {
     if (!k.run) return;
@@ -1165,6 +1169,7 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     if (rc != ZKGPU_OK && first_rc == ZKGPU_OK) first_rc = rc;
     if (k.blk) { zkgpu_txblock_destroy(k.blk); k.blk = nullptr; }
     t_wait += now() - t0;
+    mark("proofs collected, chunk at", k.lo);
   };
   // signature stage of a chunk whose aggregated keys have arrived
   auto sigs_start = [&](TxChunk& k) {
@@ -1195,16 +1200,17 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
         memcpy(k.spt.data() + 32 * k.soff[q], t.sig_points.data() + 32, t.sig_points.size() - 32);
       }
     });
-    if (note(verify_ps_enqueue(v->aux_sigs, v->ps, ns, k.ssc.data(), k.spt.data(), k.soff.data(), k.sst.data(), k.sidx.data(), k.sst_off.data()),
-             v->aux_sigs) == ZKGPU_OK)
+    zkgpu_ctx* sc = v->aux_sigs[k.index & 1];
+    if (note(verify_ps_enqueue(sc, v->ps, ns, k.ssc.data(), k.spt.data(), k.soff.data(), k.sst.data(), k.sidx.data(), k.sst_off.data()), sc) == ZKGPU_OK)
       k.sigs_pending = true;
     t_sigs += now() - t0;
+    mark("signatures queued, chunk at", k.lo);
   };
 
   for (size_t ci = 0; ci < n_chunks && first_rc == ZKGPU_OK; ++ci) {
     ck[ci].reset(new TxChunk());
     TxChunk& k = *ck[ci];
-    k.lo = cuts[ci]; k.n = cuts[ci + 1] - cuts[ci];
+    k.lo = cuts[ci]; k.n = cuts[ci + 1] - cuts[ci]; k.index = ci;
     // ---- VM
     double t0 = now();
     k.st.resize(k.n);
@@ -1222,6 +1228,7 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
       if (k.st[i].status == TX_OK) k.live.push_back(i);
     }
     t_vm += now() - t0;
+    mark("VM done, chunk", ci);
     const size_t nl = k.live.size();
     k.pbits.assign((nl + 7) / 8 + 1, 0);
     k.kok.assign((nl + 7) / 8 + 1, 0);
@@ -1244,9 +1251,10 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
         k.keys_pending = true;
     }
     t_keys += now() - t0;
+    mark("keys queued, chunk", ci);
     // ---- signatures of the previous chunk (its keys have just arrived); the one before that is collected first
     if (ci > 0 && !ck[ci - 1]->live.empty()) {
-      if (ci > 1) sigs_collect(*ck[ci - 2]);
+      if (ci > 2) sigs_collect(*ck[ci - 3]);            // (the chunk that used this stage's context last)
       sigs_start(*ck[ci - 1]);
     }
     if (nl) {
@@ -1268,13 +1276,14 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
         if (k.run->rc != ZKGPU_OK) note(k.run->rc, nullptr);
       }
       t_stage += now() - t0;
+      mark("proofs queued, chunk", ci);
     }
   }
   // drain: the last chunk's keys and signatures, then every verdict
   if (n_chunks > 0 && ck[n_chunks - 1]) {
     TxChunk& last = *ck[n_chunks - 1];
     keys_collect(last);
-    if (n_chunks > 1 && ck[n_chunks - 2]) sigs_collect(*ck[n_chunks - 2]);
+    if (n_chunks > 2 && ck[n_chunks - 3]) sigs_collect(*ck[n_chunks - 3]);
     if (!last.live.empty() && first_rc == ZKGPU_OK) sigs_start(last);
   }
   for (size_t ci = 0; ci < n_chunks; ++ci) {

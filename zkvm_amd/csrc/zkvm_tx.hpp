@@ -274,7 +274,8 @@ inline bool parse_contract(const uint8_t* p, size_t n, const uint8_t*& predicate
 // txid_slot / a_slots: where the transaction ID and the MuSig coefficients will be found.
 struct TxSlots { uint16_t txid = 0; std::vector<uint16_t> a; std::vector<const uint8_t*> keys; const uint8_t* sig = nullptr; };
 inline void tx_structure(const uint8_t* tx, size_t len, TxStatement& st, TxPlan& P, TxSlots& out) {
-  st = TxStatement();
+  st.status = TX_INVALID; st.why = ""; st.n_in = st.n_out = 0; st.proof = nullptr; st.proof_len = 0;      // (field by field: the
+  st.commitments.resize(0); st.sig_scalars.resize(0); st.sig_points.resize(0);                             //  inline buffers stay as they are)
   P.clear();
   out.a.clear(); out.keys.clear();
   auto fail = [&st](TxStatus s, const char* why) { st.status = s; st.why = why; };
