@@ -476,7 +476,13 @@ k_challenges(PrepShape sh, const uint32_t* __restrict__ raw /*[B][n_ch][16]*/, c
 // one carry pass, sums and differences are limb-wise (bounds in the comments where they matter).
 // LDS (10-word slots): chs[n_ch] | sym[n_mono] | strides[PREP_STRIDES] (these three converted from k_transcript's
 // 8-word Montgomery slots) | wv[n_targets] | region A: zpow[n_cons] tv[tv_cap + 32], and once the flattening is
-// done yip[pn] sv[pn] red[8] in its place.
+// done yip[pn] sv[pn] red[8] shr[8] in its place.
+//
+// Values that every lane of the workgroup needs (x U, a P1 rho Y, b P1, c', ...) are computed ONCE, each by one lane, beside
+// work that leaves lanes idle anyway, and handed over through shr[]: written as plain expressions they are products of
+// wavefront-uniform values, which the compiler moves to the scalar unit -- four scalar instructions per multiply-add in
+// one dependent chain, repeated by every wavefront (measured, round 3: 5 000 scalar instructions per wavefront beside
+// 7 000 vector ones, SQ_INSTS_SALU 2.0e8 per launch).  lane_zero() keeps single-lane sections on the vector unit.
 //
 // Power tables are built by doubling (entry q + 2^L = entry q * stride_L, one product per entry)
 // instead of one square-and-multiply per entry, and y^-i is kept in PLAIN form: a Montgomery
@@ -491,14 +497,27 @@ constexpr uint32_t HEAVY_TERMS = 16;      // lazy sums are reduced every so many
 
 // bytes: 40-byte slots, except the two tables of the second life (yip, sv: products < 2^255 packed into 32 bytes)
 __host__ __device__ inline size_t prepare_lds_bytes(const PrepShape& sh) {
-  const size_t first = ((size_t)sh.n_cons + sh.tv_cap + 32) * 40, second = (size_t)2 * sh.pn * 32 + 8 * 40;
+  const size_t first = ((size_t)sh.n_cons + sh.tv_cap + 32) * 40, second = (size_t)2 * sh.pn * 32 + 16 * 40;
   return ((size_t)sh.n_ch_ext + sh.n_targets) * 40 + 16 + (first > second ? first : second);
 }
 
+// a zero in a vector register that the compiler cannot see through: added to a shared address it makes the loaded value
+// lane-specific in the compiler's eyes, so that arithmetic on it stays on the vector unit
+__device__ __forceinline__ uint32_t lane_zero() {
+  uint32_t z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+}
 __device__ __forceinline__ void ld_scl(scl& s, const uint32_t* p) {
   const uint2* q = reinterpret_cast<const uint2*>(p);
 #pragma unroll
   for (int i = 0; i < 5; ++i) { const uint2 w = q[i]; s.v[2 * i] = w.x; s.v[2 * i + 1] = w.y; }
+}
+// p is the same address in every lane: the value lives in scalar registers afterwards
+__device__ __forceinline__ void ld_scl_shared(scl& s, const uint32_t* p) {
+  ld_scl(s, p);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) s.v[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.v[i]);
 }
 __device__ __forceinline__ void st_scl(uint32_t* p, const scl& s) {
   uint2* q = reinterpret_cast<uint2*>(p);
@@ -531,7 +550,7 @@ __device__ __forceinline__ scl wave_sum_scl(scl part) {
   return part;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* __restrict__ mono_pow,
           const uint32_t* __restrict__ tgt_off, const uint32_t* __restrict__ term_info,
           const uint2* __restrict__ prod_qm, const uint32_t* __restrict__ prod_coef,
@@ -550,6 +569,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   uint32_t* yip = zpow;                          // region A, second life: two packed tables (8 words per entry)
   uint32_t* sv = yip + sh.pn * 8;
   uint32_t* red = sv + sh.pn * 8;
+  uint32_t* shr = red + 8 * SW;                  // 0: x U  1: a P1  2: b P1  3: c' (plain)  4: a P1 rho Y (plain)  5: c' (Montgomery)  6: rho Y (plain)  7: plain 1
   const uint32_t tx = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
 
   // the transaction's slots (canonical Montgomery words) -> limb form
@@ -579,7 +599,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
       const bool second = t == nt - 1;
       scl a, b;
       // first lane: x*x | x^2*x | x^4*x        second lane: - | x^2*x^2 | x^4*x^2
-      if (L == 0) { ld_scl(a, chs + 3 * SW); b = a; if (!second) st_scl(xp + 0 * SW, scl_mul(a, b)); }
+      if (L == 0) { ld_scl(a, chs + 3 * SW + lane_zero()); b = a; if (!second) st_scl(xp + 0 * SW, scl_mul(a, b)); }
       else if (L == 1) {
         ld_scl(a, xp + 0 * SW);
         if (second) b = a; else ld_scl(b, chs + 3 * SW);
@@ -592,7 +612,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     }
     if (L == 2 && t == nt - 3) {                                       // r x^2
       scl a, b;
-      ld_scl(a, chs + 7 * SW); ld_scl(b, xp + 0 * SW);
+      ld_scl(a, chs + 7 * SW + lane_zero()); ld_scl(b, xp + 0 * SW);
       st_scl(xp + 5 * SW, scl_mul(a, b));
     }
     __syncthreads();
@@ -664,9 +684,16 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   // Both tables grow by doubling (entry + 2^L = entry * stride_L).
   if (t == 0) {
     scl rho;
-    ld_scl(rho, chs + 13 * SW);
+    ld_scl(rho, chs + 13 * SW + lane_zero());
     st_scl8(yip, scl_mul(rho, scl_plain_one()));
     st_scl8(sv, scl_one());
+  } else if (t >= nt - 3) {                       // x U | a P1 | b P1 on three lanes of the last wavefront
+    const uint32_t w = t - (nt - 3);
+    scl a, b;
+    ld_scl(a, chs + (w == 0 ? 3 : w == 1 ? 11 : 12) * SW);
+    ld_scl(b, chs + (w == 0 ? 6 : 5) * SW);
+    st_scl(shr + w * SW, scl_mul(a, b));
+    if (w == 0) st_scl(shr + 7 * SW, scl_plain_one());
   }
   __syncthreads();
 #pragma unroll 1
@@ -703,25 +730,34 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     }
     part = wave_sum_scl(scl_weak(part));          // <= 32 products, limbs < 2^31
     if ((t & 63) == 0) st_scl(red + SW * (1 + (t >> 6)), part);
+    if (t >= nt - 2) {                            // c' = U rho Y | a P1 rho Y, both plain (rho Y = yip[pn-1] is plain)
+      const bool second = t == nt - 1;
+      scl a, b;
+      ld_scl8(a, yip + 8 * (sh.pn - 1));
+      ld_scl(b, second ? shr + 1 * SW : chs + 6 * SW);
+      st_scl(shr + (second ? 4 : 3) * SW, scl_mul(b, a));
+      if (!second) st_scl(shr + 6 * SW, a);       // rho Y, unpacked
+    }
     __syncthreads();
-    if (t == 0) {
+    if (t == 0) {                                 // the sum, converted plain -> Montgomery
+      const uint32_t z = lane_zero();
       scl tot = scl_zero();
-      for (uint32_t wI = 0; wI < (nt >> 6); ++wI) { scl v; ld_scl(v, red + SW * (1 + wI)); tot = scl_add(tot, v); }
-      st_scl(red, scl_weak(tot));
+      for (uint32_t wI = 0; wI < (nt >> 6); ++wI) { scl v; ld_scl(v, red + SW * (1 + wI) + z); tot = scl_add(tot, v); }
+      st_scl(red, scl_mul(scl_weak(tot), scl_r2()));
+    } else if (t == nt - 1) {                     // c', Montgomery
+      scl c;
+      ld_scl(c, shr + 3 * SW + lane_zero());
+      st_scl(shr + 5 * SW, scl_mul(c, scl_r2()));
     }
     __syncthreads();
   }
-  scl x, u, r, U, rhoY_plain, cp_plain, cp;
-  ld_scl(u, chs + 2 * SW); ld_scl(x, chs + 3 * SW); ld_scl(U, chs + 6 * SW); ld_scl(r, chs + 7 * SW);
-  ld_scl8(rhoY_plain, yip + 8 * (sh.pn - 1));    // rho y^(pn-1), plain
-  cp_plain = scl_mul(U, rhoY_plain);             // c', plain
   uint32_t* ds = dyn_scalars + (uint64_t)tx * sh.n_dyn * 8;
   uint32_t* dr = dyn_recoded + (uint64_t)tx * sh.n_dyn * 8;
   uint32_t* ss = static_scalars + (uint64_t)tx * sh.n_static * 8;
   // ---- proof-point scalars, B and B_blinding: the last wavefront, BEFORE its share of the generator scalars, so that
   // this short serial tail runs beside the other wavefronts' generator loop instead of after it.  Every lane does the
-  // same three rounds v = a * b with operands of its own (a lane that needs fewer rounds passes its value through);
-  // the scalar of B is spread over four lanes: with c' delta = U dsum,
+  // same three rounds v = a * b with operands of its own, read from LDS where they are needed (a lane that needs fewer
+  // rounds passes its value through); the scalar of B is spread over four lanes: with c' delta = U dsum,
   //     c' (w (t_x - a b) + r (x^2 (wc + delta) - t_x))  =  c' w (t_x - [a b])  +  r (x^2 ([c' wc] + [U dsum]) - [c' t_x])
   // lane jB: a b, then w (t_x - .), then c' (.);  jB+1: c' wc, then x^2 (. + U dsum), then r (. - c' t_x);
   // jB+2: U dsum;  jB+3: c' t_x;  the partial results travel by wavefront shuffles.  The factor c' of everything else
@@ -729,34 +765,40 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   const uint32_t tail0 = nt - 64;
   if (t >= tail0) {
     const uint32_t lane = t - tail0, n_dyn = sh.n_dyn;
-    scl dsum;
-    ld_scl(dsum, red);
-    dsum = scl_mul(dsum, scl_r2());               // plain sum -> Montgomery
-    cp = scl_mul(cp_plain, scl_r2());             // c', Montgomery
+    const uint32_t* const p_u = chs + 2 * SW;
+    const uint32_t* const p_x = chs + 3 * SW;
+    const uint32_t* const p_U = chs + 6 * SW;
+    const uint32_t* const p_r = chs + 7 * SW;
+    const uint32_t* const p_cp = shr + 5 * SW;     // c', Montgomery
     // positions: 0 B (a b ..), 1 B's second half (c' wc ..), 2 U dsum, 3 c' t_x, 4 B_blinding, 5 + j the proof point j
 #pragma unroll 1
     for (uint32_t pos0 = 0; pos0 < n_dyn + 5; pos0 += 64) {
       const uint32_t pos = pos0 + lane;
       const uint32_t j = pos - 5;                 // proof-point index when pos >= 5
-      scl a = scl_one(), b = scl_one(), v = scl_one(), conv_by = cp_plain;
-      bool m1 = false;                            // does round 1 multiply?
-      if (pos == 0) { ld_scl(a, chs + 11 * SW); ld_scl(b, chs + 12 * SW); m1 = true; }                        // a b
-      else if (pos == 1) { a = cp; ld_scl(b, wc); m1 = true; }                                               // c' wc
-      else if (pos == 2) { a = U; b = dsum; m1 = true; }                                                     // U dsum
-      else if (pos == 3) { a = cp; ld_scl(b, chs + 8 * SW); m1 = true; }                                     // c' t_x
-      else if (pos == 4) { a = r; ld_scl(b, chs + 9 * SW); m1 = true; }                                      // r t_x_blinding
-      else if (j < 3) { if (j == 0) v = x; else ld_scl(v, xp + (j - 1) * SW); }                              // x, x^2, x^3
-      else if (j < 6) { if (j == 3) a = x; else ld_scl(a, xp + (j - 4) * SW); b = u; m1 = true; }            // u x^(1..3)
-      else if (j < 6 + sh.m) { ld_scl(a, wV + SW * (j - 6)); ld_scl(b, xp + 5 * SW); m1 = true; }            // wV_j r x^2
+      const uint32_t* pa = p_x;
+      const uint32_t* pb = p_x;
+      const uint32_t* pconv = shr + 3 * SW;       // c', plain
+      bool m1 = true;                             // does round 1 multiply?  (otherwise v = a)
+      if (pos == 0) { pa = chs + 11 * SW; pb = chs + 12 * SW; }                                              // a b
+      else if (pos == 1) { pa = p_cp; pb = wc; }                                                             // c' wc
+      else if (pos == 2) { pa = p_U; pb = red; }                                                             // U dsum
+      else if (pos == 3) { pa = p_cp; pb = chs + 8 * SW; }                                                   // c' t_x
+      else if (pos == 4) { pa = p_r; pb = chs + 9 * SW; }                                                    // r t_x_blinding
+      else if (j < 3) { if (j) pa = xp + (j - 1) * SW; m1 = false; }                                         // x, x^2, x^3
+      else if (j < 6) { if (j > 3) pa = xp + (j - 4) * SW; pb = p_u; }                                       // u x^(1..3)
+      else if (j < 6 + sh.m) { pa = wV + SW * (j - 6); pb = xp + 5 * SW; }                                   // wV_j r x^2
       else if (j < 11 + sh.m) {                                                                              // r x, r x^3 .. r x^6
         const uint32_t q = j - 6 - sh.m;
-        if (q == 0) a = x; else ld_scl(a, xp + q * SW);
-        b = r; m1 = true;
+        if (q) pa = xp + q * SW;
+        pb = p_r;
       } else if (j < n_dyn) {
         const uint32_t q = j - 11 - sh.m;         // u_j^2 for L_j; for R_j  c' u_j^-2 = rho Y prod_{l != j} u_l^2
-        if (q < sh.k) { ld_scl(a, chs + (CH_FIXED + sh.n_chal2 + q) * SW); b = a; m1 = true; }
-        else { ld_scl(v, chs + (CH_FIXED + sh.n_chal2 + sh.k + (q - sh.k)) * SW); conv_by = rhoY_plain; }
-      }
+        if (q < sh.k) { pa = pb = chs + (CH_FIXED + sh.n_chal2 + q) * SW; }
+        else { pa = chs + (CH_FIXED + sh.n_chal2 + sh.k + (q - sh.k)) * SW; pconv = shr + 6 * SW; m1 = false; }
+      } else m1 = false;
+      scl a, b, v;
+      ld_scl(a, pa); ld_scl(b, pb);
+      v = a;
       {
         const scl pr = scl_mul(a, b);
         if (m1) v = pr;
@@ -771,13 +813,15 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
         if (m2) v = pr2;
         other = shfl_down_scl(v, 2);
         bool m3 = false;
-        if (pos == 0) { a = cp; b = v; m3 = true; }                                                                          // c' w (t_x - a b)
-        else if (pos == 1) { a = r; b = scl_sub(v, other); m3 = true; }                                                      // r (x^2 (..) - c' t_x)
+        if (pos == 0) { ld_scl(a, p_cp); b = v; m3 = true; }                                                                 // c' w (t_x - a b)
+        else if (pos == 1) { ld_scl(a, p_r); b = scl_sub(v, other); m3 = true; }                                             // r (x^2 (..) - c' t_x)
         const scl pr3 = scl_mul(a, b);
         if (m3) v = pr3;
         other = shfl_down_scl(v, 1);
-        if (pos == 0) { v = scl_add(v, other); conv_by = scl_plain_one(); }
+        if (pos == 0) { v = scl_add(v, other); pconv = shr + 7 * SW; }
       }
+      scl conv_by;
+      ld_scl(conv_by, pconv);
       uint32_t o[8];
       scl_canon_words(o, scl_mul(v, conv_by));    // Montgomery -> canonical words, times the plain factor
       if (pos >= 5 && j < n_dyn) {
@@ -800,11 +844,9 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   //   c' g_i = (x U) wR_i yp[pn-1-i] - (a P1 rho Y) sU_i
   //   c' h_i = yp[pn-1-i] ((x U) wL_i + U wO_i - (b P1) sU_(pn-1-i)) - c'        (times u for i >= n1)
   {
-    scl P1, a_, b_;
-    ld_scl(P1, chs + 5 * SW); ld_scl(a_, chs + 11 * SW); ld_scl(b_, chs + 12 * SW);
-    const scl xU = scl_mul(x, U);
-    const scl aY_plain = scl_mul(scl_mul(a_, P1), rhoY_plain);
-    const scl bP = scl_mul(b_, P1);
+    scl xU, aY_plain, bP, U, u, cp_plain;         // shared by the workgroup: kept in scalar registers
+    ld_scl_shared(xU, shr + 0 * SW); ld_scl_shared(aY_plain, shr + 4 * SW); ld_scl_shared(bP, shr + 2 * SW);
+    ld_scl_shared(U, chs + 6 * SW); ld_scl_shared(u, chs + 2 * SW); ld_scl_shared(cp_plain, shr + 3 * SW);
     for (uint32_t i = t; i < sh.pn; i += nt) {
       scl yp, si, sr;
       ld_scl8(yp, yip + 8 * (sh.pn - 1 - i)); ld_scl8(si, sv + 8 * i); ld_scl8(sr, sv + 8 * (sh.pn - 1 - i));
