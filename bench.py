@@ -361,10 +361,23 @@ def tx_verify_microbench(ctx, gens, host_threads: int):
             dt = time.perf_counter() - t0
             best8 = dt if best8 is None else min(best8, dt)
         assert bm8 == bitmap_of([1] * len(big)) and not any(st8), "a committed transaction was not accepted"
+        # ... and thirty-two times over (what a block of a busy chain looks like: more chunks per call, the tail of the
+        # call -- the last chunk's keys -> signatures chain -- a smaller share of it)
+        huge = txs * 32
+        blob32, lens32 = b"".join(huge), np.asarray([len(t) for t in huge], dtype=np.uint64)
+        bv.verify_txs_packed(blob32, lens32, host_threads)
+        best32 = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            bm32, st32 = bv.verify_txs_packed(blob32, lens32, host_threads)
+            dt = time.perf_counter() - t0
+            best32 = dt if best32 is None else min(best32, dt)
+        assert bm32 == bitmap_of([1] * len(huge)) and not any(st32), "a committed transaction was not accepted"
     finally:
         bv.close()
     return {"tx_per_s": round(len(txs) / best, 1), "batch": len(txs), "ms": round(best * 1e3, 3), "host_threads": host_threads,
             "tx_per_s_8192_per_call": round(len(big) / best8, 1), "ms_8192_per_call": round(best8 * 1e3, 3),
+            "tx_per_s_32768_per_call": round(len(huge) / best32, 1), "ms_32768_per_call": round(best32 * 1e3, 3),
             "tx_bytes": len(txs[0]),
             "note": "zkgpu_tx_verify_batch on 1024 serialized 2-in/2-out payment transactions (host memory in): VM and "
                     "transaction IDs on host threads; key aggregation, signature equations and cloak proofs on the device; "

@@ -151,7 +151,7 @@ int zkgpu_verify_batch_ps_dev(zkgpu_ctx *ctx, const zkgpu_pointset *ps, size_t b
  * commitments (quantity, flavor) -- commitments holds 64 * (n_in[i] + n_out[i]) bytes per
  * statement, back to back; proofs / proof_offsets are a CSR of R1CSProof encodings.
  * The transcript replay, constraint flattening and verification scalars run on
- * `host_threads` host threads (0 = all), the multiscalar multiplications in ONE device
+ * `host_threads` host threads (0 = as many as the process may keep busy: affinity mask and control-group CPU quota), the multiscalar multiplications in ONE device
  * call.  `ps` must hold [B, B_blinding, G_0..G_{cap-1}, H_0..H_{cap-1}] (zkgpu_pedersen_gens
  * + zkgpu_bulletproof_gens with gens_capacity = cap).  r_bytes: 64 uniform bytes per
  * statement for the verifier's random weight r, or NULL to draw them from the OS.

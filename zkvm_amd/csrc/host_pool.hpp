@@ -3,7 +3,7 @@
 // The host stages on the product path (the transaction VM and ids of zkgpu_tx_verify_batch, the witness rows of the
 // device prover) are short -- a millisecond or two per call -- and creating and joining a dozen threads per call
 // costs a good part of that.  The workers are created on first use, sleep on a condition variable between calls and
-// are joined when the library is unloaded.  One call uses the pool at a time; a second caller arriving meanwhile (two
+// are joined when the library is unloaded.  One call uses a pool at a time; a second caller arriving meanwhile (two
 // prover calls in flight on two contexts) waits for its turn; a process forked after the pool was made runs with
 // threads of its own.
 #pragma once
@@ -13,13 +13,56 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <cstdio>
+#include <cstdlib>
+#include <sched.h>
 #include <unistd.h>
 
 namespace zk {
 
+// How many threads a host stage may keep busy when the caller does not say: the CPUs this process may run on (its affinity
+// mask) and, inside a container, the CPU-time quota of its control group (cpu.max of cgroup v2, cpu.cfs_quota_us of v1) --
+// not the machine's core count: threads beyond the quota do not run side by side, they use up the group's time slice
+// and the whole process, the thread that feeds the GPU included, is paused until the next period.
+inline int usable_cpus() {
+  static const int n = [] {
+    int cpus = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0 && a < cpus) cpus = a; }
+    auto quota = [](const char* path, bool v2) -> double {
+      FILE* f = fopen(path, "r");
+      if (!f) return 0;
+      char buf[64] = {0};
+      const size_t got = fread(buf, 1, sizeof buf - 1, f);
+      fclose(f);
+      if (!got) return 0;
+      if (v2) {
+        long long q = 0, per = 0;
+        if (sscanf(buf, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) return (double)q / (double)per;
+        return 0;                                                       // "max ..."
+      }
+      return atof(buf);
+    };
+    double q = quota("/sys/fs/cgroup/cpu.max", true);
+    if (q <= 0) {
+      const double us = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", false), per = quota("/sys/fs/cgroup/cpu/cpu.cfs_period_us", false);
+      if (us > 0 && per > 0) q = us / per;
+    }
+    if (q > 0 && q < cpus) cpus = (int)(q + 0.5);
+    return cpus > 0 ? cpus : 1;
+  }();
+  return n;
+}
+
 class HostPool {
  public:
   static HostPool& get() {
+    static HostPool p;
+    return p;
+  }
+  // a second, independent set of workers: for a caller whose short parallel loops run WHILE another thread of the same call
+  // keeps the first pool busy (zkgpu_tx_verify_batch: the thread that talks to the device, beside the one that runs the VM)
+  static HostPool& second() {
     static HostPool p;
     return p;
   }

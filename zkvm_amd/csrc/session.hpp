@@ -42,6 +42,7 @@ struct zkgpu_verifier {
   size_t gens_capacity = 0;
   std::vector<zkgpu_ctx*> lanes;                      // root + forks: one batch in flight on each
   std::map<std::pair<uint32_t, uint32_t>, zkgpu_cloak_plan*> plans;   // nullptr: the shape cannot be verified here
+  std::mutex plans_mu;                                  // (asked for by the staging thread of zkgpu_tx_verify_batch as well)
   std::map<std::pair<uint32_t, uint32_t>, uint64_t> costs;
   size_t chunk = 2048;                                // transactions per batch in flight
   // ---- blocks in flight (zkgpu_verifier_block_start / _finish): which batch of which block a lane is running
@@ -62,11 +63,13 @@ struct zkgpu_verifier {
   // zkgpu_tx_verify_batch: two contexts of their own for the key and the signature stages (each a pair of streams beside
   // the lanes'), and a ring of staging areas (pinned host + device, grow-only) for the cloak statements of the chunks in
   // flight -- nothing on that path allocates or frees device memory once the sizes have been seen (hipFree synchronises)
-  zkgpu_ctx* aux_keys = nullptr;
+  zkgpu_ctx* aux_keys[2] = {nullptr, nullptr};           // aggregated keys of the chunks, in turn
   zkgpu_ctx* aux_sigs[2] = {nullptr, nullptr};           // signature equations of the chunks, in turn: a stage may still run when the next is queued
   struct TxArena { void* h_pin = nullptr; size_t h_cap = 0; char* dev = nullptr; size_t d_cap = 0; hipEvent_t copied = nullptr; };
   hipStream_t copy_stream = nullptr;                    // staging copies run here; the lanes wait for TxArena::copied
   std::vector<TxArena> tx_arenas;
+  std::vector<zk::zkvm::TxStatement> tx_statements;     // what the VM leaves per transaction, kept between calls (fresh memory costs
+                                                        // a page fault per 4 KB: 0.4 ms per 3000 transactions, measured)
   size_t tx_chunk = 0;                                  // transactions per chunk of zkgpu_tx_verify_batch (0: automatic)
   uint8_t basepoint[32] = {0};                          // encoding of B, computed once (the signature equations name it)
   bool have_basepoint = false;
@@ -89,6 +92,8 @@ struct zkgpu_txblock {
   std::vector<Group> groups;
   char* dev = nullptr;                                // one allocation: commitments | proofs | r, group after group
   size_t dev_bytes = 0;
+  std::unique_ptr<uint8_t[]> host_owned;              // staged image between txblock_stage_host and txblock_upload (no arena)
+  const uint8_t* host_image = nullptr;
 };
 
 struct zkgpu_comm {
@@ -204,6 +209,7 @@ uint64_t cloak_msm_terms(uint32_t n_in, uint32_t n_out) {
 // caller fails its block or ticket with that error -- a transient fault must not turn into "the proof is invalid".
 zkgpu_cloak_plan* verifier_plan(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, int* rc) {
   *rc = ZKGPU_OK;
+  std::lock_guard<std::mutex> plk(v->plans_mu);
   const auto key = std::make_pair(n_in, n_out);
   auto it = v->plans.find(key);
   if (it != v->plans.end()) return it->second;
@@ -284,7 +290,7 @@ void zkgpu_verifier_destroy(zkgpu_verifier* v) {
   (void)drain(v, scratch);
   for (auto& kv : v->requests) delete kv.second;
   for (size_t i = 1; i < v->lanes.size(); ++i) zkgpu_destroy(v->lanes[i]);
-  if (v->aux_keys) zkgpu_destroy(v->aux_keys);
+  for (zkgpu_ctx* a : v->aux_keys) if (a) zkgpu_destroy(a);
   for (zkgpu_ctx* a : v->aux_sigs) if (a) zkgpu_destroy(a);
   {
     DeviceGuard g(v->root->device);
@@ -337,11 +343,13 @@ namespace {
 // One transaction of a block being staged: where its commitments (64 (n_in + n_out) bytes) and its proof lie in host memory
 struct TxSource { uint32_t n_in, n_out; const uint8_t* com; const uint8_t* proof; uint64_t proof_len; };
 
-// groups the transactions by (inputs, outputs, proof length), lays the groups out, gathers them on host threads and
-// copies the block to HBM
-// (v->mu held: the plans and last_error are the verifier's)
-int txblock_build_locked(zkgpu_verifier* v, size_t batch, const TxSource* src, const uint8_t* r_bytes, int host_threads, zkgpu_txblock** out,
-                         zkgpu_verifier::TxArena* arena = nullptr) {
+// groups the transactions by (inputs, outputs, proof length), lays the groups out and gathers them on host threads into
+// the staging image (the arena's pinned memory, or a buffer of the block's own): host work only -- apart from the first
+// sight of a shape (its plan) and of a size (the arena), which touch the device.  `err` receives what went wrong.
+// May run on another thread than the one that owns the verifier (zkgpu_tx_verify_batch): touches the plans (plans_mu),
+// the given arena and nothing else of *v.
+int txblock_stage_host(zkgpu_verifier* v, size_t batch, const TxSource* src, const uint8_t* r_bytes, int host_threads, zkgpu_txblock** out,
+                       zkgpu_verifier::TxArena* arena, std::string* err) {
   zkgpu_ctx* c = v->root;
   std::unique_ptr<zkgpu_txblock> b(new zkgpu_txblock());
   b->v = v; b->batch = batch;
@@ -359,7 +367,7 @@ int txblock_build_locked(zkgpu_verifier* v, size_t batch, const TxSource* src, c
         g.n_in = src[i].n_in; g.n_out = src[i].n_out; g.proof_len = (size_t)src[i].proof_len;
         int prc = ZKGPU_OK;
         g.plan = verifier_plan(v, g.n_in, g.n_out, &prc);
-        if (prc != ZKGPU_OK) return prc;
+        if (prc != ZKGPU_OK) { *err = zkgpu_last_error(v->root); return prc; }
         if (g.plan && !proof_len_fits(g.plan->shape, g.proof_len)) g.plan = nullptr;   // wrong length for the statement
         g.com_off = g.proof_off = g.r_off = 0;
         it = where.emplace(key, b->groups.size()).first;
@@ -382,39 +390,36 @@ int txblock_build_locked(zkgpu_verifier* v, size_t batch, const TxSource* src, c
     g.proof_off = total; total = align(total + n * g.proof_len);
     g.r_off = total; total = align(total + n * 64);
   }
-  const bool timing = getenv("ZKGPU_PROVER_TIMING") != nullptr;
-  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double tb0 = now();
-  double tb1 = 0, tb2 = 0;
+  b->dev_bytes = total;
   if (total) {
-    DeviceGuard dg(c->device);
-    std::unique_ptr<uint8_t[]> owned;
     uint8_t* host = nullptr;
     if (arena) {                                        // the verifier's staging area: pinned host memory, device memory kept
+      DeviceGuard dg(c->device);
       if (arena->h_cap < total) {
         if (arena->h_pin) (void)hipHostFree(arena->h_pin);
         arena->h_pin = nullptr; arena->h_cap = 0;
         const size_t want = total + total / 4 + 4096;
-        if (hipHostMalloc(&arena->h_pin, want, hipHostMallocDefault) != hipSuccess) { v->last_error = "hipHostMalloc (transaction staging)"; return ZKGPU_ENOMEM; }
+        if (hipHostMalloc(&arena->h_pin, want, hipHostMallocDefault) != hipSuccess) { *err = "hipHostMalloc (transaction staging)"; return ZKGPU_ENOMEM; }
         arena->h_cap = want;
       }
       if (arena->d_cap < total) {
         if (arena->dev) (void)hipFree(arena->dev);
         arena->dev = nullptr; arena->d_cap = 0;
         const size_t want = total + total / 4 + 4096;
-        if (hipMalloc((void**)&arena->dev, want) != hipSuccess) { v->last_error = "hipMalloc (transaction staging)"; return ZKGPU_ENOMEM; }
+        if (hipMalloc((void**)&arena->dev, want) != hipSuccess) { *err = "hipMalloc (transaction staging)"; return ZKGPU_ENOMEM; }
         arena->d_cap = want;
       }
       host = (uint8_t*)arena->h_pin;
     } else {
-      owned.reset(new uint8_t[total]);
-      host = owned.get();
+      b->host_owned.reset(new uint8_t[total]);
+      host = b->host_owned.get();
     }
+    b->host_image = host;
     // verifier randomness when the caller gives none: 32 bytes from the OS (getrandom(2)) per block, expanded per
     // transaction with SHAKE256(seed || position) on the gathering threads -- getrandom itself delivers ~0.35 GB/s on one
     // thread, which for 64 bytes per transaction would be a quarter of this stage's time
     uint8_t seed[40] = {0};
-    if (!r_bytes && !os_random(seed, 32)) { v->last_error = "getrandom failed"; return ZKGPU_EINVAL; }
+    if (!r_bytes && !os_random(seed, 32)) { *err = "getrandom failed"; return ZKGPU_EINVAL; }
     host_parallel(batch, host_threads, [&](size_t i) {
       const zkgpu_txblock::Group& g = b->groups[group_of[i]];
       if (!g.plan) return;
@@ -432,31 +437,47 @@ int txblock_build_locked(zkgpu_verifier* v, size_t batch, const TxSource* src, c
         sp.squeeze(&host[g.r_off + j * 64], 64);
       }
     });
-    tb1 = now();
-    tb2 = now();
-    if (arena) {
-      b->dev = arena->dev;
-      b->owns_dev = false;
-    } else {
-      hipError_t e = hipMalloc((void**)&b->dev, total);
-      if (e != hipSuccess) { v->last_error = std::string("hipMalloc: ") + hipGetErrorString(e); b->dev = nullptr; return ZKGPU_ENOMEM; }
-    }
-    b->dev_bytes = total;
-    hipError_t e;
-    if (arena) {                                        // queued on the copy stream: the host goes on, the lanes wait for the event
-      e = v->copy_stream ? hipSuccess : hipStreamCreateWithFlags(&v->copy_stream, hipStreamNonBlocking);
-      if (e == hipSuccess && !arena->copied) e = hipEventCreateWithFlags(&arena->copied, hipEventDisableTiming);
-      if (e == hipSuccess) e = hipMemcpyAsync(b->dev, host, total, hipMemcpyHostToDevice, v->copy_stream);
-      if (e == hipSuccess) e = hipEventRecord(arena->copied, v->copy_stream);
-      if (e == hipSuccess) b->ready = arena->copied;
-    } else {
-      e = hipMemcpy(b->dev, host, total, hipMemcpyHostToDevice);
-    }
-    if (e != hipSuccess) { v->last_error = hipGetErrorString(e); if (b->owns_dev) (void)hipFree(b->dev); b->dev = nullptr; return ZKGPU_EHIP; }
   }
-  if (timing && total) fprintf(stderr, "txblock: gather %.2f ms, randomness %.2f ms, allocation + copy %.2f ms (%zu bytes)\n",
-                               (tb1 - tb0) * 1e3, (tb2 - tb1) * 1e3, (now() - tb2) * 1e3, total);
   *out = b.release();
+  return ZKGPU_OK;
+}
+
+// the staged image -> HBM: queued on the copy stream when the block lives in an arena (the host goes on, the lanes wait
+// for the event), a plain copy into memory of the block's own otherwise.  (v->mu held.)
+int txblock_upload(zkgpu_verifier* v, zkgpu_txblock* b, zkgpu_verifier::TxArena* arena) {
+  const size_t total = b->dev_bytes;
+  if (!total) return ZKGPU_OK;
+  DeviceGuard dg(v->root->device);
+  hipError_t e;
+  if (arena) {
+    b->dev = arena->dev;
+    b->owns_dev = false;
+    e = v->copy_stream ? hipSuccess : hipStreamCreateWithFlags(&v->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess && !arena->copied) e = hipEventCreateWithFlags(&arena->copied, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->dev, b->host_image, total, hipMemcpyHostToDevice, v->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(arena->copied, v->copy_stream);
+    if (e == hipSuccess) b->ready = arena->copied;
+  } else {
+    e = hipMalloc((void**)&b->dev, total);
+    if (e != hipSuccess) { v->last_error = std::string("hipMalloc: ") + hipGetErrorString(e); b->dev = nullptr; return ZKGPU_ENOMEM; }
+    e = hipMemcpy(b->dev, b->host_image, total, hipMemcpyHostToDevice);
+    b->host_owned.reset();
+    b->host_image = nullptr;
+  }
+  if (e != hipSuccess) { v->last_error = hipGetErrorString(e); if (b->owns_dev && b->dev) (void)hipFree(b->dev); b->dev = nullptr; return ZKGPU_EHIP; }
+  return ZKGPU_OK;
+}
+
+// (v->mu held: last_error is the verifier's)
+int txblock_build_locked(zkgpu_verifier* v, size_t batch, const TxSource* src, const uint8_t* r_bytes, int host_threads, zkgpu_txblock** out,
+                         zkgpu_verifier::TxArena* arena = nullptr) {
+  std::string err;
+  zkgpu_txblock* b = nullptr;
+  int rc = txblock_stage_host(v, batch, src, r_bytes, host_threads, &b, arena, &err);
+  if (rc != ZKGPU_OK) { v->last_error = err; return rc; }
+  rc = txblock_upload(v, b, arena);
+  if (rc != ZKGPU_OK) { zkgpu_txblock_destroy(b); return rc; }
+  *out = b;
   return ZKGPU_OK;
 }
 
@@ -992,7 +1013,8 @@ namespace {
 // One chunk of a zkgpu_tx_verify_batch call on its way through the stages (see below)
 struct TxChunk {
   size_t lo = 0, n = 0, index = 0;                      // transactions [lo, lo + n) of the call; which chunk
-  std::vector<zk::zkvm::TxStatement> st;
+  zk::zkvm::TxStatement* st = nullptr;                  // [n], in the verifier's store (or st_own beyond its cap)
+  std::vector<zk::zkvm::TxStatement> st_own;
   std::vector<size_t> live;                             // positions in the chunk the VM accepted
   // aggregated keys: rows of (a_i, X_i)
   std::vector<uint64_t> koff;
@@ -1007,6 +1029,10 @@ struct TxChunk {
   zkgpu_verifier::BlockRun* run = nullptr;
   std::vector<uint8_t> pbits;
   bool keys_pending = false, sigs_pending = false;
+  bool sig_asked = false;                               // its signature rows have been asked of the staging thread
+  bool keys_done_without_sigs = false;                  // no live transaction: nothing to ask
+  int stage_rc = 0;                                     // what staging its statements came to (staging thread)
+  std::string stage_err;
 };
 
 // host arrays -> the context's input buffers -> kernels and result copy queued (batch_device_enqueue, value mode);
@@ -1036,6 +1062,14 @@ int split_collect(zkgpu_ctx* c, uint8_t* bitmap, uint8_t* values) {
   DeviceGuard g(c->device);
   c->pending = false;
   return batch_collect(c, bitmap, values);
+}
+
+// has everything queued by the last *_enqueue on this context run?  (never blocks)
+bool split_done(zkgpu_ctx* c) {
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  if (c->split.kind == 0 || c->split.batch == 0) return true;
+  DeviceGuard g(c->device);
+  return hipStreamQuery(c->split.stream) != hipErrorNotReady;
 }
 
 // the same for rows of dynamic terms + terms on the resident set's tables (the signature equations)
@@ -1078,12 +1112,15 @@ int zkgpu_verifier_set_tx_chunk(zkgpu_verifier* v, size_t transactions) {
 }
 
 // The call is cut into chunks of ~3000 transactions that travel through four stages, the host's share of one chunk
-// beside the device's share of the others (ONE calling thread: every device stage is queued asynchronously):
-//   VM        host pool: wire format, the VM, contract ids, transaction ID, the (a_i, X_i) rows and s, R of the signature
-//   proofs    host pool gathers the cloak statements of the chunk's live transactions into a pinned staging area, one
-//             copy to HBM, and the chunk's batches are queued on the verifier's lanes (block_start)          [lanes]
-//   keys      X = sum a_i X_i per transaction, as encodings: queued on a context of its own                  [aux_keys]
-//   sigs      host pool: c = H(txid, X, R); the equations s B - R - sum (c a_i) X_i == identity queued       [aux_sigs]
+// beside the device's share of the others.  TWO host threads drive it:
+//   the staging thread (made for the call; its loops run on the worker pool): per chunk the wire format, the VM, contract
+//     ids, transaction ID, the (a_i, X_i) rows and s, R of the signature; the cloak statements of the chunk's live
+//     transactions gathered into a pinned staging area; and, whenever the calling thread hands it a chunk whose
+//     aggregated keys have arrived, the signature transcripts c = H(txid, X, R) and the rows of the equations;
+//   the calling thread: everything that talks to the device, queued asynchronously -- per chunk
+//     keys      X = sum a_i X_i per transaction, as encodings                                               [aux_keys]
+//     proofs    one copy of the staged statements to HBM, the chunk's batches on the verifier's lanes        [lanes]
+//     sigs      the equations s B - R - sum (c a_i) X_i == identity                                          [aux_sigs]
 // and the verdicts are collected at the end: accept = the VM accepted & the keys decode & the signature holds & the
 // proof verifies.  (The proofs of a chunk do not wait for its signatures: a transaction whose signature fails has its
 // proof verified for nothing -- that is the rare case -- and in exchange nothing on the device waits for a host round trip.)
@@ -1104,82 +1141,72 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   const bool timing = getenv("ZKGPU_PROVER_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t00 = now();
-  double t_vm = 0, t_stage = 0, t_keys = 0, t_sigs = 0, t_wait = 0;
+  double t_vm = 0, t_stage = 0, t_keys = 0, t_sigs = 0, t_wait = 0, t_wait_host = 0;
   zkgpu_ctx* c = v->root;
   // the lanes' batches in flight are collected first: the call owns the verifier (tickets and runs keep their verdicts)
   while (!v->block_busy.empty()) block_collect(v, v->block_busy.front());
   while (!v->busy.empty()) ticket_collect(v, v->busy.front());
   {
     DeviceGuard g(c->device);
-    if (!v->aux_keys && ctx_create(c->device, nullptr, &v->aux_keys, true) != ZKGPU_OK) { v->aux_keys = nullptr; v->last_error = "no context for the key stage"; return ZKGPU_EHIP; }
+    for (zkgpu_ctx*& a : v->aux_keys)
+      if (!a && ctx_create(c->device, nullptr, &a, true) != ZKGPU_OK) { a = nullptr; v->last_error = "no context for the key stage"; return ZKGPU_EHIP; }
     for (zkgpu_ctx*& a : v->aux_sigs)
       if (!a && ctx_create(c->device, nullptr, &a, true) != ZKGPU_OK) { a = nullptr; v->last_error = "no context for the signature stage"; return ZKGPU_EHIP; }
   }
   if (!v->have_basepoint) {
     uint8_t Bb[32];
-    const int rc = zkgpu_pedersen_gens(v->aux_keys, v->basepoint, Bb);
-    if (rc != ZKGPU_OK) { v->last_error = zkgpu_last_error(v->aux_keys); return rc; }
+    const int rc = zkgpu_pedersen_gens(v->aux_keys[0], v->basepoint, Bb);
+    if (rc != ZKGPU_OK) { v->last_error = zkgpu_last_error(v->aux_keys[0]); return rc; }
     v->have_basepoint = true;
   }
   const uint8_t* B = v->basepoint;
-  constexpr size_t RING = 4;
+  constexpr size_t RING = 6;
   if (v->tx_arenas.size() < RING) v->tx_arenas.resize(RING);
-  // chunk boundaries: ~3000 transactions each (zkgpu_verifier_set_tx_chunk overrides), the LAST one half as long -- what
-  // follows the last chunk's VM stage (its keys -> signatures chain, its proofs) is the tail of the call
+  // chunk boundaries: ~3000 transactions each (zkgpu_verifier_set_tx_chunk overrides), the LAST one short -- what follows
+  // the last chunk's VM stage (its keys -> signatures chain, its proofs) is the tail of the call -- and at most 1536, the
+  // longest batch whose transcript is replayed cooperatively (0.2 instead of 0.5 ms at the head of its chain of kernels)
   std::vector<size_t> cuts{0};
   {
     const size_t chunk = v->tx_chunk ? v->tx_chunk : 3072;
-    const size_t full = std::max<size_t>(1, (batch + chunk / 2) / chunk);           // chunks if all were equal
-    if (full == 1 || v->tx_chunk) {
+    if (v->tx_chunk || batch <= chunk + chunk / 2) {
       for (size_t at = 0; at < batch; at += chunk) cuts.push_back(std::min(batch, at + chunk));
     } else {
-      const double unit = (double)batch / ((double)full - 0.5);                     // full - 1 whole chunks and a half one
-      for (size_t q = 1; q < full; ++q) cuts.push_back(std::min(batch, (size_t)(unit * (double)q)));
+      const size_t last = 1536, rest = batch - last;
+      const size_t whole = std::max<size_t>(1, (rest + chunk / 2) / chunk);
+      for (size_t q = 1; q <= whole; ++q) cuts.push_back(rest * q / whole);
       cuts.push_back(batch);
     }
   }
   const size_t n_chunks = cuts.size() - 1;
   std::vector<std::unique_ptr<TxChunk>> ck(n_chunks);
-  auto par = [&](size_t n, const std::function<void(size_t)>& f) { host_parallel(n, host_threads, f); };
+  constexpr size_t STATEMENTS_KEPT = (size_t)1 << 17;    // ~90 MB
+  if (v->tx_statements.size() < std::min(batch, STATEMENTS_KEPT)) v->tx_statements.resize(std::min(batch, STATEMENTS_KEPT));
+  for (size_t ci = 0; ci < n_chunks; ++ci) {
+    ck[ci].reset(new TxChunk());
+    TxChunk& k = *ck[ci];
+    k.lo = cuts[ci]; k.n = cuts[ci + 1] - cuts[ci]; k.index = ci;
+    if (k.lo + k.n <= v->tx_statements.size()) k.st = v->tx_statements.data() + k.lo;
+  }
   int first_rc = ZKGPU_OK;
   auto note = [&](int rc, zkgpu_ctx* where) { if (rc != ZKGPU_OK && first_rc == ZKGPU_OK) { first_rc = rc; if (where) v->last_error = zkgpu_last_error(where); } return rc; };
-
   auto mark = [&](const char* what, size_t ci) { if (timing) fprintf(stderr, "    %7.3f ms  %s %zu\n", (now() - t00) * 1e3, what, ci); };
-  auto keys_collect = [&](TxChunk& k) {
-    if (!k.keys_pending) return;
-    k.keys_pending = false;
-    const double t0 = now();
-    note(split_collect(v->aux_keys, k.kok.data(), k.agg.data()), v->aux_keys);
-    t_wait += now() - t0;
-    mark("keys collected, chunk at", k.lo);
-  };
-  auto sigs_collect = [&](TxChunk& k) {
-    if (!k.sigs_pending) return;
-    k.sigs_pending = false;
-    const double t0 = now();
-    note(split_collect(v->aux_sigs[k.index & 1], k.sig_bits.data(), nullptr), v->aux_sigs[k.index & 1]);
-    t_wait += now() - t0;
-    mark("signatures collected, chunk at", k.lo);
-  };
-  auto proofs_collect = [&](TxChunk& k) {
-    if (!k.run) return;
-    const double t0 = now();
-    const int rc = block_finish(v, k.run, k.pbits.data());
-    k.run = nullptr;
-    if (rc != ZKGPU_OK && first_rc == ZKGPU_OK) first_rc = rc;
-    if (k.blk) { zkgpu_txblock_destroy(k.blk); k.blk = nullptr; }
-    t_wait += now() - t0;
-    mark("proofs collected, chunk at", k.lo);
-  };
-  // signature stage of a chunk whose aggregated keys have arrived
-  auto sigs_start = [&](TxChunk& k) {
-    const double t0 = now();
+
+  // ---- the staging thread.  What the two threads tell each other (under hm): rows_ready[ci] -- chunk ci has been through the
+  // VM and the rows of its aggregated keys are made; staged[ci] -- its statements are in arena ci % RING as well; arena_free[ci] -- the calling thread has collected chunk ci's proofs (its
+  // arena may be reused); sig_jobs -- chunks whose aggregated keys have arrived; sig_ready[ci]; quit.
+  std::mutex hm;
+  std::condition_variable hcv;
+  std::vector<char> rows_ready(n_chunks, 0), staged(n_chunks, 0), arena_free(n_chunks, 0), sig_ready(n_chunks, 0);
+  std::deque<size_t> sig_jobs;
+  bool quit = false;
+  double t_sig_host = 0, t_stage_host = 0;
+  auto sig_rows = [&](TxChunk& k) {                     // transcripts + rows of the equations of a chunk (staging thread)
     const size_t nl = k.live.size();
     k.keyed.clear();
     for (size_t j = 0; j < nl; ++j) if ((k.kok[j / 8] >> (j % 8)) & 1) k.keyed.push_back(j);
     const size_t ns = k.keyed.size();
     k.sig_bits.assign((ns + 7) / 8 + 1, 0);
-    if (ns == 0 || first_rc != ZKGPU_OK) return;
+    if (ns == 0) return;
     k.soff.assign(ns + 1, 0);
     for (size_t q = 0; q < ns; ++q) k.soff[q + 1] = k.soff[q] + k.st[k.live[k.keyed[q]]].sig_scalars.size() / 32 - 1;
     k.ssc.resize(32 * k.soff.back()); k.spt.resize(32 * k.soff.back());
@@ -1187,7 +1214,7 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     k.sidx.assign(ns, 0);
     k.sst_off.resize(ns + 1);
     for (size_t q = 0; q <= ns; ++q) k.sst_off[q] = q;
-    par((ns + 7) / 8, [&](size_t g) {              // eight challenges c = H(txid, X, R) at a time
+    host_parallel((ns + 7) / 8, host_threads, [&](size_t g) {              // eight challenges c = H(txid, X, R) at a time
       TxStatement* tp[8];
       const uint8_t* ap[8];
       const size_t first = 8 * g, cnt = std::min<size_t>(8, ns - first);
@@ -1200,101 +1227,250 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
         memcpy(k.spt.data() + 32 * k.soff[q], t.sig_points.data() + 32, t.sig_points.size() - 32);
       }
     });
-    zkgpu_ctx* sc = v->aux_sigs[k.index & 1];
-    if (note(verify_ps_enqueue(sc, v->ps, ns, k.ssc.data(), k.spt.data(), k.soff.data(), k.sst.data(), k.sidx.data(), k.sst_off.data()), sc) == ZKGPU_OK)
-      k.sigs_pending = true;
-    t_sigs += now() - t0;
-    mark("signatures queued, chunk at", k.lo);
+  };
+  auto run_sig_jobs = [&](std::unique_lock<std::mutex>& lk) {          // hm held on entry and on return
+    while (!sig_jobs.empty() && !quit) {
+      const size_t ci = sig_jobs.front();
+      sig_jobs.pop_front();
+      lk.unlock();
+      const double t0 = now();
+      sig_rows(*ck[ci]);
+      const double dt = now() - t0;
+      lk.lock();
+      t_sig_host += dt;
+      sig_ready[ci] = 1;
+      hcv.notify_all();
+    }
+  };
+  std::thread stager([&] {
+    for (size_t ci = 0; ci < n_chunks; ++ci) {
+      TxChunk& k = *ck[ci];
+      {
+        std::unique_lock<std::mutex> lk(hm);
+        run_sig_jobs(lk);
+        if (ci >= RING) hcv.wait(lk, [&] { return quit || arena_free[ci - RING]; });
+        if (quit) return;
+      }
+      const double t0 = now();
+      if (!k.st) { k.st_own.resize(k.n); k.st = k.st_own.data(); }
+      const double ta = now();
+      // eight transactions per task: the hashing of transactions of one shape runs in lockstep on AVX-512 (zkvm_tx.hpp,
+      // tx_prepare_many; merlin_x8.hpp)
+      host_parallel((k.n + 7) / 8, host_threads, [&](size_t g) {
+        const uint8_t* p[8];
+        size_t l[8];
+        const size_t first = 8 * g, cnt = std::min<size_t>(8, k.n - first);
+        for (size_t q = 0; q < cnt; ++q) { p[q] = txs + tx_offsets[k.lo + first + q]; l[q] = (size_t)(tx_offsets[k.lo + first + q + 1] - tx_offsets[k.lo + first + q]); }
+        tx_prepare_many(p, l, &k.st[first], cnt);
+      });
+      const double tb = now();
+      for (size_t i = 0; i < k.n; ++i) {
+        if (status && k.st[i].status == TX_UNSUPPORTED) status[k.lo + i] = TX_UNSUPPORTED;     // (TX_OK is written at the very end only)
+        if (k.st[i].status == TX_OK) k.live.push_back(i);
+      }
+      const size_t nl = k.live.size();
+      k.pbits.assign((nl + 7) / 8 + 1, 0);
+      k.kok.assign((nl + 7) / 8 + 1, 0);
+      k.agg.assign(32 * std::max<size_t>(nl, 1), 0);
+      const double t1 = now();
+      if (nl) {
+        // rows (a_i, X_i) of the aggregated keys
+        k.koff.assign(nl + 1, 0);
+        for (size_t j = 0; j < nl; ++j) k.koff[j + 1] = k.koff[j] + k.st[k.live[j]].sig_scalars.size() / 32 - 2;
+        k.ksc.resize(32 * k.koff.back()); k.kpt.resize(32 * k.koff.back());
+        for (size_t j = 0; j < nl; ++j) {               // (a few hundred KB: not worth waking the pool for)
+          const TxStatement& t = k.st[k.live[j]];
+          memcpy(k.ksc.data() + 32 * k.koff[j], t.sig_scalars.data() + 64, t.sig_scalars.size() - 64);
+          memcpy(k.kpt.data() + 32 * k.koff[j], t.sig_points.data() + 64, t.sig_points.size() - 64);
+        }
+        {                                                // the keys can go out while the statements are gathered
+          std::lock_guard<std::mutex> lk(hm);
+          rows_ready[ci] = 1;
+          hcv.notify_all();
+        }
+        // the cloak statements, gathered into the chunk's staging area
+        std::vector<TxSource> src(nl);
+        for (size_t q = 0; q < nl; ++q) {
+          const TxStatement& t = k.st[k.live[q]];
+          src[q] = TxSource{t.n_in, t.n_out, t.commitments.data(), t.proof, t.proof_len};
+        }
+        const double tc = now();
+        k.stage_rc = txblock_stage_host(v, nl, src.data(), nullptr, host_threads, &k.blk, &v->tx_arenas[ci % RING], &k.stage_err);
+        if (timing) fprintf(stderr, "    staging thread, chunk %zu: statements %.3f ms, VM %.3f, scan %.3f, key rows + sources %.3f, gather %.3f\n", ci,
+                            (ta - t0) * 1e3, (tb - ta) * 1e3, (t1 - tb) * 1e3, (tc - t1) * 1e3, (now() - tc) * 1e3);
+      }
+      const double t2 = now();
+      std::unique_lock<std::mutex> lk(hm);
+      t_vm += t1 - t0;
+      t_stage_host += t2 - t1;
+      staged[ci] = 1;
+      hcv.notify_all();
+    }
+    std::unique_lock<std::mutex> lk(hm);
+    for (;;) {
+      run_sig_jobs(lk);
+      if (quit) return;
+      hcv.wait(lk, [&] { return quit || !sig_jobs.empty(); });
+    }
+  });
+  struct StagerJoin {                                    // whatever way the call ends, the thread is told and waited for
+    std::mutex& m; std::condition_variable& cv; bool& quit; std::thread& th;
+    ~StagerJoin() { { std::lock_guard<std::mutex> lk(m); quit = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+  } stager_join{hm, hcv, quit, stager};
+  g_thread_pool = &HostPool::second();                   // this thread's own short loops do not wait for the staging thread's
+  struct PoolReset { ~PoolReset() { g_thread_pool = nullptr; } } pool_reset;
+
+  auto keys_collect = [&](TxChunk& k) {
+    if (!k.keys_pending) return;
+    k.keys_pending = false;
+    const double t0 = now();
+    note(split_collect(v->aux_keys[k.index & 1], k.kok.data(), k.agg.data()), v->aux_keys[k.index & 1]);
+    t_wait += now() - t0;
+    mark("keys collected, chunk at", k.lo);
+    if (first_rc == ZKGPU_OK && !k.live.empty()) {      // its signature transcripts: over to the staging thread
+      std::lock_guard<std::mutex> lk(hm);
+      sig_jobs.push_back(k.index);
+      k.sig_asked = true;
+      hcv.notify_all();
+    }
+  };
+  auto sigs_collect = [&](TxChunk& k) {
+    if (!k.sigs_pending) return;
+    k.sigs_pending = false;
+    const double t0 = now();
+    note(split_collect(v->aux_sigs[k.index & 1], k.sig_bits.data(), nullptr), v->aux_sigs[k.index & 1]);
+    t_wait += now() - t0;
+    mark("signatures collected, chunk at", k.lo);
+  };
+  auto proofs_collect = [&](TxChunk& k) {
+    if (k.run) {
+      const double t0 = now();
+      const int rc = block_finish(v, k.run, k.pbits.data());
+      k.run = nullptr;
+      if (rc != ZKGPU_OK && first_rc == ZKGPU_OK) first_rc = rc;
+      t_wait += now() - t0;
+      mark("proofs collected, chunk at", k.lo);
+    }
+    if (k.blk) { zkgpu_txblock_destroy(k.blk); k.blk = nullptr; }
+    std::lock_guard<std::mutex> lk(hm);
+    arena_free[k.index] = 1;
+    hcv.notify_all();
+  };
+  // the equations of the chunks whose rows are ready, in chunk order (wait: for the next one if it has been asked for)
+  size_t next_sig = 0;
+  auto sigs_enqueue = [&](bool wait) {
+    while (next_sig < n_chunks && first_rc == ZKGPU_OK) {
+      TxChunk& k = *ck[next_sig];
+      if (!k.sig_asked) {
+        if (k.keys_done_without_sigs) { ++next_sig; continue; }
+        return;
+      }
+      {
+        std::unique_lock<std::mutex> lk(hm);
+        if (!sig_ready[next_sig]) {
+          if (!wait) return;
+          const double t0 = now();
+          hcv.wait(lk, [&] { return sig_ready[next_sig] != 0; });
+          t_wait_host += now() - t0;
+        }
+      }
+      const double t0 = now();
+      if (next_sig >= 2) sigs_collect(*ck[next_sig - 2]);           // (the chunk that used this stage's context last)
+      const size_t ns = k.keyed.size();
+      if (ns) {
+        zkgpu_ctx* sc = v->aux_sigs[k.index & 1];
+        if (note(verify_ps_enqueue(sc, v->ps, ns, k.ssc.data(), k.spt.data(), k.soff.data(), k.sst.data(), k.sidx.data(), k.sst_off.data()), sc) == ZKGPU_OK)
+          k.sigs_pending = true;
+      }
+      t_sigs += now() - t0;
+      mark("signatures queued, chunk at", k.lo);
+      ++next_sig;
+    }
   };
 
-  for (size_t ci = 0; ci < n_chunks && first_rc == ZKGPU_OK; ++ci) {
-    ck[ci].reset(new TxChunk());
+  // The calling thread never waits for one thing while another could be queued: it looks, in turn, for a chunk the staging
+  // thread has finished (its keys, then its proofs go out -- the keys BEFORE the proofs: what follows them is a chain, keys ->
+  // host transcripts -> equations, and queued behind the proofs' chip-filling kernels its short kernels would wait for
+  // CUs), for aggregated keys that have arrived (over to the staging thread for the signature transcripts), and for
+  // signature rows that are ready (the equations go out); with nothing to do it sleeps until the staging thread has news,
+  // 50 us at most (what the device has finished is found out by asking).
+  size_t next_rows = 0, next_stage = 0, next_keys = 0;
+  auto enqueue_keys = [&](size_t ci) {
     TxChunk& k = *ck[ci];
-    k.lo = cuts[ci]; k.n = cuts[ci + 1] - cuts[ci]; k.index = ci;
-    // ---- VM
-    double t0 = now();
-    k.st.resize(k.n);
-    // eight transactions per task: the hashing of transactions of one shape runs in lockstep on AVX-512 (zkvm_tx.hpp,
-    // tx_prepare_many; merlin_x8.hpp)
-    par((k.n + 7) / 8, [&](size_t g) {
-      const uint8_t* p[8];
-      size_t l[8];
-      const size_t first = 8 * g, cnt = std::min<size_t>(8, k.n - first);
-      for (size_t q = 0; q < cnt; ++q) { p[q] = txs + tx_offsets[k.lo + first + q]; l[q] = (size_t)(tx_offsets[k.lo + first + q + 1] - tx_offsets[k.lo + first + q]); }
-      tx_prepare_many(p, l, &k.st[first], cnt);
-    });
-    for (size_t i = 0; i < k.n; ++i) {
-      if (status && k.st[i].status == TX_UNSUPPORTED) status[k.lo + i] = TX_UNSUPPORTED;     // (TX_OK is written at the very end only)
-      if (k.st[i].status == TX_OK) k.live.push_back(i);
-    }
-    t_vm += now() - t0;
-    mark("VM done, chunk", ci);
+    mark("rows ready, chunk", ci);
     const size_t nl = k.live.size();
-    k.pbits.assign((nl + 7) / 8 + 1, 0);
-    k.kok.assign((nl + 7) / 8 + 1, 0);
-    k.agg.assign(32 * std::max<size_t>(nl, 1), 0);
-    // ---- keys: the previous chunk's have had this chunk's VM stage to finish in and are collected first (one operation at
-    //      a time on aux_keys); then this chunk's rows go out, BEFORE its proofs: what follows them is a chain (keys -> host
-    //      transcripts -> equations), and queued behind the proofs' chip-filling kernels its short kernels would wait for CUs
-    t0 = now();
-    if (ci > 0) keys_collect(*ck[ci - 1]);
+    const double t0 = now();
     if (nl) {
-      k.koff.assign(nl + 1, 0);
-      for (size_t j = 0; j < nl; ++j) k.koff[j + 1] = k.koff[j] + k.st[k.live[j]].sig_scalars.size() / 32 - 2;
-      k.ksc.resize(32 * k.koff.back()); k.kpt.resize(32 * k.koff.back());
-      par(nl, [&](size_t j) {
-        const TxStatement& t = k.st[k.live[j]];
-        memcpy(k.ksc.data() + 32 * k.koff[j], t.sig_scalars.data() + 64, t.sig_scalars.size() - 64);
-        memcpy(k.kpt.data() + 32 * k.koff[j], t.sig_points.data() + 64, t.sig_points.size() - 64);
-      });
-      if (first_rc == ZKGPU_OK && note(msm_values_enqueue(v->aux_keys, k.ksc.data(), k.kpt.data(), k.koff.data(), nl), v->aux_keys) == ZKGPU_OK)
-        k.keys_pending = true;
-    }
+      zkgpu_ctx* kc = v->aux_keys[ci & 1];
+      if (note(msm_values_enqueue(kc, k.ksc.data(), k.kpt.data(), k.koff.data(), nl), kc) == ZKGPU_OK) k.keys_pending = true;
+    } else k.keys_done_without_sigs = true;
     t_keys += now() - t0;
     mark("keys queued, chunk", ci);
-    // ---- signatures of the previous chunk (its keys have just arrived); the one before that is collected first
-    if (ci > 0 && !ck[ci - 1]->live.empty()) {
-      if (ci > 2) sigs_collect(*ck[ci - 3]);            // (the chunk that used this stage's context last)
-      sigs_start(*ck[ci - 1]);
+  };
+  auto enqueue_proofs = [&](size_t ci) {
+    TxChunk& k = *ck[ci];
+    if (k.stage_rc != ZKGPU_OK) { if (first_rc == ZKGPU_OK) { first_rc = k.stage_rc; v->last_error = k.stage_err; } return; }
+    if (k.live.empty()) return;
+    // one copy to HBM, and the chunk's batches queued on the lanes
+    const double t0 = now();
+    if (note(txblock_upload(v, k.blk, &v->tx_arenas[ci % RING]), nullptr) == ZKGPU_OK) {
+      // a chunk of one shape goes to the device as few, large batches (measured: the last chunk in batches short enough for
+      // the one-wavefront-per-transaction transcript, or cut in two, does not shorten the tail of the call)
+      const size_t saved_chunk = v->chunk;
+      v->chunk = std::max<size_t>(saved_chunk, 4096);
+      k.run = block_start(v, k.blk);
+      v->chunk = saved_chunk;
+      if (k.run->rc != ZKGPU_OK) note(k.run->rc, nullptr);
     }
-    if (nl) {
-      // ---- proofs: staged and queued on the lanes (the ring slot's previous user is finished first)
-      t0 = now();
-      if (ci >= RING) proofs_collect(*ck[ci - RING]);
-      std::vector<TxSource> src(nl);
-      for (size_t q = 0; q < nl; ++q) {
-        const TxStatement& t = k.st[k.live[q]];
-        src[q] = TxSource{t.n_in, t.n_out, t.commitments.data(), t.proof, t.proof_len};
-      }
-      if (first_rc == ZKGPU_OK && note(txblock_build_locked(v, nl, src.data(), nullptr, host_threads, &k.blk, &v->tx_arenas[ci % RING]), nullptr) == ZKGPU_OK) {
-        // a chunk of one shape goes to the device as few, large batches (measured: the last chunk in batches short enough for
-        // the one-wavefront-per-transaction transcript, or cut in two, does not shorten the tail of the call)
-        const size_t saved_chunk = v->chunk;
-        v->chunk = std::max<size_t>(saved_chunk, 4096);
-        k.run = block_start(v, k.blk);
-        v->chunk = saved_chunk;
-        if (k.run->rc != ZKGPU_OK) note(k.run->rc, nullptr);
-      }
-      t_stage += now() - t0;
-      mark("proofs queued, chunk", ci);
+    t_stage += now() - t0;
+    mark("proofs queued, chunk", ci);
+  };
+  while (first_rc == ZKGPU_OK && (next_stage < n_chunks || next_keys < n_chunks || next_sig < n_chunks)) {
+    bool progress = false;
+    // a staged chunk (its key context is free once the chunk two back has been collected; its staging area once the
+    // chunk RING back has)
+    if (next_stage >= RING && next_stage < n_chunks && !arena_free[next_stage - RING]) proofs_collect(*ck[next_stage - RING]);
+    if (next_rows < n_chunks && (next_rows < 2 || next_keys + 2 > next_rows)) {
+      bool ready;
+      { std::lock_guard<std::mutex> lk(hm); ready = rows_ready[next_rows] != 0 || staged[next_rows] != 0; }
+      if (ready) { enqueue_keys(next_rows++); progress = true; }
+    }
+    if (first_rc == ZKGPU_OK && next_stage < next_rows) {
+      bool ready;
+      { std::lock_guard<std::mutex> lk(hm); ready = staged[next_stage] != 0; }
+      if (ready) { enqueue_proofs(next_stage++); progress = true; }
+    }
+    // aggregated keys, in chunk order
+    if (first_rc == ZKGPU_OK && next_keys < next_rows) {
+      TxChunk& k = *ck[next_keys];
+      if (!k.keys_pending || split_done(v->aux_keys[k.index & 1])) { keys_collect(k); ++next_keys; progress = true; }
+    }
+    const size_t before = next_sig;
+    sigs_enqueue(false);
+    progress |= next_sig != before;
+    if (!progress) {
+      std::unique_lock<std::mutex> lk(hm);
+      const double t0 = now();
+      hcv.wait_for(lk, std::chrono::microseconds(50));
+      t_wait_host += now() - t0;
     }
   }
-  // drain: the last chunk's keys and signatures, then every verdict
-  if (n_chunks > 0 && ck[n_chunks - 1]) {
-    TxChunk& last = *ck[n_chunks - 1];
-    keys_collect(last);
-    if (n_chunks > 2 && ck[n_chunks - 3]) sigs_collect(*ck[n_chunks - 3]);
-    if (!last.live.empty() && first_rc == ZKGPU_OK) sigs_start(last);
+  {
+    std::lock_guard<std::mutex> lk(hm);
+    quit = true;
   }
+  hcv.notify_all();
+  stager.join();
   for (size_t ci = 0; ci < n_chunks; ++ci) {
-    if (!ck[ci]) continue;
     keys_collect(*ck[ci]);                              // (only after an error: nothing is left pending on the contexts)
     sigs_collect(*ck[ci]);
     proofs_collect(*ck[ci]);
   }
-  if (timing) fprintf(stderr, "tx verify: %zu transactions in %zu chunks: VM + ids %.2f ms, staging + queueing the proofs %.2f ms, key rows %.2f ms, "
-                              "signature transcripts + rows %.2f ms, waiting for the device %.2f ms, %.2f ms in all\n",
-                      batch, n_chunks, t_vm * 1e3, t_stage * 1e3, t_keys * 1e3, t_sigs * 1e3, t_wait * 1e3, (now() - t00) * 1e3);
+  if (timing) fprintf(stderr, "tx verify: %zu transactions in %zu chunks: staging thread: VM + ids %.2f ms, rows + gather %.2f ms, signature transcripts %.2f ms; "
+                              "calling thread: waiting for the staging thread %.2f ms, queueing keys %.2f, proofs %.2f, signatures %.2f ms, "
+                              "waiting for the device %.2f ms; %.2f ms in all\n",
+                      batch, n_chunks, t_vm * 1e3, t_stage_host * 1e3, t_sig_host * 1e3, t_wait_host * 1e3, t_keys * 1e3, t_stage * 1e3, t_sigs * 1e3,
+                      t_wait * 1e3, (now() - t00) * 1e3);
   if (first_rc != ZKGPU_OK) return first_rc;             // both outputs still read "nothing accepted"
   for (size_t ci = 0; ci < n_chunks; ++ci) {
     const TxChunk& k = *ck[ci];

@@ -1931,11 +1931,14 @@ int ipa_on_device(zkgpu_ctx* c, const zkgpu_pointset* ps, std::vector<std::uniqu
 }
 
 // ---- the device prover ------------------------------------------------------------------------------------
-// f(i) for i < n on up to `threads` host threads (0: hardware concurrency)
+// f(i) for i < n on up to `threads` host threads (0: usable_cpus(): affinity mask and control-group quota)
+// (a thread may name the pool its loops run on: g_thread_pool, see HostPool::second)
+thread_local HostPool* g_thread_pool = nullptr;
 void host_parallel(size_t n, int threads, const std::function<void(size_t)>& f) {
-  const int nt = (int)std::max<size_t>(1, std::min<size_t>(n / 16 + 1, (size_t)std::min<int>(threads > 0 ? threads : (int)std::thread::hardware_concurrency(), 256)));
+  const int nt = (int)std::max<size_t>(1, std::min<size_t>(n / 16 + 1, (size_t)std::min<int>(threads > 0 ? threads : usable_cpus(), 256)));
   if (nt <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
-  if (HostPool::get().run(n, std::min(nt, HostPool::MAX_WORKERS + 1), f)) return;
+  HostPool& pool = g_thread_pool ? *g_thread_pool : HostPool::get();
+  if (pool.run(n, std::min(nt, HostPool::MAX_WORKERS + 1), f)) return;
   std::vector<std::thread> th;
   for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { for (size_t i = (size_t)t; i < n; i += (size_t)nt) f(i); });
   for (auto& t : th) t.join();
@@ -2135,7 +2138,7 @@ int prove_lockstep(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, int hos
                    uint8_t* proofs, size_t proof_stride, size_t* proof_len) {
   std::vector<std::unique_ptr<R1csProver>> pr(batch);
   std::vector<std::vector<MsmRow>> rows(batch);
-  const int nt = std::max(1, std::min<int>(host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency(), 256));
+  const int nt = std::max(1, std::min<int>(host_threads > 0 ? host_threads : usable_cpus(), 256));
   auto parallel = [&](const std::function<void(size_t)>& f) {
     if (nt == 1 || batch == 1) { for (size_t i = 0; i < batch; ++i) f(i); return; }
     std::vector<std::thread> th;
@@ -2345,7 +2348,7 @@ int prepare_cloak_batch(size_t gens_capacity, size_t batch, const uint32_t* n_in
     if (!os_random(rnd.data(), rnd.size())) return ZKGPU_EINVAL;
     r_bytes = rnd.data();
   }
-  const int nt = std::max(1, std::min<int>(host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency(), 256));
+  const int nt = std::max(1, std::min<int>(host_threads > 0 ? host_threads : usable_cpus(), 256));
   auto work = [&](int tid) {
     for (size_t i = (size_t)tid; i < batch; i += (size_t)nt) {
       if (proof_offsets[i + 1] < proof_offsets[i]) continue;
@@ -2974,7 +2977,7 @@ int zkgpu_r1cs_verify_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, const zkgpu_
   }
   std::vector<VerifierMsm> prep(batch);
   std::vector<uint8_t> wellformed(batch, 0);
-  const int nt = std::max(1, std::min<int>(host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency(), 256));
+  const int nt = std::max(1, std::min<int>(host_threads > 0 ? host_threads : usable_cpus(), 256));
   auto work = [&](int tid) {
     for (size_t i = (size_t)tid; i < batch; i += (size_t)nt)
       wellformed[i] = prepare_desc(desc, commitments + 32ull * desc.m * i, proofs + proof_len * i, proof_len,
