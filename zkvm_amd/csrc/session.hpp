@@ -255,19 +255,22 @@ int zkgpu_verifier_create(zkgpu_ctx* ctx, const zkgpu_pointset* ps, size_t gens_
   // sets 24 when it is the first), and streams beyond that share queues: two lanes on one queue take turns, and when they
   // also wait for each other's events they crawl (measured in round 2: 3x - 10x slower with 8 and 10 lanes than with 7 and
   // 9).  So every new lane is probed against the lanes kept so far (two spinning wavefronts, ~0.2 ms per pair, idle
-  // device assumed) and dropped if it serialises with one of them: fewer lanes, every one of them real.
+  // device assumed) and not kept if it serialises with one of them; a stream made next lands on the runtime's next queue, so
+  // a rejected lane is tried again, up to as many times as lanes were asked for: fewer lanes in the end, every one real.
   {
     DeviceGuard g(ctx->device);
-    for (int i = 1; i < batches_in_flight; ++i) {
+    int retries = batches_in_flight;
+    while ((int)v->lanes.size() < batches_in_flight) {
       zkgpu_ctx* f = nullptr;
       if (zkgpu_ctx_fork(ctx, &f) != ZKGPU_OK) break;     // fewer lanes than asked for: still correct
       bool alone = true;
       for (zkgpu_ctx* kept : v->lanes)
         if (streams_overlap(kept->stream_l, f->stream_l) == 0) { alone = false; break; }
       if (alone) { v->lanes.push_back(f); continue; }
-      ++v->lanes_dropped;
       zkgpu_destroy(f);
+      if (retries-- <= 0) break;
     }
+    v->lanes_dropped = batches_in_flight - (int)v->lanes.size();
   }
   if (g_hw_queues_late) {
     v->last_error = "the HIP runtime of this process started before GPU_MAX_HW_QUEUES was set: it runs on its default of 4 hardware "
