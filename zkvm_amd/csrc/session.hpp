@@ -1016,26 +1016,26 @@ namespace {
 // One chunk of a zkgpu_tx_verify_batch call on its way through the stages (see below)
 struct TxChunk {
   size_t lo = 0, n = 0, index = 0;                      // transactions [lo, lo + n) of the call; which chunk
+  size_t g0 = 0;                                        // live transactions of the call before this chunk
   zk::zkvm::TxStatement* st = nullptr;                  // [n], in the verifier's store (or st_own beyond its cap)
   std::vector<zk::zkvm::TxStatement> st_own;
   std::vector<size_t> live;                             // positions in the chunk the VM accepted
-  // aggregated keys: rows of (a_i, X_i)
-  std::vector<uint64_t> koff;
-  std::vector<uint8_t> ksc, kpt, agg, kok;
-  // signature equations of the transactions whose keys all decode
-  std::vector<size_t> keyed;                            // positions in `live`
-  std::vector<uint64_t> soff, sst_off;
-  std::vector<uint8_t> ssc, spt, sst, sig_bits;
-  std::vector<uint32_t> sidx;
   // cloak proofs (every live transaction: the signature verdict is ANDed in at the end)
   zkgpu_txblock* blk = nullptr;
   zkgpu_verifier::BlockRun* run = nullptr;
   std::vector<uint8_t> pbits;
-  bool keys_pending = false, sigs_pending = false;
-  bool sig_asked = false;                               // its signature rows have been asked of the staging thread
-  bool keys_done_without_sigs = false;                  // no live transaction: nothing to ask
   int stage_rc = 0;                                     // what staging its statements came to (staging thread)
   std::string stage_err;
+};
+
+// The signature equations of a run of chunks: made when their transaction IDs and the call's aggregated keys are both there
+struct TxSigStage {
+  size_t first = 0, last = 0;                           // chunks [first, last)
+  std::vector<size_t> keyed;                            // global live indices of the transactions whose keys all decode
+  std::vector<uint64_t> soff, sst_off;
+  std::vector<uint8_t> ssc, spt, sst, bits;
+  std::vector<uint32_t> sidx;
+  bool pending = false, queued = false;
 };
 
 // host arrays -> the context's input buffers -> kernels and result copy queued (batch_device_enqueue, value mode);
@@ -1166,7 +1166,7 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   constexpr size_t RING = 6;
   if (v->tx_arenas.size() < RING) v->tx_arenas.resize(RING);
   // chunk boundaries: ~3000 transactions each (zkgpu_verifier_set_tx_chunk overrides), the LAST one short -- what follows
-  // the last chunk's VM stage (its keys -> signatures chain, its proofs) is the tail of the call -- and at most 1536, the
+  // the last chunk's VM stage (its signature equations, its proofs) is the tail of the call -- and at most 1536, the
   // longest batch whose transcript is replayed cooperatively (0.2 instead of 0.5 ms at the head of its chain of kernels)
   std::vector<size_t> cuts{0};
   {
@@ -1179,141 +1179,213 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
       for (size_t q = 1; q <= whole; ++q) cuts.push_back(rest * q / whole);
       cuts.push_back(batch);
     }
+    // (multiples of eight: the groups of eight the VM hashes in lockstep are then the same in both passes, and none
+    // straddles the end of the verifier's statement store)
+    for (size_t q = 1; q + 1 < cuts.size(); ++q) cuts[q] = std::max(cuts[q - 1], cuts[q] & ~(size_t)7);
+    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    if (cuts.size() < 2) cuts = {0, batch};
   }
   const size_t n_chunks = cuts.size() - 1;
   std::vector<std::unique_ptr<TxChunk>> ck(n_chunks);
   constexpr size_t STATEMENTS_KEPT = (size_t)1 << 17;    // ~90 MB
   if (v->tx_statements.size() < std::min(batch, STATEMENTS_KEPT)) v->tx_statements.resize(std::min(batch, STATEMENTS_KEPT));
+  std::vector<TxStatement> st_beyond(batch > v->tx_statements.size() ? batch - v->tx_statements.size() : 0);
+  auto statement = [&](size_t i) -> TxStatement& { return i < v->tx_statements.size() ? v->tx_statements[i] : st_beyond[i - v->tx_statements.size()]; };
   for (size_t ci = 0; ci < n_chunks; ++ci) {
     ck[ci].reset(new TxChunk());
     TxChunk& k = *ck[ci];
     k.lo = cuts[ci]; k.n = cuts[ci + 1] - cuts[ci]; k.index = ci;
-    if (k.lo + k.n <= v->tx_statements.size()) k.st = v->tx_statements.data() + k.lo;
   }
   int first_rc = ZKGPU_OK;
   auto note = [&](int rc, zkgpu_ctx* where) { if (rc != ZKGPU_OK && first_rc == ZKGPU_OK) { first_rc = rc; if (where) v->last_error = zkgpu_last_error(where); } return rc; };
   auto mark = [&](const char* what, size_t ci) { if (timing) fprintf(stderr, "    %7.3f ms  %s %zu\n", (now() - t00) * 1e3, what, ci); };
 
-  // ---- the staging thread.  What the two threads tell each other (under hm): rows_ready[ci] -- chunk ci has been through the
-  // VM and the rows of its aggregated keys are made; staged[ci] -- its statements are in arena ci % RING as well; arena_free[ci] -- the calling thread has collected chunk ci's proofs (its
-  // arena may be reused); sig_jobs -- chunks whose aggregated keys have arrived; sig_ready[ci]; quit.
+  // ---- segments: runs of chunks of ~10 000 transactions in all.  The aggregated keys of a segment are computed in ONE
+  // key stage, queued before anything else of the segment (a first pass of the VM over the segment's transactions that goes
+  // as far as the keys and their MuSig coefficients); the signature equations of its chunks follow in one stage (two for the
+  // last segment: its last chunk on its own), when the keys are back and the chunks' transaction IDs are made.  All
+  // boundaries depend on the size of the call alone: the same call made again has stages of the same sizes, and the stage
+  // contexts' buffers, grown once, are never grown again (hipMalloc waits for the device).
+  struct Segment {
+    size_t c_lo = 0, c_hi = 0;                            // chunks
+    size_t g_lo = 0, g_hi = 0;                            // live transactions of the call (positions in live_all)
+    std::vector<uint64_t> koff;                           // rows (a_i, X_i) per live transaction
+    std::vector<uint8_t> ksc, kpt, kok;
+    bool pending = false;
+  };
+  std::vector<Segment> seg;
+  std::vector<size_t> seg_of(n_chunks, 0);
+  {
+    size_t c = 0;
+    while (c < n_chunks) {
+      Segment sgm;
+      sgm.c_lo = c;
+      size_t count = 0;
+      while (c < n_chunks && (count == 0 || count + ck[c]->n <= 10240 + 1536)) { count += ck[c]->n; ++c; }
+      sgm.c_hi = c;
+      for (size_t q = sgm.c_lo; q < sgm.c_hi; ++q) seg_of[q] = seg.size();
+      seg.push_back(std::move(sgm));
+    }
+  }
+  const size_t n_seg = seg.size();
+  struct SigPlan { size_t first, last, segment; };
+  std::vector<SigPlan> sig_plan;
+  for (size_t sI = 0; sI < n_seg; ++sI) {
+    const Segment& g = seg[sI];
+    if (sI + 1 == n_seg && g.c_hi - g.c_lo > 1) { sig_plan.push_back({g.c_lo, g.c_hi - 1, sI}); sig_plan.push_back({g.c_hi - 1, g.c_hi, sI}); }
+    else sig_plan.push_back({g.c_lo, g.c_hi, sI});
+  }
+  // ---- what the two threads share (under hm).  key_rows[s]: the rows of segment s are made; keys_arrived[s]: the calling
+  // thread has its encodings back; staged[ci]: chunk ci has been through the VM and its statements are in arena ci % RING;
+  // arena_free[ci]: its proofs have been collected (the arena may be reused); sig_stages: the signature stages made so
+  // far (the calling thread queues stage s once n_sig_stages > s); all_sigs_made; quit.
   std::mutex hm;
   std::condition_variable hcv;
-  std::vector<char> rows_ready(n_chunks, 0), staged(n_chunks, 0), arena_free(n_chunks, 0), sig_ready(n_chunks, 0);
-  std::deque<size_t> sig_jobs;
-  bool quit = false;
-  double t_sig_host = 0, t_stage_host = 0;
-  auto sig_rows = [&](TxChunk& k) {                     // transcripts + rows of the equations of a chunk (staging thread)
-    const size_t nl = k.live.size();
-    k.keyed.clear();
-    for (size_t j = 0; j < nl; ++j) if ((k.kok[j / 8] >> (j % 8)) & 1) k.keyed.push_back(j);
-    const size_t ns = k.keyed.size();
-    k.sig_bits.assign((ns + 7) / 8 + 1, 0);
+  std::vector<char> staged(n_chunks, 0), arena_free(n_chunks, 0), key_rows(n_seg, 0), keys_arrived(n_seg, 0);
+  bool all_sigs_made = false, quit = false;
+  std::vector<std::unique_ptr<TxSigStage>> sig_stages;
+  size_t n_sig_stages = 0;
+  double t_keys_host = 0, t_sig_host = 0, t_stage_host = 0;
+  std::vector<size_t> live_all;                          // transactions the VM accepts, in call order (staging thread appends)
+  live_all.reserve(batch);
+  std::vector<uint8_t> agg(32 * std::max<size_t>(batch, 1), 0), key_ok(batch, 0);   // per live transaction: X, "its keys all decode"
+
+  auto sig_rows = [&](TxSigStage& sg) {                 // transcripts + rows of the equations of chunks [first, last) (staging thread)
+    const size_t g_lo = ck[sg.first]->g0, g_hi = ck[sg.last - 1]->g0 + ck[sg.last - 1]->live.size();
+    sg.keyed.clear();
+    for (size_t g = g_lo; g < g_hi; ++g) if (key_ok[g]) sg.keyed.push_back(g);
+    const size_t ns = sg.keyed.size();
+    sg.bits.assign((ns + 7) / 8 + 1, 0);
     if (ns == 0) return;
-    k.soff.assign(ns + 1, 0);
-    for (size_t q = 0; q < ns; ++q) k.soff[q + 1] = k.soff[q] + k.st[k.live[k.keyed[q]]].sig_scalars.size() / 32 - 1;
-    k.ssc.resize(32 * k.soff.back()); k.spt.resize(32 * k.soff.back());
-    k.sst.resize(32 * ns);
-    k.sidx.assign(ns, 0);
-    k.sst_off.resize(ns + 1);
-    for (size_t q = 0; q <= ns; ++q) k.sst_off[q] = q;
+    sg.soff.assign(ns + 1, 0);
+    for (size_t q = 0; q < ns; ++q) sg.soff[q + 1] = sg.soff[q] + statement(live_all[sg.keyed[q]]).sig_scalars.size() / 32 - 1;
+    sg.ssc.resize(32 * sg.soff.back()); sg.spt.resize(32 * sg.soff.back());
+    sg.sst.resize(32 * ns);
+    sg.sidx.assign(ns, 0);
+    sg.sst_off.resize(ns + 1);
+    for (size_t q = 0; q <= ns; ++q) sg.sst_off[q] = q;
     host_parallel((ns + 7) / 8, host_threads, [&](size_t g) {              // eight challenges c = H(txid, X, R) at a time
       TxStatement* tp[8];
       const uint8_t* ap[8];
       const size_t first = 8 * g, cnt = std::min<size_t>(8, ns - first);
-      for (size_t q = 0; q < cnt; ++q) { tp[q] = &k.st[k.live[k.keyed[first + q]]]; ap[q] = &k.agg[32 * k.keyed[first + q]]; }
+      for (size_t q = 0; q < cnt; ++q) { tp[q] = &statement(live_all[sg.keyed[first + q]]); ap[q] = &agg[32 * sg.keyed[first + q]]; }
       tx_finish_signature_many(tp, ap, B, cnt);
       for (size_t q = first; q < first + cnt; ++q) {
         const TxStatement& t = *tp[q - first];
-        memcpy(&k.sst[32 * q], t.sig_scalars.data(), 32);
-        memcpy(k.ssc.data() + 32 * k.soff[q], t.sig_scalars.data() + 32, t.sig_scalars.size() - 32);
-        memcpy(k.spt.data() + 32 * k.soff[q], t.sig_points.data() + 32, t.sig_points.size() - 32);
+        memcpy(&sg.sst[32 * q], t.sig_scalars.data(), 32);
+        memcpy(sg.ssc.data() + 32 * sg.soff[q], t.sig_scalars.data() + 32, t.sig_scalars.size() - 32);
+        memcpy(sg.spt.data() + 32 * sg.soff[q], t.sig_points.data() + 32, t.sig_points.size() - 32);
       }
     });
   };
-  auto run_sig_jobs = [&](std::unique_lock<std::mutex>& lk) {          // hm held on entry and on return
-    while (!sig_jobs.empty() && !quit) {
-      const size_t ci = sig_jobs.front();
-      sig_jobs.pop_front();
+  // the signature stages that are due: their chunks staged, their segment's keys back (staging thread; hm held on entry and
+  // on return)
+  size_t sig_next = 0;
+  auto make_sig_stages = [&](std::unique_lock<std::mutex>& lk, size_t staged_upto) {
+    while (!quit && sig_next < sig_plan.size() && keys_arrived[sig_plan[sig_next].segment] && sig_plan[sig_next].last <= staged_upto) {
+      std::unique_ptr<TxSigStage> sg(new TxSigStage());
+      sg->first = sig_plan[sig_next].first; sg->last = sig_plan[sig_next].last;
+      ++sig_next;
       lk.unlock();
       const double t0 = now();
-      sig_rows(*ck[ci]);
+      sig_rows(*sg);
       const double dt = now() - t0;
       lk.lock();
       t_sig_host += dt;
-      sig_ready[ci] = 1;
+      sig_stages.push_back(std::move(sg));
+      ++n_sig_stages;
+      if (sig_next == sig_plan.size()) all_sigs_made = true;
       hcv.notify_all();
     }
   };
   std::thread stager([&] {
-    for (size_t ci = 0; ci < n_chunks; ++ci) {
-      TxChunk& k = *ck[ci];
+    for (size_t sI = 0; sI < n_seg; ++sI) {
+      Segment& sgm = seg[sI];
+      // ---- first pass over the segment: the VM as far as the signature's keys (no transaction IDs yet), so that the
+      // segment's key stage is on the device before the rest of its hashing starts
       {
+        const double t0 = now();
+        const size_t t_lo = ck[sgm.c_lo]->lo, t_hi = ck[sgm.c_hi - 1]->lo + ck[sgm.c_hi - 1]->n;
+        host_parallel((t_hi - t_lo + 7) / 8, host_threads, [&](size_t g) {
+          const uint8_t* p[8];
+          size_t l[8];
+          const size_t first = t_lo + 8 * g, cnt = std::min<size_t>(8, t_hi - first);
+          for (size_t q = 0; q < cnt; ++q) { p[q] = txs + tx_offsets[first + q]; l[q] = (size_t)(tx_offsets[first + q + 1] - tx_offsets[first + q]); }
+          // (consecutive statements: the store's, or the overflow's -- a group of eight never straddles the two: chunk
+          // boundaries and the store's cap are multiples of eight)
+          tx_prepare_many(p, l, &statement(first), cnt, true, P_MUSIG);
+        });
+        sgm.g_lo = live_all.size();
+        for (size_t ci = sgm.c_lo; ci < sgm.c_hi; ++ci) {
+          TxChunk& k = *ck[ci];
+          k.g0 = live_all.size();
+          for (size_t i = 0; i < k.n; ++i) {
+            const TxStatement& t = statement(k.lo + i);
+            if (status && t.status == TX_UNSUPPORTED) status[k.lo + i] = TX_UNSUPPORTED;     // (TX_OK is written at the very end only)
+            if (t.status == TX_OK) { k.live.push_back(i); live_all.push_back(k.lo + i); }
+          }
+          k.pbits.assign((k.live.size() + 7) / 8 + 1, 0);
+        }
+        sgm.g_hi = live_all.size();
+        const size_t nl = sgm.g_hi - sgm.g_lo;
+        sgm.kok.assign((nl + 7) / 8 + 1, 0);
+        sgm.koff.assign(nl + 1, 0);
+        for (size_t j = 0; j < nl; ++j) sgm.koff[j + 1] = sgm.koff[j] + statement(live_all[sgm.g_lo + j]).sig_scalars.size() / 32 - 2;
+        sgm.ksc.resize(32 * sgm.koff.back()); sgm.kpt.resize(32 * sgm.koff.back());
+        host_parallel(nl, host_threads, [&](size_t j) {
+          const TxStatement& t = statement(live_all[sgm.g_lo + j]);
+          memcpy(sgm.ksc.data() + 32 * sgm.koff[j], t.sig_scalars.data() + 64, t.sig_scalars.size() - 64);
+          memcpy(sgm.kpt.data() + 32 * sgm.koff[j], t.sig_points.data() + 64, t.sig_points.size() - 64);
+        });
+        std::lock_guard<std::mutex> lk(hm);
+        t_keys_host += now() - t0;
+        key_rows[sI] = 1;
+        hcv.notify_all();
+      }
+      // ---- second pass, chunk by chunk: everything else the VM hashes (contract ids, transaction ID), the statements gathered
+      for (size_t ci = sgm.c_lo; ci < sgm.c_hi; ++ci) {
+        TxChunk& k = *ck[ci];
+        {
+          std::unique_lock<std::mutex> lk(hm);
+          make_sig_stages(lk, ci);
+          if (ci >= RING) hcv.wait(lk, [&] { return quit || arena_free[ci - RING]; });
+          if (quit) return;
+        }
+        const double t0 = now();
+        // eight transactions per task: the hashing of transactions of one shape runs in lockstep on AVX-512 (zkvm_tx.hpp,
+        // tx_prepare_many; merlin_x8.hpp)
+        host_parallel((k.n + 7) / 8, host_threads, [&](size_t g) {
+          const uint8_t* p[8];
+          size_t l[8];
+          const size_t first = 8 * g, cnt = std::min<size_t>(8, k.n - first);
+          for (size_t q = 0; q < cnt; ++q) { p[q] = txs + tx_offsets[k.lo + first + q]; l[q] = (size_t)(tx_offsets[k.lo + first + q + 1] - tx_offsets[k.lo + first + q]); }
+          tx_prepare_many(p, l, &statement(k.lo + first), cnt);
+        });
+        const double t1 = now();
+        const size_t nl = k.live.size();
+        if (nl) {
+          // the cloak statements, gathered into the chunk's staging area
+          std::vector<TxSource> src(nl);
+          for (size_t q = 0; q < nl; ++q) {
+            const TxStatement& t = statement(k.lo + k.live[q]);
+            src[q] = TxSource{t.n_in, t.n_out, t.commitments.data(), t.proof, t.proof_len};
+          }
+          k.stage_rc = txblock_stage_host(v, nl, src.data(), nullptr, host_threads, &k.blk, &v->tx_arenas[ci % RING], &k.stage_err);
+        }
+        const double t2 = now();
+        if (timing) fprintf(stderr, "    staging thread, chunk %zu: VM %.3f ms, gather %.3f\n", ci, (t1 - t0) * 1e3, (t2 - t1) * 1e3);
         std::unique_lock<std::mutex> lk(hm);
-        run_sig_jobs(lk);
-        if (ci >= RING) hcv.wait(lk, [&] { return quit || arena_free[ci - RING]; });
-        if (quit) return;
+        t_vm += t1 - t0;
+        t_stage_host += t2 - t1;
+        staged[ci] = 1;
+        hcv.notify_all();
       }
-      const double t0 = now();
-      if (!k.st) { k.st_own.resize(k.n); k.st = k.st_own.data(); }
-      const double ta = now();
-      // eight transactions per task: the hashing of transactions of one shape runs in lockstep on AVX-512 (zkvm_tx.hpp,
-      // tx_prepare_many; merlin_x8.hpp)
-      host_parallel((k.n + 7) / 8, host_threads, [&](size_t g) {
-        const uint8_t* p[8];
-        size_t l[8];
-        const size_t first = 8 * g, cnt = std::min<size_t>(8, k.n - first);
-        for (size_t q = 0; q < cnt; ++q) { p[q] = txs + tx_offsets[k.lo + first + q]; l[q] = (size_t)(tx_offsets[k.lo + first + q + 1] - tx_offsets[k.lo + first + q]); }
-        tx_prepare_many(p, l, &k.st[first], cnt);
-      });
-      const double tb = now();
-      for (size_t i = 0; i < k.n; ++i) {
-        if (status && k.st[i].status == TX_UNSUPPORTED) status[k.lo + i] = TX_UNSUPPORTED;     // (TX_OK is written at the very end only)
-        if (k.st[i].status == TX_OK) k.live.push_back(i);
-      }
-      const size_t nl = k.live.size();
-      k.pbits.assign((nl + 7) / 8 + 1, 0);
-      k.kok.assign((nl + 7) / 8 + 1, 0);
-      k.agg.assign(32 * std::max<size_t>(nl, 1), 0);
-      const double t1 = now();
-      if (nl) {
-        // rows (a_i, X_i) of the aggregated keys
-        k.koff.assign(nl + 1, 0);
-        for (size_t j = 0; j < nl; ++j) k.koff[j + 1] = k.koff[j] + k.st[k.live[j]].sig_scalars.size() / 32 - 2;
-        k.ksc.resize(32 * k.koff.back()); k.kpt.resize(32 * k.koff.back());
-        for (size_t j = 0; j < nl; ++j) {               // (a few hundred KB: not worth waking the pool for)
-          const TxStatement& t = k.st[k.live[j]];
-          memcpy(k.ksc.data() + 32 * k.koff[j], t.sig_scalars.data() + 64, t.sig_scalars.size() - 64);
-          memcpy(k.kpt.data() + 32 * k.koff[j], t.sig_points.data() + 64, t.sig_points.size() - 64);
-        }
-        {                                                // the keys can go out while the statements are gathered
-          std::lock_guard<std::mutex> lk(hm);
-          rows_ready[ci] = 1;
-          hcv.notify_all();
-        }
-        // the cloak statements, gathered into the chunk's staging area
-        std::vector<TxSource> src(nl);
-        for (size_t q = 0; q < nl; ++q) {
-          const TxStatement& t = k.st[k.live[q]];
-          src[q] = TxSource{t.n_in, t.n_out, t.commitments.data(), t.proof, t.proof_len};
-        }
-        const double tc = now();
-        k.stage_rc = txblock_stage_host(v, nl, src.data(), nullptr, host_threads, &k.blk, &v->tx_arenas[ci % RING], &k.stage_err);
-        if (timing) fprintf(stderr, "    staging thread, chunk %zu: statements %.3f ms, VM %.3f, scan %.3f, key rows + sources %.3f, gather %.3f\n", ci,
-                            (ta - t0) * 1e3, (tb - ta) * 1e3, (t1 - tb) * 1e3, (tc - t1) * 1e3, (now() - tc) * 1e3);
-      }
-      const double t2 = now();
-      std::unique_lock<std::mutex> lk(hm);
-      t_vm += t1 - t0;
-      t_stage_host += t2 - t1;
-      staged[ci] = 1;
-      hcv.notify_all();
     }
     std::unique_lock<std::mutex> lk(hm);
     for (;;) {
-      run_sig_jobs(lk);
-      if (quit) return;
-      hcv.wait(lk, [&] { return quit || !sig_jobs.empty(); });
+      make_sig_stages(lk, n_chunks);
+      if (quit || all_sigs_made) return;
+      hcv.wait(lk, [&] { return quit || keys_arrived[sig_plan[sig_next].segment]; });
     }
   });
   struct StagerJoin {                                    // whatever way the call ends, the thread is told and waited for
@@ -1323,27 +1395,25 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   g_thread_pool = &HostPool::second();                   // this thread's own short loops do not wait for the staging thread's
   struct PoolReset { ~PoolReset() { g_thread_pool = nullptr; } } pool_reset;
 
-  auto keys_collect = [&](TxChunk& k) {
-    if (!k.keys_pending) return;
-    k.keys_pending = false;
-    const double t0 = now();
-    note(split_collect(v->aux_keys[k.index & 1], k.kok.data(), k.agg.data()), v->aux_keys[k.index & 1]);
-    t_wait += now() - t0;
-    mark("keys collected, chunk at", k.lo);
-    if (first_rc == ZKGPU_OK && !k.live.empty()) {      // its signature transcripts: over to the staging thread
-      std::lock_guard<std::mutex> lk(hm);
-      sig_jobs.push_back(k.index);
-      k.sig_asked = true;
-      hcv.notify_all();
+  auto keys_collect = [&](size_t sI) {
+    Segment& sgm = seg[sI];
+    if (sgm.pending) {
+      sgm.pending = false;
+      const double t0 = now();
+      note(split_collect(v->aux_keys[sI & 1], sgm.kok.data(), agg.data() + 32 * sgm.g_lo), v->aux_keys[sI & 1]);
+      t_wait += now() - t0;
+      for (size_t j = 0; j < sgm.g_hi - sgm.g_lo; ++j) key_ok[sgm.g_lo + j] = (sgm.kok[j / 8] >> (j % 8)) & 1;
+      mark("keys collected, segment", sI);
     }
   };
-  auto sigs_collect = [&](TxChunk& k) {
-    if (!k.sigs_pending) return;
-    k.sigs_pending = false;
+  auto sigs_collect = [&](size_t si) {
+    TxSigStage& sg = *sig_stages[si];
+    if (!sg.pending) return;
+    sg.pending = false;
     const double t0 = now();
-    note(split_collect(v->aux_sigs[k.index & 1], k.sig_bits.data(), nullptr), v->aux_sigs[k.index & 1]);
+    note(split_collect(v->aux_sigs[si & 1], sg.bits.data(), nullptr), v->aux_sigs[si & 1]);
     t_wait += now() - t0;
-    mark("signatures collected, chunk at", k.lo);
+    mark("signatures collected, stage", si);
   };
   auto proofs_collect = [&](TxChunk& k) {
     if (k.run) {
@@ -1359,59 +1429,9 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     arena_free[k.index] = 1;
     hcv.notify_all();
   };
-  // the equations of the chunks whose rows are ready, in chunk order (wait: for the next one if it has been asked for)
-  size_t next_sig = 0;
-  auto sigs_enqueue = [&](bool wait) {
-    while (next_sig < n_chunks && first_rc == ZKGPU_OK) {
-      TxChunk& k = *ck[next_sig];
-      if (!k.sig_asked) {
-        if (k.keys_done_without_sigs) { ++next_sig; continue; }
-        return;
-      }
-      {
-        std::unique_lock<std::mutex> lk(hm);
-        if (!sig_ready[next_sig]) {
-          if (!wait) return;
-          const double t0 = now();
-          hcv.wait(lk, [&] { return sig_ready[next_sig] != 0; });
-          t_wait_host += now() - t0;
-        }
-      }
-      const double t0 = now();
-      if (next_sig >= 2) sigs_collect(*ck[next_sig - 2]);           // (the chunk that used this stage's context last)
-      const size_t ns = k.keyed.size();
-      if (ns) {
-        zkgpu_ctx* sc = v->aux_sigs[k.index & 1];
-        if (note(verify_ps_enqueue(sc, v->ps, ns, k.ssc.data(), k.spt.data(), k.soff.data(), k.sst.data(), k.sidx.data(), k.sst_off.data()), sc) == ZKGPU_OK)
-          k.sigs_pending = true;
-      }
-      t_sigs += now() - t0;
-      mark("signatures queued, chunk at", k.lo);
-      ++next_sig;
-    }
-  };
-
-  // The calling thread never waits for one thing while another could be queued: it looks, in turn, for a chunk the staging
-  // thread has finished (its keys, then its proofs go out -- the keys BEFORE the proofs: what follows them is a chain, keys ->
-  // host transcripts -> equations, and queued behind the proofs' chip-filling kernels its short kernels would wait for
-  // CUs), for aggregated keys that have arrived (over to the staging thread for the signature transcripts), and for
-  // signature rows that are ready (the equations go out); with nothing to do it sleeps until the staging thread has news,
-  // 50 us at most (what the device has finished is found out by asking).
-  size_t next_rows = 0, next_stage = 0, next_keys = 0;
-  auto enqueue_keys = [&](size_t ci) {
-    TxChunk& k = *ck[ci];
-    mark("rows ready, chunk", ci);
-    const size_t nl = k.live.size();
-    const double t0 = now();
-    if (nl) {
-      zkgpu_ctx* kc = v->aux_keys[ci & 1];
-      if (note(msm_values_enqueue(kc, k.ksc.data(), k.kpt.data(), k.koff.data(), nl), kc) == ZKGPU_OK) k.keys_pending = true;
-    } else k.keys_done_without_sigs = true;
-    t_keys += now() - t0;
-    mark("keys queued, chunk", ci);
-  };
   auto enqueue_proofs = [&](size_t ci) {
     TxChunk& k = *ck[ci];
+    mark("staged, chunk", ci);
     if (k.stage_rc != ZKGPU_OK) { if (first_rc == ZKGPU_OK) { first_rc = k.stage_rc; v->last_error = k.stage_err; } return; }
     if (k.live.empty()) return;
     // one copy to HBM, and the chunk's batches queued on the lanes
@@ -1428,29 +1448,63 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     t_stage += now() - t0;
     mark("proofs queued, chunk", ci);
   };
-  while (first_rc == ZKGPU_OK && (next_stage < n_chunks || next_keys < n_chunks || next_sig < n_chunks)) {
-    bool progress = false;
-    // a staged chunk (its key context is free once the chunk two back has been collected; its staging area once the
-    // chunk RING back has)
-    if (next_stage >= RING && next_stage < n_chunks && !arena_free[next_stage - RING]) proofs_collect(*ck[next_stage - RING]);
-    if (next_rows < n_chunks && (next_rows < 2 || next_keys + 2 > next_rows)) {
-      bool ready;
-      { std::lock_guard<std::mutex> lk(hm); ready = rows_ready[next_rows] != 0 || staged[next_rows] != 0; }
-      if (ready) { enqueue_keys(next_rows++); progress = true; }
+  // The calling thread never waits for one thing while another could be queued: it looks, in turn, for the key rows of a
+  // segment (its key stage goes out, before any of its proofs: what follows the keys is a chain, keys -> host transcripts ->
+  // equations, and queued behind the proofs' chip-filling kernels its short kernels would wait for CUs), for a chunk the
+  // staging thread has finished (its proofs go out), for aggregated keys that have arrived (the staging thread is told),
+  // and for signature stages that are ready (the equations go out); with nothing to do it sleeps until the staging thread
+  // has news, 50 us at most (what the device has finished is found out by asking).
+  size_t next_key = 0, next_kcollect = 0, next_stage = 0, next_sig = 0;
+  while (first_rc == ZKGPU_OK) {
+    bool progress = false, sigs_all, rows = false, st_ready = false;
+    size_t sig_avail;
+    {
+      std::lock_guard<std::mutex> lk(hm);
+      sig_avail = n_sig_stages; sigs_all = all_sigs_made;
+      if (next_key < n_seg) rows = key_rows[next_key] != 0;
+      if (next_stage < n_chunks) st_ready = staged[next_stage] != 0;
     }
-    if (first_rc == ZKGPU_OK && next_stage < next_rows) {
-      bool ready;
-      { std::lock_guard<std::mutex> lk(hm); ready = staged[next_stage] != 0; }
-      if (ready) { enqueue_proofs(next_stage++); progress = true; }
+    if (next_kcollect == n_seg && next_stage == n_chunks && sigs_all && next_sig == sig_avail) break;
+    if (rows && (next_key < 2 || next_kcollect + 2 > next_key)) {           // (its context is free once segment next_key - 2 is collected)
+      Segment& sgm = seg[next_key];
+      mark("key rows ready, segment", next_key);
+      const double t0 = now();
+      if (sgm.g_hi > sgm.g_lo) {
+        zkgpu_ctx* kc = v->aux_keys[next_key & 1];
+        if (note(msm_values_enqueue(kc, sgm.ksc.data(), sgm.kpt.data(), sgm.koff.data(), sgm.g_hi - sgm.g_lo), kc) == ZKGPU_OK) sgm.pending = true;
+      }
+      t_keys += now() - t0;
+      mark("keys queued, segment", next_key);
+      ++next_key;
+      progress = true;
     }
-    // aggregated keys, in chunk order
-    if (first_rc == ZKGPU_OK && next_keys < next_rows) {
-      TxChunk& k = *ck[next_keys];
-      if (!k.keys_pending || split_done(v->aux_keys[k.index & 1])) { keys_collect(k); ++next_keys; progress = true; }
+    if (first_rc == ZKGPU_OK && next_stage < n_chunks && seg_of[next_stage] < next_key) {     // (proofs after their segment's keys, always)
+      if (next_stage >= RING && !arena_free[next_stage - RING]) proofs_collect(*ck[next_stage - RING]);
+      if (st_ready) { enqueue_proofs(next_stage++); progress = true; }
     }
-    const size_t before = next_sig;
-    sigs_enqueue(false);
-    progress |= next_sig != before;
+    if (first_rc == ZKGPU_OK && next_kcollect < next_key && (!seg[next_kcollect].pending || split_done(v->aux_keys[next_kcollect & 1]))) {
+      keys_collect(next_kcollect);
+      { std::lock_guard<std::mutex> lk(hm); keys_arrived[next_kcollect] = 1; }
+      hcv.notify_all();
+      ++next_kcollect;
+      progress = true;
+    }
+    while (first_rc == ZKGPU_OK && next_sig < sig_avail) {
+      TxSigStage& sg = *sig_stages[next_sig];
+      const double t0 = now();
+      if (next_sig >= 2) sigs_collect(next_sig - 2);                // (the stage that used this context last)
+      const size_t ns = sg.keyed.size();
+      if (ns) {
+        zkgpu_ctx* sc = v->aux_sigs[next_sig & 1];
+        if (note(verify_ps_enqueue(sc, v->ps, ns, sg.ssc.data(), sg.spt.data(), sg.soff.data(), sg.sst.data(), sg.sidx.data(), sg.sst_off.data()), sc) == ZKGPU_OK)
+          sg.pending = true;
+      }
+      sg.queued = true;
+      t_sigs += now() - t0;
+      mark("signatures queued, stage", next_sig);
+      ++next_sig;
+      progress = true;
+    }
     if (!progress) {
       std::unique_lock<std::mutex> lk(hm);
       const double t0 = now();
@@ -1464,23 +1518,22 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   }
   hcv.notify_all();
   stager.join();
-  for (size_t ci = 0; ci < n_chunks; ++ci) {
-    keys_collect(*ck[ci]);                              // (only after an error: nothing is left pending on the contexts)
-    sigs_collect(*ck[ci]);
-    proofs_collect(*ck[ci]);
-  }
-  if (timing) fprintf(stderr, "tx verify: %zu transactions in %zu chunks: staging thread: VM + ids %.2f ms, rows + gather %.2f ms, signature transcripts %.2f ms; "
-                              "calling thread: waiting for the staging thread %.2f ms, queueing keys %.2f, proofs %.2f, signatures %.2f ms, "
+  for (size_t sI = 0; sI < n_seg; ++sI) keys_collect(sI);   // (only after an error: nothing is left pending on the contexts)
+  for (size_t si = 0; si < sig_stages.size(); ++si) sigs_collect(si);
+  for (size_t ci = 0; ci < n_chunks; ++ci) proofs_collect(*ck[ci]);
+  if (timing) fprintf(stderr, "tx verify: %zu transactions in %zu chunks: staging thread: keys pass %.2f ms, VM + ids %.2f ms, gather %.2f ms, signature "
+                              "transcripts %.2f ms (%zu stages); calling thread: idle %.2f ms, queueing keys %.2f, proofs %.2f, signatures %.2f ms, "
                               "waiting for the device %.2f ms; %.2f ms in all\n",
-                      batch, n_chunks, t_vm * 1e3, t_stage_host * 1e3, t_sig_host * 1e3, t_wait_host * 1e3, t_keys * 1e3, t_stage * 1e3, t_sigs * 1e3,
-                      t_wait * 1e3, (now() - t00) * 1e3);
+                      batch, n_chunks, t_keys_host * 1e3, t_vm * 1e3, t_stage_host * 1e3, t_sig_host * 1e3, sig_stages.size(), t_wait_host * 1e3,
+                      t_keys * 1e3, t_stage * 1e3, t_sigs * 1e3, t_wait * 1e3, (now() - t00) * 1e3);
   if (first_rc != ZKGPU_OK) return first_rc;             // both outputs still read "nothing accepted"
+  std::vector<uint8_t> sig_ok(live_all.size(), 0);
+  for (const auto& sg : sig_stages)
+    for (size_t q = 0; q < sg->keyed.size(); ++q) if ((sg->bits[q / 8] >> (q % 8)) & 1) sig_ok[sg->keyed[q]] = 1;
   for (size_t ci = 0; ci < n_chunks; ++ci) {
     const TxChunk& k = *ck[ci];
-    std::vector<uint8_t> sig_ok(k.live.size(), 0);
-    for (size_t q = 0; q < k.keyed.size(); ++q) if ((k.sig_bits[q / 8] >> (q % 8)) & 1) sig_ok[k.keyed[q]] = 1;
     for (size_t j = 0; j < k.live.size(); ++j) {
-      if (!sig_ok[j] || !((k.pbits[j / 8] >> (j % 8)) & 1)) continue;
+      if (!sig_ok[k.g0 + j] || !((k.pbits[j / 8] >> (j % 8)) & 1)) continue;
       const size_t i = k.lo + k.live[j];
       accept_bitmap[i / 8] |= (uint8_t)(1u << (i % 8));
       if (status) status[i] = TX_OK;

@@ -126,9 +126,18 @@ struct TxPlan {
   std::vector<uint8_t> imm;
   std::vector<uint32_t> shape;   // everything that must agree for two plans to run in lockstep (no pointers, no contents)
   uint16_t n_slots = 0;
-  void clear() { jobs.clear(); pieces.clear(); imm.clear(); shape.clear(); n_slots = 0; }
-  void begin(uint8_t proto) { jobs.push_back(HashJob{proto, 0, 0, 0, (uint32_t)pieces.size(), 0}); shape.push_back(0x4a000000u | proto); }
+  // only != 0xff: the plan keeps the jobs of that protocol alone -- whatever else the VM asks to be hashed is dropped as it
+  // is written down (its slot numbers read 0 and are used by dropped jobs only): the keys-first pass of a call
+  uint8_t only = 0xff;
+  bool dropping = false;
+  void clear() { jobs.clear(); pieces.clear(); imm.clear(); shape.clear(); n_slots = 0; dropping = false; }
+  void begin(uint8_t proto) {
+    dropping = only != 0xff && proto != only;
+    if (dropping) return;
+    jobs.push_back(HashJob{proto, 0, 0, 0, (uint32_t)pieces.size(), 0}); shape.push_back(0x4a000000u | proto);
+  }
   void piece(uint8_t label, uint8_t kind, const uint8_t* p, uint32_t len, uint32_t msg_len, uint16_t slot = 0, uint32_t off = 0) {
+    if (dropping) return;
     HashPiece h; h.label = label; h.kind = kind; h.p = p; h.len = len; h.msg_len = msg_len; h.slot = slot; h.off = off;
     pieces.push_back(h);
     shape.push_back(((uint32_t)label << 24) | ((uint32_t)kind << 16) | slot);
@@ -138,6 +147,7 @@ struct TxPlan {
   void bytes(uint8_t label, const uint8_t* p, uint32_t len, uint32_t msg_len) { piece(label, HashPiece::Bytes, p, len, msg_len); }
   void slot(uint8_t label, uint16_t s, uint32_t msg_len = 32) { piece(label, HashPiece::Slot, nullptr, 32, msg_len, s); }
   void immediate(uint8_t label, const uint8_t* b, uint32_t len, uint32_t msg_len) {
+    if (dropping) return;
     const uint32_t off = (uint32_t)imm.size();
     imm.insert(imm.end(), b, b + len);
     piece(label, HashPiece::Imm, nullptr, len, msg_len, 0, off);
@@ -149,6 +159,7 @@ struct TxPlan {
   }
   // closes the job: its challenge (32 bytes, or 64 bytes reduced to a canonical scalar) goes to a new slot
   uint16_t end(uint8_t chal_label, uint8_t out_len) {
+    if (dropping) { dropping = false; return 0; }
     HashJob& j = jobs.back();
     j.chal_label = chal_label; j.out_len = out_len; j.out_slot = n_slots++;
     j.count = (uint32_t)pieces.size() - j.first;
@@ -162,10 +173,13 @@ inline const uint8_t* piece_bytes(const TxPlan& P, const HashPiece& h, const uin
   return h.kind == HashPiece::Bytes ? h.p : h.kind == HashPiece::Slot ? slots + 32 * (size_t)h.slot : P.imm.data() + h.off;
 }
 
-// slots: 32 bytes per slot.  One transaction.
-inline void run_plan(const TxPlan& P, uint8_t* slots) {
+// slots: 32 bytes per slot.  One transaction.  only != ALL_PROTOS: just the jobs of that protocol (they must not read slots
+// of the others: true of P_MUSIG, whose inputs are keys and counters).
+constexpr uint8_t ALL_PROTOS = 0xff;
+inline void run_plan(const TxPlan& P, uint8_t* slots, uint8_t only = ALL_PROTOS) {
   static thread_local std::vector<uint8_t> msg;
   for (const HashJob& j : P.jobs) {
+    if (only != ALL_PROTOS && j.proto != only) continue;
     Transcript t = proto_transcript(j.proto);
     for (uint32_t q = j.first; q < j.first + j.count;) {
       const HashPiece& h = P.pieces[q];
@@ -186,10 +200,11 @@ inline void run_plan(const TxPlan& P, uint8_t* slots) {
 
 #if ZK_HAVE_X8
 // Eight plans of one shape in lockstep (lanes may repeat a plan: padding).  slots[l]: lane l's slot memory.
-ZK_X8 inline void run_plans_x8(const TxPlan* const P[8], uint8_t* const slots[8]) {
+ZK_X8 inline void run_plans_x8(const TxPlan* const P[8], uint8_t* const slots[8], uint8_t only = ALL_PROTOS) {
   const TxPlan& P0 = *P[0];
   for (size_t ji = 0; ji < P0.jobs.size(); ++ji) {
     const HashJob& j = P0.jobs[ji];
+    if (only != ALL_PROTOS && j.proto != only) continue;
     TranscriptX8 t(proto_transcript(j.proto));
     for (uint32_t q = j.first; q < j.first + j.count; ++q) {
       const HashPiece& h = P0.pieces[q];
@@ -483,12 +498,17 @@ inline void tx_finish_hashes(TxStatement& st, const TxSlots& out, const uint8_t*
 // Runs up to eight transactions: parse, VM, transaction ID, signature terms.  Transactions whose plans have one shape
 // (payments of the same arity and payload sizes, as a block mostly holds) are hashed in lockstep, eight Keccak states per
 // AVX-512 register; anything else -- other shapes side by side, a CPU without AVX-512 -- one at a time.  Same results.
-inline void tx_prepare_many(const uint8_t* const* tx, const size_t* len, TxStatement* st, size_t count, bool allow_x8 = true) {
+// only = P_MUSIG: the signature's key rows alone -- status, s, R, the keys X_i and their MuSig coefficients a_i are what the
+// statement holds afterwards (no transaction ID yet): the first pass of zkgpu_tx_verify_batch, which wants the aggregated
+// keys of a whole call on their way to the device before the rest of the hashing starts.
+inline void tx_prepare_many(const uint8_t* const* tx, const size_t* len, TxStatement* st, size_t count, bool allow_x8 = true,
+                            uint8_t only = ALL_PROTOS) {
   static thread_local TxPlan plans[8];
   static thread_local TxSlots outs[8];
   static thread_local std::vector<uint8_t> slot_mem[8];
   int live[8], n_live = 0;
   for (size_t i = 0; i < count && i < 8; ++i) {
+    plans[i].only = only;
     tx_structure(tx[i], len[i], st[i], plans[i], outs[i]);
     if (st[i].status != TX_OK) continue;
     slot_mem[i].resize(32 * (size_t)plans[i].n_slots + 32);
@@ -506,13 +526,13 @@ inline void tx_prepare_many(const uint8_t* const* tx, const size_t* len, TxState
       if (l < n_live) { P[l] = &plans[live[l]]; S[l] = slot_mem[live[l]].data(); }
       else { P[l] = &plans[live[0]]; spare[l].resize(slot_mem[live[0]].size()); S[l] = spare[l].data(); }     // padding: lane 0's work again
     }
-    run_plans_x8(P, S);
+    run_plans_x8(P, S, only);
   }
 #endif
   for (int q = 0; q < n_live; ++q) {
     const int i = live[q];
-    if (!lockstep) run_plan(plans[i], slot_mem[i].data());
-    tx_finish_hashes(st[i], outs[i], slot_mem[i].data());
+    if (!lockstep) run_plan(plans[i], slot_mem[i].data(), only);
+    tx_finish_hashes(st[i], outs[i], slot_mem[i].data());     // (only = P_MUSIG: the transaction ID copied here is not one yet)
   }
 }
 
