@@ -1298,7 +1298,8 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
       hcv.notify_all();
     }
   };
-  std::thread stager([&] {
+  bool stager_failed = false;                            // (under hm) out of host memory on the staging thread: the call fails
+  auto staging = [&] {
     for (size_t sI = 0; sI < n_seg; ++sI) {
       Segment& sgm = seg[sI];
       // ---- first pass over the segment: the VM as far as the signature's keys (no transaction IDs yet), so that the
@@ -1387,6 +1388,15 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
       if (quit || all_sigs_made) return;
       hcv.wait(lk, [&] { return quit || keys_arrived[sig_plan[sig_next].segment]; });
     }
+  };
+  std::thread stager([&] {
+    try {
+      staging();
+    } catch (...) {                                      // std::bad_alloc in practice: an error for the call, not the end of the process
+      std::lock_guard<std::mutex> lk(hm);
+      stager_failed = true;
+      hcv.notify_all();
+    }
   });
   struct StagerJoin {                                    // whatever way the call ends, the thread is told and waited for
     std::mutex& m; std::condition_variable& cv; bool& quit; std::thread& th;
@@ -1460,6 +1470,7 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     size_t sig_avail;
     {
       std::lock_guard<std::mutex> lk(hm);
+      if (stager_failed) { first_rc = ZKGPU_ENOMEM; v->last_error = "out of host memory while staging the transactions"; break; }
       sig_avail = n_sig_stages; sigs_all = all_sigs_made;
       if (next_key < n_seg) rows = key_rows[next_key] != 0;
       if (next_stage < n_chunks) st_ready = staged[next_stage] != 0;
