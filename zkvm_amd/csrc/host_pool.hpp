@@ -3,7 +3,7 @@
 // The host stages on the product path (the transaction VM and ids of zkgpu_tx_verify_batch, the witness rows of the
 // device prover) are short -- a millisecond or two per call -- and creating and joining a dozen threads per call
 // costs a good part of that.  The workers are created on first use, sleep on a condition variable between calls and
-// are joined when the library is unloaded.  One call uses a pool at a time; a second caller arriving meanwhile (two
+// are joined when the library is unloaded.  One call uses the pool at a time; a second caller arriving meanwhile (two
 // prover calls in flight on two contexts) waits for its turn; a process forked after the pool was made runs with
 // threads of its own.
 #pragma once
@@ -57,12 +57,6 @@ inline int usable_cpus() {
 class HostPool {
  public:
   static HostPool& get() {
-    static HostPool p;
-    return p;
-  }
-  // a second, independent set of workers: for a caller whose short parallel loops run WHILE another thread of the same call
-  // keeps the first pool busy (zkgpu_tx_verify_batch: the thread that talks to the device, beside the one that runs the VM)
-  static HostPool& second() {
     static HostPool p;
     return p;
   }

@@ -1402,8 +1402,6 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     std::mutex& m; std::condition_variable& cv; bool& quit; std::thread& th;
     ~StagerJoin() { { std::lock_guard<std::mutex> lk(m); quit = true; } cv.notify_all(); if (th.joinable()) th.join(); }
   } stager_join{hm, hcv, quit, stager};
-  g_thread_pool = &HostPool::second();                   // this thread's own short loops do not wait for the staging thread's
-  struct PoolReset { ~PoolReset() { g_thread_pool = nullptr; } } pool_reset;
 
   auto keys_collect = [&](size_t sI) {
     Segment& sgm = seg[sI];

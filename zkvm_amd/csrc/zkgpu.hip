@@ -1932,13 +1932,10 @@ int ipa_on_device(zkgpu_ctx* c, const zkgpu_pointset* ps, std::vector<std::uniqu
 
 // ---- the device prover ------------------------------------------------------------------------------------
 // f(i) for i < n on up to `threads` host threads (0: usable_cpus(): affinity mask and control-group quota)
-// (a thread may name the pool its loops run on: g_thread_pool, see HostPool::second)
-thread_local HostPool* g_thread_pool = nullptr;
 void host_parallel(size_t n, int threads, const std::function<void(size_t)>& f) {
   const int nt = (int)std::max<size_t>(1, std::min<size_t>(n / 16 + 1, (size_t)std::min<int>(threads > 0 ? threads : usable_cpus(), 256)));
   if (nt <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
-  HostPool& pool = g_thread_pool ? *g_thread_pool : HostPool::get();
-  if (pool.run(n, std::min(nt, HostPool::MAX_WORKERS + 1), f)) return;
+  if (HostPool::get().run(n, std::min(nt, HostPool::MAX_WORKERS + 1), f)) return;
   std::vector<std::thread> th;
   for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { for (size_t i = (size_t)t; i < n; i += (size_t)nt) f(i); });
   for (auto& t : th) t.join();
