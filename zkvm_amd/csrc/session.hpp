@@ -1213,27 +1213,23 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     std::vector<uint8_t> ksc, kpt, kok;
     bool pending = false;
   };
-  std::vector<Segment> seg;
+  std::vector<Segment> seg(n_chunks);                    // one key stage per chunk
   std::vector<size_t> seg_of(n_chunks, 0);
+  for (size_t c = 0; c < n_chunks; ++c) { seg[c].c_lo = c; seg[c].c_hi = c + 1; seg_of[c] = c; }
+  const size_t n_seg = seg.size();
+  // signature stages: runs of chunks of ~10 000 transactions in all, the last run's last chunk on its own
+  struct SigPlan { size_t first, last; };
+  std::vector<SigPlan> sig_plan, groups;                 // groups: the runs themselves -- the staging thread's unit of work
   {
     size_t c = 0;
     while (c < n_chunks) {
-      Segment sgm;
-      sgm.c_lo = c;
+      const size_t first = c;
       size_t count = 0;
       while (c < n_chunks && (count == 0 || count + ck[c]->n <= 10240 + 1536)) { count += ck[c]->n; ++c; }
-      sgm.c_hi = c;
-      for (size_t q = sgm.c_lo; q < sgm.c_hi; ++q) seg_of[q] = seg.size();
-      seg.push_back(std::move(sgm));
+      groups.push_back({first, c});
+      if (c == n_chunks && c - first > 1) { sig_plan.push_back({first, c - 1}); sig_plan.push_back({c - 1, c}); }
+      else sig_plan.push_back({first, c});
     }
-  }
-  const size_t n_seg = seg.size();
-  struct SigPlan { size_t first, last, segment; };
-  std::vector<SigPlan> sig_plan;
-  for (size_t sI = 0; sI < n_seg; ++sI) {
-    const Segment& g = seg[sI];
-    if (sI + 1 == n_seg && g.c_hi - g.c_lo > 1) { sig_plan.push_back({g.c_lo, g.c_hi - 1, sI}); sig_plan.push_back({g.c_hi - 1, g.c_hi, sI}); }
-    else sig_plan.push_back({g.c_lo, g.c_hi, sI});
   }
   // ---- what the two threads share (under hm).  key_rows[s]: the rows of segment s are made; keys_arrived[s]: the calling
   // thread has its encodings back; staged[ci]: chunk ci has been through the VM and its statements are in arena ci % RING;
@@ -1278,11 +1274,12 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
       }
     });
   };
-  // the signature stages that are due: their chunks staged, their segment's keys back (staging thread; hm held on entry and
-  // on return)
-  size_t sig_next = 0;
-  auto make_sig_stages = [&](std::unique_lock<std::mutex>& lk, size_t staged_upto) {
-    while (!quit && sig_next < sig_plan.size() && keys_arrived[sig_plan[sig_next].segment] && sig_plan[sig_next].last <= staged_upto) {
+  // the signature stages that are due: their chunks' transaction IDs made, their segment's keys back (staging thread; hm
+  // held on entry and on return)
+  size_t sig_next = 0, hashed_upto = 0;
+  auto keys_back = [&](const SigPlan& sp) { for (size_t c = sp.first; c < sp.last; ++c) if (!keys_arrived[c]) return false; return true; };
+  auto make_sig_stages = [&](std::unique_lock<std::mutex>& lk, size_t ids_upto) {
+    while (!quit && sig_next < sig_plan.size() && sig_plan[sig_next].last <= ids_upto && keys_back(sig_plan[sig_next])) {
       std::unique_ptr<TxSigStage> sg(new TxSigStage());
       sg->first = sig_plan[sig_next].first; sg->last = sig_plan[sig_next].last;
       ++sig_next;
@@ -1300,10 +1297,11 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   };
   bool stager_failed = false;                            // (under hm) out of host memory on the staging thread: the call fails
   auto staging = [&] {
-    for (size_t sI = 0; sI < n_seg; ++sI) {
+   for (const SigPlan& grp : groups) {                   // a run of chunks: keys and proofs of each on their way, then their IDs
+    for (size_t sI = grp.first; sI < grp.last; ++sI) {
       Segment& sgm = seg[sI];
-      // ---- first pass over the segment: the VM as far as the signature's keys (no transaction IDs yet), so that the
-      // segment's key stage is on the device before the rest of its hashing starts
+      // ---- first pass over the chunk: the VM as far as the signature's keys (no transaction IDs yet) -- its key stage
+      // goes to the device at once, and so do its proofs (below)
       {
         const double t0 = now();
         const size_t t_lo = ck[sgm.c_lo]->lo, t_hi = ck[sgm.c_hi - 1]->lo + ck[sgm.c_hi - 1]->n;
@@ -1316,6 +1314,7 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
           // boundaries and the store's cap are multiples of eight)
           tx_prepare_many(p, l, &statement(first), cnt, true, P_MUSIG);
         });
+        const double ta = now();
         sgm.g_lo = live_all.size();
         for (size_t ci = sgm.c_lo; ci < sgm.c_hi; ++ci) {
           TxChunk& k = *ck[ci];
@@ -1333,23 +1332,53 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
         sgm.koff.assign(nl + 1, 0);
         for (size_t j = 0; j < nl; ++j) sgm.koff[j + 1] = sgm.koff[j] + statement(live_all[sgm.g_lo + j]).sig_scalars.size() / 32 - 2;
         sgm.ksc.resize(32 * sgm.koff.back()); sgm.kpt.resize(32 * sgm.koff.back());
+        const double tb = now();
         host_parallel(nl, host_threads, [&](size_t j) {
           const TxStatement& t = statement(live_all[sgm.g_lo + j]);
           memcpy(sgm.ksc.data() + 32 * sgm.koff[j], t.sig_scalars.data() + 64, t.sig_scalars.size() - 64);
           memcpy(sgm.kpt.data() + 32 * sgm.koff[j], t.sig_points.data() + 64, t.sig_points.size() - 64);
         });
+        if (timing) fprintf(stderr, "    staging thread, segment %zu: keys pass %.3f ms, scan %.3f, rows %.3f\n", sI, (ta - t0) * 1e3, (tb - ta) * 1e3, (now() - tb) * 1e3);
         std::lock_guard<std::mutex> lk(hm);
         t_keys_host += now() - t0;
         key_rows[sI] = 1;
         hcv.notify_all();
       }
-      // ---- second pass, chunk by chunk: everything else the VM hashes (contract ids, transaction ID), the statements gathered
+      // ---- the chunk's cloak statements: what the proofs need (commitments, proof bytes) is there after the first pass --
+      // the VM's stack machine has run, only hashing is outstanding -- so the proofs go to the device now
       for (size_t ci = sgm.c_lo; ci < sgm.c_hi; ++ci) {
         TxChunk& k = *ck[ci];
         {
           std::unique_lock<std::mutex> lk(hm);
-          make_sig_stages(lk, ci);
           if (ci >= RING) hcv.wait(lk, [&] { return quit || arena_free[ci - RING]; });
+          if (quit) return;
+        }
+        const double t1 = now();
+        const size_t nl = k.live.size();
+        if (nl) {
+          std::vector<TxSource> src(nl);
+          for (size_t q = 0; q < nl; ++q) {
+            const TxStatement& t = statement(k.lo + k.live[q]);
+            src[q] = TxSource{t.n_in, t.n_out, t.commitments.data(), t.proof, t.proof_len};
+          }
+          k.stage_rc = txblock_stage_host(v, nl, src.data(), nullptr, host_threads, &k.blk, &v->tx_arenas[ci % RING], &k.stage_err);
+        }
+        const double t2 = now();
+        if (timing) fprintf(stderr, "    staging thread, chunk %zu: gather %.3f ms\n", ci, (t2 - t1) * 1e3);
+        std::unique_lock<std::mutex> lk(hm);
+        t_stage_host += t2 - t1;
+        staged[ci] = 1;
+        hcv.notify_all();
+      }
+    }
+    // ---- second pass, chunk by chunk: everything else the VM hashes (contract ids, anchors, the transaction ID), which
+    // the signature transcripts wait for -- after the keys and proofs of every chunk of the run are on their way
+    {
+      for (size_t ci = grp.first; ci < grp.last; ++ci) {
+        TxChunk& k = *ck[ci];
+        {
+          std::unique_lock<std::mutex> lk(hm);
+          make_sig_stages(lk, ci);
           if (quit) return;
         }
         const double t0 = now();
@@ -1363,30 +1392,18 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
           tx_prepare_many(p, l, &statement(k.lo + first), cnt);
         });
         const double t1 = now();
-        const size_t nl = k.live.size();
-        if (nl) {
-          // the cloak statements, gathered into the chunk's staging area
-          std::vector<TxSource> src(nl);
-          for (size_t q = 0; q < nl; ++q) {
-            const TxStatement& t = statement(k.lo + k.live[q]);
-            src[q] = TxSource{t.n_in, t.n_out, t.commitments.data(), t.proof, t.proof_len};
-          }
-          k.stage_rc = txblock_stage_host(v, nl, src.data(), nullptr, host_threads, &k.blk, &v->tx_arenas[ci % RING], &k.stage_err);
-        }
-        const double t2 = now();
-        if (timing) fprintf(stderr, "    staging thread, chunk %zu: VM %.3f ms, gather %.3f\n", ci, (t1 - t0) * 1e3, (t2 - t1) * 1e3);
+        if (timing) fprintf(stderr, "    staging thread, chunk %zu: VM %.3f ms\n", ci, (t1 - t0) * 1e3);
         std::unique_lock<std::mutex> lk(hm);
         t_vm += t1 - t0;
-        t_stage_host += t2 - t1;
-        staged[ci] = 1;
-        hcv.notify_all();
+        hashed_upto = ci + 1;
       }
     }
+   }
     std::unique_lock<std::mutex> lk(hm);
     for (;;) {
-      make_sig_stages(lk, n_chunks);
+      make_sig_stages(lk, hashed_upto);
       if (quit || all_sigs_made) return;
-      hcv.wait(lk, [&] { return quit || keys_arrived[sig_plan[sig_next].segment]; });
+      hcv.wait(lk, [&] { return quit || keys_back(sig_plan[sig_next]); });
     }
   };
   std::thread stager([&] {
