@@ -245,12 +245,12 @@ def test_the_1024_fixture_transactions_on_the_device():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tx_chunk", [0, 1000])
+@pytest.mark.parametrize("tx_chunk", [0, 1000, 2304])
 def test_a_long_call_travels_through_the_stages_in_chunks(tx_chunk):
     """zkgpu_tx_verify_batch on 7168 transactions in ONE call: the call is cut into chunks whose host stages (VM, signature
     transcripts) run beside the device stages of the others (aggregated keys, signature equations, cloak proofs on the
-    lanes) -- with the default chunking (three chunks, the last one short) and with chunks of 1000 (eight chunks: the
-    staging ring of four is reused).  Sixty transactions are damaged in every part, in every chunk: their verdicts are the
+    lanes) -- with the default chunking (one chunk up to 8192 transactions), with chunks of 1000 (eight chunks: the staging
+    ring of six is reused) and of 2304 (four chunks, the last one short).  Sixty transactions are damaged in every part, in every chunk: their verdicts are the
     oracle's Tx::verify, everybody else's is "accepted"; and status 0 appears exactly beside accept bits of 1."""
     import random
     import sys
