@@ -18,6 +18,9 @@ bv.set_tx_format(bv.TXFORMAT_RECOLLECTED_V1)
 if len(sys.argv) > 3:
     bv.set_tx_chunk(int(sys.argv[3]))
 HT = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+if os.environ.get("TX_BENCH_TRANSCRIPT_MODE"):        # experiment: the lanes' transcript replay (0 automatic, 1 lane, 2 cooperative)
+    for i in range(bv.lanes()):
+        bv.lane(i).set_transcript_mode(int(os.environ["TX_BENCH_TRANSCRIPT_MODE"]))
 bv.verify_txs(txs[:64])
 blob, lens = b"".join(txs), [len(t) for t in txs]
 for _ in range(4):
