@@ -432,4 +432,14 @@ def test_host_worker_pool(host):
     host.zkhost_pool_selftest.argtypes = [C.c_uint32, C.c_uint32]
     assert host.zkhost_pool_selftest(3, 1) == 0
     assert host.zkhost_pool_selftest(3, 4) == 0
+    # host_threads = 0: never more than the affinity mask allows, never more than the control group's CPU quota
+    host.zkhost_usable_cpus.restype = C.c_int
+    n = host.zkhost_usable_cpus()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            assert n <= max(1, round(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
     assert host.zkhost_pool_selftest(1, 1) == 0

@@ -245,12 +245,13 @@ def test_the_1024_fixture_transactions_on_the_device():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tx_chunk", [0, 1000, 2304])
-def test_a_long_call_travels_through_the_stages_in_chunks(tx_chunk):
-    """zkgpu_tx_verify_batch on 7168 transactions in ONE call: the call is cut into chunks whose host stages (VM, signature
+@pytest.mark.parametrize("n_tx,tx_chunk", [(7168, 0), (7168, 1000), (7168, 2304), (12288, 1000)])
+def test_a_long_call_travels_through_the_stages_in_chunks(n_tx, tx_chunk):
+    """zkgpu_tx_verify_batch on 7168 (12 288) transactions in ONE call: the call is cut into chunks whose host stages (VM, signature
     transcripts) run beside the device stages of the others (aggregated keys, signature equations, cloak proofs on the
     lanes) -- with the default chunking (one chunk up to 8192 transactions), with chunks of 1000 (eight chunks: the staging
-    ring of six is reused) and of 2304 (four chunks, the last one short).  Sixty transactions are damaged in every part, in every chunk: their verdicts are the
+    ring of six is reused), of 2304 (four chunks, the last one short), and 12 288 transactions in chunks of 1000 (two runs of
+    chunks: three signature stages, the key stages of thirteen chunks in turn on two contexts).  Sixty transactions are damaged in every part, in every chunk: their verdicts are the
     oracle's Tx::verify, everybody else's is "accepted"; and status 0 appears exactly beside accept bits of 1."""
     import random
     import sys
@@ -260,8 +261,8 @@ def test_a_long_call_travels_through_the_stages_in_chunks(tx_chunk):
     from zkvm_amd import Context
     from zkvm_amd.verifier import BulletproofGens, BlockVerifier
     base = load_tx_fixture()
-    txs = [base[i % 1024] for i in range(7168)]
-    rng = random.Random(77 + tx_chunk)
+    txs = [base[i % 1024] for i in range(n_tx)]
+    rng = random.Random(77 + tx_chunk + n_tx)
     damaged = {}
     for i in sorted(rng.sample(range(len(txs)), 60)):
         t = bytearray(txs[i])

@@ -695,6 +695,9 @@ extern "C" uint64_t zkhost_rng_coop_selftest(uint64_t seed, uint32_t n_draws) {
 // once for a range of sizes and thread counts, calls from `callers` threads at once (one at a time gets the pool, the
 // others wait their turn), and repeated use of the sleeping workers.  Returns the number of violations.
 #include "host_pool.hpp"
+// what host_threads = 0 means: the CPUs this process may keep busy (affinity mask, control-group quota)
+extern "C" int zkhost_usable_cpus() { return zk::usable_cpus(); }
+
 extern "C" uint64_t zkhost_pool_selftest(uint32_t rounds, uint32_t callers) {
   std::atomic<uint64_t> bad{0}, took{0}, refused{0};
   auto one = [&](uint32_t salt) {
