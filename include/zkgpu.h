@@ -493,13 +493,18 @@ int zkgpu_verifier_wait(zkgpu_verifier *v, uint64_t ticket, uint8_t *accept_bitm
  * only beside an accept bit of 1, after every stage has passed; on any error every transaction inside the subset reads
  * "rejected" and the bitmap is zero.  The call holds the verifier for its whole length and first collects whatever its
  * lanes have in flight (tickets and blocks keep their verdicts).
- * Inside, the call is cut into chunks (default ~3000 transactions; zkgpu_verifier_set_tx_chunk, 0 = automatic) that travel
- * through four stages -- VM on the host threads; the cloak proofs staged through pinned memory and queued on the lanes;
- * the aggregated keys, then the signature equations, on two contexts of their own -- so that the host's share of one
- * chunk runs beside the device's share of the others, from ONE calling thread. */
+ * Inside, the call is cut into chunks (equal parts of at most 8192 transactions, 4096 for calls longer than 16 384;
+ * zkgpu_verifier_set_tx_chunk, 0 = automatic) that travel through the stages -- a first VM pass as far as the signature's
+ * keys, the aggregated keys and the cloak proofs (staged through pinned memory, queued on the lanes) on the device at
+ * once; the rest of the VM's hashing beside them; then the signature equations -- on a staging thread of the call's own
+ * (its loops on the library's worker pool, `host_threads` wide) and the calling thread, which only talks to the device.
+ * The verifier keeps what the VM leaves per transaction (700 bytes) between calls, for at most
+ * zkgpu_verifier_set_tx_statements_kept transactions (default 131 072, i.e. 90 MB; what a longer call needs beyond
+ * that is allocated for the call). */
 #define ZKGPU_TXFORMAT_RECOLLECTED_V1 1
 int zkgpu_verifier_set_tx_format(zkgpu_verifier *v, int format);
 int zkgpu_verifier_set_tx_chunk(zkgpu_verifier *v, size_t transactions);
+int zkgpu_verifier_set_tx_statements_kept(zkgpu_verifier *v, size_t transactions);
 int zkgpu_tx_verify_batch(zkgpu_verifier *v, size_t batch, const uint8_t *txs, const uint64_t *tx_offsets, int host_threads,
                           uint8_t *accept_bitmap, uint8_t *status);
 

@@ -245,13 +245,14 @@ def test_the_1024_fixture_transactions_on_the_device():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_tx,tx_chunk", [(7168, 0), (7168, 1000), (7168, 2304), (12288, 1000)])
-def test_a_long_call_travels_through_the_stages_in_chunks(n_tx, tx_chunk):
+@pytest.mark.parametrize("n_tx,tx_chunk,kept", [(7168, 0, None), (7168, 1000, None), (7168, 2304, 2051), (12288, 1000, None)])
+def test_a_long_call_travels_through_the_stages_in_chunks(n_tx, tx_chunk, kept):
     """zkgpu_tx_verify_batch on 7168 (12 288) transactions in ONE call: the call is cut into chunks whose host stages (VM, signature
     transcripts) run beside the device stages of the others (aggregated keys, signature equations, cloak proofs on the
     lanes) -- with the default chunking (one chunk up to 8192 transactions), with chunks of 1000 (eight chunks: the staging
     ring of six is reused), of 2304 (four chunks, the last one short), and 12 288 transactions in chunks of 1000 (two runs of
-    chunks: three signature stages, the key stages of thirteen chunks in turn on two contexts).  Sixty transactions are damaged in every part, in every chunk: their verdicts are the
+    chunks: three signature stages, the key stages of thirteen chunks in turn on two contexts); once with a verifier that
+    keeps only 2051 transactions' VM results between calls (the rest of the call's live in memory of the call's own).  Sixty transactions are damaged in every part, in every chunk: their verdicts are the
     oracle's Tx::verify, everybody else's is "accepted"; and status 0 appears exactly beside accept bits of 1."""
     import random
     import sys
@@ -291,6 +292,8 @@ def test_a_long_call_travels_through_the_stages_in_chunks(n_tx, tx_chunk):
     bv = BlockVerifier(ctx, gens)
     bv.set_tx_format(bv.TXFORMAT_RECOLLECTED_V1)
     bv.set_tx_chunk(tx_chunk)
+    if kept is not None:
+        bv.set_tx_statements_kept(kept)
     try:
         for _ in range(2):
             bm, st = bv.verify_txs(txs, host_threads=8)

@@ -70,6 +70,7 @@ struct zkgpu_verifier {
   std::vector<TxArena> tx_arenas;
   std::vector<zk::zkvm::TxStatement> tx_statements;     // what the VM leaves per transaction, kept between calls (fresh memory costs
                                                         // a page fault per 4 KB: 0.4 ms per 3000 transactions, measured)
+  size_t tx_statements_kept = (size_t)1 << 17;          // at most so many (~90 MB): zkgpu_verifier_set_tx_statements_kept
   size_t tx_chunk = 0;                                  // transactions per chunk of zkgpu_tx_verify_batch (0: automatic)
   uint8_t basepoint[32] = {0};                          // encoding of B, computed once (the signature equations name it)
   bool have_basepoint = false;
@@ -1107,6 +1108,13 @@ int verify_ps_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, cons
 
 }  // namespace
 
+int zkgpu_verifier_set_tx_statements_kept(zkgpu_verifier* v, size_t transactions) {
+  if (!v || transactions >= ((size_t)1 << 31)) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  v->tx_statements_kept = transactions;
+  return ZKGPU_OK;
+}
+
 int zkgpu_verifier_set_tx_chunk(zkgpu_verifier* v, size_t transactions) {
   if (!v || transactions >= (1u << 24)) return ZKGPU_EINVAL;
   std::lock_guard<std::mutex> lk(v->mu);
@@ -1184,8 +1192,9 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   }
   const size_t n_chunks = cuts.size() - 1;
   std::vector<std::unique_ptr<TxChunk>> ck(n_chunks);
-  constexpr size_t STATEMENTS_KEPT = (size_t)1 << 17;    // ~90 MB
-  if (v->tx_statements.size() < std::min(batch, STATEMENTS_KEPT)) v->tx_statements.resize(std::min(batch, STATEMENTS_KEPT));
+  const size_t kept = v->tx_statements_kept & ~(size_t)7;          // (a multiple of eight: see the chunk boundaries)
+  if (v->tx_statements.size() > kept) { v->tx_statements.resize(kept); v->tx_statements.shrink_to_fit(); }
+  if (v->tx_statements.size() < std::min(batch, kept)) v->tx_statements.resize(std::min(batch, kept));
   std::vector<TxStatement> st_beyond(batch > v->tx_statements.size() ? batch - v->tx_statements.size() : 0);
   auto statement = [&](size_t i) -> TxStatement& { return i < v->tx_statements.size() ? v->tx_statements[i] : st_beyond[i - v->tx_statements.size()]; };
   for (size_t ci = 0; ci < n_chunks; ++ci) {

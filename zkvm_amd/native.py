@@ -153,6 +153,7 @@ def load_library():
     lib.zkgpu_verifier_queue_info.argtypes = [vp, C.POINTER(C.c_int)]
     lib.zkgpu_ctx_queue_info.argtypes = [vp, C.POINTER(C.c_int)]
     lib.zkgpu_verifier_set_tx_chunk.argtypes = [vp, sz]
+    lib.zkgpu_verifier_set_tx_statements_kept.argtypes = [vp, sz]
     lib.zkgpu_measure_hbm_copy.argtypes = [vp, sz, C.c_int, C.POINTER(C.c_double)]
     lib.zkgpu_debug_comm_mock.argtypes = [vp, C.c_int, u8p, sz]
     lib.zkgpu_debug_comm_mock.restype = C.c_longlong

@@ -261,6 +261,10 @@ class BlockVerifier:
         """zkgpu_verifier_set_tx_chunk: transactions per chunk of the staged pipeline inside verify_txs (0 = automatic)"""
         self._check(self.lib.zkgpu_verifier_set_tx_chunk(self.h, transactions))
 
+    def set_tx_statements_kept(self, transactions: int) -> None:
+        """zkgpu_verifier_set_tx_statements_kept: how many transactions' VM results (700 B each) the verifier keeps between calls"""
+        self._check(self.lib.zkgpu_verifier_set_tx_statements_kept(self.h, transactions))
+
     def verify_txs(self, txs: Sequence[bytes], host_threads: int = 0):
         """zkgpu_tx_verify_batch: serialized ZkVM transactions (payment subset) -> (accept bitmap, status bytes:
         0 accepted, 1 rejected, 2 outside the subset).  Inert until set_tx_format names a format."""
