@@ -9,7 +9,8 @@ from zkvm_amd.verifier import BulletproofGens, BlockVerifier
 rep = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 txs = load_tx_fixture() * rep
-blob, lens = b"".join(txs), [len(t) for t in txs]
+import numpy as np
+blob, lens = b"".join(txs), np.asarray([len(t) for t in txs], dtype=np.uint64)      # (a Python list of lengths costs more than the call)
 ctx = Context(0)
 gens = BulletproofGens(ctx, 256, table_bits=16)
 ctxs = [ctx, ctx.fork()]
