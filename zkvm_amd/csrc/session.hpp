@@ -1159,10 +1159,28 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   while (!v->busy.empty()) ticket_collect(v, v->busy.front());
   {
     DeviceGuard g(c->device);
+    // a stage context is worth having only if its streams run BESIDE the lanes' (a stream made late in a process may land
+    // on a hardware queue a lane already uses, and the two then take turns -- DESIGN.md sec 5.1): probed like the lanes
+    // were (the device is idle: everything in flight has just been collected), and made again a few times if not
+    auto stage_ctx = [&](zkgpu_ctx*& a) {
+      if (a) return true;
+      std::vector<zkgpu_ctx*> rejected;
+      for (int attempt = 0; attempt < 6; ++attempt) {
+        zkgpu_ctx* made = nullptr;
+        if (ctx_create(c->device, nullptr, &made, true) != ZKGPU_OK) break;
+        bool beside = true;
+        for (zkgpu_ctx* lane : v->lanes)
+          if (streams_overlap(lane->stream_l, made->stream) == 0 || streams_overlap(lane->stream_l, made->stream2) == 0) { beside = false; break; }
+        if (beside || attempt == 5) { a = made; break; }
+        rejected.push_back(made);                          // (kept until a good one is found: its queues stay taken meanwhile)
+      }
+      for (zkgpu_ctx* r : rejected) zkgpu_destroy(r);
+      return a != nullptr;
+    };
     for (zkgpu_ctx*& a : v->aux_keys)
-      if (!a && ctx_create(c->device, nullptr, &a, true) != ZKGPU_OK) { a = nullptr; v->last_error = "no context for the key stage"; return ZKGPU_EHIP; }
+      if (!stage_ctx(a)) { v->last_error = "no context for the key stage"; return ZKGPU_EHIP; }
     for (zkgpu_ctx*& a : v->aux_sigs)
-      if (!a && ctx_create(c->device, nullptr, &a, true) != ZKGPU_OK) { a = nullptr; v->last_error = "no context for the signature stage"; return ZKGPU_EHIP; }
+      if (!stage_ctx(a)) { v->last_error = "no context for the signature stage"; return ZKGPU_EHIP; }
   }
   if (!v->have_basepoint) {
     uint8_t Bb[32];
