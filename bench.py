@@ -615,7 +615,9 @@ def run_config2(args, W):
     ctx.set_locate_parts(args.locate_parts)
     ctx.set_tail_mode(args.tail_mode)
     ctx.set_horner_mode(args.horner_mode)
-    ctxs = [ctx] + [ctx.fork() for _ in range((min(max(1, args.inflight), 10) if args.tickets <= 0 else 5) - 1)]
+    # (with tickets the plain forks serve the single-rank side legs only: at N > 1 they would be four more streams beside the
+    # verifier's lanes and the communicator's, on a device whose queue slots are limited -- DESIGN.md sec 5.1)
+    ctxs = [ctx] + [ctx.fork() for _ in range((min(max(1, args.inflight), 10) if args.tickets <= 0 else (5 if world == 1 else 1)) - 1)]
     gv = Verifier(ctx, gens)
     torch.cuda.synchronize()
     host_time = {"submit": 0.0, "n": 0}
