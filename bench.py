@@ -45,8 +45,13 @@ import os
 # point, so it is.
 # (ranks made to SHARE one GPU -- the two-rank test mode -- share its queue slots too: 24 each is 48 on one device, which
 # then time-slices them: 0.44-0.7 M tx/s against 2.1 M with 8 each, measured)
+# (N > 1: two RCCL communicators -- torch's for the barrier and the timing reduction, the library's for the bitmaps -- bring
+# streams of their own; with 24 queues for ours the process would sit at the device's limit of queues that run side by
+# side, beyond which they are time-sliced (5 - 40 ms stalls).  16 is measured 0 - 2 % below 24 at N = 1
+# and has that margin.)
 _HWQ_PRESET = "GPU_MAX_HW_QUEUES" in os.environ
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8" if os.environ.get("ZKGPU_BENCH_SHARE_GPU") else "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8" if os.environ.get("ZKGPU_BENCH_SHARE_GPU")
+                      else "16" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "24")
 # stdout carries exactly ONE line, the JSON record: whatever libraries print there (RCCL's version banner, gloo's
 # connection chatter) is sent to stderr instead
 _JSON_OUT = os.fdopen(os.dup(1), "w")
