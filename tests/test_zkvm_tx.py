@@ -158,6 +158,16 @@ def test_lockstep_hashing_of_eight_transactions_equals_one_at_a_time(host, oracl
         out[mode] = (st.raw, ids.raw, dig.raw)
     assert out[0] == out[1]
     assert out[0][0].count(b"\x00") >= 190 and out[0][0].count(b"\x02") >= 3
+    # the keys-first pass of zkgpu_tx_verify_batch (a plan that drops every hash job but the MuSig coefficients') leaves the
+    # same status, arity, commitments, s, a_i, R and keys as the full pass -- in lockstep and one at a time
+    rows = {}
+    for lockstep in (0, 1):
+        for keys_only in (0, 1):
+            st, dig = C.create_string_buffer(len(txs)), C.create_string_buffer(64 * len(txs))
+            host.zkhost_tx_rows_group(blob, offs, C.c_size_t(len(txs)), lockstep, keys_only, st, dig)
+            rows[lockstep, keys_only] = (st.raw, dig.raw)
+    assert rows[0, 0] == rows[0, 1] == rows[1, 0] == rows[1, 1]
+    assert rows[0, 0][0] == out[0][0]
     if not have:
         pytest.skip("no AVX-512 on this CPU: both modes ran one transaction at a time")
     for i in (0, 7, 100, 202, 203, 211, 212, 219):                              # and the one-at-a-time form is the oracle's

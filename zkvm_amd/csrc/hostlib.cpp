@@ -738,6 +738,34 @@ extern "C" int zkhost_comm_unpack(const uint8_t* all, size_t slot, const uint64_
   return commframe::unpack(all, slot, cuts, world, rank, whole);
 }
 
+// ---- the keys-first pass of zkgpu_tx_verify_batch (tx_prepare_many with only = P_MUSIG: the plan drops every other hash job)
+// ---- against the full pass, for the CPU tests: per transaction status and a SHA3-512 digest over what BOTH must leave in
+// ---- the statement before the signature challenge -- arity, proof length, commitments, s, -1, the MuSig coefficients
+// ---- a_i, R and the keys X_i.
+extern "C" void zkhost_tx_rows_group(const uint8_t* txs, const uint64_t* offs, size_t count, int lockstep, int keys_only,
+                                     uint8_t* status, uint8_t* digest /*64 per tx*/) {
+  using namespace zk::zkvm;
+  for (size_t g = 0; g < count; g += 8) {
+    const size_t n = std::min<size_t>(8, count - g);
+    const uint8_t* p[8]; size_t l[8];
+    TxStatement st[8];
+    for (size_t i = 0; i < n; ++i) { p[i] = txs + offs[g + i]; l[i] = (size_t)(offs[g + i + 1] - offs[g + i]); }
+    tx_prepare_many(p, l, st, n, lockstep != 0, keys_only ? (uint8_t)P_MUSIG : ALL_PROTOS);
+    for (size_t i = 0; i < n; ++i) {
+      status[g + i] = (uint8_t)st[i].status;
+      Sponge sp = sha3_512_sponge();
+      if (st[i].status == TX_OK) {
+        const uint64_t head[3] = {st[i].n_in, st[i].n_out, (uint64_t)st[i].proof_len};
+        sp.absorb((const uint8_t*)head, sizeof head);
+        sp.absorb(st[i].commitments.data(), st[i].commitments.size());
+        sp.absorb(st[i].sig_scalars.data(), st[i].sig_scalars.size());
+        sp.absorb(st[i].sig_points.data() + 32, st[i].sig_points.size() - 32);     // ([0] is the basepoint's place, filled later)
+      }
+      sp.squeeze(digest + 64 * (g + i), 64);
+    }
+  }
+}
+
 // ---- the lockstep (AVX-512, eight transactions at a time) form of the payment VM's hashing against the one-at-a-time
 // ---- form: for the CPU tests.  Per transaction out: status | txid (32) | then, for accepted ones, the statement's
 // ---- commitments, signature scalars and points (after the challenge has been applied with the given aggregated keys)
