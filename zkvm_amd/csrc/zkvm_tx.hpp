@@ -176,6 +176,7 @@ inline const uint8_t* piece_bytes(const TxPlan& P, const HashPiece& h, const uin
 // slots: 32 bytes per slot.  One transaction.  only != ALL_PROTOS: just the jobs of that protocol (they must not read slots
 // of the others: true of P_MUSIG, whose inputs are keys and counters).
 constexpr uint8_t ALL_PROTOS = 0xff;
+constexpr uint8_t NO_PROTO = 0xfe;      // (as `only`: no job at all -- the VM's stack machine alone)
 inline void run_plan(const TxPlan& P, uint8_t* slots, uint8_t only = ALL_PROTOS) {
   static thread_local std::vector<uint8_t> msg;
   for (const HashJob& j : P.jobs) {
