@@ -1018,8 +1018,6 @@ namespace {
 struct TxChunk {
   size_t lo = 0, n = 0, index = 0;                      // transactions [lo, lo + n) of the call; which chunk
   size_t g0 = 0;                                        // live transactions of the call before this chunk
-  zk::zkvm::TxStatement* st = nullptr;                  // [n], in the verifier's store (or st_own beyond its cap)
-  std::vector<zk::zkvm::TxStatement> st_own;
   std::vector<size_t> live;                             // positions in the chunk the VM accepted
   // cloak proofs (every live transaction: the signature verdict is ANDed in at the end)
   zkgpu_txblock* blk = nullptr;
@@ -1224,12 +1222,11 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   auto note = [&](int rc, zkgpu_ctx* where) { if (rc != ZKGPU_OK && first_rc == ZKGPU_OK) { first_rc = rc; if (where) v->last_error = zkgpu_last_error(where); } return rc; };
   auto mark = [&](const char* what, size_t ci) { if (timing) fprintf(stderr, "    %7.3f ms  %s %zu\n", (now() - t00) * 1e3, what, ci); };
 
-  // ---- segments: runs of chunks of ~10 000 transactions in all.  The aggregated keys of a segment are computed in ONE
-  // key stage, queued before anything else of the segment (a first pass of the VM over the segment's transactions that goes
-  // as far as the keys and their MuSig coefficients); the signature equations of its chunks follow in one stage (two for the
-  // last segment: its last chunk on its own), when the keys are back and the chunks' transaction IDs are made.  All
-  // boundaries depend on the size of the call alone: the same call made again has stages of the same sizes, and the stage
-  // contexts' buffers, grown once, are never grown again (hipMalloc waits for the device).
+  // ---- key stages: one per chunk (X = sum a_i X_i for the chunk's transactions, after a VM pass that goes as far as the keys
+  // and their MuSig coefficients); the signature equations follow in stages over RUNS of chunks (~10 000 transactions; the
+  // last run's last chunk on its own), when the runs' keys are back and their transaction IDs are made.  All boundaries
+  // depend on the size of the call alone: the same call made again has stages of the same sizes, and the stage contexts'
+  // buffers, grown once, are never grown again (hipMalloc waits for the device).
   struct Segment {
     size_t c_lo = 0, c_hi = 0;                            // chunks
     size_t g_lo = 0, g_hi = 0;                            // live transactions of the call (positions in live_all)
@@ -1238,8 +1235,7 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     bool pending = false;
   };
   std::vector<Segment> seg(n_chunks);                    // one key stage per chunk
-  std::vector<size_t> seg_of(n_chunks, 0);
-  for (size_t c = 0; c < n_chunks; ++c) { seg[c].c_lo = c; seg[c].c_hi = c + 1; seg_of[c] = c; }
+  for (size_t c = 0; c < n_chunks; ++c) { seg[c].c_lo = c; seg[c].c_hi = c + 1; }
   const size_t n_seg = seg.size();
   // signature stages: runs of chunks of ~10 000 transactions in all, the last run's last chunk on its own
   struct SigPlan { size_t first, last; };
@@ -1545,7 +1541,7 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
       ++next_key;
       progress = true;
     }
-    if (first_rc == ZKGPU_OK && next_stage < n_chunks && (proofs_first || seg_of[next_stage] < next_key)) {     // (a chunk's proofs after its keys, unless the call is one chunk)
+    if (first_rc == ZKGPU_OK && next_stage < n_chunks && (proofs_first || next_stage < next_key)) {     // (a chunk's proofs after its keys, unless the call is one chunk)
       if (next_stage >= RING && !arena_free[next_stage - RING]) proofs_collect(*ck[next_stage - RING]);
       if (st_ready) { enqueue_proofs(next_stage++); progress = true; }
     }
