@@ -137,7 +137,7 @@ class TranscriptX8 {
   static constexpr unsigned kRate = 166;
   static constexpr uint8_t kI = 1, kA = 2, kC = 4, kM = 16, kK = 32;
   __m512i st_[25];
-  alignas(64) uint8_t buf_[8][176];         // bytes to XOR into the rate (168 used), per lane
+  alignas(64) uint8_t buf_[8][192];         // bytes to XOR into the rate (168 used; three 64-byte blocks), per lane
   unsigned pos_ = 0, pos_begin_ = 0;
 
   static void xor_bytes(uint8_t* dst, const uint8_t* src, size_t n) { for (size_t i = 0; i < n; ++i) dst[i] ^= src[i]; }
@@ -152,9 +152,26 @@ class TranscriptX8 {
   }
   ZK_X8 void run_f() {
     for (int l = 0; l < 8; ++l) { buf_[l][pos_] ^= (uint8_t)pos_begin_; buf_[l][pos_ + 1] ^= 0x04; buf_[l][kRate + 1] ^= 0x80; }
-    const __m512i idx = _mm512_setr_epi64(0, 22, 44, 66, 88, 110, 132, 154);       // lane l: word w of buf_[l] (176 / 8 = 22 words per lane)
-    for (int w = 0; w < 21; ++w)
-      st_[w] = _mm512_xor_si512(st_[w], _mm512_i64gather_epi64(idx, (const long long*)&buf_[0][0] + w, 8));
+    // lane l's 64-byte block j holds its words 8 j .. 8 j + 7; state word w wants word w of all eight lanes: an 8 x 8
+    // transpose of 64-bit elements per block (8 unpacks, 8 two-source permutes, 8 lane shuffles -- a gather per word
+    // costs three times that)
+    const __m512i IA = _mm512_setr_epi64(0, 1, 8, 9, 2, 3, 10, 11), IB = _mm512_setr_epi64(4, 5, 12, 13, 6, 7, 14, 15);
+    for (int j = 0; j < 3; ++j) {
+      __m512i r[8], a[4], b[4];
+      for (int l = 0; l < 8; ++l) r[l] = _mm512_load_si512((const void*)(buf_[l] + 64 * j));
+      for (int k = 0; k < 4; ++k) { a[k] = _mm512_unpacklo_epi64(r[2 * k], r[2 * k + 1]); b[k] = _mm512_unpackhi_epi64(r[2 * k], r[2 * k + 1]); }
+      const __m512i pa_lo = _mm512_permutex2var_epi64(a[0], IA, a[1]), pa_hi = _mm512_permutex2var_epi64(a[0], IB, a[1]);
+      const __m512i qa_lo = _mm512_permutex2var_epi64(a[2], IA, a[3]), qa_hi = _mm512_permutex2var_epi64(a[2], IB, a[3]);
+      const __m512i pb_lo = _mm512_permutex2var_epi64(b[0], IA, b[1]), pb_hi = _mm512_permutex2var_epi64(b[0], IB, b[1]);
+      const __m512i qb_lo = _mm512_permutex2var_epi64(b[2], IA, b[3]), qb_hi = _mm512_permutex2var_epi64(b[2], IB, b[3]);
+      __m512i col[8];
+      col[0] = _mm512_shuffle_i64x2(pa_lo, qa_lo, 0x44); col[2] = _mm512_shuffle_i64x2(pa_lo, qa_lo, 0xEE);
+      col[4] = _mm512_shuffle_i64x2(pa_hi, qa_hi, 0x44); col[6] = _mm512_shuffle_i64x2(pa_hi, qa_hi, 0xEE);
+      col[1] = _mm512_shuffle_i64x2(pb_lo, qb_lo, 0x44); col[3] = _mm512_shuffle_i64x2(pb_lo, qb_lo, 0xEE);
+      col[5] = _mm512_shuffle_i64x2(pb_hi, qb_hi, 0x44); col[7] = _mm512_shuffle_i64x2(pb_hi, qb_hi, 0xEE);
+      const int n = j < 2 ? 8 : 5;                        // words 16 .. 20 of the rate in the last block
+      for (int c = 0; c < n; ++c) st_[8 * j + c] = _mm512_xor_si512(st_[8 * j + c], col[c]);
+    }
     std::memset(buf_, 0, sizeof buf_);
     keccak_f1600_x8(st_);
     pos_ = 0;
