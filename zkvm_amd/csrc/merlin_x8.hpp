@@ -140,7 +140,13 @@ class TranscriptX8 {
   alignas(64) uint8_t buf_[8][192];         // bytes to XOR into the rate (168 used; three 64-byte blocks), per lane
   unsigned pos_ = 0, pos_begin_ = 0;
 
-  static void xor_bytes(uint8_t* dst, const uint8_t* src, size_t n) { for (size_t i = 0; i < n; ++i) dst[i] ^= src[i]; }
+  // the buffers are zero wherever nothing has been absorbed since the last permutation, and every position is written at
+  // most once before the next: XORing the bytes in is copying them (32 and 8 bytes at a time are what the plans mostly hold)
+  ZK_X8 static void xor_bytes(uint8_t* dst, const uint8_t* src, size_t n) {
+    if (n == 32) { _mm256_storeu_si256((__m256i*)dst, _mm256_loadu_si256((const __m256i*)src)); return; }
+    if (n == 8) { uint64_t w; std::memcpy(&w, src, 8); std::memcpy(dst, &w, 8); return; }
+    std::memcpy(dst, src, n);
+  }
   ZK_X8 void same(const uint8_t* d, size_t n) {
     size_t at = 0;
     while (at < n) {
