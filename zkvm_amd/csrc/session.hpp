@@ -1443,15 +1443,21 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
       hcv.wait(lk, [&] { return quit || keys_back(sig_plan[sig_next]); });
     }
   };
-  std::thread stager([&] {
-    try {
-      staging();
-    } catch (...) {                                      // std::bad_alloc in practice: an error for the call, not the end of the process
-      std::lock_guard<std::mutex> lk(hm);
-      stager_failed = true;
-      hcv.notify_all();
-    }
-  });
+  std::thread stager;
+  try {
+    stager = std::thread([&] {
+      try {
+        staging();
+      } catch (...) {                                    // std::bad_alloc in practice: an error for the call, not the end of the process
+        std::lock_guard<std::mutex> lk(hm);
+        stager_failed = true;
+        hcv.notify_all();
+      }
+    });
+  } catch (...) {                                        // no thread to be had: an error for the call as well
+    v->last_error = "the staging thread of the call could not be started";
+    return ZKGPU_ENOMEM;
+  }
   struct StagerJoin {                                    // whatever way the call ends, the thread is told and waited for
     std::mutex& m; std::condition_variable& cv; bool& quit; std::thread& th;
     ~StagerJoin() { { std::lock_guard<std::mutex> lk(m); quit = true; } cv.notify_all(); if (th.joinable()) th.join(); }
