@@ -397,10 +397,11 @@ int zkgpu_decode_check(zkgpu_ctx *ctx, const uint8_t *points, size_t n, uint8_t 
 
 /* ---- whole blocks of transactions of mixed shapes (BASELINE configs[3]) -----------------------
  * zkgpu_verifier mirrors the reference's `Verifier` for a block: it owns up to `batches_in_flight`
- * contexts (the given one and forks of it; 0 = default 6, at most 10.  More than 7 is not recommended: every
- * context brings a stream of its own, and on MI355X runs with 8 and with 10 contexts were measured 3x and 10x slower
- * than with 6, 7 or 9 -- the hardware-queue effect of DESIGN.md sec 7) and one device plan per statement shape,
- * created on first use.  zkgpu_verifier_verify takes the block as Tx::verify sees it -- per
+ * contexts (the given one and forks of it; 0 = default 6, at most 10.  Every context brings a stream of its own for
+ * its latency-bound kernels; a lane whose stream does not really run beside the other lanes' -- the device co-schedules
+ * fewer hardware queues than the runtime hands out -- is probed for at creation and NOT kept, so asking for more lanes
+ * than the device serves costs nothing: zkgpu_verifier_queue_info reports lanes asked / kept / dropped; DESIGN.md
+ * sec 5.1) and one device plan per statement shape, created on first use.  zkgpu_verifier_verify takes the block as Tx::verify sees it -- per
  * transaction (n_in, n_out), its 64 (n_in + n_out) commitment bytes back to back, its R1CSProof bytes
  * (CSR) and 64 bytes of verifier randomness (NULL: getrandom(2)) -- groups the transactions by shape,
  * verifies the groups as uniform batches of at most `chunk` transactions (default 2048) kept in flight
@@ -528,7 +529,9 @@ int zkgpu_tx_verify_batch(zkgpu_verifier *v, size_t batch, const uint8_t *txs, c
  * with the whole block in host memory on every rank.
  * zkgpu_debug_comm_mock: test hook -- world > 0 replaces the collective function table by an in-process mock of a world
  * of `world` ranks whose other ranks contribute peer_slots (world x slot_bytes bytes), so that the exchange step can be
- * exercised at world 2 .. 8 on one GPU; world = 0 restores RCCL.  Returns the all-gathers the mock has served. */
+ * exercised at world 2 .. 8 on one GPU; world = 0 restores RCCL.  Returns the all-gathers the mock has served.
+ * Refused (ZKGPU_EINVAL) unless ZKGPU_TEST_HOOKS=1 was in the environment when the library was loaded; a communicator
+ * keeps the function table it was created with for its whole life, whatever the switch does afterwards. */
 long long zkgpu_debug_comm_mock(zkgpu_ctx *ctx, int world, const uint8_t *peer_slots, size_t slot_bytes);
 #define ZKGPU_COMM_ID_BYTES 128
 typedef struct zkgpu_comm zkgpu_comm;

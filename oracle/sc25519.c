@@ -3,7 +3,8 @@
  * TEST INFRASTRUCTURE (see oracle.h).  Restates curve25519-dalek `Scalar`
  * (not mounted under /root/reference) from RFC 9496
  * sec 4.4.  Plain 4 x 64-bit limbs, schoolbook product, reduction by folding
- * 2^252 = -c (mod l); checked against Python ints in tests/test_oracle_scalar.py.
+ * 2^252 = -c (mod l); checked against Python ints and libsodium's scalar vectors in
+ * tests/test_oracle_field.py.
  */
 #include "oracle.h"
 #include <string.h>

@@ -15,6 +15,7 @@
 #include "oracle.h"
 #include "r1cs.h"
 
+#include <limits.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -23,9 +24,9 @@ int zko_cloak_prove(const uint64_t *q, const uint8_t *flavors, size_t n_in, size
 int zko_cloak_verify(const uint8_t *commitments, size_t n_in, size_t n_out, const uint8_t *proof, size_t proof_len,
                      const uint8_t r_bytes[64]);
 
-#define TXV_MAX_STACK 256
-#define TXV_MAX_LOG 160
-#define TXV_MAX_KEYS 64
+/* No capacity of this restatement is a rule of the format: the stack, the log and the key list grow with the program
+ * (until round 3 they were fixed arrays -- 256 items, 160 log entries, 64 keys -- and a longer transaction was reported
+ * INVALID, which the product's VM, having no such limits, did not do: ADVICE r03). */
 
 enum { IT_DATA = 0, IT_VAR = 1, IT_VALUE = 2, IT_CONTRACT = 3 };
 typedef struct { int kind; const uint8_t *p; size_t n; uint8_t own[64]; } item;   /* a value lives in own[] (p unused), everything else points into the transaction */
@@ -85,11 +86,11 @@ static void root_of(const entry *e, size_t lo, size_t hi, uint8_t out[32]) {
 
 /* walks a serialized contract; returns the number of payload items or -1 (malformed) / -2 (outside the subset);
  * items (optional) receive the payload in order */
-static int walk_contract(const uint8_t *p, size_t n, item *items, int cap) {
+static long walk_contract(const uint8_t *p, size_t n, item *items, long cap) {
   if (n < 68) return -1;
   uint32_t k = le32(p + 64);
   size_t pos = 68;
-  int count = 0;
+  long count = 0;
   for (uint32_t i = 0; i < k; ++i) {
     if (pos >= n) return -1;
     uint8_t type = p[pos++];
@@ -121,13 +122,32 @@ typedef struct {
   uint8_t commitments[64 * 128];
   const uint8_t *proof; size_t proof_len;
   const uint8_t *sig;
-  size_t n_keys;
-  uint8_t keys[TXV_MAX_KEYS][32];
+  size_t n_keys, keys_cap;
+  uint8_t (*keys)[32];
 } tx_run;
+static void tx_run_free(tx_run *r) { if (r) { free(r->keys); free(r); } }
 
-/* 0 ok, 1 invalid, 2 unsupported */
-static int run_tx(const uint8_t *tx, size_t len, tx_run *out) {
-  memset(out, 0, sizeof *out);
+typedef struct { item *stack; size_t sp, stack_cap; entry *log; size_t nlog, log_cap; item *payload; } vm_mem;
+static int stack_room(vm_mem *v, size_t more) {
+  if (v->sp + more <= v->stack_cap) return 1;
+  size_t cap = v->stack_cap ? v->stack_cap : 64;
+  while (cap < v->sp + more) cap *= 2;
+  item *p = realloc(v->stack, cap * sizeof(item));
+  if (!p) return 0;
+  v->stack = p; v->stack_cap = cap;
+  return 1;
+}
+static int log_room(vm_mem *v) {
+  if (v->nlog < v->log_cap) return 1;
+  size_t cap = v->log_cap ? 2 * v->log_cap : 64;
+  entry *p = realloc(v->log, cap * sizeof(entry));
+  if (!p) return 0;
+  v->log = p; v->log_cap = cap;
+  return 1;
+}
+
+/* 0 ok, 1 invalid, 2 unsupported, 3 out of memory (never seen by the tests: reported as such, not as a verdict) */
+static int run_vm(const uint8_t *tx, size_t len, tx_run *out, vm_mem *v) {
   if (len < 28) return 1;
   out->version = le64(tx); out->mintime = le64(tx + 8); out->maxtime = le64(tx + 16);
   size_t pos = 24;
@@ -142,10 +162,13 @@ static int run_tx(const uint8_t *tx, size_t len, tx_run *out) {
   if (out->version != 1) return 2;
   if (out->mintime > out->maxtime) return 1;
 
-  static __thread item stack[TXV_MAX_STACK];
-  static __thread entry log[TXV_MAX_LOG];
-  int sp = 0, nlog = 0, cloaked = 0, have_anchor = 0;
+#define stack (v->stack)
+#define log (v->log)
+#define sp (v->sp)
+#define nlog (v->nlog)
+  int cloaked = 0, have_anchor = 0;
   uint8_t anchor[32];
+  if (!log_room(v)) return 3;
   log[nlog].kind = 0; log[nlog].a = out->version; log[nlog].b = out->mintime; log[nlog].c = out->maxtime; ++nlog;
   size_t pc = 0;
   while (pc < plen) {
@@ -155,7 +178,8 @@ static int run_tx(const uint8_t *tx, size_t len, tx_run *out) {
       case 0x00:
         if (plen - pc < 4) return 1;
         n = le32(prog + pc); pc += 4;
-        if (plen - pc < n || sp >= TXV_MAX_STACK) return 1;
+        if (plen - pc < n) return 1;
+        if (!stack_room(v, 1)) return 3;
         stack[sp].kind = IT_DATA; stack[sp].p = prog + pc; stack[sp].n = n; ++sp;
         pc += n;
         break;
@@ -166,16 +190,17 @@ static int run_tx(const uint8_t *tx, size_t len, tx_run *out) {
       case 0x03:
         if (plen - pc < 4) return 1;
         k = le32(prog + pc); pc += 4;
-        if (k >= (uint32_t)sp || sp >= TXV_MAX_STACK) return 1;
+        if (k >= sp) return 1;
+        if (!stack_room(v, 1)) return 3;
         if (stack[sp - 1 - k].kind == IT_VALUE || stack[sp - 1 - k].kind == IT_CONTRACT) return 1;
         stack[sp] = stack[sp - 1 - k]; ++sp;
         break;
       case 0x04: {
         if (plen - pc < 4) return 1;
         k = le32(prog + pc); pc += 4;
-        if (k >= (uint32_t)sp) return 1;
+        if (k >= sp) return 1;
         item t = stack[sp - 1 - k];
-        for (int i = sp - 1 - (int)k; i < sp - 1; ++i) stack[i] = stack[i + 1];
+        for (size_t i = sp - 1 - k; i < sp - 1; ++i) stack[i] = stack[i + 1];
         stack[sp - 1] = t;
         break;
       }
@@ -190,7 +215,7 @@ static int run_tx(const uint8_t *tx, size_t len, tx_run *out) {
         if (m == 0 || n == 0 || m > 64 || n > 64) return 2;
         if ((size_t)sp < (size_t)m + 2 * (size_t)n) return 1;
         /* stack, bottom to top: value_0 .. value_{m-1}, q_0, f_0, .., q_{n-1}, f_{n-1} */
-        int base = sp - (int)(m + 2 * n);
+        size_t base = sp - (m + 2 * (size_t)n);
         for (uint32_t i = 0; i < m; ++i) {
           if (stack[base + i].kind != IT_VALUE) return 1;
           memcpy(out->commitments + 64 * i, stack[base + i].own, 64);
@@ -201,6 +226,7 @@ static int run_tx(const uint8_t *tx, size_t len, tx_run *out) {
         }
         out->n_in = m; out->n_out = n;
         sp = base;
+        if (!stack_room(v, n)) return 3;
         for (uint32_t j = 0; j < n; ++j) {
           stack[sp].kind = IT_VALUE;
           memcpy(stack[sp].own, out->commitments + 64 * (m + j), 64);
@@ -212,9 +238,10 @@ static int run_tx(const uint8_t *tx, size_t len, tx_run *out) {
       }
       case 0x1b: {
         if (sp == 0 || stack[sp - 1].kind != IT_DATA) return 1;
-        int cnt = walk_contract(stack[sp - 1].p, stack[sp - 1].n, NULL, TXV_MAX_STACK);
+        long cnt = walk_contract(stack[sp - 1].p, stack[sp - 1].n, NULL, LONG_MAX);
         if (cnt == -2) return 2;
-        if (cnt < 0 || nlog >= TXV_MAX_LOG) return 1;
+        if (cnt < 0) return 1;
+        if (!log_room(v)) return 3;
         log[nlog].kind = 1;
         cid(stack[sp - 1].p, stack[sp - 1].n, log[nlog].id);
         memcpy(anchor, log[nlog].id, 32);
@@ -227,17 +254,19 @@ static int run_tx(const uint8_t *tx, size_t len, tx_run *out) {
         if (plen - pc < 4) return 1;
         k = le32(prog + pc); pc += 4;
         if ((size_t)sp < (size_t)k + 1) return 1;
-        if (stack[sp - 1].kind != IT_DATA || stack[sp - 1].n != 32 || !have_anchor || nlog >= TXV_MAX_LOG) return 1;
+        if (stack[sp - 1].kind != IT_DATA || stack[sp - 1].n != 32 || !have_anchor) return 1;
+        if (!log_room(v)) return 3;
         const uint8_t *pred = stack[sp - 1].p;
         --sp;
         size_t total = 68;
         for (uint32_t i = 0; i < k; ++i) {
-          const item *it = &stack[sp - (int)k + (int)i];
+          const item *it = &stack[sp - k + i];
           if (it->kind == IT_VALUE) total += 65;
           else if (it->kind == IT_DATA) total += 5 + it->n;
           else return 1;
         }
         uint8_t *ser = malloc(total);
+        if (!ser) return 3;
         uint8_t fresh[32];
         ratchet(anchor, fresh);
         memcpy(anchor, fresh, 32);
@@ -246,7 +275,7 @@ static int run_tx(const uint8_t *tx, size_t len, tx_run *out) {
         put32(ser + 64, k);
         size_t w = 68;
         for (uint32_t i = 0; i < k; ++i) {
-          const item *it = &stack[sp - (int)k + (int)i];
+          const item *it = &stack[sp - k + i];
           if (it->kind == IT_VALUE) { ser[w++] = 0x02; memcpy(ser + w, it->own, 64); w += 64; }
           else { ser[w++] = 0x00; put32(ser + w, (uint32_t)it->n); w += 4; memcpy(ser + w, it->p, it->n); w += it->n; }
         }
@@ -254,20 +283,29 @@ static int run_tx(const uint8_t *tx, size_t len, tx_run *out) {
         cid(ser, total, log[nlog].id);
         ++nlog;
         free(ser);
-        sp -= (int)k;
+        sp -= k;
         break;
       }
       case 0x20: {
-        if (sp == 0 || stack[sp - 1].kind != IT_CONTRACT || out->n_keys >= TXV_MAX_KEYS) return 1;
+        if (sp == 0 || stack[sp - 1].kind != IT_CONTRACT) return 1;
         const uint8_t *ser = stack[sp - 1].p;
         size_t sn = stack[sp - 1].n;
         --sp;
-        item payload[64];
-        int cnt = walk_contract(ser, sn, payload, 64);
-        if (cnt < 0 || sp + cnt > TXV_MAX_STACK) return 1;
+        long cnt = walk_contract(ser, sn, NULL, LONG_MAX);      /* count first, then read into room made for it */
+        if (cnt < 0) return 1;
+        free(v->payload);
+        v->payload = malloc(((size_t)cnt + 1) * sizeof(item));
+        if (!v->payload || !stack_room(v, (size_t)cnt)) return 3;
+        walk_contract(ser, sn, v->payload, cnt);
+        if (out->n_keys == out->keys_cap) {
+          size_t cap = out->keys_cap ? 2 * out->keys_cap : 16;
+          void *p = realloc(out->keys, cap * 32);
+          if (!p) return 3;
+          out->keys = p; out->keys_cap = cap;
+        }
         memcpy(out->keys[out->n_keys++], ser + 32, 32);
-        for (int i = 0; i < cnt; ++i) {
-          stack[sp] = payload[i];
+        for (long i = 0; i < cnt; ++i) {
+          stack[sp] = v->payload[i];
           ++sp;
         }
         break;
@@ -279,8 +317,20 @@ static int run_tx(const uint8_t *tx, size_t len, tx_run *out) {
   if (sp != 0) return 1;
   if (!cloaked) return 2;
   if (out->n_keys == 0) return 1;
-  root_of(log, 0, (size_t)nlog, out->txid);
+  root_of(log, 0, nlog, out->txid);
   return 0;
+#undef stack
+#undef log
+#undef sp
+#undef nlog
+}
+static int run_tx(const uint8_t *tx, size_t len, tx_run *out) {
+  vm_mem v;
+  memset(&v, 0, sizeof v);
+  memset(out, 0, sizeof *out);
+  int rc = run_vm(tx, len, out, &v);
+  free(v.stack); free(v.log); free(v.payload);
+  return rc;
 }
 
 /* MuSig factors and the aggregated key; 0 when a key does not decode */
@@ -316,7 +366,7 @@ int zko_tx_id(const uint8_t *tx, size_t len, uint8_t txid[32], size_t *n_in, siz
   tx_run *r = malloc(sizeof *r);
   int rc = run_tx(tx, len, r);
   if (rc == 0) { memcpy(txid, r->txid, 32); if (n_in) *n_in = r->n_in; if (n_out) *n_out = r->n_out; }
-  free(r);
+  tx_run_free(r);
   return rc;
 }
 
@@ -324,8 +374,8 @@ int zko_tx_id(const uint8_t *tx, size_t len, uint8_t txid[32], size_t *n_in, siz
 int zko_tx_verify(const uint8_t *tx, size_t len, const uint8_t r_bytes[64]) {
   tx_run *r = malloc(sizeof *r);
   int rc = run_tx(tx, len, r);
-  if (rc) { free(r); return rc; }
-  sc factors[TXV_MAX_KEYS], s, c;
+  if (rc) { tx_run_free(r); return rc; }
+  sc *factors = malloc((r->n_keys + 1) * sizeof(sc)), s, c;
   ge X, R, B, lhs, rhs, cX;
   int ok = aggregate(r, factors, &X) && sc_from_canonical_bytes(&s, r->sig + 32) && ristretto_decode(&R, r->sig);
   if (ok) {
@@ -339,7 +389,8 @@ int zko_tx_verify(const uint8_t *tx, size_t len, const uint8_t r_bytes[64]) {
     ok = ge_ristretto_eq(&lhs, &rhs);
   }
   if (ok) ok = zko_cloak_verify(r->commitments, r->n_in, r->n_out, r->proof, r->proof_len, r_bytes);
-  free(r);
+  free(factors);
+  tx_run_free(r);
   return ok ? 0 : 1;
 }
 
@@ -411,7 +462,7 @@ size_t zko_tx_wrap_payment(size_t n_in, size_t n_out, const uint8_t *com, const 
   tx_run *run = malloc(sizeof *run);
   size_t ret = 0;
   if (run_tx(out, total, run) == 0 && run->n_keys == n_in) {
-    sc factors[TXV_MAX_KEYS], xsum, nonce, c, t;
+    sc factors[16], xsum, nonce, c, t;       /* n_in <= 16 here */
     ge X, R;
     if (aggregate(run, factors, &X)) {
       uint8_t wide[64], Xenc[32];
@@ -429,7 +480,7 @@ size_t zko_tx_wrap_payment(size_t n_in, size_t n_out, const uint8_t *com, const 
       ret = total;
     }
   }
-  free(run); free(prog);
+  tx_run_free(run); free(prog);
   return ret;
 }
 

@@ -53,3 +53,23 @@ def test_product_never_touches_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 for needle in ("liboracle", "from oracle", "import oracle", "oracle/_build", "oracle.h"):
                     assert needle not in text, (f, needle)
+
+
+def test_collective_mock_hook_is_refused_unless_the_process_asked_for_test_hooks():
+    """zkgpu_debug_comm_mock is in the shipped ABI; it must do nothing in a process that did not set
+    ZKGPU_TEST_HOOKS=1 before loading the library (fresh interpreters: the answer is read once per process)."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from zkvm_amd import native; lib = native.load_library(); "
+            "print(int(lib.zkgpu_debug_comm_mock(None, 0, None, 0)))" % ROOT)
+    out = {}
+    for hooks in ("", "1"):
+        env = dict(os.environ)
+        env.pop("ZKGPU_TEST_HOOKS", None)
+        if hooks:
+            env["ZKGPU_TEST_HOOKS"] = hooks
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        out[hooks] = int(r.stdout.strip().splitlines()[-1])
+    assert out[""] == -1          # ZKGPU_EINVAL: refused
+    assert out["1"] == 0          # switched (to RCCL, which it already was): no all-gather served yet

@@ -241,6 +241,26 @@ def test_msm_batch_values_vs_oracle(ctx, oracle):
     assert bits(ok, len(sizes)) == [1, 1, 1, 0, 1, 1, 1]
 
 
+def test_many_small_rows_uniform_and_with_one_very_long_row(ctx, oracle):
+    """zkgpu_msm_batch with >= 64 rows of a few terms takes the per-point-table path (one workgroup per row); a batch whose
+    AVERAGE row is short but which holds one row of 3000 terms must not (the longest row is bounded too, such a
+    batch goes through the bucket pipeline).  Both against the oracle, value by value."""
+    for tag, sizes in (("u", [3] * 40 + [1, 0, 7, 2] * 10), ("s", [2] * 100 + [3000] + [4] * 27)):
+        sc, pt, offs, want = b"", b"", [0], []
+        for i, n in enumerate(sizes):
+            s, p = scalars("%s%d" % (tag, i), n), points(oracle, "%s%d" % (tag, i), n, distinct=min(n, 16) or 1)[: 32 * n]
+            rc, enc, _ = oracle.msm(s, p)
+            assert rc == 0
+            want.append(enc)
+            sc += s
+            pt += p
+            offs.append(offs[-1] + n)
+        assert offs[-1] <= 64 * len(sizes)                      # the average alone would choose the small path for both
+        out, ok = ctx.msm_batch(sc, pt, offs)
+        assert [out[32 * i: 32 * i + 32] for i in range(len(sizes))] == want, tag
+        assert bits(ok, len(sizes)) == [1] * len(sizes)
+
+
 @pytest.mark.parametrize("w", [4, 7, 9, 16])
 def test_fixed_base_tables_equal_generic_path(ctx, oracle, w):
     """Generator terms summed out of the fixed-base window tables must give the same accept bits as the

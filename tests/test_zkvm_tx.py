@@ -104,6 +104,83 @@ def test_transactions_outside_the_subset_are_reported_not_rejected(host, oracle)
         assert prepare(host, bad)[0] == want
 
 
+def _with_program(tx, prog):
+    plen = struct.unpack("<I", tx[24:28])[0]
+    return tx[:24] + struct.pack("<I", len(prog)) + prog + tx[28 + plen:]
+
+
+def test_transaction_with_more_than_65536_hash_jobs(host, oracle):
+    """hash-job slots were 16-bit and a structurally valid transaction of ~700 KB wrapped them (a heap
+    overflow on the slot memory, aliased slots in the transaction ID).  17 000 empty outputs after a payment: two contract-id
+    chains, a Merkle leaf and a node each -- about 68 000 jobs.  The transaction ID must be the oracle's (whose log, stack and
+    key list grow with the program since this round: no capacity is a rule of the format), one at a time and in lockstep."""
+    tx = payment(oracle, 1, 1, 4242)
+    plen = struct.unpack("<I", tx[24:28])[0]
+    prog = tx[28: 28 + plen]
+    reps = 17000
+    tail = b"".join(b"\x00" + struct.pack("<I", 32) + hashlib.sha256(b"pred %d" % i).digest() + b"\x1c" + struct.pack("<I", 0) for i in range(reps))
+    big = _with_program(tx, prog + tail)
+    assert len(big) > 600_000
+    want_rc, want_id, wa, wb = oracle.tx_id(big)
+    assert (want_rc, wa, wb) == (0, 1, 1)
+    assert want_id != oracle.tx_id(tx)[1]
+    rc, txid, a, b, com, ss, sp, po, pl = prepare(host, big)
+    assert (rc, txid, a, b) == (0, want_id, 1, 1)
+    assert po + pl == len(big)
+    # a shorter relative of it, eight in lockstep (AVX-512 where the CPU has it) against one at a time: 9 000 outputs each,
+    # the ids of different transactions in one group
+    txs = []
+    for q in range(8):
+        t = payment(oracle, 1, 1, 4300 + q)
+        pl_q = struct.unpack("<I", t[24:28])[0]
+        txs.append(_with_program(t, t[28: 28 + pl_q] + tail[: 42 * 9000]))
+    blob = b"".join(txs)
+    offs = (C.c_uint64 * 9)()
+    for i, t in enumerate(txs):
+        offs[i + 1] = offs[i] + len(t)
+    agg = hashlib.shake_256(b"agg").digest(32 * 8)
+    got = {}
+    for mode in (0, 1):
+        st, ids, dig = C.create_string_buffer(8), C.create_string_buffer(32 * 8), C.create_string_buffer(64 * 8)
+        host.zkhost_tx_prepare_group(blob, offs, C.c_size_t(8), mode, agg, st, ids, dig)
+        got[mode] = (st.raw, ids.raw, dig.raw)
+    assert got[0] == got[1] and got[0][0] == bytes(8)
+    for q in (0, 5):
+        assert oracle.tx_id(txs[q])[1] == got[0][1][32 * q: 32 * q + 32]
+
+
+def test_long_programs_beyond_the_old_fixed_capacities_agree_with_the_oracle(host, oracle):
+    """More than 256 stack items, more than 160 log entries, more than 64 payload items of a signed contract, a contract
+    string duplicated and spent many times (more than 64 keys): verdict and transaction ID as the oracle's."""
+    tx = payment(oracle, 2, 2, 99)
+    plen = struct.unpack("<I", tx[24:28])[0]
+    prog = tx[28: 28 + plen]
+    push = lambda b: b"\x00" + struct.pack("<I", len(b)) + b                 # noqa: E731
+    drop, inp, signtx = b"\x02", b"\x1b", b"\x20"
+    dup = lambda k: b"\x03" + struct.pack("<I", k)                           # noqa: E731
+    out = lambda k: b"\x1c" + struct.pack("<I", k)                           # noqa: E731
+    pred = prog[5 + 32: 5 + 64]                       # the first input's key: predicates that sign must decode
+    # (a) 400 strings on the stack at once, then dropped
+    a = prog + push(b"x") * 400 + drop * 400
+    # (b) 300 outputs of no items: 301 log entries beyond the payment's
+    b = prog + (push(pred) + out(0)) * 300
+    # (c) a contract with 100 data items, spent: its payload comes back onto the stack, and leaves in one output:100
+    contract = hashlib.sha256(b"anchor").digest() + pred + struct.pack("<I", 100) + b"".join(b"\x00" + struct.pack("<I", 3) + b"abc" for _ in range(100))
+    c = prog + push(contract) + inp + signtx + push(pred) + out(100)
+    # (d) one contract string spent 70 times: 70 more keys, 70 inputs
+    small = hashlib.sha256(b"anchor2").digest() + pred + struct.pack("<I", 0)
+    d = prog + push(small) + dup(0) * 69 + (inp + signtx) * 70
+    # (e) the same with a payload item left on the stack at the end: invalid in both
+    e = prog + push(contract) + inp + signtx
+    for name, p, want in (("a", a, 0), ("b", b, 0), ("c", c, 0), ("d", d, 0), ("e", e, 1)):
+        t = _with_program(tx, p)
+        rc, txid, wa, wb = oracle.tx_id(t)
+        got = prepare(host, t)
+        assert rc == want and got[0] == want, name
+        if want == 0:
+            assert got[1] == txid and (got[2], got[3]) == (wa, wb) == (2, 2), name
+
+
 def test_committed_transaction_fixture_is_what_the_oracle_accepts(host, oracle):
     """tests/golden/tx_2x2_1024_wrappers.bin (+ the committed cloak proofs): a sample verifies under the oracle, and the
     product's host half reads the same transaction IDs out of all 1024."""

@@ -101,6 +101,7 @@ struct zkgpu_comm {
   zkgpu_ctx* ctx = nullptr;
   int rank = 0, world = 1;
   ncclComm_t comm = nullptr;
+  const void* api = nullptr;                            // RcclApi*: the function table this communicator was made with, for its whole life
   hipStream_t stream = nullptr;
   // exchange buffers of a fixed size, made with the communicator: no allocation -- nothing that can fail on ONE rank --
   // stands between a call and its collective (slot = bytes one rank contributes, at most COMM_MAX_SLOT)
@@ -164,17 +165,12 @@ ncclResult_t mock_all_gather(const void* send, void* recv, size_t bytes, ncclDat
 ncclResult_t mock_comm_destroy(ncclComm_t) { return ncclSuccess; }
 const char* mock_error_string(ncclResult_t) { return "mock collective error"; }
 
-RcclApi& rccl() {
-  static RcclApi api, mock;
-  static std::once_flag once, once_mock;
-  if (g_comm_mock.on) {
-    std::call_once(once_mock, [] {
-      mock.handle = (void*)&g_comm_mock;
-      mock.GetUniqueId = mock_get_unique_id; mock.CommInitRank = mock_comm_init_rank; mock.AllGather = mock_all_gather;
-      mock.CommDestroy = mock_comm_destroy; mock.GetErrorString = mock_error_string;
-    });
-    return mock;
-  }
+// The function table a communicator uses is chosen ONCE, when it is created, and stays with it (zkgpu_comm::api): the
+// switch of the test hook is read under its lock at that moment only, so toggling it later cannot route a live
+// communicator's all-gather or its destruction to the other table.
+RcclApi& rccl_real() {
+  static RcclApi api;
+  static std::once_flag once;
   std::call_once(once, [] {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -189,6 +185,28 @@ RcclApi& rccl() {
     if (!api.ok()) api.error = "RCCL library lacks an expected symbol";
   });
   return api;
+}
+RcclApi& rccl_mock() {
+  static RcclApi mock;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    mock.handle = (void*)&g_comm_mock;
+    mock.GetUniqueId = mock_get_unique_id; mock.CommInitRank = mock_comm_init_rank; mock.AllGather = mock_all_gather;
+    mock.CommDestroy = mock_comm_destroy; mock.GetErrorString = mock_error_string;
+  });
+  return mock;
+}
+const RcclApi& comm_api(const zkgpu_comm* cm) { return *(const RcclApi*)cm->api; }
+RcclApi& rccl_for_new_comm() {
+  bool mocked;
+  { std::lock_guard<std::mutex> lk(g_comm_mock_mu); mocked = g_comm_mock.on; }
+  return mocked ? rccl_mock() : rccl_real();
+}
+// The hook exists in the shipped library only for processes that ask for it BEFORE they load it: a deployed verifier never
+// has the variable set, and zkgpu_debug_comm_mock refuses.
+bool test_hooks_enabled() {
+  static const bool on = [] { const char* e = getenv("ZKGPU_TEST_HOOKS"); return e && e[0] == '1'; }();
+  return on;
 }
 
 // number of terms of the verification multiscalar multiplication of one cloak statement: the weight
@@ -208,7 +226,9 @@ uint64_t cloak_msm_terms(uint32_t n_in, uint32_t n_out) {
 // transactions (InvalidGeneratorsLength / a VM error) and so does the caller, one by one; that answer is cached.
 // *rc != ZKGPU_OK: the plan could not be made THIS time (out of device memory, a HIP error): nothing is cached, and the
 // caller fails its block or ticket with that error -- a transient fault must not turn into "the proof is invalid".
-zkgpu_cloak_plan* verifier_plan(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, int* rc) {
+// May run on the staging thread of zkgpu_tx_verify_batch: the error text goes to `err` (the caller's, who knows which lock
+// guards v->last_error), never to the verifier from here.
+zkgpu_cloak_plan* verifier_plan(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, int* rc, std::string* err) {
   *rc = ZKGPU_OK;
   std::lock_guard<std::mutex> plk(v->plans_mu);
   const auto key = std::make_pair(n_in, n_out);
@@ -216,7 +236,7 @@ zkgpu_cloak_plan* verifier_plan(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out
   if (it != v->plans.end()) return it->second;
   zkgpu_cloak_plan* p = nullptr;
   const int r = zkgpu_cloak_plan_create(v->root, n_in, n_out, v->gens_capacity, &p);
-  if (r != ZKGPU_OK && r != ZKGPU_EINVAL) { *rc = r; v->last_error = zkgpu_last_error(v->root); return nullptr; }
+  if (r != ZKGPU_OK && r != ZKGPU_EINVAL) { *rc = r; if (err) *err = zkgpu_last_error(v->root); return nullptr; }
   if (r != ZKGPU_OK) p = nullptr;
   v->plans[key] = p;
   return p;
@@ -370,8 +390,8 @@ int txblock_stage_host(zkgpu_verifier* v, size_t batch, const TxSource* src, con
         zkgpu_txblock::Group g;
         g.n_in = src[i].n_in; g.n_out = src[i].n_out; g.proof_len = (size_t)src[i].proof_len;
         int prc = ZKGPU_OK;
-        g.plan = verifier_plan(v, g.n_in, g.n_out, &prc);
-        if (prc != ZKGPU_OK) { *err = zkgpu_last_error(v->root); return prc; }
+        g.plan = verifier_plan(v, g.n_in, g.n_out, &prc, err);
+        if (prc != ZKGPU_OK) return prc;
         if (g.plan && !proof_len_fits(g.plan->shape, g.proof_len)) g.plan = nullptr;   // wrong length for the statement
         g.com_off = g.proof_off = g.r_off = 0;
         it = where.emplace(key, b->groups.size()).first;
@@ -684,7 +704,9 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
     }
     zkgpu_ctx* L = v->lanes[(size_t)lane];
     int rc = ZKGPU_OK;
-    zkgpu_cloak_plan* plan = verifier_plan(v, head->n_in, head->n_out, &rc);   // rc != OK: no plan THIS time -> the tickets fail with it
+    std::string plan_err;
+    zkgpu_cloak_plan* plan = verifier_plan(v, head->n_in, head->n_out, &rc, &plan_err);   // rc != OK: no plan THIS time -> the tickets fail with it
+    if (rc != ZKGPU_OK) v->last_error = plan_err;                                          // (v->mu held)
     const void *p_com = pick[0]->d_com, *p_proofs = pick[0]->d_proofs, *p_r = pick[0]->d_r;
     if (plan && proof_len_fits(plan->shape, head->proof_len) && pick.size() > 1) {
       std::lock_guard<std::recursive_mutex> lk(L->mu);
@@ -836,6 +858,7 @@ int zkgpu_shard_cuts(size_t batch, const uint32_t* n_in, const uint32_t* n_out, 
 // then created with is overwritten by what that rank really sends); world = 0 switches back to RCCL.  Returns the number
 // of all-gathers the mock has served so far.
 long long zkgpu_debug_comm_mock(zkgpu_ctx* ctx, int world, const uint8_t* peer_slots, size_t slot_bytes) {
+  if (!test_hooks_enabled()) return ZKGPU_EINVAL;        // (ZKGPU_TEST_HOOKS=1 in the environment when the library was loaded)
   std::lock_guard<std::mutex> lk(g_comm_mock_mu);
   CommMock& m = g_comm_mock;
   if (world <= 0) { m.on = false; return (long long)m.gathers; }
@@ -851,7 +874,7 @@ long long zkgpu_debug_comm_mock(zkgpu_ctx* ctx, int world, const uint8_t* peer_s
 int zkgpu_comm_unique_id(uint8_t id[ZKGPU_COMM_ID_BYTES]) {
   if (!id) return ZKGPU_EINVAL;
   static_assert(sizeof(ncclUniqueId) == ZKGPU_COMM_ID_BYTES, "unique id size");
-  RcclApi& api = rccl();
+  RcclApi& api = rccl_for_new_comm();
   if (!api.ok()) return ZKGPU_ENOCOMM;
   ncclUniqueId uid;
   if (api.GetUniqueId(&uid) != ncclSuccess) return ZKGPU_ENOCOMM;
@@ -865,8 +888,9 @@ int zkgpu_comm_create(zkgpu_ctx* ctx, int rank, int world, const uint8_t id[ZKGP
   std::unique_ptr<zkgpu_comm> cm(new zkgpu_comm());
   cm->ctx = ctx; cm->rank = rank; cm->world = world;
   if (world > 1 || id) {
-    RcclApi& api = rccl();
+    RcclApi& api = rccl_for_new_comm();
     if (!api.ok()) { ctx->last_error = api.error; return ZKGPU_ENOCOMM; }
+    cm->api = &api;
     DeviceGuard g(ctx->device);
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
@@ -897,7 +921,7 @@ int zkgpu_comm_create(zkgpu_ctx* ctx, int rank, int world, const uint8_t id[ZKGP
 void zkgpu_comm_destroy(zkgpu_comm* cm) {
   if (!cm) return;
   DeviceGuard g(cm->ctx->device);
-  if (cm->comm) (void)rccl().CommDestroy(cm->comm);
+  if (cm->comm) (void)comm_api(cm).CommDestroy(cm->comm);
   if (cm->stream) (void)hipStreamDestroy(cm->stream);
   if (cm->d_send) (void)hipFree(cm->d_send);
   if (cm->d_recv) (void)hipFree(cm->d_recv);
@@ -932,8 +956,8 @@ int zkgpu_comm_allgather(zkgpu_comm* cm, const uint8_t* local, size_t bytes, uin
     if (e != hipSuccess && rc == ZKGPU_OK) { c->last_error = std::string(what) + ": " + hipGetErrorString(e); rc = ZKGPU_EHIP; }
   };
   note(hipMemcpyAsync(cm->d_send, h, bytes, hipMemcpyHostToDevice, cm->stream), "zkgpu_comm_allgather: copy in");
-  const ncclResult_t r = rccl().AllGather(cm->d_send, cm->d_recv, bytes, ncclUint8, cm->comm, cm->stream);
-  if (r != ncclSuccess && rc == ZKGPU_OK) { c->last_error = std::string("ncclAllGather: ") + rccl().GetErrorString(r); rc = ZKGPU_ENOCOMM; }
+  const ncclResult_t r = comm_api(cm).AllGather(cm->d_send, cm->d_recv, bytes, ncclUint8, cm->comm, cm->stream);
+  if (r != ncclSuccess && rc == ZKGPU_OK) { c->last_error = std::string("ncclAllGather: ") + comm_api(cm).GetErrorString(r); rc = ZKGPU_ENOCOMM; }
   note(hipMemcpyAsync(h + COMM_MAX_SLOT, cm->d_recv, total, hipMemcpyDeviceToHost, cm->stream), "zkgpu_comm_allgather: copy out");
   {
     static const uint32_t poison = COMM_POISON;        // (pageable source of an async copy: staged by the runtime)
@@ -1053,6 +1077,7 @@ int msm_values_enqueue(zkgpu_ctx* c, const uint8_t* scalars, const uint8_t* poin
   job.d_dyn_offsets = (const uint64_t*)c->in_offsets.p;
   job.n_dyn = n;
   job.n_msm = (uint32_t)batch;
+  job.max_dyn_row = longest_row(offsets, batch);
   const int rc = batch_device_enqueue(c, job, true);
   if (rc != ZKGPU_OK) { c->split = zkgpu_ctx::SplitOp{}; return rc; }
   c->pending = true; c->pending_batch = batch;
@@ -1098,6 +1123,7 @@ int verify_ps_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, cons
   job.n_static = ns;
   job.d_static_rows = ps->rows;
   job.n_msm = (uint32_t)batch;
+  job.max_dyn_row = longest_row(dyn_offsets, batch);
   const int rc = (ps->table && ns) ? batch_device_tables_enqueue(c, job, ps) : batch_device_enqueue(c, job, false);
   if (rc != ZKGPU_OK) { c->split = zkgpu_ctx::SplitOp{}; return rc; }
   c->pending = true; c->pending_batch = batch;
@@ -1260,6 +1286,7 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
   std::vector<char> staged(n_chunks, 0), arena_free(n_chunks, 0), key_rows(n_seg, 0), keys_arrived(n_seg, 0);
   bool all_sigs_made = false, quit = false;
   std::vector<std::unique_ptr<TxSigStage>> sig_stages;
+  sig_stages.reserve(sig_plan.size());                   // the calling thread indexes it while the staging thread appends: it must never move
   size_t n_sig_stages = 0;
   double t_keys_host = 0, t_sig_host = 0, t_stage_host = 0;
   std::vector<size_t> live_all;                          // transactions the VM accepts, in call order (staging thread appends)

@@ -301,7 +301,13 @@ struct Job {
   const uint32_t* d_static_rows = nullptr;
   uint32_t n_msm = 1;
   const uint32_t* d_wellformed = nullptr;   // optional per-MSM flags ANDed into the accept bitmap
+  uint64_t max_dyn_row = ~0ull;             // longest row of dynamic terms, when the caller's offsets are in host memory (~0: not known)
 };
+inline uint64_t longest_row(const uint64_t* offsets, size_t batch) {
+  uint64_t m = 0;
+  for (size_t i = 0; i < batch; ++i) m = std::max(m, offsets[i + 1] - offsets[i]);
+  return m;
+}
 
 // Runs decompress .. window sums.  On return (stream not yet synchronised):
 //   c->window_sums / c->window_flags hold n_msm * n_windows extended points
@@ -558,9 +564,12 @@ int batch_device_enqueue(zkgpu_ctx* c, const Job& job, bool values) {
   c->split = zkgpu_ctx::SplitOp{1, B, values, c->stream};
   if (B == 0) return ZKGPU_OK;
   JobDesc jd;
-  if (!c->forced_w && job.n_static == 0 && job.n_dyn && job.n_dyn <= 64ull * B && B >= 64) {
+  if (!c->forced_w && job.n_static == 0 && job.n_dyn && job.n_dyn <= 64ull * B && B >= 64 && job.max_dyn_row <= 256) {
     // many SMALL multiscalar multiplications (a few terms each: aggregated keys, signature equations): per-point tables
-    // and one wavefront per row -- four launches, no global sort, no atomics -- instead of the bucket pipeline's seventeen
+    // and one wavefront per row -- four launches, no global sort, no atomics -- instead of the bucket pipeline's seventeen.
+    // EVERY row must be short, not just the average: one workgroup walks a row serially, and the tables are 1280 B per
+    // term -- a batch with one very long row among many short ones (or offsets this side cannot see: the _dev entry points)
+    // takes the bucket pipeline, which spreads a row over the chip
     hipStream_t s = c->stream;
     jd.w = 4; jd.n_windows = 64;
     c->last_w = 4;
@@ -1483,6 +1492,7 @@ int zkgpu_verify_batch(zkgpu_ctx* c, const uint8_t* scalars, const uint8_t* poin
   job.d_dyn_offsets = (const uint64_t*)c->in_offsets.p;
   job.n_dyn = n;
   job.n_msm = (uint32_t)batch;
+  job.max_dyn_row = longest_row(offsets, batch);
   int rc = batch_device(c, job, accept_bitmap);
   if (rc != ZKGPU_OK) memset(accept_bitmap, 0, (batch + 7) / 8);
   return rc;
@@ -2542,6 +2552,10 @@ int zkgpu_cloak_plan_create(zkgpu_ctx* c, uint32_t n_in, uint32_t n_out, size_t 
   p->gens_capacity = gens_capacity;
   try {
     p->host = PlanBuilder::build(n_in, n_out);     // the cloak gadget traced into a description, then the generic path
+  } catch (const std::bad_alloc&) {                // out of host memory THIS time: not "the shape can never be verified"
+    c->last_error = "out of host memory while tracing the cloak gadget";
+    delete p;
+    return ZKGPU_ENOMEM;
   } catch (const std::exception& e) {
     c->last_error = e.what();
     delete p;
@@ -3024,6 +3038,7 @@ int zkgpu_msm_batch(zkgpu_ctx* c, const uint8_t* scalars, const uint8_t* points,
   job.d_dyn_offsets = (const uint64_t*)c->in_offsets.p;
   job.n_dyn = n;
   job.n_msm = (uint32_t)batch;
+  job.max_dyn_row = longest_row(offsets, batch);
   int rc = batch_device(c, job, ok_bitmap, out);
   if (rc != ZKGPU_OK) { memset(out, 0, 32 * batch); memset(ok_bitmap, 0, (batch + 7) / 8); }
   return rc;

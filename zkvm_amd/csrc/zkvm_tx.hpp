@@ -114,18 +114,18 @@ struct HashPiece {
   enum Kind : uint8_t { Bytes = 0, Slot = 1, Imm = 2 };
   uint8_t label = L_CONT;        // != L_CONT: this piece opens a message of msg_len bytes in all
   uint8_t kind = Bytes;
-  uint16_t slot = 0;             // Slot: which
+  uint32_t slot = 0;             // Slot: which (32 bits: the number of hash jobs of a transaction is bounded by its length alone)
   uint32_t len = 0, msg_len = 0;
   uint32_t off = 0;              // Imm: offset into the plan's immediate pool
   const uint8_t* p = nullptr;    // Bytes: where
 };
-struct HashJob { uint8_t proto, chal_label, out_len; uint16_t out_slot; uint32_t first, count; };
+struct HashJob { uint8_t proto, chal_label, out_len; uint32_t out_slot; uint32_t first, count; };
 struct TxPlan {
   std::vector<HashJob> jobs;
   std::vector<HashPiece> pieces;
   std::vector<uint8_t> imm;
   std::vector<uint32_t> shape;   // everything that must agree for two plans to run in lockstep (no pointers, no contents)
-  uint16_t n_slots = 0;
+  uint32_t n_slots = 0;
   // only != 0xff: the plan keeps the jobs of that protocol alone -- whatever else the VM asks to be hashed is dropped as it
   // is written down (its slot numbers read 0 and are used by dropped jobs only): the keys-first pass of a call
   uint8_t only = 0xff;
@@ -136,16 +136,17 @@ struct TxPlan {
     if (dropping) return;
     jobs.push_back(HashJob{proto, 0, 0, 0, (uint32_t)pieces.size(), 0}); shape.push_back(0x4a000000u | proto);
   }
-  void piece(uint8_t label, uint8_t kind, const uint8_t* p, uint32_t len, uint32_t msg_len, uint16_t slot = 0, uint32_t off = 0) {
+  void piece(uint8_t label, uint8_t kind, const uint8_t* p, uint32_t len, uint32_t msg_len, uint32_t slot = 0, uint32_t off = 0) {
     if (dropping) return;
     HashPiece h; h.label = label; h.kind = kind; h.p = p; h.len = len; h.msg_len = msg_len; h.slot = slot; h.off = off;
     pieces.push_back(h);
-    shape.push_back(((uint32_t)label << 24) | ((uint32_t)kind << 16) | slot);
+    shape.push_back(((uint32_t)label << 24) | ((uint32_t)kind << 16));
+    shape.push_back(slot);
     shape.push_back(len);
     shape.push_back(msg_len);
   }
   void bytes(uint8_t label, const uint8_t* p, uint32_t len, uint32_t msg_len) { piece(label, HashPiece::Bytes, p, len, msg_len); }
-  void slot(uint8_t label, uint16_t s, uint32_t msg_len = 32) { piece(label, HashPiece::Slot, nullptr, 32, msg_len, s); }
+  void slot(uint8_t label, uint32_t s, uint32_t msg_len = 32) { piece(label, HashPiece::Slot, nullptr, 32, msg_len, s); }
   void immediate(uint8_t label, const uint8_t* b, uint32_t len, uint32_t msg_len) {
     if (dropping) return;
     const uint32_t off = (uint32_t)imm.size();
@@ -158,7 +159,7 @@ struct TxPlan {
     immediate(label, b, 8, 8);
   }
   // closes the job: its challenge (32 bytes, or 64 bytes reduced to a canonical scalar) goes to a new slot
-  uint16_t end(uint8_t chal_label, uint8_t out_len) {
+  uint32_t end(uint8_t chal_label, uint8_t out_len) {
     if (dropping) { dropping = false; return 0; }
     HashJob& j = jobs.back();
     j.chal_label = chal_label; j.out_len = out_len; j.out_slot = n_slots++;
@@ -229,9 +230,9 @@ ZK_X8 inline void run_plans_x8(const TxPlan* const P[8], uint8_t* const slots[8]
 struct LogEntry {
   enum Kind : uint8_t { Header, Input, Output } kind;
   uint64_t a = 0, b = 0, c = 0;
-  uint16_t id_slot = 0;
+  uint32_t id_slot = 0;
 };
-inline uint16_t plan_merkle(TxPlan& P, const LogEntry* e, size_t n) {
+inline uint32_t plan_merkle(TxPlan& P, const LogEntry* e, size_t n) {
   if (n == 0) { P.begin(P_TXID); return P.end(L_merkle_empty, 32); }
   if (n == 1) {
     P.begin(P_TXID);
@@ -244,7 +245,7 @@ inline uint16_t plan_merkle(TxPlan& P, const LogEntry* e, size_t n) {
   }
   size_t k = 1;
   while (2 * k < n) k *= 2;
-  const uint16_t l = plan_merkle(P, e, k), r = plan_merkle(P, e + k, n - k);
+  const uint32_t l = plan_merkle(P, e, k), r = plan_merkle(P, e + k, n - k);
   P.begin(P_TXID);
   P.slot(L_L, l);
   P.slot(L_R, r);
@@ -288,7 +289,7 @@ inline bool parse_contract(const uint8_t* p, size_t n, const uint8_t*& predicate
 // First half: parse, VM, and the PLAN of everything there is to hash (nothing is hashed yet).  The statement refers into
 // `tx` (proof bytes), the plan into `tx` and into st.commitments: neither may move until the plan has run.
 // txid_slot / a_slots: where the transaction ID and the MuSig coefficients will be found.
-struct TxSlots { uint16_t txid = 0; std::vector<uint16_t> a; std::vector<const uint8_t*> keys; const uint8_t* sig = nullptr; };
+struct TxSlots { uint32_t txid = 0; std::vector<uint32_t> a; std::vector<const uint8_t*> keys; const uint8_t* sig = nullptr; };
 inline void tx_structure(const uint8_t* tx, size_t len, TxStatement& st, TxPlan& P, TxSlots& out) {
   st.status = TX_INVALID; st.why = ""; st.n_in = st.n_out = 0; st.proof = nullptr; st.proof_len = 0;      // (field by field: the
   st.commitments.resize(0); st.sig_scalars.resize(0); st.sig_points.resize(0);                             //  inline buffers stay as they are)
@@ -322,7 +323,7 @@ inline void tx_structure(const uint8_t* tx, size_t len, TxStatement& st, TxPlan&
   LogEntry hdr; hdr.kind = LogEntry::Header; hdr.a = st.version; hdr.b = st.mintime; hdr.c = st.maxtime;
   log.push_back(hdr);
   bool have_anchor = false, cloaked = false;
-  uint16_t last_anchor = 0;              // slot
+  uint32_t last_anchor = 0;              // slot
   size_t pc = 0;
   auto imm32 = [&](uint32_t& v) { if (prog_len - pc < 4) return false; v = rd32(prog + pc); pc += 4; return true; };
   while (pc < prog_len) {
