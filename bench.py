@@ -24,8 +24,11 @@ bitmap (copied to the host).
 Launch:  python bench.py [--gpus N --steps K --warmup W] [--config 4]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
                 --master-port P bench.py --gpus N --steps K --warmup W [--config 4]
-One process per GPU; shards are independent (weak scaling); the only collective on the data path is
-the all-gather of the accept bitmaps.
+Both forms work for N > 1: started WITHOUT a launcher (WORLD_SIZE unset) `--gpus N` makes this process spawn N fresh
+rank processes itself (zkvm_amd/launch.py) before anything in it touches the GPU, relay rank 0's line and exit non-zero
+if any rank did.  One process per GPU; shards are independent (weak scaling); the only collective on the data path is
+the all-gather of the accept bitmaps (ncclAllGather behind zkgpu_comm_allgather_bitmap -- the ONLY RCCL communicator of
+a rank; barriers, the timing reduction and the id broadcast run over gloo on the host).
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (the dominant kernel of the step -- by
 summed solo kernel time -- against the HBM roofline the north-star names, the whole step against
@@ -45,13 +48,12 @@ import os
 # point, so it is.
 # (ranks made to SHARE one GPU -- the two-rank test mode -- share its queue slots too: 24 each is 48 on one device, which
 # then time-slices them: 0.44-0.7 M tx/s against 2.1 M with 8 each, measured)
-# (N > 1: two RCCL communicators -- torch's for the barrier and the timing reduction, the library's for the bitmaps -- bring
-# streams of their own; with 24 queues for ours the process would sit at the device's limit of queues that run side by
-# side, beyond which they are time-sliced (5 - 40 ms stalls).  16 is measured 0 - 2 % below 24 at N = 1
-# and has that margin.)
+# (N > 1, one rank per GPU: the control plane -- barrier, timing reduction, the 128-byte id broadcast -- runs over gloo on
+# the host, so the ONLY RCCL communicator of a rank is the library's own (zkgpu_comm): the process holds the streams of one
+# verifier and one communicator, as at N = 1, and asks for the same 24 queues.  Until round 3 torch's "nccl" group was a
+# second communicator per rank and the bench asked for 16 to leave it room.)
 _HWQ_PRESET = "GPU_MAX_HW_QUEUES" in os.environ
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8" if os.environ.get("ZKGPU_BENCH_SHARE_GPU")
-                      else "16" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8" if os.environ.get("ZKGPU_BENCH_SHARE_GPU") else "24")
 # stdout carries exactly ONE line, the JSON record: whatever libraries print there (RCCL's version banner, gloo's
 # connection chatter) is sent to stderr instead
 _JSON_OUT = os.fdopen(os.dup(1), "w")
@@ -458,6 +460,9 @@ def prover_microbench(ctx, gens, host_threads: int, batch: int = 2048, ctx2=None
 
 # ---- distributed plumbing ------------------------------------------------------------------------
 class World:
+    """One process per GPU.  Control plane (barrier, max over ranks, the 128-byte communicator id, the per-rank records)
+    over gloo on the host; the data path's one collective is the library's (zkgpu_comm, RCCL)."""
+
     def __init__(self, args):
         import torch
         self.torch = torch
@@ -466,25 +471,26 @@ class World:
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if self.world != args.gpus and self.world > 1:
             raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (self.world, args.gpus))
-        if args.gpus > 1 and self.world == 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        if args.gpus > 1 and self.world == 1:               # (main() spawns the ranks before it gets here)
+            raise SystemExit("--gpus %d needs %d rank processes" % (args.gpus, args.gpus))
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (libzkgpu has no CPU fallback)")
         # ZKGPU_BENCH_SHARE_GPU=1 (exercising the N > 1 code path on a 1-GPU box): every rank uses device 0 and the
         # bitmaps travel over gloo from host memory instead of RCCL (which refuses two ranks on one device)
         self.share_gpu = os.environ.get("ZKGPU_BENCH_SHARE_GPU") == "1"
+        if not self.share_gpu and self.world > torch.cuda.device_count():
+            raise SystemExit("%d ranks but %d GPUs visible (ZKGPU_BENCH_SHARE_GPU=1 puts every rank on device 0: a rehearsal, "
+                             "not a measurement)" % (self.world, torch.cuda.device_count()))
         self.local = 0 if self.share_gpu else local
         torch.cuda.set_device(self.local)
         self.dev = torch.device("cuda", self.local)
-        self.coll_dev = torch.device("cpu") if self.share_gpu else self.dev
+        self.coll_dev = torch.device("cpu")
         self.dist = None
         if self.world > 1:
+            import datetime
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if self.share_gpu:
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-            else:
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=datetime.timedelta(minutes=20))
             self.dist = dist
 
     def barrier(self):
@@ -495,16 +501,24 @@ class World:
     def max_over_ranks(self, x: float) -> float:
         if not self.dist:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.coll_dev)
+        t = self.torch.tensor([x], dtype=self.torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather_objects(self, mine):
+        """every rank's object, in rank order, on every rank (collective)"""
+        if not self.dist:
+            return [mine]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, mine)
+        return out
 
     def broadcast_bytes(self, b: bytes, n: int) -> bytes:
         if not self.dist:
             return b
-        t = self.torch.frombuffer(bytearray(b if self.rank == 0 else bytes(n)), dtype=self.torch.uint8).to(self.coll_dev)
+        t = self.torch.frombuffer(bytearray(b if self.rank == 0 else bytes(n)), dtype=self.torch.uint8)
         self.dist.broadcast(t, src=0)
-        return bytes(t.cpu().numpy().tobytes())
+        return bytes(t.numpy().tobytes())
 
     def describe_ranks(self):
         """per rank: the device it runs on, and the collective library's version -- so that a multi-GPU record says by
@@ -513,21 +527,29 @@ class World:
         p = torch.cuda.get_device_properties(self.local)
         mine = {"rank": self.rank, "device": self.local, "name": p.name, "gcn_arch": getattr(p, "gcnArchName", ""),
                 "pci_bus_id": "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0)),
-                "hbm_GiB": round(p.total_memory / 2**30, 1), "pid": os.getpid()}
+                "hbm_GiB": round(p.total_memory / 2**30, 1), "pid": os.getpid(),
+                "launched_by": os.environ.get("ZKGPU_LAUNCHED_BY", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "the caller")}
         try:
             mine["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception as e:                                  # noqa: BLE001
             mine["rccl_version"] = "unknown (%s)" % type(e).__name__
-        if not self.dist:
-            return [mine]
-        out = [None] * self.world
-        self.dist.all_gather_object(out, mine)
-        return out
+        return self.gather_objects(mine)
 
     def close(self):
         if self.dist:
             self.dist.barrier()
             self.dist.destroy_process_group()
+
+
+def rccl_roll_call(W, comm):
+    """What RCCL itself saw: every rank contributes its rank number through the library's communicator (a real
+    ncclAllGather when world > 1) and reports how many distinct ranks came back and the communicator's own world size."""
+    if comm is None:
+        return None
+    got = comm.allgather(W.rank.to_bytes(4, "little"))
+    seen = sorted({int.from_bytes(got[4 * i: 4 * i + 4], "little") for i in range(W.world)})
+    assert seen == list(range(W.world)), "the all-gather returned ranks %s in a world of %d" % (seen, W.world)
+    return {"rccl_ranks_seen": len(seen), "zkgpu_comm_world": int(comm.ctx.lib.zkgpu_comm_world(comm.h))}
 
 
 def common_line(args, W, value, elapsed, data, config):
@@ -777,6 +799,7 @@ def run_config2(args, W):
     t0 = time.perf_counter()
     host_time.update(submit=0.0, n=0)
     bm = timed(args.steps, base=0)
+    own_elapsed = time.perf_counter() - t0                     # this rank's own steps, before it waits for the others
     W.barrier()
     elapsed = time.perf_counter() - t0
     submit_ms = host_time["submit"] / max(host_time["n"], 1) * 1e3
@@ -784,6 +807,8 @@ def run_config2(args, W):
         c.profile(False)
     elapsed = W.max_over_ranks(elapsed)
     ranks_info = W.describe_ranks()
+    per_rank = W.gather_objects({"rank": rank, "tx_per_s": round(batch * args.steps / own_elapsed, 1), "ms": round(own_elapsed * 1e3, 3)})
+    roll_call = rccl_roll_call(W, shared_comm[0])
 
     if rank == 0:
         prof = profile_lanes(prof_ctxs)
@@ -807,7 +832,8 @@ def run_config2(args, W):
                             "calls_in_flight": min(args.tickets, args.steps) if bv is not None else len(ctxs), "group_size": args.group,
                             "merged_device_batches": ({"transactions": args.merge, "lanes": bv.lanes()} if bv is not None else None),
                             "distinct_step_inputs": n_sets, "exchange": exchange_name, "steps_per_exchange": gather_every if world > 1 else None,
-                            "ranks": ranks_info,
+                            "ranks": ranks_info, "per_rank": per_rank, "rccl": roll_call,
+                            "control_plane": "gloo (host)" if world > 1 else None,
                             "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "hw_queues_set_by": "caller" if _HWQ_PRESET else "bench.py, before the HIP runtime started",
                             "parallelism": "tx-sharded x%d, RCCL all-gather of accept bitmaps" % world})
         line["roofline"] = roofline_object(solo, launches, in_flight_ms, alg_dev, dev_batch, ms_per_dev_batch, table_bytes,
@@ -1092,10 +1118,13 @@ def run_config4(args, W):
     W.barrier()
     t0 = time.perf_counter()
     whole = steps(args.steps)
+    own_elapsed = time.perf_counter() - t0
     W.barrier()
     elapsed = W.max_over_ranks(time.perf_counter() - t0)
     assert whole == want
     ranks_info = W.describe_ranks()
+    per_rank = W.gather_objects({"rank": rank, "tx_per_s": round((hi - lo) * args.steps / own_elapsed, 1), "ms": round(own_elapsed * 1e3, 3)})
+    roll_call = rccl_roll_call(W, _comm)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -1134,7 +1163,8 @@ def run_config4(args, W):
                             "shard_tx": [b - a for a, b in parts], "shard_terms": shard_terms,
                             "generator_table_bits": args.table_bits, "gens_capacity": 512, "calls_in_flight": bv.lanes(), "blocks_in_flight": depth,
                             "chunk": args.chunk or 2048, "group_size": args.group,
-                            "exchange": exchange_name, "ranks": ranks_info,
+                            "exchange": exchange_name, "ranks": ranks_info, "per_rank": per_rank, "rccl": roll_call,
+                            "control_plane": "gloo (host)" if world > 1 else None,
                             "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                             "parallelism": "tx-sharded x%d" % world})
         line["roofline"] = roofline_object(solo, launches, {}, alg_step, hi - lo, ms_per_step, table_bytes,
@@ -1211,6 +1241,14 @@ def main():
         args.merge = DEFAULT_MERGE
     if args.inflight <= 0:
         args.inflight = 5 if args.tickets > 0 else (10 if args.config == 4 and args.blocks_in_flight > 1 else 6)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher above us: this process becomes one.  It has not imported torch and never touches the GPU; the ranks
+        # are fresh interpreters running this same command line (zkvm_amd/launch.py), rank 0's line is relayed as ours.
+        from zkvm_amd.launch import spawn_ranks
+        rc, codes = spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, out=_JSON_OUT, err=sys.stderr)
+        if rc != 0:
+            print("bench.py: rank exit codes %s" % codes, file=sys.stderr)
+        sys.exit(rc)
     W = World(args)
     (run_config2 if args.config == 2 else run_config4)(args, W)
 
