@@ -563,7 +563,7 @@ def common_line(args, W, value, elapsed, data, config):
 class StepSet:
     """One step's batch resident in HBM: commitments, proofs, verifier randomness (torch tensors) and the accept bitmap
     the construction implies."""
-    __slots__ = ("com", "proofs", "r", "want", "bits", "txs", "r_bytes")
+    __slots__ = ("com", "proofs", "r", "want", "bits", "txs", "r_bytes", "host")
 
 
 def make_exchange(W, ctx, cuts, always_comm=False, comm=None):
@@ -622,6 +622,8 @@ def run_config2(args, W):
         S.com, S.proofs, S.r = to_dev(b"".join(t[2] for t in txs)), to_dev(b"".join(t[3] for t in txs)), to_dev(r_bytes)
         S.bits, S.want = expected, bitmap_of(expected)
         S.txs, S.r_bytes = (txs, r_bytes) if sidx == 0 else (None, None)
+        # the same step in HOST memory for the host_memory leg (the first 64 steps: 1.4 MB each)
+        S.host = (b"".join(t[2] for t in txs), b"".join(t[3] for t in txs), r_bytes) if sidx < 64 and rank == 0 else None
         sets.append(S)
     txs, r_bytes = sets[0].txs, sets[0].r_bytes
     n_in, n_out = txs[0][0], txs[0][1]
@@ -737,6 +739,27 @@ def run_config2(args, W):
             t, j = q.popleft()
             bm = checked(bv.wait(t), j, gather)
         flush_exchange()
+        return bm
+
+    def run_tickets_host(n, base=0, depth=None):
+        # the same arrangement fed from HOST memory (zkgpu_verifier_submit / _submit_many): what a caller of Tx::verify has.
+        # Step sets 0..63 (their host copies), cycled.
+        depth = depth or args.tickets
+        q, bm = collections.deque(), None
+        first = min(n, depth)
+        idx = [(base + i) % 64 for i in range(first)]
+        tk = bv.submit_many(n_in, n_out, batch, [sets[j].host[0] for j in idx], [sets[j].host[1] for j in idx], proof_len,
+                            [sets[j].host[2] for j in idx])
+        q.extend(zip(tk, idx))
+        for i in range(first, n):
+            if len(q) >= depth:
+                t, j = q.popleft()
+                bm = checked(bv.wait(t), j, False)
+            j = (base + i) % 64
+            q.append((bv.submit(n_in, n_out, batch, sets[j].host[0], sets[j].host[1], proof_len, sets[j].host[2]), j))
+        while q:
+            t, j = q.popleft()
+            bm = checked(bv.wait(t), j, False)
         return bm
 
     # what the device executes are merged batches of --merge transactions: the per-kernel figures (solo pass, PMC passes)
@@ -871,6 +894,20 @@ def run_config2(args, W):
             line["steady_state"] = {"tx_per_s": round(batch * steady_steps / dt, 1), "ms_per_step": round(dt / steady_steps * 1e3, 4),
                                     "steps": steady_steps, "tickets_in_flight": 64,
                                     "note": "same verifier, same merge target, 200 distinct steps with up to 64 tickets in flight"}
+        host_tickets = None
+        if bv is not None and not args.lean:
+            # tickets from host memory: the timed arrangement again (same --steps, same tickets in flight, same merge target),
+            # every step's bytes handed over from host memory; then 200 steps of it
+            run_tickets_host(max(bv.lanes() * rep, n_warm), base=32)                    # staging areas are made here
+            t1 = time.perf_counter()
+            run_tickets_host(args.steps, base=0)
+            dt = time.perf_counter() - t1
+            host_tickets = {"tx_per_s": round(batch * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 4), "steps": args.steps}
+            if steady_steps:
+                t1 = time.perf_counter()
+                run_tickets_host(steady_steps, base=0, depth=64)
+                dt = time.perf_counter() - t1
+                host_tickets["steady_tx_per_s"] = round(batch * steady_steps / dt, 1)
         if not args.lean:
             line["hbm_copy"] = hbm_copy_leg(ctx)
             line["cpu2"] = ("omitted: BASELINE.md's second CPU line (libsodium naive sum of crypto_scalarmult_ristretto255) needs "
@@ -937,12 +974,18 @@ def run_config2(args, W):
             line["msm_boundary"] = {"tx_per_s": round(batch / msm_only_s, 1), "ms_per_step": round(msm_only_s * 1e3, 4),
                                     "note": "zkgpu_verify_batch_ps_submit_dev alone: decompress + MSM + identity test on scalars "
                                             "prepared beforehand (the argument list of dalek's mega_check resident in HBM)"}
-            line["host_memory"] = {"gpu_resident_tx_per_s": round(batch / e2e_gpu_s, 1),
+            line["host_memory"] = {"gpu_resident_tx_per_s": host_tickets["tx_per_s"] if host_tickets else round(batch / e2e_gpu_s, 1),
+                                   "tickets": host_tickets,
+                                   "per_context_submit_tx_per_s": round(batch / e2e_gpu_s, 1),
                                    "host_prepared_tx_per_s": round(batch / e2e_s, 1), "host_threads": host_threads,
                                    "host_prepare_ms_per_batch": round(prep_s * 1e3, 2),
                                    "note": "proof bytes in host memory -> accept bits, PCIe copies and python marshalling included.  "
-                                           "gpu_resident: zkgpu_cloak_verify_submit (everything after the copy on the device).  "
-                                           "host_prepared: zkgpu_cloak_verify_batch (verifier head on %d host threads).  Neither is "
+                                           "gpu_resident (= tickets.tx_per_s): the timed arrangement of `value` -- same steps, same tickets in "
+                                           "flight, same merge target -- with every step handed over from host memory "
+                                           "(zkgpu_verifier_submit_many for the first wave, zkgpu_verifier_submit after it: pinned staging, "
+                                           "three copies per device batch on the verifier's copy stream); tickets.steady_tx_per_s: 200 steps "
+                                           "of it.  per_context_submit: zkgpu_cloak_verify_submit on plain contexts (no merging; round 3's "
+                                           "figure).  host_prepared: zkgpu_cloak_verify_batch (verifier head on %d host threads).  None is "
                                            "`value`." % host_threads}
             hv.close()
             if world == 1 and not args.no_cpu:

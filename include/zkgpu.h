@@ -475,6 +475,20 @@ int zkgpu_verifier_submit_dev(zkgpu_verifier *v, uint32_t n_in, uint32_t n_out, 
 int zkgpu_verifier_submit_many_dev(zkgpu_verifier *v, uint32_t n_in, uint32_t n_out, size_t count, size_t batch_each,
                                    const void *const *d_commitments, const void *const *d_proofs, size_t proof_len,
                                    const void *const *d_r, uint64_t *tickets);
+/* Tickets from HOST memory -- what a caller of Tx::verify has: bytes in its own memory (upstream: the `R1CSProof` and the
+ * commitments of `Tx`, zkvm `Verifier::verify_tx`; no file:line exists under /root/reference).  Same queue, same merging, same
+ * zkgpu_verifier_wait; the inputs are copied into pinned staging memory DURING the call (they may be reused or freed as soon
+ * as it returns) side by side with the other tickets of the device batch being formed, and reach the device as three
+ * copies per DEVICE batch on a copy stream of the verifier's own, beside the batches in flight -- no merge kernel, no copy
+ * per ticket.  r_bytes: 64 bytes of verifier randomness per transaction, or NULL (the OS's, expanded with SHAKE256).
+ * A ticket of a shape the generator set cannot serve, or with a proof length that is wrong for its shape, is answered
+ * with an all-zero bitmap and ZKGPU_OK by zkgpu_verifier_wait, as the reference answers each such transaction with Err. */
+int zkgpu_verifier_submit(zkgpu_verifier *v, uint32_t n_in, uint32_t n_out, size_t batch, const uint8_t *commitments,
+                          const uint8_t *proofs, size_t proof_len, const uint8_t *r_bytes, uint64_t *ticket);
+/* `count` batches of one shape and size at once (arrays of count host pointers; r_bytes or any r_bytes[i] may be NULL) */
+int zkgpu_verifier_submit_many(zkgpu_verifier *v, uint32_t n_in, uint32_t n_out, size_t count, size_t batch_each,
+                               const uint8_t *const *commitments, const uint8_t *const *proofs, size_t proof_len,
+                               const uint8_t *const *r_bytes, uint64_t *tickets);
 int zkgpu_verifier_wait(zkgpu_verifier *v, uint64_t ticket, uint8_t *accept_bitmap);
 
 /* ---- serialized transactions (replaces Tx::verify / Verifier::verify_tx for the PAYMENT SUBSET) --

@@ -608,6 +608,89 @@ def test_benched_arrangement_tickets_merged_into_device_batches_vs_oracle(ctx, o
         gens.close()
 
 
+def test_tickets_from_host_memory_benched_steps_vs_oracle(ctx, oracle):
+    """zkgpu_verifier_submit / _submit_many: the benched step sets handed over in HOST memory -- one
+    submit_many for the first 20, merged into device batches of 10 240 in pinned staging memory and copied to the lane's
+    merge buffers by the verifier's copy stream -- every bit of every ticket against the oracle's verdicts; the caller's
+    buffers overwritten right after the call (the library must have copied them); then one by one with up to 16 in flight,
+    mixed with DEVICE tickets of other steps in the same queue; then the edge cases: a ticket larger than the merge target,
+    a ticket of another shape in between, randomness from the OS (r_bytes = NULL), a proof length that is wrong for the
+    shape (all bits zero, no error), a ticket waited for while its batch is still being formed."""
+    import ctypes as C
+    from gpu_util import benched_randomness, benched_step, mixed_block
+    from zkvm_amd.verifier import BlockVerifier, BulletproofGens
+    n_steps, batch, merge = 20, 1024, 10240
+    gens = BulletproofGens(ctx, 256, table_bits=12)
+    bv = BlockVerifier(ctx, gens, batches_in_flight=5)
+    bv.set_merge(merge)
+    sets, dev = [], []
+    try:
+        for s in range(n_steps + 24):
+            txs, expected = benched_step(batch, 0, 64, s)
+            r = benched_randomness(0, s, batch)
+            n_in, n_out, plen = txs[0][0], txs[0][1], len(txs[0][3])
+            com, proofs = b"".join(t[2] for t in txs), b"".join(t[3] for t in txs)
+            if s < 6 or s % 9 == 0:
+                assert list(oracle.cloak_verify_batch(com, n_in, n_out, proofs, plen, r, threads=16)) == expected, s
+            sets.append((com, proofs, r, expected))
+        # mutable copies handed to the library and scribbled over as soon as the call is back
+        bufs = [[C.create_string_buffer(x, len(x)) for x in st[:3]] for st in sets[:n_steps]]
+        count = n_steps
+        t = (C.c_uint64 * count)()
+        ptrs = [(C.c_void_p * count)(*[C.addressof(b[k]) for b in bufs]) for k in range(3)]
+        bv._check(bv.lib.zkgpu_verifier_submit_many(bv.h, n_in, n_out, count, batch, ptrs[0], ptrs[1], plen, ptrs[2], t))
+        for b in bufs:
+            for x in b:
+                C.memset(x, 0xA5, len(x))
+        for k in range(count):
+            bm = C.create_string_buffer(batch // 8)
+            bv._check(bv.lib.zkgpu_verifier_wait(bv.h, t[k], bm))
+            assert bits(bm.raw, batch) == sets[k][3], k
+        # one by one, 16 in flight, every third step as a DEVICE ticket in the same queue
+        q = []
+        for s in range(n_steps, n_steps + 24):
+            if len(q) >= 16:
+                k, tk = q.pop(0)
+                assert bits(bv.wait(tk), batch) == sets[k][3], k
+            com, proofs, r, _ = sets[s]
+            if s % 3 == 0:
+                d = [ctx.to_device(x) for x in (com, proofs, r)]
+                dev.append(d)
+                q.append((s, bv.submit_dev(n_in, n_out, batch, d[0], d[1], plen, d[2])))
+            else:
+                q.append((s, bv.submit(n_in, n_out, batch, com, proofs, plen, r)))
+        for k, tk in q:
+            assert bits(bv.wait(tk), batch) == sets[k][3], k
+        # edge cases
+        big_com, big_proofs, big_r = (b"".join(sets[s][j] for s in range(11)) for j in range(3))            # 11 264 > merge
+        big_want = [b for s in range(11) for b in sets[s][3]]
+        other = [tx for tx in mixed_block(60, seed=5, bad_every=5) if (tx[0], tx[1]) == (1, 2)]
+        assert len(other) >= 4
+        o_r = hashlib.shake_256(b"other shape").digest(64 * len(other))
+        o_want = [int(oracle.cloak_verify(tx[2], 1, 2, tx[3], o_r[64 * i: 64 * i + 64])) for i, tx in enumerate(other)]
+        assert 0 in o_want and 1 in o_want
+        t_a = bv.submit(n_in, n_out, batch, *sets[0][:2], plen, sets[0][2])
+        t_o = bv.submit(1, 2, len(other), b"".join(tx[2] for tx in other), b"".join(tx[3] for tx in other), len(other[0][3]), o_r)
+        t_big = bv.submit(n_in, n_out, 11 * batch, big_com, big_proofs, plen, big_r)
+        t_os = bv.submit(n_in, n_out, batch, *sets[1][:2], plen, None)                     # the OS's randomness
+        t_len = bv.submit(n_in, n_out, 8, sets[2][0][: 8 * 256], sets[2][1][: 8 * (plen - 32)], plen - 32, sets[2][2][: 8 * 64])
+        t_b = bv.submit(n_in, n_out, batch, *sets[3][:2], plen, sets[3][2])
+        assert bits(bv.wait(t_b), batch) == sets[3][3]                                     # waited for first: its batch goes out as it is
+        assert bits(bv.wait(t_len), 8) == [0] * 8
+        assert bits(bv.wait(t_os), batch) == sets[1][3]                                    # (no verdict here depends on r)
+        assert bits(bv.wait(t_big), 11 * batch) == big_want
+        assert bits(bv.wait(t_o), len(other)) == o_want
+        assert bits(bv.wait(t_a), batch) == sets[0][3]
+        with pytest.raises(Exception):
+            bv.wait(t_a)                                                                   # a ticket is waited for once
+    finally:
+        bv.close()
+        for d in dev:
+            for x in d:
+                ctx.free_device(x)
+        gens.close()
+
+
 def test_msm_2p20_equals_committed_expected_value(ctx):
     """BASELINE.json configs[2] at full size against tests/golden/msm_2p20.json (the oracle's result, computed in
     the build container): inputs regenerated from SHAKE256 here, points mapped on the device -- whose 32 MiB of

@@ -26,7 +26,22 @@ struct zkgpu_request {                 // one submitted batch (zkgpu_verifier_su
   const void *d_com = nullptr, *d_proofs = nullptr, *d_r = nullptr;
   int state = 0;                       // 0 queued, 1 in flight on `lane`, 2 done
   int lane = -1, rc = 0;
+  struct zkgpu_host_batch* form = nullptr;   // host-memory ticket: the device batch it was staged into (state 0 only)
   std::vector<uint8_t> bits;
+};
+
+// Tickets from HOST memory (zkgpu_verifier_submit): a device batch is FORMED in pinned host memory -- every ticket's
+// commitments, proof bytes and randomness copied side by side at submission, so that the caller's buffers are free again
+// when the call returns -- and goes to the device as three copies on the verifier's copy stream, straight into the lane's
+// merge buffers: the merge that device tickets need as a kernel costs nothing here.
+struct zkgpu_host_batch {
+  uint32_t n_in = 0, n_out = 0;
+  size_t proof_len = 0, wcom = 0;
+  size_t cap_tx = 0, total = 0;        // transactions it has room for / holds
+  size_t o_proofs = 0, o_r = 0;        // offsets of the three pieces inside the staging area
+  int stage = -1;                      // which pinned area
+  zkgpu_cloak_plan* plan = nullptr;
+  std::vector<zkgpu_request*> members;
 };
 
 struct zkgpu_verifier {
@@ -37,6 +52,11 @@ struct zkgpu_verifier {
   std::vector<std::vector<zkgpu_request*>> running;     // per lane: the members of its merged batch in flight
   std::deque<int> busy;                                 // lanes in flight, oldest first
   size_t merge_target = 4096;                           // transactions per merged device batch
+  // host-memory tickets: pinned staging areas (lanes + 2 of them, grow-only) and the device batches being formed in them,
+  // oldest first; a batch that is full waits here for a free lane
+  struct HostStage { void* pin = nullptr; size_t cap = 0; hipEvent_t copied = nullptr; bool taken = false; bool copying = false; };
+  std::vector<HostStage> host_stages;
+  std::deque<std::unique_ptr<zkgpu_host_batch>> forming;
   zkgpu_ctx* root = nullptr;
   const zkgpu_pointset* ps = nullptr;
   size_t gens_capacity = 0;
@@ -116,6 +136,7 @@ constexpr uint32_t COMM_POISON = 0x80000001u;          // what d_send's first wo
 namespace {
 void ticket_collect(zkgpu_verifier* v, int lane);
 int ticket_dispatch(zkgpu_verifier* v, bool force);
+int host_dispatch(zkgpu_verifier* v, zkgpu_host_batch* must);
 void block_collect(zkgpu_verifier* v, int lane);
 
 // ---- RCCL, bound on first use -------------------------------------------------------------
@@ -319,6 +340,7 @@ void zkgpu_verifier_destroy(zkgpu_verifier* v) {
   {
     DeviceGuard g(v->root->device);
     for (auto& a : v->tx_arenas) { if (a.h_pin) (void)hipHostFree(a.h_pin); if (a.dev) (void)hipFree(a.dev); if (a.copied) (void)hipEventDestroy(a.copied); }
+    for (auto& hs : v->host_stages) { if (hs.pin) (void)hipHostFree(hs.pin); if (hs.copied) (void)hipEventDestroy(hs.copied); }
     if (v->copy_stream) (void)hipStreamDestroy(v->copy_stream);
   }
   for (auto& kv : v->plans) if (kv.second) zkgpu_cloak_plan_destroy(kv.second);
@@ -768,6 +790,191 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
 
 }  // namespace
 
+namespace {
+
+// ---- host-memory tickets (v->mu held throughout) --------------------------------------------------------------------
+int free_ticket_lane(zkgpu_verifier* v) {
+  for (size_t i = 0; i < v->lanes.size(); ++i) if (v->running[i].empty() && !v->lane_job[i].run) return (int)i;
+  return -1;
+}
+
+// a staging area nobody forms a batch in; its last copy to the device is waited for (long done in practice).  -1: none
+int host_stage_acquire(zkgpu_verifier* v, size_t bytes, int* rc) {
+  *rc = ZKGPU_OK;
+  if (v->host_stages.empty()) v->host_stages.resize(v->lanes.size() + 2);
+  for (size_t i = 0; i < v->host_stages.size(); ++i) {
+    zkgpu_verifier::HostStage& hs = v->host_stages[i];
+    if (hs.taken) continue;
+    DeviceGuard g(v->root->device);
+    if (hs.copying) { (void)hipEventSynchronize(hs.copied); hs.copying = false; }
+    if (hs.cap < bytes) {
+      if (hs.pin) (void)hipHostFree(hs.pin);
+      hs.pin = nullptr; hs.cap = 0;
+      const size_t want = bytes + bytes / 8 + 4096;
+      if (hipHostMalloc(&hs.pin, want, hipHostMallocDefault) != hipSuccess) { v->last_error = "hipHostMalloc (ticket staging)"; *rc = ZKGPU_ENOMEM; return -1; }
+      hs.cap = want;
+    }
+    if (!hs.copied && hipEventCreateWithFlags(&hs.copied, hipEventDisableTiming) != hipSuccess) { v->last_error = "hipEventCreate (ticket staging)"; *rc = ZKGPU_EHIP; return -1; }
+    hs.taken = true;
+    return (int)i;
+  }
+  return -1;
+}
+
+void host_batch_fail(zkgpu_verifier* v, zkgpu_host_batch* F, int rc) {      // every member done, with rc (OK: all bits zero)
+  for (zkgpu_request* r : F->members) { r->state = 2; r->rc = rc; r->form = nullptr; r->bits.assign((r->batch + 7) / 8, 0); }
+  if (F->stage >= 0) v->host_stages[(size_t)F->stage].taken = false;
+}
+
+// the formed batch F -> lane: three copies on the copy stream into the lane's merge buffers, then the batch itself
+int host_launch(zkgpu_verifier* v, zkgpu_host_batch* F, int lane) {
+  zkgpu_ctx* L = v->lanes[(size_t)lane];
+  zkgpu_verifier::HostStage& hs = v->host_stages[(size_t)F->stage];
+  int rc = ZKGPU_OK;
+  {
+    std::lock_guard<std::recursive_mutex> lk(L->mu);
+    DeviceGuard g(L->device);
+    rc = ensure(L, L->coal_com, F->total * F->wcom);
+    if (rc == ZKGPU_OK) rc = ensure(L, L->coal_proofs, F->total * F->proof_len + 16);
+    if (rc == ZKGPU_OK) rc = ensure(L, L->coal_r, F->total * 64);
+    if (rc == ZKGPU_OK) {
+      const char* h = (const char*)hs.pin;
+      hipError_t e = v->copy_stream ? hipSuccess : hipStreamCreateWithFlags(&v->copy_stream, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipMemcpyAsync(L->coal_com.p, h, F->total * F->wcom, hipMemcpyHostToDevice, v->copy_stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(L->coal_proofs.p, h + F->o_proofs, F->total * F->proof_len, hipMemcpyHostToDevice, v->copy_stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(L->coal_r.p, h + F->o_r, F->total * 64, hipMemcpyHostToDevice, v->copy_stream);
+      if (e == hipSuccess) e = hipEventRecord(hs.copied, v->copy_stream);
+      if (e != hipSuccess) { L->last_error = std::string("ticket staging copy: ") + hipGetErrorString(e); rc = ZKGPU_EHIP; }
+      else { hs.copying = true; L->dep_event = hs.copied; }
+    }
+  }
+  if (rc == ZKGPU_OK) rc = zkgpu_cloak_verify_submit_dev(L, v->ps, F->plan, F->total, L->coal_com.p, L->coal_proofs.p, F->proof_len, L->coal_r.p);
+  if (rc != ZKGPU_OK) {
+    v->last_error = zkgpu_last_error(L);
+    { std::lock_guard<std::recursive_mutex> lk(L->mu); L->dep_event = nullptr; }
+    if (hs.copying) { DeviceGuard g(L->device); (void)hipEventSynchronize(hs.copied); hs.copying = false; }
+    host_batch_fail(v, F, rc);
+    return rc;
+  }
+  size_t off = 0;
+  for (zkgpu_request* r : F->members) { r->bit_off = off; off += r->batch; r->state = 1; r->lane = lane; r->form = nullptr; }
+  v->running[(size_t)lane] = F->members;
+  v->busy.push_back(lane);
+  hs.taken = false;                      // (its event guards the next use)
+  return ZKGPU_OK;
+}
+
+// launches the formed batches that are full, oldest first, while lanes are free; `must`: that one whatever it holds, and
+// if no lane is free the oldest batch in flight is collected first
+int host_dispatch(zkgpu_verifier* v, zkgpu_host_batch* must) {
+  for (size_t i = 0; i < v->forming.size();) {
+    zkgpu_host_batch* F = v->forming[i].get();
+    const bool due = F == must || F->total >= std::min(F->cap_tx, v->merge_target);
+    if (!due) { ++i; continue; }
+    int lane = free_ticket_lane(v);
+    if (lane < 0) {
+      if (F != must) return ZKGPU_OK;    // (full batches keep their order: the next free lane is the oldest one's)
+      if (!v->busy.empty()) ticket_collect(v, v->busy.front()); else if (!v->block_busy.empty()) block_collect(v, v->block_busy.front());
+      continue;
+    }
+    std::unique_ptr<zkgpu_host_batch> owned = std::move(v->forming[i]);
+    v->forming.erase(v->forming.begin() + (long)i);
+    (void)host_launch(v, owned.get(), lane);     // (a failure is recorded in its tickets)
+  }
+  return ZKGPU_OK;
+}
+
+// the caller's bytes -> pinned staging memory: on one thread ~10 GB/s, i.e. 0.14 ms per 1024-transaction ticket and 1.4 ms
+// before the FIRST device batch of a burst can leave; pieces of 8 KB on up to eight pool threads beyond 256 KB
+void staged_copy(void* dst, const void* src, size_t n) {
+  if (n < (256u << 10)) { memcpy(dst, src, n); return; }
+  constexpr size_t PIECE = 8u << 10;
+  host_parallel((n + PIECE - 1) / PIECE, std::min(usable_cpus(), 8), [&](size_t i) {
+    const size_t at = i * PIECE;
+    memcpy((char*)dst + at, (const char*)src + at, std::min(PIECE, n - at));
+  });
+}
+
+// one ticket from host memory: copied into the batch being formed for its shape (a new one when that is full)
+int host_submit_one(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, size_t batch, const uint8_t* com, const uint8_t* proofs,
+                    size_t proof_len, const uint8_t* r_bytes, uint64_t* ticket) {
+  zkgpu_request* r = new zkgpu_request();
+  r->id = v->next_id++;
+  r->n_in = n_in; r->n_out = n_out; r->batch = batch; r->proof_len = proof_len;
+  v->requests[r->id] = r;
+  *ticket = r->id;
+  int rc = ZKGPU_OK;
+  std::string plan_err;
+  zkgpu_cloak_plan* plan = verifier_plan(v, n_in, n_out, &rc, &plan_err);
+  if (rc != ZKGPU_OK) v->last_error = plan_err;
+  if (rc != ZKGPU_OK || !plan || !proof_len_fits(plan->shape, proof_len)) {   // no plan THIS time: the ticket fails with rc; a shape or
+    r->state = 2; r->rc = rc; r->bits.assign((batch + 7) / 8, 0);             // length the reference rejects: every proof is Err
+    return ZKGPU_OK;
+  }
+  const size_t wcom = (size_t)plan->shape.m * 32;
+  zkgpu_host_batch* F = nullptr;
+  for (auto& f : v->forming)
+    if (f->n_in == n_in && f->n_out == n_out && f->proof_len == proof_len && f->total < std::min(f->cap_tx, v->merge_target) && f->total + batch <= f->cap_tx) F = f.get();
+  while (!F) {
+    const size_t cap_tx = std::max(v->merge_target, batch);
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_proofs = align(cap_tx * wcom), o_r = align(o_proofs + cap_tx * proof_len + 16), bytes = o_r + cap_tx * 64;
+    const int st = host_stage_acquire(v, bytes, &rc);
+    if (rc != ZKGPU_OK) { r->state = 2; r->rc = rc; r->bits.assign((batch + 7) / 8, 0); return ZKGPU_OK; }
+    if (st < 0) {                         // every area holds a batch that waits: the oldest goes out now (a lane is made free for it)
+      (void)host_dispatch(v, v->forming.front().get());
+      continue;
+    }
+    std::unique_ptr<zkgpu_host_batch> nf(new zkgpu_host_batch());
+    nf->n_in = n_in; nf->n_out = n_out; nf->proof_len = proof_len; nf->wcom = wcom; nf->cap_tx = cap_tx;
+    nf->o_proofs = o_proofs; nf->o_r = o_r; nf->stage = st; nf->plan = plan;
+    F = nf.get();
+    v->forming.push_back(std::move(nf));
+  }
+  char* h = (char*)v->host_stages[(size_t)F->stage].pin;
+  staged_copy(h + F->total * wcom, com, batch * wcom);
+  staged_copy(h + F->o_proofs + F->total * proof_len, proofs, batch * proof_len);
+  if (r_bytes) {
+    staged_copy(h + F->o_r + F->total * 64, r_bytes, batch * 64);
+  } else {                                // verifier randomness: SHAKE256 of 32 bytes from the OS and the ticket number
+    uint8_t seed[40] = {0};
+    if (!os_random(seed, 32)) { r->state = 2; r->rc = ZKGPU_EINVAL; r->bits.assign((batch + 7) / 8, 0); v->last_error = "getrandom failed"; return ZKGPU_OK; }
+    for (int q = 0; q < 8; ++q) seed[32 + q] = (uint8_t)(r->id >> (8 * q));
+    Sponge sp = shake256_sponge();
+    sp.absorb(seed, 40);
+    sp.squeeze((uint8_t*)h + F->o_r + F->total * 64, batch * 64);
+  }
+  r->form = F;
+  F->members.push_back(r);
+  F->total += batch;
+  return ZKGPU_OK;
+}
+
+}  // namespace
+
+// Tickets from HOST memory: as zkgpu_verifier_submit_dev, but the inputs lie in the caller's memory and are free again
+// when the call returns (they are copied into pinned staging memory here).  r_bytes == NULL: verifier randomness from the OS.
+int zkgpu_verifier_submit(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, size_t batch, const uint8_t* commitments,
+                          const uint8_t* proofs, size_t proof_len, const uint8_t* r_bytes, uint64_t* ticket) {
+  if (!v || !ticket || batch == 0 || batch >= (1ull << 24) || !commitments || !proofs) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  TRY(host_submit_one(v, n_in, n_out, batch, commitments, proofs, proof_len, r_bytes, ticket));
+  return host_dispatch(v, nullptr);
+}
+
+int zkgpu_verifier_submit_many(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, size_t count, size_t batch_each,
+                               const uint8_t* const* commitments, const uint8_t* const* proofs, size_t proof_len,
+                               const uint8_t* const* r_bytes, uint64_t* tickets) {
+  if (!v || !tickets || !commitments || !proofs || batch_each == 0 || batch_each >= (1ull << 24)) return ZKGPU_EINVAL;
+  for (size_t i = 0; i < count; ++i) if (!commitments[i] || !proofs[i]) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  for (size_t i = 0; i < count; ++i) {
+    TRY(host_submit_one(v, n_in, n_out, batch_each, commitments[i], proofs[i], proof_len, r_bytes ? r_bytes[i] : nullptr, &tickets[i]));
+    (void)host_dispatch(v, nullptr);      // a batch that became full goes out while the next is being formed
+  }
+  return ZKGPU_OK;
+}
+
 int zkgpu_verifier_set_merge(zkgpu_verifier* v, size_t transactions) {
   if (!v || transactions == 0 || transactions >= (1u << 24)) return ZKGPU_EINVAL;
   std::lock_guard<std::mutex> lk(v->mu);
@@ -815,7 +1022,8 @@ int zkgpu_verifier_wait(zkgpu_verifier* v, uint64_t ticket, uint8_t* accept_bitm
   if (it == v->requests.end()) return ZKGPU_EINVAL;
   zkgpu_request* r = it->second;
   while (r->state != 2) {
-    if (r->state == 0) (void)ticket_dispatch(v, true);
+    if (r->state == 0 && r->form) (void)host_dispatch(v, r->form);     // (a host-memory ticket: its batch goes out as it is)
+    else if (r->state == 0) (void)ticket_dispatch(v, true);
     else ticket_collect(v, r->lane);
   }
   const int rc = r->rc;
@@ -824,6 +1032,7 @@ int zkgpu_verifier_wait(zkgpu_verifier* v, uint64_t ticket, uint8_t* accept_bitm
   v->requests.erase(it);
   delete r;
   if (!v->queue.empty()) (void)ticket_dispatch(v, false);
+  if (!v->forming.empty()) (void)host_dispatch(v, nullptr);
   return rc;
 }
 

@@ -158,6 +158,8 @@ def load_library():
     lib.zkgpu_debug_comm_mock.argtypes = [vp, C.c_int, u8p, sz]
     lib.zkgpu_debug_comm_mock.restype = C.c_longlong
     lib.zkgpu_verifier_submit_many_dev.argtypes = [vp, C.c_uint32, C.c_uint32, sz, sz, vp, vp, sz, vp, vp]
+    lib.zkgpu_verifier_submit.argtypes = [vp, C.c_uint32, C.c_uint32, sz, C.c_char_p, C.c_char_p, sz, C.c_char_p, C.POINTER(C.c_uint64)]
+    lib.zkgpu_verifier_submit_many.argtypes = [vp, C.c_uint32, C.c_uint32, sz, sz, vp, vp, sz, vp, vp]
     lib.zkgpu_r1cs_plan_create.argtypes = [vp, vp, sz, C.POINTER(vp)]
     lib.zkgpu_r1cs_plan_destroy.argtypes = [vp]
     lib.zkgpu_r1cs_plan_destroy.restype = None

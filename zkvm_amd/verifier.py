@@ -218,6 +218,31 @@ class BlockVerifier:
             self.__dict__.setdefault("_ticket_batch", {})[t[i]] = batch_each
         return [int(t[i]) for i in range(count)]
 
+    def submit(self, n_in: int, n_out: int, batch: int, commitments: bytes, proofs: bytes, proof_len: int, r_bytes: Optional[bytes]) -> int:
+        """zkgpu_verifier_submit: queue one uniform batch from HOST memory (copied into pinned staging memory during the
+        call: the buffers are free again when it returns); -> ticket"""
+        assert len(commitments) >= batch * 64 * (n_in + n_out) and len(proofs) >= batch * proof_len and (r_bytes is None or len(r_bytes) >= 64 * batch)
+        t = C.c_uint64(0)
+        self._check(self.lib.zkgpu_verifier_submit(self.h, n_in, n_out, batch, commitments, proofs, proof_len, r_bytes, C.byref(t)))
+        self.__dict__.setdefault("_ticket_batch", {})[t.value] = batch
+        return int(t.value)
+
+    def submit_many(self, n_in: int, n_out: int, batch_each: int, commitments: Sequence[bytes], proofs: Sequence[bytes], proof_len: int,
+                    r_bytes: Optional[Sequence[Optional[bytes]]]) -> List[int]:
+        """zkgpu_verifier_submit_many: queue len(commitments) uniform batches from host memory in one call; -> tickets"""
+        count = len(commitments)
+        assert len(proofs) == count and (r_bytes is None or len(r_bytes) == count)
+        for i in range(count):
+            assert len(commitments[i]) >= batch_each * 64 * (n_in + n_out) and len(proofs[i]) >= batch_each * proof_len
+            assert r_bytes is None or r_bytes[i] is None or len(r_bytes[i]) >= 64 * batch_each
+        arr = lambda xs: (C.c_char_p * max(count, 1))(*xs)                # noqa: E731
+        t = (C.c_uint64 * max(count, 1))()
+        self._check(self.lib.zkgpu_verifier_submit_many(self.h, n_in, n_out, count, batch_each, arr(commitments), arr(proofs), proof_len,
+                                                        arr(r_bytes) if r_bytes is not None else None, t))
+        for i in range(count):
+            self.__dict__.setdefault("_ticket_batch", {})[t[i]] = batch_each
+        return [int(t[i]) for i in range(count)]
+
     def wait(self, ticket: int) -> bytes:
         """zkgpu_verifier_wait: the accept bitmap of that ticket's batch"""
         batch = self.__dict__["_ticket_batch"].pop(ticket)
