@@ -50,6 +50,13 @@ extern "C" {
 #define ZKGPU_ENODEVICE (-5)
 #define ZKGPU_ENOCOMM (-6)         /* RCCL could not be loaded / initialised, or a collective failed */
 #define ZKGPU_EREMOTE (-7)         /* sharded verification: another rank reported an error (bitmap zeroed everywhere) */
+/* the one POSITIVE status: the call succeeded and its result is usable, but the caller should know something */
+#define ZKGPU_WSECOND_VERIFIER 1   /* zkgpu_verifier_create: another verifier is alive on this device in this process while the
+                                      runtime hands out 20 or more hardware queues: their streams together oversubscribe the
+                                      device's queue slots and calls take 5 - 40 ms instead of a steady 6.
+                                      The verifier IS created (*out is valid).  Use ONE verifier per process and device --
+                                      tickets, blocks and transaction calls of any mix go through one -- or export
+                                      GPU_MAX_HW_QUEUES=16 before the process's first HIP call. */
 
 typedef struct zkgpu_ctx zkgpu_ctx;
 typedef struct zkgpu_pointset zkgpu_pointset;

@@ -17,6 +17,7 @@ pub const ZKGPU_ENOMEM: c_int = -4;
 pub const ZKGPU_ENODEVICE: c_int = -5;
 pub const ZKGPU_ENOCOMM: c_int = -6;
 pub const ZKGPU_EREMOTE: c_int = -7;
+pub const ZKGPU_WSECOND_VERIFIER: c_int = 1;
 pub const ZKGPU_TXFORMAT_RECOLLECTED_V1: c_int = 1;
 pub const ZKGPU_COMM_ID_BYTES: usize = 128;
 

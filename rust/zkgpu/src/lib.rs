@@ -120,6 +120,7 @@ pub struct GpuVerifier {
     ctx: *mut sys::zkgpu_ctx,
     gens: Generators,
     v: *mut sys::zkgpu_verifier,
+    warning: Option<String>,
 }
 
 // the library serialises calls on a verifier with its own mutex; the handles are plain pointers to its heap objects
@@ -156,14 +157,21 @@ impl GpuVerifier {
                 return Err(e);
             }
             let mut v: *mut sys::zkgpu_verifier = ptr::null_mut();
-            if let Err(e) = check(unsafe { sys::zkgpu_verifier_create(ctx, ps, gens_capacity, lanes as c_int, &mut v) }, ctx_err(ctx)) {
-                unsafe { sys::zkgpu_pointset_destroy(ps) };
-                return Err(e);
+            let rc = unsafe { sys::zkgpu_verifier_create(ctx, ps, gens_capacity, lanes as c_int, &mut v) };
+            // ZKGPU_WSECOND_VERIFIER: created, with a warning (another verifier is alive on this device): `warning()` has the text
+            if rc != sys::ZKGPU_WSECOND_VERIFIER {
+                if let Err(e) = check(rc, ctx_err(ctx)) {
+                    unsafe { sys::zkgpu_pointset_destroy(ps) };
+                    return Err(e);
+                }
             }
-            Ok((ps, v))
+            Ok((ps, v, rc == sys::ZKGPU_WSECOND_VERIFIER))
         })();
         match built {
-            Ok((ps, v)) => Ok(GpuVerifier { ctx, gens: Generators { ps, capacity: gens_capacity }, v }),
+            Ok((ps, v, warned)) => {
+                let warning = if warned { Some(text(unsafe { sys::zkgpu_verifier_last_error(v) })) } else { None };
+                Ok(GpuVerifier { ctx, gens: Generators { ps, capacity: gens_capacity }, v, warning })
+            }
             Err(e) => {
                 unsafe { sys::zkgpu_destroy(ctx) };
                 Err(e)
@@ -173,6 +181,12 @@ impl GpuVerifier {
 
     fn err(&self) -> impl FnOnce() -> String + '_ {
         move || text(unsafe { sys::zkgpu_verifier_last_error(self.v) })
+    }
+
+    /// Set when the verifier was created beside another live one on the same device (`ZKGPU_WSECOND_VERIFIER`): it works,
+    /// but one verifier per process and device is the shape the library's queue budget is made for.
+    pub fn warning(&self) -> Option<&str> {
+        self.warning.as_deref()
     }
 
     pub fn gens_capacity(&self) -> usize {

@@ -405,6 +405,47 @@ print("RESULT", used, asked, late, int(got == [0 if i %% 41 == 3 else 1 for i in
     assert late == 1 and "before GPU_MAX_HW_QUEUES was set" in line[0], line[0]
 
 
+def test_a_second_verifier_on_the_device_is_created_with_a_warning_when_queues_are_many():
+    """"nothing stops an integrator from creating two".  zkgpu_verifier_create now says so: status
+    ZKGPU_WSECOND_VERIFIER (1, the verifier IS created and works) when another verifier is alive on the device and the
+    runtime hands out 20 or more hardware queues -- the range in which two verifiers were measured to stall each other
+     -- and plain 0 with 16 queues, or once the other one has been destroyed.  Fresh processes: the queue
+    count is read when the HIP runtime starts."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r"""
+import os, sys, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from gpu_util import bits, load_cloak_fixture
+from zkvm_amd import Context
+from zkvm_amd.verifier import BlockVerifier, BulletproofGens, CloakTx
+ctx = Context(0)
+gens = BulletproofGens(ctx, 256, table_bits=8)
+a = BlockVerifier(ctx, gens, batches_in_flight=3)
+b = BlockVerifier(ctx, gens, batches_in_flight=3)
+fix, n_in, n_out, plen = load_cloak_fixture()
+txs = [CloakTx(n_in, n_out, *fix[i]) for i in range(40)]
+ok = bits(b.verify(txs, hashlib.shake_256(b"second").digest(64 * 40)), 40) == [1] * 40
+a.close()
+c = BlockVerifier(ctx, gens, batches_in_flight=3)          # b is still alive
+b.close(); c.close()
+d = BlockVerifier(ctx, gens, batches_in_flight=3)          # nobody else is
+print("RESULT", int(bool(a.warning)), int(bool(b.warning)), int(bool(c.warning)), int(bool(d.warning)), int(ok), "|", b.warning)
+d.close(); gens.close(); ctx.close()
+""" % (root, root)
+    seen = {}
+    for queues in ("24", "16"):
+        env = dict(os.environ, GPU_MAX_HW_QUEUES=queues)
+        out = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, env=env)
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, (out.stdout[-2000:], out.stderr[-2000:])
+        seen[queues] = ([int(x) for x in line[0].split()[1:6]], line[0])
+    assert seen["24"][0] == [0, 1, 1, 0, 1], seen["24"]
+    assert "one verifier per process and device" in seen["24"][1]
+    assert seen["16"][0] == [0, 0, 0, 0, 1], seen["16"]
+
+
 def test_cooperative_keccak_primitives_and_permutation(ctx, oracle):
     """keccak_coop.hpp on the hardware: every cross-lane primitive (DPP row_ror:8 / row_shr:1 / row_shl:1,
     v_permlane16_swap, v_permlane32_swap, ds_bpermute) behaves as the host emulation assumes, and Keccak-f[1600] with

@@ -377,13 +377,14 @@ def test_msm_values_over_resident_set(ctx, oracle, w):
 
 
 def test_table_width_is_chosen_by_capacity_and_free_memory(ctx, oracle):
-    """zkgpu_pointset_build_tables(.., 0): the library picks the window width -- 16 bits for the 514 generators of the
-    2-in/2-out statement on a 288 GB MI355X, fewer for sets whose tables would not fit a quarter of the device -- and the
-    verdicts are the same whatever the width (here against a set built at 9 bits)."""
+    """zkgpu_pointset_build_tables(.., 0): the library picks the window width -- the KNEE: the narrowest width whose addition
+    count per generator term is within 19/16 of the widest feasible width's (14 bits = 7.7 GB instead of 16 bits = 25.9 GB for
+    the 1026 generators of the 2-in/2-out statement on a 288 GB MI355X: 0.5 - 4 % measured), fewer for sets whose tables would
+    not fit a quarter of the device -- and the verdicts are the same whatever the width (here against a set built at 9 bits)."""
     import ctypes as C
     lib = ctx.lib
-    assert lib.zkgpu_choose_table_bits(ctx.h, 514) == 16
-    assert lib.zkgpu_choose_table_bits(ctx.h, 1026) == 16
+    assert lib.zkgpu_choose_table_bits(ctx.h, 514) == 14
+    assert lib.zkgpu_choose_table_bits(ctx.h, 1026) == 14
     w_big = lib.zkgpu_choose_table_bits(ctx.h, 200000)
     assert 4 <= w_big < 14
     assert lib.zkgpu_choose_table_bits(ctx.h, 0) == -1
@@ -391,8 +392,8 @@ def test_table_width_is_chosen_by_capacity_and_free_memory(ctx, oracle):
     auto = BulletproofGens(ctx, 64, table_bits=-1)
     nine = BulletproofGens(ctx, 64, table_bits=9)
     try:
-        assert auto.points.table_bits() == 16 and nine.points.table_bits() == 9
-        assert lib.zkgpu_pointset_table_bytes(auto.points.h) == 16 * 130 * 32768 * 96
+        assert auto.points.table_bits() == 14 and nine.points.table_bits() == 9
+        assert lib.zkgpu_pointset_table_bytes(auto.points.h) == 19 * 130 * 8192 * 96
         com, proofs = oracle.cloak_prove_batch(3, 1, 1, b"auto width".ljust(32, b"\0"), threads=3)      # 1-in/1-out: 64 generators
         bad = bytearray(proofs[1]); bad[-40] ^= 1
         txs = [CloakTx(1, 1, com[128 * i: 128 * (i + 1)], bytes(bad) if i == 1 else proofs[i]) for i in range(3)]

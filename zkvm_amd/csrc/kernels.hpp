@@ -1001,17 +1001,16 @@ k_spin(unsigned long long cycles, uint32_t* __restrict__ sink) {
 }
 
 // ---- k_hbm_copy -----------------------------------------------------------------
-// The achievable-HBM yardstick of SURVEY.md sec 8(d) ("measure achievable HBM with a copy kernel and report both"): 16 bytes
-// per lane, consecutive lanes on consecutive vectors, four independent loads in flight per lane, grid-stride over the buffer.
+// The achievable-HBM yardstick of SURVEY.md sec 8(d) ("measure achievable HBM with a copy kernel and report both"): ONE
+// 16-byte vector per lane, one workgroup per 4 KiB, no loop -- the shape that reaches the 6.2-6.3 TB/s the microarchitecture
+// guide quotes for a float4 copy.  Measured on an MI355X, 2 GiB, read + write bytes (tools/ubench/hbm_copy.hip,
+// profiles/r04_hbm_copy_variants.txt): this form 6.24 TB/s; the grid-stride loop with four loads in flight that was here
+// until round 3: 4.7-4.95 TB/s whatever the grid; block-contiguous tiles of 4 / 8 vectors per lane 5.4-5.7, non-temporal
+// 5.6-6.0; hipMemcpyDtoD 5.45.
 __global__ void __launch_bounds__(256)
 k_hbm_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n_vec) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n_vec; i += 4 * stride) {
-    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-  }
-  for (; i < n_vec; i += stride) dst[i] = src[i];
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n_vec) dst[i] = src[i];
 }
 
 // per-batch scratch state in one launch (instead of five fills): status words, per-MSM failure

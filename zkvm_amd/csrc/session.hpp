@@ -134,6 +134,10 @@ constexpr size_t COMM_MAX_SLOT = 1u << 20;             // bytes per rank and cal
 constexpr uint32_t COMM_POISON = 0x80000001u;          // what d_send's first word holds between calls: "this rank failed"
 
 namespace {
+// verifiers alive per device in this process (zkgpu_verifier_create warns about a second one: ZKGPU_WSECOND_VERIFIER)
+std::mutex g_live_verifiers_mu;
+std::map<int, int> g_live_verifiers;
+
 void ticket_collect(zkgpu_verifier* v, int lane);
 int ticket_dispatch(zkgpu_verifier* v, bool force);
 int host_dispatch(zkgpu_verifier* v, zkgpu_host_batch* must);
@@ -326,11 +330,26 @@ int zkgpu_verifier_create(zkgpu_ctx* ctx, const zkgpu_pointset* ps, size_t gens_
   v->running.resize(v->lanes.size());
   v->lane_job.resize(v->lanes.size());
   *out = v;
+  // One verifier per process and device is what the queue budget is made for: a second one is created
+  // all the same, and the caller is TOLD when the runtime's queue count is in the range where two verifiers were measured to
+  // stall each other (20 and more) -- a positive status, the only one the library has.
+  int others;
+  { std::lock_guard<std::mutex> lk(g_live_verifiers_mu); others = g_live_verifiers[ctx->device]++; }
+  const char* q = getenv("GPU_MAX_HW_QUEUES");
+  if (others > 0 && !g_hw_queues_late && q && atoi(q) >= 20) {
+    char msg[320];
+    snprintf(msg, sizeof msg, "%d other verifier(s) alive on device %d with GPU_MAX_HW_QUEUES=%s: the streams of two verifiers oversubscribe the "
+             "device's queue slots (calls of 5 - 40 ms instead of a steady 6): use one verifier per process and device, or export "
+             "GPU_MAX_HW_QUEUES=16 before the first HIP call", others, ctx->device, q);
+    v->last_error = msg;
+    return ZKGPU_WSECOND_VERIFIER;
+  }
   return ZKGPU_OK;
 }
 
 void zkgpu_verifier_destroy(zkgpu_verifier* v) {
   if (!v) return;
+  { std::lock_guard<std::mutex> lk(g_live_verifiers_mu); --g_live_verifiers[v->root->device]; }
   std::vector<uint8_t> scratch;
   (void)drain(v, scratch);
   for (auto& kv : v->requests) delete kv.second;

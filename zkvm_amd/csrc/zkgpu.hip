@@ -1209,6 +1209,7 @@ const char* zkgpu_strerror(int code) {
     case ZKGPU_ENODEVICE: return "no usable HIP device";
     case ZKGPU_ENOCOMM: return "RCCL unavailable or a collective failed";
     case ZKGPU_EREMOTE: return "another rank of the sharded verification failed";
+    case ZKGPU_WSECOND_VERIFIER: return "created, but another verifier is alive on this device with 20 or more hardware queues (warning)";
     default: return "unknown error";
   }
 }
@@ -1544,19 +1545,29 @@ static inline uint64_t table_build_bytes_for(uint64_t n, int w) {
   return table_bytes_for(n, w) + lanes * (1ull << (w - 1)) * EXT_WORDS * 4 + lanes * EXT_WORDS * 4;
 }
 
-// window_bits == 0: the library chooses.  Wider windows mean fewer mixed additions per generator term (255/w + 1 of them:
-// 16 at 16 bits, 20 at 13) and exponentially more table: the widest width, at most 16, whose tables take no more than a
-// quarter of the device's memory and whose construction (tables + 1.7x scratch) fits in 60 % of what is free right now.
-// On a 288 GB MI355X: 16 bits up to ~1400 points (two sets of 514 / 1026 points fit side by side), 15 bits up to ~2800, ...
-// Measured throughput by width: bench.py, setup.table_bits_sweep.
+// window_bits == 0: the library chooses the KNEE, not the widest table that fits.  Wider windows mean fewer mixed additions
+// per generator term (W = 255/w + 1 of them: 16 at 16 bits, 18 at 15, 19 at 14, 20 at 13) and exponentially more table
+// (1026 generators: 25.9 / 14.6 / 7.7 / 4.0 GB).  Measured on MI355X (bench.py, setup.table_bits_sweep, rounds 3 and 4; device
+// batches of 8192 distinct transactions): 16 / 15 / 14 / 13 bits = 3.32 / 3.31 / 3.30 / 3.20 M tx/s and 3.48 / 3.36 / 3.33 /
+// 3.32 M -- the generator kernel is 8 % of the batch's instructions, so three more additions per term cost 0.5 - 4 %, and
+// the widest table buys that with 18 GB.  Rule: take the widest width that is feasible (at most 16; tables no more than a
+// quarter of the device's memory; construction -- tables + 1.7x scratch -- within 60 % of what is free right now), then the
+// NARROWEST width whose addition count is within 19/16 of that one's ("the narrowest width within 3 % of the
+// widest measured").  On a 288 GB MI355X: 14 bits (7.7 GB for 1026 generators, 15.3 GB for 2050).  A caller who wants the
+// last per cent passes the width itself (16).
 int zkgpu_choose_table_bits(zkgpu_ctx* c, size_t n_points) {
   if (!c || n_points == 0) return ZKGPU_EINVAL;
   DeviceGuard g(c->device);
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return ZKGPU_EHIP;
+  int widest = 4;
   for (int w = 16; w >= 4; --w)
-    if (table_bytes_for(n_points, w) <= total_b / 4 && table_build_bytes_for(n_points, w) <= free_b / 10 * 6) return w;
-  return 4;
+    if (table_bytes_for(n_points, w) <= total_b / 4 && table_build_bytes_for(n_points, w) <= free_b / 10 * 6) { widest = w; break; }
+  const int adds_widest = 255 / widest + 1;
+  int knee = widest;
+  for (int w = widest - 1; w >= 4; --w)
+    if (16 * (255 / w + 1) <= 19 * adds_widest) knee = w; else break;
+  return knee;
 }
 
 int zkgpu_pointset_table_bits(const zkgpu_pointset* ps) { return (ps && ps->table) ? ps->tbl_w : 0; }
@@ -3131,8 +3142,8 @@ int zkgpu_measure_hbm_copy(zkgpu_ctx* c, size_t bytes, int iters, double* gbytes
   if (e == hipSuccess) e = hipEventCreate(&e1);
   if (e == hipSuccess) e = hipMemsetAsync(a, 0x5a, bytes, c->stream);
   float best = 0;
-  // enough workgroups for every CU to hold its full complement of wavefronts several times over
-  const unsigned blocks = 256 * 32;
+  bytes = std::min<size_t>(bytes, (size_t)0x7fffffffu * 4096);            // (one workgroup per 4 KiB: the grid's x dimension)
+  const unsigned blocks = (unsigned)((bytes / 16 + 255) / 256);
   for (int it = 0; e == hipSuccess && it <= iters; ++it) {        // (the first launch warms up and is not counted)
     (void)hipEventRecord(e0, c->stream);
     hipLaunchKernelGGL(k_hbm_copy, dim3(blocks), dim3(256), 0, c->stream, (const uint4*)(it & 1 ? b : a), (uint4*)(it & 1 ? a : b), (uint64_t)(bytes / 16));

@@ -160,8 +160,11 @@ class BlockVerifier:
     def __init__(self, ctx: Context, bp_gens: BulletproofGens, batches_in_flight: int = 0, chunk: int = 0):
         self.ctx, self.lib, self.bp_gens = ctx, ctx.lib, bp_gens
         self.h = C.c_void_p()
-        ctx._check(self.lib.zkgpu_verifier_create(ctx.h, bp_gens.points.h, bp_gens.gens_capacity, batches_in_flight,
-                                                  C.byref(self.h)))
+        rc = self.lib.zkgpu_verifier_create(ctx.h, bp_gens.points.h, bp_gens.gens_capacity, batches_in_flight, C.byref(self.h))
+        # ZKGPU_WSECOND_VERIFIER (1): created, with a warning -- another verifier is alive on this device
+        self.warning = self.lib.zkgpu_verifier_last_error(self.h).decode() if rc == 1 else ""
+        if rc != 1:
+            ctx._check(rc)
         self._runs = {}
         if chunk:
             self._check(self.lib.zkgpu_verifier_set_chunk(self.h, chunk))
