@@ -331,3 +331,50 @@ def load_tx_fixture():
         pos += 4 + n
     assert pos == len(raw)
     return txs
+
+
+def built_transactions(count: int, call: int = 0, bad_every: int = 64, threads: int = 0):
+    """`count` DISTINCT signed 2-in/2-out payment transactions for the serialized-transaction legs of bench.py and their
+    tests (no call may repeat transactions): transaction i wraps proof (i + 131 call) mod 1024 of the committed
+    cloak fixture with keys, anchors, recipients and nonce of its own -- seed = SHA-256("zkvm_amd tx|call|i") -- built by the
+    PRODUCT's builder (csrc/zkvm_tx_build.hpp through libzkhost: byte-identical to the oracle's, tests/test_zkvm_tx.py).
+    count // bad_every of them are damaged at DRAWN positions (SHAKE256 of the call number), one byte each, the kind
+    cycling: proof, signature scalar, signature nonce, a key inside the program, the header's maxtime.
+    -> (list of transactions, expected accept bits by construction; the tests hold them against the oracle)"""
+    import ctypes as C
+    import hashlib
+    import struct
+    from zkvm_amd.build import HOST_OUT, build
+    build()
+    host = C.CDLL(HOST_OUT)
+    host.zkhost_tx_wrap_many.restype = C.c_int
+    recs, n_in, n_out, plen = load_cloak_fixture()
+    pick = [(i + 131 * call) % len(recs) for i in range(count)]
+    coms = b"".join(recs[p][0] for p in pick)
+    proofs = b"".join(recs[p][1] for p in pick)
+    seeds = b"".join(hashlib.sha256(b"zkvm_amd tx|%d|%d" % (call, i)).digest() for i in range(count))
+    cap = count * (plen + 1024)
+    out = C.create_string_buffer(cap)
+    offs = (C.c_uint64 * (count + 1))()
+    rc = host.zkhost_tx_wrap_many(C.c_size_t(count), C.c_size_t(n_in), C.c_size_t(n_out), coms, proofs, C.c_size_t(plen), seeds,
+                                  C.c_uint64(1000 + 100000 * call), C.c_uint64(10 ** 12), C.c_int(threads), out, C.c_size_t(cap), offs)
+    assert rc == 0
+    blob = out.raw[: offs[count]]
+    txs = [blob[offs[i]: offs[i + 1]] for i in range(count)]
+    expected = [1] * count
+    if bad_every:
+        raw = hashlib.shake_256(b"zkvm_amd tx damage|%d" % call).digest(8 * count)
+        bad, k = {}, 0
+        while len(bad) < max(1, count // bad_every) and k < count:
+            pos = int.from_bytes(raw[8 * k: 8 * k + 4], "little") % count
+            bad.setdefault(pos, len(bad) % 5)
+            k += 1
+        for pos, kind in bad.items():
+            t = bytearray(txs[pos])
+            prog_len = struct.unpack("<I", t[24:28])[0]
+            sig_at = 28 + prog_len
+            at = {0: len(t) - 40, 1: sig_at + 35, 2: sig_at + 3, 3: 28 + 5 + 32 + 7, 4: 16}[kind]
+            t[at] ^= 1 << (raw[8 * pos + 5] % 8 if kind != 1 else 0)
+            txs[pos] = bytes(t)
+            expected[pos] = 0
+    return txs, expected

@@ -134,3 +134,84 @@ def test_host_worker_pool_under_tsan(tmp_path):
     p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
     assert p.returncode == 0 and "ThreadSanitizer" not in p.stderr, p.stderr[-4000:]
+
+
+TXCALL_MAIN = r"""
+// drives zkhost_txcall_selftest (hostlib.cpp: TxCall on the stand-in device) from a file the test wrote:
+//   u64 batch | u64 blob bytes | offsets[batch + 1] u64 | proof_ok[batch] | expected[batch] | blob
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+extern "C" int zkhost_txcall_selftest(size_t, const uint8_t*, const uint64_t*, const uint8_t*, int, size_t, uint32_t, int, uint8_t*, uint8_t*,
+                                      size_t*, size_t*, size_t*);
+int main(int argc, char** argv) {
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  uint64_t batch = 0, blob_len = 0;
+  if (fread(&batch, 8, 1, f) != 1 || fread(&blob_len, 8, 1, f) != 1) return 2;
+  std::vector<uint64_t> offs(batch + 1);
+  std::vector<uint8_t> proof_ok(batch), expected(batch), blob(blob_len);
+  if (fread(offs.data(), 8, batch + 1, f) != batch + 1 || fread(proof_ok.data(), 1, batch, f) != batch ||
+      fread(expected.data(), 1, batch, f) != batch || fread(blob.data(), 1, blob_len, f) != blob_len) return 2;
+  fclose(f);
+  std::vector<uint8_t> bm((batch + 7) / 8 + 1), st(batch);
+  size_t nc = 0, ns = 0, leaked = 0;
+  const size_t chunks[] = {0, 8, 16, 24};
+  for (int round = 0; round < 4; ++round) {
+    int rc = zkhost_txcall_selftest(batch, blob.data(), offs.data(), proof_ok.data(), 4, chunks[round], 40u + round, -1, bm.data(), st.data(), &nc, &ns, &leaked);
+    if (rc != 0 || leaked != 0) { printf("round %d: rc %d leaked %zu\n", round, rc, leaked); return 1; }
+    for (uint64_t i = 0; i < batch; ++i)
+      if (((bm[i / 8] >> (i % 8)) & 1) != expected[i]) { printf("round %d: bit %llu differs\n", round, (unsigned long long)i); return 1; }
+  }
+  // faults: every third device operation of a many-chunk call
+  for (int k = 0; k < 40; k += 3) {
+    int rc = zkhost_txcall_selftest(batch, blob.data(), offs.data(), proof_ok.data(), 4, 16, 90u + k, k, bm.data(), st.data(), &nc, &ns, &leaked);
+    if (leaked != 0) { printf("fault %d: leaked %zu\n", k, leaked); return 1; }
+    if (rc != 0) for (uint64_t i = 0; i < (batch + 7) / 8; ++i) if (bm[i]) { printf("fault %d: a bit survived\n", k); return 1; }
+  }
+  printf("txcall ok\n");
+  return 0;
+}
+"""
+
+
+def _txcall_input(path, count=72):
+    import struct
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import built_transactions
+    txs, expected = built_transactions(count, call=11, bad_every=8)
+    clean, _ = built_transactions(count, call=11, bad_every=0)
+    proof_ok = []
+    for a, b in zip(txs, clean):
+        plen = struct.unpack("<I", b[24:28])[0]
+        proof_ok.append(0 if a[28 + plen + 64:] != b[28 + plen + 64:] else 1)
+    blob = b"".join(txs)
+    offs = [0]
+    for t in txs:
+        offs.append(offs[-1] + len(t))
+    with open(path, "wb") as f:
+        f.write(struct.pack("<QQ", count, len(blob)) + struct.pack("<%dQ" % (count + 1), *offs) + bytes(proof_ok) + bytes(expected) + blob)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_transaction_call_scheduling_under_tsan_and_asan(tmp_path, sanitizer):
+    """csrc/tx_call.hpp -- the two threads of a zkgpu_tx_verify_batch call, their flags, the ring of staging areas, the stage
+    slots, the error paths -- under ThreadSanitizer and under AddressSanitizer + UBSan, on the stand-in device whose stages
+    complete on threads of their own after random delays ("no CPU-side test of its scheduling"): one-chunk and
+    many-chunk calls with the verdicts checked, then device faults injected along a many-chunk call."""
+    lib = "libtsan.so" if sanitizer == "thread" else "libasan.so"
+    have = subprocess.run(["gcc", "-print-file-name=" + lib], capture_output=True, text=True).stdout.strip()
+    if not (os.path.isabs(have) and os.path.exists(have)):
+        pytest.skip("gcc has no %s here" % lib)
+    main = tmp_path / "main.cpp"
+    main.write_text(TXCALL_MAIN)
+    exe = tmp_path / "txcall_san"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + sanitizer, "-fno-omit-frame-pointer", "-pthread", str(main),
+                    os.path.join(ROOT, "zkvm_amd", "csrc", "hostlib.cpp"), "-o", str(exe)], check=True)
+    data = tmp_path / "txs.bin"
+    _txcall_input(str(data))
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    p = subprocess.run([str(exe), str(data)], capture_output=True, text=True, timeout=800, env=env)
+    assert p.returncode == 0 and "txcall ok" in p.stdout and "Sanitizer" not in p.stderr, (p.stdout[-1500:], p.stderr[-4000:])

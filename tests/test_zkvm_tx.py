@@ -181,6 +181,94 @@ def test_long_programs_beyond_the_old_fixed_capacities_agree_with_the_oracle(hos
             assert got[1] == txid and (got[2], got[3]) == (wa, wb) == (2, 2), name
 
 
+def test_product_builder_makes_the_oracle_builders_bytes(host, oracle):
+    """csrc/zkvm_tx_build.hpp (what bench.py and the GPU tests make their distinct transactions with) against the oracle's
+    separate builder: the same bytes for the same proof and seed, for several shapes; and the transactions of
+    gpu_util.built_transactions -- distinct, 1 in 64 damaged at drawn positions -- get the verdict their construction
+    says from the oracle's Tx::verify."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from gpu_util import built_transactions, load_mixed_fixture
+    host.zkhost_tx_wrap_payment.restype = C.c_size_t
+    fix = load_mixed_fixture()
+    for (n_in, n_out), recs in sorted(fix.items()):
+        for k in (0, 7):
+            com, proof = recs[k]
+            seed = hashlib.sha256(b"builder %d %d %d" % (n_in, n_out, k)).digest()
+            want = oracle.tx_wrap_payment(n_in, n_out, com, proof, seed, mintime=5 + k, maxtime=10 ** 9)
+            out = C.create_string_buffer(len(want) + 64)
+            n = host.zkhost_tx_wrap_payment(C.c_size_t(n_in), C.c_size_t(n_out), com, proof, C.c_size_t(len(proof)), seed, C.c_uint64(5 + k),
+                                            C.c_uint64(10 ** 9), out, C.c_size_t(len(want) + 64))
+            assert n == len(want) and out.raw[:n] == want, (n_in, n_out, k)
+    txs, expected = built_transactions(192, call=3, bad_every=16)
+    assert len(set(txs)) == 192 and expected.count(0) == 12
+    r = hashlib.shake_256(b"built").digest(64)
+    for i in list(range(0, 192, 17)) + [i for i, e in enumerate(expected) if not e]:
+        assert (oracle.tx_verify(txs[i], r) == 0) == bool(expected[i]), i
+    assert not set(built_transactions(64, call=4, bad_every=0)[0]) & set(txs)          # another call: other transactions
+
+
+def _txcall(host, txs, proof_ok, chunk, seed, fail_at=-1, threads=4):
+    blob = b"".join(txs)
+    offs = (C.c_uint64 * (len(txs) + 1))()
+    for i, t in enumerate(txs):
+        offs[i + 1] = offs[i] + len(t)
+    n = len(txs)
+    bm, st = C.create_string_buffer((n + 7) // 8 + 1), C.create_string_buffer(n)
+    nc, ns, leaked = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    rc = host.zkhost_txcall_selftest(C.c_size_t(n), blob, offs, bytes(proof_ok), C.c_int(threads), C.c_size_t(chunk), C.c_uint32(seed),
+                                     C.c_int(fail_at), bm, st, C.byref(nc), C.byref(ns), C.byref(leaked))
+    return rc, [(bm.raw[i // 8] >> (i % 8)) & 1 for i in range(n)], list(st.raw), nc.value, ns.value, leaked.value
+
+
+def test_scheduling_of_a_transaction_call_on_a_stand_in_device(host, oracle):
+    """csrc/tx_call.hpp (what zkgpu_tx_verify_batch runs on the GPU) driven on the CPU by a stand-in device whose stages
+    finish on threads of their own after random delays (hostlib.cpp: HostTxDevice -- aggregated keys and signature
+    equations with the reference group arithmetic, cloak proofs by a table): one chunk (proofs first) and many chunks (keys
+    first; more chunks than ring slots; several signature stages), ragged last chunks, transactions of other shapes and
+    damaged ones in every part, unsupported ones -- every accept bit and status byte as constructed; then a device fault
+    injected at EVERY device operation in turn: an error, all-zero outputs, no hang, every staged chunk released."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from gpu_util import built_transactions
+    txs, expected = built_transactions(150, call=9, bad_every=8)
+    # kinds 0 (proof) are the only ones the stand-in cannot see by itself: they go into its table
+    proof_ok = [1] * len(txs)
+    clean, _ = built_transactions(150, call=9, bad_every=0)
+    for i, (a, b) in enumerate(zip(txs, clean)):
+        plen = struct.unpack("<I", b[24:28])[0]
+        if a[28 + plen + 64:] != b[28 + plen + 64:]:
+            proof_ok[i] = 0
+    assert 2 <= proof_ok.count(0) <= 6 and expected.count(0) == 18
+    txs[5] = payment(oracle, 1, 2, 77)                                    # other shapes in between
+    txs[77] = payment(oracle, 3, 2, 78, two_flavors=True)
+    txs[100] = txs[100][:8] + b"\x00" * 8 + txs[100][16:]                 # (mintime 0: still valid? no -- the txid changes: rejected)
+    expected[100] = 0
+    t = bytearray(txs[120]); t[0] = 2; txs[120] = bytes(t)                # a later version: outside the subset
+    expected[120] = 0
+    want_status = [0 if e else 1 for e in expected]
+    want_status[120] = 2
+    for chunk, seed in ((0, 1), (8, 2), (16, 3), (24, 4), (40, 5), (64, 6), (1000, 7)):
+        rc, bits_, st, nc, ns, leaked = _txcall(host, txs, proof_ok, chunk, seed)
+        assert rc == 0 and leaked == 0, (chunk, rc)
+        assert bits_ == expected, (chunk, [i for i in range(len(txs)) if bits_[i] != expected[i]])
+        assert st == want_status, chunk
+        if chunk == 8:
+            assert nc == 19 and ns >= 1                                   # more chunks than ring slots (6)
+    # a fault at every device operation of a many-chunk call, and of a one-chunk call
+    for chunk in (16, 0):
+        ops, k = 0, 0
+        while True:
+            rc, bits_, st, nc, ns, leaked = _txcall(host, txs[:64], proof_ok[:64], chunk, 100 + k, fail_at=k)
+            if rc == 0:
+                assert bits_ == expected[:64]
+                break
+            assert rc == -3 and not any(bits_) and 0 not in st and leaked == 0, (chunk, k)
+            k += 1
+            assert k < 200
+        assert k >= (9 if chunk else 5), (chunk, k)                       # that many device operations could fail
+
+
 def test_committed_transaction_fixture_is_what_the_oracle_accepts(host, oracle):
     """tests/golden/tx_2x2_1024_wrappers.bin (+ the committed cloak proofs): a sample verifies under the oracle, and the
     product's host half reads the same transaction IDs out of all 1024."""

@@ -7,6 +7,7 @@
 // prover calls in flight on two contexts) waits for its turn; a process forked after the pool was made runs with
 // threads of its own.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -138,5 +139,15 @@ class HostPool {
   uint64_t gen_ = 0;
   bool stop_ = false;
 };
+
+// f(i) for i < n on up to `threads` host threads (0: usable_cpus(): affinity mask and control-group quota)
+inline void host_parallel(size_t n, int threads, const std::function<void(size_t)>& f) {
+  const int nt = (int)std::max<size_t>(1, std::min<size_t>(n / 16 + 1, (size_t)std::min<int>(threads > 0 ? threads : usable_cpus(), 256)));
+  if (nt <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+  if (HostPool::get().run(n, std::min(nt, HostPool::MAX_WORKERS + 1), f)) return;
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { for (size_t i = (size_t)t; i < n; i += (size_t)nt) f(i); });
+  for (auto& t : th) t.join();
+}
 
 }  // namespace zk

@@ -799,3 +799,245 @@ extern "C" int zkhost_tx_prepare_group(const uint8_t* txs, const uint64_t* offs,
   }
   return x8_available() ? 1 : 0;
 }
+
+// ---- building transactions (zkvm_tx_build.hpp): what bench.py and the tests feed zkgpu_tx_verify_batch with -----------
+#include "zkvm_tx_build.hpp"
+#include <thread>
+
+// one signed payment around an existing cloak proof -> its length (0: it does not fit `cap`, or the arities are outside 1..16)
+extern "C" size_t zkhost_tx_wrap_payment(size_t n_in, size_t n_out, const uint8_t* com, const uint8_t* proof, size_t proof_len,
+                                         const uint8_t seed[32], uint64_t mintime, uint64_t maxtime, uint8_t* out, size_t cap) {
+  const std::vector<uint8_t> tx = zk::zkvm::tx_wrap_payment(n_in, n_out, com, proof, proof_len, seed, mintime, maxtime);
+  if (tx.empty() || tx.size() > cap) return 0;
+  std::memcpy(out, tx.data(), tx.size());
+  return tx.size();
+}
+
+// `count` of them on `threads` threads: statement i = coms[i] (64 (n_in + n_out) bytes), proofs[i] (proof_len bytes), seeds[i]
+// (32 bytes), mintime = mintime0 + i; the transactions back to back in `out`, offsets[count + 1].  -> 0, or -1 (one did not
+// build or `cap` is too small)
+extern "C" int zkhost_tx_wrap_many(size_t count, size_t n_in, size_t n_out, const uint8_t* coms, const uint8_t* proofs, size_t proof_len,
+                                   const uint8_t* seeds, uint64_t mintime0, uint64_t maxtime, int threads, uint8_t* out, size_t cap,
+                                   uint64_t* offsets) {
+  std::vector<std::vector<uint8_t>> made(count);
+  (void)zk::zkvm::base_table();                       // (built before the threads start)
+  const int nt = std::max(1, std::min<int>(threads > 0 ? threads : zk::usable_cpus(), 64));
+  std::vector<std::thread> th;
+  const size_t wcom = 64 * (n_in + n_out);
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      for (size_t i = (size_t)t; i < count; i += (size_t)nt)
+        made[i] = zk::zkvm::tx_wrap_payment(n_in, n_out, coms + i * wcom, proofs + i * proof_len, proof_len, seeds + 32 * i, mintime0 + i, maxtime);
+    });
+  for (auto& t : th) t.join();
+  offsets[0] = 0;
+  for (size_t i = 0; i < count; ++i) {
+    if (made[i].empty()) return -1;
+    offsets[i + 1] = offsets[i] + made[i].size();
+  }
+  if (offsets[count] > cap) return -1;
+  for (size_t i = 0; i < count; ++i) std::memcpy(out + offsets[i], made[i].data(), made[i].size());
+  return 0;
+}
+
+// ---- the scheduling of a transaction call on the CPU (tx_call.hpp) ----------------------------------------------------
+// zkgpu_tx_verify_batch = TxCall + a device.  Here the device is a stand-in: every stage "runs" on a thread of its own that
+// first sleeps a pseudo-random while (so that completions arrive in every order the real device could produce) and then
+// computes the stage with this library's reference group arithmetic -- aggregated keys and signature equations for real,
+// cloak proofs by a table the caller supplies (proof_ok[i]: this test is about the scheduling, and the reference R1CS
+// verifier takes 30 ms per proof).  The sanitizer tier runs it under ThreadSanitizer and AddressSanitizer: flags, ring,
+// stage cuts, hand-overs, the error paths (fail_at: the n-th device operation fails) -- no GPU involved.
+#include "tx_call.hpp"
+#include <atomic>
+#include <random>
+
+namespace {
+using namespace zk::zkvm;
+
+void ge_scalarmult_host(ge& out, const Scalar& s, const ge& p) {
+  uint8_t b[32];
+  s.to_bytes(b);
+  ge_identity(out);
+  for (int i = 255; i >= 0; --i) {
+    ge_double(out, out);
+    if ((b[i >> 3] >> (i & 7)) & 1) ge_add(out, out, p);
+  }
+}
+bool decode_host(ge& p, const uint8_t enc[32]) {
+  uint32_t w[8];
+  std::memcpy(w, enc, 32);
+  return ristretto_decode(p, w);
+}
+
+class HostTxDevice : public TxDevice {
+ public:
+  HostTxDevice(const uint8_t* txs, const uint64_t* offs, size_t batch, const uint8_t* proof_ok, uint32_t seed, int fail_at)
+      : txs_(txs), offs_(offs), batch_(batch), proof_ok_(proof_ok), rng_(seed), fail_at_(fail_at) {
+    ge B;
+    B.X = fe_BASE_X(); B.Y = fe_BASE_Y(); B.Z = fe_one(); B.T = fe_BASE_T();
+    encode_point(base_, B);
+  }
+  ~HostTxDevice() override {
+    for (auto& s : keys_) if (s.th.joinable()) s.th.join();
+    for (auto& s : sigs_) if (s.th.joinable()) s.th.join();
+  }
+  const uint8_t* basepoint() override { return base_; }
+  int keys_enqueue(int slot, const uint8_t* sc, const uint8_t* pt, const uint64_t* off, size_t rows) override {
+    if (failing()) return -3;
+    Stage& s = keys_[slot];
+    if (s.th.joinable()) { err_ = "key slot reused before it was collected"; return -1; }
+    s.done = false;
+    s.ok.assign((rows + 7) / 8 + 1, 0);
+    s.values.assign(32 * rows, 0);
+    const unsigned us = delay();
+    s.th = std::thread([=, &s] {
+      std::this_thread::sleep_for(std::chrono::microseconds(us));
+      for (size_t r = 0; r < rows; ++r) {
+        ge acc;
+        ge_identity(acc);
+        bool ok = true;
+        for (uint64_t t = off[r]; t < off[r + 1]; ++t) {
+          ge X, aX;
+          Scalar a;
+          if (!decode_host(X, pt + 32 * t) || !Scalar::from_canonical(sc + 32 * t, a)) { ok = false; break; }
+          ge_scalarmult_host(aX, a, X);
+          ge_add(acc, acc, aX);
+        }
+        if (ok) { s.ok[r / 8] |= (uint8_t)(1u << (r % 8)); encode_point(&s.values[32 * r], acc); }
+      }
+      s.done = true;
+    });
+    return 0;
+  }
+  bool keys_done(int slot) override { return keys_[slot].done; }
+  int keys_collect(int slot, uint8_t* ok_bits, uint8_t* values) override {
+    Stage& s = keys_[slot];
+    if (!s.th.joinable()) { err_ = "nothing to collect in this key slot"; return -1; }
+    s.th.join();
+    if (failing()) return -3;
+    std::memcpy(ok_bits, s.ok.data(), s.ok.size() - 1);
+    std::memcpy(values, s.values.data(), s.values.size());
+    return 0;
+  }
+  int proofs_stage(size_t ring_slot, size_t n, const TxProofSource* src, int, void** handle, std::string* err) override {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (ring_busy_[ring_slot]) { *err = "ring slot staged while its last chunk is still in flight"; return -1; }
+      ring_busy_[ring_slot] = true;
+      ++staged_total_;
+    }
+    Proofs* p = new Proofs();
+    p->ring_slot = ring_slot;
+    p->src.assign(src, src + n);
+    *handle = p;
+    return 0;
+  }
+  int proofs_start(size_t ring_slot, void* handle) override {
+    Proofs* p = (Proofs*)handle;
+    if (p->ring_slot != ring_slot) { err_ = "chunk started on another ring slot than it was staged in"; return -1; }
+    if (failing()) return -3;
+    p->bits.assign((p->src.size() + 7) / 8 + 1, 0);
+    const unsigned us = delay();
+    p->th = std::thread([this, p, us] {
+      std::this_thread::sleep_for(std::chrono::microseconds(us));
+      for (size_t q = 0; q < p->src.size(); ++q) {
+        // which transaction of the call does this proof belong to?  (the proof lies inside its bytes)
+        const uint64_t at = (uint64_t)(p->src[q].proof - txs_);
+        size_t lo = 0, hi = batch_;
+        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (offs_[mid] <= at) lo = mid; else hi = mid; }
+        if (proof_ok_[lo]) p->bits[q / 8] |= (uint8_t)(1u << (q % 8));
+      }
+    });
+    return 0;
+  }
+  int proofs_finish(void* handle, uint8_t* accept_bits) override {
+    Proofs* p = (Proofs*)handle;
+    if (p->th.joinable()) p->th.join();
+    const bool fail = failing();
+    if (!fail) std::memcpy(accept_bits, p->bits.data(), p->bits.size() - 1);
+    proofs_release(handle);
+    return fail ? -3 : 0;
+  }
+  void proofs_release(void* handle) override {
+    Proofs* p = (Proofs*)handle;
+    if (p->th.joinable()) p->th.join();
+    { std::lock_guard<std::mutex> lk(mu_); ring_busy_[p->ring_slot] = false; ++released_total_; }
+    delete p;
+  }
+  int sigs_enqueue(int slot, size_t rows, const uint8_t* dsc, const uint8_t* dpt, const uint64_t* doff, const uint8_t* bsc) override {
+    if (failing()) return -3;
+    Stage& s = sigs_[slot];
+    if (s.th.joinable()) { err_ = "signature slot reused before it was collected"; return -1; }
+    s.ok.assign((rows + 7) / 8 + 1, 0);
+    const unsigned us = delay();
+    s.th = std::thread([=, &s] {
+      std::this_thread::sleep_for(std::chrono::microseconds(us));
+      for (size_t r = 0; r < rows; ++r) {
+        Scalar sb;
+        if (!Scalar::from_canonical(bsc + 32 * r, sb)) continue;
+        ge acc;
+        base_mul(acc, sb);
+        bool ok = true;
+        for (uint64_t t = doff[r]; t < doff[r + 1]; ++t) {
+          ge X, aX;
+          Scalar a;
+          if (!decode_host(X, dpt + 32 * t) || !Scalar::from_canonical(dsc + 32 * t, a)) { ok = false; break; }
+          ge_scalarmult_host(aX, a, X);
+          ge_add(acc, acc, aX);
+        }
+        if (ok && ge_is_identity(acc)) s.ok[r / 8] |= (uint8_t)(1u << (r % 8));
+      }
+    });
+    return 0;
+  }
+  int sigs_collect(int slot, uint8_t* bits) override {
+    Stage& s = sigs_[slot];
+    if (!s.th.joinable()) { err_ = "nothing to collect in this signature slot"; return -1; }
+    s.th.join();
+    if (failing()) return -3;
+    std::memcpy(bits, s.ok.data(), s.ok.size() - 1);
+    return 0;
+  }
+  std::string last_error() override { return err_.empty() ? "injected device fault" : err_; }
+  size_t leaked() { std::lock_guard<std::mutex> lk(mu_); return staged_total_ - released_total_; }
+
+ private:
+  struct Stage { std::thread th; std::atomic<bool> done{false}; std::vector<uint8_t> ok, values; };
+  struct Proofs { size_t ring_slot = 0; std::vector<TxProofSource> src; std::vector<uint8_t> bits; std::thread th; };
+  unsigned delay() { std::lock_guard<std::mutex> lk(mu_); return (unsigned)(rng_() % 400); }
+  bool failing() { return fail_at_ >= 0 && ops_.fetch_add(1) == fail_at_; }
+  const uint8_t* txs_;
+  const uint64_t* offs_;
+  size_t batch_;
+  const uint8_t* proof_ok_;
+  std::mutex mu_;
+  std::mt19937 rng_;
+  const int fail_at_;
+  std::atomic<int> ops_{0};
+  Stage keys_[2], sigs_[2];
+  bool ring_busy_[TxCall::RING] = {false};
+  size_t staged_total_ = 0, released_total_ = 0;
+  uint8_t base_[32];
+  std::string err_;
+};
+}  // namespace
+
+// -> the call's return code; *n_chunks, *n_sig_stages: what was planned; *leaked: staged chunks never released (must be 0)
+extern "C" int zkhost_txcall_selftest(size_t batch, const uint8_t* txs, const uint64_t* offs, const uint8_t* proof_ok, int host_threads,
+                                      size_t chunk, uint32_t delay_seed, int fail_at, uint8_t* accept_bitmap, uint8_t* status,
+                                      size_t* n_chunks, size_t* n_sig_stages, size_t* leaked) {
+  std::memset(accept_bitmap, 0, (batch + 7) / 8);
+  std::memset(status, TX_INVALID, batch);
+  std::vector<TxStatement> store;
+  HostTxDevice dev(txs, offs, batch, proof_ok, delay_seed, fail_at);
+  int rc;
+  {
+    TxCall call(dev, store, (size_t)1 << 17, batch, txs, offs, host_threads, chunk, accept_bitmap, status);
+    *n_chunks = call.n_chunks();
+    *n_sig_stages = call.n_sig_stages_planned();
+    rc = call.run();
+  }
+  *leaked = dev.leaked();
+  if (rc != 0) std::memset(accept_bitmap, 0, (batch + 7) / 8);
+  return rc;
+}

@@ -13,6 +13,7 @@
 // the library loads and every single-GPU entry point works on a machine without it.
 #pragma once
 #include "comm_frame.hpp"
+#include "tx_call.hpp"
 #include "zkvm_tx.hpp"
 
 #include <deque>
@@ -406,7 +407,7 @@ size_t zkgpu_txblock_shapes(const zkgpu_txblock* b) { return b ? b->groups.size(
 namespace {
 
 // One transaction of a block being staged: where its commitments (64 (n_in + n_out) bytes) and its proof lie in host memory
-struct TxSource { uint32_t n_in, n_out; const uint8_t* com; const uint8_t* proof; uint64_t proof_len; };
+using TxSource = zk::zkvm::TxProofSource;
 
 // groups the transactions by (inputs, outputs, proof length), lays the groups out and gathers them on host threads into
 // the staging image (the arena's pinned memory, or a buffer of the block's own): host work only -- apart from the first
@@ -1266,29 +1267,6 @@ int zkgpu_verifier_set_tx_format(zkgpu_verifier* v, int format) {
 
 namespace {
 
-// One chunk of a zkgpu_tx_verify_batch call on its way through the stages (see below)
-struct TxChunk {
-  size_t lo = 0, n = 0, index = 0;                      // transactions [lo, lo + n) of the call; which chunk
-  size_t g0 = 0;                                        // live transactions of the call before this chunk
-  std::vector<size_t> live;                             // positions in the chunk the VM accepted
-  // cloak proofs (every live transaction: the signature verdict is ANDed in at the end)
-  zkgpu_txblock* blk = nullptr;
-  zkgpu_verifier::BlockRun* run = nullptr;
-  std::vector<uint8_t> pbits;
-  int stage_rc = 0;                                     // what staging its statements came to (staging thread)
-  std::string stage_err;
-};
-
-// The signature equations of a run of chunks: made when their transaction IDs and the call's aggregated keys are both there
-struct TxSigStage {
-  size_t first = 0, last = 0;                           // chunks [first, last)
-  std::vector<size_t> keyed;                            // global live indices of the transactions whose keys all decode
-  std::vector<uint64_t> soff, sst_off;
-  std::vector<uint8_t> ssc, spt, sst, bits;
-  std::vector<uint32_t> sidx;
-  bool pending = false, queued = false;
-};
-
 // host arrays -> the context's input buffers -> kernels and result copy queued (batch_device_enqueue, value mode);
 // msm_values_collect finishes.  The arrays must stay alive until then; the context is marked busy meanwhile.
 int msm_values_enqueue(zkgpu_ctx* c, const uint8_t* scalars, const uint8_t* points, const uint64_t* offsets, size_t batch) {
@@ -1374,37 +1352,81 @@ int zkgpu_verifier_set_tx_chunk(zkgpu_verifier* v, size_t transactions) {
   return ZKGPU_OK;
 }
 
-// The call is cut into chunks of ~3000 transactions that travel through four stages, the host's share of one chunk
-// beside the device's share of the others.  TWO host threads drive it:
-//   the staging thread (made for the call; its loops run on the worker pool): per chunk the wire format, the VM, contract
-//     ids, transaction ID, the (a_i, X_i) rows and s, R of the signature; the cloak statements of the chunk's live
-//     transactions gathered into a pinned staging area; and, whenever the calling thread hands it a chunk whose
-//     aggregated keys have arrived, the signature transcripts c = H(txid, X, R) and the rows of the equations;
-//   the calling thread: everything that talks to the device, queued asynchronously -- per chunk
-//     keys      X = sum a_i X_i per transaction, as encodings                                               [aux_keys]
-//     proofs    one copy of the staged statements to HBM, the chunk's batches on the verifier's lanes        [lanes]
-//     sigs      the equations s B - R - sum (c a_i) X_i == identity                                          [aux_sigs]
-// and the verdicts are collected at the end: accept = the VM accepted & the keys decode & the signature holds & the
-// proof verifies.  (The proofs of a chunk do not wait for its signatures: a transaction whose signature fails has its
-// proof verified for nothing -- that is the rare case -- and in exchange nothing on the device waits for a host round trip.)
-int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, const uint64_t* tx_offsets, int host_threads,
-                          uint8_t* accept_bitmap, uint8_t* status) {
-  using namespace zk::zkvm;
-  if (!v || !accept_bitmap) return ZKGPU_EINVAL;
-  memset(accept_bitmap, 0, (batch + 7) / 8);
-  if (status) memset(status, TX_INVALID, batch);
-  if (batch == 0) return ZKGPU_OK;
-  if (!txs || !tx_offsets || batch >= (1ull << 31)) return ZKGPU_EINVAL;
-  for (size_t i = 0; i < batch; ++i) if (tx_offsets[i + 1] < tx_offsets[i]) return ZKGPU_EINVAL;
-  std::lock_guard<std::mutex> vlk(v->mu);
-  if (v->tx_format != ZKGPU_TXFORMAT_RECOLLECTED_V1) {            // no format enabled: nothing is inside the subset
-    if (status) memset(status, TX_UNSUPPORTED, batch);
+namespace {
+
+// The device side of a transaction call (tx_call.hpp: TxDevice) on a verifier: key stages on aux_keys[slot], signature
+// stages on aux_sigs[slot] (contexts of their own, each a pair of streams beside the lanes'), cloak proofs as blocks of
+// mixed shapes on the lanes, staged through the verifier's ring of pinned / device areas.  v->mu is held by the call.
+static_assert(zk::zkvm::TxCall::OK == ZKGPU_OK && zk::zkvm::TxCall::ENOMEM_ == ZKGPU_ENOMEM, "tx_call.hpp restates two status codes");
+class GpuTxDevice : public zk::zkvm::TxDevice {
+ public:
+  explicit GpuTxDevice(zkgpu_verifier* v) : v_(v) {}
+  const uint8_t* basepoint() override { return v_->basepoint; }
+  int keys_enqueue(int slot, const uint8_t* scalars, const uint8_t* points, const uint64_t* offsets, size_t rows) override {
+    return seen(msm_values_enqueue(v_->aux_keys[slot], scalars, points, offsets, rows), v_->aux_keys[slot]);
+  }
+  bool keys_done(int slot) override { return split_done(v_->aux_keys[slot]); }
+  int keys_collect(int slot, uint8_t* ok_bits, uint8_t* values) override { return seen(split_collect(v_->aux_keys[slot], ok_bits, values), v_->aux_keys[slot]); }
+  // (staging thread: touches the plans -- plans_mu -- the given arena and nothing else of the verifier)
+  int proofs_stage(size_t ring_slot, size_t n, const zk::zkvm::TxProofSource* src, int host_threads, void** handle, std::string* err) override {
+    zkgpu_txblock* blk = nullptr;
+    const int rc = txblock_stage_host(v_, n, src, nullptr, host_threads, &blk, &v_->tx_arenas[ring_slot], err);
+    if (rc != ZKGPU_OK) return rc;
+    Staged* st = new Staged();
+    st->blk = blk;
+    *handle = st;
     return ZKGPU_OK;
   }
-  const bool timing = getenv("ZKGPU_PROVER_TIMING") != nullptr;
-  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t00 = now();
-  double t_vm = 0, t_stage = 0, t_keys = 0, t_sigs = 0, t_wait = 0, t_wait_host = 0;
+  int proofs_start(size_t ring_slot, void* handle) override {
+    Staged* st = (Staged*)handle;
+    // one copy to HBM, and the chunk's batches queued on the lanes
+    int rc = txblock_upload(v_, st->blk, &v_->tx_arenas[ring_slot]);
+    if (rc != ZKGPU_OK) { err_ = v_->last_error; return rc; }
+    // a chunk of one shape goes to the device as few, large batches (measured: the last chunk in batches short enough for
+    // the one-wavefront-per-transaction transcript, or cut in two, does not shorten the tail of the call)
+    const size_t saved_chunk = v_->chunk;
+    v_->chunk = std::max<size_t>(saved_chunk, 4096);
+    st->run = block_start(v_, st->blk);
+    v_->chunk = saved_chunk;
+    if (st->run->rc != ZKGPU_OK) { err_ = v_->last_error; return st->run->rc; }     // (proofs_finish still collects what was queued)
+    return ZKGPU_OK;
+  }
+  int proofs_finish(void* handle, uint8_t* accept_bits) override {
+    Staged* st = (Staged*)handle;
+    int rc = ZKGPU_OK;
+    if (st->run) { rc = block_finish(v_, st->run, accept_bits); if (rc != ZKGPU_OK) err_ = v_->last_error; }
+    proofs_release(handle);
+    return rc;
+  }
+  void proofs_release(void* handle) override {
+    Staged* st = (Staged*)handle;
+    if (st->blk) zkgpu_txblock_destroy(st->blk);
+    delete st;
+  }
+  int sigs_enqueue(int slot, size_t rows, const uint8_t* dyn_scalars, const uint8_t* dyn_points, const uint64_t* dyn_offsets,
+                   const uint8_t* base_scalars) override {
+    // one term per row on the resident set's tables: index 0 = the basepoint B
+    sidx_[slot].assign(rows, 0);
+    soff_[slot].resize(rows + 1);
+    for (size_t q = 0; q <= rows; ++q) soff_[slot][q] = q;
+    return seen(verify_ps_enqueue(v_->aux_sigs[slot], v_->ps, rows, dyn_scalars, dyn_points, dyn_offsets, base_scalars, sidx_[slot].data(),
+                                  soff_[slot].data()), v_->aux_sigs[slot]);
+  }
+  int sigs_collect(int slot, uint8_t* bits) override { return seen(split_collect(v_->aux_sigs[slot], bits, nullptr), v_->aux_sigs[slot]); }
+  std::string last_error() override { return err_; }
+
+ private:
+  struct Staged { zkgpu_txblock* blk = nullptr; zkgpu_verifier::BlockRun* run = nullptr; };
+  int seen(int rc, zkgpu_ctx* where) { if (rc != ZKGPU_OK) err_ = zkgpu_last_error(where); return rc; }
+  zkgpu_verifier* v_;
+  std::vector<uint32_t> sidx_[2];
+  std::vector<uint64_t> soff_[2];
+  std::string err_;
+};
+
+// what a transaction call needs of the verifier before it starts (v->mu held): nothing in flight on the lanes, the stage
+// contexts, the basepoint's encoding, the ring of staging areas
+int tx_call_prepare(zkgpu_verifier* v) {
   zkgpu_ctx* c = v->root;
   // the lanes' batches in flight are collected first: the call owns the verifier (tickets and runs keep their verdicts)
   while (!v->block_busy.empty()) block_collect(v, v->block_busy.front());
@@ -1440,430 +1462,44 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     if (rc != ZKGPU_OK) { v->last_error = zkgpu_last_error(v->aux_keys[0]); return rc; }
     v->have_basepoint = true;
   }
-  const uint8_t* B = v->basepoint;
-  constexpr size_t RING = 6;
-  if (v->tx_arenas.size() < RING) v->tx_arenas.resize(RING);
-  // chunk boundaries: equal chunks of at most 8192 transactions (4096 when the call is longer than 16 384;
-  // zkgpu_verifier_set_tx_chunk overrides).  Measured with the two-pass staging below, 4096 / 8192 / 16 384 / 32 768 per call:
-  // chunks of 3072 with a short last one 4.1 / 6.0 / 9.7 / 16.7-19 ms, of 4096: 3.5 / 5.7 / 9.3 / 16.2-18, of 8192: 3.5 / 5.65 / 9.1 /
-  // 18 -- a chunk's proofs are one device batch, and longer batches are the more efficient ones; the first pass is cheap
-  // enough (0.6 ms per 8192) for the device not to wait long for the first.
-  std::vector<size_t> cuts{0};
-  {
-    const size_t chunk = v->tx_chunk ? v->tx_chunk : (batch <= 16384 ? 8192 : 4096);
-    const size_t parts = (batch + chunk - 1) / chunk;
-    for (size_t q = 1; q < parts; ++q) cuts.push_back(v->tx_chunk ? std::min(batch, q * chunk) : batch * q / parts);
-    cuts.push_back(batch);
-    // (multiples of eight: the groups of eight the VM hashes in lockstep are then the same in both passes, and none
-    // straddles the end of the verifier's statement store)
-    for (size_t q = 1; q + 1 < cuts.size(); ++q) cuts[q] = std::max(cuts[q - 1], cuts[q] & ~(size_t)7);
-    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
-    if (cuts.size() < 2) cuts = {0, batch};
-  }
-  const size_t n_chunks = cuts.size() - 1;
-  std::vector<std::unique_ptr<TxChunk>> ck(n_chunks);
-  const size_t kept = v->tx_statements_kept & ~(size_t)7;          // (a multiple of eight: see the chunk boundaries)
-  if (v->tx_statements.size() > kept) { v->tx_statements.resize(kept); v->tx_statements.shrink_to_fit(); }
-  if (v->tx_statements.size() < std::min(batch, kept)) v->tx_statements.resize(std::min(batch, kept));
-  std::vector<TxStatement> st_beyond(batch > v->tx_statements.size() ? batch - v->tx_statements.size() : 0);
-  auto statement = [&](size_t i) -> TxStatement& { return i < v->tx_statements.size() ? v->tx_statements[i] : st_beyond[i - v->tx_statements.size()]; };
-  for (size_t ci = 0; ci < n_chunks; ++ci) {
-    ck[ci].reset(new TxChunk());
-    TxChunk& k = *ck[ci];
-    k.lo = cuts[ci]; k.n = cuts[ci + 1] - cuts[ci]; k.index = ci;
-  }
-  int first_rc = ZKGPU_OK;
-  auto note = [&](int rc, zkgpu_ctx* where) { if (rc != ZKGPU_OK && first_rc == ZKGPU_OK) { first_rc = rc; if (where) v->last_error = zkgpu_last_error(where); } return rc; };
-  auto mark = [&](const char* what, size_t ci) { if (timing) fprintf(stderr, "    %7.3f ms  %s %zu\n", (now() - t00) * 1e3, what, ci); };
-
-  // ---- key stages: one per chunk (X = sum a_i X_i for the chunk's transactions, after a VM pass that goes as far as the keys
-  // and their MuSig coefficients); the signature equations follow in stages over RUNS of chunks (~10 000 transactions; the
-  // last run's last chunk on its own), when the runs' keys are back and their transaction IDs are made.  All boundaries
-  // depend on the size of the call alone: the same call made again has stages of the same sizes, and the stage contexts'
-  // buffers, grown once, are never grown again (hipMalloc waits for the device).
-  struct Segment {
-    size_t c_lo = 0, c_hi = 0;                            // chunks
-    size_t g_lo = 0, g_hi = 0;                            // live transactions of the call (positions in live_all)
-    std::vector<uint64_t> koff;                           // rows (a_i, X_i) per live transaction
-    std::vector<uint8_t> ksc, kpt, kok;
-    bool pending = false;
-  };
-  std::vector<Segment> seg(n_chunks);                    // one key stage per chunk
-  for (size_t c = 0; c < n_chunks; ++c) { seg[c].c_lo = c; seg[c].c_hi = c + 1; }
-  const size_t n_seg = seg.size();
-  // signature stages: runs of chunks of ~10 000 transactions in all, the last run's last chunk on its own
-  struct SigPlan { size_t first, last; };
-  std::vector<SigPlan> sig_plan, groups;                 // groups: the runs themselves -- the staging thread's unit of work
-  {
-    size_t c = 0;
-    while (c < n_chunks) {
-      const size_t first = c;
-      size_t count = 0;
-      while (c < n_chunks && (count == 0 || count + ck[c]->n <= 10240 + 1536)) { count += ck[c]->n; ++c; }
-      groups.push_back({first, c});
-      if (c == n_chunks && c - first > 1) { sig_plan.push_back({first, c - 1}); sig_plan.push_back({c - 1, c}); }
-      else sig_plan.push_back({first, c});
-    }
-  }
-  // ---- what the two threads share (under hm).  key_rows[s]: the rows of segment s are made; keys_arrived[s]: the calling
-  // thread has its encodings back; staged[ci]: chunk ci has been through the VM and its statements are in arena ci % RING;
-  // arena_free[ci]: its proofs have been collected (the arena may be reused); sig_stages: the signature stages made so
-  // far (the calling thread queues stage s once n_sig_stages > s); all_sigs_made; quit.
-  std::mutex hm;
-  std::condition_variable hcv;
-  std::vector<char> staged(n_chunks, 0), arena_free(n_chunks, 0), key_rows(n_seg, 0), keys_arrived(n_seg, 0);
-  bool all_sigs_made = false, quit = false;
-  std::vector<std::unique_ptr<TxSigStage>> sig_stages;
-  sig_stages.reserve(sig_plan.size());                   // the calling thread indexes it while the staging thread appends: it must never move
-  size_t n_sig_stages = 0;
-  double t_keys_host = 0, t_sig_host = 0, t_stage_host = 0;
-  std::vector<size_t> live_all;                          // transactions the VM accepts, in call order (staging thread appends)
-  live_all.reserve(batch);
-  std::vector<uint8_t> agg(32 * std::max<size_t>(batch, 1), 0), key_ok(batch, 0);   // per live transaction: X, "its keys all decode"
-
-  auto sig_rows = [&](TxSigStage& sg) {                 // transcripts + rows of the equations of chunks [first, last) (staging thread)
-    const size_t g_lo = ck[sg.first]->g0, g_hi = ck[sg.last - 1]->g0 + ck[sg.last - 1]->live.size();
-    sg.keyed.clear();
-    for (size_t g = g_lo; g < g_hi; ++g) if (key_ok[g]) sg.keyed.push_back(g);
-    const size_t ns = sg.keyed.size();
-    sg.bits.assign((ns + 7) / 8 + 1, 0);
-    if (ns == 0) return;
-    sg.soff.assign(ns + 1, 0);
-    for (size_t q = 0; q < ns; ++q) sg.soff[q + 1] = sg.soff[q] + statement(live_all[sg.keyed[q]]).sig_scalars.size() / 32 - 1;
-    sg.ssc.resize(32 * sg.soff.back()); sg.spt.resize(32 * sg.soff.back());
-    sg.sst.resize(32 * ns);
-    sg.sidx.assign(ns, 0);
-    sg.sst_off.resize(ns + 1);
-    for (size_t q = 0; q <= ns; ++q) sg.sst_off[q] = q;
-    host_parallel((ns + 7) / 8, host_threads, [&](size_t g) {              // eight challenges c = H(txid, X, R) at a time
-      TxStatement* tp[8];
-      const uint8_t* ap[8];
-      const size_t first = 8 * g, cnt = std::min<size_t>(8, ns - first);
-      for (size_t q = 0; q < cnt; ++q) { tp[q] = &statement(live_all[sg.keyed[first + q]]); ap[q] = &agg[32 * sg.keyed[first + q]]; }
-      tx_finish_signature_many(tp, ap, B, cnt);
-      for (size_t q = first; q < first + cnt; ++q) {
-        const TxStatement& t = *tp[q - first];
-        memcpy(&sg.sst[32 * q], t.sig_scalars.data(), 32);
-        memcpy(sg.ssc.data() + 32 * sg.soff[q], t.sig_scalars.data() + 32, t.sig_scalars.size() - 32);
-        memcpy(sg.spt.data() + 32 * sg.soff[q], t.sig_points.data() + 32, t.sig_points.size() - 32);
-      }
-    });
-  };
-  // the signature stages that are due: their chunks' transaction IDs made, their segment's keys back (staging thread; hm
-  // held on entry and on return)
-  size_t sig_next = 0, hashed_upto = 0;
-  auto keys_back = [&](const SigPlan& sp) { for (size_t c = sp.first; c < sp.last; ++c) if (!keys_arrived[c]) return false; return true; };
-  auto make_sig_stages = [&](std::unique_lock<std::mutex>& lk, size_t ids_upto) {
-    while (!quit && sig_next < sig_plan.size() && sig_plan[sig_next].last <= ids_upto && keys_back(sig_plan[sig_next])) {
-      std::unique_ptr<TxSigStage> sg(new TxSigStage());
-      sg->first = sig_plan[sig_next].first; sg->last = sig_plan[sig_next].last;
-      ++sig_next;
-      lk.unlock();
-      const double t0 = now();
-      sig_rows(*sg);
-      const double dt = now() - t0;
-      lk.lock();
-      t_sig_host += dt;
-      sig_stages.push_back(std::move(sg));
-      ++n_sig_stages;
-      if (sig_next == sig_plan.size()) all_sigs_made = true;
-      hcv.notify_all();
-    }
-  };
-  bool stager_failed = false;                            // (under hm) out of host memory on the staging thread: the call fails
-  // A call that is ONE chunk (up to 8192 transactions) sends its proofs first: theirs is the longest chain, and what they
-  // need is known once the VM's stack machine has run, before anything is hashed (measured, 4096 / 8192 per call: 3.7 -> 3.2,
-  // 5.5 -> 5.1 ms).  A longer call keeps "keys, then proofs" per chunk: with proofs of earlier chunks on the device, key
-  // kernels queued behind a chunk's proofs wait too long (32 768 per call: 16.5 -> 18.4 ms the other way round).
-  const bool proofs_first = n_chunks == 1;
-  auto staging = [&] {
-   for (const SigPlan& grp : groups) {                   // a run of chunks: keys and proofs of each on their way, then their IDs
-    for (size_t sI = grp.first; sI < grp.last; ++sI) {
-      Segment& sgm = seg[sI];
-      TxChunk& k = *ck[sI];                               // (one key stage per chunk)
-      const size_t t_lo = k.lo, t_hi = k.lo + k.n;
-      auto vm_pass = [&](uint8_t only) {                  // the VM over the chunk, hashing the jobs of `only` alone
-        const double t0 = now();
-        host_parallel((t_hi - t_lo + 7) / 8, host_threads, [&](size_t g) {
-          const uint8_t* p[8];
-          size_t l[8];
-          const size_t first = t_lo + 8 * g, cnt = std::min<size_t>(8, t_hi - first);
-          for (size_t q = 0; q < cnt; ++q) { p[q] = txs + tx_offsets[first + q]; l[q] = (size_t)(tx_offsets[first + q + 1] - tx_offsets[first + q]); }
-          // (consecutive statements: the store's, or the overflow's -- a group of eight never straddles the two: chunk
-          // boundaries and the store's cap are multiples of eight)
-          tx_prepare_many(p, l, &statement(first), cnt, true, only);
-        });
-        std::lock_guard<std::mutex> lk(hm);
-        t_keys_host += now() - t0;
-      };
-      auto scan = [&] {                                   // which transactions the VM accepts
-        sgm.g_lo = k.g0 = live_all.size();
-        for (size_t i = 0; i < k.n; ++i) {
-          const TxStatement& t = statement(k.lo + i);
-          if (status && t.status == TX_UNSUPPORTED) status[k.lo + i] = TX_UNSUPPORTED;     // (TX_OK is written at the very end only)
-          if (t.status == TX_OK) { k.live.push_back(i); live_all.push_back(k.lo + i); }
-        }
-        k.pbits.assign((k.live.size() + 7) / 8 + 1, 0);
-        sgm.g_hi = live_all.size();
-      };
-      auto key_rows_out = [&] {                           // rows (a_i, X_i) of the chunk's aggregated keys -> the calling thread
-        const double t0 = now();
-        const size_t nl = sgm.g_hi - sgm.g_lo;
-        sgm.kok.assign((nl + 7) / 8 + 1, 0);
-        sgm.koff.assign(nl + 1, 0);
-        for (size_t j = 0; j < nl; ++j) sgm.koff[j + 1] = sgm.koff[j] + statement(live_all[sgm.g_lo + j]).sig_scalars.size() / 32 - 2;
-        sgm.ksc.resize(32 * sgm.koff.back()); sgm.kpt.resize(32 * sgm.koff.back());
-        host_parallel(nl, host_threads, [&](size_t j) {
-          const TxStatement& t = statement(live_all[sgm.g_lo + j]);
-          memcpy(sgm.ksc.data() + 32 * sgm.koff[j], t.sig_scalars.data() + 64, t.sig_scalars.size() - 64);
-          memcpy(sgm.kpt.data() + 32 * sgm.koff[j], t.sig_points.data() + 64, t.sig_points.size() - 64);
-        });
-        std::lock_guard<std::mutex> lk(hm);
-        t_keys_host += now() - t0;
-        key_rows[sI] = 1;
-        hcv.notify_all();
-      };
-      auto gather = [&]() -> bool {                       // the chunk's cloak statements into its staging area; false: the call is over
-        {
-          std::unique_lock<std::mutex> lk(hm);
-          if (sI >= RING) hcv.wait(lk, [&] { return quit || arena_free[sI - RING]; });
-          if (quit) return false;
-        }
-        const double t1 = now();
-        const size_t nl = k.live.size();
-        if (nl) {
-          std::vector<TxSource> src(nl);
-          for (size_t q = 0; q < nl; ++q) {
-            const TxStatement& t = statement(k.lo + k.live[q]);
-            src[q] = TxSource{t.n_in, t.n_out, t.commitments.data(), t.proof, t.proof_len};
-          }
-          k.stage_rc = txblock_stage_host(v, nl, src.data(), nullptr, host_threads, &k.blk, &v->tx_arenas[sI % RING], &k.stage_err);
-        }
-        const double t2 = now();
-        if (timing) fprintf(stderr, "    staging thread, chunk %zu: gather %.3f ms\n", sI, (t2 - t1) * 1e3);
-        std::unique_lock<std::mutex> lk(hm);
-        t_stage_host += t2 - t1;
-        staged[sI] = 1;
-        hcv.notify_all();
-        return true;
-      };
-      // what the proofs need -- arity, commitments, proof bytes -- is known once the VM's stack machine has run; the keys
-      // X_i and their MuSig coefficients a_i after the plan's MuSig jobs have; everything else (contract ids, anchors, the
-      // transaction ID) only the signature transcripts wait for: the second pass below
-      if (proofs_first) {
-        vm_pass(NO_PROTO);
-        scan();
-        if (!gather()) return;
-        vm_pass(P_MUSIG);
-        key_rows_out();
-      } else {
-        vm_pass(P_MUSIG);
-        scan();
-        key_rows_out();
-        if (!gather()) return;
-      }
-    }
-    // ---- second pass, chunk by chunk: everything else the VM hashes (contract ids, anchors, the transaction ID), which
-    // the signature transcripts wait for -- after the keys and proofs of every chunk of the run are on their way
-    {
-      for (size_t ci = grp.first; ci < grp.last; ++ci) {
-        TxChunk& k = *ck[ci];
-        {
-          std::unique_lock<std::mutex> lk(hm);
-          make_sig_stages(lk, ci);
-          if (quit) return;
-        }
-        const double t0 = now();
-        // eight transactions per task: the hashing of transactions of one shape runs in lockstep on AVX-512 (zkvm_tx.hpp,
-        // tx_prepare_many; merlin_x8.hpp)
-        host_parallel((k.n + 7) / 8, host_threads, [&](size_t g) {
-          const uint8_t* p[8];
-          size_t l[8];
-          const size_t first = 8 * g, cnt = std::min<size_t>(8, k.n - first);
-          for (size_t q = 0; q < cnt; ++q) { p[q] = txs + tx_offsets[k.lo + first + q]; l[q] = (size_t)(tx_offsets[k.lo + first + q + 1] - tx_offsets[k.lo + first + q]); }
-          tx_prepare_many(p, l, &statement(k.lo + first), cnt);
-        });
-        const double t1 = now();
-        if (timing) fprintf(stderr, "    staging thread, chunk %zu: VM %.3f ms\n", ci, (t1 - t0) * 1e3);
-        std::unique_lock<std::mutex> lk(hm);
-        t_vm += t1 - t0;
-        hashed_upto = ci + 1;
-      }
-    }
-   }
-    std::unique_lock<std::mutex> lk(hm);
-    for (;;) {
-      make_sig_stages(lk, hashed_upto);
-      if (quit || all_sigs_made) return;
-      hcv.wait(lk, [&] { return quit || keys_back(sig_plan[sig_next]); });
-    }
-  };
-  std::thread stager;
-  try {
-    stager = std::thread([&] {
-      try {
-        staging();
-      } catch (...) {                                    // std::bad_alloc in practice: an error for the call, not the end of the process
-        std::lock_guard<std::mutex> lk(hm);
-        stager_failed = true;
-        hcv.notify_all();
-      }
-    });
-  } catch (...) {                                        // no thread to be had: an error for the call as well
-    v->last_error = "the staging thread of the call could not be started";
-    return ZKGPU_ENOMEM;
-  }
-  struct StagerJoin {                                    // whatever way the call ends, the thread is told and waited for
-    std::mutex& m; std::condition_variable& cv; bool& quit; std::thread& th;
-    ~StagerJoin() { { std::lock_guard<std::mutex> lk(m); quit = true; } cv.notify_all(); if (th.joinable()) th.join(); }
-  } stager_join{hm, hcv, quit, stager};
-
-  auto keys_collect = [&](size_t sI) {
-    Segment& sgm = seg[sI];
-    if (sgm.pending) {
-      sgm.pending = false;
-      const double t0 = now();
-      note(split_collect(v->aux_keys[sI & 1], sgm.kok.data(), agg.data() + 32 * sgm.g_lo), v->aux_keys[sI & 1]);
-      t_wait += now() - t0;
-      for (size_t j = 0; j < sgm.g_hi - sgm.g_lo; ++j) key_ok[sgm.g_lo + j] = (sgm.kok[j / 8] >> (j % 8)) & 1;
-      mark("keys collected, segment", sI);
-    }
-  };
-  auto sigs_collect = [&](size_t si) {
-    TxSigStage& sg = *sig_stages[si];
-    if (!sg.pending) return;
-    sg.pending = false;
-    const double t0 = now();
-    note(split_collect(v->aux_sigs[si & 1], sg.bits.data(), nullptr), v->aux_sigs[si & 1]);
-    t_wait += now() - t0;
-    mark("signatures collected, stage", si);
-  };
-  auto proofs_collect = [&](TxChunk& k) {
-    if (k.run) {
-      const double t0 = now();
-      const int rc = block_finish(v, k.run, k.pbits.data());
-      k.run = nullptr;
-      if (rc != ZKGPU_OK && first_rc == ZKGPU_OK) first_rc = rc;
-      t_wait += now() - t0;
-      mark("proofs collected, chunk at", k.lo);
-    }
-    if (k.blk) { zkgpu_txblock_destroy(k.blk); k.blk = nullptr; }
-    std::lock_guard<std::mutex> lk(hm);
-    arena_free[k.index] = 1;
-    hcv.notify_all();
-  };
-  auto enqueue_proofs = [&](size_t ci) {
-    TxChunk& k = *ck[ci];
-    mark("staged, chunk", ci);
-    if (k.stage_rc != ZKGPU_OK) { if (first_rc == ZKGPU_OK) { first_rc = k.stage_rc; v->last_error = k.stage_err; } return; }
-    if (k.live.empty()) return;
-    // one copy to HBM, and the chunk's batches queued on the lanes
-    const double t0 = now();
-    if (note(txblock_upload(v, k.blk, &v->tx_arenas[ci % RING]), nullptr) == ZKGPU_OK) {
-      // a chunk of one shape goes to the device as few, large batches (measured: the last chunk in batches short enough for
-      // the one-wavefront-per-transaction transcript, or cut in two, does not shorten the tail of the call)
-      const size_t saved_chunk = v->chunk;
-      v->chunk = std::max<size_t>(saved_chunk, 4096);
-      k.run = block_start(v, k.blk);
-      v->chunk = saved_chunk;
-      if (k.run->rc != ZKGPU_OK) note(k.run->rc, nullptr);
-    }
-    t_stage += now() - t0;
-    mark("proofs queued, chunk", ci);
-  };
-  // The calling thread never waits for one thing while another could be queued: it looks, in turn, for the key rows of a
-  // segment (its key stage goes out, before any of its proofs: what follows the keys is a chain, keys -> host transcripts ->
-  // equations, and queued behind the proofs' chip-filling kernels its short kernels would wait for CUs), for a chunk the
-  // staging thread has finished (its proofs go out), for aggregated keys that have arrived (the staging thread is told),
-  // and for signature stages that are ready (the equations go out); with nothing to do it sleeps until the staging thread
-  // has news, 50 us at most (what the device has finished is found out by asking).
-  size_t next_key = 0, next_kcollect = 0, next_stage = 0, next_sig = 0;
-  while (first_rc == ZKGPU_OK) {
-    bool progress = false, sigs_all, rows = false, st_ready = false;
-    size_t sig_avail;
-    {
-      std::lock_guard<std::mutex> lk(hm);
-      if (stager_failed) { first_rc = ZKGPU_ENOMEM; v->last_error = "out of host memory while staging the transactions"; break; }
-      sig_avail = n_sig_stages; sigs_all = all_sigs_made;
-      if (next_key < n_seg) rows = key_rows[next_key] != 0;
-      if (next_stage < n_chunks) st_ready = staged[next_stage] != 0;
-    }
-    if (next_kcollect == n_seg && next_stage == n_chunks && sigs_all && next_sig == sig_avail) break;
-    if (rows && (next_key < 2 || next_kcollect + 2 > next_key)) {           // (its context is free once segment next_key - 2 is collected)
-      Segment& sgm = seg[next_key];
-      mark("key rows ready, segment", next_key);
-      const double t0 = now();
-      if (sgm.g_hi > sgm.g_lo) {
-        zkgpu_ctx* kc = v->aux_keys[next_key & 1];
-        if (note(msm_values_enqueue(kc, sgm.ksc.data(), sgm.kpt.data(), sgm.koff.data(), sgm.g_hi - sgm.g_lo), kc) == ZKGPU_OK) sgm.pending = true;
-      }
-      t_keys += now() - t0;
-      mark("keys queued, segment", next_key);
-      ++next_key;
-      progress = true;
-    }
-    if (first_rc == ZKGPU_OK && next_stage < n_chunks && (proofs_first || next_stage < next_key)) {     // (a chunk's proofs after its keys, unless the call is one chunk)
-      if (next_stage >= RING && !arena_free[next_stage - RING]) proofs_collect(*ck[next_stage - RING]);
-      if (st_ready) { enqueue_proofs(next_stage++); progress = true; }
-    }
-    if (first_rc == ZKGPU_OK && next_kcollect < next_key && (!seg[next_kcollect].pending || split_done(v->aux_keys[next_kcollect & 1]))) {
-      keys_collect(next_kcollect);
-      { std::lock_guard<std::mutex> lk(hm); keys_arrived[next_kcollect] = 1; }
-      hcv.notify_all();
-      ++next_kcollect;
-      progress = true;
-    }
-    while (first_rc == ZKGPU_OK && next_sig < sig_avail) {
-      TxSigStage& sg = *sig_stages[next_sig];
-      const double t0 = now();
-      if (next_sig >= 2) sigs_collect(next_sig - 2);                // (the stage that used this context last)
-      const size_t ns = sg.keyed.size();
-      if (ns) {
-        zkgpu_ctx* sc = v->aux_sigs[next_sig & 1];
-        if (note(verify_ps_enqueue(sc, v->ps, ns, sg.ssc.data(), sg.spt.data(), sg.soff.data(), sg.sst.data(), sg.sidx.data(), sg.sst_off.data()), sc) == ZKGPU_OK)
-          sg.pending = true;
-      }
-      sg.queued = true;
-      t_sigs += now() - t0;
-      mark("signatures queued, stage", next_sig);
-      ++next_sig;
-      progress = true;
-    }
-    if (!progress) {
-      std::unique_lock<std::mutex> lk(hm);
-      const double t0 = now();
-      hcv.wait_for(lk, std::chrono::microseconds(50));
-      t_wait_host += now() - t0;
-    }
-  }
-  {
-    std::lock_guard<std::mutex> lk(hm);
-    quit = true;
-  }
-  hcv.notify_all();
-  stager.join();
-  for (size_t sI = 0; sI < n_seg; ++sI) keys_collect(sI);   // (only after an error: nothing is left pending on the contexts)
-  for (size_t si = 0; si < sig_stages.size(); ++si) sigs_collect(si);
-  for (size_t ci = 0; ci < n_chunks; ++ci) proofs_collect(*ck[ci]);
-  if (timing) fprintf(stderr, "tx verify: %zu transactions in %zu chunks: staging thread: keys pass %.2f ms, VM + ids %.2f ms, gather %.2f ms, signature "
-                              "transcripts %.2f ms (%zu stages); calling thread: idle %.2f ms, queueing keys %.2f, proofs %.2f, signatures %.2f ms, "
-                              "waiting for the device %.2f ms; %.2f ms in all\n",
-                      batch, n_chunks, t_keys_host * 1e3, t_vm * 1e3, t_stage_host * 1e3, t_sig_host * 1e3, sig_stages.size(), t_wait_host * 1e3,
-                      t_keys * 1e3, t_stage * 1e3, t_sigs * 1e3, t_wait * 1e3, (now() - t00) * 1e3);
-  if (first_rc != ZKGPU_OK) return first_rc;             // both outputs still read "nothing accepted"
-  std::vector<uint8_t> sig_ok(live_all.size(), 0);
-  for (const auto& sg : sig_stages)
-    for (size_t q = 0; q < sg->keyed.size(); ++q) if ((sg->bits[q / 8] >> (q % 8)) & 1) sig_ok[sg->keyed[q]] = 1;
-  for (size_t ci = 0; ci < n_chunks; ++ci) {
-    const TxChunk& k = *ck[ci];
-    for (size_t j = 0; j < k.live.size(); ++j) {
-      if (!sig_ok[k.g0 + j] || !((k.pbits[j / 8] >> (j % 8)) & 1)) continue;
-      const size_t i = k.lo + k.live[j];
-      accept_bitmap[i / 8] |= (uint8_t)(1u << (i % 8));
-      if (status) status[i] = TX_OK;
-    }
-  }
+  if (v->tx_arenas.size() < zk::zkvm::TxCall::RING) v->tx_arenas.resize(zk::zkvm::TxCall::RING);
   return ZKGPU_OK;
+}
+
+}  // namespace
+
+// The scheduling of a call -- chunks, stages, the staging thread and the calling thread -- is csrc/tx_call.hpp (TxCall); the
+// device side is GpuTxDevice above.  The calling thread is the one that talks to the device.
+int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, const uint64_t* tx_offsets, int host_threads,
+                          uint8_t* accept_bitmap, uint8_t* status) {
+  using namespace zk::zkvm;
+  if (!v || !accept_bitmap) return ZKGPU_EINVAL;
+  memset(accept_bitmap, 0, (batch + 7) / 8);
+  if (status) memset(status, TX_INVALID, batch);
+  if (batch == 0) return ZKGPU_OK;
+  if (!txs || !tx_offsets || batch >= (1ull << 31)) return ZKGPU_EINVAL;
+  for (size_t i = 0; i < batch; ++i) if (tx_offsets[i + 1] < tx_offsets[i]) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> vlk(v->mu);
+  if (v->tx_format != ZKGPU_TXFORMAT_RECOLLECTED_V1) {            // no format enabled: nothing is inside the subset
+    if (status) memset(status, TX_UNSUPPORTED, batch);
+    return ZKGPU_OK;
+  }
+  TRY(tx_call_prepare(v));
+  GpuTxDevice dev(v);
+  int rc;
+  try {
+    TxCall call(dev, v->tx_statements, v->tx_statements_kept, batch, txs, tx_offsets, host_threads, v->tx_chunk, accept_bitmap, status);
+    rc = call.run();
+    if (rc != ZKGPU_OK) v->last_error = call.error_text();
+  } catch (const std::bad_alloc&) {
+    v->last_error = "out of host memory while planning the transaction call";
+    rc = ZKGPU_ENOMEM;
+  }
+  if (rc != ZKGPU_OK) {                                          // both outputs read "nothing accepted"
+    memset(accept_bitmap, 0, (batch + 7) / 8);
+    if (status) for (size_t i = 0; i < batch; ++i) if (status[i] == TX_OK) status[i] = TX_INVALID;
+  }
+  return rc;
 }
 
 }  // extern "C"

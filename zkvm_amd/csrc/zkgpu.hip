@@ -1952,15 +1952,7 @@ int ipa_on_device(zkgpu_ctx* c, const zkgpu_pointset* ps, std::vector<std::uniqu
 }
 
 // ---- the device prover ------------------------------------------------------------------------------------
-// f(i) for i < n on up to `threads` host threads (0: usable_cpus(): affinity mask and control-group quota)
-void host_parallel(size_t n, int threads, const std::function<void(size_t)>& f) {
-  const int nt = (int)std::max<size_t>(1, std::min<size_t>(n / 16 + 1, (size_t)std::min<int>(threads > 0 ? threads : usable_cpus(), 256)));
-  if (nt <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
-  if (HostPool::get().run(n, std::min(nt, HostPool::MAX_WORKERS + 1), f)) return;
-  std::vector<std::thread> th;
-  for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { for (size_t i = (size_t)t; i < n; i += (size_t)nt) f(i); });
-  for (auto& t : th) t.join();
-}
+// (host_parallel: host_pool.hpp)
 
 // values of `rows` multiscalar multiplications over the tables, everything resident: queued on the context's stream,
 // encodings written to d_out (32 bytes per row)
