@@ -167,7 +167,7 @@ struct TxPlan {
     shape.push_back(0x4b000000u | ((uint32_t)chal_label << 8) | out_len);
     return j.out_slot;
   }
-  bool same_shape(const TxPlan& o) const { return shape.size() == o.shape.size() && std::memcmp(shape.data(), o.shape.data(), 4 * shape.size()) == 0; }
+  bool same_shape(const TxPlan& o) const { return shape.size() == o.shape.size() && (shape.empty() || std::memcmp(shape.data(), o.shape.data(), 4 * shape.size()) == 0); }
 };
 
 inline const uint8_t* piece_bytes(const TxPlan& P, const HashPiece& h, const uint8_t* slots) {
