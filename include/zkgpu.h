@@ -529,6 +529,18 @@ int zkgpu_verifier_set_tx_chunk(zkgpu_verifier *v, size_t transactions);
 int zkgpu_verifier_set_tx_statements_kept(zkgpu_verifier *v, size_t transactions);
 int zkgpu_tx_verify_batch(zkgpu_verifier *v, size_t batch, const uint8_t *txs, const uint64_t *tx_offsets, int host_threads,
                           uint8_t *accept_bitmap, uint8_t *status);
+/* Calls in flight (upstream's Tx::verify is pure and callable from many threads: SURVEY.md sec 8(b)).  zkgpu_tx_verify_submit
+ * queues a call and returns its id at once; an engine thread of the verifier runs everything that is queued as ONE merged
+ * call (up to 16 384 transactions per round: calls that arrive while a round runs make up the next one -- dynamic batching,
+ * as tickets do for proofs), and zkgpu_tx_verify_wait blocks until that call's round is done and writes ITS accept bitmap and
+ * status bytes (status may be NULL).  txs and tx_offsets must stay valid until the call has been waited for; every id is
+ * waited for exactly once.  Same verdicts, same opt-in format, same fail-closed rule as zkgpu_tx_verify_batch: a round that
+ * fails gives every call in it the error and all-zero outputs.  Safe to call from many threads.  zkgpu_tx_verify_stats:
+ * out[0] rounds run so far, out[1] calls they held. */
+int zkgpu_tx_verify_submit(zkgpu_verifier *v, size_t batch, const uint8_t *txs, const uint64_t *tx_offsets, int host_threads,
+                           uint64_t *call_id);
+int zkgpu_tx_verify_wait(zkgpu_verifier *v, uint64_t call_id, uint8_t *accept_bitmap, uint8_t *status);
+int zkgpu_tx_verify_stats(zkgpu_verifier *v, uint64_t out[2]);
 
 /* ---- one process per GPU: sharding and the RCCL exchange ------------------
  * Transactions are independent, so a block is cut into `world` contiguous shards balanced by the

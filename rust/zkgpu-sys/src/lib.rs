@@ -265,6 +265,12 @@ extern "C" {
         v: *mut zkgpu_verifier, batch: usize, txs: *const u8, tx_offsets: *const u64, host_threads: c_int,
         accept_bitmap: *mut u8, status: *mut u8,
     ) -> c_int;
+    pub fn zkgpu_tx_verify_submit(
+        v: *mut zkgpu_verifier, batch: usize, txs: *const u8, tx_offsets: *const u64, host_threads: c_int,
+        call_id: *mut u64,
+    ) -> c_int;
+    pub fn zkgpu_tx_verify_wait(v: *mut zkgpu_verifier, call_id: u64, accept_bitmap: *mut u8, status: *mut u8) -> c_int;
+    pub fn zkgpu_tx_verify_stats(v: *mut zkgpu_verifier, out: *mut u64) -> c_int;
     pub fn zkgpu_debug_comm_mock(
         ctx: *mut zkgpu_ctx, world: c_int, peer_slots: *const u8, slot_bytes: usize,
     ) -> c_longlong;

@@ -481,6 +481,66 @@ def test_a_long_call_travels_through_the_stages_in_chunks(n_tx, tx_chunk, kept):
         ctx.close()
 
 
+@pytest.mark.gpu
+def test_transaction_calls_in_flight_on_one_verifier_keep_their_own_verdicts():
+    """zkgpu_tx_verify_submit / _wait: calls in flight on ONE verifier, merged by its engine into rounds.
+    DISTINCT transactions (gpu_util.built_transactions -- the inputs of bench.py's tx_verify leg: one in 16 damaged at drawn
+    positions here), their constructed expectation held against the oracle's Tx::verify for every damaged one and a sample
+    of the others; 12 calls of 300 submitted from four threads at once, waited for in another order; a synchronous call and
+    a block of cloak proofs between them; a transaction outside the subset and one of another shape keep their own status;
+    the engine has run fewer rounds than calls (they were merged)."""
+    import sys
+    import threading
+    import oracle.binding as oracle
+    sys.path.insert(0, os.path.dirname(__file__))
+    from gpu_util import bits, built_transactions, load_cloak_fixture
+    from zkvm_amd import Context
+    from zkvm_amd.verifier import BulletproofGens, BlockVerifier, CloakTx
+    txs, expected = built_transactions(3600, call=21, bad_every=16)
+    assert len(set(txs)) == 3600
+    r = hashlib.shake_256(b"in flight").digest(64)
+    for i in [i for i, e in enumerate(expected) if not e][:40] + list(range(0, 3600, 211)):
+        assert (oracle.tx_verify(txs[i], r) == 0) == bool(expected[i]), i
+    status = [0 if e else 1 for e in expected]
+    t = bytearray(txs[700]); t[0] = 2; txs[700] = bytes(t); expected[700] = 0; status[700] = 2           # a later version
+    txs[1300] = payment(oracle, 1, 2, 501); expected[1300] = 1; status[1300] = 0                            # another shape in the middle
+    ctx = Context(0)
+    gens = BulletproofGens(ctx, 256, table_bits=10)
+    bv = BlockVerifier(ctx, gens)
+    try:
+        cid = bv.submit_txs(txs[:10])                               # no format named yet: everything is outside the subset
+        bm, st = bv.wait_txs(cid)
+        assert bm == bytes(2) and list(st) == [2] * 10
+        bv.set_tx_format(bv.TXFORMAT_RECOLLECTED_V1)
+        ids = [None] * 12
+        def submit(k):
+            ids[k] = bv.submit_txs(txs[300 * k: 300 * (k + 1)], host_threads=8)
+        th = [threading.Thread(target=lambda a=a: [submit(k) for k in range(a, 12, 4)]) for a in range(4)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        # a synchronous call and a block of proofs while the calls are in flight: they take their turn
+        fix, n_in, n_out, plen = load_cloak_fixture()
+        assert bits(bv.verify([CloakTx(n_in, n_out, *fix[i]) for i in range(50)], hashlib.shake_256(b"blk").digest(64 * 50)), 50) == [1] * 50
+        bm, st = bv.verify_txs(txs[:64], host_threads=8)
+        assert bits(bm, 64) == expected[:64]
+        for k in (11, 3, 0, 7, 1, 2, 4, 5, 6, 8, 9, 10):
+            bm, st = bv.wait_txs(ids[k])
+            assert bits(bm, 300) == expected[300 * k: 300 * (k + 1)], k
+            assert list(st) == status[300 * k: 300 * (k + 1)], k
+        rounds, calls = bv.tx_stats()
+        assert calls == 13 and rounds < calls
+        with pytest.raises(Exception):
+            bv.lib.zkgpu_tx_verify_wait.restype = C.c_int
+            rc = bv.lib.zkgpu_tx_verify_wait(bv.h, ids[0], C.create_string_buffer(64), None)
+            assert rc == 0                                              # an id is waited for once: this is ZKGPU_EINVAL
+    finally:
+        bv.close()
+        gens.close()
+        ctx.close()
+
+
 def test_random_programs_get_the_same_verdict_from_both_implementations(host, oracle):
     """Differential fuzzing of the two independently written VMs (zkvm_tx.hpp, oracle/zkvm_tx.c): random instruction
     sequences over the subset's opcodes (and a few outside it), random immediates, spliced fragments of a valid program --

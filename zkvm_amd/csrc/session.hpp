@@ -97,6 +97,27 @@ struct zkgpu_verifier {
   bool have_basepoint = false;
   std::mutex mu;
   std::string last_error;
+  // zkgpu_tx_verify_submit / _wait: calls in flight.  An engine thread (made at the first submit) takes everything that is
+  // queued and runs it as ONE merged call -- dynamic batching, as tickets do for proofs -- then hands every caller its own
+  // bits.  tx_mu guards the queue and the records; the engine takes `mu` for the length of a round like any other call.
+  struct TxPending {
+    uint64_t id = 0;
+    size_t batch = 0;
+    const uint8_t* txs = nullptr;
+    const uint64_t* offsets = nullptr;
+    int host_threads = 0;
+    int state = 0, rc = 0;                              // 0 queued, 1 in a round, 2 done
+    std::vector<uint8_t> bits, status;
+  };
+  std::mutex tx_mu;
+  std::condition_variable tx_cv;
+  std::deque<TxPending*> tx_queue;
+  std::map<uint64_t, std::unique_ptr<TxPending>> tx_calls;
+  uint64_t tx_next_id = 1;
+  std::thread tx_engine;
+  bool tx_engine_quit = false;
+  size_t tx_merge_max = 16384;                          // transactions per merged round
+  uint64_t tx_rounds = 0, tx_round_calls = 0;           // statistics: rounds run, calls they held (zkgpu_tx_verify_stats)
 };
 
 struct zkgpu_txblock {
@@ -351,6 +372,11 @@ int zkgpu_verifier_create(zkgpu_ctx* ctx, const zkgpu_pointset* ps, size_t gens_
 void zkgpu_verifier_destroy(zkgpu_verifier* v) {
   if (!v) return;
   { std::lock_guard<std::mutex> lk(g_live_verifiers_mu); --g_live_verifiers[v->root->device]; }
+  {                                                      // the engine of the transaction calls in flight: told, and waited for
+    { std::lock_guard<std::mutex> lk(v->tx_mu); v->tx_engine_quit = true; }
+    v->tx_cv.notify_all();
+    if (v->tx_engine.joinable()) v->tx_engine.join();
+  }
   std::vector<uint8_t> scratch;
   (void)drain(v, scratch);
   for (auto& kv : v->requests) delete kv.second;
@@ -1500,6 +1526,127 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
     if (status) for (size_t i = 0; i < batch; ++i) if (status[i] == TX_OK) status[i] = TX_INVALID;
   }
   return rc;
+}
+
+
+// ---- transaction calls in flight -------------------------------------------------------------------------------------------
+// Upstream's Tx::verify is pure and callable from many threads at once; a node's mempool hands over small
+// batches as they arrive.  One call at a time per verifier left a 1024-transaction call at 3 ms -- the latency of a lone
+// device batch -- and a second verifier is not the answer.  zkgpu_tx_verify_submit QUEUES a call and returns;
+// an engine thread of the verifier takes everything queued (up to 16 384 transactions) and runs it as ONE call (TxCall over
+// the pieces): calls that arrive while a round is running are merged into the next one, so that eight callers of 1024 see
+// the throughput of calls of several thousand.  zkgpu_tx_verify_wait blocks until that call's round is done and writes ITS
+// bitmap and status bytes.  The transaction bytes and offsets must stay valid until the call has been waited for.  Verdicts
+// are those of separate calls.  Fail-closed: a round that fails gives every call in it the error and all-zero outputs.
+namespace {
+void tx_engine_main(zkgpu_verifier* v) {
+  using namespace zk::zkvm;
+  for (;;) {
+    std::vector<zkgpu_verifier::TxPending*> round;
+    {
+      std::unique_lock<std::mutex> lk(v->tx_mu);
+      v->tx_cv.wait(lk, [&] { return v->tx_engine_quit || !v->tx_queue.empty(); });
+      if (v->tx_queue.empty()) return;                   // (quit with nothing queued; what is queued at quit is still served)
+      size_t total = 0;
+      while (!v->tx_queue.empty() && (round.empty() || total + v->tx_queue.front()->batch <= v->tx_merge_max)) {
+        round.push_back(v->tx_queue.front());
+        total += round.back()->batch;
+        round.back()->state = 1;
+        v->tx_queue.pop_front();
+      }
+      ++v->tx_rounds; v->tx_round_calls += round.size();
+    }
+    size_t total = 0;
+    int threads = 0;
+    std::vector<TxCall::Piece> pieces;
+    for (auto* p : round) { pieces.push_back({p->txs, p->offsets, p->batch}); total += p->batch; threads = std::max(threads, p->host_threads); }
+    std::vector<uint8_t> bits((total + 7) / 8 + 1, 0), status(total, TX_INVALID);
+    int rc = ZKGPU_OK;
+    std::string err;
+    {
+      std::lock_guard<std::mutex> vlk(v->mu);
+      if (v->tx_format != ZKGPU_TXFORMAT_RECOLLECTED_V1) {
+        std::fill(status.begin(), status.end(), (uint8_t)TX_UNSUPPORTED);
+      } else {
+        rc = tx_call_prepare(v);
+        if (rc == ZKGPU_OK) {
+          GpuTxDevice dev(v);
+          try {
+            TxCall call(dev, v->tx_statements, v->tx_statements_kept, pieces, threads, v->tx_chunk, bits.data(), status.data());
+            rc = call.run();
+            if (rc != ZKGPU_OK) v->last_error = call.error_text();
+          } catch (const std::bad_alloc&) {
+            v->last_error = "out of host memory while planning the transaction call";
+            rc = ZKGPU_ENOMEM;
+          }
+        }
+      }
+    }
+    {
+      std::lock_guard<std::mutex> lk(v->tx_mu);
+      size_t at = 0;
+      for (auto* p : round) {
+        p->bits.assign((p->batch + 7) / 8, 0);
+        p->status.assign(p->batch, TX_INVALID);
+        p->rc = rc;
+        for (size_t i = 0; i < p->batch; ++i) {
+          const size_t g = at + i;
+          if (rc == ZKGPU_OK) {
+            if ((bits[g / 8] >> (g % 8)) & 1) p->bits[i / 8] |= (uint8_t)(1u << (i % 8));
+            p->status[i] = status[g];
+          } else if (status[g] == TX_UNSUPPORTED) {
+            p->status[i] = TX_UNSUPPORTED;
+          }
+        }
+        at += p->batch;
+        p->state = 2;
+      }
+    }
+    v->tx_cv.notify_all();
+  }
+}
+}  // namespace
+
+int zkgpu_tx_verify_submit(zkgpu_verifier* v, size_t batch, const uint8_t* txs, const uint64_t* tx_offsets, int host_threads, uint64_t* call_id) {
+  if (!v || !call_id || batch == 0 || batch >= (1ull << 31) || !txs || !tx_offsets) return ZKGPU_EINVAL;
+  for (size_t i = 0; i < batch; ++i) if (tx_offsets[i + 1] < tx_offsets[i]) return ZKGPU_EINVAL;
+  std::unique_ptr<zkgpu_verifier::TxPending> p(new zkgpu_verifier::TxPending());
+  p->batch = batch; p->txs = txs; p->offsets = tx_offsets; p->host_threads = host_threads;
+  std::lock_guard<std::mutex> lk(v->tx_mu);
+  if (v->tx_engine_quit) return ZKGPU_EINVAL;
+  if (!v->tx_engine.joinable()) {
+    try { v->tx_engine = std::thread(tx_engine_main, v); }
+    catch (...) { return ZKGPU_ENOMEM; }
+  }
+  p->id = v->tx_next_id++;
+  *call_id = p->id;
+  v->tx_queue.push_back(p.get());
+  v->tx_calls[p->id] = std::move(p);
+  v->tx_cv.notify_all();
+  return ZKGPU_OK;
+}
+
+int zkgpu_tx_verify_wait(zkgpu_verifier* v, uint64_t call_id, uint8_t* accept_bitmap, uint8_t* status) {
+  if (!v || !accept_bitmap) return ZKGPU_EINVAL;
+  std::unique_lock<std::mutex> lk(v->tx_mu);
+  auto it = v->tx_calls.find(call_id);
+  if (it == v->tx_calls.end()) return ZKGPU_EINVAL;
+  zkgpu_verifier::TxPending* p = it->second.get();
+  v->tx_cv.wait(lk, [&] { return p->state == 2; });
+  const int rc = p->rc;
+  memset(accept_bitmap, 0, (p->batch + 7) / 8);
+  if (rc == ZKGPU_OK) memcpy(accept_bitmap, p->bits.data(), p->bits.size());
+  if (status) memcpy(status, p->status.data(), p->batch);
+  v->tx_calls.erase(it);
+  return rc;
+}
+
+// out[0] rounds the engine has run, out[1] calls they held in all (calls per round = out[1] / out[0])
+int zkgpu_tx_verify_stats(zkgpu_verifier* v, uint64_t out[2]) {
+  if (!v || !out) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->tx_mu);
+  out[0] = v->tx_rounds; out[1] = v->tx_round_calls;
+  return ZKGPU_OK;
 }
 
 }  // extern "C"

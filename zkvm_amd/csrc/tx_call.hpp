@@ -72,8 +72,22 @@ class TxCall {
   // at most `kept` entries of it are used, the rest of a longer call lives in the call.
   TxCall(TxDevice& dev, std::vector<TxStatement>& store, size_t kept, size_t batch, const uint8_t* txs, const uint64_t* tx_offsets,
          int host_threads, size_t chunk_override, uint8_t* accept_bitmap, uint8_t* status)
-      : dev_(dev), store_(store), batch_(batch), txs_(txs), offs_(tx_offsets), threads_(host_threads), accept_(accept_bitmap),
+      : dev_(dev), store_(store), batch_(batch), threads_(host_threads), accept_(accept_bitmap),
         status_(status), timing_(getenv("ZKGPU_PROVER_TIMING") != nullptr), t00_(now()) {
+    ptr_.resize(batch); len_.resize(batch);
+    for (size_t i = 0; i < batch; ++i) { ptr_[i] = txs + tx_offsets[i]; len_[i] = (size_t)(tx_offsets[i + 1] - tx_offsets[i]); }
+    plan(chunk_override, kept);
+  }
+  // several callers' transactions as ONE call (zkgpu_tx_verify_submit: calls in flight are merged as tickets are): the
+  // pieces in order, transaction i of the merged call = the i-th transaction counted through them
+  struct Piece { const uint8_t* txs; const uint64_t* tx_offsets; size_t batch; };
+  TxCall(TxDevice& dev, std::vector<TxStatement>& store, size_t kept, const std::vector<Piece>& pieces, int host_threads,
+         size_t chunk_override, uint8_t* accept_bitmap, uint8_t* status)
+      : dev_(dev), store_(store), batch_(total_of(pieces)), threads_(host_threads), accept_(accept_bitmap), status_(status),
+        timing_(getenv("ZKGPU_PROVER_TIMING") != nullptr), t00_(now()) {
+    ptr_.reserve(batch_); len_.reserve(batch_);
+    for (const Piece& pc : pieces)
+      for (size_t i = 0; i < pc.batch; ++i) { ptr_.push_back(pc.txs + pc.tx_offsets[i]); len_.push_back((size_t)(pc.tx_offsets[i + 1] - pc.tx_offsets[i])); }
     plan(chunk_override, kept);
   }
   ~TxCall() { stop_stager(); }
@@ -137,6 +151,7 @@ class TxCall {
   };
   struct Span { size_t first, last; };
 
+  static size_t total_of(const std::vector<Piece>& pieces) { size_t n = 0; for (const Piece& p : pieces) n += p.batch; return n; }
   static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   void mark(const char* what, size_t i) const { if (timing_) fprintf(stderr, "    %7.3f ms  %s %zu\n", (now() - t00_) * 1e3, what, i); }
   TxStatement& statement(size_t i) { return i < store_.size() ? store_[i] : beyond_[i - store_.size()]; }
@@ -194,7 +209,7 @@ class TxCall {
       const uint8_t* p[8];
       size_t l[8];
       const size_t first = t_lo + 8 * g, cnt = std::min<size_t>(8, t_hi - first);
-      for (size_t q = 0; q < cnt; ++q) { p[q] = txs_ + offs_[first + q]; l[q] = (size_t)(offs_[first + q + 1] - offs_[first + q]); }
+      for (size_t q = 0; q < cnt; ++q) { p[q] = ptr_[first + q]; l[q] = len_[first + q]; }
       // (consecutive statements: the store's, or the overflow's -- a group of eight never straddles the two)
       tx_prepare_many(p, l, &statement(first), cnt, true, only);
     });
@@ -493,8 +508,8 @@ class TxCall {
   std::vector<TxStatement>& store_;
   std::vector<TxStatement> beyond_;
   const size_t batch_;
-  const uint8_t* const txs_;
-  const uint64_t* const offs_;
+  std::vector<const uint8_t*> ptr_;                      // where every transaction of the call lies, and how long it is
+  std::vector<size_t> len_;
   const int threads_;
   uint8_t* const accept_;
   uint8_t* const status_;

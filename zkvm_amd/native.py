@@ -150,6 +150,9 @@ def load_library():
     lib.zkgpu_verifier_verify_sharded.argtypes = [vp, vp, sz, u32p, u32p, u8p, u8p, u64p, u8p, u8p]
     lib.zkgpu_tx_verify_batch.argtypes = [vp, sz, u8p, u64p, C.c_int, u8p, u8p]
     lib.zkgpu_verifier_set_tx_format.argtypes = [vp, C.c_int]
+    lib.zkgpu_tx_verify_submit.argtypes = [vp, sz, u8p, u64p, C.c_int, C.POINTER(C.c_uint64)]
+    lib.zkgpu_tx_verify_wait.argtypes = [vp, C.c_uint64, u8p, u8p]
+    lib.zkgpu_tx_verify_stats.argtypes = [vp, u64p]
     lib.zkgpu_verifier_queue_info.argtypes = [vp, C.POINTER(C.c_int)]
     lib.zkgpu_ctx_queue_info.argtypes = [vp, C.POINTER(C.c_int)]
     lib.zkgpu_verifier_set_tx_chunk.argtypes = [vp, sz]

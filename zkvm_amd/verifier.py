@@ -310,6 +310,39 @@ class BlockVerifier:
         self._check(self.lib.zkgpu_tx_verify_batch(self.h, batch, blob, offs.ctypes.data_as(C.POINTER(C.c_uint64)), host_threads, bm, st))
         return bm.raw[: (batch + 7) // 8], st.raw[:batch]
 
+    def submit_txs_packed(self, blob: bytes, lengths, host_threads: int = 0) -> int:
+        """zkgpu_tx_verify_submit: the call is queued (calls in flight are merged into rounds); -> call id for wait_txs.  The
+        buffers are kept alive here until the call has been waited for."""
+        batch = len(lengths)
+        offs = np.zeros(batch + 1, dtype=np.uint64)
+        np.cumsum(lengths if isinstance(lengths, np.ndarray) and lengths.dtype == np.uint64 else np.asarray(lengths, dtype=np.uint64), out=offs[1:])
+        if int(offs[-1]) != len(blob):
+            raise ValueError("the lengths add up to %d bytes, the buffer holds %d" % (int(offs[-1]), len(blob)))
+        cid = C.c_uint64(0)
+        self._check(self.lib.zkgpu_tx_verify_submit(self.h, batch, blob, offs.ctypes.data_as(C.POINTER(C.c_uint64)), host_threads, C.byref(cid)))
+        self.__dict__.setdefault("_tx_calls", {})[int(cid.value)] = (blob, offs, batch)
+        return int(cid.value)
+
+    def submit_txs(self, txs: Sequence[bytes], host_threads: int = 0) -> int:
+        return self.submit_txs_packed(b"".join(txs), [len(t) for t in txs], host_threads)
+
+    def wait_txs(self, call_id: int):
+        """zkgpu_tx_verify_wait -> (accept bitmap, status bytes) of that call"""
+        _, _, batch = self.__dict__["_tx_calls"][call_id]
+        bm = C.create_string_buffer(max((batch + 7) // 8, 1))
+        st = C.create_string_buffer(max(batch, 1))
+        try:
+            self._check(self.lib.zkgpu_tx_verify_wait(self.h, call_id, bm, st))
+        finally:
+            del self.__dict__["_tx_calls"][call_id]
+        return bm.raw[: (batch + 7) // 8], st.raw[:batch]
+
+    def tx_stats(self):
+        """zkgpu_tx_verify_stats -> (rounds the engine has run, calls they held in all)"""
+        out = (C.c_uint64 * 2)()
+        self._check(self.lib.zkgpu_tx_verify_stats(self.h, out))
+        return int(out[0]), int(out[1])
+
     def verify_sharded(self, comm, txs: Sequence[CloakTx], r_bytes: Optional[bytes] = None) -> bytes:
         """zkgpu_verifier_verify_sharded: every rank passes the whole block and receives the whole bitmap."""
         batch = len(txs)
