@@ -145,6 +145,7 @@ TXCALL_MAIN = r"""
 #include <vector>
 extern "C" int zkhost_txcall_selftest(size_t, const uint8_t*, const uint64_t*, const uint8_t*, int, size_t, uint32_t, int, uint8_t*, uint8_t*,
                                       size_t*, size_t*, size_t*);
+extern "C" int zkhost_txcall_pair_selftest(size_t, size_t, const uint8_t*, const uint64_t*, const uint8_t*, int, size_t, uint32_t, uint8_t*, uint8_t*, size_t*);
 int main(int argc, char** argv) {
   FILE* f = fopen(argv[1], "rb");
   if (!f) return 2;
@@ -163,6 +164,14 @@ int main(int argc, char** argv) {
     if (rc != 0 || leaked != 0) { printf("round %d: rc %d leaked %zu\n", round, rc, leaked); return 1; }
     for (uint64_t i = 0; i < batch; ++i)
       if (((bm[i / 8] >> (i % 8)) & 1) != expected[i]) { printf("round %d: bit %llu differs\n", round, (unsigned long long)i); return 1; }
+  }
+  // two calls stepped by one thread, one stage slot each (the engine's way of keeping two rounds in flight)
+  for (int round = 0; round < 3; ++round) {
+    const size_t splits[] = {32, 8, 48};
+    int rc = zkhost_txcall_pair_selftest(batch, splits[round], blob.data(), offs.data(), proof_ok.data(), 4, chunks[round + 1], 70u + round, bm.data(), st.data(), &leaked);
+    if (rc != 0 || leaked != 0) { printf("pair %d: rc %d leaked %zu\n", round, rc, leaked); return 1; }
+    for (uint64_t i = 0; i < batch; ++i)
+      if (((bm[i / 8] >> (i % 8)) & 1) != expected[i]) { printf("pair %d: bit %llu differs\n", round, (unsigned long long)i); return 1; }
   }
   // faults: every third device operation of a many-chunk call
   for (int k = 0; k < 40; k += 3) {

@@ -255,6 +255,20 @@ def test_scheduling_of_a_transaction_call_on_a_stand_in_device(host, oracle):
         assert st == want_status, chunk
         if chunk == 8:
             assert nc == 19 and ns >= 1                                   # more chunks than ring slots (6)
+    # two calls driven by ONE thread through start / step / done / finish, one stage slot each (the engine of
+    # zkgpu_tx_verify_submit keeps two rounds in flight this way)
+    blob = b"".join(txs)
+    offs = (C.c_uint64 * (len(txs) + 1))()
+    for i, t in enumerate(txs):
+        offs[i + 1] = offs[i] + len(t)
+    for split, chunk, seed in ((64, 0, 1), (80, 16, 2), (8, 24, 3), (144, 8, 4)):
+        bm, st = C.create_string_buffer((len(txs) + 7) // 8 + 1), C.create_string_buffer(len(txs))
+        leaked = C.c_size_t(0)
+        rc = host.zkhost_txcall_pair_selftest(C.c_size_t(len(txs)), C.c_size_t(split), blob, offs, bytes(proof_ok), C.c_int(4), C.c_size_t(chunk),
+                                              C.c_uint32(seed), bm, st, C.byref(leaked))
+        assert rc == 0 and leaked.value == 0, (split, rc)
+        assert [(bm.raw[i // 8] >> (i % 8)) & 1 for i in range(len(txs))] == expected, split
+        assert list(st.raw) == want_status, split
     # a fault at every device operation of a many-chunk call, and of a one-chunk call
     for chunk in (16, 0):
         ops, k = 0, 0

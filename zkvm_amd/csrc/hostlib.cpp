@@ -1041,3 +1041,50 @@ extern "C" int zkhost_txcall_selftest(size_t batch, const uint8_t* txs, const ui
   if (rc != 0) std::memset(accept_bitmap, 0, (batch + 7) / 8);
   return rc;
 }
+
+// TWO calls driven by ONE thread through start / step / done / finish, one stage slot each -- how the engine of
+// zkgpu_tx_verify_submit keeps two rounds in flight: the transactions [0, split) and [split, batch) as two calls whose steps
+// alternate; the caller naps on a condition variable the calls' staging threads signal (on_news).  -> 0, or the first error
+extern "C" int zkhost_txcall_pair_selftest(size_t batch, size_t split, const uint8_t* txs, const uint64_t* offs, const uint8_t* proof_ok,
+                                           int host_threads, size_t chunk, uint32_t delay_seed, uint8_t* accept_bitmap, uint8_t* status,
+                                           size_t* leaked) {
+  std::memset(accept_bitmap, 0, (batch + 7) / 8);
+  std::memset(status, TX_INVALID, batch);
+  if (split == 0 || split >= batch || split % 8) return -1;
+  std::vector<TxStatement> store[2];
+  std::vector<uint8_t> bits[2] = {std::vector<uint8_t>((split + 7) / 8 + 1, 0), std::vector<uint8_t>((batch - split + 7) / 8 + 1, 0)};
+  std::mutex news_mu;
+  std::condition_variable news_cv;
+  bool news = false;
+  int rc_all = 0;
+  size_t leaked_all = 0;
+  {
+    HostTxDevice dev0(txs, offs, batch, proof_ok, delay_seed, -1), dev1(txs, offs, batch, proof_ok, delay_seed + 1, -1);
+    std::vector<TxCall::Piece> p0{{txs, offs, split}}, p1{{txs, offs + split, batch - split}};
+    // (the second call's offsets are still relative to `txs`: Piece = base pointer + its own offsets)
+    TxCall c0(dev0, store[0], (size_t)1 << 17, p0, host_threads, chunk, bits[0].data(), status, 1);
+    TxCall c1(dev1, store[1], (size_t)1 << 17, p1, host_threads, chunk, bits[1].data(), status + split, 1);
+    TxCall* calls[2] = {&c0, &c1};
+    for (TxCall* c : calls) {
+      c->set_on_news([&] { { std::lock_guard<std::mutex> nl(news_mu); news = true; } news_cv.notify_one(); });
+      const int rc = c->start();
+      if (rc != 0 && rc_all == 0) rc_all = rc;
+    }
+    while (!c0.done() || !c1.done()) {
+      bool progress = false;
+      for (TxCall* c : calls) if (!c->done()) progress |= c->step();
+      if (!progress) {
+        std::unique_lock<std::mutex> nl(news_mu);
+        if (!news) news_cv.wait_until(nl, std::chrono::system_clock::now() + std::chrono::microseconds(50));
+        news = false;
+      }
+    }
+    for (TxCall* c : calls) { const int rc = c->finish(); if (rc != 0 && rc_all == 0) rc_all = rc; }
+    leaked_all = dev0.leaked() + dev1.leaked();
+  }
+  *leaked = leaked_all;
+  if (rc_all != 0) return rc_all;
+  for (size_t i = 0; i < split; ++i) if ((bits[0][i / 8] >> (i % 8)) & 1) accept_bitmap[i / 8] |= (uint8_t)(1u << (i % 8));
+  for (size_t i = split; i < batch; ++i) { const size_t q = i - split; if ((bits[1][q / 8] >> (q % 8)) & 1) accept_bitmap[i / 8] |= (uint8_t)(1u << (i % 8)); }
+  return 0;
+}

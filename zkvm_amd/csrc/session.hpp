@@ -91,6 +91,7 @@ struct zkgpu_verifier {
   std::vector<TxArena> tx_arenas;
   std::vector<zk::zkvm::TxStatement> tx_statements;     // what the VM leaves per transaction, kept between calls (fresh memory costs
                                                         // a page fault per 4 KB: 0.4 ms per 3000 transactions, measured)
+  std::vector<zk::zkvm::TxStatement> tx_statements_b;   // the same for the second round in flight (zkgpu_tx_verify_submit)
   size_t tx_statements_kept = (size_t)1 << 17;          // at most so many (~90 MB): zkgpu_verifier_set_tx_statements_kept
   size_t tx_chunk = 0;                                  // transactions per chunk of zkgpu_tx_verify_batch (0: automatic)
   uint8_t basepoint[32] = {0};                          // encoding of B, computed once (the signature equations name it)
@@ -1386,17 +1387,19 @@ namespace {
 static_assert(zk::zkvm::TxCall::OK == ZKGPU_OK && zk::zkvm::TxCall::ENOMEM_ == ZKGPU_ENOMEM, "tx_call.hpp restates two status codes");
 class GpuTxDevice : public zk::zkvm::TxDevice {
  public:
-  explicit GpuTxDevice(zkgpu_verifier* v) : v_(v) {}
+  // slot_base / arena_base: which of the verifier's stage contexts and staging areas this call uses (a call alone: slots 0
+  // and 1, areas 0 .. RING - 1; two rounds in flight: one slot and one set of areas each)
+  explicit GpuTxDevice(zkgpu_verifier* v, int slot_base = 0, size_t arena_base = 0) : v_(v), sb_(slot_base), ab_(arena_base) {}
   const uint8_t* basepoint() override { return v_->basepoint; }
   int keys_enqueue(int slot, const uint8_t* scalars, const uint8_t* points, const uint64_t* offsets, size_t rows) override {
-    return seen(msm_values_enqueue(v_->aux_keys[slot], scalars, points, offsets, rows), v_->aux_keys[slot]);
+    return seen(msm_values_enqueue(keys(slot), scalars, points, offsets, rows), keys(slot));
   }
-  bool keys_done(int slot) override { return split_done(v_->aux_keys[slot]); }
-  int keys_collect(int slot, uint8_t* ok_bits, uint8_t* values) override { return seen(split_collect(v_->aux_keys[slot], ok_bits, values), v_->aux_keys[slot]); }
+  bool keys_done(int slot) override { return split_done(keys(slot)); }
+  int keys_collect(int slot, uint8_t* ok_bits, uint8_t* values) override { return seen(split_collect(keys(slot), ok_bits, values), keys(slot)); }
   // (staging thread: touches the plans -- plans_mu -- the given arena and nothing else of the verifier)
   int proofs_stage(size_t ring_slot, size_t n, const zk::zkvm::TxProofSource* src, int host_threads, void** handle, std::string* err) override {
     zkgpu_txblock* blk = nullptr;
-    const int rc = txblock_stage_host(v_, n, src, nullptr, host_threads, &blk, &v_->tx_arenas[ring_slot], err);
+    const int rc = txblock_stage_host(v_, n, src, nullptr, host_threads, &blk, &v_->tx_arenas[ab_ + ring_slot], err);
     if (rc != ZKGPU_OK) return rc;
     Staged* st = new Staged();
     st->blk = blk;
@@ -1406,7 +1409,7 @@ class GpuTxDevice : public zk::zkvm::TxDevice {
   int proofs_start(size_t ring_slot, void* handle) override {
     Staged* st = (Staged*)handle;
     // one copy to HBM, and the chunk's batches queued on the lanes
-    int rc = txblock_upload(v_, st->blk, &v_->tx_arenas[ring_slot]);
+    int rc = txblock_upload(v_, st->blk, &v_->tx_arenas[ab_ + ring_slot]);
     if (rc != ZKGPU_OK) { err_ = v_->last_error; return rc; }
     // a chunk of one shape goes to the device as few, large batches (measured: the last chunk in batches short enough for
     // the one-wavefront-per-transaction transcript, or cut in two, does not shorten the tail of the call)
@@ -1435,16 +1438,20 @@ class GpuTxDevice : public zk::zkvm::TxDevice {
     sidx_[slot].assign(rows, 0);
     soff_[slot].resize(rows + 1);
     for (size_t q = 0; q <= rows; ++q) soff_[slot][q] = q;
-    return seen(verify_ps_enqueue(v_->aux_sigs[slot], v_->ps, rows, dyn_scalars, dyn_points, dyn_offsets, base_scalars, sidx_[slot].data(),
-                                  soff_[slot].data()), v_->aux_sigs[slot]);
+    return seen(verify_ps_enqueue(sigs(slot), v_->ps, rows, dyn_scalars, dyn_points, dyn_offsets, base_scalars, sidx_[slot].data(),
+                                  soff_[slot].data()), sigs(slot));
   }
-  int sigs_collect(int slot, uint8_t* bits) override { return seen(split_collect(v_->aux_sigs[slot], bits, nullptr), v_->aux_sigs[slot]); }
+  int sigs_collect(int slot, uint8_t* bits) override { return seen(split_collect(sigs(slot), bits, nullptr), sigs(slot)); }
   std::string last_error() override { return err_; }
 
  private:
   struct Staged { zkgpu_txblock* blk = nullptr; zkgpu_verifier::BlockRun* run = nullptr; };
   int seen(int rc, zkgpu_ctx* where) { if (rc != ZKGPU_OK) err_ = zkgpu_last_error(where); return rc; }
+  zkgpu_ctx* keys(int slot) const { return v_->aux_keys[(sb_ + slot) & 1]; }
+  zkgpu_ctx* sigs(int slot) const { return v_->aux_sigs[(sb_ + slot) & 1]; }
   zkgpu_verifier* v_;
+  const int sb_;
+  const size_t ab_;
   std::vector<uint32_t> sidx_[2];
   std::vector<uint64_t> soff_[2];
   std::string err_;
@@ -1452,11 +1459,20 @@ class GpuTxDevice : public zk::zkvm::TxDevice {
 
 // what a transaction call needs of the verifier before it starts (v->mu held): nothing in flight on the lanes, the stage
 // contexts, the basepoint's encoding, the ring of staging areas
-int tx_call_prepare(zkgpu_verifier* v) {
+int tx_call_prepare(zkgpu_verifier* v, bool collect_lanes = true) {
   zkgpu_ctx* c = v->root;
-  // the lanes' batches in flight are collected first: the call owns the verifier (tickets and runs keep their verdicts)
-  while (!v->block_busy.empty()) block_collect(v, v->block_busy.front());
-  while (!v->busy.empty()) ticket_collect(v, v->busy.front());
+  // the lanes' batches in flight are collected first: the call owns the verifier (tickets and runs keep their verdicts).
+  // (Not when another round of transaction calls is in flight: its proofs are on the lanes, and share them.)
+  if (collect_lanes) {
+    while (!v->block_busy.empty()) block_collect(v, v->block_busy.front());
+    while (!v->busy.empty()) ticket_collect(v, v->busy.front());
+  }
+  if (v->aux_keys[0] && v->aux_keys[1] && v->aux_sigs[0] && v->aux_sigs[1] && v->have_basepoint && v->tx_arenas.size() >= 2 * zk::zkvm::TxCall::RING)
+    return ZKGPU_OK;
+  if (!collect_lanes) {                                  // (the probes below want an idle device)
+    while (!v->block_busy.empty()) block_collect(v, v->block_busy.front());
+    while (!v->busy.empty()) ticket_collect(v, v->busy.front());
+  }
   {
     DeviceGuard g(c->device);
     // a stage context is worth having only if its streams run BESIDE the lanes' (a stream made late in a process may land
@@ -1488,7 +1504,7 @@ int tx_call_prepare(zkgpu_verifier* v) {
     if (rc != ZKGPU_OK) { v->last_error = zkgpu_last_error(v->aux_keys[0]); return rc; }
     v->have_basepoint = true;
   }
-  if (v->tx_arenas.size() < zk::zkvm::TxCall::RING) v->tx_arenas.resize(zk::zkvm::TxCall::RING);
+  if (v->tx_arenas.size() < 2 * zk::zkvm::TxCall::RING) v->tx_arenas.resize(2 * zk::zkvm::TxCall::RING);     // (two sets: two rounds in flight)
   return ZKGPU_OK;
 }
 
@@ -1539,70 +1555,131 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
 // bitmap and status bytes.  The transaction bytes and offsets must stay valid until the call has been waited for.  Verdicts
 // are those of separate calls.  Fail-closed: a round that fails gives every call in it the error and all-zero outputs.
 namespace {
+// One round of merged calls on its way: its own device view (one stage slot, one set of staging areas, one statement store)
+struct TxRound {
+  std::vector<zkgpu_verifier::TxPending*> calls;
+  std::vector<zk::zkvm::TxCall::Piece> pieces;
+  std::vector<uint8_t> bits, status;
+  std::unique_ptr<GpuTxDevice> dev;
+  std::unique_ptr<zk::zkvm::TxCall> call;
+  size_t total = 0;
+  int rc = ZKGPU_OK;
+};
+
+// hands every call of a finished round its own bits (tx_mu held)
+void tx_round_distribute(TxRound& r) {
+  using namespace zk::zkvm;
+  size_t at = 0;
+  for (auto* p : r.calls) {
+    p->bits.assign((p->batch + 7) / 8, 0);
+    p->status.assign(p->batch, TX_INVALID);
+    p->rc = r.rc;
+    for (size_t i = 0; i < p->batch; ++i) {
+      const size_t g = at + i;
+      if (r.rc == ZKGPU_OK) {
+        if ((r.bits[g / 8] >> (g % 8)) & 1) p->bits[i / 8] |= (uint8_t)(1u << (i % 8));
+        p->status[i] = r.status[g];
+      } else if (r.status[g] == TX_UNSUPPORTED) {
+        p->status[i] = TX_UNSUPPORTED;
+      }
+    }
+    at += p->batch;
+    p->state = 2;
+  }
+}
+
+// The engine: up to TWO rounds in flight, driven by this one thread (TxCall::step never blocks).  A lone round walks its
+// chain of stages -- keys, proofs, transaction IDs, signatures -- with the device idle for most of it; the second round's
+// stages fill those gaps.  Each round has one key / signature stage slot and one set of staging areas; both share the lanes.
+// The verifier's mutex is held from the first admission until nothing is in flight: the verifier belongs to the calls.
 void tx_engine_main(zkgpu_verifier* v) {
   using namespace zk::zkvm;
+  std::unique_ptr<TxRound> active[2];
+  std::mutex news_mu;
+  std::condition_variable news_cv;
+  bool news = false;
+  std::unique_lock<std::mutex> vlk(v->mu, std::defer_lock);
   for (;;) {
-    std::vector<zkgpu_verifier::TxPending*> round;
+    // ---- admit: a free slot takes everything that is queued (up to tx_merge_max transactions)
+    std::unique_ptr<TxRound> fresh[2];
     {
       std::unique_lock<std::mutex> lk(v->tx_mu);
-      v->tx_cv.wait(lk, [&] { return v->tx_engine_quit || !v->tx_queue.empty(); });
-      if (v->tx_queue.empty()) return;                   // (quit with nothing queued; what is queued at quit is still served)
-      size_t total = 0;
-      while (!v->tx_queue.empty() && (round.empty() || total + v->tx_queue.front()->batch <= v->tx_merge_max)) {
-        round.push_back(v->tx_queue.front());
-        total += round.back()->batch;
-        round.back()->state = 1;
-        v->tx_queue.pop_front();
+      if (!active[0] && !active[1]) {
+        if (vlk.owns_lock()) vlk.unlock();              // idle: the verifier is everybody's again
+        v->tx_cv.wait(lk, [&] { return v->tx_engine_quit || !v->tx_queue.empty(); });
+        if (v->tx_queue.empty()) return;                 // (quit with nothing queued; what is queued at quit is still served)
       }
-      ++v->tx_rounds; v->tx_round_calls += round.size();
+      for (int set = 0; set < 2; ++set) {
+        if (active[set] || v->tx_queue.empty()) continue;
+        fresh[set].reset(new TxRound());
+        TxRound& r = *fresh[set];
+        while (!v->tx_queue.empty() && (r.calls.empty() || r.total + v->tx_queue.front()->batch <= v->tx_merge_max)) {
+          r.calls.push_back(v->tx_queue.front());
+          r.total += r.calls.back()->batch;
+          r.calls.back()->state = 1;
+          v->tx_queue.pop_front();
+        }
+        ++v->tx_rounds; v->tx_round_calls += r.calls.size();
+      }
     }
-    size_t total = 0;
-    int threads = 0;
-    std::vector<TxCall::Piece> pieces;
-    for (auto* p : round) { pieces.push_back({p->txs, p->offsets, p->batch}); total += p->batch; threads = std::max(threads, p->host_threads); }
-    std::vector<uint8_t> bits((total + 7) / 8 + 1, 0), status(total, TX_INVALID);
-    int rc = ZKGPU_OK;
-    std::string err;
-    {
-      std::lock_guard<std::mutex> vlk(v->mu);
+    if (!vlk.owns_lock()) vlk.lock();
+    bool progress = false;
+    for (int set = 0; set < 2; ++set) {
+      if (!fresh[set]) continue;
+      TxRound& r = *fresh[set];
+      int threads = 0;
+      for (auto* p : r.calls) { r.pieces.push_back({p->txs, p->offsets, p->batch}); threads = std::max(threads, p->host_threads); }
+      r.bits.assign((r.total + 7) / 8 + 1, 0);
+      r.status.assign(r.total, TX_INVALID);
       if (v->tx_format != ZKGPU_TXFORMAT_RECOLLECTED_V1) {
-        std::fill(status.begin(), status.end(), (uint8_t)TX_UNSUPPORTED);
+        std::fill(r.status.begin(), r.status.end(), (uint8_t)TX_UNSUPPORTED);       // no format enabled: nothing is inside the subset
       } else {
-        rc = tx_call_prepare(v);
-        if (rc == ZKGPU_OK) {
-          GpuTxDevice dev(v);
+        r.rc = tx_call_prepare(v, !active[0] && !active[1]);
+        if (r.rc == ZKGPU_OK) {
           try {
-            TxCall call(dev, v->tx_statements, v->tx_statements_kept, pieces, threads, v->tx_chunk, bits.data(), status.data());
-            rc = call.run();
-            if (rc != ZKGPU_OK) v->last_error = call.error_text();
+            r.dev.reset(new GpuTxDevice(v, set, (size_t)set * TxCall::RING));
+            r.call.reset(new TxCall(*r.dev, set ? v->tx_statements_b : v->tx_statements, v->tx_statements_kept, r.pieces, threads, v->tx_chunk,
+                                    r.bits.data(), r.status.data(), 1));
+            r.call->set_on_news([&] { { std::lock_guard<std::mutex> nl(news_mu); news = true; } news_cv.notify_one(); });
+            r.rc = r.call->start();
+            if (r.rc != ZKGPU_OK) v->last_error = r.call->error_text();
           } catch (const std::bad_alloc&) {
             v->last_error = "out of host memory while planning the transaction call";
-            rc = ZKGPU_ENOMEM;
+            r.rc = ZKGPU_ENOMEM;
+            r.call.reset();
           }
         }
       }
+      active[set] = std::move(fresh[set]);
+      progress = true;
     }
-    {
-      std::lock_guard<std::mutex> lk(v->tx_mu);
-      size_t at = 0;
-      for (auto* p : round) {
-        p->bits.assign((p->batch + 7) / 8, 0);
-        p->status.assign(p->batch, TX_INVALID);
-        p->rc = rc;
-        for (size_t i = 0; i < p->batch; ++i) {
-          const size_t g = at + i;
-          if (rc == ZKGPU_OK) {
-            if ((bits[g / 8] >> (g % 8)) & 1) p->bits[i / 8] |= (uint8_t)(1u << (i % 8));
-            p->status[i] = status[g];
-          } else if (status[g] == TX_UNSUPPORTED) {
-            p->status[i] = TX_UNSUPPORTED;
-          }
+    // ---- step what is in flight; a round that is done hands out its verdicts
+    for (int set = 0; set < 2; ++set) {
+      if (!active[set]) continue;
+      TxRound& r = *active[set];
+      const bool running = r.call && r.rc == ZKGPU_OK;
+      if (running && !r.call->done()) progress |= r.call->step();
+      if (!running || r.call->done()) {
+        if (r.call) {
+          const int rc = r.call->finish();
+          if (r.rc == ZKGPU_OK) r.rc = rc;
+          if (rc != ZKGPU_OK) v->last_error = r.call->error_text();
+          r.call.reset();                                // (joins its staging thread: nothing calls on_news afterwards)
         }
-        at += p->batch;
-        p->state = 2;
+        {
+          std::lock_guard<std::mutex> lk(v->tx_mu);
+          tx_round_distribute(r);
+        }
+        v->tx_cv.notify_all();
+        active[set].reset();
+        progress = true;
       }
     }
-    v->tx_cv.notify_all();
+    if (!progress) {                                     // nothing to do now: until a staging thread or a caller has news, 50 us at most
+      std::unique_lock<std::mutex> nl(news_mu);
+      if (!news) news_cv.wait_for(nl, std::chrono::microseconds(50));
+      news = false;
+    }
   }
 }
 }  // namespace

@@ -28,6 +28,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -71,9 +72,9 @@ class TxCall {
   // store: what the VM leaves per transaction, kept by the caller between calls (fresh memory costs a page fault per 4 KB);
   // at most `kept` entries of it are used, the rest of a longer call lives in the call.
   TxCall(TxDevice& dev, std::vector<TxStatement>& store, size_t kept, size_t batch, const uint8_t* txs, const uint64_t* tx_offsets,
-         int host_threads, size_t chunk_override, uint8_t* accept_bitmap, uint8_t* status)
+         int host_threads, size_t chunk_override, uint8_t* accept_bitmap, uint8_t* status, int n_slots = 2)
       : dev_(dev), store_(store), batch_(batch), threads_(host_threads), accept_(accept_bitmap),
-        status_(status), timing_(getenv("ZKGPU_PROVER_TIMING") != nullptr), t00_(now()) {
+        status_(status), timing_(getenv("ZKGPU_PROVER_TIMING") != nullptr), t00_(now()), n_slots_((size_t)std::max(1, std::min(2, n_slots))) {
     ptr_.resize(batch); len_.resize(batch);
     for (size_t i = 0; i < batch; ++i) { ptr_[i] = txs + tx_offsets[i]; len_[i] = (size_t)(tx_offsets[i + 1] - tx_offsets[i]); }
     plan(chunk_override, kept);
@@ -82,9 +83,9 @@ class TxCall {
   // pieces in order, transaction i of the merged call = the i-th transaction counted through them
   struct Piece { const uint8_t* txs; const uint64_t* tx_offsets; size_t batch; };
   TxCall(TxDevice& dev, std::vector<TxStatement>& store, size_t kept, const std::vector<Piece>& pieces, int host_threads,
-         size_t chunk_override, uint8_t* accept_bitmap, uint8_t* status)
+         size_t chunk_override, uint8_t* accept_bitmap, uint8_t* status, int n_slots = 2)
       : dev_(dev), store_(store), batch_(total_of(pieces)), threads_(host_threads), accept_(accept_bitmap), status_(status),
-        timing_(getenv("ZKGPU_PROVER_TIMING") != nullptr), t00_(now()) {
+        timing_(getenv("ZKGPU_PROVER_TIMING") != nullptr), t00_(now()), n_slots_((size_t)std::max(1, std::min(2, n_slots))) {
     ptr_.reserve(batch_); len_.reserve(batch_);
     for (const Piece& pc : pieces)
       for (size_t i = 0; i < pc.batch; ++i) { ptr_.push_back(pc.txs + pc.tx_offsets[i]); len_.push_back((size_t)(pc.tx_offsets[i + 1] - pc.tx_offsets[i])); }
@@ -96,6 +97,29 @@ class TxCall {
 
   // -> 0, or the first error (both outputs then still read "nothing accepted"); error_text(): what it was
   int run() {
+    const int rc = start();
+    if (rc != OK) return rc;
+    while (!done()) {
+      if (step()) continue;
+      std::unique_lock<std::mutex> lk(hm_);
+      const double t0 = now();
+#if defined(__SANITIZE_THREAD__)
+      // (gcc 11's ThreadSanitizer does not intercept pthread_cond_clockwait, which wait_for on the steady clock becomes with
+      // glibc >= 2.30: it then misses the unlock inside the wait and reports a "double lock".  Same nap on the system clock.)
+      hcv_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(50));
+#else
+      hcv_.wait_for(lk, std::chrono::microseconds(50));
+#endif
+      t_wait_host_ += now() - t0;
+    }
+    return finish();
+  }
+  // The same in pieces, for a caller that drives SEVERAL calls from one thread (the engine of zkgpu_tx_verify_submit): start()
+  // makes the staging thread; step() does whatever can be done now without blocking and says whether anything was; done():
+  // nothing is left to queue (or the call has failed); finish() collects what is in flight and writes the verdicts.
+  // on_news: called by the staging thread whenever it has published something (to wake a caller that naps elsewhere).
+  void set_on_news(std::function<void()> f) { on_news_ = std::move(f); }
+  int start() {
     try {
       stager_ = std::thread([this] {
         try {
@@ -105,12 +129,18 @@ class TxCall {
           stager_failed_ = true;
           hcv_.notify_all();
         }
+        if (on_news_) on_news_();
       });
     } catch (...) {                                      // no thread to be had: an error for the call as well
       error_ = "the staging thread of the call could not be started";
+      rc_ = ENOMEM_;
+      finished_ = true;
       return ENOMEM_;
     }
-    drive();
+    return OK;
+  }
+  bool done() const { return finished_; }
+  int finish() {
     stop_stager();
     // (after an error: nothing is left pending on the device)
     for (size_t s = 0; s < seg_.size(); ++s) keys_collect(s);
@@ -241,7 +271,7 @@ class TxCall {
     std::lock_guard<std::mutex> lk(hm_);
     t_keys_host_ += now() - t0;
     key_rows_[ci] = 1;
-    hcv_.notify_all();
+    news();
   }
   bool gather(size_t ci, Chunk& k) {                    // the chunk's cloak statements into its staging area; false: the call is over
     {
@@ -264,7 +294,7 @@ class TxCall {
     std::lock_guard<std::mutex> lk(hm_);
     t_stage_host_ += t2 - t1;
     staged_[ci] = 1;
-    hcv_.notify_all();
+    news();
     return true;
   }
   void sig_rows(SigStage& sg) {                         // transcripts + rows of the equations of chunks [first, last)
@@ -293,6 +323,7 @@ class TxCall {
       }
     });
   }
+  void news() { hcv_.notify_all(); if (on_news_) on_news_(); }     // (hm_ held)
   bool keys_back(const Span& sp) const { for (size_t c = sp.first; c < sp.last; ++c) if (!keys_arrived_[c]) return false; return true; }
   // the signature stages that are due: their chunks' transaction IDs made, their keys back (hm_ held on entry and on return)
   void make_sig_stages(std::unique_lock<std::mutex>& lk, size_t ids_upto) {
@@ -309,7 +340,7 @@ class TxCall {
       sig_stages_.push_back(std::move(sg));              // (reserved: never reallocates)
       ++n_sig_stages_;
       if (sig_next_ == sig_plan_.size()) all_sigs_made_ = true;
-      hcv_.notify_all();
+      news();
     }
   }
   void staging_main() {
@@ -364,7 +395,7 @@ class TxCall {
     if (!sg.pending) return;
     sg.pending = false;
     const double t0 = now();
-    const int rc = dev_.keys_collect((int)(s & 1), sg.kok.data(), agg_.data() + 32 * sg.g_lo);
+    const int rc = dev_.keys_collect((int)(s % n_slots_), sg.kok.data(), agg_.data() + 32 * sg.g_lo);
     if (rc != OK) note(rc, dev_.last_error());
     t_wait_ += now() - t0;
     for (size_t j = 0; j < sg.g_hi - sg.g_lo; ++j) key_ok_[sg.g_lo + j] = (sg.kok[j / 8] >> (j % 8)) & 1;
@@ -375,7 +406,7 @@ class TxCall {
     if (!sg.pending) return;
     sg.pending = false;
     const double t0 = now();
-    const int rc = dev_.sigs_collect((int)(s & 1), sg.bits.data());
+    const int rc = dev_.sigs_collect((int)(s % n_slots_), sg.bits.data());
     if (rc != OK) note(rc, dev_.last_error());
     t_wait_ += now() - t0;
     mark("signatures collected, stage", s);
@@ -414,73 +445,64 @@ class TxCall {
   // staging thread has finished (its proofs go out), for aggregated keys that have arrived (the staging thread is told), and
   // for signature stages that are ready (the equations go out); with nothing to do it sleeps until the staging thread has
   // news, 50 us at most (what the device has finished is found out by asking).
-  void drive() {
+ public:
+  bool step() {
+    if (finished_) return false;
+    if (rc_ != OK) { finished_ = true; return true; }
     const size_t n_seg = seg_.size(), n_chunks = chunks_.size();
-    size_t next_key = 0, next_kcollect = 0, next_stage = 0, next_sig = 0;
-    while (rc_ == OK) {
-      bool progress = false, sigs_all, rows = false, st_ready = false, ring_free = true;
-      size_t sig_avail;
-      {
-        std::lock_guard<std::mutex> lk(hm_);
-        if (stager_failed_) { note(ENOMEM_, "out of host memory while staging the transactions"); break; }
-        sig_avail = n_sig_stages_; sigs_all = all_sigs_made_;
-        if (next_key < n_seg) rows = key_rows_[next_key] != 0;
-        if (next_stage < n_chunks) st_ready = staged_[next_stage] != 0;
-        if (next_stage >= RING) ring_free = arena_free_[next_stage - RING] != 0;
-      }
-      if (next_kcollect == n_seg && next_stage == n_chunks && sigs_all && next_sig == sig_avail) break;
-      if (rows && (next_key < 2 || next_kcollect + 2 > next_key)) {           // (its slot is free once segment next_key - 2 is collected)
-        Segment& sg = seg_[next_key];
-        mark("key rows ready, segment", next_key);
-        const double t0 = now();
-        if (sg.g_hi > sg.g_lo) {
-          const int rc = dev_.keys_enqueue((int)(next_key & 1), sg.ksc.data(), sg.kpt.data(), sg.koff.data(), sg.g_hi - sg.g_lo);
-          if (rc != OK) note(rc, dev_.last_error()); else sg.pending = true;
-        }
-        t_keys_ += now() - t0;
-        mark("keys queued, segment", next_key);
-        ++next_key;
-        progress = true;
-      }
-      if (rc_ == OK && next_stage < n_chunks && (proofs_first_ || next_stage < next_key)) {     // (a chunk's proofs after its keys, unless the call is one chunk)
-        if (!ring_free) proofs_collect(*chunks_[next_stage - RING]);
-        if (st_ready) { enqueue_proofs(next_stage++); progress = true; }
-      }
-      if (rc_ == OK && next_kcollect < next_key && (!seg_[next_kcollect].pending || dev_.keys_done((int)(next_kcollect & 1)))) {
-        keys_collect(next_kcollect);
-        { std::lock_guard<std::mutex> lk(hm_); keys_arrived_[next_kcollect] = 1; }
-        hcv_.notify_all();
-        ++next_kcollect;
-        progress = true;
-      }
-      while (rc_ == OK && next_sig < sig_avail) {
-        const double t0 = now();
-        if (next_sig >= 2) sigs_collect(next_sig - 2);                // (the stage that used this slot last)
-        SigStage& sg = *sig_stages_[next_sig];
-        const size_t ns = sg.keyed.size();
-        if (ns) {
-          const int rc = dev_.sigs_enqueue((int)(next_sig & 1), ns, sg.ssc.data(), sg.spt.data(), sg.soff.data(), sg.sst.data());
-          if (rc != OK) note(rc, dev_.last_error()); else sg.pending = true;
-        }
-        t_sigs_ += now() - t0;
-        mark("signatures queued, stage", next_sig);
-        ++next_sig;
-        progress = true;
-      }
-      if (!progress) {
-        std::unique_lock<std::mutex> lk(hm_);
-        const double t0 = now();
-#if defined(__SANITIZE_THREAD__)
-        // (gcc 11's ThreadSanitizer does not intercept pthread_cond_clockwait, which wait_for on the steady clock becomes with
-        // glibc >= 2.30: it then misses the unlock inside the wait and reports a "double lock".  Same nap on the system clock.)
-        hcv_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(50));
-#else
-        hcv_.wait_for(lk, std::chrono::microseconds(50));
-#endif
-        t_wait_host_ += now() - t0;
-      }
+    bool progress = false, sigs_all, rows = false, st_ready = false, ring_free = true;
+    size_t sig_avail;
+    {
+      std::lock_guard<std::mutex> lk(hm_);
+      if (stager_failed_) { note(ENOMEM_, "out of host memory while staging the transactions"); finished_ = true; return true; }
+      sig_avail = n_sig_stages_; sigs_all = all_sigs_made_;
+      if (next_key_ < n_seg) rows = key_rows_[next_key_] != 0;
+      if (next_stage_ < n_chunks) st_ready = staged_[next_stage_] != 0;
+      if (next_stage_ >= RING) ring_free = arena_free_[next_stage_ - RING] != 0;
     }
+    if (next_kcollect_ == n_seg && next_stage_ == n_chunks && sigs_all && next_sig_ == sig_avail) { finished_ = true; return true; }
+    if (rows && next_kcollect_ + n_slots_ > next_key_) {                     // (its slot is free once segment next_key - n_slots is collected)
+      Segment& sg = seg_[next_key_];
+      mark("key rows ready, segment", next_key_);
+      const double t0 = now();
+      if (sg.g_hi > sg.g_lo) {
+        const int rc = dev_.keys_enqueue((int)(next_key_ % n_slots_), sg.ksc.data(), sg.kpt.data(), sg.koff.data(), sg.g_hi - sg.g_lo);
+        if (rc != OK) note(rc, dev_.last_error()); else sg.pending = true;
+      }
+      t_keys_ += now() - t0;
+      mark("keys queued, segment", next_key_);
+      ++next_key_;
+      progress = true;
+    }
+    if (rc_ == OK && next_stage_ < n_chunks && (proofs_first_ || next_stage_ < next_key_)) {     // (a chunk's proofs after its keys, unless the call is one chunk)
+      if (!ring_free) { proofs_collect(*chunks_[next_stage_ - RING]); progress = true; }
+      if (st_ready) { enqueue_proofs(next_stage_++); progress = true; }
+    }
+    if (rc_ == OK && next_kcollect_ < next_key_ && (!seg_[next_kcollect_].pending || dev_.keys_done((int)(next_kcollect_ % n_slots_)))) {
+      keys_collect(next_kcollect_);
+      { std::lock_guard<std::mutex> lk(hm_); keys_arrived_[next_kcollect_] = 1; }
+      hcv_.notify_all();
+      ++next_kcollect_;
+      progress = true;
+    }
+    while (rc_ == OK && next_sig_ < sig_avail) {
+      const double t0 = now();
+      if (next_sig_ >= n_slots_) sigs_collect(next_sig_ - n_slots_);          // (the stage that used this slot last)
+      SigStage& sg = *sig_stages_[next_sig_];
+      const size_t ns = sg.keyed.size();
+      if (ns) {
+        const int rc = dev_.sigs_enqueue((int)(next_sig_ % n_slots_), ns, sg.ssc.data(), sg.spt.data(), sg.soff.data(), sg.sst.data());
+        if (rc != OK) note(rc, dev_.last_error()); else sg.pending = true;
+      }
+      t_sigs_ += now() - t0;
+      mark("signatures queued, stage", next_sig_);
+      ++next_sig_;
+      progress = true;
+    }
+    if (rc_ != OK) { finished_ = true; return true; }
+    return progress;
   }
+ private:
   void verdicts() {
     std::vector<uint8_t> sig_ok(live_all_.size(), 0);
     for (const auto& sg : sig_stages_)
@@ -515,6 +537,8 @@ class TxCall {
   uint8_t* const status_;
   const bool timing_;
   const double t00_;
+  const size_t n_slots_;                                 // key / signature stages in flight at once (2; 1 when two calls share the stage contexts)
+  std::function<void()> on_news_;
   // the plan
   std::vector<std::unique_ptr<Chunk>> chunks_;
   std::vector<Segment> seg_;                             // one key stage per chunk
@@ -537,6 +561,8 @@ class TxCall {
   std::vector<uint8_t> agg_, key_ok_;
   std::thread stager_;
   // calling thread only
+  size_t next_key_ = 0, next_kcollect_ = 0, next_stage_ = 0, next_sig_ = 0;
+  bool finished_ = false;
   int rc_ = OK;
   std::string error_;
   double t_keys_ = 0, t_stage_ = 0, t_sigs_ = 0, t_wait_ = 0, t_wait_host_ = 0;
