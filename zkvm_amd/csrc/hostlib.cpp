@@ -947,9 +947,11 @@ class HostTxDevice : public TxDevice {
         while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (offs_[mid] <= at) lo = mid; else hi = mid; }
         if (proof_ok_[lo]) p->bits[q / 8] |= (uint8_t)(1u << (q % 8));
       }
+      p->done = true;
     });
     return 0;
   }
+  bool proofs_done(void* handle) override { return ((Proofs*)handle)->done; }
   int proofs_finish(void* handle, uint8_t* accept_bits) override {
     Proofs* p = (Proofs*)handle;
     if (p->th.joinable()) p->th.join();
@@ -968,6 +970,7 @@ class HostTxDevice : public TxDevice {
     if (failing()) return -3;
     Stage& s = sigs_[slot];
     if (s.th.joinable()) { err_ = "signature slot reused before it was collected"; return -1; }
+    s.done = false;
     s.ok.assign((rows + 7) / 8 + 1, 0);
     const unsigned us = delay();
     s.th = std::thread([=, &s] {
@@ -987,9 +990,11 @@ class HostTxDevice : public TxDevice {
         }
         if (ok && ge_is_identity(acc)) s.ok[r / 8] |= (uint8_t)(1u << (r % 8));
       }
+      s.done = true;
     });
     return 0;
   }
+  bool sigs_done(int slot) override { return sigs_[slot].done; }
   int sigs_collect(int slot, uint8_t* bits) override {
     Stage& s = sigs_[slot];
     if (!s.th.joinable()) { err_ = "nothing to collect in this signature slot"; return -1; }
@@ -1003,7 +1008,7 @@ class HostTxDevice : public TxDevice {
 
  private:
   struct Stage { std::thread th; std::atomic<bool> done{false}; std::vector<uint8_t> ok, values; };
-  struct Proofs { size_t ring_slot = 0; std::vector<TxProofSource> src; std::vector<uint8_t> bits; std::thread th; };
+  struct Proofs { size_t ring_slot = 0; std::vector<TxProofSource> src; std::vector<uint8_t> bits; std::thread th; std::atomic<bool> done{false}; };
   unsigned delay() { std::lock_guard<std::mutex> lk(mu_); return (unsigned)(rng_() % 400); }
   bool failing() { return fail_at_ >= 0 && ops_.fetch_add(1) == fail_at_; }
   const uint8_t* txs_;
@@ -1079,6 +1084,8 @@ extern "C" int zkhost_txcall_pair_selftest(size_t batch, size_t split, const uin
         news = false;
       }
     }
+    // (the engine's rule: finish() only once the device has settled, so that it never sleeps inside one call)
+    for (int spins = 0; !(c0.settled() && c1.settled()) && spins < 2000000; ++spins) std::this_thread::sleep_for(std::chrono::microseconds(20));
     for (TxCall* c : calls) { const int rc = c->finish(); if (rc != 0 && rc_all == 0) rc_all = rc; }
     leaked_all = dev0.leaked() + dev1.leaked();
   }

@@ -1420,6 +1420,14 @@ class GpuTxDevice : public zk::zkvm::TxDevice {
     if (st->run->rc != ZKGPU_OK) { err_ = v_->last_error; return st->run->rc; }     // (proofs_finish still collects what was queued)
     return ZKGPU_OK;
   }
+  bool proofs_done(void* handle) override {                // have the lanes finished every batch of this block?  (never blocks)
+    Staged* st = (Staged*)handle;
+    if (!st->run) return true;
+    DeviceGuard g(v_->root->device);
+    for (int l : v_->block_busy)
+      if (v_->lane_job[(size_t)l].run == st->run && hipEventQuery(v_->lanes[(size_t)l]->ev_done) == hipErrorNotReady) return false;
+    return true;
+  }
   int proofs_finish(void* handle, uint8_t* accept_bits) override {
     Staged* st = (Staged*)handle;
     int rc = ZKGPU_OK;
@@ -1441,6 +1449,7 @@ class GpuTxDevice : public zk::zkvm::TxDevice {
     return seen(verify_ps_enqueue(sigs(slot), v_->ps, rows, dyn_scalars, dyn_points, dyn_offsets, base_scalars, sidx_[slot].data(),
                                   soff_[slot].data()), sigs(slot));
   }
+  bool sigs_done(int slot) override { return split_done(sigs(slot)); }
   int sigs_collect(int slot, uint8_t* bits) override { return seen(split_collect(sigs(slot), bits, nullptr), sigs(slot)); }
   std::string last_error() override { return err_; }
 
@@ -1588,13 +1597,19 @@ void tx_round_distribute(TxRound& r) {
   }
 }
 
-// The engine: up to TWO rounds in flight, driven by this one thread (TxCall::step never blocks).  A lone round walks its
-// chain of stages -- keys, proofs, transaction IDs, signatures -- with the device idle for most of it; the second round's
-// stages fill those gaps.  Each round has one key / signature stage slot and one set of staging areas; both share the lanes.
-// The verifier's mutex is held from the first admission until nothing is in flight: the verifier belongs to the calls.
+// The engine: rounds of merged calls, driven by this one thread (TxCall::step never blocks; a round is finished only once
+// the device has settled).  It can keep TWO rounds in flight -- one key / signature stage slot and one set of staging areas
+// each, the lanes shared -- but does so only on request (see max_rounds: measured slower).  The verifier's mutex is held
+// from the first admission until nothing is in flight: the verifier belongs to the calls.
 void tx_engine_main(zkgpu_verifier* v) {
   using namespace zk::zkvm;
   std::unique_ptr<TxRound> active[2];
+  // ONE round at a time by default.  Two in flight (ZKGPU_TX_ROUNDS=2; the machinery below serves both) were measured on
+  // MI355X and lost: 8 calls of 1024 in flight 0.92 - 0.96 M tx/s with one round against 0.56 - 0.60 M with two, and stalls
+  // of 5 - 20 ms in single stages (profiles/r04e_inflight.txt, r04f_inflight_timing.txt) -- two rounds keep both key
+  // contexts, both signature contexts and the lanes busy at once, which is more streams than the device runs side by side
+  // (DESIGN.md sec 5.1).  What merging buys is the rate of the larger call, not a second chain beside the first.
+  const int max_rounds = (getenv("ZKGPU_TX_ROUNDS") && atoi(getenv("ZKGPU_TX_ROUNDS")) == 2) ? 2 : 1;
   std::mutex news_mu;
   std::condition_variable news_cv;
   bool news = false;
@@ -1609,7 +1624,7 @@ void tx_engine_main(zkgpu_verifier* v) {
         v->tx_cv.wait(lk, [&] { return v->tx_engine_quit || !v->tx_queue.empty(); });
         if (v->tx_queue.empty()) return;                 // (quit with nothing queued; what is queued at quit is still served)
       }
-      for (int set = 0; set < 2; ++set) {
+      for (int set = 0; set < max_rounds; ++set) {
         if (active[set] || v->tx_queue.empty()) continue;
         fresh[set].reset(new TxRound());
         TxRound& r = *fresh[set];
@@ -1659,7 +1674,9 @@ void tx_engine_main(zkgpu_verifier* v) {
       TxRound& r = *active[set];
       const bool running = r.call && r.rc == ZKGPU_OK;
       if (running && !r.call->done()) progress |= r.call->step();
-      if (!running || r.call->done()) {
+      // (a round whose stages are all queued is finished only once the device has settled: finish() then returns without
+      // waiting, and the other round is never kept from queueing its stages meanwhile)
+      if (!running || (r.call->done() && r.call->settled())) {
         if (r.call) {
           const int rc = r.call->finish();
           if (r.rc == ZKGPU_OK) r.rc = rc;

@@ -55,11 +55,13 @@ class TxDevice {
   // exactly once -- by proofs_finish, or by proofs_release if it was never started.
   virtual int proofs_stage(size_t ring_slot, size_t n, const TxProofSource* src, int host_threads, void** handle, std::string* err) = 0;
   virtual int proofs_start(size_t ring_slot, void* handle) = 0;
+  virtual bool proofs_done(void* handle) = 0;                               // never blocks: would proofs_finish return at once?
   virtual int proofs_finish(void* handle, uint8_t* accept_bits) = 0;
   virtual void proofs_release(void* handle) = 0;
   // signature equations: per row dynamic terms (scalars, points) + one term on the basepoint's table -> "is the identity"
   virtual int sigs_enqueue(int slot, size_t rows, const uint8_t* dyn_scalars, const uint8_t* dyn_points, const uint64_t* dyn_offsets,
                            const uint8_t* base_scalars) = 0;
+  virtual bool sigs_done(int slot) = 0;                                     // never blocks
   virtual int sigs_collect(int slot, uint8_t* bits) = 0;
   virtual std::string last_error() = 0;
 };
@@ -140,6 +142,16 @@ class TxCall {
     return OK;
   }
   bool done() const { return finished_; }
+  // after done(): has the device finished everything this call still has in flight, i.e. would finish() return without
+  // waiting?  (A caller that drives several calls asks before it calls finish(), so that it never sleeps inside one call
+  // while another has work to queue.)  Never blocks.
+  bool settled() {
+    for (size_t s = 0; s < seg_.size(); ++s) if (seg_[s].pending && !dev_.keys_done((int)(s % n_slots_))) return false;
+    const size_t n_sig = n_sig_made_locked();
+    for (size_t s = 0; s < n_sig; ++s) if (sig_stages_[s]->pending && !dev_.sigs_done((int)(s % n_slots_))) return false;
+    for (const auto& k : chunks_) if (k->handle && k->started && !dev_.proofs_done(k->handle)) return false;
+    return true;
+  }
   int finish() {
     stop_stager();
     // (after an error: nothing is left pending on the device)
@@ -475,7 +487,10 @@ class TxCall {
       progress = true;
     }
     if (rc_ == OK && next_stage_ < n_chunks && (proofs_first_ || next_stage_ < next_key_)) {     // (a chunk's proofs after its keys, unless the call is one chunk)
-      if (!ring_free) { proofs_collect(*chunks_[next_stage_ - RING]); progress = true; }
+      if (!ring_free) {                                   // the ring slot's last chunk: collected as soon as the device is through with it
+        Chunk& old = *chunks_[next_stage_ - RING];
+        if (!old.handle || !old.started || dev_.proofs_done(old.handle)) { proofs_collect(old); progress = true; }
+      }
       if (st_ready) { enqueue_proofs(next_stage_++); progress = true; }
     }
     if (rc_ == OK && next_kcollect_ < next_key_ && (!seg_[next_kcollect_].pending || dev_.keys_done((int)(next_kcollect_ % n_slots_)))) {
@@ -487,7 +502,10 @@ class TxCall {
     }
     while (rc_ == OK && next_sig_ < sig_avail) {
       const double t0 = now();
-      if (next_sig_ >= n_slots_) sigs_collect(next_sig_ - n_slots_);          // (the stage that used this slot last)
+      if (next_sig_ >= n_slots_) {                                            // the stage that used this slot last: collected once it is done
+        if (sig_stages_[next_sig_ - n_slots_]->pending && !dev_.sigs_done((int)(next_sig_ % n_slots_))) break;
+        sigs_collect(next_sig_ - n_slots_);
+      }
       SigStage& sg = *sig_stages_[next_sig_];
       const size_t ns = sg.keyed.size();
       if (ns) {
