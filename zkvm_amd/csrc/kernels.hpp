@@ -463,11 +463,56 @@ k_part_hist(JobDesc j, PartShape ps, uint32_t* __restrict__ hist, uint32_t* __re
   for (uint32_t p = threadIdx.x; p < ps.n_part; p += 256) hist[(uint64_t)p * ps.n_tiles + blockIdx.x] = cnt[p];
 }
 
+// Offsets of the (partition, tile) cells in ONE launch (until round 3: the generic three-launch scan over all n_part x n_tiles
+// cells, 0.3 ms of a 2.8 ms call for 4 MB of counters -- launch latency, not bandwidth).  One workgroup per partition: an
+// exclusive scan of its tile counts in place (the position of every tile's run INSIDE the partition) and the partition's
+// total; the workgroup that finishes last -- a ticket counter tells it -- scans the totals into the partitions' bases
+// (part_base[n_part] = the grand total).  The scatter adds the two.
 __global__ void __launch_bounds__(256)
-k_part_scatter(JobDesc j, PartShape ps, const uint32_t* __restrict__ offs, uint32_t* __restrict__ pe,
-               uint8_t* __restrict__ plo) {
+k_part_offsets(PartShape ps, uint32_t* __restrict__ hist /*[n_part][n_tiles], in place*/, uint32_t* __restrict__ totals /*[n_part]*/,
+               uint32_t* __restrict__ part_base /*[n_part + 1]*/, uint32_t* __restrict__ ticket) {
+  __shared__ uint32_t last;
+  const uint32_t p = blockIdx.x, t = threadIdx.x;
+  uint32_t* row = hist + (uint64_t)p * ps.n_tiles;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < ps.n_tiles; base += 256) {
+    const uint32_t i = base + t;
+    const uint32_t v = i < ps.n_tiles ? row[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(v, total);
+    if (i < ps.n_tiles) row[i] = carry + ex;
+    carry += total;
+  }
+  if (t == 0) {
+    totals[p] = carry;
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  uint32_t run = 0;
+  for (uint32_t base = 0; base < ps.n_part; base += 256) {
+    const uint32_t i = base + t;
+    const uint32_t v = i < ps.n_part ? atomicAdd(&totals[i], 0u) : 0u;      // (read at the L2: written by other workgroups)
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(v, total);
+    if (i < ps.n_part) part_base[i] = run + ex;
+    run += total;
+  }
+  if (t == 0) { part_base[ps.n_part] = run; *ticket = 0; }
+}
+
+// An entry on its way through the partition sort carries its low bucket bits with it: [31:24] low bucket bits, [23] sign,
+// [22:0] term index (the path is taken for at most 2^23 terms) -- one scattered 4-byte store per entry instead of a 4-byte
+// and a 1-byte one, and one array for the partition kernel to read.
+constexpr uint32_t PART_IDX_BITS = 23;
+
+__global__ void __launch_bounds__(256)
+k_part_scatter(JobDesc j, PartShape ps, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ part_base,
+               uint32_t* __restrict__ pe) {
   extern __shared__ uint32_t cur[];
-  for (uint32_t p = threadIdx.x; p < ps.n_part; p += 256) cur[p] = offs[(uint64_t)p * ps.n_tiles + blockIdx.x];
+  for (uint32_t p = threadIdx.x; p < ps.n_part; p += 256) cur[p] = part_base[p] + offs[(uint64_t)p * ps.n_tiles + blockIdx.x];
   __syncthreads();
   const uint64_t base = (uint64_t)blockIdx.x * PART_TILE;
   const uint32_t lo_mask = (1u << ps.lo_bits) - 1;
@@ -478,35 +523,53 @@ k_part_scatter(JobDesc j, PartShape ps, const uint32_t* __restrict__ offs, uint3
       for_each_digit(sc, j.w, j.n_windows, [&](int t, int d) {
         const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
         const uint32_t pos = atomicAdd(&cur[((uint32_t)t << ps.hi_bits) | (b >> ps.lo_bits)], 1u);
-        pe[pos] = ENTRY_DYN | (uint32_t)g | (d < 0 ? ENTRY_NEG : 0u);
-        plo[pos] = (uint8_t)(b & lo_mask);
+        pe[pos] = ((b & lo_mask) << 24) | (d < 0 ? 1u << PART_IDX_BITS : 0u) | (uint32_t)g;
       });
     }
   }
 }
 
+// One workgroup per partition: histogram of the low bucket bits (LDS), scan, then every entry to its final position -- in
+// LDS when the partition fits (PART_SORT_LDS entries: the sorted run then leaves as whole cache lines; placed straight into
+// HBM, as until round 3, the 4-byte stores of 2048 concurrent workgroups thrashed the L2: 492 MB written for 67 MB of
+// entries), straight to HBM otherwise (adversarial inputs: every term in one partition).  Also emits the bin end offsets
+// the accumulate kernel reads and, for the bin ordering, the size-class histogram of its 256 bins (k_bin_classes folded in).
+constexpr uint32_t PART_SORT_LDS = 12288;
+constexpr int SIZE_CLASSES = 256;
+
 __global__ void __launch_bounds__(256)
-k_part_sort(PartShape ps, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ pe,
-            const uint8_t* __restrict__ plo, uint32_t* __restrict__ entries, uint32_t* __restrict__ cursor) {
-  __shared__ uint32_t c[256], cur[256];
+k_part_sort(PartShape ps, const uint32_t* __restrict__ part_base, const uint32_t* __restrict__ pe,
+            uint32_t* __restrict__ entries, uint32_t* __restrict__ cursor, uint32_t* __restrict__ class_count) {
+  __shared__ uint32_t c[256], cur[256], cls[SIZE_CLASSES];
+  extern __shared__ uint32_t staged[];                  // PART_SORT_LDS entries
   const uint32_t p = blockIdx.x, t = threadIdx.x;
-  const uint32_t start = offs[(uint64_t)p * ps.n_tiles];
-  const uint32_t end = offs[(uint64_t)(p + 1) * ps.n_tiles];   // one extra element holds the grand total
-  c[t] = 0;
+  const uint32_t start = part_base[p], end = part_base[p + 1];
+  c[t] = 0; cls[t] = 0;
   __syncthreads();
-  for (uint32_t e = start + t; e < end; e += 256) atomicAdd(&c[plo[e]], 1u);
+  for (uint32_t e = start + t; e < end; e += 256) atomicAdd(&c[pe[e] >> 24], 1u);
   __syncthreads();
   uint32_t total;
   const uint32_t mine = c[t];
   const uint32_t ex = block_exclusive_scan(mine, total);
-  cur[t] = start + ex;
+  cur[t] = ex;
   const uint32_t n_lo = 1u << ps.lo_bits;
-  if (t < n_lo) cursor[(uint64_t)p * n_lo + t] = start + ex + mine;   // END offset of bin (p, lo = t)
-  __syncthreads();
-  for (uint32_t e = start + t; e < end; e += 256) {
-    const uint32_t pos = atomicAdd(&cur[plo[e]], 1u);
-    entries[pos] = pe[e];
+  if (t < n_lo) {
+    cursor[(uint64_t)p * n_lo + t] = start + ex + mine;   // END offset of bin (p, lo = t)
+    atomicAdd(&cls[(SIZE_CLASSES - 1) - min(mine, (uint32_t)(SIZE_CLASSES - 1))], 1u);
   }
+  __syncthreads();
+  if (cls[t]) atomicAdd(&class_count[t], cls[t]);
+  const uint32_t n = end - start;
+  const bool in_lds = n <= PART_SORT_LDS;
+  for (uint32_t e = start + t; e < end; e += 256) {
+    const uint32_t v = pe[e];
+    const uint32_t pos = atomicAdd(&cur[v >> 24], 1u);
+    const uint32_t out = ENTRY_DYN | (v & ((1u << PART_IDX_BITS) - 1)) | ((v >> PART_IDX_BITS) & 1u ? ENTRY_NEG : 0u);
+    if (in_lds) staged[pos] = out; else entries[start + pos] = out;
+  }
+  if (!in_lds) return;
+  __syncthreads();
+  for (uint32_t i = t; i < n; i += 256) entries[start + i] = staged[i];
 }
 
 __device__ __forceinline__ void shfl_down_ge(ge& out, const ge& in, int delta) {
@@ -525,7 +588,6 @@ __device__ __forceinline__ void shfl_down_ge(ge& out, const ge& in, int delta) {
 // sort): the lanes of a wavefront get bins of (nearly) equal size, and the fullest
 // bins -- e.g. the top window, whose few significant bits concentrate the terms in a
 // handful of buckets -- start first instead of forming a tail.
-constexpr int SIZE_CLASSES = 256;
 __device__ __forceinline__ uint32_t bin_size_class(const uint32_t* __restrict__ cursor, uint64_t bin) {
   const uint32_t cnt = cursor[bin] - (bin ? cursor[bin - 1] : 0u);
   return (SIZE_CLASSES - 1) - min(cnt, (uint32_t)(SIZE_CLASSES - 1));   // class 0 = fullest
@@ -703,20 +765,22 @@ k_bucket_reduce(const uint32_t* __restrict__ cursor, const uint32_t* __restrict_
 }
 
 // ---- k_window_partials ------------------------------------------------------------
-// One wave per window: fold `chunks_per_window` partials into the window sum.
-// Each lane adds its strided share, then the 64 lane sums are combined with
-// wavefront shuffles (40 dwords per point per step).
-
-__global__ void __launch_bounds__(64)
+// One workgroup of four wavefronts per window: fold `chunks_per_window` partials into the window sum.  Each lane adds its
+// strided share, the 64 lane sums of a wavefront are combined with shuffles (40 dwords per point per step), the four
+// wavefront sums through LDS.  (Until round 3 one wavefront per window: 32 + 6 dependent additions for the 2048 partials of
+// a 16-bit window; now 8 + 6 + 3.)
+__global__ void __launch_bounds__(256)
 k_window_partials(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ partial_nonempty,
                   uint32_t* __restrict__ window_sums, uint32_t* __restrict__ window_nonempty,
                   uint32_t chunks_per_window) {
+  __shared__ uint32_t wave_pts[4 * EXT_WORDS];
+  __shared__ int wave_have[4];
   const uint64_t win = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   ge acc;
   ge_identity(acc);
   int have = 0;
-  for (uint32_t c = lane; c < chunks_per_window; c += 64) {
+  for (uint32_t c = t; c < chunks_per_window; c += 256) {
     const uint64_t task = win * chunks_per_window + c;
     if (partial_nonempty[task]) {
       ge p;
@@ -736,9 +800,21 @@ k_window_partials(const uint32_t* __restrict__ partials, const uint32_t* __restr
     }
   }
   if (lane == 0) {
-    window_nonempty[win] = (uint32_t)have;
-    if (have) store_ext(window_sums + win * EXT_WORDS, acc);
+    wave_have[wid] = have;
+    uint32_t* w = wave_pts + wid * EXT_WORDS;
+    for (int q = 0; q < 10; ++q) { w[q] = acc.X.v[q]; w[10 + q] = acc.Y.v[q]; w[20 + q] = acc.Z.v[q]; w[30 + q] = acc.T.v[q]; }
   }
+  __syncthreads();
+  if (t != 0) return;
+  for (int wv = 1; wv < 4; ++wv) {
+    if (!wave_have[wv]) continue;
+    ge o;
+    const uint32_t* w = wave_pts + wv * EXT_WORDS;
+    for (int q = 0; q < 10; ++q) { o.X.v[q] = w[q]; o.Y.v[q] = w[10 + q]; o.Z.v[q] = w[20 + q]; o.T.v[q] = w[30 + q]; }
+    if (have) ge_add(acc, acc, o); else { acc = o; have = 1; }
+  }
+  window_nonempty[win] = (uint32_t)have;
+  if (have) store_ext(window_sums + win * EXT_WORDS, acc);
 }
 
 // ---- k_msm_finish ----------------------------------------------------------------

@@ -394,7 +394,11 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
                        (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, job.n_msm,
                        (uint32_t*)c->msm_fail.p, bad_index, (uint8_t*)nullptr);
   }
-  const bool part_sort = job.n_msm == 1 && job.n_static == 0 && w - 1 >= PART_LO_BITS && n_terms >= 32768;
+  const bool part_sort = job.n_msm == 1 && job.n_static == 0 && w - 1 >= PART_LO_BITS && n_terms >= 32768 && n_terms <= (1ull << PART_IDX_BITS);
+  TRY(ensure(c, c->class_count, 2 * SIZE_CLASSES * 4));
+  uint32_t* class_count = (uint32_t*)c->class_count.p;
+  uint32_t* class_cursor = class_count + SIZE_CLASSES;
+  HIP_TRY(c, hipMemsetAsync(class_count, 0, SIZE_CLASSES * 4, s));
   if (part_sort) {
     // single large MSM: two-level sort with LDS atomics only
     PartShape ps;
@@ -402,36 +406,32 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
     ps.hi_bits = (uint32_t)(w - 1 - PART_LO_BITS);
     ps.n_part = (uint32_t)jd.n_windows << ps.hi_bits;
     ps.n_tiles = (uint32_t)blocks_for(n_terms, PART_TILE);
-    const uint64_t n_cells = (uint64_t)ps.n_part * ps.n_tiles + 1;     // + grand total
-    const unsigned cell_blocks = blocks_for(n_cells, SCAN_TILE);
+    const uint64_t n_cells = (uint64_t)ps.n_part * ps.n_tiles;
     TRY(ensure(c, c->part_hist, n_cells * 4));
-    TRY(ensure(c, c->block_sums, ((size_t)cell_blocks + 1) * 4));
+    TRY(ensure(c, c->block_sums, ((size_t)2 * ps.n_part + 4) * 4));        // totals[n_part] | part_base[n_part + 1] | ticket
     TRY(ensure(c, c->part_entries, std::max<uint64_t>(max_entries, 1) * 4));
-    TRY(ensure(c, c->part_lo, std::max<uint64_t>(max_entries, 1)));
-    HIP_TRY(c, hipMemsetAsync((uint32_t*)c->part_hist.p + (n_cells - 1), 0, 4, s));
+    uint32_t* totals = (uint32_t*)c->block_sums.p;
+    uint32_t* part_base = totals + ps.n_part;
+    uint32_t* ticket = part_base + ps.n_part + 1;
+    HIP_TRY(c, hipMemsetAsync(ticket, 0, 4, s));
     {
       Launch l(c, "k_part_hist");
       hipLaunchKernelGGL(k_part_hist, dim3(ps.n_tiles), dim3(256), ps.n_part * 4, s, jd, ps, (uint32_t*)c->part_hist.p,
                          status);
     }
     {
-      Launch l(c, "k_scan");
-      hipLaunchKernelGGL(k_scan_reduce, dim3(cell_blocks), dim3(SCAN_BLOCK), 0, s, (const uint32_t*)c->part_hist.p,
-                         n_cells, (uint32_t*)c->block_sums.p);
-      hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, s, (uint32_t*)c->block_sums.p, cell_blocks);
-      hipLaunchKernelGGL(k_scan_apply, dim3(cell_blocks), dim3(SCAN_BLOCK), 0, s, (uint32_t*)c->part_hist.p, n_cells,
-                         (const uint32_t*)c->block_sums.p);
+      Launch l(c, "k_part_offsets");
+      hipLaunchKernelGGL(k_part_offsets, dim3(ps.n_part), dim3(256), 0, s, ps, (uint32_t*)c->part_hist.p, totals, part_base, ticket);
     }
     {
       Launch l(c, "k_part_scatter");
       hipLaunchKernelGGL(k_part_scatter, dim3(ps.n_tiles), dim3(256), ps.n_part * 4, s, jd, ps,
-                         (const uint32_t*)c->part_hist.p, (uint32_t*)c->part_entries.p, (uint8_t*)c->part_lo.p);
+                         (const uint32_t*)c->part_hist.p, (const uint32_t*)part_base, (uint32_t*)c->part_entries.p);
     }
     {
       Launch l(c, "k_part_sort");
-      hipLaunchKernelGGL(k_part_sort, dim3(ps.n_part), dim3(256), 0, s, ps, (const uint32_t*)c->part_hist.p,
-                         (const uint32_t*)c->part_entries.p, (const uint8_t*)c->part_lo.p, (uint32_t*)c->entries.p,
-                         (uint32_t*)c->bins.p);
+      hipLaunchKernelGGL(k_part_sort, dim3(ps.n_part), dim3(256), PART_SORT_LDS * 4, s, ps, (const uint32_t*)part_base,
+                         (const uint32_t*)c->part_entries.p, (uint32_t*)c->entries.p, (uint32_t*)c->bins.p, class_count);
     }
   } else {
     if (n_terms) {
@@ -454,16 +454,13 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
     }
   }
   TRY(ensure(c, c->bin_order, n_bins * 4));
-  TRY(ensure(c, c->class_count, 2 * SIZE_CLASSES * 4));
-  uint32_t* class_count = (uint32_t*)c->class_count.p;
-  uint32_t* class_cursor = class_count + SIZE_CLASSES;
-  HIP_TRY(c, hipMemsetAsync(class_count, 0, SIZE_CLASSES * 4, s));
   TRY(ensure(c, c->heavy, (HEAVY_MAX + 1) * 4));
   HIP_TRY(c, hipMemsetAsync(c->heavy.p, 0, 4, s));
   {
     Launch l(c, "k_bin_order");
-    hipLaunchKernelGGL(k_bin_classes, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p, n_bins,
-                       class_count);
+    if (!part_sort)                                      // (the partition sort counts the size classes of its bins itself)
+      hipLaunchKernelGGL(k_bin_classes, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p, n_bins,
+                         class_count);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(256), 0, s, (const uint32_t*)class_count, class_cursor);
     hipLaunchKernelGGL(k_bin_order, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p, n_bins,
                        class_cursor, (uint32_t*)c->bin_order.p, (uint32_t*)c->heavy.p);
@@ -491,7 +488,7 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
   }
   if (chunks > 1) {
     Launch l(c, "k_window_partials");
-    hipLaunchKernelGGL(k_window_partials, dim3((unsigned)n_wins), dim3(64), 0, s, (const uint32_t*)c->partials.p,
+    hipLaunchKernelGGL(k_window_partials, dim3((unsigned)n_wins), dim3(256), 0, s, (const uint32_t*)c->partials.p,
                        (const uint32_t*)c->partial_flags.p, (uint32_t*)c->window_sums.p,
                        (uint32_t*)c->window_flags.p, chunks);
   }
