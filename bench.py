@@ -164,6 +164,31 @@ def pmc_tables():
     return out
 
 
+def side_leg_counters(ctx, call, call_s, pmc_name):
+    """One more call of a side leg with the library's per-launch HIP events on: the sum of its kernels' durations against
+    the call's own time (how much of the call the device is busy -- kernels of one call run one after the other on its
+    stream), and, with the committed SQ_INSTS_VALU pass of the same workload (profiles/<pmc_name>.json, tools/profile_bench.sh),
+    the wave instructions of the call and the fraction of the chip's issue peak they make over the call's time."""
+    ctx.profile_reset()
+    ctx.profile(True)
+    call()
+    ctx.profile(False)
+    prof = {k: v for k, v in ctx.profile_read().items() if v[0]}
+    kernel_ms = sum(v[1] for v in prof.values())
+    out = {"kernel_sum_ms": round(kernel_ms, 3), "call_ms": round(call_s * 1e3, 3), "kernel_sum_over_call": round(kernel_ms / (call_s * 1e3), 4),
+           "launches": int(sum(v[0] for v in prof.values())),
+           "top_kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:6]}}
+    try:
+        tbl = json.load(open(os.path.join(ROOT, "profiles", pmc_name + ".json")))
+        missing = [k for k in prof if k not in tbl]
+        insts = sum(v[0] * tbl[k] for k, v in prof.items() if k in tbl)
+        out.update(valu_wave_instructions=int(insts), valu_issue_frac=round(insts / (call_s * VALU_PEAK_GINST * 1e9 / 64), 4),
+                   valu_kernels_without_counter=missing or None, valu_source="profiles/%s.json (SQ_INSTS_VALU per launch x launches of this call)" % pmc_name)
+    except Exception as e:                                      # noqa: BLE001
+        out.update(valu_wave_instructions=None, valu_issue_frac=None, valu_source="no committed counter table (%s)" % type(e).__name__)
+    return out
+
+
 def roofline_object(solo, launches_per_step, in_flight_ms, alg_bytes_step, units_step, ms_per_step, table_bytes, note, counters=True):
     """solo: kernel -> mean ms alone on the chip (HIP events, measured live after the timed region);
     launches_per_step: kernel -> launches per step; dominant = largest summed solo time per step.
@@ -328,9 +353,10 @@ def prover_program_microbench(ctx, host_threads: int, batch: int = 1024):
     v = R1csVerifier(ctx, gens, desc)
     bm = v.verify_gpu(batch, b"".join(coms), b"".join(proofs), len(proofs[0]), shake(b"program-r", 64 * batch))
     v.close()
-    gens.close()
     assert bm == bitmap_of([1] * batch), "a proof of the 1032-constraint program did not verify"
-    return {"proofs_per_s": round(batch / dt, 1), "batch": batch, "ms_per_proof": round(dt / batch * 1e3, 4),
+    counters = side_leg_counters(ctx, lambda: pr.prove(vals, givens, seeds), dt, "pmc_valu_proverprog")
+    gens.close()
+    return {"proofs_per_s": round(batch / dt, 1), "batch": batch, "ms_per_proof": round(dt / batch * 1e3, 4), "device": counters,
             "constraints": len(cons), "multipliers": n, "commitments": m, "proof_bytes": len(proofs[0]), "host_threads": host_threads,
             "host_lockstep_proofs_per_s": round(256 / dt_host, 1),
             "note": "zkgpu_r1cs_prove_batch on a described constraint system (8 x 64-bit range proofs), time of the library "
@@ -474,7 +500,9 @@ def prover_microbench(ctx, gens, host_threads: int, batch: int = 2048, ctx2=None
     bm = v.verify_bitmap_gpu(txs, shake(b"prover-r", 64 * batch))
     v.close()
     assert bm == bitmap_of([1] * batch), "a proof of the GPU prover did not verify"
-    return {"proofs_per_s": round(batch / best, 1), "batch": batch, "ms_per_proof": round(best / batch * 1e3, 4),
+    pr.host_threads = host_threads
+    counters = side_leg_counters(ctx, lambda: pr.prove_packed(2, 2, batch, qa, fl, sd), best, "pmc_valu_prover")
+    return {"proofs_per_s": round(batch / best, 1), "batch": batch, "ms_per_proof": round(best / batch * 1e3, 4), "device": counters,
             "two_calls_in_flight_proofs_per_s": round(2 * rounds * batch / dt2, 1),
             "host_threads": host_threads, "host_lockstep_proofs_per_s": round(512 / dt_host, 1),
             "note": "zkgpu_cloak_prove_batch on contiguous inputs, time of the library call: the whole proof on the device "

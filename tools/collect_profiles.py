@@ -25,8 +25,11 @@ def short(name):
     return n.split("<")[0]
 
 
-for kind in ("prof", "solo", "msm", "prover"):
-    label = {"prof": "bench", "solo": "solo", "msm": "msm", "prover": "prover"}[kind]
+for kind in ("prof", "solo", "msm", "prover", "proverprog", "tx"):
+    label = {"prof": "bench", "solo": "solo", "msm": "msm", "prover": "prover", "proverprog": "proverprog", "tx": "tx"}[kind]
+    txt_out = os.path.join(go, "%s_%s.txt" % (kind, tag))
+    if os.path.exists(txt_out) and os.path.getsize(txt_out):
+        shutil.copy(txt_out, os.path.join(out, "%s_%s_output.txt" % (tag, label)))
     stats = glob.glob(os.path.join(go, "%s_%s" % (kind, tag), "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, label)))
@@ -80,4 +83,29 @@ v = {"_note": "SQ_INSTS_VALU per launch (wave instructions; x 64 lanes for threa
 v["_units_per_launch"] = units
 v.update({k: int(x) for k, x in sorted(valu.items())})
 json.dump(v, open(os.path.join(out, "pmc_valu.json"), "w"), indent=1, sort_keys=True)
+# the side paths: SQ_INSTS_VALU per launch of every kernel of the prover / the 1032-constraint program / a transaction call
+for prefix, what in (("pmcprover", "tools/prover_profile.py (2048 cloak proofs per call)"),
+                     ("pmcproverprog", "tools/prover_program_profile.py (1024 proofs of the 1032-constraint program per call)"),
+                     ("pmctx", "tools/tx_call_profile.py (8192 distinct serialized transactions per call)")):
+    files = glob.glob(os.path.join(go, "%s_%s_SQ_WAVE_CYCLES" % (prefix, tag), "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    agg = collections.OrderedDict()
+    for r in csv.DictReader(open(files[0])):
+        agg.setdefault(short(r["Kernel_Name"]), collections.OrderedDict()).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    side = {"_note": "SQ_INSTS_VALU per launch (wave instructions), rocprofv3 --pmc pass of tools/profile_bench.sh %s on %s: mean over "
+                     "the last <= 8 dispatches of each kernel (kernels launched with several sizes per call show the mean of them); "
+                     "_per_call = every dispatch of the run summed / the calls the script makes" % (tag, what)}
+    with open(os.path.join(out, "%s_%s_SQ_WAVE_CYCLES.txt" % (tag, prefix)), "w") as f:
+        f.write("# rocprofv3 --pmc (tools/profile_bench.sh %s), %s; per kernel: counter, dispatches, last value, mean\n" % (tag, what))
+        total = 0.0
+        for k, cs in agg.items():
+            for c, v in sorted(cs.items()):
+                f.write("%-30s %-22s %5d %16.1f %16.1f\n" % (k[:30], c, len(v), v[-1], sum(v) / len(v)))
+                if c == "SQ_INSTS_VALU":
+                    tail = v[-8:] if len(v) >= 8 else v
+                    side[k] = int(sum(tail) / len(tail))
+                    total += sum(v)
+    side["_all_dispatches_valu"] = int(total)
+    json.dump(side, open(os.path.join(out, "pmc_valu_%s.json" % prefix[3:]), "w"), indent=1, sort_keys=True)
 print("wrote", sorted(f for f in os.listdir(out) if f.startswith(tag) or f.startswith("pmc_")))
