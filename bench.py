@@ -869,9 +869,10 @@ def run_config2(args, W):
     timed(n_warm, base=args.steps)                            # warm-up on sets the timed steps do not use
     # HIP events around every launch of the contexts in flight
     prof_ctxs = [bv.lane(i) for i in range(bv.lanes())] if bv is not None else ctxs[:1]
+    inflight_events = os.environ.get("ZKGPU_BENCH_NO_INFLIGHT_EVENTS") != "1"      # (experiment: what the HIP events around every launch cost)
     for c in prof_ctxs:
         c.profile_reset()
-        c.profile(True)
+        c.profile(inflight_events)
     W.barrier()
     t0 = time.perf_counter()
     host_time.update(submit=0.0, n=0)
