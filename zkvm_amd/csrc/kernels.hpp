@@ -170,46 +170,52 @@ k_decompress(const uint32_t* __restrict__ pts, uint32_t* __restrict__ rows, uint
 //   (w = v * u2^2, r = w^((p-5)/8))
 constexpr int DEC_WORDS = 64;
 
+// what DECODE computes before the square root: s, u1 = 1 - s^2, u2 = 1 + s^2, v, w = v u2^2 (the argument of
+// SQRT_RATIO_M1(1, w)), w^7 (what the chain is handed) and "s is canonical and non-negative".  A dozen products: cheap enough
+// to compute TWICE -- k_decompress_pre keeps w^7 alone, k_decompress_post reads the 32 bytes of the point again and
+// recomputes the rest -- which takes 200 B per point out of the scratch traffic of each of the two kernels (round 4: they
+// are bandwidth-bound and sit on the critical path of the 2^20 MSM; until round 3 s, u1, u2, v, w went through the scratch).
+struct DecFront { fe s, u1, u2, v, w, w7; bool pre_ok; };
+__device__ __forceinline__ void dec_front(DecFront& d, const uint32_t* __restrict__ pts, uint64_t i) {
+  const uint4* p4 = reinterpret_cast<const uint4*>(pts + 8 * i);
+  uint4 a = p4[0], b = p4[1];
+  uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  fe ss, u2_sqr, t;
+  fe_from_words(d.s, w);
+  uint32_t chk[8];
+  fe_to_words(chk, d.s);
+  bool canonical = true;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) canonical &= (chk[k] == w[k]);
+  d.pre_ok = canonical && !(w[0] & 1);
+  fe_sq(ss, d.s);
+  fe_sub(d.u1, fe_one(), ss);
+  fe_add(d.u2, fe_one(), ss);
+  fe_carry(d.u1);
+  fe_carry(d.u2);
+  fe_sq(u2_sqr, d.u2);
+  fe_sq(t, d.u1);
+  fe_mul(t, t, fe_D());
+  fe_add(t, t, u2_sqr);
+  fe_sub_c(d.v, fe_zero(), t);
+  fe_mul(d.w, d.v, u2_sqr);           // w: the argument of SQRT_RATIO_M1(1, w)
+  // (1 * w^7)^((p-5)/8) is what the chain computes
+  fe w2, w3;
+  fe_sq(w2, d.w);
+  fe_mul(w3, w2, d.w);
+  fe_sq(d.w7, w3);
+  fe_mul(d.w7, d.w7, d.w);
+}
+
 __global__ void __launch_bounds__(256)
 k_decompress_pre(const uint32_t* __restrict__ pts, uint32_t* __restrict__ scratch, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint4* p4 = reinterpret_cast<const uint4*>(pts + 8 * i);
-  uint4 a = p4[0], b = p4[1];
-  uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  fe s, ss, u1, u2, u2_sqr, v, t;
-  fe_from_words(s, w);
-  uint32_t chk[8];
-  fe_to_words(chk, s);
-  bool canonical = true;
+  DecFront d;
+  dec_front(d, pts, i);
+  uint32_t* col = scratch + (uint64_t)50 * n + i;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) canonical &= (chk[k] == w[k]);
-  const bool pre_ok = canonical && !(w[0] & 1);
-  fe_sq(ss, s);
-  fe_sub(u1, fe_one(), ss);
-  fe_add(u2, fe_one(), ss);
-  fe_carry(u1);
-  fe_carry(u2);
-  fe_sq(u2_sqr, u2);
-  fe_sq(t, u1);
-  fe_mul(t, t, fe_D());
-  fe_add(t, t, u2_sqr);
-  fe_sub_c(v, fe_zero(), t);
-  fe_mul(t, v, u2_sqr);               // w: the argument of SQRT_RATIO_M1(1, w)
-  // (1 * w^7)^((p-5)/8) is what the chain computes: hand it w^7 and keep w^3 for afterwards
-  fe w2, w3, w7;
-  fe_sq(w2, t);
-  fe_mul(w3, w2, t);
-  fe_sq(w7, w3);
-  fe_mul(w7, w7, t);
-  uint32_t* col = scratch + i;
-#pragma unroll
-  for (int k = 0; k < 10; ++k) {
-    col[(uint64_t)k * n] = s.v[k]; col[(uint64_t)(10 + k) * n] = u1.v[k]; col[(uint64_t)(20 + k) * n] = u2.v[k];
-    col[(uint64_t)(30 + k) * n] = v.v[k]; col[(uint64_t)(40 + k) * n] = t.v[k]; col[(uint64_t)(50 + k) * n] = w7.v[k];
-  }
-  col[(uint64_t)60 * n] = pre_ok ? 1u : 0u;
-  (void)w3;
+  for (int k = 0; k < 10; ++k) col[(uint64_t)k * n] = d.w7.v[k];
 }
 
 // row[50..59] <- row[50..59]^((p-5)/8)
@@ -227,19 +233,19 @@ k_pow22523(uint32_t* __restrict__ scratch, uint64_t n) {
 }
 
 __global__ void __launch_bounds__(256)
-k_decompress_post(const uint32_t* __restrict__ scratch, uint32_t* __restrict__ rows, uint64_t n,
+k_decompress_post(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scratch, uint32_t* __restrict__ rows, uint64_t n,
                   const uint64_t* __restrict__ offsets, uint32_t n_msm, uint32_t* __restrict__ msm_fail,
                   unsigned long long* __restrict__ bad_index) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t* col = scratch + i;
-  fe s, u1, u2, v, w, pw;
+  DecFront d;
+  dec_front(d, pts, i);
+  const fe s = d.s, u1 = d.u1, u2 = d.u2, v = d.v, w = d.w;
+  const bool pre_ok = d.pre_ok;
+  const uint32_t* col = scratch + (uint64_t)50 * n + i;
+  fe pw;
 #pragma unroll
-  for (int k = 0; k < 10; ++k) {
-    s.v[k] = col[(uint64_t)k * n]; u1.v[k] = col[(uint64_t)(10 + k) * n]; u2.v[k] = col[(uint64_t)(20 + k) * n];
-    v.v[k] = col[(uint64_t)(30 + k) * n]; w.v[k] = col[(uint64_t)(40 + k) * n]; pw.v[k] = col[(uint64_t)(50 + k) * n];
-  }
-  const bool pre_ok = col[(uint64_t)60 * n] != 0;
+  for (int k = 0; k < 10; ++k) pw.v[k] = col[(uint64_t)k * n];
   // SQRT_RATIO_M1(1, w): r = w^3 * (w^7)^((p-5)/8); check = w r^2
   fe w3, r, t, check, r_prime, neg_r;
   fe_sq(t, w);

@@ -356,7 +356,8 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
   TRY(ensure(c, c->status, 64));
 
   hipStream_t s = c->stream;
-  HIP_TRY(c, hipMemsetAsync(c->bins.p, 0, (n_bins + 1) * 4, s));
+  const bool part_sort = job.n_msm == 1 && job.n_static == 0 && w - 1 >= PART_LO_BITS && n_terms >= 32768 && n_terms <= (1ull << PART_IDX_BITS);
+  if (!part_sort) HIP_TRY(c, hipMemsetAsync(c->bins.p, 0, (n_bins + 1) * 4, s));     // (the partition sort writes every bin's end offset itself)
   HIP_TRY(c, hipMemsetAsync(c->msm_fail.p, 0, (size_t)job.n_msm * 4, s));
   if (reset_status) {
     HIP_TRY(c, hipMemsetAsync(c->status.p, 0, 8, s));
@@ -383,7 +384,7 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
                          (uint32_t*)c->dec_scratch.p, job.n_dyn);
       hipLaunchKernelGGL(k_pow22523, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, sd, (uint32_t*)c->dec_scratch.p,
                          job.n_dyn);
-      hipLaunchKernelGGL(k_decompress_post, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, sd,
+      hipLaunchKernelGGL(k_decompress_post, dim3(blocks_for(job.n_dyn, 256)), dim3(256), 0, sd, job.d_dyn_points,
                          (const uint32_t*)c->dec_scratch.p, (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets,
                          job.n_msm, (uint32_t*)c->msm_fail.p, bad_index);
     }
@@ -394,7 +395,6 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
                        (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, job.n_msm,
                        (uint32_t*)c->msm_fail.p, bad_index, (uint8_t*)nullptr);
   }
-  const bool part_sort = job.n_msm == 1 && job.n_static == 0 && w - 1 >= PART_LO_BITS && n_terms >= 32768 && n_terms <= (1ull << PART_IDX_BITS);
   TRY(ensure(c, c->class_count, 2 * SIZE_CLASSES * 4));
   uint32_t* class_count = (uint32_t*)c->class_count.p;
   uint32_t* class_cursor = class_count + SIZE_CLASSES;
