@@ -287,6 +287,57 @@ def test_exchange_step_in_a_mocked_world_of_n_ranks(ctx, oracle, world, rank):
         gens.close()
 
 
+def test_config4_at_full_size_in_a_mocked_world_of_eight(ctx, gens512, oracle):
+    """BASELINE configs[3] in its stated size on the one GPU there is: 65 536 mixed-arity transactions (bench.py's own
+    construction: gpu_util.mixed_block, 1 in 61 damaged, every kind in every shape), cut into EIGHT shards by
+    zkgpu_shard_cuts, and zkgpu_verifier_verify_sharded run as every rank 0 .. 7 in turn -- each time this GPU verifies that
+    rank's shard and the other seven bitmaps arrive through the exchange from the collective mock -- so that every one of
+    the 65 536 transactions has been verified on the device through the product's sharded path (cuts, shard verification,
+    framing, unpacking), and the whole bitmap on every rank equals the expectation.  The expectation is bench.py's
+    (damaged -> 0, everything else 1) and is held against the oracle's full verifier for the first shard and a sample of
+    every other.  What this cannot cover is RCCL's own rendezvous between eight processes."""
+    from zkvm_amd.native import Comm, shard_cuts
+    from zkvm_amd.verifier import BlockVerifier
+    world, n = 8, 65536
+    txs = mixed_block(n, seed=0x5A6B564D)                    # (bench.py --config 4 --gpus 8 builds exactly this block)
+    want = [0 if i % 61 == 3 else 1 for i in range(n)]
+    r = hashlib.shake_256(b"config 4 full size").digest(64 * n)
+    cuts = shard_cuts([(t[0], t[1]) for t in txs], world)
+    assert cuts[0] == 0 and cuts[-1] == n and all(4000 < b - a < 13000 for a, b in zip(cuts, cuts[1:]))
+    # the constructed expectation against the oracle: the whole first shard, and 300 transactions of every other
+    idx = list(range(cuts[0], cuts[1])) + [i for k in range(1, world) for i in range(cuts[k], cuts[k + 1], max(1, (cuts[k + 1] - cuts[k]) // 300))]
+    idx += [i for i in range(3, n, 61 * 7)]                                         # and damaged ones everywhere
+    idx = sorted(set(idx))
+    got = oracle_block_bits(oracle, [txs[i] for i in idx], b"".join(r[64 * i: 64 * i + 64] for i in idx), threads=16)
+    assert got == [want[i] for i in idx]
+
+    def shard_bitmap(k):
+        b = bytearray((cuts[k + 1] - cuts[k] + 7) // 8)
+        for j, i in enumerate(range(cuts[k], cuts[k + 1])):
+            b[j // 8] |= want[i] << (j % 8)
+        return bytes(b)
+    whole = bytearray((n + 7) // 8)
+    for i, v in enumerate(want):
+        whole[i // 8] |= v << (i % 8)
+    good = [_slot(cuts, k, shard_bitmap(k)) for k in range(world)]
+    lib = ctx.lib
+    block = _cloak(txs)
+    bv = BlockVerifier(ctx, gens512)
+    try:
+        for rank in range(world):
+            junk = list(good)
+            junk[rank] = b"\xff" * len(good[0])                    # (overwritten by what this rank really sends)
+            assert lib.zkgpu_debug_comm_mock(ctx.h, world, b"".join(junk), len(junk[0])) >= 0
+            comm = Comm(ctx, rank, world, bytes(128))
+            try:
+                assert bv.verify_sharded(comm, block, r) == bytes(whole), rank
+            finally:
+                comm.close()
+    finally:
+        lib.zkgpu_debug_comm_mock(ctx.h, 0, None, 0)
+        bv.close()
+
+
 def test_synchronous_calls_never_run_over_a_batch_in_flight(ctx, oracle):
     """A context with a submitted batch refuses every synchronous entry point (they share its status words and pinned
     result buffer), and the batch's verdicts are untouched; zkgpu_tx_verify_batch -- whose key and signature stages are
