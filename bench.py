@@ -468,6 +468,13 @@ def prover_microbench(ctx, gens, host_threads: int, batch: int = 2048, ctx2=None
         seeds.append(hashlib.sha256(b"bench prover %d" % i).digest())
     qa = (C.c_uint64 * (4 * batch))(*[q for row in qs for q in row])
     fl, sd = b"".join(f for row in fs for f in row), b"".join(seeds)
+    # the prover is mostly multiscalar multiplications ON THE GENERATORS (a third of its time is k_static_accumulate): for it the
+    # widest tables pay -- 79 k proofs/s over 16-bit tables against 69 k over the 14-bit ones the library chooses for a
+    # verifier (zkgpu_choose_table_bits: the knee of the VERIFIER's sweep) -- so this leg builds 16-bit tables of its own
+    from zkvm_amd.verifier import BulletproofGens
+    own_gens = None
+    if gens.points.table_bits() != 16:
+        own_gens = gens = BulletproofGens(ctx, 256, table_bits=16)
     pr = Prover(ctx, gens, host_threads=host_threads)
     ctx.set_prover_mode(1)                                     # the round-1 arrangement: host threads in lockstep
     pr.prove(2, 2, qs[:8], fs[:8], seeds[:8])
@@ -502,7 +509,10 @@ def prover_microbench(ctx, gens, host_threads: int, batch: int = 2048, ctx2=None
     assert bm == bitmap_of([1] * batch), "a proof of the GPU prover did not verify"
     pr.host_threads = host_threads
     counters = side_leg_counters(ctx, lambda: pr.prove_packed(2, 2, batch, qa, fl, sd), best, "pmc_valu_prover")
+    if own_gens is not None:
+        own_gens.close()
     return {"proofs_per_s": round(batch / best, 1), "batch": batch, "ms_per_proof": round(best / batch * 1e3, 4), "device": counters,
+            "generator_table_bits": 16,
             "two_calls_in_flight_proofs_per_s": round(2 * rounds * batch / dt2, 1),
             "host_threads": host_threads, "host_lockstep_proofs_per_s": round(512 / dt_host, 1),
             "note": "zkgpu_cloak_prove_batch on contiguous inputs, time of the library call: the whole proof on the device "
