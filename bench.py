@@ -1178,18 +1178,27 @@ def run_config4(args, W):
         bv.lane(i).set_locate_parts(args.locate_parts)
         bv.lane(i).set_tail_mode(args.tail_mode)
         bv.lane(i).set_horner_mode(args.horner_mode)
+    # since round 4 a block's batches are tickets: batches of one shape from the blocks in flight are merged into device batches
+    # of up to `merge` transactions (8192 here).  Every lane's workspace is sized for that beforehand (zkgpu_verifier_reserve):
+    # batches of five shapes and varying sizes would otherwise keep growing workspaces -- hipMalloc synchronises the device --
+    # for many steps
+    merge4 = args.merge if args.merge_given else 8192
+    bv.set_merge(merge4)
+    for shape in sorted(set(shapes[lo:hi])):
+        bv.reserve(shape[0], shape[1], merge4)
     mine = [CloakTx(*t) for t in txs[lo:hi]]
     block = bv.block(mine, r_bytes[64 * lo: 64 * hi])          # this rank's shard, resident in HBM, grouped by shape
     # the exchange step: RCCL behind the C ABI (zkgpu_comm), the same function config 2 uses; gloo when several ranks share one GPU
     exchange, close_exchange, exchange_name, _comm = make_exchange(W, ctx, cuts, always_comm=True)   # (a world of one too: through RCCL)
     parts = [(cuts[i], cuts[i + 1]) for i in range(world)]
 
-    # a step = one whole block: its batches queued on the lanes (zkgpu_verifier_block_start), its verdicts waited for
-    # (zkgpu_verifier_block_finish) and exchanged.  --blocks-in-flight 2 queues block k+1 before block k is waited for,
-    # as a node verifying a stream of blocks could.  Measured (8192 mixed tx per block): no gain with the default 6
-    # lanes (1.96 vs 1.97 M tx/s: the second block waits for lanes), +5-7 % with 7 or 9 lanes, and with 8 or 10 lanes the
-    # run falls off the hardware-queue cliff of DESIGN.md sec 7 (0.72 / 0.20 M tx/s) -- so the default stays one block
-    # at a time.
+    # a step = one whole block: its batches queued (zkgpu_verifier_block_start), its verdicts waited for
+    # (zkgpu_verifier_block_finish) and exchanged.  --blocks-in-flight D (default 4) queues blocks k+1 .. k+D-1 before block k is
+    # waited for, as a node verifying a stream of blocks does: since round 4 the batches of one shape from the blocks in flight
+    # are MERGED (they are tickets of the verifier's queue) instead of competing for lanes.  Measured on one MI355X, 8192 mixed
+    # transactions per block (profiles/r04p_*, r04q_*): one block at a time 2.0 M tx/s (five batches of ~1640 transactions, a
+    # burst with its own head and tail every step); 2 / 3 / 4 / 6 / 8 in flight at merge 8192: 2.6 / 2.8 / 2.93 / 3.0 / 3.09 M.
+    # Until round 3 a second block in flight bought nothing (1.96 vs 1.97 M: it waited for lanes).
     depth = max(1, args.blocks_in_flight)
 
     def start():
@@ -1317,7 +1326,7 @@ def main():
                     help="device batches in flight per GPU (contexts): default 5 with --tickets, 6 without, 6 for config 4")
     ap.add_argument("--group", type=int, default=16, help="transactions per group check (1 = every transaction on its own)")
     ap.add_argument("--chunk", type=int, default=0, help="config 4: transactions per batch in flight (0 = library default)")
-    ap.add_argument("--blocks-in-flight", type=int, default=1, help="config 4: blocks whose batches are on the lanes at once (default 1: one block at a time)")
+    ap.add_argument("--blocks-in-flight", type=int, default=4, help="config 4: blocks started before the oldest is waited for; their batches of one shape are merged (default 4)")
     ap.add_argument("--bad-every", type=int, default=64, help="config 2: one transaction in this many is corrupted (0 = none)")
     ap.add_argument("--tickets", type=int, default=-1,
                     help="config 2: batches kept in flight as tickets of a zkgpu_verifier, which merges them into device batches of --merge tx (0 = plain contexts)")
@@ -1347,6 +1356,7 @@ def main():
     # steps simply has fewer tickets in flight, and its last device batch is as large as what is left.)
     if args.tickets < 0:
         args.tickets = 64
+    args.merge_given = args.merge > 0
     if args.merge <= 0:
         args.merge = DEFAULT_MERGE
     if args.inflight <= 0:

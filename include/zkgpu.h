@@ -476,6 +476,11 @@ int zkgpu_verifier_block_finish(zkgpu_verifier *v, uint64_t run_id, uint8_t *acc
  * until their ticket has been waited for; do not run zkgpu_verifier_verify* calls concurrently with tickets in flight
  * (they first finish them).  (A runtime policy -- dynamic batching -- with no counterpart in the reference.) */
 int zkgpu_verifier_set_merge(zkgpu_verifier *v, size_t transactions);
+/* Sizes every lane's workspace for device batches of `transactions` statements of the shape (n_in, n_out) beforehand, so that
+ * no lane allocates -- hipMalloc synchronises the device -- when it first meets a batch that large: for verifiers whose
+ * batches vary in shape and size (blocks of mixed shapes; since round 4 a block's batches are merged with those of the other
+ * blocks in flight, up to the merge target).  Optional: without it workspaces grow on demand and are never shrunk. */
+int zkgpu_verifier_reserve(zkgpu_verifier *v, uint32_t n_in, uint32_t n_out, size_t transactions);
 int zkgpu_verifier_submit_dev(zkgpu_verifier *v, uint32_t n_in, uint32_t n_out, size_t batch, const void *d_commitments,
                               const void *d_proofs, size_t proof_len, const void *d_r, uint64_t *ticket);
 /* the same for `count` batches of one shape and size at once (arrays of count device pointers; tickets[count]) */

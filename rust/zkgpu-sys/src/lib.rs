@@ -240,6 +240,7 @@ extern "C" {
     pub fn zkgpu_verifier_block_start(v: *mut zkgpu_verifier, block: *const zkgpu_txblock, run_id: *mut u64) -> c_int;
     pub fn zkgpu_verifier_block_finish(v: *mut zkgpu_verifier, run_id: u64, accept_bitmap: *mut u8) -> c_int;
     pub fn zkgpu_verifier_set_merge(v: *mut zkgpu_verifier, transactions: usize) -> c_int;
+    pub fn zkgpu_verifier_reserve(v: *mut zkgpu_verifier, n_in: u32, n_out: u32, transactions: usize) -> c_int;
     pub fn zkgpu_verifier_submit_dev(
         v: *mut zkgpu_verifier, n_in: u32, n_out: u32, batch: usize, d_commitments: *const c_void,
         d_proofs: *const c_void, proof_len: usize, d_r: *const c_void, ticket: *mut u64,

@@ -287,6 +287,45 @@ def test_exchange_step_in_a_mocked_world_of_n_ranks(ctx, oracle, world, rank):
         gens.close()
 
 
+def test_batches_of_blocks_in_flight_are_merged_and_workspaces_can_be_reserved(ctx, gens512, oracle):
+    """Since round 4 a block's batches are requests of the verifier's ticket queue: zkgpu_verifier_block_start only QUEUES them
+    (they leave when the merge target is reached or a run is finished), and batches of one shape from DIFFERENT blocks in
+    flight go to the device as one batch.  Four different mixed blocks started, finished in another order, twice (cold and
+    warm), with zkgpu_verifier_reserve having sized every lane for the merged batches beforehand; tickets of the caller's
+    own queued in between keep their own verdicts; every bit against the oracle."""
+    from zkvm_amd import ZkGpuError
+    from zkvm_amd.verifier import BlockVerifier
+    blocks = []
+    for k, n in enumerate((900, 1100, 700, 1000)):
+        txs = mixed_block(n, seed=60 + k, bad_every=9)
+        r = hashlib.shake_256(b"merged blocks %d" % k).digest(64 * n)
+        want = oracle_block_bits(oracle, txs, r, threads=16)
+        assert 0 < sum(want) < n
+        blocks.append((txs, r, want))
+    fix, n_in, n_out, plen = load_cloak_fixture()
+    t_com, t_proofs = b"".join(fix[i][0] for i in range(64)), b"".join(fix[i][1] for i in range(64))
+    t_r = hashlib.shake_256(b"ticket beside blocks").digest(64 * 64)
+    bv = BlockVerifier(ctx, gens512, batches_in_flight=4)
+    bv.set_merge(2048)
+    try:
+        for shape in ((1, 1), (1, 2), (2, 2), (3, 3), (4, 4)):
+            bv.reserve(shape[0], shape[1], 2048)
+        bv.reserve(64, 64, 10)                                       # a shape the generator set cannot serve: nothing to do
+        with pytest.raises(ZkGpuError):
+            bv.reserve(2, 2, 0)
+        resident = [bv.block(_cloak(txs), r) for txs, r, _ in blocks]
+        for order in ((2, 0, 3, 1), (0, 1, 2, 3)):
+            runs = [bv.block_start(b) for b in resident]
+            tk = bv.submit(n_in, n_out, 64, t_com, t_proofs, plen, t_r)
+            for k in order:
+                assert bits(bv.block_finish(runs[k]), len(blocks[k][0])) == blocks[k][2], k
+            assert bits(bv.wait(tk), 64) == [1] * 64
+        for b in resident:
+            b.close()
+    finally:
+        bv.close()
+
+
 def test_config4_at_full_size_in_a_mocked_world_of_eight(ctx, gens512, oracle):
     """BASELINE configs[3] in its stated size on the one GPU there is: 65 536 mixed-arity transactions (bench.py's own
     construction: gpu_util.mixed_block, 1 in 61 damaged, every kind in every shape), cut into EIGHT shards by

@@ -28,6 +28,11 @@ struct zkgpu_request {                 // one submitted batch (zkgpu_verifier_su
   int state = 0;                       // 0 queued, 1 in flight on `lane`, 2 done
   int lane = -1, rc = 0;
   struct zkgpu_host_batch* form = nullptr;   // host-memory ticket: the device batch it was staged into (state 0 only)
+  // a batch of a BLOCK (zkgpu_verifier_block_start): the run it belongs to (zkgpu_verifier::BlockRun*), which of the block's
+  // shape groups, where in it; `ready`: the copy of the block to HBM is still queued -- whoever launches this waits for it
+  void* run = nullptr;
+  size_t group = 0, off = 0;
+  hipEvent_t ready = nullptr;
   std::vector<uint8_t> bits;
 };
 
@@ -67,16 +72,16 @@ struct zkgpu_verifier {
   std::map<std::pair<uint32_t, uint32_t>, uint64_t> costs;
   size_t chunk = 2048;                                // transactions per batch in flight
   // ---- blocks in flight (zkgpu_verifier_block_start / _finish): which batch of which block a lane is running
+  // Since round 4 a block's batches ARE tickets: one request per (shape group, chunk) in the same queue, merged with the
+  // requests of the same shape of OTHER blocks in flight into device batches of up to merge_target transactions.
   struct BlockRun {
     const struct zkgpu_txblock* b = nullptr;
     std::vector<uint8_t> bits;                          // verdicts gathered so far, by position in the block
-    size_t pending = 0;                                 // batches of the block still on a lane
+    size_t pending = 0;                                 // batches of the block not yet collected (queued or on a lane)
+    std::vector<zkgpu_request*> reqs;                   // those batches (the run owns them until they are collected)
     int rc = 0;
     uint64_t id = 0;
   };
-  struct LaneJob { BlockRun* run = nullptr; size_t group = 0, off = 0, n = 0; };
-  std::vector<LaneJob> lane_job;                        // per lane
-  std::deque<int> block_busy;                           // lanes running a block's batch, oldest first
   std::map<uint64_t, std::unique_ptr<BlockRun>> block_runs;
   uint64_t next_run = 1;
   int lanes_requested = 0, lanes_dropped = 0;           // lanes whose light stream shared a hardware queue with an earlier lane's were not kept
@@ -164,7 +169,7 @@ std::map<int, int> g_live_verifiers;
 void ticket_collect(zkgpu_verifier* v, int lane);
 int ticket_dispatch(zkgpu_verifier* v, bool force);
 int host_dispatch(zkgpu_verifier* v, zkgpu_host_batch* must);
-void block_collect(zkgpu_verifier* v, int lane);
+void collect_oldest(zkgpu_verifier* v);
 
 // ---- RCCL, bound on first use -------------------------------------------------------------
 struct RcclApi {
@@ -351,7 +356,6 @@ int zkgpu_verifier_create(zkgpu_ctx* ctx, const zkgpu_pointset* ps, size_t gens_
     v->last_error = msg;
   }
   v->running.resize(v->lanes.size());
-  v->lane_job.resize(v->lanes.size());
   *out = v;
   // One verifier per process and device is what the queue budget is made for: a second one is created
   // all the same, and the caller is TOLD when the runtime's queue count is in the range where two verifiers were measured to
@@ -381,6 +385,7 @@ void zkgpu_verifier_destroy(zkgpu_verifier* v) {
   std::vector<uint8_t> scratch;
   (void)drain(v, scratch);
   for (auto& kv : v->requests) delete kv.second;
+  for (auto& kv : v->block_runs) for (zkgpu_request* r : kv.second->reqs) delete r;    // (runs never finished: queued batches)
   for (size_t i = 1; i < v->lanes.size(); ++i) zkgpu_destroy(v->lanes[i]);
   for (zkgpu_ctx* a : v->aux_keys) if (a) zkgpu_destroy(a);
   for (zkgpu_ctx* a : v->aux_sigs) if (a) zkgpu_destroy(a);
@@ -603,69 +608,54 @@ int zkgpu_txblock_create(zkgpu_verifier* v, size_t batch, const uint32_t* n_in, 
 // accept_bitmap is the verdict of transaction i of the block.  Any device error: all bits zero.
 namespace {
 
-// the verdicts of the block batch on `lane` into its run (v->mu held)
-void block_collect(zkgpu_verifier* v, int lane) {
-  zkgpu_verifier::LaneJob job = v->lane_job[(size_t)lane];
-  v->lane_job[(size_t)lane] = zkgpu_verifier::LaneJob{};
-  for (auto it = v->block_busy.begin(); it != v->block_busy.end(); ++it) if (*it == lane) { v->block_busy.erase(it); break; }
-  if (!job.run) return;
-  std::vector<uint8_t> bm((job.n + 7) / 8, 0);
-  const int r = zkgpu_verify_wait(v->lanes[(size_t)lane], bm.data());
-  if (r == ZKGPU_OK) {
-    const auto& idx = job.run->b->groups[job.group].idx;
-    for (size_t j = 0; j < job.n; ++j)
-      if ((bm[j / 8] >> (j % 8)) & 1) { const uint32_t i = idx[job.off + j]; job.run->bits[i / 8] |= (uint8_t)(1u << (i % 8)); }
-  } else if (job.run->rc == ZKGPU_OK) {
-    job.run->rc = r;
-    v->last_error = zkgpu_last_error(v->lanes[(size_t)lane]);
-  }
-  --job.run->pending;
-}
-
-// a lane with nothing in flight; if there is none, the oldest batch of a block (else of the tickets) is waited for
-int free_lane(zkgpu_verifier* v) {
-  for (;;) {
-    for (size_t i = 0; i < v->lanes.size(); ++i) if (v->running[i].empty() && !v->lane_job[i].run) return (int)i;
-    if (!v->block_busy.empty()) block_collect(v, v->block_busy.front());
-    else ticket_collect(v, v->busy.front());
-  }
-}
-
-// queues every batch of the block (v->mu held)
-zkgpu_verifier::BlockRun* block_start(zkgpu_verifier* v, const zkgpu_txblock* b) {
-  (void)ticket_dispatch(v, true);                      // queued tickets go first
+// Queues every batch of the block as a request of the ticket queue (v->mu held).  now: launch at once whatever the merge
+// target says (a block somebody is about to wait for); otherwise the requests wait -- for requests of the same shape from
+// the next blocks, until the merge target is reached -- and block_finish forces them out.
+zkgpu_verifier::BlockRun* block_start(zkgpu_verifier* v, const zkgpu_txblock* b, bool now) {
   std::unique_ptr<zkgpu_verifier::BlockRun> owned(new zkgpu_verifier::BlockRun());
   zkgpu_verifier::BlockRun* run = owned.get();
   run->b = b;
   run->bits.assign((b->batch + 7) / 8, 0);
-  for (size_t gi = 0; gi < b->groups.size() && run->rc == ZKGPU_OK; ++gi) {
+  for (size_t gi = 0; gi < b->groups.size(); ++gi) {
     const auto& g = b->groups[gi];
     if (!g.plan) continue;
     const size_t wcom = 64 * ((size_t)g.n_in + g.n_out);
     for (size_t off = 0; off < g.idx.size(); off += v->chunk) {
-      const size_t n = std::min(v->chunk, g.idx.size() - off);
-      const int lane = free_lane(v);
-      v->lanes[(size_t)lane]->dep_event = b->ready;
-      const int rc = zkgpu_cloak_verify_submit_dev(v->lanes[(size_t)lane], v->ps, g.plan, n, b->dev + g.com_off + off * wcom,
-                                                   b->dev + g.proof_off + off * g.proof_len, g.proof_len, b->dev + g.r_off + off * 64);
-      if (rc != ZKGPU_OK) { run->rc = rc; v->last_error = zkgpu_last_error(v->lanes[(size_t)lane]); break; }
-      v->lane_job[(size_t)lane] = zkgpu_verifier::LaneJob{run, gi, off, n};
-      v->block_busy.push_back(lane);
+      zkgpu_request* r = new zkgpu_request();
+      r->id = 0;                                          // (not a ticket of the caller's: found through its run)
+      r->n_in = g.n_in; r->n_out = g.n_out; r->proof_len = g.proof_len;
+      r->batch = std::min(v->chunk, g.idx.size() - off);
+      r->d_com = b->dev + g.com_off + off * wcom;
+      r->d_proofs = b->dev + g.proof_off + off * g.proof_len;
+      r->d_r = b->dev + g.r_off + off * 64;
+      r->run = run; r->group = gi; r->off = off; r->ready = b->ready;
+      run->reqs.push_back(r);
+      v->queue.push_back(r);
       ++run->pending;
     }
   }
   run->id = v->next_run++;
   v->block_runs[run->id] = std::move(owned);
+  (void)ticket_dispatch(v, now);
   return run;
 }
 
-// waits for the block's batches (always all of them: no lane is left pending after an error); v->mu held
+// has the device finished every batch of the run?  (never blocks; v->mu held)
+bool block_done(zkgpu_verifier* v, zkgpu_verifier::BlockRun* run) {
+  DeviceGuard g(v->root->device);
+  for (zkgpu_request* r : run->reqs) {
+    if (r->state == 0) return false;
+    if (r->state == 1 && hipEventQuery(v->lanes[(size_t)r->lane]->ev_done) == hipErrorNotReady) return false;
+  }
+  return true;
+}
+
+// waits for the block's batches (always all of them: nothing of the run is left queued or on a lane after an error); v->mu held
 int block_finish(zkgpu_verifier* v, zkgpu_verifier::BlockRun* run, uint8_t* accept_bitmap) {
   while (run->pending) {
-    int lane = -1;
-    for (int l : v->block_busy) if (v->lane_job[(size_t)l].run == run) { lane = l; break; }
-    if (lane < 0) { run->pending = 0; break; }          // (cannot happen: every pending batch is on a lane)
-    block_collect(v, lane);
+    zkgpu_request* r = run->reqs.back();                // (collected requests leave the list: see ticket_collect)
+    if (r->state == 0) (void)ticket_dispatch(v, true);  // everything that is queued goes out, merged by shape across blocks
+    else if (r->state == 1) ticket_collect(v, r->lane);
   }
   const int rc = run->rc;
   const size_t nbytes = (run->b->batch + 7) / 8;
@@ -674,13 +664,31 @@ int block_finish(zkgpu_verifier* v, zkgpu_verifier::BlockRun* run, uint8_t* acce
   return rc;
 }
 
+// a block's request has its verdicts (or its error): into the run, and the request is gone (v->mu held)
+void block_request_done(zkgpu_verifier* v, zkgpu_request* r) {
+  zkgpu_verifier::BlockRun* run = (zkgpu_verifier::BlockRun*)r->run;
+  if (r->rc == ZKGPU_OK) {
+    const auto& idx = run->b->groups[r->group].idx;
+    for (size_t j = 0; j < r->batch; ++j)
+      if ((r->bits[j / 8] >> (j % 8)) & 1) { const uint32_t i = idx[r->off + j]; run->bits[i / 8] |= (uint8_t)(1u << (i % 8)); }
+  } else if (run->rc == ZKGPU_OK) {
+    run->rc = r->rc;
+  }
+  for (auto it = run->reqs.begin(); it != run->reqs.end(); ++it) if (*it == r) { run->reqs.erase(it); break; }
+  --run->pending;
+  delete r;
+}
+
+// the oldest device batch in flight is waited for (v->mu held; there is one)
+void collect_oldest(zkgpu_verifier* v) { ticket_collect(v, v->busy.front()); }
+
 }  // namespace
 
 int zkgpu_verifier_verify_block(zkgpu_verifier* v, const zkgpu_txblock* b, uint8_t* accept_bitmap) {
   if (!v || !b || b->v != v || !accept_bitmap) return ZKGPU_EINVAL;
   memset(accept_bitmap, 0, (b->batch + 7) / 8);
   std::lock_guard<std::mutex> lk(v->mu);
-  return block_finish(v, block_start(v, b), accept_bitmap);
+  return block_finish(v, block_start(v, b, true), accept_bitmap);
 }
 
 // The same in two halves, so that the next block's batches are on the lanes before the last one's verdicts are waited
@@ -689,7 +697,7 @@ int zkgpu_verifier_verify_block(zkgpu_verifier* v, const zkgpu_txblock* b, uint8
 int zkgpu_verifier_block_start(zkgpu_verifier* v, const zkgpu_txblock* b, uint64_t* run_id) {
   if (!v || !b || b->v != v || !run_id) return ZKGPU_EINVAL;
   std::lock_guard<std::mutex> lk(v->mu);
-  *run_id = block_start(v, b)->id;
+  *run_id = block_start(v, b, false)->id;               // (launched when the merge target is reached, or when a run is finished)
   return ZKGPU_OK;
 }
 
@@ -746,6 +754,7 @@ void ticket_collect(zkgpu_verifier* v, int lane) {       // v->mu held
       }
     r->rc = rc;
     r->state = 2;
+    if (r->run) block_request_done(v, r);                // (a block's batch: its verdicts go to the block's run)
   }
 }
 
@@ -765,10 +774,10 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
     }
     if (total < v->merge_target && !force) return ZKGPU_OK;
     int lane = -1;
-    for (size_t i = 0; i < v->lanes.size(); ++i) if (v->running[i].empty() && !v->lane_job[i].run) { lane = (int)i; break; }
+    for (size_t i = 0; i < v->lanes.size(); ++i) if (v->running[i].empty()) { lane = (int)i; break; }
     if (lane < 0) {
       if (!force) return ZKGPU_OK;
-      if (!v->busy.empty()) ticket_collect(v, v->busy.front()); else block_collect(v, v->block_busy.front());
+      collect_oldest(v);
       continue;
     }
     zkgpu_ctx* L = v->lanes[(size_t)lane];
@@ -777,7 +786,17 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
     zkgpu_cloak_plan* plan = verifier_plan(v, head->n_in, head->n_out, &rc, &plan_err);   // rc != OK: no plan THIS time -> the tickets fail with it
     if (rc != ZKGPU_OK) v->last_error = plan_err;                                          // (v->mu held)
     const void *p_com = pick[0]->d_com, *p_proofs = pick[0]->d_proofs, *p_r = pick[0]->d_r;
-    if (plan && proof_len_fits(plan->shape, head->proof_len) && pick.size() > 1) {
+    // batches of blocks whose copy to HBM is still queued on the copy stream: whoever reads their inputs waits for it
+    if (pick.size() == 1) {
+      if (pick[0]->ready) { std::lock_guard<std::recursive_mutex> lk(L->mu); L->dep_event = pick[0]->ready; }
+    } else {
+      std::lock_guard<std::recursive_mutex> lk(L->mu);
+      DeviceGuard g(L->device);
+      hipEvent_t seen = nullptr;
+      for (zkgpu_request* r : pick)
+        if (r->ready && r->ready != seen) { seen = r->ready; if (hipStreamWaitEvent(L->stream_l, r->ready, 0) != hipSuccess && rc == ZKGPU_OK) { L->last_error = "hipStreamWaitEvent (block copy)"; rc = ZKGPU_EHIP; } }
+    }
+    if (rc == ZKGPU_OK && plan && proof_len_fits(plan->shape, head->proof_len) && pick.size() > 1) {
       std::lock_guard<std::recursive_mutex> lk(L->mu);
       DeviceGuard g(L->device);
       const size_t wcom = (size_t)plan->shape.m * 32;
@@ -830,7 +849,11 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
       else { r->state = 2; r->rc = rc; r->bits.assign((r->batch + 7) / 8, 0); }   // rc OK and no plan: every proof is Err
     }
     if (rc == ZKGPU_OK && plan) { v->running[(size_t)lane] = pick; v->busy.push_back(lane); }
-    else if (rc != ZKGPU_OK && plan) v->last_error = zkgpu_last_error(L);
+    else {
+      if (rc != ZKGPU_OK && plan) v->last_error = zkgpu_last_error(L);
+      { std::lock_guard<std::recursive_mutex> lk(L->mu); L->dep_event = nullptr; }
+      for (zkgpu_request* r : pick) if (r->run) block_request_done(v, r);     // (a block's batches answer to their run, at once)
+    }
   }
   return ZKGPU_OK;
 }
@@ -841,7 +864,7 @@ namespace {
 
 // ---- host-memory tickets (v->mu held throughout) --------------------------------------------------------------------
 int free_ticket_lane(zkgpu_verifier* v) {
-  for (size_t i = 0; i < v->lanes.size(); ++i) if (v->running[i].empty() && !v->lane_job[i].run) return (int)i;
+  for (size_t i = 0; i < v->lanes.size(); ++i) if (v->running[i].empty()) return (int)i;
   return -1;
 }
 
@@ -921,7 +944,7 @@ int host_dispatch(zkgpu_verifier* v, zkgpu_host_batch* must) {
     int lane = free_ticket_lane(v);
     if (lane < 0) {
       if (F != must) return ZKGPU_OK;    // (full batches keep their order: the next free lane is the oldest one's)
-      if (!v->busy.empty()) ticket_collect(v, v->busy.front()); else if (!v->block_busy.empty()) block_collect(v, v->block_busy.front());
+      if (!v->busy.empty()) collect_oldest(v);
       continue;
     }
     std::unique_ptr<zkgpu_host_batch> owned = std::move(v->forming[i]);
@@ -1018,6 +1041,36 @@ int zkgpu_verifier_submit_many(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out,
   for (size_t i = 0; i < count; ++i) {
     TRY(host_submit_one(v, n_in, n_out, batch_each, commitments[i], proofs[i], proof_len, r_bytes ? r_bytes[i] : nullptr, &tickets[i]));
     (void)host_dispatch(v, nullptr);      // a batch that became full goes out while the next is being formed
+  }
+  return ZKGPU_OK;
+}
+
+// Sizes every lane's workspace (and its merge buffers) for device batches of `transactions` statements of the shape, so that no
+// lane allocates when it first meets a batch that large: hipMalloc / hipFree synchronise the device, and a verifier whose
+// batches vary in shape and size (blocks of mixed shapes merged across blocks in flight) otherwise keeps growing workspaces for
+// many calls (measured, config 4 with three blocks in flight: steps of 12 - 20 ms among steps of 3 ms).  A shape the
+// generator set cannot serve: ZKGPU_OK, nothing to do.
+int zkgpu_verifier_reserve(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, size_t transactions) {
+  if (!v || transactions == 0 || transactions >= (1ull << 24)) return ZKGPU_EINVAL;
+  std::lock_guard<std::mutex> lk(v->mu);
+  int rc = ZKGPU_OK;
+  std::string err;
+  zkgpu_cloak_plan* plan = verifier_plan(v, n_in, n_out, &rc, &err);
+  if (rc != ZKGPU_OK) { v->last_error = err; return rc; }
+  if (!plan) return ZKGPU_OK;
+  while (!v->busy.empty()) ticket_collect(v, v->busy.front());       // (the lanes must be idle: their workspaces are about to move)
+  const size_t proof_len = 1 + 4 * (size_t)plan->shape.proof_words;
+  const size_t wcom = (size_t)plan->shape.m * 32;
+  for (zkgpu_ctx* L : v->lanes) {
+    rc = cloak_reserve(L, v->ps, plan, transactions, proof_len);
+    if (rc == ZKGPU_OK) {
+      std::lock_guard<std::recursive_mutex> llk(L->mu);
+      DeviceGuard g(L->device);
+      rc = ensure(L, L->coal_com, transactions * wcom);
+      if (rc == ZKGPU_OK) rc = ensure(L, L->coal_proofs, transactions * proof_len + 16);
+      if (rc == ZKGPU_OK) rc = ensure(L, L->coal_r, transactions * 64);
+    }
+    if (rc != ZKGPU_OK) { v->last_error = zkgpu_last_error(L); return rc; }
   }
   return ZKGPU_OK;
 }
@@ -1415,7 +1468,7 @@ class GpuTxDevice : public zk::zkvm::TxDevice {
     // the one-wavefront-per-transaction transcript, or cut in two, does not shorten the tail of the call)
     const size_t saved_chunk = v_->chunk;
     v_->chunk = std::max<size_t>(saved_chunk, 4096);
-    st->run = block_start(v_, st->blk);
+    st->run = block_start(v_, st->blk, true);
     v_->chunk = saved_chunk;
     if (st->run->rc != ZKGPU_OK) { err_ = v_->last_error; return st->run->rc; }     // (proofs_finish still collects what was queued)
     return ZKGPU_OK;
@@ -1423,10 +1476,7 @@ class GpuTxDevice : public zk::zkvm::TxDevice {
   bool proofs_done(void* handle) override {                // have the lanes finished every batch of this block?  (never blocks)
     Staged* st = (Staged*)handle;
     if (!st->run) return true;
-    DeviceGuard g(v_->root->device);
-    for (int l : v_->block_busy)
-      if (v_->lane_job[(size_t)l].run == st->run && hipEventQuery(v_->lanes[(size_t)l]->ev_done) == hipErrorNotReady) return false;
-    return true;
+    return block_done(v_, st->run);
   }
   int proofs_finish(void* handle, uint8_t* accept_bits) override {
     Staged* st = (Staged*)handle;
@@ -1473,13 +1523,11 @@ int tx_call_prepare(zkgpu_verifier* v, bool collect_lanes = true) {
   // the lanes' batches in flight are collected first: the call owns the verifier (tickets and runs keep their verdicts).
   // (Not when another round of transaction calls is in flight: its proofs are on the lanes, and share them.)
   if (collect_lanes) {
-    while (!v->block_busy.empty()) block_collect(v, v->block_busy.front());
     while (!v->busy.empty()) ticket_collect(v, v->busy.front());
   }
   if (v->aux_keys[0] && v->aux_keys[1] && v->aux_sigs[0] && v->aux_sigs[1] && v->have_basepoint && v->tx_arenas.size() >= 2 * zk::zkvm::TxCall::RING)
     return ZKGPU_OK;
   if (!collect_lanes) {                                  // (the probes below want an idle device)
-    while (!v->block_busy.empty()) block_collect(v, v->block_busy.front());
     while (!v->busy.empty()) ticket_collect(v, v->busy.front());
   }
   {

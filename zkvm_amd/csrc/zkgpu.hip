@@ -93,6 +93,7 @@ struct zkgpu_ctx {
   struct SplitOp { int kind = 0; size_t batch = 0; bool values = false; hipStream_t stream = nullptr; } split;
   int pair_overlaps = -1;          // root contexts: do stream and stream2 run side by side (streams_overlap at creation; -1 not probed)
   hipEvent_t dep_event = nullptr;  // the next whole-proof submit on this context waits for it first (its inputs are still being copied)
+  bool reserve_only = false;       // zkgpu_verifier_reserve: the next whole-proof enqueue sizes the workspace and launches nothing
   std::vector<uint8_t> sync_result; // result of a submit that had to run synchronously
   bool sync_result_valid = false;
   int sync_rc = 0;
@@ -874,6 +875,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   TRY(ensure(c, c->small_tbl, std::max<uint64_t>(job.n_dyn, 1) * SMALL_TBL * EXT_WORDS * 4));
   TRY(ensure(c, c->recoded, std::max<uint64_t>(job.n_dyn, 1) * 32));
   c->last_w = 4;
+  if (c->reserve_only) return ZKGPU_OK;                 // (the workspace now fits a batch of this shape and size: nothing is launched)
   {
     Launch l(c, "k_batch_init", L);
     hipLaunchKernelGGL(k_batch_init, dim3(blocks_for(B, 256)), dim3(256), 0, L, (uint32_t*)c->status.p,
@@ -2814,6 +2816,7 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
   // general shapes (no generator tables, forced window width, many proof points): one stream, synchronous
   hipStream_t s = c->stream;
   TRY(ensure(c, c->recoded, std::max<uint64_t>(job.n_dyn, 1) * 32));
+  if (c->reserve_only) return ZKGPU_OK;
   HIP_TRY(c, hipStreamSynchronize(c->stream_l));      // uploads, if any, were queued on the light stream
   HIP_TRY(c, hipMemsetAsync(c->prep_wf.p, 0xff, (size_t)B * 4, s));
   {
@@ -2878,6 +2881,22 @@ int zkgpu_cloak_verify_submit_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_
   return cloak_verify_gpu_enqueue(c, ps, plan, batch, (const uint32_t*)d_commitments, (const uint8_t*)d_proofs,
                                   (const uint32_t*)d_r, proof_len);
 }
+
+namespace {
+// sizes the context's workspace for a whole-proof batch of `batch` statements of the plan's shape without launching anything
+// (every buffer the pipeline would need: the ensure() calls of the enqueue path, run dry)
+int cloak_reserve(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak_plan* plan, size_t batch, size_t proof_len) {
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  if (c->pending) return ZKGPU_EINVAL;
+  DeviceGuard g(c->device);
+  c->reserve_only = true;
+  static const uint32_t dummy[4] = {0, 0, 0, 0};        // (never dereferenced: nothing is launched)
+  const int rc = cloak_verify_gpu_enqueue(c, ps, plan, batch, dummy, (const uint8_t*)dummy, dummy, proof_len);
+  c->reserve_only = false;
+  c->last.valid = false;
+  return rc;
+}
+}  // namespace
 
 int zkgpu_verify_batch_ps_submit_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, const void* d_dyn_scalars,
                                      const void* d_dyn_points, const void* d_dyn_offsets, size_t n_dyn,

@@ -119,6 +119,7 @@ def load_library():
     lib.zkgpu_verifier_set_chunk.argtypes = [vp, sz]
     lib.zkgpu_verifier_lanes.argtypes = [vp]
     lib.zkgpu_verifier_set_merge.argtypes = [vp, sz]
+    lib.zkgpu_verifier_reserve.argtypes = [vp, C.c_uint32, C.c_uint32, sz]
     lib.zkgpu_verifier_submit_dev.argtypes = [vp, C.c_uint32, C.c_uint32, sz, vp, vp, sz, vp, C.POINTER(C.c_uint64)]
     lib.zkgpu_verifier_wait.argtypes = [vp, C.c_uint64, u8p]
     lib.zkgpu_verifier_lane.argtypes = [vp, C.c_int]

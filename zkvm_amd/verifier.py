@@ -198,6 +198,10 @@ class BlockVerifier:
     def set_merge(self, transactions: int) -> None:
         self._check(self.lib.zkgpu_verifier_set_merge(self.h, transactions))
 
+    def reserve(self, n_in: int, n_out: int, transactions: int) -> None:
+        """zkgpu_verifier_reserve: every lane's workspace sized for device batches of that many statements of the shape"""
+        self._check(self.lib.zkgpu_verifier_reserve(self.h, n_in, n_out, transactions))
+
     def submit_dev(self, n_in: int, n_out: int, batch: int, d_commitments, d_proofs, proof_len: int, d_r) -> int:
         """zkgpu_verifier_submit_dev: queue one uniform batch (device buffers); -> ticket"""
         from .native import _ptr
