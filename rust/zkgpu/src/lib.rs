@@ -296,6 +296,12 @@ impl GpuVerifier {
         check(unsafe { sys::zkgpu_verifier_set_merge(self.v, transactions) }, self.err())
     }
 
+    /// Sizes every lane's workspace for device batches of `transactions` statements of the shape beforehand (otherwise
+    /// workspaces grow on demand, and `hipMalloc` synchronises the device): for verifiers whose batches vary in shape and size.
+    pub fn reserve(&self, n_in: u32, n_out: u32, transactions: usize) -> Result<(), Error> {
+        check(unsafe { sys::zkgpu_verifier_reserve(self.v, n_in, n_out, transactions) }, self.err())
+    }
+
     /// Queues `batch` statements of ONE shape from host memory and returns at once; the slices are free again on return
     /// (they are copied into pinned staging memory).  Batches in flight are merged into device batches.
     pub fn submit(&self, n_in: u32, n_out: u32, batch: usize, commitments: &[u8], proofs: &[u8], proof_len: usize, randomness: Option<&[u8]>) -> Result<Ticket, Error> {
