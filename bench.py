@@ -50,10 +50,13 @@ import os
 # then time-slices them: 0.44-0.7 M tx/s against 2.1 M with 8 each, measured)
 # (N > 1, one rank per GPU: the control plane -- barrier, timing reduction, the 128-byte id broadcast -- runs over gloo on
 # the host, so the ONLY RCCL communicator of a rank is the library's own (zkgpu_comm): the process holds the streams of one
-# verifier and one communicator, as at N = 1, and asks for the same 24 queues.  Until round 3 torch's "nccl" group was a
-# second communicator per rank and the bench asked for 16 to leave it room.)
+# verifier and one communicator, as at N = 1, and asks for the same number of queues.  Until round 3 torch's "nccl" group
+# was a second communicator per rank and the bench asked for 16 to leave it room.)
+# (18 = what zkgpu_init itself asks for when it is the process's first HIP user -- here torch may be: the runtime keeps that
+# many queues per stream priority, the verifier's low- and default-priority streams come on top, and from 25 in all the
+# device stops running them side by side in one process out of four: DESIGN.md sec 5.1, profiles/r04v / r04w)
 _HWQ_PRESET = "GPU_MAX_HW_QUEUES" in os.environ
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8" if os.environ.get("ZKGPU_BENCH_SHARE_GPU") else "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8" if os.environ.get("ZKGPU_BENCH_SHARE_GPU") else "18")
 # stdout carries exactly ONE line, the JSON record: whatever libraries print there (RCCL's version banner, gloo's
 # connection chatter) is sent to stderr instead
 _JSON_OUT = os.fdopen(os.dup(1), "w")

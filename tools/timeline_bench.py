@@ -5,7 +5,7 @@ in the same stream finished, plus the totals: sum of durations, sum of gaps, wal
 import os, sys, collections
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "18")
 path = os.environ.setdefault("ZKGPU_TIMELINE", "/tmp/zk_timeline.txt")
 import torch
 import bench

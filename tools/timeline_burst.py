@@ -3,7 +3,7 @@
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "18")
 path = os.environ.setdefault("ZKGPU_TIMELINE", "/tmp/zk_timeline_burst.txt")
 import time
 import torch

@@ -348,7 +348,7 @@ int zkgpu_verifier_create(zkgpu_ctx* ctx, const zkgpu_pointset* ps, size_t gens_
   }
   if (g_hw_queues_late) {
     v->last_error = "the HIP runtime of this process started before GPU_MAX_HW_QUEUES was set: it runs on its default of 4 hardware "
-                    "queues, on which batches in flight take turns -- export GPU_MAX_HW_QUEUES=24 before the process's first HIP call";
+                    "queues, on which batches in flight take turns -- export GPU_MAX_HW_QUEUES=18 before the process's first HIP call";
   } else if (v->lanes_dropped) {
     char msg[256];
     snprintf(msg, sizeof msg, "%d of %d lanes not kept: their streams share a hardware queue with another lane's (GPU_MAX_HW_QUEUES=%s; "

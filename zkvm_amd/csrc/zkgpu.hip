@@ -1337,6 +1337,11 @@ int zkgpu_init(int device, zkgpu_ctx** out) {
   // hardware queues unless told otherwise, and streams that share a queue while waiting on each
   // other's events crawl.  Only effective if the HIP runtime has not started yet in this process
   // (otherwise the embedding application must export it itself); never overrides the caller.
+  // 18, not more: the runtime keeps that many queues PER PRIORITY; a verifier's high-priority streams take all of them, its
+  // low-priority and default-priority streams (2 + 2) come on top, and from 25 queues in all the device no longer runs them
+  // side by side -- which ones wait is a per-process lottery (measured, profiles/r04v_tx_hwq.txt, r04w_hwq_bench.txt: a
+  // 32 768-transaction call at 16.1-18.8 ms in every process with 18; 16.5-18.5 OR 23-53 ms, one process in four, with 20 / 24;
+  // headline, steady state and config 4 equal at 16 / 18 / 24).  DESIGN.md sec 5.1.
   {
     // The variable is read ONCE, when the HIP runtime starts.  Unset and the runtime not yet started (the kernel driver's
     // device node not yet open in this process): set it, it will count.  Unset and the runtime already up -- an embedding
@@ -1347,7 +1352,7 @@ int zkgpu_init(int device, zkgpu_ctx** out) {
     std::call_once(once, [] {
       if (getenv("GPU_MAX_HW_QUEUES")) return;
       g_hw_queues_late = kfd_is_open();
-      setenv("GPU_MAX_HW_QUEUES", "24", 0);
+      setenv("GPU_MAX_HW_QUEUES", "18", 0);
     });
   }
   int count = 0;
