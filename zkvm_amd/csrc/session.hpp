@@ -1647,17 +1647,25 @@ void tx_round_distribute(TxRound& r) {
 
 // The engine: rounds of merged calls, driven by this one thread (TxCall::step never blocks; a round is finished only once
 // the device has settled).  It can keep TWO rounds in flight -- one key / signature stage slot and one set of staging areas
-// each, the lanes shared -- but does so only on request (see max_rounds: measured slower).  The verifier's mutex is held
+// each, the lanes shared -- when the process's queue count allows (see max_rounds).  The verifier's mutex is held
 // from the first admission until nothing is in flight: the verifier belongs to the calls.
 void tx_engine_main(zkgpu_verifier* v) {
   using namespace zk::zkvm;
   std::unique_ptr<TxRound> active[2];
-  // ONE round at a time by default.  Two in flight (ZKGPU_TX_ROUNDS=2; the machinery below serves both) were measured on
-  // MI355X and lost: 8 calls of 1024 in flight 0.92 - 0.96 M tx/s with one round against 0.56 - 0.60 M with two, and stalls
-  // of 5 - 20 ms in single stages (profiles/r04e_inflight.txt, r04f_inflight_timing.txt) -- two rounds keep both key
-  // contexts, both signature contexts and the lanes busy at once, which is more streams than the device runs side by side
-  // (DESIGN.md sec 5.1).  What merging buys is the rate of the larger call, not a second chain beside the first.
-  const int max_rounds = (getenv("ZKGPU_TX_ROUNDS") && atoi(getenv("ZKGPU_TX_ROUNDS")) == 2) ? 2 : 1;
+  // Two rounds in flight while the process's hardware queues are few enough for the device to run them all side by side
+  // (GPU_MAX_HW_QUEUES <= 19: DESIGN.md sec 5.1), else one.  Measured on MI355X, three processes per setting
+  // (profiles/r04y_rounds_hwq.txt), at 18 queues: 4 calls of 4096 in flight 1.72 - 1.76 M tx/s with two rounds against
+  // 0.98 - 1.41 M with one, 8 calls of 1024 1.15 - 1.30 M against 1.00 - 1.12 M; at 24 queues (28 in all priorities) two
+  // rounds LOST -- 0.56 - 0.60 M against 0.92 - 0.96 M, single stages stalling 5 - 20 ms (profiles/r04e_inflight.txt,
+  // r04f_inflight_timing.txt): both key contexts, both signature contexts and the lanes busy at once were more queues than
+  // the device runs side by side.  ZKGPU_TX_ROUNDS=1 / 2 overrides.
+  int max_rounds = 1;
+  {
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    const int queues = q ? atoi(q) : 4;
+    if (!g_hw_queues_late && queues >= 8 && queues <= 19) max_rounds = 2;
+    if (const char* r = getenv("ZKGPU_TX_ROUNDS")) { const int k = atoi(r); if (k == 1 || k == 2) max_rounds = k; }
+  }
   std::mutex news_mu;
   std::condition_variable news_cv;
   bool news = false;
