@@ -14,6 +14,8 @@ ctx = Context(0)
 gens = BulletproofGens(ctx, 256, table_bits=-1)
 bv = BlockVerifier(ctx, gens)
 bv.set_tx_format(bv.TXFORMAT_RECOLLECTED_V1)
+if os.environ.get("TXCHUNK"):
+    bv.set_tx_chunk(int(os.environ["TXCHUNK"]))
 blob, lens = b"".join(txs), np.asarray([len(t) for t in txs], dtype=np.uint64)
 for _ in range(bv.lanes()):
     bv.verify_txs_packed(blob, lens)

@@ -154,6 +154,16 @@ class TxCall {
   }
   int finish() {
     stop_stager();
+    if (timing_ && rc_ == OK) {                          // (timing only: poll, so that the marks say which chain ends the call)
+      std::vector<uint8_t> seen_s(sig_stages_.size(), 0);
+      const double t_end = now() + 1.0;
+      while (!settled() && now() < t_end) {
+        device_marks();
+        for (size_t q = 0; q < n_sig_made_locked(); ++q)
+          if (!seen_s[q] && sig_stages_[q]->pending && dev_.sigs_done((int)(q % n_slots_))) { seen_s[q] = 1; mark("signatures done on the device, stage", q); }
+      }
+      device_marks();
+    }
     // (after an error: nothing is left pending on the device)
     for (size_t s = 0; s < seg_.size(); ++s) keys_collect(s);
     for (size_t s = 0; s < n_sig_made_locked(); ++s) sigs_collect(s);
@@ -518,9 +528,18 @@ class TxCall {
       progress = true;
     }
     if (rc_ != OK) { finished_ = true; return true; }
+    if (timing_) device_marks();
     return progress;
   }
  private:
+  // (timing only) when the device is through with a chunk's proofs / a signature stage, as seen by the polling thread
+  void device_marks() {
+    if (seen_pdone_.size() != chunks_.size()) seen_pdone_.assign(chunks_.size(), 0);
+    for (size_t c = 0; c < chunks_.size(); ++c) {
+      Chunk& k = *chunks_[c];
+      if (!seen_pdone_[c] && k.handle && k.started && dev_.proofs_done(k.handle)) { seen_pdone_[c] = 1; mark("proofs done on the device, chunk", c); }
+    }
+  }
   void verdicts() {
     std::vector<uint8_t> sig_ok(live_all_.size(), 0);
     for (const auto& sg : sig_stages_)
@@ -544,6 +563,7 @@ class TxCall {
             t_keys_ * 1e3, t_stage_ * 1e3, t_sigs_ * 1e3, t_wait_ * 1e3, (now() - t00_) * 1e3);
   }
 
+  std::vector<uint8_t> seen_pdone_;
   TxDevice& dev_;
   std::vector<TxStatement>& store_;
   std::vector<TxStatement> beyond_;
