@@ -9,6 +9,7 @@ timeout 600 python __graft_entry__.py --smoke > gpurun_out/${TAG}_smoke.log 2>&1
 S=$(date +%s); python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driverflags.json 2> gpurun_out/${TAG}_bench_driverflags.err; echo "driver command wall: $(( $(date +%s) - S )) s"
 S=$(date +%s); ZKGPU_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_n2_selflaunched_shared_gpu.json 2> gpurun_out/${TAG}_bench_n2_selflaunched_shared_gpu.err; echo "N=2 self-launched (both ranks on this GPU): rc $? wall $(( $(date +%s) - S )) s"
 S=$(date +%s); python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "default command wall: $(( $(date +%s) - S )) s"
+S=$(date +%s); python bench.py --config 4 > gpurun_out/${TAG}_bench_config4.json 2> gpurun_out/${TAG}_bench_config4.err; echo "config 4: rc $? wall $(( $(date +%s) - S )) s; $(python -c "import json; d=json.loads(open('gpurun_out/${TAG}_bench_config4.json').readline()); print(d['value'], d['config'].get('workload'))")"
 python - <<PY
 import json
 for name in ("driverflags", "default"):
