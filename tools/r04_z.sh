@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+for rep in 1 2 3; do
+  echo "default rounds, rep=$rep"; python3 tools/tx_inflight.py 1024 8 64 2>&1 | tail -2
+  python3 tools/tx_inflight.py 4096 4 32 2>&1 | tail -2
+  python3 tools/tx_inflight.py 2048 8 32 2>&1 | tail -1
+done
+python3 -m pytest tests -m gpu -x -q > gpurun_out/r04z2_gpu_tests.log 2>&1; grep -n "passed\|failed\|error" gpurun_out/r04z2_gpu_tests.log | tail -3
