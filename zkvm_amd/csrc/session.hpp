@@ -611,31 +611,46 @@ namespace {
 // Queues every batch of the block as a request of the ticket queue (v->mu held).  now: launch at once whatever the merge
 // target says (a block somebody is about to wait for); otherwise the requests wait -- for requests of the same shape from
 // the next blocks, until the merge target is reached -- and block_finish forces them out.
+// nullptr: out of host memory while queueing (nothing of the block is left queued; v->last_error says so).
 zkgpu_verifier::BlockRun* block_start(zkgpu_verifier* v, const zkgpu_txblock* b, bool now) {
-  std::unique_ptr<zkgpu_verifier::BlockRun> owned(new zkgpu_verifier::BlockRun());
-  zkgpu_verifier::BlockRun* run = owned.get();
-  run->b = b;
-  run->bits.assign((b->batch + 7) / 8, 0);
-  for (size_t gi = 0; gi < b->groups.size(); ++gi) {
-    const auto& g = b->groups[gi];
-    if (!g.plan) continue;
-    const size_t wcom = 64 * ((size_t)g.n_in + g.n_out);
-    for (size_t off = 0; off < g.idx.size(); off += v->chunk) {
-      zkgpu_request* r = new zkgpu_request();
-      r->id = 0;                                          // (not a ticket of the caller's: found through its run)
-      r->n_in = g.n_in; r->n_out = g.n_out; r->proof_len = g.proof_len;
-      r->batch = std::min(v->chunk, g.idx.size() - off);
-      r->d_com = b->dev + g.com_off + off * wcom;
-      r->d_proofs = b->dev + g.proof_off + off * g.proof_len;
-      r->d_r = b->dev + g.r_off + off * 64;
-      r->run = run; r->group = gi; r->off = off; r->ready = b->ready;
-      run->reqs.push_back(r);
-      v->queue.push_back(r);
-      ++run->pending;
+  zkgpu_verifier::BlockRun* run = nullptr;
+  try {
+    std::unique_ptr<zkgpu_verifier::BlockRun> owned(new zkgpu_verifier::BlockRun());
+    run = owned.get();
+    run->b = b;
+    run->bits.assign((b->batch + 7) / 8, 0);
+    run->id = v->next_run++;
+    v->block_runs[run->id] = std::move(owned);
+    for (size_t gi = 0; gi < b->groups.size(); ++gi) {
+      const auto& g = b->groups[gi];
+      if (!g.plan) continue;
+      const size_t wcom = 64 * ((size_t)g.n_in + g.n_out);
+      for (size_t off = 0; off < g.idx.size(); off += v->chunk) {
+        std::unique_ptr<zkgpu_request> r(new zkgpu_request());
+        r->id = 0;                                        // (not a ticket of the caller's: found through its run)
+        r->n_in = g.n_in; r->n_out = g.n_out; r->proof_len = g.proof_len;
+        r->batch = std::min(v->chunk, g.idx.size() - off);
+        r->d_com = b->dev + g.com_off + off * wcom;
+        r->d_proofs = b->dev + g.proof_off + off * g.proof_len;
+        r->d_r = b->dev + g.r_off + off * 64;
+        r->run = run; r->group = gi; r->off = off; r->ready = b->ready;
+        run->reqs.reserve(run->reqs.size() + 1);
+        v->queue.push_back(r.get());
+        run->reqs.push_back(r.release());                 // (cannot throw: reserved)
+        ++run->pending;
+      }
     }
+  } catch (const std::bad_alloc&) {
+    if (run) {                                            // what was queued of this block leaves the queue again
+      for (zkgpu_request* r : run->reqs) {
+        for (auto it = v->queue.begin(); it != v->queue.end(); ++it) if (*it == r) { v->queue.erase(it); break; }
+        delete r;
+      }
+      v->block_runs.erase(run->id);
+    }
+    v->last_error = "out of host memory while queueing the block's batches";
+    return nullptr;
   }
-  run->id = v->next_run++;
-  v->block_runs[run->id] = std::move(owned);
   (void)ticket_dispatch(v, now);
   return run;
 }
@@ -688,7 +703,8 @@ int zkgpu_verifier_verify_block(zkgpu_verifier* v, const zkgpu_txblock* b, uint8
   if (!v || !b || b->v != v || !accept_bitmap) return ZKGPU_EINVAL;
   memset(accept_bitmap, 0, (b->batch + 7) / 8);
   std::lock_guard<std::mutex> lk(v->mu);
-  return block_finish(v, block_start(v, b, true), accept_bitmap);
+  zkgpu_verifier::BlockRun* run = block_start(v, b, true);
+  return run ? block_finish(v, run, accept_bitmap) : ZKGPU_ENOMEM;
 }
 
 // The same in two halves, so that the next block's batches are on the lanes before the last one's verdicts are waited
@@ -697,7 +713,9 @@ int zkgpu_verifier_verify_block(zkgpu_verifier* v, const zkgpu_txblock* b, uint8
 int zkgpu_verifier_block_start(zkgpu_verifier* v, const zkgpu_txblock* b, uint64_t* run_id) {
   if (!v || !b || b->v != v || !run_id) return ZKGPU_EINVAL;
   std::lock_guard<std::mutex> lk(v->mu);
-  *run_id = block_start(v, b, false)->id;               // (launched when the merge target is reached, or when a run is finished)
+  zkgpu_verifier::BlockRun* run = block_start(v, b, false);   // (launched when the merge target is reached, or when a run is finished)
+  if (!run) return ZKGPU_ENOMEM;
+  *run_id = run->id;
   return ZKGPU_OK;
 }
 
@@ -1470,6 +1488,7 @@ class GpuTxDevice : public zk::zkvm::TxDevice {
     v_->chunk = std::max<size_t>(saved_chunk, 4096);
     st->run = block_start(v_, st->blk, true);
     v_->chunk = saved_chunk;
+    if (!st->run) { err_ = v_->last_error; return ZKGPU_ENOMEM; }
     if (st->run->rc != ZKGPU_OK) { err_ = v_->last_error; return st->run->rc; }     // (proofs_finish still collects what was queued)
     return ZKGPU_OK;
   }
