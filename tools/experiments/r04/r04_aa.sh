@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 for c in 0 2048 4096; do
   for rep in 1 2; do
     echo -n "8192 per call, chunk=$c rep=$rep: "

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the single 2^20 multiplication in two slices (run_sliced) against the unsliced chain, same box; then the MSM parity tests
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 for rep in 1 2 3; do
   for sl in 0 1 2; do
     echo -n "slices=$sl rep=$rep: "

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 export TMPDIR=/tmp
 for sl in 0 1 2; do
   ZKGPU_MSM_SLICES=$sl rocprofv3 --kernel-trace --output-format csv -d gpurun_out/msmtl_$sl -- python3 tools/msm_bench.py > /dev/null 2> gpurun_out/msmtl_$sl.err

@@ -1,6 +1,6 @@
 #!/bin/bash
 # k_bucket_accumulate with the next row prefetched into LDS (global_load_lds) against the register form, same box
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 for rep in 1 2 3; do
   for g in 0 1; do
     echo -n "glds=$g rep=$rep: "

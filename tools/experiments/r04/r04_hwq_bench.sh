@@ -1,7 +1,7 @@
 #!/bin/bash
 # which GPU_MAX_HW_QUEUES should the library ask for?  (a) the 32768-per-call transaction lottery at 17 / 18 / 19, (b) the
 # bench's headline, steady state and transaction leg at 16 / 18 / 24, (c) config 4
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 for q in 17 18 19; do
   for rep in 1 2 3 4; do
     echo -n "tx q=$q rep=$rep: "

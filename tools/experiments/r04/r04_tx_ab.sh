@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the serialized-transaction call between two trees (library + host mirror) on ONE box
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 for rep in 1 2; do
   for tree in build/ab/r04z .; do
     for n in 8192 32768; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # after the library's default went to 18 hardware queues: the transaction call per process (no variable exported), calls in
 # flight with one and two rounds, the bench's full default line, the GPU tests
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 for rep in 1 2 3 4; do
   for n in 8192 32768; do
     echo -n "tx n=$n rep=$rep: "

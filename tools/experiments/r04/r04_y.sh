@@ -1,6 +1,6 @@
 #!/bin/bash
 # two transaction rounds in flight again, by hardware queues (the r04e / r04f measurements were taken at 24)
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../../.."
 for q in 12 14 16 18; do
   for rep in 1 2 3; do
     for r in 1 2; do
