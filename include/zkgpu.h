@@ -537,7 +537,7 @@ int zkgpu_tx_verify_batch(zkgpu_verifier *v, size_t batch, const uint8_t *txs, c
 /* Calls in flight (upstream's Tx::verify is pure and callable from many threads: SURVEY.md sec 8(b)).  zkgpu_tx_verify_submit
  * queues a call and returns its id at once; an engine thread of the verifier runs everything that is queued as ONE merged
  * call (up to 16 384 transactions per round: calls that arrive while a round runs make up the next one -- dynamic batching,
- * as tickets do for proofs), and zkgpu_tx_verify_wait blocks until that call's round is done and writes ITS accept bitmap and
+ * as tickets do for proofs; two rounds in flight while GPU_MAX_HW_QUEUES is 8..19, the library's own setting, else one), and zkgpu_tx_verify_wait blocks until that call's round is done and writes ITS accept bitmap and
  * status bytes (status may be NULL).  txs and tx_offsets must stay valid until the call has been waited for; every id is
  * waited for exactly once.  Same verdicts, same opt-in format, same fail-closed rule as zkgpu_tx_verify_batch: a round that
  * fails gives every call in it the error and all-zero outputs.  Safe to call from many threads.  zkgpu_tx_verify_stats:
