@@ -496,8 +496,11 @@ def test_a_long_call_travels_through_the_stages_in_chunks(n_tx, tx_chunk, kept):
 
 
 @pytest.mark.gpu
-def test_transaction_calls_in_flight_on_one_verifier_keep_their_own_verdicts():
-    """zkgpu_tx_verify_submit / _wait: calls in flight on ONE verifier, merged by its engine into rounds.
+@pytest.mark.parametrize("engine_rounds", ["1", "2"])
+def test_transaction_calls_in_flight_on_one_verifier_keep_their_own_verdicts(engine_rounds, monkeypatch):
+    """zkgpu_tx_verify_submit / _wait: calls in flight on ONE verifier, merged by its engine into rounds
+    -- one round at a time, and two in flight (ZKGPU_TX_ROUNDS, read when the verifier's engine starts; the library's own
+    choice depends on the process's hardware queues: DESIGN.md sec 10.3).
     DISTINCT transactions (gpu_util.built_transactions -- the inputs of bench.py's tx_verify leg: one in 16 damaged at drawn
     positions here), their constructed expectation held against the oracle's Tx::verify for every damaged one and a sample
     of the others; 12 calls of 300 submitted from four threads at once, waited for in another order; a synchronous call and
@@ -510,6 +513,7 @@ def test_transaction_calls_in_flight_on_one_verifier_keep_their_own_verdicts():
     from gpu_util import bits, built_transactions, load_cloak_fixture
     from zkvm_amd import Context
     from zkvm_amd.verifier import BulletproofGens, BlockVerifier, CloakTx
+    monkeypatch.setenv("ZKGPU_TX_ROUNDS", engine_rounds)
     txs, expected = built_transactions(3600, call=21, bad_every=16)
     assert len(set(txs)) == 3600
     r = hashlib.shake_256(b"in flight").digest(64)
