@@ -5,4 +5,4 @@ for rep in 1 2 3; do
   python3 tools/tx_inflight.py 4096 4 32 2>&1 | tail -2
   python3 tools/tx_inflight.py 2048 8 32 2>&1 | tail -1
 done
-python3 -m pytest tests -m gpu -x -q > gpurun_out/r04z2_gpu_tests.log 2>&1; grep -n "passed\|failed\|error" gpurun_out/r04z2_gpu_tests.log | tail -3
+

@@ -113,6 +113,7 @@ struct zkgpu_verifier {
     const uint64_t* offsets = nullptr;
     int host_threads = 0;
     int state = 0, rc = 0;                              // 0 queued, 1 in a round, 2 done
+    std::chrono::steady_clock::time_point arrived;      // (the engine lets a small queue wait a little while a round is running)
     std::vector<uint8_t> bits, status;
   };
   std::mutex tx_mu;
@@ -1631,6 +1632,8 @@ int zkgpu_tx_verify_batch(zkgpu_verifier* v, size_t batch, const uint8_t* txs, c
 // bitmap and status bytes.  The transaction bytes and offsets must stay valid until the call has been waited for.  Verdicts
 // are those of separate calls.  Fail-closed: a round that fails gives every call in it the error and all-zero outputs.
 namespace {
+constexpr size_t TX_LINGER_ENOUGH = 4096;                                  // transactions queued: no reason to wait for more
+constexpr std::chrono::microseconds TX_LINGER(300);
 // One round of merged calls on its way: its own device view (one stage slot, one set of staging areas, one statement store)
 struct TxRound {
   std::vector<zkgpu_verifier::TxPending*> calls;
@@ -1701,6 +1704,15 @@ void tx_engine_main(zkgpu_verifier* v) {
       }
       for (int set = 0; set < max_rounds; ++set) {
         if (active[set] || v->tx_queue.empty()) continue;
+        // While the other round is still running the device is busy anyway: a SMALL queue then waits up to TX_LINGER for the
+        // calls that are about to arrive (a caller that has just been handed four verdicts submits its next four calls one
+        // after the other, microseconds apart: admitted at once, the first would make a round of its own -- measured:
+        // 2.3 - 2.7 calls of 1024 per round instead of 4).  An idle engine admits at once.
+        if (active[set ^ 1] && !v->tx_engine_quit) {
+          size_t queued = 0;
+          for (auto* p : v->tx_queue) queued += p->batch;
+          if (queued < TX_LINGER_ENOUGH && std::chrono::steady_clock::now() - v->tx_queue.front()->arrived < TX_LINGER) continue;
+        }
         fresh[set].reset(new TxRound());
         TxRound& r = *fresh[set];
         while (!v->tx_queue.empty() && (r.calls.empty() || r.total + v->tx_queue.front()->batch <= v->tx_merge_max)) {
@@ -1781,6 +1793,7 @@ int zkgpu_tx_verify_submit(zkgpu_verifier* v, size_t batch, const uint8_t* txs, 
   for (size_t i = 0; i < batch; ++i) if (tx_offsets[i + 1] < tx_offsets[i]) return ZKGPU_EINVAL;
   std::unique_ptr<zkgpu_verifier::TxPending> p(new zkgpu_verifier::TxPending());
   p->batch = batch; p->txs = txs; p->offsets = tx_offsets; p->host_threads = host_threads;
+  p->arrived = std::chrono::steady_clock::now();
   std::lock_guard<std::mutex> lk(v->tx_mu);
   if (v->tx_engine_quit) return ZKGPU_EINVAL;
   if (!v->tx_engine.joinable()) {
