@@ -570,6 +570,7 @@ class World:
         torch.cuda.set_device(self.local)
         self.dev = torch.device("cuda", self.local)
         self.coll_dev = torch.device("cpu")
+        self.no_rccl = None                                  # (set by make_exchange when the communicator cannot be made: the reason)
         self.dist = None
         if self.world > 1:
             import datetime
@@ -656,21 +657,43 @@ def make_exchange(W, ctx, cuts, always_comm=False, comm=None):
     whole batch out on every rank -- through the C ABI (zkgpu_comm_allgather_bitmap: ncclAllGather over xGMI) in both
     configs; gloo only when several ranks share one GPU (ZKGPU_BENCH_SHARE_GPU, the 1-GPU rehearsal: RCCL refuses two
     ranks on one device).  -> (exchange(local_bitmap, status) -> whole bitmap, close())"""
-    if W.world == 1 and not always_comm:
+    if W.world == 1 and (not always_comm or W.no_rccl):
         def alone(local, status=0):
             if status:
                 raise RuntimeError("verification failed with status %d" % status)
             return local
-        return alone, (lambda: None), "none (one rank)", None
+        return alone, (lambda: None), (W.no_rccl or "none (one rank)"), None
     parts = [(cuts[i], cuts[i + 1]) for i in range(W.world)]
-    if W.share_gpu:
+    # (ZKGPU_BENCH_TRY_RCCL=1 with ranks sharing a GPU: RCCL is tried all the same -- it refuses, which rehearses the fallback below)
+    if (W.share_gpu and os.environ.get("ZKGPU_BENCH_TRY_RCCL") != "1") or W.no_rccl:
         from zkvm_amd.sharded import gather_bitmaps
-        return (lambda local, status=0: gather_bitmaps(parts, local, status != 0, W.dist, None)), (lambda: None), "gloo (ranks share one GPU)", None
+        return (lambda local, status=0: gather_bitmaps(parts, local, status != 0, W.dist, None)), (lambda: None), (W.no_rccl or "gloo (ranks share one GPU)"), None
     from zkvm_amd.native import Comm
     own = comm is None
     if own:
+        # The communicator, and one real all-gather through it, before anything is timed.  If RCCL cannot be brought up on
+        # this node (it has only ever run as a world of one on the 1-GPU boxes this was built on), the run still measures the
+        # verification -- the bitmaps then travel over gloo, and the line says so and why; nothing is silently swapped.
         uid = W.broadcast_bytes(Comm.unique_id() if W.rank == 0 else b"", 128)
-        comm = Comm(ctx, W.rank, W.world, uid)
+        err = None
+        try:
+            comm = Comm(ctx, W.rank, W.world, uid)
+            got = comm.allgather(W.rank.to_bytes(4, "little"))
+            if [int.from_bytes(got[4 * i: 4 * i + 4], "little") for i in range(W.world)] != list(range(W.world)):
+                raise RuntimeError("the first all-gather returned the wrong ranks")
+        except Exception as e:                                  # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, str(e)[:300])
+        errs = W.gather_objects(err)
+        if any(errs):
+            if comm is not None:
+                try:
+                    comm.close()
+                except Exception:                               # noqa: BLE001
+                    pass
+            bad = next(i for i, e in enumerate(errs) if e)
+            W.no_rccl = "gloo -- RCCL could not be brought up on rank %d (%s)" % (bad, errs[bad])
+            print("bench.py: " + W.no_rccl, file=sys.stderr)
+            return make_exchange(W, ctx, cuts, always_comm, None)
     ex = (lambda local, status=0: comm.allgather_bitmap(cuts, local, status)), (comm.close if own else (lambda: None)), "ncclAllGather via zkgpu_comm_allgather_bitmap"
     return ex + (comm,)
 

@@ -21,7 +21,7 @@ from typing import Dict, Optional, Sequence, Tuple
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-OK, EINVAL, EINVALID_POINT, EHIP, ENOMEM, ENODEVICE = 0, -1, -2, -3, -4, -5
+OK, EINVAL, EINVALID_POINT, EHIP, ENOMEM, ENODEVICE, ENOCOMM = 0, -1, -2, -3, -4, -5, -6
 
 
 class ZkGpuError(RuntimeError):
@@ -358,7 +358,7 @@ class Context:
 
     def _check(self, rc: int, index: Optional[int] = None) -> None:
         if rc != OK:
-            detail = self.lib.zkgpu_last_error(self.h).decode() if rc in (EHIP, ENOMEM, EINVAL) else ""
+            detail = self.lib.zkgpu_last_error(self.h).decode() if rc in (EHIP, ENOMEM, EINVAL, ENOCOMM) else ""
             raise ZkGpuError(rc, self.lib.zkgpu_strerror(rc).decode() + (": " + detail if detail else ""), index)
 
     # ---- single MSM ---------------------------------------------------------
