@@ -89,3 +89,30 @@ def test_bench_gpus_2_without_a_launcher_spawns_ranks_and_fails_when_they_do():
     assert r.returncode != 0
     assert r.stdout.strip() == ""
     assert r.stderr.count("needs a GPU") == 2 and "rank exit codes [1, 1]" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("try_rccl", [False, True])
+def test_bench_gpus_2_on_one_gpu_prints_one_line_and_says_how_the_bitmaps_travelled(try_rccl):
+    """`python3 bench.py --gpus 2` as the driver would type it, both ranks made to share the one GPU of the test box
+    (ZKGPU_BENCH_SHARE_GPU=1: a rehearsal of the N > 1 code path, not a measurement): ONE JSON line on standard output, two
+    ranks in it, every step's bitmap exchanged and checked on both.  With ZKGPU_BENCH_TRY_RCCL=1 the ranks try to bring RCCL
+    up all the same -- it refuses two ranks on one device -- and must then agree to exchange over gloo and say why in the
+    line, instead of dying: the shape of a node on which RCCL cannot start."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["ZKGPU_BENCH_SHARE_GPU"] = "1"
+    if try_rccl:
+        env["ZKGPU_BENCH_TRY_RCCL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--lean"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0
+    assert len(d["config"]["per_rank"]) == 2
+    ex = d["config"]["exchange"]
+    if try_rccl:
+        assert ex.startswith("gloo -- RCCL could not be brought up on rank") and d["config"].get("rccl") is None, ex
+    else:
+        assert ex == "gloo (ranks share one GPU)", ex
