@@ -110,6 +110,15 @@ pub struct Ticket {
     batch: usize,
 }
 
+/// A call of serialized transactions in flight (`GpuVerifier::submit_txs`).  It owns the bytes the library reads until the
+/// call has been waited for.
+pub struct TxCall {
+    id: u64,
+    n: usize,
+    _blob: Vec<u8>,
+    _offsets: Vec<u64>,
+}
+
 struct Generators {
     ps: *mut sys::zkgpu_pointset,
     capacity: usize,
@@ -287,6 +296,42 @@ impl GpuVerifier {
                 (0, 1) => TxVerdict::Accepted,
                 (2, _) => TxVerdict::OutsideSubset,
                 _ => TxVerdict::Rejected, // (status 0 without its accept bit cannot happen; it would be a rejection)
+            })
+            .collect())
+    }
+
+    /// `verify_txs` in two halves, callable from many threads at once (upstream's `Tx::verify` is pure and `&self`): the
+    /// call is queued and this returns; an engine thread of the verifier merges whatever is queued into rounds (dynamic
+    /// batching), so that eight threads handing over 1024 transactions each see the rate of calls of several thousand.
+    pub fn submit_txs(&self, txs: &[&[u8]], host_threads: i32) -> Result<TxCall, Error> {
+        let n = txs.len();
+        if n == 0 {
+            return Err(Error::InvalidArgument("submit_txs: no transactions".into()));
+        }
+        let mut blob = Vec::with_capacity(txs.iter().map(|t| t.len()).sum());
+        let mut offsets = Vec::with_capacity(n + 1);
+        offsets.push(0u64);
+        for t in txs {
+            blob.extend_from_slice(t);
+            offsets.push(blob.len() as u64);
+        }
+        let mut id = 0u64;
+        // (the heap buffers of `blob` and `offsets` do not move when the vectors are moved into the handle)
+        check(unsafe { sys::zkgpu_tx_verify_submit(self.v, n, blob.as_ptr(), offsets.as_ptr(), host_threads as c_int, &mut id) }, self.err())?;
+        Ok(TxCall { id, n, _blob: blob, _offsets: offsets })
+    }
+
+    /// Blocks until the call's round is done: one verdict per transaction of THAT call.
+    pub fn wait_txs(&self, call: TxCall) -> Result<Vec<TxVerdict>, Error> {
+        let n = call.n;
+        let mut bitmap = vec![0u8; (n + 7) / 8];
+        let mut status = vec![1u8; n];
+        check(unsafe { sys::zkgpu_tx_verify_wait(self.v, call.id, bitmap.as_mut_ptr(), status.as_mut_ptr()) }, self.err())?;
+        Ok((0..n)
+            .map(|i| match (status[i], (bitmap[i / 8] >> (i % 8)) & 1) {
+                (0, 1) => TxVerdict::Accepted,
+                (2, _) => TxVerdict::OutsideSubset,
+                _ => TxVerdict::Rejected,
             })
             .collect())
     }
