@@ -1453,14 +1453,30 @@ k_merge_inputs(MergeSources src, uint32_t com_vec /*uint4 per transaction*/, uin
     const uint32_t tx = (uint32_t)(g / 4), k = source_of(tx);
     r[g] = src.r[k][g - (uint64_t)src.first[k] * 4];
   }
-  // proofs: byte-aligned sources (a proof is 1 + 32 k bytes): four bytes per lane of the destination
+  // proofs: byte-aligned sources (a proof is 1 + 32 k bytes): four bytes per lane of the destination -- from two ALIGNED
+  // words of the source and a funnel shift wherever the four bytes lie inside one source and not at its very end (a word
+  // read there could reach past the caller's buffer); byte by byte at the seams.  (Until round 4 always byte by byte, one
+  // thread per word: 3.5 M threads for a device batch of 10 240 -- beside a chip-filling kernel its 13 700 workgroups
+  // trickled in over 0.55 ms and held up the batch's head; now a bounded grid that is resident at once, grid-stride.)
+  const uint64_t n_bytes = (uint64_t)total * proof_len;
   for (uint64_t g = g0; g < n_pw; g += stride) {
+    const uint64_t at0 = 4 * g;
+    const uint32_t tx0 = (uint32_t)(at0 / proof_len), k0 = source_of(tx0);
+    const uint64_t lo_b = (uint64_t)src.first[k0] * proof_len, hi_b = (uint64_t)src.first[k0 + 1] * proof_len;
     uint32_t w = 0;
-    for (int b = 0; b < 4; ++b) {
-      const uint64_t at = 4 * g + b;
-      if (at >= (uint64_t)total * proof_len) break;
-      const uint32_t tx = (uint32_t)(at / proof_len), k = source_of(tx);
-      w |= (uint32_t)src.proofs[k][at - (uint64_t)src.first[k] * proof_len] << (8 * b);
+    if (at0 >= lo_b + 4 && at0 + 12 <= hi_b) {            // all four bytes in source k0, a word of it before and two after (aligned reads stay inside)
+      const uint8_t* p = src.proofs[k0] + (at0 - lo_b);
+      const uintptr_t a = (uintptr_t)p & ~(uintptr_t)3;
+      const uint32_t sh = (uint32_t)((uintptr_t)p & 3);
+      const uint32_t w0 = *reinterpret_cast<const uint32_t*>(a), w1 = *reinterpret_cast<const uint32_t*>(a + 4);
+      w = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    } else {
+      for (int b = 0; b < 4; ++b) {
+        const uint64_t at = at0 + b;
+        if (at >= n_bytes) break;
+        const uint32_t tx = (uint32_t)(at / proof_len), k = source_of(tx);
+        w |= (uint32_t)src.proofs[k][at - (uint64_t)src.first[k] * proof_len] << (8 * b);
+      }
     }
     reinterpret_cast<uint32_t*>(proofs)[g] = w;
   }

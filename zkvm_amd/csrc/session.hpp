@@ -780,6 +780,46 @@ void ticket_collect(zkgpu_verifier* v, int lane) {       // v->mu held
 // launches the batches at the head of the queue that share its shape; force: even below the merge target, and
 // if no lane is free the oldest one in flight is collected first
 int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
+  // Device batches that leave in one call are queued piece by piece (zkgpu_ctx::enqueue_phase): every batch's light front, then
+  // every batch's point decoding, then the rest of each -- the second batch's transcript and decoding then run beside the
+  // first's.  `fronts`: batches whose later pieces are still owed.
+  struct Front { int lane; zkgpu_cloak_plan* plan; size_t total, proof_len; const void *com, *proofs, *r; };
+  std::vector<Front> fronts;
+  auto flush_backs = [&]() {
+    std::vector<int> mid_rc(fronts.size(), ZKGPU_OK);
+    for (size_t i = 0; i < fronts.size(); ++i) {        // every batch's chip-filling decoding, then every batch's rest
+      const Front& f = fronts[i];
+      zkgpu_ctx* L = v->lanes[(size_t)f.lane];
+      { std::lock_guard<std::recursive_mutex> lk(L->mu); L->enqueue_phase = zkgpu_ctx::ENQ_MID; }
+      mid_rc[i] = zkgpu_cloak_verify_submit_dev(L, v->ps, f.plan, f.total, f.com, f.proofs, f.proof_len, f.r);
+      { std::lock_guard<std::recursive_mutex> lk(L->mu); L->enqueue_phase = zkgpu_ctx::ENQ_ALL; }
+    }
+    for (size_t i = 0; i < fronts.size(); ++i) {
+      const Front& f = fronts[i];
+      zkgpu_ctx* L = v->lanes[(size_t)f.lane];
+      int rc = mid_rc[i];
+      if (rc == ZKGPU_OK) {
+        { std::lock_guard<std::recursive_mutex> lk(L->mu); L->enqueue_phase = zkgpu_ctx::ENQ_BACK; }
+        rc = zkgpu_cloak_verify_submit_dev(L, v->ps, f.plan, f.total, f.com, f.proofs, f.proof_len, f.r);
+      }
+      { std::lock_guard<std::recursive_mutex> lk(L->mu); L->enqueue_phase = zkgpu_ctx::ENQ_ALL; L->awaiting_back = false; }
+      if (rc != ZKGPU_OK) {
+        // the back half could not be queued (a launch failed): what the front half queued is waited for, and the batch's
+        // requests fail with the error -- nothing is left in flight on the lane
+        v->last_error = zkgpu_last_error(L);
+        { DeviceGuard g(L->device); (void)hipDeviceSynchronize(); }
+        std::vector<zkgpu_request*> members;
+        members.swap(v->running[(size_t)f.lane]);
+        for (auto it = v->busy.begin(); it != v->busy.end(); ++it) if (*it == f.lane) { v->busy.erase(it); break; }
+        for (zkgpu_request* r : members) {
+          r->state = 2; r->rc = rc; r->bits.assign((r->batch + 7) / 8, 0);
+          if (r->run) block_request_done(v, r);
+        }
+      }
+    }
+    fronts.clear();
+  };
+  struct FlushAtExit { decltype(flush_backs)& f; ~FlushAtExit() { f(); } } flush_at_exit{flush_backs};
   while (!v->queue.empty()) {
     zkgpu_request* head = v->queue.front();
     std::vector<zkgpu_request*> pick;
@@ -796,6 +836,7 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
     for (size_t i = 0; i < v->lanes.size(); ++i) if (v->running[i].empty()) { lane = (int)i; break; }
     if (lane < 0) {
       if (!force) return ZKGPU_OK;
+      flush_backs();                                    // (a lane that is waited for must have its whole batch queued)
       collect_oldest(v);
       continue;
     }
@@ -841,7 +882,7 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
         ms.first[ms.n] = (uint32_t)(off - base);
         if (aligned && (base * head->proof_len) % 4 == 0) {
           const uint32_t span = ms.first[ms.n];
-          hipLaunchKernelGGL(k_merge_inputs, dim3(blocks_for((uint64_t)span * (head->proof_len / 4 + 1), 256)), dim3(256), 0, L->stream_l, ms,
+          hipLaunchKernelGGL(k_merge_inputs, dim3(std::min<unsigned>(blocks_for((uint64_t)span * (head->proof_len / 4 + 1), 256), 1024u)), dim3(256), 0, L->stream_l, ms,
                              (uint32_t)(wcom / 16), (uint32_t)head->proof_len, (uint4*)((char*)L->coal_com.p + base * wcom),
                              (uint8_t*)L->coal_proofs.p + base * head->proof_len, (uint4*)((char*)L->coal_r.p + base * 64));
           if (hipGetLastError() != hipSuccess) { L->last_error = "k_merge_inputs"; rc = ZKGPU_EHIP; }
@@ -859,7 +900,13 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
       }
       p_com = L->coal_com.p; p_proofs = L->coal_proofs.p; p_r = L->coal_r.p;
     }
-    if (rc == ZKGPU_OK && plan) rc = zkgpu_cloak_verify_submit_dev(L, v->ps, plan, total, p_com, p_proofs, head->proof_len, p_r);
+    bool front_only = false;
+    if (rc == ZKGPU_OK && plan) {
+      { std::lock_guard<std::recursive_mutex> lk(L->mu); L->enqueue_phase = zkgpu_ctx::ENQ_FRONT; L->awaiting_back = false; }
+      rc = zkgpu_cloak_verify_submit_dev(L, v->ps, plan, total, p_com, p_proofs, head->proof_len, p_r);
+      { std::lock_guard<std::recursive_mutex> lk(L->mu); L->enqueue_phase = zkgpu_ctx::ENQ_ALL; front_only = rc == ZKGPU_OK && L->awaiting_back; }
+      if (front_only) fronts.push_back(Front{lane, plan, total, head->proof_len, p_com, p_proofs, p_r});
+    }
     size_t off = 0;
     for (zkgpu_request* r : pick) {
       for (auto it = v->queue.begin(); it != v->queue.end(); ++it) if (*it == r) { v->queue.erase(it); break; }

@@ -94,6 +94,15 @@ struct zkgpu_ctx {
   int pair_overlaps = -1;          // root contexts: do stream and stream2 run side by side (streams_overlap at creation; -1 not probed)
   hipEvent_t dep_event = nullptr;  // the next whole-proof submit on this context waits for it first (its inputs are still being copied)
   bool reserve_only = false;       // zkgpu_verifier_reserve: the next whole-proof enqueue sizes the workspace and launches nothing
+  // A whole-proof batch queued in three pieces (session.hpp, ticket_dispatch: several device batches leaving together).  FRONT =
+  // the light kernels that need the proof bytes alone -- unpack, the transcript replay; MID = the proof points' decoding and
+  // tables (chip-filling); BACK = everything that waits for the transcript.  The verifier queues the FRONT of every batch,
+  // then the MID of every batch, then the BACKs, so that the second batch's transcript and decoding run beside the first's
+  // instead of 0.6 ms later, when the host has finished queueing the first batch's ~45 launches
+  // (profiles/r04am_timeline.txt).  The same call is made once per piece with the same arguments.
+  enum { ENQ_ALL = 0, ENQ_FRONT = 1, ENQ_MID = 2, ENQ_BACK = 3 };
+  int enqueue_phase = ENQ_ALL;
+  bool awaiting_back = false;      // an ENQ_FRONT call really queued a front half (shapes outside the pipeline run whole, at once)
   std::vector<uint8_t> sync_result; // result of a submit that had to run synchronously
   bool sync_result_valid = false;
   int sync_rc = 0;
@@ -876,6 +885,8 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
   TRY(ensure(c, c->recoded, std::max<uint64_t>(job.n_dyn, 1) * 32));
   c->last_w = 4;
   if (c->reserve_only) return ZKGPU_OK;                 // (the workspace now fits a batch of this shape and size: nothing is launched)
+  const int phase = prep ? c->enqueue_phase : (int)zkgpu_ctx::ENQ_ALL;        // (two halves: whole proofs only)
+  if (phase == zkgpu_ctx::ENQ_ALL || phase == zkgpu_ctx::ENQ_FRONT) {
   {
     Launch l(c, "k_batch_init", L);
     hipLaunchKernelGGL(k_batch_init, dim3(blocks_for(B, 256)), dim3(256), 0, L, (uint32_t*)c->status.p,
@@ -889,17 +900,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
                          prep->d_proofs, (uint64_t)prep->proof_len, (uint32_t*)c->prep_pw.p, sh.proof_words,
                          (uint32_t)B, (uint32_t*)c->prep_wf.p, proof_is_compact(sh, prep->proof_len));
     }
-    // the proof-specific points need the proof bytes only: gather, decompress and build their small
-    // tables on the shared stream while the transcript is replayed
     HIP_TRY(c, hipEventRecord(c->ev_u, L));
-    HIP_TRY(c, hipStreamWaitEvent(H1, c->ev_u, 0));
-    {
-      Launch l(c, "k_points_tables", H1);
-      hipLaunchKernelGGL(k_points_tables, dim3(blocks_for((uint64_t)B * sh.n_dyn, 256)), dim3(256), 0, H1, sh,
-                         prep->d_com, (const uint32_t*)c->prep_pw.p, (uint32_t)B, (uint32_t*)c->small_tbl.p,
-                         (uint32_t*)c->msm_fail.p, (unsigned long long*)((char*)c->status.p + 8));
-    }
-    HIP_TRY(c, hipEventRecord(c->ev_dig, H1));      // msm_fail is final: the group sums leave such transactions out
     // one wavefront per transaction while that still leaves the chip room (the cooperative form costs ~9x the
     // wave-instructions of the one-lane form, and buys latency only); beyond that, one lane per transaction
     const bool coop = prep->n_seg && (c->transcript_mode == 2 || (c->transcript_mode == 0 && B <= COOP_TRANSCRIPT_MAX));
@@ -929,6 +930,25 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     }
   }
   HIP_TRY(c, hipEventRecord(c->ev_t, L));
+  }                                                     // (front)
+  if (phase == zkgpu_ctx::ENQ_FRONT) { HIP_TRY(c, hipGetLastError()); c->awaiting_back = true; return ZKGPU_OK; }
+  if (prep && (phase == zkgpu_ctx::ENQ_ALL || phase == zkgpu_ctx::ENQ_MID)) {
+    // the proof-specific points need the proof bytes only: gather, decompress and build their small tables on the shared
+    // stream while the transcript is replayed.  Queued AFTER the transcript: k_points_tables takes every register of the chip
+    // (255 per lane, two wavefronts per SIMD), and a light kernel queued behind it waits for one of its wavefronts to retire
+    // -- ~0.6 ms (measured: the next batch's 30 us merge copy took 0.59 ms there, profiles/r04an_timeline.txt)
+    const PrepShape& sh = prep->sh;
+    HIP_TRY(c, hipStreamWaitEvent(H1, c->ev_u, 0));
+    {
+      Launch l(c, "k_points_tables", H1);
+      hipLaunchKernelGGL(k_points_tables, dim3(blocks_for((uint64_t)B * sh.n_dyn, 256)), dim3(256), 0, H1, sh,
+                         prep->d_com, (const uint32_t*)c->prep_pw.p, (uint32_t)B, (uint32_t*)c->small_tbl.p,
+                         (uint32_t*)c->msm_fail.p, (unsigned long long*)((char*)c->status.p + 8));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_dig, H1));      // msm_fail is final: the group sums leave such transactions out
+  }
+  if (phase == zkgpu_ctx::ENQ_MID) { HIP_TRY(c, hipGetLastError()); return ZKGPU_OK; }
+  c->awaiting_back = false;
   if (prep) {
     hipStream_t H3 = H3s;
     HIP_TRY(c, hipStreamWaitEvent(H3, c->ev_t, 0));
