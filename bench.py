@@ -347,7 +347,7 @@ def prover_program_microbench(ctx, host_threads: int, batch: int = 1024):
     from zkvm_amd.verifier import BulletproofGens, R1csProver, R1csVerifier
     m, n1, n, labels, cons = describe_ranges(8)
     desc = R1csDescription(GADGET_LABEL, m, n1, n, labels, cons)
-    gens = BulletproofGens(ctx, 512, table_bits=16)            # 51.6 GB beside the 25.9 GB of the 2x2 generators
+    gens = BulletproofGens(ctx, 512, table_bits=16)            # 68.9 GB beside the tables of the 2x2 generators
     rng = random.Random(SEED)
     vals, givens, seeds, mult_def = [], [], [], None
     for i in range(batch):

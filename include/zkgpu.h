@@ -98,7 +98,7 @@ size_t zkgpu_pointset_size(const zkgpu_pointset *ps);
 
 /* Build fixed-base window tables for the set: for every window position t and
  * point j the affine multiples d * 2^(w t) * P_j, d = 1 .. 2^(w-1)
- * ((255/w + 1) * n * 2^(w-1) packed rows of 96 B; w = 16, n = 514: 25.9 GB, n = 1026: 51.7 GB;
+ * ((255/w + 1) * n * 2^(w-1) packed rows of 96 B, one per 128-byte line; w = 16, n = 514: 34.5 GB, n = 1026: 68.9 GB;
  * w = 12, n = 514: 2.2 GB).  With tables present zkgpu_verify_batch_ps* and every whole-proof
  * entry point sum static terms straight out of them: one mixed addition per term and window,
  * no doublings, no sorting.  One-time cost: ~0.2 s at 16 bits and 514 points (50 MB per point),

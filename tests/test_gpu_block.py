@@ -633,7 +633,7 @@ def test_device_verifier_head_bytes_equal_oracle(ctx, gens512, oracle, group, mo
 
 
 def test_benched_configuration_full_size_vs_oracle(ctx, oracle):
-    """What bench.py times, as a parity test: 16-bit generator tables (25.9 GB), six batches in flight on forked
+    """What bench.py times, as a parity test: 16-bit generator tables (34.5 GB), six batches in flight on forked
     contexts sharing the chip-filling streams, groups of 16, the 1024 DISTINCT golden proofs per batch (every step
     under fresh verifier randomness and its own corruptions), inputs resident in HBM -- every accept bit of
     every step against the oracle's full verifier; then one 4096-transaction batch."""
@@ -693,7 +693,7 @@ def test_benched_arrangement_tickets_merged_into_device_batches_vs_oracle(ctx, o
     """EXACTLY what bench.py times with the driver's flags (--steps 20): 20 batches of 1024 transactions -- bench.py's own
     input construction (gpu_util.benched_step / benched_randomness: every batch its own rotation of the 1024 distinct
     golden proofs, its own corruptions, its own verifier randomness) -- queued by ONE zkgpu_verifier_submit_many_dev on a
-    verifier with 5 lanes, merged into device batches of 10 240 transactions over 16-bit generator tables (25.9 GB),
+    verifier with 5 lanes, merged into device batches of 10 240 transactions over 16-bit generator tables (34.5 GB),
     groups of 16, inputs resident in HBM: every accept bit of every ticket against the oracle's full verifier (and against
     the constructed expectation bench.py asserts); then the steady-state form: 40 more tickets, 64 in flight at most,
     submitted one by one as earlier ones are waited for."""

@@ -299,7 +299,7 @@ def test_fixed_base_tables_equal_generic_path(ctx, oracle, w):
     plain = ctx.verify_batch_ps(ps, dyn_sc, dyn_pt, dyn_off, st_sc, st_off, static_index=st_idx)
     assert plain == want
     nbytes = ps.build_tables(w)
-    assert nbytes == (255 // w + 1) * n_gen * (1 << (w - 1)) * 96
+    assert nbytes == (255 // w + 1) * n_gen * (1 << (w - 1)) * 128      # (96-byte rows, one per 128-byte line)
     for parts in (0, 1, 3):
         ctx.set_static_parts(parts)
         assert ctx.verify_batch_ps(ps, dyn_sc, dyn_pt, dyn_off, st_sc, st_off, static_index=st_idx) == want
@@ -378,7 +378,7 @@ def test_msm_values_over_resident_set(ctx, oracle, w):
 
 def test_table_width_is_chosen_by_capacity_and_free_memory(ctx, oracle):
     """zkgpu_pointset_build_tables(.., 0): the library picks the window width -- the KNEE: the narrowest width whose addition
-    count per generator term is within 19/16 of the widest feasible width's (14 bits = 7.7 GB instead of 16 bits = 25.9 GB for
+    count per generator term is within 19/16 of the widest feasible width's (14 bits = 10.2 GB instead of 16 bits = 34.5 GB for
     the 1026 generators of the 2-in/2-out statement on a 288 GB MI355X: 0.5 - 4 % measured), fewer for sets whose tables would
     not fit a quarter of the device -- and the verdicts are the same whatever the width (here against a set built at 9 bits)."""
     import ctypes as C
@@ -393,7 +393,7 @@ def test_table_width_is_chosen_by_capacity_and_free_memory(ctx, oracle):
     nine = BulletproofGens(ctx, 64, table_bits=9)
     try:
         assert auto.points.table_bits() == 14 and nine.points.table_bits() == 9
-        assert lib.zkgpu_pointset_table_bytes(auto.points.h) == 19 * 130 * 8192 * 96
+        assert lib.zkgpu_pointset_table_bytes(auto.points.h) == 19 * 130 * 8192 * 128
         com, proofs = oracle.cloak_prove_batch(3, 1, 1, b"auto width".ljust(32, b"\0"), threads=3)      # 1-in/1-out: 64 generators
         bad = bytearray(proofs[1]); bad[-40] ^= 1
         txs = [CloakTx(1, 1, com[128 * i: 128 * (i + 1)], bytes(bad) if i == 1 else proofs[i]) for i in range(3)]

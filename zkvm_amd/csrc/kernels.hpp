@@ -37,6 +37,7 @@ constexpr int EXT_WORDS = 40;
 constexpr int REDUCE_CHUNK = 64;   // buckets per lane in k_bucket_reduce when a window has at most this many
 constexpr int REDUCE_CHUNK_BIG = 16;  // ... and when it has more (more lanes, shorter serial chains)
 constexpr int TABLE_WORDS = 24;    // fixed-base table row: three canonical 255-bit values, 96 B
+constexpr int TABLE_STRIDE = 32;   // ... one row per 128-byte line (96-byte rows at a 96-byte stride straddle lines: 2.07x the bytes addressed)
 
 struct JobDesc {
   // dynamic terms (own compressed points)
@@ -1134,7 +1135,7 @@ k_pack_bitmap(const uint8_t* __restrict__ accept, const uint32_t* __restrict__ w
 // The generators never change, so the device keeps, for every window position t
 // and every generator j, the affine-Niels rows of d * 2^(w t) * G_j for
 // d = 1 .. 2^(w-1):
-//     table[((t * n_set + j) * H + (d - 1)) * 24 words],  H = 2^(w-1)   (96-byte packed rows)
+//     table[((t * n_set + j) * H + (d - 1)) * 32 words],  H = 2^(w-1)   (96-byte packed rows, one per 128-byte line)
 // A generator term s * G_j then costs one mixed addition per window with NO
 // doublings, no sorting and no bucket reduction, and every lane of the kernel
 // does the same number of additions.  Memory is what MI355X has plenty of:
@@ -1181,7 +1182,7 @@ k_tbl_multiples(const uint32_t* __restrict__ base, uint32_t* __restrict__ tmp, u
   }
   fe inv;
   fe_invert(inv, prod);           // 1 / (Z_1 ... Z_H)
-  uint32_t* myrows = table + lane * (uint64_t)H * TABLE_WORDS;
+  uint32_t* myrows = table + lane * (uint64_t)H * TABLE_STRIDE;
   for (uint32_t d = H; d-- > 0;) {
     ge rec;
     load_ext(rec, mytmp + (uint64_t)d * EXT_WORDS);
@@ -1198,7 +1199,7 @@ k_tbl_multiples(const uint32_t* __restrict__ base, uint32_t* __restrict__ tmp, u
     fe_mul(y, rec.Y, zinv);
     ge_niels nq;
     niels_from_affine(nq, x, y);
-    store_table_row(myrows + (uint64_t)d * TABLE_WORDS, nq);
+    store_table_row(myrows + (uint64_t)d * TABLE_STRIDE, nq);
   }
 }
 
@@ -1247,7 +1248,7 @@ k_static_accumulate(const int16_t* __restrict__ digits, const uint64_t* __restri
     d = (d == -32768) ? 32768 : d;   // w = 16: +2^15 is stored wrapped (the recoding never yields -2^15)
     const uint32_t idx = st_index ? st_index[k] : (uint32_t)(k - k0);
     const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-    const uint32_t* row = table + ((tbase + idx) * H + (mag ? mag - 1 : 0)) * TABLE_WORDS;
+    const uint32_t* row = table + ((tbase + idx) * H + (mag ? mag - 1 : 0)) * TABLE_STRIDE;
     load_table_row(q, row);
     if (d == 0) niels_identity(q);
     neg = d < 0;
@@ -1324,7 +1325,7 @@ __device__ inline void static_row_share(ge& acc, const int16_t* __restrict__ dig
     d = (d == -32768) ? 32768 : d;
     const uint32_t idx = st_index ? st_index[k] : j;
     const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-    load_table_row(q, table + (((uint64_t)t * n_set + idx) * H + (mag ? mag - 1 : 0)) * TABLE_WORDS);
+    load_table_row(q, table + (((uint64_t)t * n_set + idx) * H + (mag ? mag - 1 : 0)) * TABLE_STRIDE);
     if (d == 0) niels_identity(q);
     neg = d < 0;
   };

@@ -1563,7 +1563,7 @@ void zkgpu_pointset_destroy(zkgpu_pointset* ps) {
 size_t zkgpu_pointset_size(const zkgpu_pointset* ps) { return ps ? ps->n : 0; }
 
 // bytes of the tables of n points at w bits, and of the scratch their construction needs beside them
-static inline uint64_t table_bytes_for(uint64_t n, int w) { return (uint64_t)(255 / w + 1) * n * (1ull << (w - 1)) * TABLE_WORDS * 4; }
+static inline uint64_t table_bytes_for(uint64_t n, int w) { return (uint64_t)(255 / w + 1) * n * (1ull << (w - 1)) * TABLE_STRIDE * 4; }
 static inline uint64_t table_build_bytes_for(uint64_t n, int w) {
   const uint64_t lanes = (uint64_t)(255 / w + 1) * n;
   return table_bytes_for(n, w) + lanes * (1ull << (w - 1)) * EXT_WORDS * 4 + lanes * EXT_WORDS * 4;
@@ -1577,7 +1577,7 @@ static inline uint64_t table_build_bytes_for(uint64_t n, int w) {
 // the widest table buys that with 18 GB.  Rule: take the widest width that is feasible (at most 16; tables no more than a
 // quarter of the device's memory; construction -- tables + 1.7x scratch -- within 60 % of what is free right now), then the
 // NARROWEST width whose addition count is within 19/16 of that one's ("the narrowest width within 3 % of the
-// widest measured").  On a 288 GB MI355X: 14 bits (7.7 GB for 1026 generators, 15.3 GB for 2050).  A caller who wants the
+// widest measured").  On a 288 GB MI355X: 14 bits (10.2 GB for 514 generators, 20.4 GB for 1026).  A caller who wants the
 // last per cent passes the width itself (16).
 int zkgpu_choose_table_bits(zkgpu_ctx* c, size_t n_points) {
   if (!c || n_points == 0) return ZKGPU_EINVAL;
@@ -1611,7 +1611,7 @@ int zkgpu_pointset_build_tables(zkgpu_ctx* c, zkgpu_pointset* ps, int window_bit
   const uint64_t n_lanes = (uint64_t)W * ps->n;
   const uint64_t n_rows = n_lanes * H;
   uint32_t *base = nullptr, *tmp = nullptr, *table = nullptr;
-  hipError_t e = hipMalloc((void**)&table, n_rows * TABLE_WORDS * 4);
+  hipError_t e = hipMalloc((void**)&table, n_rows * TABLE_STRIDE * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&base, n_lanes * EXT_WORDS * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&tmp, n_rows * EXT_WORDS * 4);
   if (e != hipSuccess) {
@@ -1642,7 +1642,7 @@ int zkgpu_pointset_build_tables(zkgpu_ctx* c, zkgpu_pointset* ps, int window_bit
 }
 
 size_t zkgpu_pointset_table_bytes(const zkgpu_pointset* ps) {
-  return (ps && ps->table) ? (size_t)ps->tbl_W * ps->n * ps->tbl_H * TABLE_WORDS * 4 : 0;
+  return (ps && ps->table) ? (size_t)ps->tbl_W * ps->n * ps->tbl_H * TABLE_STRIDE * 4 : 0;
 }
 
 // Test hook: the intermediate buffers of the last device-side preparation on this context
