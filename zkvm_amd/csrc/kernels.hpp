@@ -579,6 +579,15 @@ k_part_sort(PartShape ps, const uint32_t* __restrict__ part_base, const uint32_t
   for (uint32_t i = t; i < n; i += 256) entries[start + i] = staged[i];
 }
 
+__device__ __forceinline__ void shfl_up_ge(ge& out, const ge& in, int delta) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    out.X.v[i] = __shfl_up(in.X.v[i], delta);
+    out.Y.v[i] = __shfl_up(in.Y.v[i], delta);
+    out.Z.v[i] = __shfl_up(in.Z.v[i], delta);
+    out.T.v[i] = __shfl_up(in.T.v[i], delta);
+  }
+}
 __device__ __forceinline__ void shfl_down_ge(ge& out, const ge& in, int delta) {
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
@@ -1716,30 +1725,37 @@ __device__ inline void locate_group(const uint32_t* __restrict__ partials2, uint
     }
     const uint32_t tx = G * group + (uint32_t)lane;
     const bool live = (uint32_t)lane < group && tx < n_msm && !tx_excluded(msm_fail, wellformed, tx);
-    const int bits = 32 - __clz(group);          // positions 1 .. group
-    // (lane + 1) * dyn_lane and (lane + 1) * S1 by one double-and-add loop (two independent chains)
-    ge d, S1, md, M;
-    ge_identity(d);
-    if (live) load_ext(d, dyn_sum + (uint64_t)tx * EXT_WORDS);
-    load_ext(S1, fail_sum + (uint64_t)f * EXT_WORDS);
-    ge_identity(md);
-    ge_identity(M);
-    const uint32_t k = (uint32_t)lane + 1;
+    // S2 = sum_lanes share + sum_k k d_k (k = lane + 1, d_k the proof-point sum of transaction k of the group), and the
+    // candidates M_k = k S1.  Neither needs a multiplication: sum_k k d_k = sum_j (sum_{k >= j} d_k) is the sum of the SUFFIX
+    // sums, and k S1 is the PREFIX sum of S1 over the lanes -- log2(group) shuffled additions each, where round 3 ran a
+    // five-step double-and-add on two chains per lane (seven points live at once: 1084 bytes of scratch in this function;
+    // the kernel sits on the tail of every batch that has a failed group).
+    const int span = 1 << (31 - __clz((int)(2 * group - 1)));      // group (1 .. 64) rounded up to a power of two
+    {
+      ge suf;
+      ge_identity(suf);
+      if (live) load_ext(suf, dyn_sum + (uint64_t)tx * EXT_WORDS);
 #pragma unroll 1
-    for (int bit = bits - 1; bit >= 0; --bit) {
-      ge x, y;
-      ge_double<true>(x, md); md = x;
-      ge_double<true>(y, M); M = y;
-      ge_add(x, md, d);
-      ge_add(y, M, S1);
-      if ((k >> bit) & 1) { md = x; M = y; }
+      for (int delta = 1; delta < span; delta <<= 1) {
+        ge other;
+        shfl_down_ge(other, suf, delta);           // (lanes >= group hold the identity)
+        if (lane + delta < span) ge_add(suf, suf, other);
+      }
+      if (lane < span) ge_add(acc, acc, suf);
     }
-    ge_add(acc, acc, md);                        // identity stays the identity for the lanes without a transaction
 #pragma unroll 1
     for (int delta = 32; delta >= 1; delta >>= 1) {
       ge other;
       shfl_down_ge(other, acc, delta);
       if (lane < delta) ge_add(acc, acc, other);
+    }
+    ge M;
+    load_ext(M, fail_sum + (uint64_t)f * EXT_WORDS);  // S1 in every lane -> (lane + 1) S1 by an inclusive scan
+#pragma unroll 1
+    for (int delta = 1; delta < span; delta <<= 1) {
+      ge other;
+      shfl_up_ge(other, M, delta);
+      if (lane >= delta) ge_add(M, M, other);
     }
     ge S2;
     shfl_ge(S2, acc, 0);

@@ -278,7 +278,8 @@ inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + pe
 // sets of shared chip-filling streams per parent context (consecutive forks alternate between them) and the
 // fork limit that keeps the process under the ~22 hardware queues the runtime hands out before it
 // multiplexes them in software (measured: 100-200 ms per step beyond that)
-constexpr int TAIL_THREADS = 512;   // threads per row in k_locate_fused / k_recheck_fused (shares of the row's generator sum)
+constexpr int TAIL_THREADS = 512;   // threads per row in k_recheck_fused (shares of the row's generator sum)
+constexpr int LOCATE_THREADS = 512; // ... in k_locate_fused: one wavefront per SIMD, so that the naming of the culprit has 512 registers and no scratch
 constexpr int STREAM_SETS = 2;
 constexpr int MAX_FORKS = 9;
 constexpr size_t LOCATE_MIN_BATCH = 2048;      // transactions per batch from which failed groups are located instead of re-checked in full
@@ -1062,7 +1063,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     const bool fused_tail = c->tail_mode == 0;
     if (locate && !spec && fused_tail) {
       Launch l(c, "k_locate_fused", L);
-      hipLaunchKernelGGL(k_locate_fused, dim3(n_groups), dim3(TAIL_THREADS), 0, L, (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index,
+      hipLaunchKernelGGL(k_locate_fused, dim3(n_groups), dim3(LOCATE_THREADS), 0, L, (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index,
                          (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, n_groups, (uint32_t*)c->grp_partials.p,
                          (const uint32_t*)c->dynsum.p, (const uint32_t*)c->msm_fail.p, job.d_wellformed, (uint32_t)B, group,
                          (const uint32_t*)fail_list, (const uint32_t*)n_fail, (const uint32_t*)c->grp_fail_sum.p,
