@@ -551,6 +551,8 @@ class World:
     def __init__(self, args):
         import torch
         self.torch = torch
+        self.args = args
+        self.bringup = None                                  # (N > 1: how the communicator's bring-up went -- in the line)
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -567,6 +569,11 @@ class World:
             raise SystemExit("%d ranks but %d GPUs visible (ZKGPU_BENCH_SHARE_GPU=1 puts every rank on device 0: a rehearsal, "
                              "not a measurement)" % (self.world, torch.cuda.device_count()))
         self.local = 0 if self.share_gpu else local
+        if self.share_gpu and self.world > 2 and args.table_bits < 0:
+            # more than two ranks on ONE device (the N = 8 rehearsal): every rank builds its own tables and workspaces in the
+            # one device's memory -- 8 x (15 GB of tables + ~16 GB of lanes) of config 4 do not fit 288 GB (the first
+            # rehearsal ended in HSA_STATUS_ERROR_OUT_OF_RESOURCES).  Narrow tables: a correctness run, not a measurement.
+            args.table_bits = 12
         torch.cuda.set_device(self.local)
         self.dev = torch.device("cuda", self.local)
         self.coll_dev = torch.device("cpu")
@@ -671,19 +678,31 @@ def make_exchange(W, ctx, cuts, always_comm=False, comm=None):
     from zkvm_amd.native import Comm
     own = comm is None
     if own:
-        # The communicator, and one real all-gather through it, before anything is timed.  If RCCL cannot be brought up on
-        # this node (it has only ever run as a world of one on the 1-GPU boxes this was built on), the run still measures the
-        # verification -- the bitmaps then travel over gloo, and the line says so and why; nothing is silently swapped.
-        uid = W.broadcast_bytes(Comm.unique_id() if W.rank == 0 else b"", 128)
-        err = None
-        try:
-            comm = Comm(ctx, W.rank, W.world, uid)
-            got = comm.allgather(W.rank.to_bytes(4, "little"))
-            if [int.from_bytes(got[4 * i: 4 * i + 4], "little") for i in range(W.world)] != list(range(W.world)):
-                raise RuntimeError("the first all-gather returned the wrong ranks")
-        except Exception as e:                                  # noqa: BLE001
-            err = "%s: %s" % (type(e).__name__, str(e)[:300])
-        errs = W.gather_objects(err)
+        # The communicator, and one real all-gather through it, before anything is timed -- and BOUNDED (zkvm_amd/bringup.py):
+        # ncclCommInitRank cannot be cancelled from inside a process, so (1) every rank first tries the bring-up in a CHILD
+        # process it can kill (a stall or a refusal there costs nothing: the ranks agree over gloo, the bitmaps then travel
+        # over gloo, and the line says so and why -- the run still measures the verification); (2) the bring-up in the rank
+        # itself, after every child has succeeded, runs under a watchdog that ends the rank with exit code 3 and the reason
+        # on standard error, so that the launcher ends the others: never a silent wait for the driver's limit.
+        from zkvm_amd import bringup
+        T = float(getattr(W.args, "comm_timeout", 120.0))
+        errs = [None] * W.world
+        if W.world > 1 and os.environ.get("ZKGPU_BENCH_COMM_PROBE", "1") != "0":
+            t0 = time.perf_counter()
+            errs = bringup.probe(W.rank, W.world, W.local, T, W.broadcast_bytes, W.gather_objects)
+            W.bringup = {"probe_s": round(time.perf_counter() - t0, 2), "probe": "child process per rank: zkgpu_comm_create + one all-gather"}
+        if not any(errs):
+            err = None
+            with bringup.Watchdog(T, "zkgpu_comm_create (ncclCommInitRank) + the first all-gather", code=3, rank=W.rank):
+                uid = W.broadcast_bytes(Comm.unique_id() if W.rank == 0 else b"", 128)
+                try:
+                    comm = Comm(ctx, W.rank, W.world, uid)
+                    got = comm.allgather(W.rank.to_bytes(4, "little"))
+                    if [int.from_bytes(got[4 * i: 4 * i + 4], "little") for i in range(W.world)] != list(range(W.world)):
+                        raise RuntimeError("the first all-gather returned the wrong ranks")
+                except Exception as e:                              # noqa: BLE001
+                    err = "%s: %s" % (type(e).__name__, str(e)[:300])
+                errs = W.gather_objects(err)
         if any(errs):
             if comm is not None:
                 try:
@@ -965,7 +984,7 @@ def run_config2(args, W):
                             "merged_device_batches": ({"transactions": args.merge, "lanes": bv.lanes()} if bv is not None else None),
                             "distinct_step_inputs": n_sets, "exchange": exchange_name, "steps_per_exchange": gather_every if world > 1 else None,
                             "ranks": ranks_info, "per_rank": per_rank, "rccl": roll_call,
-                            "control_plane": "gloo (host)" if world > 1 else None,
+                            "control_plane": "gloo (host)" if world > 1 else None, "bringup": W.bringup,
                             "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "hw_queues_set_by": "caller" if _HWQ_PRESET else "bench.py, before the HIP runtime started",
                             "parallelism": "tx-sharded x%d, RCCL all-gather of accept bitmaps" % world})
         line["roofline"] = roofline_object(solo, launches, in_flight_ms, alg_dev, dev_batch, ms_per_dev_batch, table_bytes,
@@ -1327,7 +1346,7 @@ def run_config4(args, W):
                             "generator_table_bits": args.table_bits, "gens_capacity": 512, "calls_in_flight": bv.lanes(), "blocks_in_flight": depth,
                             "chunk": args.chunk or 2048, "group_size": args.group,
                             "exchange": exchange_name, "ranks": ranks_info, "per_rank": per_rank, "rccl": roll_call,
-                            "control_plane": "gloo (host)" if world > 1 else None,
+                            "control_plane": "gloo (host)" if world > 1 else None, "bringup": W.bringup,
                             "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                             "parallelism": "tx-sharded x%d" % world})
         line["roofline"] = roofline_object(solo, launches, {}, alg_step, hi - lo, ms_per_step, table_bytes,
@@ -1365,7 +1384,10 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=(2, 4),
                     help="2: BASELINE configs[1], 1024 2x2 tx per GPU (default, the headline); 4: configs[3], mixed arity, sharded")
     ap.add_argument("--batch", type=int, default=1024, help="transactions per GPU (config 4: default 8192)")
-    ap.add_argument("--table-bits", type=int, default=-1, help="window width of the fixed-base generator tables (-1: the library chooses by capacity and free HBM: 16 on an MI355X)")
+    ap.add_argument("--table-bits", type=int, default=-1, help="window width of the fixed-base generator tables (-1: the library chooses the knee of additions per term against table bytes: 14 for 514 points on an MI355X)")
+    ap.add_argument("--launch-timeout", type=float, default=900.0, help="--gpus N > 1 started by this program: seconds before the launcher ends every rank and returns 124")
+    ap.add_argument("--comm-timeout", type=float, default=float(os.environ.get("ZKGPU_BENCH_COMM_TIMEOUT", "120")),
+                    help="N > 1: seconds the RCCL communicator's bring-up (probe in a child process, then ncclCommInitRank + one all-gather in the rank) may take")
     ap.add_argument("--inflight", type=int, default=0,
                     help="device batches in flight per GPU (contexts): default 5 with --tickets, 6 without, 6 for config 4")
     ap.add_argument("--group", type=int, default=16, help="transactions per group check (1 = every transaction on its own)")
@@ -1409,7 +1431,8 @@ def main():
         # no launcher above us: this process becomes one.  It has not imported torch and never touches the GPU; the ranks
         # are fresh interpreters running this same command line (zkvm_amd/launch.py), rank 0's line is relayed as ours.
         from zkvm_amd.launch import spawn_ranks
-        rc, codes = spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, out=_JSON_OUT, err=sys.stderr)
+        rc, codes = spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, out=_JSON_OUT, err=sys.stderr,
+                                timeout=args.launch_timeout)
         if rc != 0:
             print("bench.py: rank exit codes %s" % codes, file=sys.stderr)
         sys.exit(rc)

@@ -110,13 +110,28 @@ pub struct Ticket {
     batch: usize,
 }
 
-/// A call of serialized transactions in flight (`GpuVerifier::submit_txs`).  It owns the bytes the library reads until the
-/// call has been waited for.
-pub struct TxCall {
+/// A call of serialized transactions in flight (`GpuVerifier::submit_txs`).  It owns the bytes the library's engine thread
+/// reads until the call has been waited for, and it BORROWS the verifier: a call that is dropped without `wait_txs` -- an
+/// early `?`, a panic unwinding, a caller that discards it -- is waited for in `Drop` (verdicts thrown away), so the bytes
+/// are never freed under a round that still reads them, and the library's record of the call does not pile up.
+pub struct TxCall<'v> {
+    verifier: &'v GpuVerifier,
     id: u64,
     n: usize,
+    waited: bool,
     _blob: Vec<u8>,
     _offsets: Vec<u64>,
+}
+
+impl Drop for TxCall<'_> {
+    fn drop(&mut self) {
+        if !self.waited {
+            let mut bitmap = vec![0u8; (self.n + 7) / 8];
+            let mut status = vec![1u8; self.n];
+            // (the return code does not matter here: after this call the library no longer reads `_blob` / `_offsets`)
+            let _ = unsafe { sys::zkgpu_tx_verify_wait(self.verifier.v, self.id, bitmap.as_mut_ptr(), status.as_mut_ptr()) };
+        }
+    }
 }
 
 struct Generators {
@@ -132,7 +147,8 @@ pub struct GpuVerifier {
     warning: Option<String>,
 }
 
-// the library serialises calls on a verifier with its own mutex; the handles are plain pointers to its heap objects
+// the library serialises calls on a verifier with its own mutex, and hands out its error text as a per-thread copy made
+// under that mutex (zkgpu_verifier_last_error); the handles are plain pointers to its heap objects
 unsafe impl Send for GpuVerifier {}
 unsafe impl Sync for GpuVerifier {}
 
@@ -303,7 +319,7 @@ impl GpuVerifier {
     /// `verify_txs` in two halves, callable from many threads at once (upstream's `Tx::verify` is pure and `&self`): the
     /// call is queued and this returns; an engine thread of the verifier merges whatever is queued into rounds (dynamic
     /// batching), so that eight threads handing over 1024 transactions each see the rate of calls of several thousand.
-    pub fn submit_txs(&self, txs: &[&[u8]], host_threads: i32) -> Result<TxCall, Error> {
+    pub fn submit_txs(&self, txs: &[&[u8]], host_threads: i32) -> Result<TxCall<'_>, Error> {
         let n = txs.len();
         if n == 0 {
             return Err(Error::InvalidArgument("submit_txs: no transactions".into()));
@@ -318,15 +334,20 @@ impl GpuVerifier {
         let mut id = 0u64;
         // (the heap buffers of `blob` and `offsets` do not move when the vectors are moved into the handle)
         check(unsafe { sys::zkgpu_tx_verify_submit(self.v, n, blob.as_ptr(), offsets.as_ptr(), host_threads as c_int, &mut id) }, self.err())?;
-        Ok(TxCall { id, n, _blob: blob, _offsets: offsets })
+        Ok(TxCall { verifier: self, id, n, waited: false, _blob: blob, _offsets: offsets })
     }
 
     /// Blocks until the call's round is done: one verdict per transaction of THAT call.
-    pub fn wait_txs(&self, call: TxCall) -> Result<Vec<TxVerdict>, Error> {
+    pub fn wait_txs(&self, mut call: TxCall<'_>) -> Result<Vec<TxVerdict>, Error> {
+        if !ptr::eq(call.verifier, self) {
+            return Err(Error::InvalidArgument("wait_txs: the call was submitted to another verifier".into())); // (its Drop waits there)
+        }
         let n = call.n;
         let mut bitmap = vec![0u8; (n + 7) / 8];
         let mut status = vec![1u8; n];
-        check(unsafe { sys::zkgpu_tx_verify_wait(self.v, call.id, bitmap.as_mut_ptr(), status.as_mut_ptr()) }, self.err())?;
+        let rc = unsafe { sys::zkgpu_tx_verify_wait(self.v, call.id, bitmap.as_mut_ptr(), status.as_mut_ptr()) };
+        call.waited = true; // (whatever it returned, the library is done with the call's bytes)
+        check(rc, self.err())?;
         Ok((0..n)
             .map(|i| match (status[i], (bitmap[i / 8] >> (i % 8)) & 1) {
                 (0, 1) => TxVerdict::Accepted,
@@ -397,7 +418,17 @@ impl GpuVerifier {
         let mut com = Vec::new();
         let mut proofs = Vec::new();
         let mut offs = vec![0u64];
+        // the library reads 64 * (n_in + n_out) bytes per statement and 64 bytes of randomness per statement: the same
+        // checks as `verify_block`, or a short slice would be an out-of-bounds read behind a safe fn
+        if let Some(r) = randomness {
+            if r.len() != 64 * n {
+                return Err(Error::InvalidArgument("randomness: 64 bytes per statement".into()));
+            }
+        }
         for s in stmts {
+            if s.commitments.len() != 64 * (s.n_in as usize + s.n_out as usize) {
+                return Err(Error::InvalidArgument("commitments: 64 bytes per value".into()));
+            }
             com.extend_from_slice(s.commitments);
             proofs.extend_from_slice(s.proof);
             offs.push(proofs.len() as u64);

@@ -689,18 +689,21 @@ def test_benched_configuration_full_size_vs_oracle(ctx, oracle):
         gens.close()
 
 
-def test_benched_arrangement_tickets_merged_into_device_batches_vs_oracle(ctx, oracle):
+@pytest.mark.parametrize("table_bits", [-1, 16])
+def test_benched_arrangement_tickets_merged_into_device_batches_vs_oracle(ctx, oracle, table_bits):
     """EXACTLY what bench.py times with the driver's flags (--steps 20): 20 batches of 1024 transactions -- bench.py's own
     input construction (gpu_util.benched_step / benched_randomness: every batch its own rotation of the 1024 distinct
     golden proofs, its own corruptions, its own verifier randomness) -- queued by ONE zkgpu_verifier_submit_many_dev on a
-    verifier with 5 lanes, merged into device batches of 10 240 transactions over 16-bit generator tables (34.5 GB),
-    groups of 16, inputs resident in HBM: every accept bit of every ticket against the oracle's full verifier (and against
+    verifier with 5 lanes, merged into device batches of 10 240 transactions over the generator tables bench.py uses
+    (table_bits = -1: the LIBRARY'S choice, 14-bit windows at a 128-byte row stride for these 514 points -- what the
+    headline runs on since the end of round 4) and over 16-bit tables (34.5 GB), groups of 16, inputs resident in HBM: every accept bit of every ticket against the oracle's full verifier (and against
     the constructed expectation bench.py asserts); then the steady-state form: 40 more tickets, 64 in flight at most,
     submitted one by one as earlier ones are waited for."""
     from gpu_util import benched_randomness, benched_step
     from zkvm_amd.verifier import BlockVerifier, BulletproofGens
     n_steps, batch, merge = 20, 1024, 10240
-    gens = BulletproofGens(ctx, 256, table_bits=16)
+    gens = BulletproofGens(ctx, 256, table_bits=table_bits)
+    assert gens.points.table_bits() == (14 if table_bits < 0 else table_bits)
     bv = BlockVerifier(ctx, gens, batches_in_flight=5)
     bv.set_merge(merge)
     assert 3 <= bv.lanes() <= 5              # (lanes whose streams would not run beside the others' are not kept)
@@ -739,7 +742,8 @@ def test_benched_arrangement_tickets_merged_into_device_batches_vs_oracle(ctx, o
         gens.close()
 
 
-def test_tickets_from_host_memory_benched_steps_vs_oracle(ctx, oracle):
+@pytest.mark.parametrize("table_bits", [-1, 12])
+def test_tickets_from_host_memory_benched_steps_vs_oracle(ctx, oracle, table_bits):
     """zkgpu_verifier_submit / _submit_many: the benched step sets handed over in HOST memory -- one
     submit_many for the first 20, merged into device batches of 10 240 in pinned staging memory and copied to the lane's
     merge buffers by the verifier's copy stream -- every bit of every ticket against the oracle's verdicts; the caller's
@@ -751,7 +755,8 @@ def test_tickets_from_host_memory_benched_steps_vs_oracle(ctx, oracle):
     from gpu_util import benched_randomness, benched_step, mixed_block
     from zkvm_amd.verifier import BlockVerifier, BulletproofGens
     n_steps, batch, merge = 20, 1024, 10240
-    gens = BulletproofGens(ctx, 256, table_bits=12)
+    gens = BulletproofGens(ctx, 256, table_bits=table_bits)
+    assert gens.points.table_bits() == (14 if table_bits < 0 else table_bits)      # -1: what bench.py's host_memory leg runs on
     bv = BlockVerifier(ctx, gens, batches_in_flight=5)
     bv.set_merge(merge)
     sets, dev = [], []
@@ -814,6 +819,56 @@ def test_tickets_from_host_memory_benched_steps_vs_oracle(ctx, oracle):
         assert bits(bv.wait(t_a), batch) == sets[0][3]
         with pytest.raises(Exception):
             bv.wait(t_a)                                                                   # a ticket is waited for once
+    finally:
+        bv.close()
+        for d in dev:
+            for x in d:
+                ctx.free_device(x)
+        gens.close()
+
+
+@pytest.mark.timeout(420, method="thread")
+def test_host_memory_tickets_waited_for_newest_first_with_more_full_batches_than_lanes(ctx, oracle):
+    """48 tickets of 1024 from host memory at a merge target of 4096 on 4 lanes are 12 full device
+    batches -- more than lanes + 1 -- so that after the submit some FULL batches still stand in the forming list; the
+    tickets are then waited for NEWEST FIRST.  host_dispatch used to return at the first older full batch it could find
+    no lane for and never reached the one waited for: zkgpu_verifier_wait spun for ever holding the verifier's mutex
+    (the timeout of this test is what would report it).  Every bit against the oracle's verdicts; then the same with the
+    waits in a drawn order and device tickets of other steps in between."""
+    import random
+    from gpu_util import benched_randomness, benched_step
+    from zkvm_amd.verifier import BlockVerifier, BulletproofGens
+    n, batch, merge = 48, 1024, 4096
+    gens = BulletproofGens(ctx, 256, table_bits=12)
+    bv = BlockVerifier(ctx, gens, batches_in_flight=4)
+    bv.set_merge(merge)
+    assert bv.lanes() <= 4
+    sets, dev = [], []
+    try:
+        for s in range(n):
+            txs, expected = benched_step(batch, 0, 64, 100 + s)
+            r = benched_randomness(0, 100 + s, batch)
+            n_in, n_out, plen = txs[0][0], txs[0][1], len(txs[0][3])
+            com, proofs = b"".join(t[2] for t in txs), b"".join(t[3] for t in txs)
+            if s % 12 == 0:
+                assert list(oracle.cloak_verify_batch(com, n_in, n_out, proofs, plen, r, threads=16)) == expected, s
+            sets.append((com, proofs, r, expected))
+        tickets = [bv.submit(n_in, n_out, batch, c, p, plen, r) for c, p, r, _ in sets]
+        for k in reversed(range(n)):
+            assert bits(bv.wait(tickets[k]), batch) == sets[k][3], k
+        rng = random.Random(5)
+        tickets = []
+        for k, (c, p, r, _) in enumerate(sets):
+            if k % 5 == 2:
+                d = [ctx.to_device(x) for x in (c, p, r)]
+                dev.append(d)
+                tickets.append(bv.submit_dev(n_in, n_out, batch, d[0], d[1], plen, d[2]))
+            else:
+                tickets.append(bv.submit(n_in, n_out, batch, c, p, plen, r))
+        order = list(range(n))
+        rng.shuffle(order)
+        for k in order:
+            assert bits(bv.wait(tickets[k]), batch) == sets[k][3], k
     finally:
         bv.close()
         for d in dev:

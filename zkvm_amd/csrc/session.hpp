@@ -222,6 +222,30 @@ const char* mock_error_string(ncclResult_t) { return "mock collective error"; }
 // The function table a communicator uses is chosen ONCE, when it is created, and stays with it (zkgpu_comm::api): the
 // switch of the test hook is read under its lock at that moment only, so toggling it later cannot route a live
 // communicator's all-gather or its destruction to the other table.
+bool test_hooks_enabled();
+// Test hook for the bring-up rehearsal (bench.py's bounded communicator bring-up, tests/test_launch.py): with
+// ZKGPU_TEST_HOOKS=1 AND ZKGPU_TEST_COMM_STALL="init:<rank>|init:all|gather:<rank>|gather:all" in the environment when
+// RCCL is first bound, ncclCommInitRank (or the first ncclAllGather) of the named rank never returns -- the failure RCCL
+// shows when one rank of a node cannot reach the others, which a process cannot cancel from inside.  Inert otherwise.
+struct CommStall {
+  int where = 0, rank = -1, my_rank = -1;       // where: 1 init, 2 gather; rank -1: every rank
+  ncclResult_t (*init)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+};
+CommStall g_comm_stall;
+[[noreturn]] void stall_for_ever(const char* what) {
+  fprintf(stderr, "[zkgpu test hook] %s stalls (ZKGPU_TEST_COMM_STALL)\n", what);
+  for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
+}
+ncclResult_t stall_comm_init_rank(ncclComm_t* comm, int world, ncclUniqueId id, int rank) {
+  g_comm_stall.my_rank = rank;
+  if (g_comm_stall.where == 1 && (g_comm_stall.rank < 0 || g_comm_stall.rank == rank)) stall_for_ever("ncclCommInitRank");
+  return g_comm_stall.init(comm, world, id, rank);
+}
+ncclResult_t stall_all_gather(const void* s, void* r, size_t n, ncclDataType_t t, ncclComm_t c, hipStream_t st) {
+  if (g_comm_stall.where == 2 && (g_comm_stall.rank < 0 || g_comm_stall.rank == g_comm_stall.my_rank)) stall_for_ever("ncclAllGather");
+  return g_comm_stall.gather(s, r, n, t, c, st);
+}
 RcclApi& rccl_real() {
   static RcclApi api;
   static std::once_flag once;
@@ -236,7 +260,16 @@ RcclApi& rccl_real() {
     api.AllGather = (decltype(api.AllGather))dlsym(api.handle, "ncclAllGather");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
-    if (!api.ok()) api.error = "RCCL library lacks an expected symbol";
+    if (!api.ok()) { api.error = "RCCL library lacks an expected symbol"; return; }
+    const char* st = test_hooks_enabled() ? getenv("ZKGPU_TEST_COMM_STALL") : nullptr;
+    if (st && (!strncmp(st, "init:", 5) || !strncmp(st, "gather:", 7))) {
+      CommStall& cs = g_comm_stall;
+      cs.where = st[0] == 'i' ? 1 : 2;
+      const char* who = strchr(st, ':') + 1;
+      cs.rank = !strcmp(who, "all") ? -1 : atoi(who);
+      cs.init = api.CommInitRank; cs.gather = api.AllGather;
+      api.CommInitRank = stall_comm_init_rank; api.AllGather = stall_all_gather;
+    }
   });
   return api;
 }
@@ -424,7 +457,16 @@ zkgpu_ctx* zkgpu_verifier_lane(zkgpu_verifier* v, int i) {
   return (v && i >= 0 && i < (int)v->lanes.size()) ? v->lanes[(size_t)i] : nullptr;
 }
 
-const char* zkgpu_verifier_last_error(const zkgpu_verifier* v) { return v ? v->last_error.c_str() : ""; }
+// The text is COPIED under the verifier's mutex into a buffer of the calling thread (valid until that thread asks again):
+// calls on one verifier may come from many threads (the Rust wrapper is Sync), and a pointer into the shared string
+// could be read while another thread's failing call rewrites it.
+const char* zkgpu_verifier_last_error(const zkgpu_verifier* v) {
+  if (!v) return "";
+  static thread_local std::string mine;
+  std::lock_guard<std::mutex> lk(const_cast<zkgpu_verifier*>(v)->mu);
+  mine = v->last_error;
+  return mine.c_str();
+}
 
 uint64_t zkgpu_cloak_msm_terms(uint32_t n_in, uint32_t n_out) { return cloak_msm_terms(n_in, n_out); }
 
@@ -1001,7 +1043,9 @@ int host_launch(zkgpu_verifier* v, zkgpu_host_batch* F, int lane) {
 }
 
 // launches the formed batches that are full, oldest first, while lanes are free; `must`: that one whatever it holds, and
-// if no lane is free the oldest batch in flight is collected first
+// if no lane is free the oldest batch in flight is collected first -- also on behalf of OLDER full batches that stand
+// before `must` in the list (they keep their order and go out first; returning there instead left `must` where it was
+// for ever: a caller that waited for its newest ticket first, with more full batches formed than lanes, never came back)
 int host_dispatch(zkgpu_verifier* v, zkgpu_host_batch* must) {
   for (size_t i = 0; i < v->forming.size();) {
     zkgpu_host_batch* F = v->forming[i].get();
@@ -1009,12 +1053,19 @@ int host_dispatch(zkgpu_verifier* v, zkgpu_host_batch* must) {
     if (!due) { ++i; continue; }
     int lane = free_ticket_lane(v);
     if (lane < 0) {
-      if (F != must) return ZKGPU_OK;    // (full batches keep their order: the next free lane is the oldest one's)
-      if (!v->busy.empty()) collect_oldest(v);
+      if (!must) return ZKGPU_OK;        // (full batches keep their order: the next free lane is the oldest one's)
+      if (v->busy.empty()) {             // (cannot happen with ≥ 1 lane; never spin on it)
+        v->last_error = "host_dispatch: no lane is free and none is busy";
+        for (size_t k = 0; k < v->forming.size(); ++k)
+          if (v->forming[k].get() == must) { host_batch_fail(v, must, ZKGPU_EINVAL); v->forming.erase(v->forming.begin() + (long)k); break; }
+        return ZKGPU_EINVAL;
+      }
+      collect_oldest(v);
       continue;
     }
     std::unique_ptr<zkgpu_host_batch> owned = std::move(v->forming[i]);
     v->forming.erase(v->forming.begin() + (long)i);
+    if (owned.get() == must) must = nullptr;     // (what stands behind it waits for lanes like any other)
     (void)host_launch(v, owned.get(), lane);     // (a failure is recorded in its tickets)
   }
   return ZKGPU_OK;

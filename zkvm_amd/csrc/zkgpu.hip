@@ -133,6 +133,7 @@ struct zkgpu_ctx {
   // multiplications with their offsets / generator indices, the points coming back, the proofs
   Buffer pv_plan, pv_state, pv_in, pv_rows0, pv_rows1, pv_rows2, pv_rows3, pv_lay, pv_pts, pv_com, pv_ab, pv_proofs;
   int prover_mode = 0;             // 0: everything between the multiplications on the device, 1: host threads in lockstep
+  std::vector<zkgpu_ctx*> pv_slices;    // helper contexts (one stream each) on which the slices 1.. of a prover call run (run_sliced)
   std::vector<uint32_t> pv_plan_host;   // the tables pv_plan holds (compared before uploading again)
   size_t pv_lay_batch = 0;              // batch size the scaffolding in pv_lay was built for (0: none)
   Buffer prep_absorb, prep_raw;    // cooperative transcript: absorbed words per segment, raw challenge bytes
@@ -1285,7 +1286,8 @@ int streams_overlap(hipStream_t a, hipStream_t b) {
 
 // aux: a context for the general (one-stream-pair) paths only -- two streams of its own, no light stream, no third one:
 // what the key and signature stages of zkgpu_tx_verify_batch run on beside the verifier's lanes (session.hpp)
-int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out, bool aux = false) {
+// aux: 0 a root or forked context, 1 an auxiliary one (two high-priority streams, no light stream), 2 a prover slice (one stream)
+int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out, int aux = 0) {
   zkgpu_ctx* c = new zkgpu_ctx();
   c->device = device;
   // main stream: the proof-point pipeline, high priority; stream2: the chip-filling generator
@@ -1320,6 +1322,8 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out, bool aux = false)
     c->locate_parts = parent->locate_parts;
     c->tail_mode = parent->tail_mode;
     c->horner_mode = parent->horner_mode;
+  } else if (aux == 2) {
+    ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   } else if (aux) {
     ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
          hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_greatest) == hipSuccess;
@@ -1425,6 +1429,8 @@ int zkgpu_ctx_fork(zkgpu_ctx* parent, zkgpu_ctx** out) {
 
 void zkgpu_destroy(zkgpu_ctx* c) {
   if (!c) return;
+  for (zkgpu_ctx* t : c->pv_slices) zkgpu_destroy(t);
+  c->pv_slices.clear();
   DeviceGuard g(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
@@ -2241,17 +2247,57 @@ int prove_lockstep(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, int hos
   *proof_len = plen;
   return ZKGPU_OK;
 }
-}  // namespace
+// ---- slices: one call, several sub-batches in flight --------------------------------------------------------------------
+// A proof is a serial chain of ~75 launches in which the multiscalar multiplications on the tables (chip-filling) alternate
+// with latency-bound phases -- one workgroup per proof, a Keccak chain or a scalar inversion per proof: 10 - 20 % of the
+// vector ALU's issue rate (profiles/pmc_valu_prover.json against the kernel times).  ONE batch on ONE stream therefore leaves
+// most of the chip idle most of the time.  A call is cut into contiguous SLICES, each proved on a context of its own (one
+// stream, its own workspace; the tables are shared) by a thread of its own: one slice's phases run in the gaps of another's
+// multiplication, and the host share of one slice (blinding factors, witness queues, the upload) beside the device share of
+// another -- what a caller used to have to arrange with two threads and two contexts (bench.py: two_calls_in_flight).
+// Proofs do not depend on the slicing: every proof is a function of its own inputs and seed (tests compare with the oracle).
+int prover_slice_count(size_t batch) {
+  static const int forced = [] { const char* e = getenv("ZKGPU_PROVER_SLICES"); return e ? std::max(1, std::min(8, atoi(e))) : 0; }();
+  if (forced) return (int)std::min<size_t>((size_t)forced, std::max<size_t>(1, batch));
+  return batch >= 1024 ? 2 : 1;          // (the sweep: DESIGN.md sec 4.4)
+}
 
-int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_capacity, size_t batch, uint32_t n_in,
-                            uint32_t n_out, const uint64_t* quantities, const uint8_t* flavors, const uint8_t* seeds,
-                            int host_threads, uint8_t* commitments, uint8_t* proofs, size_t proof_stride,
-                            size_t* proof_len) {
-  if (!c || !ps || !commitments || !proofs || !proof_len) return ZKGPU_EINVAL;
-  *proof_len = 0;
-  if (batch == 0) return ZKGPU_OK;
-  if (!quantities || !flavors || !seeds || ps->n < 2 + 2 * gens_capacity || n_in + n_out == 0) return ZKGPU_EINVAL;
-  if (!ps->table) { c->last_error = "zkgpu_cloak_prove_batch needs zkgpu_pointset_build_tables first"; return ZKGPU_EINVAL; }
+// one(ctx, lo, hi, host_threads) proves statements [lo, hi) on ctx; c->mu is held by the caller
+int run_sliced(zkgpu_ctx* c, size_t batch, int host_threads, const std::function<int(zkgpu_ctx*, size_t, size_t, int)>& one) {
+  int S = prover_slice_count(batch);
+  while ((int)c->pv_slices.size() < S - 1) {
+    zkgpu_ctx* t = nullptr;
+    DeviceGuard g(c->device);
+    if (ctx_create(c->device, nullptr, &t, 2) != ZKGPU_OK) { S = (int)c->pv_slices.size() + 1; break; }   // (fewer slices: still correct)
+    c->pv_slices.push_back(t);
+  }
+  if (S <= 1) return one(c, 0, batch, host_threads);
+  const int ht = std::max(1, (host_threads > 0 ? host_threads : usable_cpus()) / S);
+  std::vector<int> rc((size_t)S, ZKGPU_OK);
+  std::vector<std::thread> th;
+  auto cut = [&](int i) { return batch * (size_t)i / (size_t)S; };
+  for (int i = 1; i < S; ++i) {
+    zkgpu_ctx* t = c->pv_slices[(size_t)i - 1];
+    t->prover_mode = c->prover_mode;
+    t->profiling = c->profiling;
+    th.emplace_back([&, i, t] { rc[(size_t)i] = one(t, cut(i), cut(i + 1), ht); });
+  }
+  rc[0] = one(c, 0, cut(1), ht);
+  for (auto& t : th) t.join();
+  int bad = ZKGPU_OK;
+  for (int i = 1; i < S; ++i) {
+    zkgpu_ctx* t = c->pv_slices[(size_t)i - 1];
+    for (const ProfEntry& e : t->prof) { ProfEntry& mine = c->prof[(size_t)prof_index(c, e.name)]; mine.launches += e.launches; mine.ms += e.ms; }
+    t->prof.clear();
+    if (rc[(size_t)i] != ZKGPU_OK && bad == ZKGPU_OK) { bad = rc[(size_t)i]; c->last_error = t->last_error; }
+  }
+  return rc[0] != ZKGPU_OK ? rc[0] : bad;
+}
+
+int cloak_prove_whole(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_capacity, size_t batch, uint32_t n_in,
+                      uint32_t n_out, const uint64_t* quantities, const uint8_t* flavors, const uint8_t* seeds,
+                      int host_threads, uint8_t* commitments, uint8_t* proofs, size_t proof_stride,
+                      size_t* proof_len) {
   const size_t nv = (size_t)n_in + n_out;
   if (c->prover_mode == 1)
     return prove_lockstep(c, ps, batch, host_threads, [&](size_t i) {
@@ -2293,15 +2339,10 @@ int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_
 
 // Proves `batch` statements of ONE described constraint system (BASELINE.json configs[4]: "R1CS proving for a
 // 1024-constraint program"): the description of zkgpu_r1cs_plan_create plus the witness -- see include/zkgpu.h.
-int zkgpu_r1cs_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, const zkgpu_r1cs_desc* d, const uint32_t* mult_def,
-                           size_t gens_capacity, size_t batch, const uint8_t* values, const uint8_t* blindings,
-                           const uint8_t* given, size_t n_given, const uint8_t* seeds, int host_threads,
-                           uint8_t* commitments, uint8_t* proofs, size_t proof_stride, size_t* proof_len) {
-  if (!c || !ps || !d || !commitments || !proofs || !proof_len) return ZKGPU_EINVAL;
-  *proof_len = 0;
-  if (batch == 0) return ZKGPU_OK;
-  if (!seeds || ps->n < 2 + 2 * gens_capacity || (d->n_commitments && !values) || (n_given && !given)) return ZKGPU_EINVAL;
-  if (!ps->table) { c->last_error = "zkgpu_r1cs_prove_batch needs zkgpu_pointset_build_tables first"; return ZKGPU_EINVAL; }
+int r1cs_prove_whole(zkgpu_ctx* c, const zkgpu_pointset* ps, const zkgpu_r1cs_desc* d, const uint32_t* mult_def,
+                     size_t gens_capacity, size_t batch, const uint8_t* values, const uint8_t* blindings,
+                     const uint8_t* given, size_t n_given, const uint8_t* seeds, int host_threads,
+                     uint8_t* commitments, uint8_t* proofs, size_t proof_stride, size_t* proof_len) {
   R1csDesc desc;
   if (!desc_from_c(c, d, desc)) return ZKGPU_EINVAL;
   try { (void)plan_from_desc(desc); } catch (const std::exception& e) { c->last_error = e.what(); return ZKGPU_EINVAL; }
@@ -2336,6 +2377,60 @@ int zkgpu_r1cs_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, const zkgpu_r
     R1csProver::derive(seeds + 32 * i, "rng", 0, &rs[32 * i], 32);
   });
   return prove_device(c, ps, hp, batch, values, blindings ? blindings : bl.data(), given, rs.data(), commitments, proofs, proof_stride, proof_len);
+}
+}  // namespace
+
+int zkgpu_cloak_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t gens_capacity, size_t batch, uint32_t n_in,
+                            uint32_t n_out, const uint64_t* quantities, const uint8_t* flavors, const uint8_t* seeds,
+                            int host_threads, uint8_t* commitments, uint8_t* proofs, size_t proof_stride,
+                            size_t* proof_len) {
+  if (!c || !ps || !commitments || !proofs || !proof_len) return ZKGPU_EINVAL;
+  *proof_len = 0;
+  if (batch == 0) return ZKGPU_OK;
+  if (!quantities || !flavors || !seeds || ps->n < 2 + 2 * gens_capacity || n_in + n_out == 0) return ZKGPU_EINVAL;
+  if (!ps->table) { c->last_error = "zkgpu_cloak_prove_batch needs zkgpu_pointset_build_tables first"; return ZKGPU_EINVAL; }
+  const size_t nv = (size_t)n_in + n_out;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  if (c->prover_mode == 1)
+    return cloak_prove_whole(c, ps, gens_capacity, batch, n_in, n_out, quantities, flavors, seeds, host_threads, commitments, proofs, proof_stride, proof_len);
+  std::atomic<size_t> len_out{0};
+  const int rc = run_sliced(c, batch, host_threads, [&](zkgpu_ctx* t, size_t lo, size_t hi, int ht) {
+    size_t pl = 0;
+    const int r = cloak_prove_whole(t, ps, gens_capacity, hi - lo, n_in, n_out, quantities + nv * lo, flavors + 32 * nv * lo, seeds + 32 * lo, ht,
+                                    commitments + 64 * nv * lo, proofs + proof_stride * lo, proof_stride, &pl);
+    if (r == ZKGPU_OK) len_out = pl;
+    return r;
+  });
+  if (rc != ZKGPU_OK) { memset(commitments, 0, 64 * nv * batch); memset(proofs, 0, proof_stride * batch); return rc; }
+  *proof_len = len_out;
+  return ZKGPU_OK;
+}
+
+int zkgpu_r1cs_prove_batch(zkgpu_ctx* c, const zkgpu_pointset* ps, const zkgpu_r1cs_desc* d, const uint32_t* mult_def,
+                           size_t gens_capacity, size_t batch, const uint8_t* values, const uint8_t* blindings,
+                           const uint8_t* given, size_t n_given, const uint8_t* seeds, int host_threads,
+                           uint8_t* commitments, uint8_t* proofs, size_t proof_stride, size_t* proof_len) {
+  if (!c || !ps || !d || !commitments || !proofs || !proof_len) return ZKGPU_EINVAL;
+  *proof_len = 0;
+  if (batch == 0) return ZKGPU_OK;
+  if (!seeds || ps->n < 2 + 2 * gens_capacity || (d->n_commitments && !values) || (n_given && !given)) return ZKGPU_EINVAL;
+  if (!ps->table) { c->last_error = "zkgpu_r1cs_prove_batch needs zkgpu_pointset_build_tables first"; return ZKGPU_EINVAL; }
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  if (c->prover_mode == 1)
+    return r1cs_prove_whole(c, ps, d, mult_def, gens_capacity, batch, values, blindings, given, n_given, seeds, host_threads, commitments, proofs, proof_stride, proof_len);
+  const size_t m = d->n_commitments;
+  std::atomic<size_t> len_out{0};
+  const int rc = run_sliced(c, batch, host_threads, [&](zkgpu_ctx* t, size_t lo, size_t hi, int ht) {
+    size_t pl = 0;
+    const int r = r1cs_prove_whole(t, ps, d, mult_def, gens_capacity, hi - lo, values ? values + 32 * m * lo : nullptr,
+                                   blindings ? blindings + 32 * m * lo : nullptr, given ? given + 64 * n_given * lo : nullptr, n_given,
+                                   seeds + 32 * lo, ht, commitments + 32 * m * lo, proofs + proof_stride * lo, proof_stride, &pl);
+    if (r == ZKGPU_OK) len_out = pl;
+    return r;
+  });
+  if (rc != ZKGPU_OK) { memset(commitments, 0, 32 * m * batch); memset(proofs, 0, proof_stride * batch); return rc; }
+  *proof_len = len_out;
+  return ZKGPU_OK;
 }
 
 int zkgpu_decode_check(zkgpu_ctx* c, const uint8_t* points, size_t n, uint8_t* ok) {
