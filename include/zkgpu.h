@@ -41,6 +41,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what this header declares is what it exports */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define ZKGPU_OK 0
 #define ZKGPU_EINVAL (-1)          /* bad argument (null pointer, bad offsets, scalar bit 255 set) */
@@ -103,10 +107,13 @@ size_t zkgpu_pointset_size(const zkgpu_pointset *ps);
  * entry point sum static terms straight out of them: one mixed addition per term and window,
  * no doublings, no sorting.  One-time cost: ~0.2 s at 16 bits and 514 points (50 MB per point),
  * milliseconds at 8-12 bits; results are identical with or without tables.
- * 2 <= window_bits <= 16, or 0: the library chooses -- the widest width, at most 16, whose tables take no more than a quarter
+ * 2 <= window_bits <= 16, or 0: the library chooses the KNEE -- among the widths whose tables take no more than a quarter
  * of the device's memory and whose construction (the tables + 1.7x scratch) fits in 60 % of what is free at the time of the
- * call (zkgpu_choose_table_bits answers the same question without building; zkgpu_pointset_table_bits: the width in use, 0
- * without tables).  Fewer bits cost throughput gently (bench.py, setup.table_bits_sweep: 13 .. 16 bits measured). */
+ * call, the narrowest whose additions per generator term stay within 19/16 of the widest feasible width's: 14 bits for 514
+ * or 1026 points on an MI355X (10.2 GB / 20.4 GB at the 128-byte row stride instead of 34.5 / 68.9 GB at 16 bits, for
+ * 0.5 - 2.5 % of verifier throughput; bench.py, setup.table_bits_sweep).  zkgpu_choose_table_bits answers the same question
+ * without building; zkgpu_pointset_table_bits: the width in use, 0 without tables.  A PROVER gains from the widest tables
+ * (16 bits: +15 %): pass the width explicitly. */
 int zkgpu_pointset_build_tables(zkgpu_ctx *ctx, zkgpu_pointset *ps, int window_bits);
 int zkgpu_choose_table_bits(zkgpu_ctx *ctx, size_t n_points);
 int zkgpu_pointset_table_bits(const zkgpu_pointset *ps);
@@ -259,12 +266,11 @@ int zkgpu_r1cs_prove_batch(zkgpu_ctx *ctx, const zkgpu_pointset *ps, const zkgpu
                            const uint8_t *given, size_t n_given, const uint8_t *seeds, int host_threads,
                            uint8_t *commitments, uint8_t *proofs, size_t proof_stride, size_t *proof_len);
 
-/* Both provers: 0 (default) = the whole proof on the device -- Merlin transcript, TranscriptRng, witness assignment from
- * the described system, constraint flattening, polynomial and inner-product algebra in kernels (one workgroup per
- * proof), the multiscalar multiplications on the tables in between, nothing of a proof in the making on the host;
- * 1 = the same algorithm on host threads in lockstep, only the multiplications and the inner-product folds on the
- * device (the round-1 arrangement, kept for comparison).  Byte-identical proofs. */
-int zkgpu_set_prover_mode(zkgpu_ctx *ctx, int mode);
+/* Both provers run the whole proof on the device -- Merlin transcript, TranscriptRng, witness assignment from the described
+ * system, constraint flattening, polynomial and inner-product algebra in kernels (one workgroup per proof), the multiscalar
+ * multiplications on the tables in between, nothing of a proof in the making on the host; a call of 1024 statements or more
+ * is cut into slices that are in flight together on streams of their own (the phases of one slice in the gaps of another's
+ * multiplications).  The round-1 arrangement (host threads in lockstep) remains behind a hook (zkgpu_hooks.h). */
 
 /* The same with commitments, proofs and verifier randomness already resident in HBM
  * (device pointers; this is what bench.py times as one step). */
@@ -287,74 +293,26 @@ int zkgpu_cloak_verify_batch_gpu_dev(zkgpu_ctx *ctx, const zkgpu_pointset *ps, z
 int zkgpu_ctx_fork(zkgpu_ctx* parent, zkgpu_ctx** out);
 
 /* Group checks for whole proofs (zkgpu_cloak_verify_batch_gpu*, *_submit_dev): the verification
- * equations of `group` transactions are added up under independent random weights (the square of
+ * equations of 16 transactions are added up under independent random weights (the square of
  * each transaction's verifier randomness r) and checked by ONE multiscalar multiplication, in which
- * the generator terms of the whole group collapse into one set of scalars; the transactions of a
- * group that fails are then re-checked one by one.  The accept bitmap is the one of per-transaction
- * verification (a bad transaction passes only with the ~2^-250 probability it already has against
- * r).  1 <= group <= 64; default 16; 1 = every transaction on its own.
+ * the generator terms of the whole group collapse into one set of scalars.  The accept bitmap is the one of
+ * per-transaction verification (a bad transaction passes only with the ~2^-250 probability it already has against r).
  * (Same device as upstream bulletproofs' batched range-proof verification; applies to
- * r1cs::Verifier::verify of many proofs over one BulletproofGens.) */
-int zkgpu_set_group_size(zkgpu_ctx* ctx, int group);
-/* A group that fails is resolved with ONE more multiscalar multiplication when a single transaction is to
+ * r1cs::Verifier::verify of many proofs over one BulletproofGens.)
+ * A group that fails is resolved with ONE more multiscalar multiplication when a single transaction is to
  * blame: with S1 = sum E_t and S2 = sum i_t E_t over the group (i_t = position), the culprit b satisfies
  * S2 = i_b S1; it alone is then checked on its own and the others are accepted iff S1 - E_b is the identity
- * (the group check restricted to them).  Groups with several bad transactions are re-checked one by one as
- * before; transactions known to be bad before the sums are formed (undecodable point, malformed proof) are
+ * (the group check restricted to them).  Groups with several bad transactions are re-checked one by one;
+ * transactions known to be bad before the sums are formed (undecodable point, malformed proof) are
  * left out of their group.  Should a located transaction ever fail to account for its group (~2^-248),
- * zkgpu_verify_wait re-runs the batch ungrouped.  Test hook: zkgpu_debug_force_regroup(ctx, 1) forces that
- * re-run; the call returns the number of re-runs so far.  With *_dev inputs the caller's device buffers must
- * stay valid until zkgpu_verify_wait returns. */
-long long zkgpu_debug_force_regroup(zkgpu_ctx* ctx, int on);
-/* 0 automatic (default: locate from 2048 transactions per batch on -- below that the two extra dependent stages cost
- * more latency than the saved work is worth, and a failed group is simply re-checked transaction by transaction),
- * 1 never locate, 2 always locate, 3 always locate with the locating sums of ALL groups formed beside the group sums (the
- * culprit is then named two dependent launches earlier, for ~3 % more point arithmetic per batch: measured slower, kept for
- * comparison).  Forks inherit the setting. */
-int zkgpu_set_locate_mode(zkgpu_ctx* ctx, int mode);
-/* The Horner chains over the windows of the proof-point sums (the longest dependent chain of a batch): 2 = one chain
- * per GROUP over the summed windows of its transactions, then one per transaction of the groups that failed (a third
- * less point arithmetic, but two chains in a row as soon as one group fails); 1 = one chain per transaction up front;
- * 0 (default) = per group as long as the batch the context family finished last had no failed group, else per
- * transaction.  Same verdicts in every mode.  Forks inherit the setting. */
-int zkgpu_set_horner_mode(zkgpu_ctx* ctx, int mode);
-
-/* Transcript replay of the whole-proof paths: 0 automatic (default: one WAVEFRONT per transaction --
- * Keccak-f with the state spread over the lanes, keccak_coop.hpp -- for batches of up to 1536
- * transactions, where it shortens the batch's dependent chain; one LANE per transaction beyond, where
- * the 17x wave-instructions of the spread form cost more than the shorter chain saves), 1 always one lane, 2 always one wavefront.  Results are
- * identical.  Forks inherit the setting.
- * zkgpu_debug_coop_selftest: test hook -- the cross-lane primitives of the cooperative Keccak on given
- * inputs (in: 3 x 64 words a, b, gather byte addresses; out: 8 x 64 words: row_ror:8(a), row_shr:1(a),
- * row_shl:1(a), permlane16_swap(a, b) -> (a', b'), permlane32_swap(a, b) -> (a', b'), ds_bpermute(addr, a))
- * and Keccak-f[1600] of n_states states (25 u64 each, in place), one wavefront per state. */
-int zkgpu_set_transcript_mode(zkgpu_ctx* ctx, int mode);
-int zkgpu_debug_coop_selftest(zkgpu_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t* states, size_t n_states);
-
-/* Test hook: the arithmetic layers on their own, one lane per element (a, b, out: n x 32 bytes).  op 0 field product,
- * 1 square, 2 inverse, 3 a + b - b + a, 4 x^((p-5)/8)  (GF(2^255-19): 32 little-endian bytes, canonical out);
- * 10 product mod l (canonical Montgomery form), 11 the same in the lazy limb form, 12 a lazy chain
- * (a-b)(a+b) + 16ab - b, 13 / 14 inverse mod l (canonical / windowed lazy), 15 a + b - a  (scalars: canonical words out,
- * inputs reduced mod l). */
-int zkgpu_debug_arith(zkgpu_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
-
-/* Measurement aid: with on != 0 the kernels of a batch run one after another on a single stream
- * (no overlap), so that the profile hooks report each kernel's duration alone on the chip. */
-int zkgpu_set_serial(zkgpu_ctx* ctx, int on);
-
-/* Test hook: intermediate buffers of the last device-side preparation on this context.
- * what = "challenges": per transaction layout[0] slots of 32 B, each x * 2^260 mod l (Montgomery form):
- *          0 y  1 z  2 u  3 x  4 w  5 prod u_j  6 prod u_j^2  7 r  8 t_x  9 t_x_blinding  10 e_blinding
- *          11 a  12 b  13 rho (weight inside a group check; 1 when transactions are checked alone)
- *          14.. the layout[2] second-phase challenges, then the k inner-product challenges u_j, ...
- *        "static_scalars" (layout[4] per transaction: B, B_blinding, G_i, H_i) and "dyn_scalars"
- *        (layout[3]: A_I1 A_O1 S1 A_I2 A_O2 S2 | V | T_1 T_3..T_6 | L | R): canonical 32-byte scalars of
- *        the verification equation MULTIPLIED THROUGH by c' = rho * y^(padded_n - 1) * prod u_j^2 (the
- *        device evaluates the equation in this inversion-free form).
- * Returns bytes copied.  zkgpu_cloak_plan_layout fills layout[0..7] = slots per transaction, challenge
- * slots proper, second-phase challenges, dynamic terms, static terms, k, m, monomials. */
-long long zkgpu_debug_read(zkgpu_ctx* ctx, const char* what, void* out, size_t bytes);
-int zkgpu_cloak_plan_layout(const zkgpu_cloak_plan* plan, uint32_t layout[8]);
+ * zkgpu_verify_wait re-runs the batch ungrouped.  With *_dev inputs the caller's device buffers must
+ * stay valid until zkgpu_verify_wait returns.  Below 2048 transactions per batch a failed group is simply re-checked
+ * transaction by transaction (the two extra dependent stages cost more latency than the saved work is worth).
+ * The transcripts are replayed one WAVEFRONT per transaction (Keccak-f with the state spread over the lanes,
+ * keccak_coop.hpp) for batches of up to 1536 transactions and one LANE per transaction beyond; the Horner chains over the
+ * windows run per GROUP while the batch the context family finished last had no failed group, else per transaction.
+ * None of these choices changes a verdict; the alternatives every sweep has rejected, the group size, and the
+ * device-side unit-test entry points are hooks (zkgpu_hooks.h), not exports. */
 
 /* Plain device memory for callers without a HIP binding of their own: what the *_dev entry points
  * take.  zkgpu_upload is a blocking host-to-device copy. */
@@ -442,9 +400,6 @@ int zkgpu_verifier_lanes(const zkgpu_verifier *v);
  * (0 = unset), out[2] the same late-start flag. */
 int zkgpu_verifier_queue_info(const zkgpu_verifier *v, int out[4]);
 int zkgpu_ctx_queue_info(zkgpu_ctx *ctx, int out[3]);
-/* context of lane i (0 = the one given to zkgpu_verifier_create), for zkgpu_set_group_size and the
- * measurement hooks below; owned by the verifier */
-zkgpu_ctx *zkgpu_verifier_lane(zkgpu_verifier *v, int i);
 const char *zkgpu_verifier_last_error(const zkgpu_verifier *v);
 int zkgpu_verifier_verify(zkgpu_verifier *v, size_t batch, const uint32_t *n_in, const uint32_t *n_out,
                           const uint8_t *commitments, const uint8_t *proofs, const uint64_t *proof_offsets,
@@ -564,13 +519,8 @@ int zkgpu_tx_verify_stats(zkgpu_verifier *v, uint64_t out[2]);
  * a call and its collective; a local fault (the caller's status, a missing bitmap, a failed copy to the device) travels
  * through the gather as that rank's status word.  Arguments that are the same on every rank (the cuts) are checked
  * before it.  Framing: csrc/comm_frame.hpp.  zkgpu_verifier_verify_sharded = cuts + verify own shard + that gather,
- * with the whole block in host memory on every rank.
- * zkgpu_debug_comm_mock: test hook -- world > 0 replaces the collective function table by an in-process mock of a world
- * of `world` ranks whose other ranks contribute peer_slots (world x slot_bytes bytes), so that the exchange step can be
- * exercised at world 2 .. 8 on one GPU; world = 0 restores RCCL.  Returns the all-gathers the mock has served.
- * Refused (ZKGPU_EINVAL) unless ZKGPU_TEST_HOOKS=1 was in the environment when the library was loaded; a communicator
- * keeps the function table it was created with for its whole life, whatever the switch does afterwards. */
-long long zkgpu_debug_comm_mock(zkgpu_ctx *ctx, int world, const uint8_t *peer_slots, size_t slot_bytes);
+ * with the whole block in host memory on every rank.  (The exchange step is exercised at world 2 .. 8 on one GPU through
+ * the hook zkgpu_debug_comm_mock, zkgpu_hooks.h; a communicator keeps the function table it was created with.) */
 #define ZKGPU_COMM_ID_BYTES 128
 typedef struct zkgpu_comm zkgpu_comm;
 uint64_t zkgpu_cloak_msm_terms(uint32_t n_in, uint32_t n_out);
@@ -587,41 +537,23 @@ int zkgpu_verifier_verify_sharded(zkgpu_verifier *v, zkgpu_comm *comm, size_t ba
                                   const uint32_t *n_out, const uint8_t *commitments, const uint8_t *proofs,
                                   const uint64_t *proof_offsets, const uint8_t *r_bytes, uint8_t *accept_bitmap);
 
-/* ---- measurement hooks (used by bench.py; not part of the reference API) ----
+/* ---- hooks ---------------------------------------------------------------------------------------------------
+ * Per-kernel timing, the tuning modes that the sweeps of DESIGN.md have settled, the device-side unit tests of the
+ * arithmetic layers and the mocked collective are NOT exports of this library: they are declared in zkgpu_hooks.h and
+ * reached by name through this one function, which answers only when ZKGPU_TEST_HOOKS=1 was in the environment when
+ * the library was loaded (tests/conftest.py and bench.py set it; a deployed verifier never does) and returns NULL
+ * otherwise -- an integrator cannot link against them, and `nm -D` shows none of them.
  * Environment variables read by the library, none of which changes a result:
  *   ZKGPU_TIMELINE=<file>     with profiling on, every launch as "ctx kernel start_ms end_ms"
  *   ZKGPU_PROVER_TIMING=1     the provers and zkgpu_tx_verify_batch print per-phase host / device times to stderr
- * and GPU_MAX_HW_QUEUES (a HIP runtime variable): zkgpu_init sets it to 24 if it is unset and the
+ *   ZKGPU_PROVER_SLICES=n     slices of a prover call in flight together (default: 2 from 1024 statements on)
+ * and GPU_MAX_HW_QUEUES (a HIP runtime variable): zkgpu_init sets it to 18 if it is unset and the
  * runtime has not started; batches in flight need a hardware queue per context. */
-/* "measure achievable HBM with a copy kernel and report both" -- a streaming copy of `bytes` bytes
- * (16 B per lane, grid-stride), best of `iters` launches by HIP events: *gbytes_per_s = (bytes read + bytes written) / time. */
-int zkgpu_measure_hbm_copy(zkgpu_ctx *ctx, size_t bytes, int iters, double *gbytes_per_s);
-/* When enabled, every kernel launch of this context is bracketed by HIP events
- * on the context's own stream. */
-int zkgpu_profile_enable(zkgpu_ctx *ctx, int on);
-void zkgpu_profile_reset(zkgpu_ctx *ctx);
-/* Number of distinct kernels seen since the last reset. */
-int zkgpu_profile_count(zkgpu_ctx *ctx);
-/* i-th kernel: name (static storage), launches, total milliseconds. */
-int zkgpu_profile_get(zkgpu_ctx *ctx, int i, const char **name, uint64_t *launches, double *total_ms);
-/* Pippenger window width (bits) chosen by the last call, and the number of
- * point additions its bucket-accumulation kernel performed. */
-int zkgpu_last_window_bits(const zkgpu_ctx *ctx);
-uint64_t zkgpu_last_bucket_adds(const zkgpu_ctx *ctx);
-/* Override the window width (0 = automatic). */
-int zkgpu_set_window_bits(zkgpu_ctx *ctx, int w);
-/* Override how many lanes share one (check, window) in the fixed-base kernel (0 = automatic). */
-int zkgpu_set_static_parts(zkgpu_ctx *ctx, int parts);
-/* Lanes per (failed group, window) of the locating multiplication of zkgpu_set_locate_mode (0 = the default, 32:
- * it runs for the failed groups only, on the tail of a batch, so short chains matter more than few partial sums).
- * Forks take the value their parent has when they are made.  Same verdicts whatever the value. */
-int zkgpu_set_locate_parts(zkgpu_ctx *ctx, int parts);
-/* The sums on the tail of a batch checked in groups (the locating multiplication of the failed groups, the individual
- * re-check of the queued transactions): 0 (default) each inside the kernel that consumes it, one workgroup per row
- * (k_locate_fused, k_recheck_fused: two dependent launches fewer per batch); 1: launches of their own, many lanes per
- * row (k_static_accumulate + k_locate_combine / k_static_combine).  Same verdicts either way; a measurement hook. */
-int zkgpu_set_tail_mode(zkgpu_ctx *ctx, int mode);
+const void *zkgpu_hook(const char *name);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

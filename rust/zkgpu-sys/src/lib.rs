@@ -160,27 +160,12 @@ extern "C" {
         seeds: *const u8, host_threads: c_int, commitments: *mut u8, proofs: *mut u8, proof_stride: usize,
         proof_len: *mut usize,
     ) -> c_int;
-    pub fn zkgpu_set_prover_mode(ctx: *mut zkgpu_ctx, mode: c_int) -> c_int;
     pub fn zkgpu_cloak_verify_batch_gpu_dev(
         ctx: *mut zkgpu_ctx, ps: *const zkgpu_pointset, plan: *mut zkgpu_cloak_plan, batch: usize,
         d_commitments: *const c_void, d_proofs: *const c_void, proof_len: usize, d_r: *const c_void,
         accept_bitmap: *mut u8,
     ) -> c_int;
     pub fn zkgpu_ctx_fork(parent: *mut zkgpu_ctx, out: *mut *mut zkgpu_ctx) -> c_int;
-    pub fn zkgpu_set_group_size(ctx: *mut zkgpu_ctx, group: c_int) -> c_int;
-    pub fn zkgpu_debug_force_regroup(ctx: *mut zkgpu_ctx, on: c_int) -> c_longlong;
-    pub fn zkgpu_set_locate_mode(ctx: *mut zkgpu_ctx, mode: c_int) -> c_int;
-    pub fn zkgpu_set_horner_mode(ctx: *mut zkgpu_ctx, mode: c_int) -> c_int;
-    pub fn zkgpu_set_transcript_mode(ctx: *mut zkgpu_ctx, mode: c_int) -> c_int;
-    pub fn zkgpu_debug_coop_selftest(
-        ctx: *mut zkgpu_ctx, in_: *const u32, out: *mut u32, states: *mut u64, n_states: usize,
-    ) -> c_int;
-    pub fn zkgpu_debug_arith(
-        ctx: *mut zkgpu_ctx, op: c_int, a: *const u8, b: *const u8, out: *mut u8, n: usize,
-    ) -> c_int;
-    pub fn zkgpu_set_serial(ctx: *mut zkgpu_ctx, on: c_int) -> c_int;
-    pub fn zkgpu_debug_read(ctx: *mut zkgpu_ctx, what: *const c_char, out: *mut c_void, bytes: usize) -> c_longlong;
-    pub fn zkgpu_cloak_plan_layout(plan: *const zkgpu_cloak_plan, layout: *mut u32) -> c_int;
     pub fn zkgpu_malloc(ctx: *mut zkgpu_ctx, bytes: usize, out: *mut *mut c_void) -> c_int;
     pub fn zkgpu_free(ctx: *mut zkgpu_ctx, d_ptr: *mut c_void) -> c_int;
     pub fn zkgpu_upload(ctx: *mut zkgpu_ctx, d_dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
@@ -221,7 +206,6 @@ extern "C" {
     pub fn zkgpu_verifier_lanes(v: *const zkgpu_verifier) -> c_int;
     pub fn zkgpu_verifier_queue_info(v: *const zkgpu_verifier, out: *mut c_int) -> c_int;
     pub fn zkgpu_ctx_queue_info(ctx: *mut zkgpu_ctx, out: *mut c_int) -> c_int;
-    pub fn zkgpu_verifier_lane(v: *mut zkgpu_verifier, i: c_int) -> *mut zkgpu_ctx;
     pub fn zkgpu_verifier_last_error(v: *const zkgpu_verifier) -> *const c_char;
     pub fn zkgpu_verifier_verify(
         v: *mut zkgpu_verifier, batch: usize, n_in: *const u32, n_out: *const u32, commitments: *const u8,
@@ -272,9 +256,6 @@ extern "C" {
     ) -> c_int;
     pub fn zkgpu_tx_verify_wait(v: *mut zkgpu_verifier, call_id: u64, accept_bitmap: *mut u8, status: *mut u8) -> c_int;
     pub fn zkgpu_tx_verify_stats(v: *mut zkgpu_verifier, out: *mut u64) -> c_int;
-    pub fn zkgpu_debug_comm_mock(
-        ctx: *mut zkgpu_ctx, world: c_int, peer_slots: *const u8, slot_bytes: usize,
-    ) -> c_longlong;
     pub fn zkgpu_cloak_msm_terms(n_in: u32, n_out: u32) -> u64;
     pub fn zkgpu_shard_cuts(batch: usize, n_in: *const u32, n_out: *const u32, world: c_int, cuts: *mut u64) -> c_int;
     pub fn zkgpu_comm_unique_id(id: *mut u8) -> c_int;
@@ -293,17 +274,5 @@ extern "C" {
         commitments: *const u8, proofs: *const u8, proof_offsets: *const u64, r_bytes: *const u8,
         accept_bitmap: *mut u8,
     ) -> c_int;
-    pub fn zkgpu_measure_hbm_copy(ctx: *mut zkgpu_ctx, bytes: usize, iters: c_int, gbytes_per_s: *mut f64) -> c_int;
-    pub fn zkgpu_profile_enable(ctx: *mut zkgpu_ctx, on: c_int) -> c_int;
-    pub fn zkgpu_profile_reset(ctx: *mut zkgpu_ctx);
-    pub fn zkgpu_profile_count(ctx: *mut zkgpu_ctx) -> c_int;
-    pub fn zkgpu_profile_get(
-        ctx: *mut zkgpu_ctx, i: c_int, name: *mut *const c_char, launches: *mut u64, total_ms: *mut f64,
-    ) -> c_int;
-    pub fn zkgpu_last_window_bits(ctx: *const zkgpu_ctx) -> c_int;
-    pub fn zkgpu_last_bucket_adds(ctx: *const zkgpu_ctx) -> u64;
-    pub fn zkgpu_set_window_bits(ctx: *mut zkgpu_ctx, w: c_int) -> c_int;
-    pub fn zkgpu_set_static_parts(ctx: *mut zkgpu_ctx, parts: c_int) -> c_int;
-    pub fn zkgpu_set_locate_parts(ctx: *mut zkgpu_ctx, parts: c_int) -> c_int;
-    pub fn zkgpu_set_tail_mode(ctx: *mut zkgpu_ctx, mode: c_int) -> c_int;
+    pub fn zkgpu_hook(name: *const c_char) -> *const c_void;
 }

@@ -1072,8 +1072,8 @@ def test_described_prover_on_device_equals_oracle_and_verifies(ctx, oracle, kind
                 values[0] += 1 << (param if kind == 1 else 64)           # the bits given are those of the value mod 2^bits
         vals.append(values); givens.append(given); seeds.append(hashlib.sha256(b"dev desc prover %d %d %d" % (kind, param, i)).digest())
     try:
-        for mode in (1, 0):                                     # host threads in lockstep; the whole proof on the device
-            ctx.set_prover_mode(mode)
+        for mode in (1, 0, 16 + 3):                             # host threads in lockstep; the whole proof on the device; the same
+            ctx.set_prover_mode(mode)                           # as three slices in flight on streams of their own (round 5)
             coms, proofs = R1csProver(ctx, gens, desc, mult_def, host_threads=8).prove(vals, givens, seeds)
             for i in range(batch):
                 rc, want_com, want_proof = oracle.gadget_prove(kind, param, vals[i], seeds[i])

@@ -251,8 +251,8 @@ def test_gpu_prover_equals_oracle_prover_and_verifies(ctx, oracle, shape):
         qs.append(q); fs.append(f); seeds.append(hashlib.sha256(b"gpu prover %d" % i).digest())
     qs[5] = list(qs[5]); qs[5][-1] += 1                        # unbalanced: outputs exceed inputs by one
     try:
-        for mode in (1, 0):                                     # host threads in lockstep; the whole proof on the device
-            ctx.set_prover_mode(mode)
+        for mode in (1, 0, 16 + 4):                             # host threads in lockstep; the whole proof on the device; the same
+            ctx.set_prover_mode(mode)                           # cut into four slices in flight (21 statements: 5 + 5 + 5 + 6)
             txs = Prover(ctx, gens, host_threads=8).prove(n_in, n_out, qs, fs, seeds)
             for i in range(batch):
                 rc, want_com, want_proof, _ = oracle.cloak_prove(qs[i], fs[i], n_in, n_out, seeds[i])

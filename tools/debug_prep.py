@@ -1,4 +1,5 @@
 """GPU debug: device-side challenges of the first golden proofs vs the host tape replay."""
+import os as _os; _os.environ.setdefault("ZKGPU_TEST_HOOKS", "1")   # the profile / mode hooks (include/zkgpu_hooks.h) are not exports
 import ctypes as C, os, struct, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

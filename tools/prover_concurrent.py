@@ -1,5 +1,6 @@
 """Device prover with several calls in flight: N host threads, each proving batches on a context of its own
 (forks of one context: shared tables).  usage: python tools/prover_concurrent.py [threads] [batch] [rounds]"""
+import os as _os; _os.environ.setdefault("ZKGPU_TEST_HOOKS", "1")   # the profile / mode hooks (include/zkgpu_hooks.h) are not exports
 import hashlib, os, random, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zkvm_amd import Context

@@ -1,4 +1,5 @@
 """Per-kernel time of one zkgpu_cloak_prove_batch call (device prover), from the library's profile hooks."""
+import os as _os; _os.environ.setdefault("ZKGPU_TEST_HOOKS", "1"); _os.environ.setdefault("ZKGPU_PROVER_SLICES", "1")   # (the counter tables describe UNSLICED launches)   # the profile / mode hooks (include/zkgpu_hooks.h) are not exports
 import hashlib, os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zkvm_amd import Context

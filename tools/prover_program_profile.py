@@ -1,4 +1,5 @@
 """Per-kernel time of one zkgpu_r1cs_prove_batch call on the 1032-constraint program (8 x 64-bit range proofs)."""
+import os as _os; _os.environ.setdefault("ZKGPU_TEST_HOOKS", "1"); _os.environ.setdefault("ZKGPU_PROVER_SLICES", "1")   # (the counter tables describe UNSLICED launches)   # the profile / mode hooks (include/zkgpu_hooks.h) are not exports
 import hashlib, os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("ZKGPU_TEST_HOOKS", "1")   # the profile / mode hooks (include/zkgpu_hooks.h) are not exports
 import time, sys
 sys.path.insert(0, '.')
 from zkvm_amd import Context

@@ -2,6 +2,7 @@
 Every context is profiled (HIP events around each launch, one device-wide clock); prints, per batch of the middle of the
 run, each kernel's start (relative to the batch's first kernel), duration and the gap since the kernel it depends on
 in the same stream finished, plus the totals: sum of durations, sum of gaps, wall time of the batch."""
+import os as _os; _os.environ.setdefault("ZKGPU_TEST_HOOKS", "1")   # the profile / mode hooks (include/zkgpu_hooks.h) are not exports
 import os, sys, collections
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))

@@ -1,5 +1,6 @@
 """Timeline of a burst: two device batches of 10240 transactions submitted together on two contexts (what the bench's
 20-step run is).  ZKGPU_TIMELINE is set here; prints every launch of both batches: start, end (ms since the first)."""
+import os as _os; _os.environ.setdefault("ZKGPU_TEST_HOOKS", "1")   # the profile / mode hooks (include/zkgpu_hooks.h) are not exports
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))

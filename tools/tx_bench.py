@@ -1,5 +1,6 @@
 """zkgpu_tx_verify_batch on the committed 1024 transactions (per-stage times with ZKGPU_PROVER_TIMING=1).
 usage: tx_bench.py [copies of the fixture per call] [block chunk] [tx chunk]"""
+import os as _os; _os.environ.setdefault("ZKGPU_TEST_HOOKS", "1")   # the profile / mode hooks (include/zkgpu_hooks.h) are not exports
 import ctypes as C
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,7 @@
 """One zkgpu_tx_verify_batch call of 8192 DISTINCT transactions (gpu_util.built_transactions, 1 in 64 damaged), six times, with
 the library's per-kernel HIP-event profile of the last call: what tools/profile_bench.sh runs under rocprofv3 for the
 serialized-transaction path (kernel trace + stats, and one SQ_INSTS_VALU pass)."""
+import os as _os; _os.environ.setdefault("ZKGPU_TEST_HOOKS", "1")   # the profile / mode hooks (include/zkgpu_hooks.h) are not exports
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

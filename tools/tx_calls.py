@@ -1,4 +1,5 @@
 """Per-call times of zkgpu_tx_verify_batch on one verifier.  usage: tx_calls.py [copies] [lanes] [second verifier: 0/1]"""
+import os as _os; _os.environ.setdefault("ZKGPU_TEST_HOOKS", "1")   # the profile / mode hooks (include/zkgpu_hooks.h) are not exports
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

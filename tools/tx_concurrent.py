@@ -1,5 +1,6 @@
 """Two zkgpu_tx_verify_batch calls in flight: two host threads, each on a context and a verifier of its own (the host
 stages of one call beside the device stages of the other).  usage: tx_concurrent.py [copies of the 1024 fixture per call] [lanes]"""
+import os as _os; _os.environ.setdefault("ZKGPU_TEST_HOOKS", "1")   # the profile / mode hooks (include/zkgpu_hooks.h) are not exports
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

@@ -1,5 +1,6 @@
 """Calls in flight on one verifier (zkgpu_tx_verify_submit / _wait): throughput by calls in flight and transactions per call.
-usage: tx_inflight.py [per_call=1024] [in_flight=8] [calls=64]      (ZKGPU_TX_ROUNDS=1: one round at a time)"""
+usage: tx_inflight.py [per_call=1024] [in_flight=8] [calls=64] [lanes=0: the default]      (ZKGPU_TX_ROUNDS=1: one round at a time)"""
+import os as _os; _os.environ.setdefault("ZKGPU_TEST_HOOKS", "1")   # the profile / mode hooks (include/zkgpu_hooks.h) are not exports
 import collections, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -13,7 +14,8 @@ n_calls = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 txs, exp = built_transactions(8192, call=1, bad_every=64)
 ctx = Context(0)
 gens = BulletproofGens(ctx, 256, table_bits=14)
-bv = BlockVerifier(ctx, gens)
+lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+bv = BlockVerifier(ctx, gens, batches_in_flight=lanes) if lanes else BlockVerifier(ctx, gens)
 bv.set_tx_format(bv.TXFORMAT_RECOLLECTED_V1)
 for _ in range(bv.lanes()):
     bv.verify_txs(txs[:4096])

@@ -1,5 +1,6 @@
 """Soak of zkgpu_tx_verify_batch: random call sizes and chunk lengths over the committed (valid) transactions, a few of them
 damaged per call (flipped signature bit: must be rejected, everybody else accepted).  usage: tx_soak.py [iterations]"""
+import os as _os; _os.environ.setdefault("ZKGPU_TEST_HOOKS", "1")   # the profile / mode hooks (include/zkgpu_hooks.h) are not exports
 import os, random, struct, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

@@ -1,0 +1,137 @@
+// Micro-benchmark: issue cost of the individual VALU opcodes that the field / scalar / point kernels of this library are
+// made of on gfx950, one opcode per kernel through inline assembly (the compiler cannot substitute another instruction),
+// eight independent chains per lane, WAVES_PER_SIMD wavefronts per SIMD (so that dependent-issue latency is covered and the
+// figure is the ISSUE cost: cycles one SIMD spends per wave-instruction).  Feeds tools/isa_mix.py: histogram of a kernel's
+// opcodes x these costs = the mix-weighted bound of the kernel ("integer-multiply
+// rate; say which binds").
+//
+// Build: hipcc -O3 --offload-arch=gfx950 valu_ops.hip -o valu_ops     Output: one line per opcode, `name cycles`.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { \
+  fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
+
+constexpr int CH = 8;            // independent chains per lane
+
+#define KERNEL32(NAME, ASMTEXT)                                                          \
+  __global__ void NAME(uint32_t* out, uint32_t a0, int iters) {                          \
+    uint32_t x[CH], a = a0 + threadIdx.x, b = a0 * 3 + 1;                                \
+    _Pragma("unroll") for (int j = 0; j < CH; ++j) x[j] = a + j;                         \
+    for (int i = 0; i < iters; ++i) {                                                    \
+      _Pragma("unroll") for (int j = 0; j < CH; ++j)                                     \
+        asm volatile(ASMTEXT : "+v"(x[j]) : "v"(a), "v"(b) : "vcc", "s20");                 \
+    }                                                                                    \
+    uint32_t s = 0;                                                                      \
+    _Pragma("unroll") for (int j = 0; j < CH; ++j) s ^= x[j];                            \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                      \
+  }
+
+#define KERNEL64(NAME, ASMTEXT)                                                          \
+  __global__ void NAME(uint32_t* out, uint32_t a0, int iters) {                          \
+    uint64_t x[CH];                                                                      \
+    uint32_t a = a0 + threadIdx.x, b = a0 * 3 + 1;                                       \
+    uint64_t w = ((uint64_t)a << 32) | b;                                                \
+    _Pragma("unroll") for (int j = 0; j < CH; ++j) x[j] = w + j;                         \
+    for (int i = 0; i < iters; ++i) {                                                    \
+      _Pragma("unroll") for (int j = 0; j < CH; ++j)                                     \
+        asm volatile(ASMTEXT : "+v"(x[j]) : "v"(a), "v"(b), "v"(w) : "vcc", "s20");         \
+    }                                                                                    \
+    uint64_t s = 0;                                                                      \
+    _Pragma("unroll") for (int j = 0; j < CH; ++j) s ^= x[j];                            \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(s ^ (s >> 32));             \
+  }
+
+// 32-bit
+KERNEL32(k_v_add_u32, "v_add_u32 %0, %1, %0")
+KERNEL32(k_v_sub_u32, "v_sub_u32 %0, %0, %1")
+KERNEL32(k_v_and_b32, "v_and_b32 %0, %1, %0")
+KERNEL32(k_v_or_b32, "v_or_b32 %0, %1, %0")
+KERNEL32(k_v_xor_b32, "v_xor_b32 %0, %1, %0")
+KERNEL32(k_v_mov_b32, "v_mov_b32 %0, %1")
+KERNEL32(k_v_lshlrev_b32, "v_lshlrev_b32 %0, 3, %0")
+KERNEL32(k_v_lshrrev_b32, "v_lshrrev_b32 %0, 3, %0")
+KERNEL32(k_v_lshl_add_u32, "v_lshl_add_u32 %0, %0, 3, %1")
+KERNEL32(k_v_add_lshl_u32, "v_add_lshl_u32 %0, %0, %1, 3")
+KERNEL32(k_v_lshl_or_b32, "v_lshl_or_b32 %0, %0, 3, %1")
+KERNEL32(k_v_and_or_b32, "v_and_or_b32 %0, %0, %1, %2")
+KERNEL32(k_v_add3_u32, "v_add3_u32 %0, %0, %1, %2")
+KERNEL32(k_v_alignbit_b32, "v_alignbit_b32 %0, %0, %1, 13")
+KERNEL32(k_v_bfe_u32, "v_bfe_u32 %0, %0, 3, 26")
+KERNEL32(k_v_bfi_b32, "v_bfi_b32 %0, %1, %0, %2")
+KERNEL32(k_v_mul_lo_u32, "v_mul_lo_u32 %0, %0, %1")
+KERNEL32(k_v_mul_hi_u32, "v_mul_hi_u32 %0, %0, %1")
+KERNEL32(k_v_mul_u32_u24, "v_mul_u32_u24 %0, %0, %1")
+KERNEL32(k_v_mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %2")
+KERNEL32(k_v_cndmask_b32, "v_cndmask_b32 %0, %0, %1, vcc")
+KERNEL32(k_v_add_co_u32, "v_add_co_u32 %0, vcc, %0, %1")
+KERNEL32(k_v_addc_co_u32, "v_addc_co_u32 %0, vcc, %0, %1, vcc")
+KERNEL32(k_v_subb_co_u32, "v_subb_co_u32 %0, vcc, %0, %1, vcc")
+KERNEL32(k_v_cmp_lt_u32, "v_cmp_lt_u32 vcc, %0, %1")
+KERNEL32(k_v_mov_b32_dpp_quad, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+KERNEL32(k_v_add_u32_dpp_quad, "v_add_u32_dpp %0, %0, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+KERNEL32(k_v_mov_b32_dpp_row_ror, "v_mov_b32_dpp %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf")
+KERNEL32(k_v_readfirstlane_b32, "v_readfirstlane_b32 s20, %0")
+KERNEL32(k_v_readlane_b32, "v_readlane_b32 s20, %0, 5")
+// 64-bit (register pairs)
+KERNEL64(k_v_lshrrev_b64, "v_lshrrev_b64 %0, 13, %0")
+KERNEL64(k_v_lshlrev_b64, "v_lshlrev_b64 %0, 3, %0")
+KERNEL64(k_v_lshl_add_u64, "v_lshl_add_u64 %0, %0, 1, %3")
+KERNEL64(k_v_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
+KERNEL64(k_v_mad_i64_i32, "v_mad_i64_i32 %0, vcc, %1, %2, %0")
+KERNEL64(k_v_add_f64, "v_add_f64 %0, %0, %3")
+KERNEL64(k_v_fma_f64, "v_fma_f64 %0, %0, %3, %3")
+KERNEL64(k_v_mov_b64, "v_mov_b64 %0, %3")
+KERNEL64(k_v_pk_add_u16_as_pair, "v_pk_mov_b32 %0, %3, %3")
+
+struct Entry { const char* name; void (*fn)(uint32_t*, uint32_t, int); };
+#define E(k) {#k, k}
+
+int main(int argc, char** argv) {
+  const int waves_per_simd = argc > 1 ? atoi(argv[1]) : 4;
+  hipDeviceProp_t p;
+  CK(hipGetDeviceProperties(&p, 0));
+  const int cus = p.multiProcessorCount;
+  const double ghz = p.clockRate * 1e-6;
+  printf("# device: CUs=%d clock=%.3f GHz waves_per_SIMD=%d chains_per_lane=%d\n", cus, ghz, waves_per_simd, CH);
+  printf("# opcode  cycles_per_wave_instruction_per_SIMD  (one SIMD issues one VALU instruction at a time)\n");
+  const int threads = 256, blocks = cus * waves_per_simd;      // 4 waves per block = one per SIMD; blocks per CU = waves per SIMD
+  uint32_t* out = nullptr;
+  CK(hipMalloc(&out, (size_t)blocks * threads * 4));
+  const Entry table[] = {
+    E(k_v_add_u32), E(k_v_sub_u32), E(k_v_and_b32), E(k_v_or_b32), E(k_v_xor_b32), E(k_v_mov_b32), E(k_v_lshlrev_b32), E(k_v_lshrrev_b32),
+    E(k_v_lshl_add_u32), E(k_v_add_lshl_u32), E(k_v_lshl_or_b32), E(k_v_and_or_b32), E(k_v_add3_u32), E(k_v_alignbit_b32), E(k_v_bfe_u32),
+    E(k_v_bfi_b32), E(k_v_mul_lo_u32), E(k_v_mul_hi_u32), E(k_v_mul_u32_u24), E(k_v_mad_u32_u24), E(k_v_cndmask_b32), E(k_v_add_co_u32),
+    E(k_v_addc_co_u32), E(k_v_subb_co_u32), E(k_v_cmp_lt_u32), E(k_v_mov_b32_dpp_quad), E(k_v_add_u32_dpp_quad), E(k_v_mov_b32_dpp_row_ror),
+    E(k_v_readfirstlane_b32), E(k_v_readlane_b32), E(k_v_lshrrev_b64), E(k_v_lshlrev_b64), E(k_v_lshl_add_u64), E(k_v_mad_u64_u32),
+    E(k_v_mad_i64_i32), E(k_v_add_f64), E(k_v_fma_f64), E(k_v_mov_b64), E(k_v_pk_add_u16_as_pair),
+  };
+  hipEvent_t t0, t1;
+  CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+  for (const Entry& e : table) {
+    const char* shown = !strcmp(e.name, "k_v_pk_add_u16_as_pair") ? "v_pk_mov_b32" : e.name + 2;
+    // two lengths, best of five each: the difference is free of launch, ramp and drain
+    const int n1 = 8192, n2 = 40960;
+    float best[2] = {1e30f, 1e30f};
+    hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(threads), 0, 0, out, 7u, 256);      // warm
+    CK(hipDeviceSynchronize());
+    for (int which = 0; which < 2; ++which)
+      for (int rep = 0; rep < 5; ++rep) {
+        CK(hipEventRecord(t0, 0));
+        hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(threads), 0, 0, out, 7u + rep, which ? n2 : n1);
+        CK(hipEventRecord(t1, 0));
+        CK(hipEventSynchronize(t1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, t0, t1));
+        if (ms < best[which]) best[which] = ms;
+      }
+    // wave-instructions per SIMD in the difference = waves_per_simd * (n2 - n1) * CH; cycles = time * clock
+    const double insts_per_simd = (double)waves_per_simd * (n2 - n1) * CH;
+    printf("%-26s %7.3f   (%.3f ms - %.3f ms)\n", shown, (best[1] - best[0]) * 1e-3 * ghz * 1e9 / insts_per_simd, best[1], best[0]);
+  }
+  CK(hipFree(out));
+  return 0;
+}

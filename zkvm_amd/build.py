@@ -9,10 +9,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "zkgpu.hip")
 OUT = os.path.join(HERE, "lib", "libzkgpu.so")
 DEPS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc")))
-        if f.endswith((".hip", ".hpp", ".cpp", ".inc", ".h"))]   # every source: a stale library is a silent wrong answer
+        if f.endswith((".hip", ".hpp", ".cpp", ".inc", ".h", ".map"))]   # every source: a stale library is a silent wrong answer
 HOST_SRC = os.path.join(HERE, "csrc", "hostlib.cpp")
 HOST_OUT = os.path.join(HERE, "lib", "libzkhost.so")
 DEPS.append(os.path.join(HERE, "..", "include", "zkgpu.h"))
+DEPS.append(os.path.join(HERE, "..", "include", "zkgpu_hooks.h"))
 
 
 def stale() -> bool:
@@ -27,7 +28,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
+    # -fvisibility=hidden: the library exports what include/zkgpu.h declares and nothing else (no C++ internals, no hooks)
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
+           "-Wl,--version-script=" + os.path.join(HERE, "csrc", "zkgpu.map"), "-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

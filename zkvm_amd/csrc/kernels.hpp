@@ -1233,16 +1233,12 @@ k_static_digits(const uint32_t* __restrict__ st_scalars, int16_t* __restrict__ d
 // lane (tx, t, part): sum over its share of the tx's static terms of
 // sign(d) * table[t][idx][|d|-1]; the next row is fetched while the current
 // addition runs.  partials[((tx * W + t) * P + part)] (extended).
-// PIPE = 1: the DIGIT (and generator index) of a term is loaded one addition earlier than its row, the row one addition
-// earlier than it is used: the two dependent gathers of a term (digit -> row address -> 96-byte row out of a multi-GB table)
-// each have a whole mixed addition to arrive in, instead of both having to fit into one.
-template <int PIPE>
 __global__ void __launch_bounds__(256)
-k_static_accumulate_t(const int16_t* __restrict__ digits, const uint64_t* __restrict__ st_offsets,
-                      const uint32_t* __restrict__ st_index, const uint32_t* __restrict__ table, uint32_t n_set,
-                      uint32_t H, int W, int P, uint32_t n_msm, uint64_t n_static, uint32_t* __restrict__ partials,
-                      const uint32_t* __restrict__ row_map /*optional: slot -> MSM*/,
-                      const uint32_t* __restrict__ n_active /*optional: slots in use, device side*/) {
+k_static_accumulate(const int16_t* __restrict__ digits, const uint64_t* __restrict__ st_offsets,
+                    const uint32_t* __restrict__ st_index, const uint32_t* __restrict__ table, uint32_t n_set,
+                    uint32_t H, int W, int P, uint32_t n_msm, uint64_t n_static, uint32_t* __restrict__ partials,
+                    const uint32_t* __restrict__ row_map /*optional: slot -> MSM*/,
+                    const uint32_t* __restrict__ n_active /*optional: slots in use, device side*/) {
   const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= (uint64_t)n_msm * W * P) return;
   // window-major lane order: the chip sweeps the table one window slice at a time
@@ -1256,8 +1252,10 @@ k_static_accumulate_t(const int16_t* __restrict__ digits, const uint64_t* __rest
   const uint64_t tbase = (uint64_t)t * n_set;
   ge acc;
   ge_identity(acc);
-  auto row_of = [&](int d, uint32_t idx, ge_niels& q, bool& neg) {
+  auto fetch = [&](uint64_t k, ge_niels& q, bool& neg) {
+    int d = dig[k];
     d = (d == -32768) ? 32768 : d;   // w = 16: +2^15 is stored wrapped (the recoding never yields -2^15)
+    const uint32_t idx = st_index ? st_index[k] : (uint32_t)(k - k0);
     const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
     const uint32_t* row = table + ((tbase + idx) * H + (mag ? mag - 1 : 0)) * TABLE_STRIDE;
     load_table_row(q, row);
@@ -1267,40 +1265,16 @@ k_static_accumulate_t(const int16_t* __restrict__ digits, const uint64_t* __rest
   uint64_t k = k0 + part;
   ge_niels cur, nxt;
   bool cur_neg = false, nxt_neg = false;
-  if constexpr (PIPE == 0) {
-    auto fetch = [&](uint64_t kk, ge_niels& q, bool& neg) { row_of(dig[kk], st_index ? st_index[kk] : (uint32_t)(kk - k0), q, neg); };
-    if (k < k1) fetch(k, cur, cur_neg);
-    while (k < k1) {
-      const uint64_t kn = k + P;
-      if (kn < k1) fetch(kn, nxt, nxt_neg);
-      ge_madd(acc, acc, cur, cur_neg);
-      cur = nxt; cur_neg = nxt_neg;
-      k = kn;
-    }
-  } else {
-    auto digit_of = [&](uint64_t kk, int& d, uint32_t& idx) { d = dig[kk]; idx = st_index ? st_index[kk] : (uint32_t)(kk - k0); };
-    int d1 = 0, d2 = 0;
-    uint32_t i1 = 0, i2 = 0;
-    if (k < k1) { digit_of(k, d1, i1); row_of(d1, i1, cur, cur_neg); }
-    if (k + P < k1) digit_of(k + P, d1, i1);
-    while (k < k1) {
-      const uint64_t kn = k + P, kn2 = kn + P;
-      if (kn2 < k1) digit_of(kn2, d2, i2);                 // two ahead: only its digit
-      if (kn < k1) row_of(d1, i1, nxt, nxt_neg);           // one ahead: its row (the digit arrived during the last addition)
-      ge_madd(acc, acc, cur, cur_neg);
-      cur = nxt; cur_neg = nxt_neg;
-      d1 = d2; i1 = i2;
-      k = kn;
-    }
+  if (k < k1) fetch(k, cur, cur_neg);
+  while (k < k1) {
+    const uint64_t kn = k + P;
+    if (kn < k1) fetch(kn, nxt, nxt_neg);
+    ge_madd(acc, acc, cur, cur_neg);
+    cur = nxt; cur_neg = nxt_neg;
+    k = kn;
   }
   store_ext(partials + (((uint64_t)slot * W + t) * P + part) * EXT_WORDS, acc);
 }
-// which form the library launches: ZKGPU_STATIC_PIPE=0/1 (read once)
-inline bool static_pipe() {
-  static const bool on = [] { const char* e = getenv("ZKGPU_STATIC_PIPE"); return e ? e[0] == '1' : false; }();
-  return on;
-}
-#define k_static_accumulate (zk::static_pipe() ? zk::k_static_accumulate_t<1> : zk::k_static_accumulate_t<0>)
 
 // one wave per tx: sum the W*P static partials and the dynamic-term sum, then
 // the ristretto identity test.  Lane sums are folded with wavefront shuffles.

@@ -944,7 +944,10 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
     }
     bool front_only = false;
     if (rc == ZKGPU_OK && plan) {
-      { std::lock_guard<std::recursive_mutex> lk(L->mu); L->enqueue_phase = zkgpu_ctx::ENQ_FRONT; L->awaiting_back = false; }
+      // a batch that leaves while nothing else is in flight: the chip is idle until its transcript is replayed (experiment:
+      // ZKGPU_IDLE_COOP=1 -> the wavefront form for it whatever its size)
+      const bool idle = v->busy.empty() && total <= IDLE_COOP_MAX;
+      { std::lock_guard<std::recursive_mutex> lk(L->mu); L->enqueue_phase = zkgpu_ctx::ENQ_FRONT; L->awaiting_back = false; L->coop_hint = idle_coop_enabled() && idle; }
       rc = zkgpu_cloak_verify_submit_dev(L, v->ps, plan, total, p_com, p_proofs, head->proof_len, p_r);
       { std::lock_guard<std::recursive_mutex> lk(L->mu); L->enqueue_phase = zkgpu_ctx::ENQ_ALL; front_only = rc == ZKGPU_OK && L->awaiting_back; }
       if (front_only) fronts.push_back(Front{lane, plan, total, head->proof_len, p_com, p_proofs, p_r});
@@ -1026,7 +1029,10 @@ int host_launch(zkgpu_verifier* v, zkgpu_host_batch* F, int lane) {
       else { hs.copying = true; L->dep_event = hs.copied; }
     }
   }
-  if (rc == ZKGPU_OK) rc = zkgpu_cloak_verify_submit_dev(L, v->ps, F->plan, F->total, L->coal_com.p, L->coal_proofs.p, F->proof_len, L->coal_r.p);
+  if (rc == ZKGPU_OK) {
+    { std::lock_guard<std::recursive_mutex> lk(L->mu); L->coop_hint = idle_coop_enabled() && v->busy.empty() && F->total <= IDLE_COOP_MAX; }
+    rc = zkgpu_cloak_verify_submit_dev(L, v->ps, F->plan, F->total, L->coal_com.p, L->coal_proofs.p, F->proof_len, L->coal_r.p);
+  }
   if (rc != ZKGPU_OK) {
     v->last_error = zkgpu_last_error(L);
     { std::lock_guard<std::recursive_mutex> lk(L->mu); L->dep_event = nullptr; }
@@ -1927,6 +1933,24 @@ int zkgpu_tx_verify_stats(zkgpu_verifier* v, uint64_t out[2]) {
   std::lock_guard<std::mutex> lk(v->tx_mu);
   out[0] = v->tx_rounds; out[1] = v->tx_round_calls;
   return ZKGPU_OK;
+}
+
+// ---- hooks (include/zkgpu_hooks.h): by name, and only for a process that asked for them before it loaded the library --------
+const void* zkgpu_hook(const char* name) {
+  if (!name || !test_hooks_enabled()) return nullptr;
+  struct Entry { const char* name; const void* fn; };
+#define ZKGPU_HOOK(f) {#f, (const void*)&f}
+  static const Entry table[] = {
+    ZKGPU_HOOK(zkgpu_set_group_size), ZKGPU_HOOK(zkgpu_set_locate_mode), ZKGPU_HOOK(zkgpu_set_horner_mode), ZKGPU_HOOK(zkgpu_set_transcript_mode),
+    ZKGPU_HOOK(zkgpu_set_static_parts), ZKGPU_HOOK(zkgpu_set_locate_parts), ZKGPU_HOOK(zkgpu_set_tail_mode), ZKGPU_HOOK(zkgpu_set_window_bits),
+    ZKGPU_HOOK(zkgpu_set_prover_mode), ZKGPU_HOOK(zkgpu_set_serial), ZKGPU_HOOK(zkgpu_measure_hbm_copy), ZKGPU_HOOK(zkgpu_profile_enable),
+    ZKGPU_HOOK(zkgpu_profile_reset), ZKGPU_HOOK(zkgpu_profile_count), ZKGPU_HOOK(zkgpu_profile_get), ZKGPU_HOOK(zkgpu_last_window_bits),
+    ZKGPU_HOOK(zkgpu_last_bucket_adds), ZKGPU_HOOK(zkgpu_verifier_lane), ZKGPU_HOOK(zkgpu_debug_arith), ZKGPU_HOOK(zkgpu_debug_coop_selftest),
+    ZKGPU_HOOK(zkgpu_debug_read), ZKGPU_HOOK(zkgpu_cloak_plan_layout), ZKGPU_HOOK(zkgpu_debug_force_regroup), ZKGPU_HOOK(zkgpu_debug_comm_mock),
+  };
+#undef ZKGPU_HOOK
+  for (const Entry& e : table) if (!strcmp(e.name, name)) return e.fn;
+  return nullptr;
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 // MSM (a strictly serial chain that one lane of a GPU runs ~10x slower than a
 // host core) and the final RFC 9496 ENCODE of its result.
 #include "../../include/zkgpu.h"
+#include "../../include/zkgpu_hooks.h"   // (not exported: reached through zkgpu_hook)
 #include "kernels.hpp"
 #include "keccak.hpp"
 
@@ -42,6 +43,13 @@
 using namespace zk;
 
 namespace {
+// experiment (ZKGPU_IDLE_COOP=1): a device batch that leaves while nothing else is in flight replays its transcripts in the
+// wavefront form whatever its size (up to IDLE_COOP_MAX transactions)
+constexpr size_t IDLE_COOP_MAX = 16384;
+inline bool idle_coop_enabled() {
+  static const bool on = [] { const char* e = getenv("ZKGPU_IDLE_COOP"); return e && e[0] == '1'; }();
+  return on;
+}
 
 struct ProfEntry {
   const char* name;
@@ -133,12 +141,15 @@ struct zkgpu_ctx {
   // multiplications with their offsets / generator indices, the points coming back, the proofs
   Buffer pv_plan, pv_state, pv_in, pv_rows0, pv_rows1, pv_rows2, pv_rows3, pv_lay, pv_pts, pv_com, pv_ab, pv_proofs;
   int prover_mode = 0;             // 0: everything between the multiplications on the device, 1: host threads in lockstep
+  int prover_slices = 0;           // 0: by the size of the call (prover_slice_count); test hook: a fixed number of slices
   std::vector<zkgpu_ctx*> pv_slices;    // helper contexts (one stream each) on which the slices 1.. of a prover call run (run_sliced)
   std::vector<uint32_t> pv_plan_host;   // the tables pv_plan holds (compared before uploading again)
   size_t pv_lay_batch = 0;              // batch size the scaffolding in pv_lay was built for (0: none)
   Buffer prep_absorb, prep_raw;    // cooperative transcript: absorbed words per segment, raw challenge bytes
   int locate_mode = 0;             // failed groups: 0 automatic, 1 always re-check every transaction, 2 always locate the culprit
   int transcript_mode = 0;         // 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction
+  bool coop_hint = false;          // set by the verifier for a device batch that leaves while NOTHING else is in flight: its transcript
+                                   // is what the whole (idle) chip waits for, so the wavefront form pays whatever the batch size
   int forced_parts = 0;
   int locate_parts = 0;            // lanes per (failed group, window) of the locating multiplication (0: 32)
   int tail_mode = 0;               // 0: the tail's sums inside k_locate_fused / k_recheck_fused; 1: launches of their own
@@ -905,7 +916,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     HIP_TRY(c, hipEventRecord(c->ev_u, L));
     // one wavefront per transaction while that still leaves the chip room (the cooperative form costs ~9x the
     // wave-instructions of the one-lane form, and buys latency only); beyond that, one lane per transaction
-    const bool coop = prep->n_seg && (c->transcript_mode == 2 || (c->transcript_mode == 0 && B <= COOP_TRANSCRIPT_MAX));
+    const bool coop = prep->n_seg && (c->transcript_mode == 2 || (c->transcript_mode == 0 && (B <= COOP_TRANSCRIPT_MAX || c->coop_hint)));
     if (coop) {
       {
         Launch l(c, "k_tape_gather", L);
@@ -1679,10 +1690,13 @@ int zkgpu_set_serial(zkgpu_ctx* c, int on) {
 
 // The provers (zkgpu_cloak_prove_batch, zkgpu_r1cs_prove_batch): 0 everything between the multiscalar multiplications on
 // the device (prover_kernels.hpp), 1 host threads in lockstep (r1cs_prover.hpp).  Same proofs.
+// mode 0 / 1 as the header says; 16 + S (S = 1 .. 8): the device prover with a call cut into S slices whatever its size
+// (the tests prove nine statements in three slices; by default only calls of 1024 statements or more are sliced)
 int zkgpu_set_prover_mode(zkgpu_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 1) return ZKGPU_EINVAL;
+  if (!c || mode < 0 || (mode > 1 && (mode < 17 || mode > 24))) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
-  c->prover_mode = mode;
+  c->prover_mode = mode > 1 ? 0 : mode;
+  c->prover_slices = mode > 1 ? mode - 16 : 0;
   return ZKGPU_OK;
 }
 
@@ -2256,15 +2270,17 @@ int prove_lockstep(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, int hos
 // multiplication, and the host share of one slice (blinding factors, witness queues, the upload) beside the device share of
 // another -- what a caller used to have to arrange with two threads and two contexts (bench.py: two_calls_in_flight).
 // Proofs do not depend on the slicing: every proof is a function of its own inputs and seed (tests compare with the oracle).
-int prover_slice_count(size_t batch) {
-  static const int forced = [] { const char* e = getenv("ZKGPU_PROVER_SLICES"); return e ? std::max(1, std::min(8, atoi(e))) : 0; }();
+int prover_slice_count(const zkgpu_ctx* c, size_t batch) {
+  static const int env = [] { const char* e = getenv("ZKGPU_PROVER_SLICES"); return e ? std::max(1, std::min(8, atoi(e))) : 0; }();
+  const int forced = c->prover_slices ? c->prover_slices : env;
   if (forced) return (int)std::min<size_t>((size_t)forced, std::max<size_t>(1, batch));
-  return batch >= 1024 ? 2 : 1;          // (the sweep: DESIGN.md sec 4.4)
+  // the sweep (profiles/r05b_prover_sweep_*.jsonl): slices of about a thousand statements
+  return batch >= 4096 ? 4 : batch >= 2048 ? 3 : batch >= 1024 ? 2 : 1;
 }
 
 // one(ctx, lo, hi, host_threads) proves statements [lo, hi) on ctx; c->mu is held by the caller
 int run_sliced(zkgpu_ctx* c, size_t batch, int host_threads, const std::function<int(zkgpu_ctx*, size_t, size_t, int)>& one) {
-  int S = prover_slice_count(batch);
+  int S = prover_slice_count(c, batch);
   while ((int)c->pv_slices.size() < S - 1) {
     zkgpu_ctx* t = nullptr;
     DeviceGuard g(c->device);
@@ -2877,7 +2893,8 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
   TRY(ensure(c, c->prep_dyn_sc, (size_t)B * sh.n_dyn * 32));
   TRY(ensure(c, c->prep_dyn_pt, (size_t)B * sh.n_dyn * 32));
   TRY(ensure(c, c->prep_st_sc, (size_t)B * sh.n_static * 32));
-  if (plan->n_seg && (c->transcript_mode == 2 || (c->transcript_mode == 0 && batch <= COOP_TRANSCRIPT_MAX))) {
+  // (sized also where the hint MAY come: a lane must not allocate when it first meets an idle device)
+  if (plan->n_seg && (c->transcript_mode == 2 || (c->transcript_mode == 0 && (batch <= COOP_TRANSCRIPT_MAX || c->coop_hint || (idle_coop_enabled() && batch <= IDLE_COOP_MAX))))) {
     TRY(ensure(c, c->prep_absorb, (size_t)B * plan->n_seg * 25 * 8));
     TRY(ensure(c, c->prep_raw, (size_t)B * sh.n_ch * 64));
   }

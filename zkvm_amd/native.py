@@ -36,6 +36,51 @@ def lib_path() -> str:
     return os.environ.get("ZKGPU_LIB") or os.path.join(HERE, "lib", "libzkgpu.so")
 
 
+def _bind_hooks(lib) -> None:
+    """include/zkgpu_hooks.h: measurement, tuning and test hooks are NOT exports of the library; `zkgpu_hook(name)` hands out
+    their addresses to a process that had ZKGPU_TEST_HOOKS=1 in its environment when it loaded the library (tests/conftest.py
+    and bench.py set it), NULL to everybody else.  Bound here under their own names, so that `lib.zkgpu_set_...` reads as it
+    would for an export; without the variable the attribute is a function that raises."""
+    vp, sz, u8p = C.c_void_p, C.c_size_t, C.c_char_p
+    lib.zkgpu_hook.restype = C.c_void_p
+    lib.zkgpu_hook.argtypes = [C.c_char_p]
+    table = {
+        "zkgpu_set_group_size": (C.c_int, [vp, C.c_int]),
+        "zkgpu_set_locate_mode": (C.c_int, [vp, C.c_int]),
+        "zkgpu_set_horner_mode": (C.c_int, [vp, C.c_int]),
+        "zkgpu_set_transcript_mode": (C.c_int, [vp, C.c_int]),
+        "zkgpu_set_static_parts": (C.c_int, [vp, C.c_int]),
+        "zkgpu_set_locate_parts": (C.c_int, [vp, C.c_int]),
+        "zkgpu_set_tail_mode": (C.c_int, [vp, C.c_int]),
+        "zkgpu_set_window_bits": (C.c_int, [vp, C.c_int]),
+        "zkgpu_set_prover_mode": (C.c_int, [vp, C.c_int]),
+        "zkgpu_set_serial": (C.c_int, [vp, C.c_int]),
+        "zkgpu_measure_hbm_copy": (C.c_int, [vp, sz, C.c_int, C.POINTER(C.c_double)]),
+        "zkgpu_profile_enable": (C.c_int, [vp, C.c_int]),
+        "zkgpu_profile_reset": (None, [vp]),
+        "zkgpu_profile_count": (C.c_int, [vp]),
+        "zkgpu_profile_get": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+        "zkgpu_last_window_bits": (C.c_int, [vp]),
+        "zkgpu_last_bucket_adds": (C.c_uint64, [vp]),
+        "zkgpu_verifier_lane": (vp, [vp, C.c_int]),
+        "zkgpu_debug_arith": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+        "zkgpu_debug_coop_selftest": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), sz]),
+        "zkgpu_debug_read": (C.c_longlong, [vp, C.c_char_p, vp, sz]),
+        "zkgpu_cloak_plan_layout": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
+        "zkgpu_debug_force_regroup": (C.c_longlong, [vp, C.c_int]),
+        "zkgpu_debug_comm_mock": (C.c_longlong, [vp, C.c_int, u8p, sz]),
+    }
+    for name, (restype, argtypes) in table.items():
+        addr = lib.zkgpu_hook(name.encode())
+        if addr:
+            fn = C.CFUNCTYPE(restype, *argtypes)(addr)
+        else:
+            def fn(*_a, _name=name):
+                raise ZkGpuError(EINVAL, "%s is a hook (include/zkgpu_hooks.h), not an export: set ZKGPU_TEST_HOOKS=1 in the environment "
+                                         "before the library is loaded" % _name)
+        setattr(lib, name, fn)
+
+
 def load_library():
     """Load libzkgpu.so.  Fails loudly when it has not been built."""
     global _LIB
@@ -74,9 +119,6 @@ def load_library():
     lib.zkgpu_cloak_prove_batch.argtypes = [vp, vp, sz, sz, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), u8p, u8p, C.c_int,
                                             u8p, u8p, sz, C.POINTER(sz)]
     lib.zkgpu_msm_ps_batch.argtypes = [vp, vp, sz, u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), u8p]
-    lib.zkgpu_set_static_parts.argtypes = [vp, C.c_int]
-    lib.zkgpu_set_locate_parts.argtypes = [vp, C.c_int]
-    lib.zkgpu_set_tail_mode.argtypes = [vp, C.c_int]
     lib.zkgpu_decode_check.argtypes = [vp, u8p, sz, u8p]
     lib.zkgpu_cloak_verify_batch.argtypes = [vp, vp, sz, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p, u8p,
                                              C.POINTER(C.c_uint64), u8p, u8p, C.c_int]
@@ -87,8 +129,6 @@ def load_library():
     lib.zkgpu_cloak_verify_batch_gpu.argtypes = [vp, vp, vp, sz, u8p, u8p, sz, u8p, u8p]
     lib.zkgpu_cloak_verify_batch_gpu_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, u8p]
     lib.zkgpu_ctx_fork.argtypes = [vp, C.POINTER(vp)]
-    lib.zkgpu_set_group_size.argtypes = [vp, C.c_int]
-    lib.zkgpu_set_serial.argtypes = [vp, C.c_int]
     lib.zkgpu_malloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.zkgpu_free.argtypes = [vp, vp]
     lib.zkgpu_upload.argtypes = [vp, vp, u8p, sz]
@@ -103,15 +143,6 @@ def load_library():
     lib.zkgpu_hash_to_points.argtypes = [vp, u8p, sz, u8p]
     lib.zkgpu_pedersen_gens.argtypes = [vp, u8p, u8p]
     lib.zkgpu_bulletproof_gens.argtypes = [vp, sz, C.c_uint32, u8p, u8p]
-    lib.zkgpu_profile_enable.argtypes = [vp, C.c_int]
-    lib.zkgpu_profile_reset.argtypes = [vp]
-    lib.zkgpu_profile_reset.restype = None
-    lib.zkgpu_profile_count.argtypes = [vp]
-    lib.zkgpu_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
-    lib.zkgpu_last_window_bits.argtypes = [vp]
-    lib.zkgpu_last_bucket_adds.argtypes = [vp]
-    lib.zkgpu_last_bucket_adds.restype = C.c_uint64
-    lib.zkgpu_set_window_bits.argtypes = [vp, C.c_int]
     u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
     lib.zkgpu_verifier_create.argtypes = [vp, vp, sz, C.c_int, C.POINTER(vp)]
     lib.zkgpu_verifier_destroy.argtypes = [vp]
@@ -122,8 +153,6 @@ def load_library():
     lib.zkgpu_verifier_reserve.argtypes = [vp, C.c_uint32, C.c_uint32, sz]
     lib.zkgpu_verifier_submit_dev.argtypes = [vp, C.c_uint32, C.c_uint32, sz, vp, vp, sz, vp, C.POINTER(C.c_uint64)]
     lib.zkgpu_verifier_wait.argtypes = [vp, C.c_uint64, u8p]
-    lib.zkgpu_verifier_lane.argtypes = [vp, C.c_int]
-    lib.zkgpu_verifier_lane.restype = vp
     lib.zkgpu_verifier_last_error.argtypes = [vp]
     lib.zkgpu_verifier_last_error.restype = C.c_char_p
     lib.zkgpu_verifier_verify.argtypes = [vp, sz, u32p, u32p, u8p, u8p, u64p, u8p, u8p]
@@ -158,9 +187,6 @@ def load_library():
     lib.zkgpu_ctx_queue_info.argtypes = [vp, C.POINTER(C.c_int)]
     lib.zkgpu_verifier_set_tx_chunk.argtypes = [vp, sz]
     lib.zkgpu_verifier_set_tx_statements_kept.argtypes = [vp, sz]
-    lib.zkgpu_measure_hbm_copy.argtypes = [vp, sz, C.c_int, C.POINTER(C.c_double)]
-    lib.zkgpu_debug_comm_mock.argtypes = [vp, C.c_int, u8p, sz]
-    lib.zkgpu_debug_comm_mock.restype = C.c_longlong
     lib.zkgpu_verifier_submit_many_dev.argtypes = [vp, C.c_uint32, C.c_uint32, sz, sz, vp, vp, sz, vp, vp]
     lib.zkgpu_verifier_submit.argtypes = [vp, C.c_uint32, C.c_uint32, sz, C.c_char_p, C.c_char_p, sz, C.c_char_p, C.POINTER(C.c_uint64)]
     lib.zkgpu_verifier_submit_many.argtypes = [vp, C.c_uint32, C.c_uint32, sz, sz, vp, vp, sz, vp, vp]
@@ -173,17 +199,7 @@ def load_library():
     lib.zkgpu_r1cs_verify_batch.argtypes = [vp, vp, vp, sz, sz, u8p, u8p, sz, u8p, u8p, C.c_int]
     lib.zkgpu_r1cs_prove_batch.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), sz, sz, u8p, u8p, u8p, sz, u8p, C.c_int, u8p, u8p, sz,
                                            C.POINTER(sz)]
-    lib.zkgpu_set_transcript_mode.argtypes = [vp, C.c_int]
-    lib.zkgpu_set_locate_mode.argtypes = [vp, C.c_int]
-    lib.zkgpu_set_horner_mode.argtypes = [vp, C.c_int]
-    lib.zkgpu_set_prover_mode.argtypes = [vp, C.c_int]
-    lib.zkgpu_debug_arith.argtypes = [vp, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
-    lib.zkgpu_debug_force_regroup.argtypes = [vp, C.c_int]
-    lib.zkgpu_debug_force_regroup.restype = C.c_longlong
-    lib.zkgpu_debug_coop_selftest.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), sz]
-    lib.zkgpu_cloak_plan_layout.argtypes = [vp, C.POINTER(C.c_uint32)]
-    lib.zkgpu_debug_read.argtypes = [vp, C.c_char_p, vp, sz]
-    lib.zkgpu_debug_read.restype = C.c_longlong
+    _bind_hooks(lib)
     _LIB = lib
     return lib
 
@@ -300,7 +316,7 @@ class Context:
         return out.raw
 
     def set_prover_mode(self, mode: int) -> None:
-        """zkgpu_set_prover_mode: 0 the whole proof on the device, 1 host threads in lockstep."""
+        """zkgpu_set_prover_mode: 0 the whole proof on the device, 1 host threads in lockstep, 16 + S: on the device in S slices."""
         self._check(self.lib.zkgpu_set_prover_mode(self.h, mode))
 
     def set_horner_mode(self, mode: int) -> None:
