@@ -210,7 +210,10 @@ def prover_leg_counters(ctx, call, call_s, pmc_name, batch, pmc_batch):
         call()
         ctx.profile(False)
         prof = {k: v for k, v in ctx.profile_read().items() if v[0]}
-        insts = sum(v[0] * tbl[k] for k, v in prof.items() if k in tbl) * batch / pmc_batch
+        if tbl.get("_per_call_valu"):      # every dispatch of the profiled (unsliced) calls summed, per full call of _batch statements
+            insts = tbl["_per_call_valu"] * batch / float(tbl["_batch"])
+        else:
+            insts = sum(v[0] * tbl[k] for k, v in prof.items() if k in tbl) * batch / pmc_batch
         out.update(valu_wave_instructions=int(insts), valu_issue_frac=round(insts / (call_s * VALU_PEAK_GINST * 1e9 / 64), 4),
                    valu_kernels_without_counter=[k for k in prof if k not in tbl] or None, single_slice_kernel_sum_ms=round(sum(v[1] for v in prof.values()), 3),
                    valu_source="profiles/%s.json (SQ_INSTS_VALU per launch of an unsliced call of %d statements x its launches x %d / %d)" % (pmc_name, pmc_batch, batch, pmc_batch))

@@ -107,5 +107,14 @@ for prefix, what in (("pmcprover", "tools/prover_profile.py (2048 cloak proofs p
                     side[k] = int(sum(tail) / len(tail))
                     total += sum(v)
     side["_all_dispatches_valu"] = int(total)
+    # the scripts say how many full calls of how many statements they made (PMC_META): instructions per full call
+    try:
+        import re
+        meta = re.search(r"PMC_META full_calls=(\d+) batch=(\d+)", open(os.path.join(out, "%s_%s_output.txt" % (tag, prefix[3:]))).read())
+        calls, batch = int(meta.group(1)), int(meta.group(2))
+        side["_batch"] = batch
+        side["_per_call_valu"] = int(total / (calls + 8.0 / batch))
+    except Exception:
+        pass
     json.dump(side, open(os.path.join(out, "pmc_valu_%s.json" % prefix[3:]), "w"), indent=1, sort_keys=True)
 print("wrote", sorted(f for f in os.listdir(out) if f.startswith(tag) or f.startswith("pmc_")))

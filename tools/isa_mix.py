@@ -82,6 +82,8 @@ def opcode_key(op, text):
         if "quad_perm" in text:
             return "v_mov_b32_dpp_quad" if base == "v_mov_b32" else "v_add_u32_dpp_quad"
         return "v_mov_b32_dpp_row_ror"
+    if op.startswith("v_cndmask_b32"):          # the mask in VCC costs more than in an SGPR pair (profiles/r05_valu_op_rates.txt)
+        return "v_cndmask_b32_e32_vcc" if (op.endswith("_e32") or text.rstrip().endswith("vcc")) else "v_cndmask_b32_e64_sgpr"
     for suffix in ("_e32", "_e64", "_sdwa"):
         if op.endswith(suffix):
             op = op[: -len(suffix)]

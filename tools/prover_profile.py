@@ -25,3 +25,4 @@ tot = 0.0
 for name, (n, ms) in sorted(ctx.profile_read().items(), key=lambda kv: -kv[1][1]):
     print("%-24s %4d launches %9.3f ms" % (name, n, ms)); tot += ms
 print("sum of kernels %.1f ms" % tot)
+print("PMC_META full_calls=2 batch=%d (plus one call of 8 statements: 0.4 %% of a full call)" % batch)

@@ -87,6 +87,32 @@ KERNEL64(k_v_fma_f64, "v_fma_f64 %0, %0, %3, %3")
 KERNEL64(k_v_mov_b64, "v_mov_b64 %0, %3")
 KERNEL64(k_v_pk_add_u16_as_pair, "v_pk_mov_b32 %0, %3, %3")
 
+// conditional moves, by the forms the compiler emits and the hazards around them (the generic macro's "vcc" clobber makes the
+// compiler put an s_nop between two of them; these kernels clobber nothing)
+#define KERNEL32_NOCLOB(NAME, ASMTEXT)                                                   \
+  __global__ void NAME(uint32_t* out, uint32_t a0, int iters) {                          \
+    uint32_t x[CH], a = a0 + threadIdx.x, b = a0 * 3 + 1;                                \
+    _Pragma("unroll") for (int j = 0; j < CH; ++j) x[j] = a + j;                         \
+    for (int i = 0; i < iters; ++i) {                                                    \
+      _Pragma("unroll") for (int j = 0; j < CH; ++j)                                     \
+        asm volatile(ASMTEXT : "+v"(x[j]) : "v"(a), "v"(b));                             \
+    }                                                                                    \
+    uint32_t s = 0;                                                                      \
+    _Pragma("unroll") for (int j = 0; j < CH; ++j) s ^= x[j];                            \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                      \
+  }
+KERNEL32_NOCLOB(k_v_cndmask_b32_e32_vcc, "v_cndmask_b32_e32 %0, %0, %1, vcc")
+KERNEL32_NOCLOB(k_v_cndmask_b32_e64_sgpr, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]")
+KERNEL32_NOCLOB(k_cmp_then_cndmask_pair, "v_cmp_lt_u32_e64 s[20:21], %0, %1\n\tv_cndmask_b32_e64 %0, %0, %2, s[20:21]")
+KERNEL32_NOCLOB(k_cmp_then_10_cndmask, "v_cmp_lt_u32_e64 s[20:21], %0, %1\n\tv_cndmask_b32_e64 %0, %0, %2, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %2, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %2, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %2, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %2, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]")
+KERNEL32_NOCLOB(k_cmp_vcc_then_cndmask_vcc, "v_cmp_lt_u32_e32 vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %0, %2, vcc")
+KERNEL32_NOCLOB(k_cmp_vcc_then_4_cndmask_vcc, "v_cmp_lt_u32_e32 vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_cndmask_b32_e32 %0, %0, %1, vcc\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_cndmask_b32_e32 %0, %0, %1, vcc")
+KERNEL32_NOCLOB(k_cmp_vcc_nop_cndmask_vcc, "v_cmp_lt_u32_e32 vcc, %0, %1\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %0, %2, vcc")
+KERNEL32_NOCLOB(k_cmp_vcc_only, "v_cmp_lt_u32_e32 vcc, %0, %1")
+KERNEL32_NOCLOB(k_cmp_sgpr_only, "v_cmp_lt_u32_e64 s[20:21], %0, %1")
+KERNEL32_NOCLOB(k_select_by_xor_and_xor, "v_xor_b32 %0, %0, %1\n\tv_and_b32 %0, %0, %2\n\tv_xor_b32 %0, %0, %1")
+KERNEL32_NOCLOB(k_s_nop_0_x1, "s_nop 0")
+
 struct Entry { const char* name; void (*fn)(uint32_t*, uint32_t, int); };
 #define E(k) {#k, k}
 
@@ -108,6 +134,8 @@ int main(int argc, char** argv) {
     E(k_v_addc_co_u32), E(k_v_subb_co_u32), E(k_v_cmp_lt_u32), E(k_v_mov_b32_dpp_quad), E(k_v_add_u32_dpp_quad), E(k_v_mov_b32_dpp_row_ror),
     E(k_v_readfirstlane_b32), E(k_v_readlane_b32), E(k_v_lshrrev_b64), E(k_v_lshlrev_b64), E(k_v_lshl_add_u64), E(k_v_mad_u64_u32),
     E(k_v_mad_i64_i32), E(k_v_add_f64), E(k_v_fma_f64), E(k_v_mov_b64), E(k_v_pk_add_u16_as_pair),
+    E(k_v_cndmask_b32_e32_vcc), E(k_v_cndmask_b32_e64_sgpr), E(k_cmp_then_cndmask_pair), E(k_cmp_then_10_cndmask), E(k_cmp_vcc_then_cndmask_vcc), E(k_cmp_vcc_then_4_cndmask_vcc),
+    E(k_cmp_vcc_nop_cndmask_vcc), E(k_cmp_vcc_only), E(k_cmp_sgpr_only), E(k_select_by_xor_and_xor), E(k_s_nop_0_x1),
   };
   hipEvent_t t0, t1;
   CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));

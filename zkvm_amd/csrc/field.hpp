@@ -34,19 +34,6 @@
 #define ZK_NOUNROLL
 #endif
 
-// (column-serial products: without the fence the optimiser re-associates the sums back into ten zero-based chains + a carry pass)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define ZK_FE_FENCE64(x) asm volatile("" : "+v"(x))
-// acc += a * b with the sum made opaque after every step: the optimiser otherwise re-associates a column's chain so that a part of
-// it starts from zero, and adds the carry with a 64-bit addition of its own.  (An inline-asm v_mad_u64_u32 was tried first and
-// computed WRONG results on the device -- its scalar carry-out operand is written by the vector unit, and the hazard
-// recogniser does not see inside an asm statement; the empty asm below contains no instruction.)
-#define ZK_FE_MAD(acc, a, b) do { (acc) += (uint64_t)(a) * (b); asm("" : "+v"(acc)); } while (0)
-#else
-#define ZK_FE_FENCE64(x) (void)0
-#define ZK_FE_MAD(acc, a, b) (acc) += (uint64_t)(a) * (b)
-#endif
-
 namespace zk {
 
 struct fe {
@@ -123,30 +110,10 @@ ZK_HD void fe_reduce_cols(fe& h, uint64_t t[10]) {
 }
 
 // h = f * g.  100 x (32x32+64->64).
-// Column by column: the carry out of column k is the value the multiply-add chain of column k + 1 STARTS from, so the 64-bit
-// addition of a separate carry pass (v_lshl_add_u64, ten per product) is done by the first multiply-add of every column for
-// free, and one 64-bit accumulator is live instead of ten.
 ZK_HD void fe_mul(fe& h, const fe& f, const fe& g) {
   uint32_t g19[10], f2[10];
   ZK_UNROLL for (int j = 0; j < 10; ++j) g19[j] = 19u * g.v[j];
   ZK_UNROLL for (int i = 0; i < 10; ++i) f2[i] = 2u * f.v[i];
-#ifdef ZK_FE_COLUMN_SERIAL
-  uint64_t acc = 0;
-  ZK_UNROLL for (int k = 0; k < 10; ++k) {
-    ZK_UNROLL for (int i = 0; i < 10; ++i) {
-      const int j = (k - i + 10) % 10;
-      const bool wrap = i + j >= 10;
-      const uint32_t a = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
-      const uint32_t b = wrap ? g19[j] : g.v[j];
-      ZK_FE_MAD(acc, a, b);
-    }
-    if (k & 1) { h.v[k] = (uint32_t)acc & M25; acc >>= 25; }
-    else       { h.v[k] = (uint32_t)acc & M26; acc >>= 26; }
-  }
-  const uint64_t w = (uint64_t)h.v[0] + 19 * acc;   // acc < 2^39
-  h.v[0] = (uint32_t)w & M26;
-  h.v[1] += (uint32_t)(w >> 26);
-#else
   uint64_t t[10];
   ZK_UNROLL for (int k = 0; k < 10; ++k) t[k] = 0;
   ZK_UNROLL for (int i = 0; i < 10; ++i) {
@@ -158,33 +125,12 @@ ZK_HD void fe_mul(fe& h, const fe& f, const fe& g) {
     }
   }
   fe_reduce_cols(h, t);
-#endif
 }
 
 // h = f^2.  55 x (32x32+64->64).
 ZK_HD void fe_sq(fe& h, const fe& f) {
   uint32_t f2[10], f19[10], f38[10];
   ZK_UNROLL for (int i = 0; i < 10; ++i) { f2[i] = 2u * f.v[i]; f19[i] = 19u * f.v[i]; f38[i] = 38u * f.v[i]; }
-#ifdef ZK_FE_COLUMN_SERIAL
-  uint64_t acc = 0;
-  ZK_UNROLL for (int k = 0; k < 10; ++k) {
-    ZK_UNROLL for (int i = 0; i < 10; ++i) {
-      const int j = (k - i + 10) % 10;
-      if (j < i) continue;                        // each unordered pair once
-      const bool wrap = i + j >= 10, both_odd = (i & 1) && (j & 1);
-      uint32_t a, b;
-      if (i == j) { a = (i & 1) ? f2[i] : f.v[i]; b = wrap ? f19[i] : f.v[i]; }
-      else if (wrap) { a = f2[i]; b = both_odd ? f38[j] : f19[j]; }
-      else { a = both_odd ? f2[i] : f.v[i]; b = f2[j]; }
-      ZK_FE_MAD(acc, a, b);
-    }
-    if (k & 1) { h.v[k] = (uint32_t)acc & M25; acc >>= 25; }
-    else       { h.v[k] = (uint32_t)acc & M26; acc >>= 26; }
-  }
-  const uint64_t w = (uint64_t)h.v[0] + 19 * acc;
-  h.v[0] = (uint32_t)w & M26;
-  h.v[1] += (uint32_t)(w >> 26);
-#else
   uint64_t t[10];
   ZK_UNROLL for (int k = 0; k < 10; ++k) t[k] = 0;
   ZK_UNROLL for (int i = 0; i < 10; ++i) {
@@ -208,7 +154,6 @@ ZK_HD void fe_sq(fe& h, const fe& f) {
     }
   }
   fe_reduce_cols(h, t);
-#endif
 }
 
 ZK_HD void fe_sqn(fe& h, const fe& f, int n) {

@@ -944,10 +944,7 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
     }
     bool front_only = false;
     if (rc == ZKGPU_OK && plan) {
-      // a batch that leaves while nothing else is in flight: the chip is idle until its transcript is replayed (experiment:
-      // ZKGPU_IDLE_COOP=1 -> the wavefront form for it whatever its size)
-      const bool idle = v->busy.empty() && total <= IDLE_COOP_MAX;
-      { std::lock_guard<std::recursive_mutex> lk(L->mu); L->enqueue_phase = zkgpu_ctx::ENQ_FRONT; L->awaiting_back = false; L->coop_hint = idle_coop_enabled() && idle; }
+      { std::lock_guard<std::recursive_mutex> lk(L->mu); L->enqueue_phase = zkgpu_ctx::ENQ_FRONT; L->awaiting_back = false; }
       rc = zkgpu_cloak_verify_submit_dev(L, v->ps, plan, total, p_com, p_proofs, head->proof_len, p_r);
       { std::lock_guard<std::recursive_mutex> lk(L->mu); L->enqueue_phase = zkgpu_ctx::ENQ_ALL; front_only = rc == ZKGPU_OK && L->awaiting_back; }
       if (front_only) fronts.push_back(Front{lane, plan, total, head->proof_len, p_com, p_proofs, p_r});
@@ -1029,10 +1026,7 @@ int host_launch(zkgpu_verifier* v, zkgpu_host_batch* F, int lane) {
       else { hs.copying = true; L->dep_event = hs.copied; }
     }
   }
-  if (rc == ZKGPU_OK) {
-    { std::lock_guard<std::recursive_mutex> lk(L->mu); L->coop_hint = idle_coop_enabled() && v->busy.empty() && F->total <= IDLE_COOP_MAX; }
-    rc = zkgpu_cloak_verify_submit_dev(L, v->ps, F->plan, F->total, L->coal_com.p, L->coal_proofs.p, F->proof_len, L->coal_r.p);
-  }
+  if (rc == ZKGPU_OK) rc = zkgpu_cloak_verify_submit_dev(L, v->ps, F->plan, F->total, L->coal_com.p, L->coal_proofs.p, F->proof_len, L->coal_r.p);
   if (rc != ZKGPU_OK) {
     v->last_error = zkgpu_last_error(L);
     { std::lock_guard<std::recursive_mutex> lk(L->mu); L->dep_event = nullptr; }

@@ -43,13 +43,6 @@
 using namespace zk;
 
 namespace {
-// experiment (ZKGPU_IDLE_COOP=1): a device batch that leaves while nothing else is in flight replays its transcripts in the
-// wavefront form whatever its size (up to IDLE_COOP_MAX transactions)
-constexpr size_t IDLE_COOP_MAX = 16384;
-inline bool idle_coop_enabled() {
-  static const bool on = [] { const char* e = getenv("ZKGPU_IDLE_COOP"); return e && e[0] == '1'; }();
-  return on;
-}
 
 struct ProfEntry {
   const char* name;
@@ -148,8 +141,6 @@ struct zkgpu_ctx {
   Buffer prep_absorb, prep_raw;    // cooperative transcript: absorbed words per segment, raw challenge bytes
   int locate_mode = 0;             // failed groups: 0 automatic, 1 always re-check every transaction, 2 always locate the culprit
   int transcript_mode = 0;         // 0 automatic, 1 one lane per transaction, 2 one wavefront per transaction
-  bool coop_hint = false;          // set by the verifier for a device batch that leaves while NOTHING else is in flight: its transcript
-                                   // is what the whole (idle) chip waits for, so the wavefront form pays whatever the batch size
   int forced_parts = 0;
   int locate_parts = 0;            // lanes per (failed group, window) of the locating multiplication (0: 32)
   int tail_mode = 0;               // 0: the tail's sums inside k_locate_fused / k_recheck_fused; 1: launches of their own
@@ -916,7 +907,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     HIP_TRY(c, hipEventRecord(c->ev_u, L));
     // one wavefront per transaction while that still leaves the chip room (the cooperative form costs ~9x the
     // wave-instructions of the one-lane form, and buys latency only); beyond that, one lane per transaction
-    const bool coop = prep->n_seg && (c->transcript_mode == 2 || (c->transcript_mode == 0 && (B <= COOP_TRANSCRIPT_MAX || c->coop_hint)));
+    const bool coop = prep->n_seg && (c->transcript_mode == 2 || (c->transcript_mode == 0 && B <= COOP_TRANSCRIPT_MAX));
     if (coop) {
       {
         Launch l(c, "k_tape_gather", L);
@@ -2893,8 +2884,7 @@ int cloak_verify_gpu_enqueue(zkgpu_ctx* c, const zkgpu_pointset* ps, zkgpu_cloak
   TRY(ensure(c, c->prep_dyn_sc, (size_t)B * sh.n_dyn * 32));
   TRY(ensure(c, c->prep_dyn_pt, (size_t)B * sh.n_dyn * 32));
   TRY(ensure(c, c->prep_st_sc, (size_t)B * sh.n_static * 32));
-  // (sized also where the hint MAY come: a lane must not allocate when it first meets an idle device)
-  if (plan->n_seg && (c->transcript_mode == 2 || (c->transcript_mode == 0 && (batch <= COOP_TRANSCRIPT_MAX || c->coop_hint || (idle_coop_enabled() && batch <= IDLE_COOP_MAX))))) {
+  if (plan->n_seg && (c->transcript_mode == 2 || (c->transcript_mode == 0 && batch <= COOP_TRANSCRIPT_MAX))) {
     TRY(ensure(c, c->prep_absorb, (size_t)B * plan->n_seg * 25 * 8));
     TRY(ensure(c, c->prep_raw, (size_t)B * sh.n_ch * 64));
   }
