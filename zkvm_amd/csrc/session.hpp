@@ -58,10 +58,14 @@ struct zkgpu_verifier {
   std::vector<std::vector<zkgpu_request*>> running;     // per lane: the members of its merged batch in flight
   std::deque<int> busy;                                 // lanes in flight, oldest first
   size_t merge_target = 4096;                           // transactions per merged device batch
-  // host-memory tickets: pinned staging areas (lanes + 2 of them, grow-only) and the device batches being formed in them,
-  // oldest first; a batch that is full waits here for a free lane
-  struct HostStage { void* pin = nullptr; size_t cap = 0; hipEvent_t copied = nullptr; bool taken = false; bool copying = false; };
+  // host-memory tickets: pinned staging areas (2 * lanes + 2 of them, grow-only), each with a TWIN of the same size in HBM,
+  // and the device batches being formed in them, oldest first; a batch that is full waits here for a free lane.  A ticket's
+  // bytes travel to the twin as soon as they are staged (three hipMemcpyAsync per ticket on the copy stream), so that the copy
+  // of a device batch runs beside the staging of its later tickets and a full batch leaves at once; the lane then reads the
+  // twin in place -- the area stays taken until the batch has been collected (`lane_stage`).
+  struct HostStage { void* pin = nullptr; void* dev = nullptr; size_t cap = 0; hipEvent_t copied = nullptr; bool taken = false; };
   std::vector<HostStage> host_stages;
+  std::vector<int> lane_stage;                          // per lane: the staging area whose twin its batch in flight reads, or -1
   std::deque<std::unique_ptr<zkgpu_host_batch>> forming;
   zkgpu_ctx* root = nullptr;
   const zkgpu_pointset* ps = nullptr;
@@ -426,7 +430,7 @@ void zkgpu_verifier_destroy(zkgpu_verifier* v) {
   {
     DeviceGuard g(v->root->device);
     for (auto& a : v->tx_arenas) { if (a.h_pin) (void)hipHostFree(a.h_pin); if (a.dev) (void)hipFree(a.dev); if (a.copied) (void)hipEventDestroy(a.copied); }
-    for (auto& hs : v->host_stages) { if (hs.pin) (void)hipHostFree(hs.pin); if (hs.copied) (void)hipEventDestroy(hs.copied); }
+    for (auto& hs : v->host_stages) { if (hs.pin) (void)hipHostFree(hs.pin); if (hs.dev) (void)hipFree(hs.dev); if (hs.copied) (void)hipEventDestroy(hs.copied); }
     if (v->copy_stream) (void)hipStreamDestroy(v->copy_stream);
   }
   for (auto& kv : v->plans) if (kv.second) zkgpu_cloak_plan_destroy(kv.second);
@@ -806,6 +810,10 @@ void ticket_collect(zkgpu_verifier* v, int lane) {       // v->mu held
   std::vector<uint8_t> big((total + 7) / 8, 0);
   const int rc = zkgpu_verify_wait(v->lanes[(size_t)lane], big.data());
   if (rc != ZKGPU_OK) v->last_error = zkgpu_last_error(v->lanes[(size_t)lane]);
+  if ((size_t)lane < v->lane_stage.size() && v->lane_stage[(size_t)lane] >= 0) {      // a batch formed from host memory: its twin is free
+    v->host_stages[(size_t)v->lane_stage[(size_t)lane]].taken = false;
+    v->lane_stage[(size_t)lane] = -1;
+  }
   for (auto* r : members) {
     r->bits.assign((r->batch + 7) / 8, 0);
     if (rc == ZKGPU_OK)
@@ -979,20 +987,22 @@ int free_ticket_lane(zkgpu_verifier* v) {
 // a staging area nobody forms a batch in; its last copy to the device is waited for (long done in practice).  -1: none
 int host_stage_acquire(zkgpu_verifier* v, size_t bytes, int* rc) {
   *rc = ZKGPU_OK;
-  if (v->host_stages.empty()) v->host_stages.resize(v->lanes.size() + 2);
+  if (v->host_stages.empty()) v->host_stages.resize(2 * v->lanes.size() + 2);     // (one per batch in flight, as many being formed, two spare)
   for (size_t i = 0; i < v->host_stages.size(); ++i) {
     zkgpu_verifier::HostStage& hs = v->host_stages[i];
-    if (hs.taken) continue;
+    if (hs.taken) continue;                // (a free area has no copy in flight: its last batch has been collected)
     DeviceGuard g(v->root->device);
-    if (hs.copying) { (void)hipEventSynchronize(hs.copied); hs.copying = false; }
     if (hs.cap < bytes) {
       if (hs.pin) (void)hipHostFree(hs.pin);
-      hs.pin = nullptr; hs.cap = 0;
+      if (hs.dev) (void)hipFree(hs.dev);
+      hs.pin = hs.dev = nullptr; hs.cap = 0;
       const size_t want = bytes + bytes / 8 + 4096;
-      if (hipHostMalloc(&hs.pin, want, hipHostMallocDefault) != hipSuccess) { v->last_error = "hipHostMalloc (ticket staging)"; *rc = ZKGPU_ENOMEM; return -1; }
+      if (hipHostMalloc(&hs.pin, want, hipHostMallocDefault) != hipSuccess) { hs.pin = nullptr; v->last_error = "hipHostMalloc (ticket staging)"; *rc = ZKGPU_ENOMEM; return -1; }
+      if (hipMalloc(&hs.dev, want) != hipSuccess) { (void)hipHostFree(hs.pin); hs.pin = hs.dev = nullptr; v->last_error = "hipMalloc (ticket staging twin)"; *rc = ZKGPU_ENOMEM; return -1; }
       hs.cap = want;
     }
     if (!hs.copied && hipEventCreateWithFlags(&hs.copied, hipEventDisableTiming) != hipSuccess) { v->last_error = "hipEventCreate (ticket staging)"; *rc = ZKGPU_EHIP; return -1; }
+    if (!v->copy_stream && hipStreamCreateWithFlags(&v->copy_stream, hipStreamNonBlocking) != hipSuccess) { v->last_error = "hipStreamCreate (ticket staging)"; *rc = ZKGPU_EHIP; return -1; }
     hs.taken = true;
     return (int)i;
   }
@@ -1001,36 +1011,24 @@ int host_stage_acquire(zkgpu_verifier* v, size_t bytes, int* rc) {
 
 void host_batch_fail(zkgpu_verifier* v, zkgpu_host_batch* F, int rc) {      // every member done, with rc (OK: all bits zero)
   for (zkgpu_request* r : F->members) { r->state = 2; r->rc = rc; r->form = nullptr; r->bits.assign((r->batch + 7) / 8, 0); }
-  if (F->stage >= 0) v->host_stages[(size_t)F->stage].taken = false;
+  if (F->stage >= 0) {
+    zkgpu_verifier::HostStage& hs = v->host_stages[(size_t)F->stage];
+    if (hs.copied) { DeviceGuard g(v->root->device); (void)hipEventSynchronize(hs.copied); }    // (copies of staged tickets may still be queued)
+    hs.taken = false;
+  }
 }
 
-// the formed batch F -> lane: three copies on the copy stream into the lane's merge buffers, then the batch itself
+// the formed batch F -> lane: its bytes are already on their way to the staging area's twin in HBM (host_submit_one); the lane
+// waits for the last of those copies and reads the twin in place
 int host_launch(zkgpu_verifier* v, zkgpu_host_batch* F, int lane) {
   zkgpu_ctx* L = v->lanes[(size_t)lane];
   zkgpu_verifier::HostStage& hs = v->host_stages[(size_t)F->stage];
-  int rc = ZKGPU_OK;
-  {
-    std::lock_guard<std::recursive_mutex> lk(L->mu);
-    DeviceGuard g(L->device);
-    rc = ensure(L, L->coal_com, F->total * F->wcom);
-    if (rc == ZKGPU_OK) rc = ensure(L, L->coal_proofs, F->total * F->proof_len + 16);
-    if (rc == ZKGPU_OK) rc = ensure(L, L->coal_r, F->total * 64);
-    if (rc == ZKGPU_OK) {
-      const char* h = (const char*)hs.pin;
-      hipError_t e = v->copy_stream ? hipSuccess : hipStreamCreateWithFlags(&v->copy_stream, hipStreamNonBlocking);
-      if (e == hipSuccess) e = hipMemcpyAsync(L->coal_com.p, h, F->total * F->wcom, hipMemcpyHostToDevice, v->copy_stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(L->coal_proofs.p, h + F->o_proofs, F->total * F->proof_len, hipMemcpyHostToDevice, v->copy_stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(L->coal_r.p, h + F->o_r, F->total * 64, hipMemcpyHostToDevice, v->copy_stream);
-      if (e == hipSuccess) e = hipEventRecord(hs.copied, v->copy_stream);
-      if (e != hipSuccess) { L->last_error = std::string("ticket staging copy: ") + hipGetErrorString(e); rc = ZKGPU_EHIP; }
-      else { hs.copying = true; L->dep_event = hs.copied; }
-    }
-  }
-  if (rc == ZKGPU_OK) rc = zkgpu_cloak_verify_submit_dev(L, v->ps, F->plan, F->total, L->coal_com.p, L->coal_proofs.p, F->proof_len, L->coal_r.p);
+  const char* d = (const char*)hs.dev;
+  { std::lock_guard<std::recursive_mutex> lk(L->mu); L->dep_event = hs.copied; }
+  const int rc = zkgpu_cloak_verify_submit_dev(L, v->ps, F->plan, F->total, d, d + F->o_proofs, F->proof_len, d + F->o_r);
   if (rc != ZKGPU_OK) {
     v->last_error = zkgpu_last_error(L);
     { std::lock_guard<std::recursive_mutex> lk(L->mu); L->dep_event = nullptr; }
-    if (hs.copying) { DeviceGuard g(L->device); (void)hipEventSynchronize(hs.copied); hs.copying = false; }
     host_batch_fail(v, F, rc);
     return rc;
   }
@@ -1038,7 +1036,8 @@ int host_launch(zkgpu_verifier* v, zkgpu_host_batch* F, int lane) {
   for (zkgpu_request* r : F->members) { r->bit_off = off; off += r->batch; r->state = 1; r->lane = lane; r->form = nullptr; }
   v->running[(size_t)lane] = F->members;
   v->busy.push_back(lane);
-  hs.taken = false;                      // (its event guards the next use)
+  if (v->lane_stage.size() < v->lanes.size()) v->lane_stage.resize(v->lanes.size(), -1);
+  v->lane_stage[(size_t)lane] = F->stage;         // (the area is free again when this lane's batch has been collected)
   return ZKGPU_OK;
 }
 
@@ -1118,7 +1117,8 @@ int host_submit_one(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, size_t bat
     F = nf.get();
     v->forming.push_back(std::move(nf));
   }
-  char* h = (char*)v->host_stages[(size_t)F->stage].pin;
+  zkgpu_verifier::HostStage& hs = v->host_stages[(size_t)F->stage];
+  char* h = (char*)hs.pin;
   staged_copy(h + F->total * wcom, com, batch * wcom);
   staged_copy(h + F->o_proofs + F->total * proof_len, proofs, batch * proof_len);
   if (r_bytes) {
@@ -1130,6 +1130,21 @@ int host_submit_one(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, size_t bat
     Sponge sp = shake256_sponge();
     sp.absorb(seed, 40);
     sp.squeeze((uint8_t*)h + F->o_r + F->total * 64, batch * 64);
+  }
+  {
+    // this ticket's three pieces -> the twin, now: the copy runs beside the staging of the batch's later tickets
+    DeviceGuard g(v->root->device);
+    char* d = (char*)hs.dev;
+    const size_t a = F->total * wcom, b = F->o_proofs + F->total * proof_len, c = F->o_r + F->total * 64;
+    hipError_t e = hipMemcpyAsync(d + a, h + a, batch * wcom, hipMemcpyHostToDevice, v->copy_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + b, h + b, batch * proof_len, hipMemcpyHostToDevice, v->copy_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + c, h + c, batch * 64, hipMemcpyHostToDevice, v->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(hs.copied, v->copy_stream);
+    if (e != hipSuccess) {
+      v->last_error = std::string("ticket staging copy: ") + hipGetErrorString(e);
+      r->state = 2; r->rc = ZKGPU_EHIP; r->bits.assign((batch + 7) / 8, 0);
+      return ZKGPU_OK;
+    }
   }
   r->form = F;
   F->members.push_back(r);
