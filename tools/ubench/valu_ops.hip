@@ -16,14 +16,17 @@
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
 
 constexpr int CH = 8;            // independent chains per lane
+constexpr int REP = 16;          // the CH statements are repeated REP times per loop iteration: a taken branch costs ~50 cycles, which a
+                                 // lone wavefront cannot hide (with 8 statements per iteration it read 11 cycles per instruction)
 
 #define KERNEL32(NAME, ASMTEXT)                                                          \
   __global__ void NAME(uint32_t* out, uint32_t a0, int iters) {                          \
     uint32_t x[CH], a = a0 + threadIdx.x, b = a0 * 3 + 1;                                \
     _Pragma("unroll") for (int j = 0; j < CH; ++j) x[j] = a + j;                         \
     for (int i = 0; i < iters; ++i) {                                                    \
+      _Pragma("unroll") for (int r = 0; r < REP; ++r)                                    \
       _Pragma("unroll") for (int j = 0; j < CH; ++j)                                     \
-        asm volatile(ASMTEXT : "+v"(x[j]) : "v"(a), "v"(b) : "vcc", "s20");                 \
+        asm volatile(ASMTEXT : "+v"(x[j]) : "v"(a), "v"(b) : "vcc", "s20");              \
     }                                                                                    \
     uint32_t s = 0;                                                                      \
     _Pragma("unroll") for (int j = 0; j < CH; ++j) s ^= x[j];                            \
@@ -37,8 +40,9 @@ constexpr int CH = 8;            // independent chains per lane
     uint64_t w = ((uint64_t)a << 32) | b;                                                \
     _Pragma("unroll") for (int j = 0; j < CH; ++j) x[j] = w + j;                         \
     for (int i = 0; i < iters; ++i) {                                                    \
+      _Pragma("unroll") for (int r = 0; r < REP; ++r)                                    \
       _Pragma("unroll") for (int j = 0; j < CH; ++j)                                     \
-        asm volatile(ASMTEXT : "+v"(x[j]) : "v"(a), "v"(b), "v"(w) : "vcc", "s20");         \
+        asm volatile(ASMTEXT : "+v"(x[j]) : "v"(a), "v"(b), "v"(w) : "vcc", "s20");      \
     }                                                                                    \
     uint64_t s = 0;                                                                      \
     _Pragma("unroll") for (int j = 0; j < CH; ++j) s ^= x[j];                            \
@@ -94,6 +98,7 @@ KERNEL64(k_v_pk_add_u16_as_pair, "v_pk_mov_b32 %0, %3, %3")
     uint32_t x[CH], a = a0 + threadIdx.x, b = a0 * 3 + 1;                                \
     _Pragma("unroll") for (int j = 0; j < CH; ++j) x[j] = a + j;                         \
     for (int i = 0; i < iters; ++i) {                                                    \
+      _Pragma("unroll") for (int r = 0; r < REP; ++r)                                    \
       _Pragma("unroll") for (int j = 0; j < CH; ++j)                                     \
         asm volatile(ASMTEXT : "+v"(x[j]) : "v"(a), "v"(b));                             \
     }                                                                                    \
@@ -142,7 +147,7 @@ int main(int argc, char** argv) {
   for (const Entry& e : table) {
     const char* shown = !strcmp(e.name, "k_v_pk_add_u16_as_pair") ? "v_pk_mov_b32" : e.name + 2;
     // two lengths, best of five each: the difference is free of launch, ramp and drain
-    const int n1 = 8192, n2 = 40960;
+    const int n1 = 512, n2 = 2560;
     float best[2] = {1e30f, 1e30f};
     hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(threads), 0, 0, out, 7u, 256);      // warm
     CK(hipDeviceSynchronize());
@@ -156,8 +161,8 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, t0, t1));
         if (ms < best[which]) best[which] = ms;
       }
-    // wave-instructions per SIMD in the difference = waves_per_simd * (n2 - n1) * CH; cycles = time * clock
-    const double insts_per_simd = (double)waves_per_simd * (n2 - n1) * CH;
+    // wave-instructions per SIMD in the difference = waves_per_simd * (n2 - n1) * CH * REP; cycles = time * clock
+    const double insts_per_simd = (double)waves_per_simd * (n2 - n1) * CH * REP;
     printf("%-26s %7.3f   (%.3f ms - %.3f ms)\n", shown, (best[1] - best[0]) * 1e-3 * ghz * 1e9 / insts_per_simd, best[1], best[0]);
   }
   CK(hipFree(out));
