@@ -83,6 +83,7 @@ v = {"_note": "SQ_INSTS_VALU per launch (wave instructions; x 64 lanes for threa
 v["_units_per_launch"] = units
 v.update({k: int(x) for k, x in sorted(valu.items())})
 json.dump(v, open(os.path.join(out, "pmc_valu.json"), "w"), indent=1, sort_keys=True)
+SETUP_KERNELS = {"k_tbl_multiples", "k_tbl_base", "k_from_uniform", "k_decompress", "k_spin", "__amd_rocclr_copyBuffer", "__amd_rocclr_fillBufferAligned"}
 # the side paths: SQ_INSTS_VALU per launch of every kernel of the prover / the 1032-constraint program / a transaction call
 for prefix, what in (("pmcprover", "tools/prover_profile.py (2048 cloak proofs per call)"),
                      ("pmcproverprog", "tools/prover_program_profile.py (1024 proofs of the 1032-constraint program per call)"),
@@ -98,7 +99,7 @@ for prefix, what in (("pmcprover", "tools/prover_profile.py (2048 cloak proofs p
                      "_per_call = every dispatch of the run summed / the calls the script makes" % (tag, what)}
     with open(os.path.join(out, "%s_%s_SQ_WAVE_CYCLES.txt" % (tag, prefix)), "w") as f:
         f.write("# rocprofv3 --pmc (tools/profile_bench.sh %s), %s; per kernel: counter, dispatches, last value, mean\n" % (tag, what))
-        total = 0.0
+        total = calls_total = 0.0
         for k, cs in agg.items():
             for c, v in sorted(cs.items()):
                 f.write("%-30s %-22s %5d %16.1f %16.1f\n" % (k[:30], c, len(v), v[-1], sum(v) / len(v)))
@@ -106,6 +107,8 @@ for prefix, what in (("pmcprover", "tools/prover_profile.py (2048 cloak proofs p
                     tail = v[-8:] if len(v) >= 8 else v
                     side[k] = int(sum(tail) / len(tail))
                     total += sum(v)
+                    if k not in SETUP_KERNELS:
+                        calls_total += sum(v)
     side["_all_dispatches_valu"] = int(total)
     # the scripts say how many full calls of how many statements they made (PMC_META): instructions per full call
     try:
@@ -113,7 +116,7 @@ for prefix, what in (("pmcprover", "tools/prover_profile.py (2048 cloak proofs p
         meta = re.search(r"PMC_META full_calls=(\d+) batch=(\d+)", open(os.path.join(out, "%s_%s_output.txt" % (tag, prefix[3:]))).read())
         calls, batch = int(meta.group(1)), int(meta.group(2))
         side["_batch"] = batch
-        side["_per_call_valu"] = int(total / (calls + 8.0 / batch))
+        side["_per_call_valu"] = int(calls_total / (calls + 8.0 / batch))      # (without the one-time kernels: tables, generators, probes)
     except Exception:
         pass
     json.dump(side, open(os.path.join(out, "pmc_valu_%s.json" % prefix[3:]), "w"), indent=1, sort_keys=True)

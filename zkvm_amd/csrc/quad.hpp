@@ -37,28 +37,46 @@ __device__ __forceinline__ void fe_select4(fe& out, int r, const fe& a0, const f
   }
 }
 
+// out = pick ? b : a
+__device__ __forceinline__ void fe_select2(fe& out, bool pick, const fe& a, const fe& b) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) out.v[i] = pick ? b.v[i] : a.v[i];
+}
+
+// h = f - g + 4p, NOT carried: for a value that is only ever the FIRST operand of a product (fe_mul doubles and multiplies
+// its first operand by small constants only where the 19-fold lands on the second).  f tight, g < 2^27 (a sum of two tight
+// values): limbs < 2^26 + 2^28 (even) / 2^25 + 2^27 (odd), never negative.
+__device__ __forceinline__ void fe_sub4_loose(fe& h, const fe& f, const fe& g) {
+  h.v[0] = f.v[0] + 4 * (M26 - 18) - g.v[0];
+#pragma unroll
+  for (int i = 1; i < 10; ++i) h.v[i] = f.v[i] + 4 * ((i & 1) ? M25 : M26) - g.v[i];
+}
+
 // p <- 2p, all four lanes of the quad hold (and receive) the same point.  r = lane & 3.
+// Between the two stages only what becomes a SECOND operand of a product (F, -(A+B)) is carried; E and G are first operands
+// only (X3 = E F, Y3 = G H', Z3 = G F, T3 = E H'), and stay as the sums they are.  Bounds: first operand < 1.25 * 2^28 (even
+// limbs) / 2^27 (odd), second tight: a column of fe_mul is at most 5 * 19 * 2^54.4 + 5 * 19 * 2^53.4 < 2^61.5 (r05: three
+// carry passes and forty conditional moves fewer per doubling than the form that carried E, G and A+B and chose among four).
 __device__ __forceinline__ void quad_double(ge& p, int r) {
   fe in, xy, v;
   fe_add(xy, p.X, p.Y);                       // loose
   fe_select4(in, r, p.X, p.Y, p.Z, xy);
   fe_sq(v, in);                               // lane r: X^2, Y^2, Z^2, (X+Y)^2
-  fe A, B, C, t, E, F, G, H;
+  fe A, B, C, t, E, F, G, Hs, Hn;
   quad_bcast_fe<0>(A, v);
   quad_bcast_fe<1>(B, v);
   quad_bcast_fe<2>(C, v);
   quad_bcast_fe<3>(t, v);
   fe_add(C, C, C);                            // 2 Z^2 (loose)
-  fe_add(H, A, B);                            // loose
-  fe_sub_c(E, t, H);                          // (X+Y)^2 - A - B
-  fe_sub(G, B, A);
-  fe_carry(G);
-  fe_sub_c(F, G, C);
-  fe_carry(H);
-  fe_neg(H, H);                               // -(A+B)
+  fe_add(Hs, A, B);                           // loose
+  fe_sub4_loose(E, t, Hs);                    // (X+Y)^2 - A - B, not carried
+  fe_sub(G, B, A);                            // B - A + 2p, not carried
+  fe_sub_c(F, G, C);                          // G - 2 Z^2, carried
+  const fe zero = fe_zero();
+  fe_sub_c(Hn, zero, Hs);                     // -(A+B), carried
   fe a, b, m;
-  fe_select4(a, r, E, G, F, E);               // X3 = E F, Y3 = G H, Z3 = F G, T3 = E H
-  fe_select4(b, r, F, H, G, H);
+  fe_select2(a, r == 1 || r == 2, E, G);      // X3 = E F, Y3 = G H', Z3 = G F, T3 = E H'
+  fe_select2(b, (r & 1) != 0, F, Hn);
   fe_mul(m, a, b);
   quad_bcast_fe<0>(p.X, m);
   quad_bcast_fe<1>(p.Y, m);
@@ -87,8 +105,8 @@ __device__ __forceinline__ void quad_add(ge& p, const ge& q, int r) {
   fe_add(H, B, A);
   fe_sub_c(F, D, C);
   fe_add(G, D, C);
-  fe_select4(a, r, E, G, F, E);
-  fe_select4(b, r, F, H, G, H);
+  fe_select2(a, r == 1 || r == 2, E, G);      // X3 = E F, Y3 = G H, Z3 = G F, T3 = E H: G (loose) is a first operand only
+  fe_select2(b, (r & 1) != 0, F, H);
   fe_mul(m, a, b);
   quad_bcast_fe<0>(p.X, m);
   quad_bcast_fe<1>(p.Y, m);

@@ -988,6 +988,21 @@ int free_ticket_lane(zkgpu_verifier* v) {
 int host_stage_acquire(zkgpu_verifier* v, size_t bytes, int* rc) {
   *rc = ZKGPU_OK;
   if (v->host_stages.empty()) v->host_stages.resize(2 * v->lanes.size() + 2);     // (one per batch in flight, as many being formed, two spare)
+  // Every FREE area is brought to the size asked for, not only the one handed out: areas stay taken while their batch is in
+  // flight, so which area a batch gets depends on timing, and an area met for the first time in the middle of a burst would
+  // cost a hipHostMalloc + hipMalloc there (both synchronise the device: one bench run in three lost half its rate to it).
+  for (size_t i = 0; i < v->host_stages.size(); ++i) {
+    zkgpu_verifier::HostStage& hs = v->host_stages[i];
+    if (hs.taken || hs.cap >= bytes) continue;
+    DeviceGuard g(v->root->device);
+    if (hs.pin) (void)hipHostFree(hs.pin);
+    if (hs.dev) (void)hipFree(hs.dev);
+    hs.pin = hs.dev = nullptr; hs.cap = 0;
+    const size_t want = bytes + bytes / 8 + 4096;
+    if (hipHostMalloc(&hs.pin, want, hipHostMallocDefault) != hipSuccess) { hs.pin = nullptr; continue; }     // (tried again when it is handed out)
+    if (hipMalloc(&hs.dev, want) != hipSuccess) { (void)hipHostFree(hs.pin); hs.pin = hs.dev = nullptr; continue; }
+    hs.cap = want;
+  }
   for (size_t i = 0; i < v->host_stages.size(); ++i) {
     zkgpu_verifier::HostStage& hs = v->host_stages[i];
     if (hs.taken) continue;                // (a free area has no copy in flight: its last batch has been collected)
