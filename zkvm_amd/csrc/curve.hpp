@@ -94,16 +94,18 @@ ZK_HD void ge_double(ge& r, const ge& p) {
   fe_add(C, C, C);            // loose
   fe_add(t, p.X, p.Y);
   fe_sq(t, t);
-  fe_add(H, A, B);            // loose: A + B
-  fe_sub_c(E, t, H);          // E = (X+Y)^2 - A - B
-  fe_sub(G, B, A);            // G = B - A        (loose)
-  fe_carry(G);
-  fe_sub_c(F, G, C);          // F = G - C
-  fe_carry(H);
-  fe_neg(H, H);               // H = -(A + B)
+  // Only what becomes the SECOND operand of a product (F, -(A+B)) is carried: fe_mul multiplies its second operand by 19 and
+  // needs it below 2^27.7; its first operand may be as loose as 1.25 * 2^28 (a column then stays below 2^61.5).  E and G are
+  // first operands only (round 5: three carry passes fewer per doubling; the same form as quad.hpp's quad_double).
+  fe_add(H, A, B);            // loose: A + B < 2^27
+  fe_sub4_loose(E, t, H);     // E = (X+Y)^2 - A - B + 4p, not carried
+  fe_sub(G, B, A);            // G = B - A + 2p, not carried
+  fe_sub_c(F, G, C);          // F = G - C, carried
+  const fe zero = fe_zero();
+  fe_sub_c(H, zero, H);       // H = -(A + B), carried
   fe_mul(r.X, E, F);
   fe_mul(r.Y, G, H);
-  fe_mul(r.Z, F, G);
+  fe_mul(r.Z, G, F);
   if (NEED_T) fe_mul(r.T, E, H);
 }
 

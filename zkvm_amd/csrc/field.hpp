@@ -84,6 +84,13 @@ ZK_HD void fe_sub_c(fe& h, const fe& f, const fe& g) {
   fe_carry(h);
 }
 
+// h = f - g + 4p, NOT carried: for a value that is only ever the FIRST operand of a product.  f tight, g < 2^27 (a sum of two
+// tight values): limbs < 2^26 + 2^28 (even) / 2^25 + 2^27 (odd), never negative.
+ZK_HD void fe_sub4_loose(fe& h, const fe& f, const fe& g) {
+  h.v[0] = f.v[0] + 4 * (M26 - 18) - g.v[0];
+  ZK_UNROLL for (int i = 1; i < 10; ++i) h.v[i] = f.v[i] + 4 * ((i & 1) ? M25 : M26) - g.v[i];
+}
+
 ZK_HD void fe_add_c(fe& h, const fe& f, const fe& g) {
   fe_add(h, f, g);
   fe_carry(h);

@@ -43,15 +43,6 @@ __device__ __forceinline__ void fe_select2(fe& out, bool pick, const fe& a, cons
   for (int i = 0; i < 10; ++i) out.v[i] = pick ? b.v[i] : a.v[i];
 }
 
-// h = f - g + 4p, NOT carried: for a value that is only ever the FIRST operand of a product (fe_mul doubles and multiplies
-// its first operand by small constants only where the 19-fold lands on the second).  f tight, g < 2^27 (a sum of two tight
-// values): limbs < 2^26 + 2^28 (even) / 2^25 + 2^27 (odd), never negative.
-__device__ __forceinline__ void fe_sub4_loose(fe& h, const fe& f, const fe& g) {
-  h.v[0] = f.v[0] + 4 * (M26 - 18) - g.v[0];
-#pragma unroll
-  for (int i = 1; i < 10; ++i) h.v[i] = f.v[i] + 4 * ((i & 1) ? M25 : M26) - g.v[i];
-}
-
 // p <- 2p, all four lanes of the quad hold (and receive) the same point.  r = lane & 3.
 // Between the two stages only what becomes a SECOND operand of a product (F, -(A+B)) is carried; E and G are first operands
 // only (X3 = E F, Y3 = G H', Z3 = G F, T3 = E H'), and stay as the sums they are.  Bounds: first operand < 1.25 * 2^28 (even
