@@ -299,7 +299,8 @@ def roofline_object(solo, launches_per_step, in_flight_ms, alg_bytes_step, units
                         if (traffic_tbl or {}).get(dom) else None),
             "algorithmic_bytes_per_launch": int(alg_per_launch),
             "units_per_launch": round(units_step / max(launches_per_step.get(dom, 1.0), 1e-9), 1),
-            "avg_launch_ms": round(solo[dom], 4), "launches_per_step": round(launches_per_step.get(dom, 1.0), 2),
+            "avg_launch_ms": round(solo[dom], 4), "launches_per_device_batch": round(launches_per_step.get(dom, 1.0), 2),
+            "launches_per_1024_tx_step": round(launches_per_step.get(dom, 1.0) * 1024.0 / max(units_step, 1), 3),
             "avg_launch_ms_in_flight": round(in_flight_ms[dom], 4) if dom in in_flight_ms else None,
             "dominant_by": "largest summed solo duration per step (HIP events around each kernel alone on the chip, same "
                            "process, after the timed region; `bench.py --solo` under rocprofv3 --stats gives the same averages)",
