@@ -80,7 +80,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 L = 2**252 + 27742317777372353535851937790883648493
 SEED = 0x5A6B564D  # "ZkVM"
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s spec
-MAD_PEAK_GOPS = 1024 * 64 * 2.4 / 4.247      # v_mad_u64_u32: 4.25 cycles per wave-instruction per SIMD (profiles/r05_valu_op_rates.txt)
+MAD_PEAK_GOPS = 1024 * 64 * 2.4 / 4.088      # v_mad_u64_u32: 4.09 cycles per wave-instruction per SIMD (profiles/r05_valu_op_rates.txt)
 VALU_PEAK_GINST = 1024 * 2.4 / 4 * 64        # 1024 SIMDs x 2.4 GHz / 4 cycles per wave instruction x 64 lanes
 N_SIMD, CLOCK_GHZ = 1024, 2.4                  # 256 CUs x 4 SIMDs; the clock tools/ubench/valu_ops.hip prices its cycles at
 BAD_POINT = bytes.fromhex("01" + "00" * 31)

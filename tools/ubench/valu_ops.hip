@@ -5,6 +5,9 @@
 // opcodes x these costs = the mix-weighted bound of the kernel ("integer-multiply
 // rate; say which binds").
 //
+// No asm statement declares a clobber: with "vcc" declared the compiler put an s_nop after EVERY statement, and a lone wavefront
+// then read 8.2 cycles per instruction (VALU + nop) where it issues every ~5.  Opcodes that write a scalar pair use s[20:21],
+// which the kernels do not otherwise touch (checked in the assembly).
 // Build: hipcc -O3 --offload-arch=gfx950 valu_ops.hip -o valu_ops     Output: one line per opcode, `name cycles`.
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -26,7 +29,7 @@ constexpr int REP = 16;          // the CH statements are repeated REP times per
     for (int i = 0; i < iters; ++i) {                                                    \
       _Pragma("unroll") for (int r = 0; r < REP; ++r)                                    \
       _Pragma("unroll") for (int j = 0; j < CH; ++j)                                     \
-        asm volatile(ASMTEXT : "+v"(x[j]) : "v"(a), "v"(b) : "vcc", "s20");              \
+        asm volatile(ASMTEXT : "+v"(x[j]) : "v"(a), "v"(b));              \
     }                                                                                    \
     uint32_t s = 0;                                                                      \
     _Pragma("unroll") for (int j = 0; j < CH; ++j) s ^= x[j];                            \
@@ -42,7 +45,7 @@ constexpr int REP = 16;          // the CH statements are repeated REP times per
     for (int i = 0; i < iters; ++i) {                                                    \
       _Pragma("unroll") for (int r = 0; r < REP; ++r)                                    \
       _Pragma("unroll") for (int j = 0; j < CH; ++j)                                     \
-        asm volatile(ASMTEXT : "+v"(x[j]) : "v"(a), "v"(b), "v"(w) : "vcc", "s20");      \
+        asm volatile(ASMTEXT : "+v"(x[j]) : "v"(a), "v"(b), "v"(w));      \
     }                                                                                    \
     uint64_t s = 0;                                                                      \
     _Pragma("unroll") for (int j = 0; j < CH; ++j) s ^= x[j];                            \
@@ -71,10 +74,10 @@ KERNEL32(k_v_mul_hi_u32, "v_mul_hi_u32 %0, %0, %1")
 KERNEL32(k_v_mul_u32_u24, "v_mul_u32_u24 %0, %0, %1")
 KERNEL32(k_v_mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %2")
 KERNEL32(k_v_cndmask_b32, "v_cndmask_b32 %0, %0, %1, vcc")
-KERNEL32(k_v_add_co_u32, "v_add_co_u32 %0, vcc, %0, %1")
-KERNEL32(k_v_addc_co_u32, "v_addc_co_u32 %0, vcc, %0, %1, vcc")
-KERNEL32(k_v_subb_co_u32, "v_subb_co_u32 %0, vcc, %0, %1, vcc")
-KERNEL32(k_v_cmp_lt_u32, "v_cmp_lt_u32 vcc, %0, %1")
+KERNEL32(k_v_add_co_u32, "v_add_co_u32 %0, s[20:21], %0, %1")
+KERNEL32(k_v_addc_co_u32, "v_addc_co_u32 %0, s[20:21], %0, %1, s[20:21]")
+KERNEL32(k_v_subb_co_u32, "v_subb_co_u32 %0, s[20:21], %0, %1, s[20:21]")
+KERNEL32(k_v_cmp_lt_u32, "v_cmp_lt_u32_e64 s[20:21], %0, %1")
 KERNEL32(k_v_mov_b32_dpp_quad, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
 KERNEL32(k_v_add_u32_dpp_quad, "v_add_u32_dpp %0, %0, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
 KERNEL32(k_v_mov_b32_dpp_row_ror, "v_mov_b32_dpp %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf")
@@ -84,8 +87,8 @@ KERNEL32(k_v_readlane_b32, "v_readlane_b32 s20, %0, 5")
 KERNEL64(k_v_lshrrev_b64, "v_lshrrev_b64 %0, 13, %0")
 KERNEL64(k_v_lshlrev_b64, "v_lshlrev_b64 %0, 3, %0")
 KERNEL64(k_v_lshl_add_u64, "v_lshl_add_u64 %0, %0, 1, %3")
-KERNEL64(k_v_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
-KERNEL64(k_v_mad_i64_i32, "v_mad_i64_i32 %0, vcc, %1, %2, %0")
+KERNEL64(k_v_mad_u64_u32, "v_mad_u64_u32 %0, s[20:21], %1, %2, %0")
+KERNEL64(k_v_mad_i64_i32, "v_mad_i64_i32 %0, s[20:21], %1, %2, %0")
 KERNEL64(k_v_add_f64, "v_add_f64 %0, %0, %3")
 KERNEL64(k_v_fma_f64, "v_fma_f64 %0, %0, %3, %3")
 KERNEL64(k_v_mov_b64, "v_mov_b64 %0, %3")
@@ -129,7 +132,10 @@ int main(int argc, char** argv) {
   const double ghz = p.clockRate * 1e-6;
   printf("# device: CUs=%d clock=%.3f GHz waves_per_SIMD=%d chains_per_lane=%d\n", cus, ghz, waves_per_simd, CH);
   printf("# opcode  cycles_per_wave_instruction_per_SIMD  (one SIMD issues one VALU instruction at a time)\n");
-  const int threads = 256, blocks = cus * waves_per_simd;      // 4 waves per block = one per SIMD; blocks per CU = waves per SIMD
+  // default: 256 threads per block (4 waves), blocks per CU = waves per SIMD.  argv[2] = threads per block (64: one wave per
+  // block, 4 x as many blocks): where a workgroup's four waves land is the dispatcher's business -- with 256 the "w=1" column
+  // reads 8.2 cycles, with 64-thread blocks it shows what a wave alone on a SIMD really issues at
+  const int threads = argc > 2 ? atoi(argv[2]) : 256, blocks = cus * waves_per_simd * (256 / threads);
   uint32_t* out = nullptr;
   CK(hipMalloc(&out, (size_t)blocks * threads * 4));
   const Entry table[] = {
