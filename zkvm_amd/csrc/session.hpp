@@ -1087,12 +1087,19 @@ int host_dispatch(zkgpu_verifier* v, zkgpu_host_batch* must) {
 
 // the caller's bytes -> pinned staging memory: on one thread ~10 GB/s, i.e. 0.14 ms per 1024-transaction ticket and 1.4 ms
 // before the FIRST device batch of a burst can leave; pieces of 8 KB on up to eight pool threads beyond 256 KB
-void staged_copy(void* dst, const void* src, size_t n) {
-  if (n < (256u << 10)) { memcpy(dst, src, n); return; }
+// Up to three spans of one ticket in ONE pass over the pool (a pass costs ~30 us to wake the workers whatever it copies: three
+// passes per ticket were most of the 0.1 ms a ticket took to stage -- and the first device batch of a burst waits for ten).
+struct CopySpan { void* dst; const void* src; size_t n; };
+void staged_copy(const CopySpan* spans, int count) {
   constexpr size_t PIECE = 8u << 10;
-  host_parallel((n + PIECE - 1) / PIECE, std::min(usable_cpus(), 8), [&](size_t i) {
+  size_t total = 0, pieces[3] = {0, 0, 0};
+  for (int k = 0; k < count; ++k) { total += spans[k].n; pieces[k] = (spans[k].n + PIECE - 1) / PIECE; }
+  if (total < (256u << 10)) { for (int k = 0; k < count; ++k) memcpy(spans[k].dst, spans[k].src, spans[k].n); return; }
+  host_parallel(pieces[0] + pieces[1] + pieces[2], std::min(usable_cpus(), 8), [&](size_t i) {
+    int k = 0;
+    while (i >= pieces[k]) { i -= pieces[k]; ++k; }
     const size_t at = i * PIECE;
-    memcpy((char*)dst + at, (const char*)src + at, std::min(PIECE, n - at));
+    memcpy((char*)spans[k].dst + at, (const char*)spans[k].src + at, std::min(PIECE, spans[k].n - at));
   });
 }
 
@@ -1134,11 +1141,12 @@ int host_submit_one(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, size_t bat
   }
   zkgpu_verifier::HostStage& hs = v->host_stages[(size_t)F->stage];
   char* h = (char*)hs.pin;
-  staged_copy(h + F->total * wcom, com, batch * wcom);
-  staged_copy(h + F->o_proofs + F->total * proof_len, proofs, batch * proof_len);
-  if (r_bytes) {
-    staged_copy(h + F->o_r + F->total * 64, r_bytes, batch * 64);
-  } else {                                // verifier randomness: SHAKE256 of 32 bytes from the OS and the ticket number
+  {
+    const CopySpan spans[3] = {{h + F->total * wcom, com, batch * wcom}, {h + F->o_proofs + F->total * proof_len, proofs, batch * proof_len},
+                               {h + F->o_r + F->total * 64, r_bytes, batch * 64}};
+    staged_copy(spans, r_bytes ? 3 : 2);
+  }
+  if (!r_bytes) {                                // verifier randomness: SHAKE256 of 32 bytes from the OS and the ticket number
     uint8_t seed[40] = {0};
     if (!os_random(seed, 32)) { r->state = 2; r->rc = ZKGPU_EINVAL; r->bits.assign((batch + 7) / 8, 0); v->last_error = "getrandom failed"; return ZKGPU_OK; }
     for (int q = 0; q < 8; ++q) seed[32 + q] = (uint8_t)(r->id >> (8 * q));
