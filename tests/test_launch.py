@@ -288,3 +288,24 @@ def test_bench_gpus_2_when_the_communicator_stalls_instead_of_refusing(probe):
         assert r.stdout.strip() == ""
         assert "did not return within 25 s" in r.stderr and "leaving with exit code 3" in r.stderr
         assert dt < 400
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_as_the_driver_launches_it():
+    """The driver's N > 1 command verbatim -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- with both ranks sharing the test box's one GPU
+    (ZKGPU_BENCH_SHARE_GPU=1, ZKGPU_BENCH_TRY_RCCL=1: RCCL is tried in the probe children, refuses two ranks on one device,
+    and the ranks agree on gloo): ONE JSON line on standard output from rank 0, two ranks in it, the fallback named."""
+    from zkvm_amd.launch import free_port
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(ZKGPU_BENCH_SHARE_GPU="1", ZKGPU_BENCH_TRY_RCCL="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--lean"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and len(d["config"]["per_rank"]) == 2
+    assert d["config"]["exchange"].startswith("gloo -- RCCL could not be brought up on rank"), d["config"]["exchange"]
+    assert d["config"]["bringup"]["probe_s"] < 120
