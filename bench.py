@@ -662,6 +662,11 @@ class World:
             import datetime
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            # the whole run of a rank is bounded too (zkvm_amd/bringup.py: Watchdog): RCCL's all-gather in the timed region
+            # cannot be cancelled either
+            from zkvm_amd import bringup
+            self.run_watchdog = bringup.Watchdog(float(getattr(args, "run_timeout", 700.0)), "this rank's run (a collective in the timed region?)",
+                                                 code=4, rank=self.rank).start()
             dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=datetime.timedelta(minutes=20))
             self.dist = dist
 
@@ -711,6 +716,7 @@ class World:
         if self.dist:
             self.dist.barrier()
             self.dist.destroy_process_group()
+            self.run_watchdog.cancel()
 
 
 def rccl_roll_call(W, comm):
@@ -1465,6 +1471,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="transactions per GPU (config 4: default 8192)")
     ap.add_argument("--table-bits", type=int, default=-1, help="window width of the fixed-base generator tables (-1: the library chooses the knee of additions per term against table bytes: 14 for 514 points on an MI355X)")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="--gpus N > 1 started by this program: seconds before the launcher ends every rank and returns 124")
+    ap.add_argument("--run-timeout", type=float, default=float(os.environ.get("ZKGPU_BENCH_RUN_TIMEOUT", "700")),
+                    help="N > 1: seconds a rank may take for its whole run (a collective that stalls in the timed region ends the rank with "
+                         "exit code 4 and the reason on standard error instead of waiting for the launcher's or the driver's limit)")
     ap.add_argument("--comm-timeout", type=float, default=float(os.environ.get("ZKGPU_BENCH_COMM_TIMEOUT", "120")),
                     help="N > 1: seconds the RCCL communicator's bring-up (probe in a child process, then ncclCommInitRank + one all-gather in the rank) may take")
     ap.add_argument("--inflight", type=int, default=0,
