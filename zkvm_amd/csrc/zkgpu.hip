@@ -2287,9 +2287,15 @@ int run_sliced(zkgpu_ctx* c, size_t batch, int host_threads, const std::function
     zkgpu_ctx* t = c->pv_slices[(size_t)i - 1];
     t->prover_mode = c->prover_mode;
     t->profiling = c->profiling;
-    th.emplace_back([&, i, t] { rc[(size_t)i] = one(t, cut(i), cut(i + 1), ht); });
+    th.emplace_back([&, i, t] {
+      try { rc[(size_t)i] = one(t, cut(i), cut(i + 1), ht); }
+      catch (const std::bad_alloc&) { t->last_error = "prover: out of host memory"; rc[(size_t)i] = ZKGPU_ENOMEM; }
+      catch (const std::exception& e) { t->last_error = e.what(); rc[(size_t)i] = ZKGPU_EINVAL; }      // (never across a thread's top frame)
+    });
   }
-  rc[0] = one(c, 0, cut(1), ht);
+  try { rc[0] = one(c, 0, cut(1), ht); }
+  catch (const std::bad_alloc&) { c->last_error = "prover: out of host memory"; rc[0] = ZKGPU_ENOMEM; }
+  catch (const std::exception& e) { c->last_error = e.what(); rc[0] = ZKGPU_EINVAL; }
   for (auto& t : th) t.join();
   int bad = ZKGPU_OK;
   for (int i = 1; i < S; ++i) {
