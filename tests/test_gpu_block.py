@@ -1189,3 +1189,17 @@ def test_random_described_systems_all_provers_and_verifiers_agree(ctx, seed, sha
     finally:
         ctx.set_prover_mode(0)
         gens.close()
+
+
+@pytest.mark.parametrize("seed,merge,lanes", [(11, 3000, 4), (12, 10240, 5)])
+def test_tickets_of_drawn_sizes_from_host_and_device_memory_waited_for_in_a_drawn_order(seed, merge, lanes):
+    """tools/ticket_soak.py as a test: 250 tickets of drawn sizes (1 .. 1024 transactions), seven in ten from HOST memory (staged,
+    copied to the HBM twin of their staging area ticket by ticket, the area held until its device batch is collected) and three
+    in ten from device memory, in ONE queue, waited for in a drawn order with a drawn number in flight -- every verdict against
+    the constructed expectation (a fresh process: the verifier's areas, lanes and queue start empty)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ticket_soak.py"), "250", str(seed), str(merge), str(lanes)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ticket soak ok: 250 tickets" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
