@@ -475,8 +475,9 @@ k_challenges(PrepShape sh, const uint32_t* __restrict__ raw /*[B][n_ch][16]*/, c
 // challenge slots are copied into LDS until the canonical words are written out: a product is the multiply-adds and
 // one carry pass, sums and differences are limb-wise (bounds in the comments where they matter).
 // LDS (10-word slots): chs[n_ch] | sym[n_mono] | strides[PREP_STRIDES] (these three converted from k_transcript's
-// 8-word Montgomery slots) | wv[n_targets] | region A: zpow[n_cons] tv[tv_cap + 32], and once the flattening is
-// done yip[pn] sv[pn] red[8] shr[8] in its place.
+// 8-word Montgomery slots) | wv[n_targets] | ylo[16] yhi[pn/16] slo[16] shi[pn/16] red[8] shr[8] | region A: zpow[n_cons]
+// tv[tv_cap + 32] (zlo[16] zhi[n_cons/16] at tv's place until zpow is made), and once the flattening is done yip[pn] sv[pn]
+// in its place.
 //
 // Values that every lane of the workgroup needs (x U, a P1 rho Y, b P1, c', ...) are computed ONCE, each by one lane, beside
 // work that leaves lanes idle anyway, and handed over through shr[]: written as plain expressions they are products of
@@ -484,8 +485,12 @@ k_challenges(PrepShape sh, const uint32_t* __restrict__ raw /*[B][n_ch][16]*/, c
 // one dependent chain, repeated by every wavefront (measured, round 3: 5 000 scalar instructions per wavefront beside
 // 7 000 vector ones, SQ_INSTS_SALU 2.0e8 per launch).  lane_zero() keeps single-lane sections on the vector unit.
 //
-// Power tables are built by doubling (entry q + 2^L = entry q * stride_L, one product per entry)
-// instead of one square-and-multiply per entry, and y^-i is kept in PLAIN form: a Montgomery
+// Power tables are OUTER PRODUCTS of two small tables, entry (16 h + l) = hi[h] * lo[l]: the small tables -- six of them, of
+// z^(q+1), rho y^i and s_i -- grow by doubling (entry q + 2^L = entry q * stride_L, one product per entry) all at once on
+// the lanes of ONE wavefront, four or five dependent products deep, and every big table is then one product per entry on
+// all lanes.  (Until round 5 the big tables themselves grew by doubling, one after the other: 17 dependent products with
+// one to 128 lanes busy -- 57 % of a workgroup's life by the per-section clocks of tools/prep_stamps.py.)
+// y^-i is kept in PLAIN form: a Montgomery
 // product with one plain operand yields a plain result, so the generator scalars come out as
 // plain values without a conversion product of their own.
 //
@@ -495,10 +500,16 @@ constexpr uint32_t SCL_WORDS = 10;
 constexpr uint32_t TERM_UNIT = 0x80000000u, TERM_NEG = 0x40000000u, TERM_IDX = 0x00ffffffu;
 constexpr uint32_t HEAVY_TERMS = 16;      // lazy sums are reduced every so many terms; targets with more are summed by the whole workgroup
 
+// the small tables every power table is the outer product of (see k_prepare): entries of z^(16 h), of the high factors of
+// rho y^i and of s_i; the low factors have 16 entries (2^k when k < 4)
+__host__ __device__ inline uint32_t prep_zhi(const PrepShape& sh) { return ((sh.n_cons ? sh.n_cons - 1 : 0) >> 4) + 1; }
+__host__ __device__ inline uint32_t prep_lo_bits(const PrepShape& sh) { return sh.k < 4 ? sh.k : 4; }
 // bytes: 40-byte slots, except the two tables of the second life (yip, sv: products < 2^255 packed into 32 bytes)
 __host__ __device__ inline size_t prepare_lds_bytes(const PrepShape& sh) {
-  const size_t first = ((size_t)sh.n_cons + sh.tv_cap + 32) * 40, second = (size_t)2 * sh.pn * 32 + 16 * 40;
-  return ((size_t)sh.n_ch_ext + sh.n_targets) * 40 + 16 + (first > second ? first : second);
+  const size_t scratch = sh.tv_cap + 32 > 16 + prep_zhi(sh) ? sh.tv_cap + 32 : 16 + prep_zhi(sh);
+  const size_t first = ((size_t)sh.n_cons + scratch) * 40, second = (size_t)2 * sh.pn * 32;
+  const size_t small = 2 * 16 + 2 * ((size_t)sh.pn >> prep_lo_bits(sh)) + 16;      // ylo yhi slo shi | red[8] shr[8]
+  return ((size_t)sh.n_ch_ext + sh.n_targets + small) * 40 + 16 + (first > second ? first : second);
 }
 
 // a zero in a vector register that the compiler cannot see through: added to a shared address it makes the loaded value
@@ -550,6 +561,17 @@ __device__ __forceinline__ scl wave_sum_scl(scl part) {
   return part;
 }
 
+// Per-section clocks (build variant -DZK_PREP_STAMPS only: tools/prep_stamps.py): thread 0 and thread 255 of the workgroups
+// 4096 .. 4351 (the middle of a 10 240-transaction launch) note s_memtime where a section ends; read back through zkgpu_debug_read("prep_stamps").
+#ifdef ZK_PREP_STAMPS
+constexpr int PREP_STAMP_SLOTS = 16;
+__device__ unsigned long long g_prep_stamps[256 * 2 * PREP_STAMP_SLOTS];
+#define PREP_STAMP(i) do { if ((blockIdx.x >> 8) == 16 && (threadIdx.x == 0 || threadIdx.x == 255)) \
+  g_prep_stamps[((blockIdx.x & 255) * 2 + (threadIdx.x ? 1 : 0)) * PREP_STAMP_SLOTS + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PREP_STAMP(i) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(256, 4)
 k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* __restrict__ mono_pow,
           const uint32_t* __restrict__ tgt_off, const uint32_t* __restrict__ term_info,
@@ -564,13 +586,21 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   uint32_t* ys = zs + 16 * SW;                   // y^-(2^L)
   uint32_t* us2 = ys + 16 * SW;                  // u_j^2
   uint32_t* wv = chs + sh.n_ch_ext * SW;
-  uint32_t* zpow = lds + (((sh.n_ch_ext + sh.n_targets) * SW + 3u) & ~3u);   // region A (16-byte aligned), first life
+  const uint32_t LB = prep_lo_bits(sh), NLO = 1u << LB, PH = sh.pn >> LB, ZLO = sh.n_cons < 16 ? sh.n_cons : 16, ZH = prep_zhi(sh);
+  uint32_t* ylo = wv + sh.n_targets * SW;       // plain y^l, l < 16            (rho y^i = ylo[i & 15] * yhi[i >> 4], plain)
+  uint32_t* yhi = ylo + 16 * SW;                 // rho y^(16 h)
+  uint32_t* slo = yhi + PH * SW;                 // s_i = slo[i & 15] * shi[i >> 4]
+  uint32_t* shi = slo + 16 * SW;
+  uint32_t* red = shi + PH * SW;
+  uint32_t* shr = red + 8 * SW;                  // 0: x U  1: a P1  2: b P1  3: c' (plain)  4: a P1 rho Y (plain)  5: c' (Montgomery)  6: rho Y (plain)  7: plain 1
+  uint32_t* zpow = lds + (((uint32_t)(shr + 8 * SW - lds) + 3u) & ~3u);       // region A (16-byte aligned), first life
   uint32_t* tv = zpow + sh.n_cons * SW;
+  uint32_t* zlo = tv;                            // z^(l+1), l < 16              (z^(q+1) = zlo[q & 15] * zhi[q >> 4])
+  uint32_t* zhi = tv + 16 * SW;                  // z^(16 h)
   uint32_t* yip = zpow;                          // region A, second life: two packed tables (8 words per entry)
   uint32_t* sv = yip + sh.pn * 8;
-  uint32_t* red = sv + sh.pn * 8;
-  uint32_t* shr = red + 8 * SW;                  // 0: x U  1: a P1  2: b P1  3: c' (plain)  4: a P1 rho Y (plain)  5: c' (Montgomery)  6: rho Y (plain)  7: plain 1
   const uint32_t tx = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  PREP_STAMP(0);
 
   // the transaction's slots (canonical Montgomery words) -> limb form
   for (uint32_t i = t; i < sh.n_ch_ext; i += nt) {
@@ -580,43 +610,65 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     st_scl(chs + i * SW, scl_from_words(w));
   }
   __syncthreads();
-  if (t < SW) zpow[t] = zs[t];
+  uint32_t* xp = us2 + 16 * SW;                  // xp[0..4] = x^2..x^6, xp[5] = r x^2
+  if (t == 0) {                                  // what the small tables start from
+    scl z, rho;
+    ld_scl(z, zs); ld_scl(rho, chs + 13 * SW);
+    st_scl(zlo, z); st_scl(zhi, scl_one());
+    st_scl(ylo, scl_plain_one()); st_scl(yhi, rho);
+    st_scl(slo, scl_one()); st_scl(shi, scl_one());
+    st_scl(shr + 7 * SW, scl_plain_one());
+  }
   __syncthreads();
-  // phase B: zpow[q] = z^(q+1) by doubling.  Its first steps keep a handful of lanes busy: two lanes of the last
-  // wavefront use them for the powers of x the proof-point scalars need (xp[0..4] = x^2..x^6, xp[5] = r x^2):
-  //   step 0: x^2 | step 1: x^3, x^4 | step 2: x^5, x^6 -- and r x^2 on the second lane in step 1
-  uint32_t* xp = us2 + 16 * SW;
+  PREP_STAMP(1);                                  // slots converted
+  // phase B: the six small tables by doubling, all in the same steps, one job = one product dst = a * b per lane.  Beside
+  // them, on the lanes that follow: the powers of x the proof-point scalars need (step 0: x^2 | step 1: x^3, x^4, r x^2 |
+  // step 2: x^5, x^6) and, in step 0, x U, a P1, b P1.  A payment's steps have 10, 15, 27, 48, 10 jobs: one wavefront.
 #pragma unroll 1
-  for (uint32_t L = 0, half = 1; half < sh.n_cons || L < 3; ++L, half <<= 1) {
-    const uint32_t end = half < sh.n_cons ? min(2 * half, sh.n_cons) : 0;
-    for (uint32_t q = half + t; q < end; q += nt) {
-      scl a, b;
-      ld_scl(a, zpow + SW * (q - half));
-      ld_scl(b, zs + SW * L);
-      st_scl(zpow + SW * q, scl_mul(a, b));
-    }
-    if (L < 3 && t >= nt - 2) {
-      const bool second = t == nt - 1;
-      scl a, b;
-      // first lane: x*x | x^2*x | x^4*x        second lane: - | x^2*x^2 | x^4*x^2
-      if (L == 0) { ld_scl(a, chs + 3 * SW + lane_zero()); b = a; if (!second) st_scl(xp + 0 * SW, scl_mul(a, b)); }
-      else if (L == 1) {
-        ld_scl(a, xp + 0 * SW);
-        if (second) b = a; else ld_scl(b, chs + 3 * SW);
-        st_scl(xp + (second ? 2 : 1) * SW, scl_mul(a, b));             // x^4 | x^3
-      } else {
-        ld_scl(a, xp + 2 * SW);
-        if (second) ld_scl(b, xp + 0 * SW); else ld_scl(b, chs + 3 * SW);
-        st_scl(xp + (second ? 4 : 3) * SW, scl_mul(a, b));             // x^6 | x^5
+  for (uint32_t L = 0, half = 1;; ++L, half <<= 1) {
+    auto fresh = [half](uint32_t n) { return n > half ? (n - half < half ? n - half : half) : 0u; };   // entries [half, 2 half) of a table of n
+    const uint32_t c0 = fresh(ZLO), c1 = fresh(ZH), c2 = fresh(NLO), c3 = fresh(PH);
+    const uint32_t n_tab = c0 + c1 + 2 * (c2 + c3), n_side = L == 0 ? 4u : L == 1 ? 3u : L == 2 ? 2u : 0u;
+    if (n_tab + n_side == 0) break;
+    for (uint32_t j0 = t; j0 < n_tab + n_side; j0 += nt) {
+      uint32_t j = j0;
+      const uint32_t* pa;
+      const uint32_t* pb;
+      uint32_t* pd;
+      if (j < c0) { pa = zlo + j * SW; pb = zs + L * SW; pd = zlo + (half + j) * SW; }
+      else if ((j -= c0) < c1) { pa = zhi + j * SW; pb = zs + (L + 4) * SW; pd = zhi + (half + j) * SW; }
+      else if ((j -= c1) < c2) { pa = ylo + j * SW; pb = ys + L * SW; pd = ylo + (half + j) * SW; }
+      else if ((j -= c2) < c3) { pa = yhi + j * SW; pb = ys + (L + LB) * SW; pd = yhi + (half + j) * SW; }
+      else if ((j -= c3) < c2) { pa = slo + j * SW; pb = us2 + (sh.k - 1 - L) * SW; pd = slo + (half + j) * SW; }
+      else if ((j -= c2) < c3) { pa = shi + j * SW; pb = us2 + (sh.k - 1 - L - LB) * SW; pd = shi + (half + j) * SW; }
+      else {
+        j -= c3;
+        const uint32_t* const px = chs + 3 * SW;
+        if (L == 0) {
+          if (j == 0) { pa = px; pb = px; pd = xp; }                                      // x^2
+          else { pa = chs + (j == 1 ? 3 : j == 2 ? 11 : 12) * SW; pb = chs + (j == 1 ? 6 : 5) * SW; pd = shr + (j - 1) * SW; }   // x U | a P1 | b P1
+        } else if (L == 1) {
+          pa = j == 2 ? chs + 7 * SW : xp;                                               // x^2 x | x^2 x^2 | r x^2
+          pb = j == 0 ? px : xp;
+          pd = xp + (j == 0 ? 1 : j == 1 ? 2 : 5) * SW;
+        } else {
+          pa = xp + 2 * SW; pb = j == 0 ? px : xp; pd = xp + (j == 0 ? 3 : 4) * SW;       // x^4 x | x^4 x^2
+        }
       }
-    }
-    if (L == 2 && t == nt - 3) {                                       // r x^2
       scl a, b;
-      ld_scl(a, chs + 7 * SW + lane_zero()); ld_scl(b, xp + 0 * SW);
-      st_scl(xp + 5 * SW, scl_mul(a, b));
+      ld_scl(a, pa); ld_scl(b, pb);
+      st_scl(pd, scl_mul(a, b));
     }
     __syncthreads();
   }
+  // ... and z^(q+1) for every constraint q, one product each
+  for (uint32_t q = t; q < sh.n_cons; q += nt) {
+    scl a, b;
+    ld_scl(a, zlo + SW * (q & 15)); ld_scl(b, zhi + SW * (q >> 4));
+    st_scl(zpow + SW * q, scl_mul(a, b));
+  }
+  __syncthreads();
+  PREP_STAMP(2);                                  // z powers (doubling)
   // phase C: plan replay, a range of targets at a time: the products of the range (one multiplication per product, two
   // when a second-phase challenge is involved), then one sum per target.  Every stored value is a product (< 2^255) or
   // a weakly reduced sum (< 2 l).
@@ -676,43 +728,23 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     }
     __syncthreads();
   }
+  PREP_STAMP(3);                                  // plan replay
   // phase E (region A is dead).  The whole equation is taken times c' = rho y^(pn-1) U, U = prod u_j^2
   // (rho: chs slot 13, 1 unless the batch is checked in groups), which needs no inverse:
   //     c' y^-i        = U * yp[pn-1-i]             yp[j] = rho y^j, kept in PLAIN form
   //     c' s_i         = yp[pn-1] * P1 * sU[i]      sU[i] = prod_j u_j^(2 bit_(k-1-j)(i)),  P1 = prod u_j
   //     c' y^-i s_r    = yp[pn-1-i] * P1 * sU[r]    (U s_i = prod u_j^(2 +- 1) = P1 sU[i])
   // Both tables grow by doubling (entry + 2^L = entry * stride_L).
-  if (t == 0) {
-    scl rho;
-    ld_scl(rho, chs + 13 * SW + lane_zero());
-    st_scl8(yip, scl_mul(rho, scl_plain_one()));
-    st_scl8(sv, scl_one());
-  } else if (t >= nt - 3) {                       // x U | a P1 | b P1 on three lanes of the last wavefront
-    const uint32_t w = t - (nt - 3);
+  for (uint32_t idx = t; idx < 2 * sh.pn; idx += nt) {
+    const bool second = idx >= sh.pn;
+    const uint32_t i = second ? idx - sh.pn : idx;
     scl a, b;
-    ld_scl(a, chs + (w == 0 ? 3 : w == 1 ? 11 : 12) * SW);
-    ld_scl(b, chs + (w == 0 ? 6 : 5) * SW);
-    st_scl(shr + w * SW, scl_mul(a, b));
-    if (w == 0) st_scl(shr + 7 * SW, scl_plain_one());
+    ld_scl(a, (second ? slo : ylo) + SW * (i & (NLO - 1)));
+    ld_scl(b, (second ? shi : yhi) + SW * (i >> LB));
+    st_scl8((second ? sv : yip) + 8 * i, scl_mul(a, b));
   }
   __syncthreads();
-#pragma unroll 1
-  for (uint32_t L = 0, half = 1; half < sh.pn; ++L, half <<= 1) {
-    for (uint32_t idx = t; idx < 2 * half; idx += nt) {
-      scl a, b;
-      if (idx < half) {
-        ld_scl8(a, yip + 8 * idx);
-        ld_scl(b, ys + SW * L);
-        st_scl8(yip + 8 * (idx + half), scl_mul(a, b));
-      } else {
-        const uint32_t i = idx - half;
-        ld_scl8(a, sv + 8 * i);
-        ld_scl(b, us2 + SW * (sh.k - 1 - L));
-        st_scl8(sv + 8 * (i + half), scl_mul(a, b));
-      }
-    }
-    __syncthreads();
-  }
+  PREP_STAMP(4);                                  // y / s tables (doubling)
   const uint32_t* wL = wv;
   const uint32_t* wR = wv + sh.n * SW;
   const uint32_t* wO = wv + 2 * sh.n * SW;
@@ -751,6 +783,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     }
     __syncthreads();
   }
+  PREP_STAMP(5);                                  // dsum, c'
   uint32_t* ds = dyn_scalars + (uint64_t)tx * sh.n_dyn * 8;
   uint32_t* dr = dyn_recoded + (uint64_t)tx * sh.n_dyn * 8;
   uint32_t* ss = static_scalars + (uint64_t)tx * sh.n_static * 8;
@@ -840,6 +873,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
       }
     }
   }
+  PREP_STAMP(6);                                  // (thread 255: the proof-point scalars of the last wavefront)
   // generator scalars (times c'), reduced to canonical words at the very end:
   //   c' g_i = (x U) wR_i yp[pn-1-i] - (a P1 rho Y) sU_i
   //   c' h_i = yp[pn-1-i] ((x U) wL_i + U wO_i - (b P1) sU_(pn-1-i)) - c'        (times u for i >= n1)
@@ -869,6 +903,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
       oh[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]); oh[1] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
     }
   }
+  PREP_STAMP(7);                                  // generator scalars
 }
 
 // the proof-specific points of every transaction in the order of the MSM's dynamic terms

@@ -1662,6 +1662,13 @@ long long zkgpu_debug_read(zkgpu_ctx* c, const char* what, void* out, size_t byt
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   DeviceGuard g(c->device);
   const std::string w(what);
+#ifdef ZK_PREP_STAMPS
+  if (w == "prep_stamps") {
+    const size_t n = std::min(bytes, sizeof(unsigned long long) * 256 * 2 * zk::PREP_STAMP_SLOTS);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out, HIP_SYMBOL(zk::g_prep_stamps), n) != hipSuccess) return ZKGPU_EHIP;
+    return (long long)n;
+  }
+#endif
   const Buffer* b = w == "challenges" ? &c->prep_ch : w == "static_scalars" ? &c->prep_st_sc :
                     w == "dyn_scalars" ? &c->prep_dyn_sc : w == "dyn_points" ? &c->prep_dyn_pt : nullptr;
   if (!b || !b->p) return ZKGPU_EINVAL;
@@ -2610,11 +2617,12 @@ int plan_finish_inner(zkgpu_ctx* c, zkgpu_cloak_plan* p, size_t gens_capacity) {
   for (uint32_t t = 0; t < s.n_targets && s.n_heavy < 8; ++t)
     if (h.tgt_off[t + 1] - h.tgt_off[t] > 2 * HEAVY_TERMS) s.heavy[s.n_heavy++] = t;
   s.n_ch_ext = s.n_ch + s.n_mono + PREP_STRIDES;
-  // fewest flattening passes (<= 5) that bring the workgroup to <= 40 KB of LDS (four workgroups per CU) -- or, where
-  // that is out of reach, beyond which the LDS need no longer shrinks; the split points are target boundaries
+  // the fewest flattening passes (<= 5) that let as many workgroups share a CU's 160 KB of LDS as any number of passes
+  // would (a payment: 45.9 KB in one pass, 42.3 KB in three or more -- three workgroups either way: one pass); the split
+  // points are target boundaries.  (Every pass costs the workgroup two barriers and a round of dependent loads.)
   const uint32_t n_prod = (uint32_t)h.prod_q.size();
   PrepShape best = s;
-  size_t best_bytes = 0;
+  size_t best_bytes = 0, best_groups = 0;
   for (uint32_t chunks = 1; chunks <= 5; ++chunks) {
     s.n_chunks = chunks;
     s.chunk_tgt[0] = 0;
@@ -2629,9 +2637,9 @@ int plan_finish_inner(zkgpu_ctx* c, zkgpu_cloak_plan* p, size_t gens_capacity) {
       cap = std::max(cap, h.prod_off[g] - h.prod_off[s.chunk_tgt[ck]]);
     }
     s.tv_cap = cap;
-    const size_t bytes = prepare_lds_bytes(s);
-    if (best_bytes == 0 || bytes < best_bytes) { best = s; best_bytes = bytes; }
-    if (bytes <= 40 * 1024) break;
+    const size_t bytes = prepare_lds_bytes(s), groups = std::min<size_t>(4, (160 * 1024) / bytes);     // (four: the kernel's launch bounds)
+    if (best_bytes == 0 || groups > best_groups || (groups == 0 && bytes < best_bytes)) { best = s; best_bytes = bytes; best_groups = groups; }
+    if (groups == 4) break;
   }
   s = best;
   p->lds_bytes = best_bytes;
