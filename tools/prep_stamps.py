@@ -44,4 +44,13 @@ for who, name in ((0, "thread 0 (wavefront 0)"), (1, "thread 255 (the last wavef
         m = statistics.median(x[i] for x in rows)
         print("  %-52s %9.0f  %5.1f %%" % (sec, m, 100.0 * m / tot))
     print("  %-52s %9.0f" % ("whole workgroup", tot))
+    inner = []
+    for wg in range(256):
+        s = [buf[(wg * 2 + who) * 16 + i] for i in range(12)]
+        if all(s[i] for i in (1, 2, 3, 8, 9, 11)):
+            inner.append((s[11] - s[1], s[2] - s[11], s[8] - s[2], s[9] - s[8], s[3] - s[9]))
+    if inner:
+        for i, sec in enumerate(["small tables (levels)", "z^(q+1): one product per entry", "plan replay: products of the (last) pass", "plan replay: sums of the light targets",
+                                 "plan replay: heavy targets"]):
+            print("    %-50s %9.0f" % (sec, statistics.median(x[i] for x in inner)))
 bv.close(); gens.close(); ctx.close()

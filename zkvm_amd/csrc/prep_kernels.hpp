@@ -554,11 +554,21 @@ __device__ __forceinline__ scl shfl_down_scl(const scl& a, int delta) {
   for (int q = 0; q < 10; ++q) o.v[q] = (uint32_t)__shfl_down((int)a.v[q], delta);
   return o;
 }
-// sum over the wavefront, in lane 0: inputs tight and < 2^255 -> tight, < 2^261
+// sum over the wavefront, in lane 63: inputs tight (limbs < 2^26, so that 64 of them fit a word) and < 2^256 -> tight, < 2 l.
+// Six DPP additions per limb (row_shr 1 2 4 8, then row_bcast 15 and 31) and ONE carry pass at the end.
 __device__ __forceinline__ scl wave_sum_scl(scl part) {
-#pragma unroll 1
-  for (int delta = 32; delta >= 1; delta >>= 1) part = scl_add_c(part, shfl_down_scl(part, delta));
-  return part;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    uint32_t v = part.v[q];
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // lane 15 of rows 0, 2 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // lane 31 -> rows 2, 3
+    part.v[q] = v;
+  }
+  return scl_weak(part);
 }
 
 // Per-section clocks (build variant -DZK_PREP_STAMPS only: tools/prep_stamps.py): thread 0 and thread 255 of the workgroups
@@ -566,8 +576,8 @@ __device__ __forceinline__ scl wave_sum_scl(scl part) {
 #ifdef ZK_PREP_STAMPS
 constexpr int PREP_STAMP_SLOTS = 16;
 __device__ unsigned long long g_prep_stamps[256 * 2 * PREP_STAMP_SLOTS];
-#define PREP_STAMP(i) do { if ((blockIdx.x >> 8) == 16 && (threadIdx.x == 0 || threadIdx.x == 255)) \
-  g_prep_stamps[((blockIdx.x & 255) * 2 + (threadIdx.x ? 1 : 0)) * PREP_STAMP_SLOTS + (i)] = __builtin_readcyclecounter(); } while (0)
+#define PREP_STAMP(i) do { if ((blockIdx.x >> 8) == 16 && (t == 0 || t == 255)) \
+  g_prep_stamps[((blockIdx.x & 255) * 2 + (t ? 1 : 0)) * PREP_STAMP_SLOTS + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PREP_STAMP(i) do { } while (0)
 #endif
@@ -661,6 +671,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
     }
     __syncthreads();
   }
+  PREP_STAMP(11);                                 // (small tables made)
   // ... and z^(q+1) for every constraint q, one product each
   for (uint32_t q = t; q < sh.n_cons; q += nt) {
     scl a, b;
@@ -685,6 +696,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
       st_scl(tv + SW * (p - p0), scl_mul(c, zq));
     }
     __syncthreads();
+    PREP_STAMP(8);                                // (products of the pass)
     // <= HEAVY_TERMS terms, each < 2^255 or its negative (256 l - v, limbs < 2^27.6): limbs < 2^31.6, value < 2^264.1
     auto term_value = [&](uint32_t e) {
       const uint32_t info = term_info[e];
@@ -705,6 +717,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
       }
       st_scl(wv + SW * g, scl_weak(acc));
     }
+    PREP_STAMP(9);                                // (sums of the light targets)
     // heavy targets: every lane sums a strided share, wavefront shuffles fold the lanes, lane 0 of
     // each wave parks its sum in the scratch slots after the products (4 per heavy target)
     for (uint32_t hI = 0; hI < sh.n_heavy; ++hI) {
@@ -718,7 +731,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
       }
       acc = wave_sum_scl(scl_weak(acc));
       uint32_t* wave_sums = tv + (sh.tv_cap + 4 * hI) * SW;
-      if ((t & 63) == 0) st_scl(wave_sums + SW * (t >> 6), acc);
+      if ((t & 63) == 63) st_scl(wave_sums + SW * (t >> 6), acc);
       __syncthreads();
       if (t == 0) {
         scl tot = scl_zero();
@@ -761,7 +774,7 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
       if (++cnt == 32) { part = scl_weak(part); cnt = 1; }
     }
     part = wave_sum_scl(scl_weak(part));          // <= 32 products, limbs < 2^31
-    if ((t & 63) == 0) st_scl(red + SW * (1 + (t >> 6)), part);
+    if ((t & 63) == 63) st_scl(red + SW * (1 + (t >> 6)), part);
     if (t >= nt - 2) {                            // c' = U rho Y | a P1 rho Y, both plain (rho Y = yip[pn-1] is plain)
       const bool second = t == nt - 1;
       scl a, b;
