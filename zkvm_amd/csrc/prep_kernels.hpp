@@ -475,7 +475,7 @@ k_challenges(PrepShape sh, const uint32_t* __restrict__ raw /*[B][n_ch][16]*/, c
 // challenge slots are copied into LDS until the canonical words are written out: a product is the multiply-adds and
 // one carry pass, sums and differences are limb-wise (bounds in the comments where they matter).
 // LDS (10-word slots): chs[n_ch] | sym[n_mono] | strides[PREP_STRIDES] (these three converted from k_transcript's
-// 8-word Montgomery slots) | wv[n_targets] | ylo[16] yhi[pn/16] slo[16] shi[pn/16] red[8] shr[8] | region A: zpow[n_cons]
+// 8-word Montgomery slots) | wv[n_targets] | ylo[16] yhi[pn/16] slo[16] shi[pn/16] red[8] shr[16] | region A: zpow[n_cons]
 // tv[tv_cap + 32] (zlo[16] zhi[n_cons/16] at tv's place until zpow is made), and once the flattening is done yip[pn] sv[pn]
 // in its place.
 //
@@ -508,7 +508,7 @@ __host__ __device__ inline uint32_t prep_lo_bits(const PrepShape& sh) { return s
 __host__ __device__ inline size_t prepare_lds_bytes(const PrepShape& sh) {
   const size_t scratch = sh.tv_cap + 32 > 16 + prep_zhi(sh) ? sh.tv_cap + 32 : 16 + prep_zhi(sh);
   const size_t first = ((size_t)sh.n_cons + scratch) * 40, second = (size_t)2 * sh.pn * 32;
-  const size_t small = 2 * 16 + 2 * ((size_t)sh.pn >> prep_lo_bits(sh)) + 16;      // ylo yhi slo shi | red[8] shr[8]
+  const size_t small = 2 * 16 + 2 * ((size_t)sh.pn >> prep_lo_bits(sh)) + 24;      // ylo yhi slo shi | red[8] shr[16]
   return ((size_t)sh.n_ch_ext + sh.n_targets + small) * 40 + 16 + (first > second ? first : second);
 }
 
@@ -603,7 +603,8 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   uint32_t* shi = slo + 16 * SW;
   uint32_t* red = shi + PH * SW;
   uint32_t* shr = red + 8 * SW;                  // 0: x U  1: a P1  2: b P1  3: c' (plain)  4: a P1 rho Y (plain)  5: c' (Montgomery)  6: rho Y (plain)  7: plain 1
-  uint32_t* zpow = lds + (((uint32_t)(shr + 8 * SW - lds) + 3u) & ~3u);       // region A (16-byte aligned), first life
+                                                 // 8 .. 12: (x U) u, (a P1 rho Y) u, (b P1) u, U u, c' u -- what slots 0, 4, 2, U, 3 are for i >= n1
+  uint32_t* zpow = lds + (((uint32_t)(shr + 16 * SW - lds) + 3u) & ~3u);      // region A (16-byte aligned), first life
   uint32_t* tv = zpow + sh.n_cons * SW;
   uint32_t* zlo = tv;                            // z^(l+1), l < 16              (z^(q+1) = zlo[q & 15] * zhi[q >> 4])
   uint32_t* zhi = tv + 16 * SW;                  // z^(16 h)
@@ -789,10 +790,15 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
       scl tot = scl_zero();
       for (uint32_t wI = 0; wI < (nt >> 6); ++wI) { scl v; ld_scl(v, red + SW * (1 + wI) + z); tot = scl_add(tot, v); }
       st_scl(red, scl_mul(scl_weak(tot), scl_r2()));
-    } else if (t == nt - 1) {                     // c', Montgomery
-      scl c;
-      ld_scl(c, shr + 3 * SW + lane_zero());
-      st_scl(shr + 5 * SW, scl_mul(c, scl_r2()));
+    } else if (t >= nt - 6) {                     // c' in Montgomery form | the generator loop's factors times u
+      const uint32_t w = nt - 1 - t;              // 0: c' R^2 | 1: (x U) u | 2: (a P1 rho Y) u | 3: (b P1) u | 4: U u | 5: c' u
+      scl a, b;
+      ld_scl(a, w == 0 || w == 5 ? shr + 3 * SW : w == 1 ? shr + 0 * SW : w == 2 ? shr + 4 * SW : w == 3 ? shr + 2 * SW : chs + 6 * SW);
+      ld_scl(b, chs + 2 * SW);
+      const scl r2 = scl_r2();
+#pragma unroll
+      for (int q = 0; q < 10; ++q) b.v[q] = w == 0 ? r2.v[q] : b.v[q];
+      st_scl(shr + (w == 0 ? 5 : 7 + w) * SW, scl_mul(a, b));
     }
     __syncthreads();
   }
@@ -891,10 +897,18 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   //   c' g_i = (x U) wR_i yp[pn-1-i] - (a P1 rho Y) sU_i
   //   c' h_i = yp[pn-1-i] ((x U) wL_i + U wO_i - (b P1) sU_(pn-1-i)) - c'        (times u for i >= n1)
   {
-    scl xU, aY_plain, bP, U, u, cp_plain;         // shared by the workgroup: kept in scalar registers
-    ld_scl_shared(xU, shr + 0 * SW); ld_scl_shared(aY_plain, shr + 4 * SW); ld_scl_shared(bP, shr + 2 * SW);
-    ld_scl_shared(U, chs + 6 * SW); ld_scl_shared(u, chs + 2 * SW); ld_scl_shared(cp_plain, shr + 3 * SW);
+    // the factors the whole workgroup shares live in scalar registers.  For i >= n1 (second-phase multipliers and the padding)
+    // both scalars carry the factor u: a wavefront whose lanes are all there reads the copies that already carry it (slots
+    // 8 .. 12: two products less per i), a mixed one multiplies at the end.  (Read per lane from LDS, whichever copy the lane
+    // needs, the factors take 50 vector registers more and the kernel spills.)
     for (uint32_t i = t; i < sh.pn; i += nt) {
+      const bool hi = i >= sh.n1;
+      const bool with_u = __builtin_amdgcn_readfirstlane((int)__all(hi)) != 0;
+      const uint32_t* const f = shr + 8 * SW;
+      scl xU, aY_plain, bP, U, cp_plain;
+      ld_scl_shared(xU, with_u ? f + 0 * SW : shr + 0 * SW); ld_scl_shared(aY_plain, with_u ? f + 1 * SW : shr + 4 * SW);
+      ld_scl_shared(bP, with_u ? f + 2 * SW : shr + 2 * SW); ld_scl_shared(U, with_u ? f + 3 * SW : chs + 6 * SW);
+      ld_scl_shared(cp_plain, with_u ? f + 4 * SW : shr + 3 * SW);
       scl yp, si, sr;
       ld_scl8(yp, yip + 8 * (sh.pn - 1 - i)); ld_scl8(si, sv + 8 * i); ld_scl8(sr, sv + 8 * (sh.pn - 1 - i));
       scl g = scl_neg(scl_mul(aY_plain, si));                 // limbs < 2^27.6, value < 2^260.1
@@ -906,7 +920,12 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
         inner = scl_add(inner, scl_add(scl_mul(xU, wl), scl_mul(U, wo)));   // limbs < 2^28, value < 2^260.2
       }
       scl h = scl_sub(scl_mul(yp, inner), cp_plain);          // yp, c' tight and < 2^255
-      if (i >= sh.n1) { g = scl_mul(g, u); h = scl_mul(h, u); }
+      if (!with_u && __any(hi)) {                             // (a wavefront that straddles n1)
+        scl u;
+        ld_scl_shared(u, chs + 2 * SW);
+        const scl gu = scl_mul(g, u), hu = scl_mul(h, u);
+        if (hi) { g = gu; h = hu; }
+      }
       uint32_t gw[8], hw[8];
       scl_canon_words(gw, g);
       scl_canon_words(hw, h);
