@@ -808,12 +808,13 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
   uint32_t* ss = static_scalars + (uint64_t)tx * sh.n_static * 8;
   // ---- proof-point scalars, B and B_blinding: the last wavefront, BEFORE its share of the generator scalars, so that
   // this short serial tail runs beside the other wavefronts' generator loop instead of after it.  Every lane does the
-  // same three rounds v = a * b with operands of its own, read from LDS where they are needed (a lane that needs fewer
-  // rounds passes its value through); the scalar of B is spread over four lanes: with c' delta = U dsum,
-  //     c' (w (t_x - a b) + r (x^2 (wc + delta) - t_x))  =  c' w (t_x - [a b])  +  r (x^2 ([c' wc] + [U dsum]) - [c' t_x])
-  // lane jB: a b, then w (t_x - .), then c' (.);  jB+1: c' wc, then x^2 (. + U dsum), then r (. - c' t_x);
-  // jB+2: U dsum;  jB+3: c' t_x;  the partial results travel by wavefront shuffles.  The factor c' of everything else
-  // rides on the final Montgomery -> plain conversion (a product with the plain c' instead of with 1).
+  // same two rounds v = a * b with operands of its own, read from LDS where they are needed (a lane that needs fewer
+  // rounds passes its value through), and the conversion; the scalar of B is spread over four lanes: with c' delta = U dsum,
+  //     c' (w (t_x - a b) + r (x^2 (wc + delta) - t_x))  =  c' [w (t_x - [a b])]  +  [r x^2] ([c' wc] + [U dsum]) - r [c' t_x]
+  // lane jB: a b, then w (t_x - .), converted TIMES the plain c';  jB+1: c' wc, then r x^2 (. + U dsum), minus jB+3's product,
+  // converted;  jB+2: U dsum;  jB+3: c' t_x, then r (.);  the partial results travel by wavefront shuffles and the two halves
+  // are added as plain values.  The factor c' of everything else rides on the final Montgomery -> plain conversion too (a
+  // product with the plain c' instead of with 1).
   const uint32_t tail0 = nt - 64;
   if (t >= tail0) {
     const uint32_t lane = t - tail0, n_dyn = sh.n_dyn;
@@ -855,27 +856,27 @@ k_prepare(PrepShape sh, const uint32_t* __restrict__ mono_chal, const uint32_t* 
         const scl pr = scl_mul(a, b);
         if (m1) v = pr;
       }
-      if (pos0 == 0) {                            // rounds 2 and 3: the scalars of B and B_blinding (first pass only, lanes 0..4)
+      if (pos0 == 0) {                            // round 2: the scalars of B and B_blinding (first pass only, lanes 0..4)
         scl other = shfl_down_scl(v, 1);
         bool m2 = false;
         if (pos == 0) { scl tx_; ld_scl(tx_, chs + 8 * SW); ld_scl(a, chs + 4 * SW); b = scl_sub(tx_, v); m2 = true; }       // w (t_x - a b)
-        else if (pos == 1) { ld_scl(a, xp + 0 * SW); b = scl_add(v, other); m2 = true; }                                      // x^2 (c' wc + U dsum)
+        else if (pos == 1) { ld_scl(a, xp + 5 * SW); b = scl_add(v, other); m2 = true; }                                      // r x^2 (c' wc + U dsum)
+        else if (pos == 3) { ld_scl(a, p_r); b = v; m2 = true; }                                                             // r c' t_x
         else if (pos == 4) { scl e; ld_scl(e, chs + 10 * SW); scl sum = scl_add(e, v); scl_carry(sum); v = scl_neg(sum); }    // -(e_blinding + r t_x_blinding)
         const scl pr2 = scl_mul(a, b);
         if (m2) v = pr2;
         other = shfl_down_scl(v, 2);
-        bool m3 = false;
-        if (pos == 0) { ld_scl(a, p_cp); b = v; m3 = true; }                                                                 // c' w (t_x - a b)
-        else if (pos == 1) { ld_scl(a, p_r); b = scl_sub(v, other); m3 = true; }                                             // r (x^2 (..) - c' t_x)
-        const scl pr3 = scl_mul(a, b);
-        if (m3) v = pr3;
-        other = shfl_down_scl(v, 1);
-        if (pos == 0) { v = scl_add(v, other); pconv = shr + 7 * SW; }
-      }
+        if (pos == 1) { v = scl_sub(v, other); pconv = shr + 7 * SW; }                // r (x^2 (..) - c' t_x), converted as it is
+      }                                                                               // (lane 0: w (t_x - a b), converted times c')
       scl conv_by;
       ld_scl(conv_by, pconv);
+      scl plain = scl_mul(v, conv_by);            // Montgomery -> plain, times the plain factor
+      if (pos0 == 0) {                            // B's two halves meet as plain values
+        const scl other = shfl_down_scl(plain, 1);
+        if (pos == 0) plain = scl_add(plain, other);
+      }
       uint32_t o[8];
-      scl_canon_words(o, scl_mul(v, conv_by));    // Montgomery -> canonical words, times the plain factor
+      scl_canon_words(o, plain);
       if (pos >= 5 && j < n_dyn) {
         // the scalar, and its recoded form s + 0x88..8 for k_small_accumulate (digit t = nibble t - 8)
         uint32_t carry = 0;
