@@ -10,7 +10,15 @@
   profiles/pmc_traffic.json                        HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B)
   profiles/pmc_valu.json                           SQ_INSTS_VALU (wave instructions) per launch
 usage: python tools/collect_profiles.py <tag>"""
-import collections, csv, glob, json, os, shutil, subprocess, sys
+import collections, csv, glob as _glob, json, os, shutil, subprocess, sys
+
+
+class glob:     # gpurun MERGES what a call wrote into gpurun_out/: a directory may hold the files of earlier runs too -- newest only
+    @staticmethod
+    def glob(pattern):
+        files = sorted(_glob.glob(pattern), key=os.path.getmtime)
+        return files[-1:]
+
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
