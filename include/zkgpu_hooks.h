@@ -60,8 +60,8 @@ zkgpu_ctx *zkgpu_verifier_lane(zkgpu_verifier *v, int i);
 /* ---- device-side unit tests --------------------------------------------------------------------------------------------- */
 /* the arithmetic layers on their own, one lane per element (a, b, out: n x 32 bytes).  op 0 field product, 1 square,
  * 2 inverse, 3 a + b - b + a, 4 x^((p-5)/8)  (GF(2^255-19): 32 little-endian bytes, canonical out); 10 product mod l
- * (canonical Montgomery form), 11 the same in the lazy limb form, 12 a lazy chain (a-b)(a+b) + 16ab - b, 13 / 14 inverse
- * mod l (canonical / windowed lazy), 15 a + b - a  (scalars: canonical words out, inputs reduced mod l) */
+ * (canonical Montgomery form), 11 the same in the lazy limb form, 12 a lazy chain (a-b)(a+b) + 16ab - b, 13 / 14 / 16 inverse
+ * mod l (a^(l-2) canonical / Euclid / a^(l-2) lazy), 15 a + b - a  (scalars: canonical words out, inputs reduced mod l) */
 int zkgpu_debug_arith(zkgpu_ctx *ctx, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
 /* the cross-lane primitives of the cooperative Keccak on given inputs (in: 3 x 64 words a, b, gather byte addresses; out:
  * 8 x 64 words: row_ror:8(a), row_shr:1(a), row_shl:1(a), permlane16_swap(a, b) -> (a', b'), permlane32_swap(a, b) ->

@@ -59,4 +59,6 @@ def test_scalar_arithmetic_in_both_forms_vs_python_integers(ctx):
     want_inv = [pow(a, L - 2, L) for a in sx]
     assert _run(ctx, 13, xs[:512], ys[:512]) == want_inv[:512]
     assert _run(ctx, 14, xs[:512], ys[:512]) == want_inv[:512]
+    assert _run(ctx, 16, xs[:512], ys[:512]) == want_inv[:512]          # the fixed chain of the lane-per-proof kernels
+    assert _run(ctx, 16, [0, 1, L - 1], [0, 0, 0]) == [0, 1, L - 1]
     assert _run(ctx, 15, xs, ys) == sy

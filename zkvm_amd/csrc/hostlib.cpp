@@ -143,8 +143,9 @@ uint64_t zkhost_scl_selftest(uint64_t seed, uint32_t rounds) {
     if (!same(scm_mul(acc, a), scl_mul(lacc, la))) ++bad;
     // the Euclidean inverse of the device prover against Fermat's
     {
-      const scm inv_f = scm_invert(a), inv_e = pv_invert(a);
+      const scm inv_f = scm_invert(a), inv_e = pv_invert(a), inv_u = pv_invert_uniform(a);
       for (int i = 0; i < 8; ++i) if (inv_f.v[i] != inv_e.v[i]) { ++bad; break; }
+      for (int i = 0; i < 8; ++i) if (inv_f.v[i] != inv_u.v[i]) { ++bad; break; }
     }
     // plain <-> Montgomery
     uint32_t plain[8];
@@ -434,6 +435,7 @@ int zkhost_r1cs_prove(const char* label, uint32_t m, uint32_t n1, uint32_t n, ui
 // with the host prover's and the oracle's.
 namespace {
 struct PvHostEnv {
+  static constexpr bool kInvertInEveryLane = false;
   uint32_t st[52];
   uint32_t tid() const { return 0; }
   uint32_t nt() const { return 1; }

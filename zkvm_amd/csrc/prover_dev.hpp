@@ -312,6 +312,22 @@ ZK_HD_NOINLINE scm pv_invert(scm am) {
   }
   return scm_from_words(is_one(u) ? x1 : x2);
 }
+
+// The same inverse as a^(l-2) in the lazy form, 253 squarings + 63 products whatever a is: for a kernel that inverts in
+// EVERY lane of a wavefront (k_pv_ipa_lanes) -- the Euclidean walk above branches on its data, and 64 lanes walking 64
+// different ways cost the wavefront every branch at every step.  0 -> 0.
+ZK_HD_NOINLINE scm pv_invert_uniform(scm am) {
+  const uint32_t e[8] = ZK_SC_LM2;
+  const scl a = scl_from_scm(am);
+  scl acc = a;                                     // bit 252 of l - 2
+  ZK_NOUNROLL for (int i = 251; i >= 0; --i) {
+    acc = pv_mul(acc, acc);
+    uint32_t word = 0;
+    ZK_UNROLL for (int k = 0; k < 8; ++k) word = (k == (i >> 5)) ? e[k] : word;
+    if ((word >> (i & 31)) & 1) acc = pv_mul(acc, a);
+  }
+  return scl_to_scm(acc);
+}
 ZK_HD scl pv_ldl(const uint32_t* p) { return scl_from_words(p); }                 // same value, limb form
 ZK_HD_NOINLINE void pv_stl(uint32_t* p, scl a) { scl_canon_words(p, a); }         // same value, canonical words
 ZK_HD void pv_st_plain(uint32_t* p, const scl& mont) { pv_stl(p, pv_mul(mont, scl_plain_one())); }   // Montgomery -> the integer's words
@@ -707,7 +723,7 @@ ZK_HD void pv_ipa_round(Env& env, const PvShape& sh, const PvBatch& B, uint32_t 
   const scm u = tr.challenge_scalar(PV_LBL("u"));
   uint32_t* out = B.ipa_u + (uint64_t)proof * 16;
   pv_st_plain(out, scl_from_scm(u));
-  pv_st_plain(out + 8, scl_from_scm(pv_invert(u)));
+  pv_st_plain(out + 8, scl_from_scm(Env::kInvertInEveryLane ? pv_invert_uniform(u) : pv_invert(u)));
   for (int i = 0; i < 52; ++i) V.s[sh.o_tr + i] = tr.w[i];
 }
 

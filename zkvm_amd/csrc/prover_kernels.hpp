@@ -8,6 +8,7 @@ namespace zk {
 constexpr uint32_t PV_LDS_WORDS = 52 + 4 * 6 * 10;   // STROBE scratch | per-wavefront partial sums
 
 struct PvDevEnv {
+  static constexpr bool kInvertInEveryLane = false;
   uint32_t* lds;
   __device__ __forceinline__ uint32_t tid() const { return threadIdx.x; }
   __device__ __forceinline__ uint32_t nt() const { return blockDim.x; }
@@ -130,11 +131,26 @@ k_pv_phase4(PvShape sh, PvPlan P, PvBatch B, const uint32_t* __restrict__ points
   PvDevEnv env{lds};
   pv_phase4(env, sh, P, B, blockIdx.x, points + (uint64_t)blockIdx.x * 40);
 }
+// A round of the inner-product argument with one LANE per proof: the round is one thread's work (L_j, R_j into the transcript,
+// the challenge, its inverse), and with a workgroup per proof (k_pv_ipa, until round 5) 63 lanes of every wavefront idled
+// through ~50 000 instructions -- a fifth of all the wavefront instructions of a proving call (profiles/r05_proverprog_*).  STROBE states side by side in LDS (53 words apart:
+// no bank conflicts), the inverse by the fixed chain pv_invert_uniform.  Byte-identical proofs.
+struct PvLaneEnv {
+  static constexpr bool kInvertInEveryLane = true;
+  uint32_t* st;
+  __device__ __forceinline__ uint32_t tid() const { return 0; }
+  __device__ __forceinline__ uint32_t nt() const { return 1; }
+  __device__ __forceinline__ void sync() {}
+  __device__ __forceinline__ uint32_t* strobe() { return st; }
+  __device__ __forceinline__ void sum(scl*, int) {}
+};
 __global__ void __launch_bounds__(64)
-k_pv_ipa(PvShape sh, PvBatch B, uint32_t round, const uint32_t* __restrict__ points) {
-  __shared__ uint32_t lds[PV_LDS_WORDS];
-  PvDevEnv env{lds};
-  pv_ipa_round(env, sh, B, blockIdx.x, round, points + (uint64_t)blockIdx.x * 16);
+k_pv_ipa_lanes(PvShape sh, PvBatch B, uint32_t round, const uint32_t* __restrict__ points, uint32_t batch) {
+  __shared__ uint32_t lds[64 * 53];
+  const uint32_t proof = blockIdx.x * 64 + threadIdx.x;
+  if (proof >= batch) return;
+  PvLaneEnv env{lds + threadIdx.x * 53};
+  pv_ipa_round(env, sh, B, proof, round, points + (uint64_t)proof * 16);
 }
 __global__ void __launch_bounds__(256)
 k_pv_finish(PvShape sh, PvBatch B, const uint32_t* __restrict__ ab, uint32_t batch, uint32_t* __restrict__ status) {
@@ -149,7 +165,7 @@ k_pv_finish(PvShape sh, PvBatch B, const uint32_t* __restrict__ ab, uint32_t bat
 // ---- test hook: the arithmetic layers alone (zkgpu_debug_arith), one lane per element ------------------------
 // op: 0 fe_mul  1 fe_sq  2 fe_invert  3 fe_add then fe_sub (a + b - b + a)  4 fe_pow22523
 //     10 scm product  11 scl product  12 scl chain ((a - b) (a + b) + 16 a b - b, lazily)  13 inverse mod l (scm_invert)
-//     14 inverse mod l (pv_invert: windows, lazy form)  15 scm sum / difference (a + b, then - a)
+//     14 inverse mod l (pv_invert: Euclid)  15 scm sum / difference (a + b, then - a)  16 inverse mod l (pv_invert_uniform)
 // field elements travel as 32 little-endian bytes (bit 255 ignored on input, canonical on output), scalars as
 // canonical words (inputs are reduced mod l first).
 __global__ void __launch_bounds__(64)
@@ -186,6 +202,7 @@ k_debug_arith(uint32_t op, const uint32_t* __restrict__ a, const uint32_t* __res
       }
       case 13: r = scm_invert(x); break;
       case 14: r = pv_invert(x); break;
+      case 16: r = pv_invert_uniform(x); break;
       default: r = scm_sub(scm_add(x, y), x); break;
     }
     scm_to_words(wo, r);

@@ -2163,7 +2163,7 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
     if (last) break;
     TRY(msm_ps_dev(c, ps, n_ipa_rows, (uint64_t)n_ipa_rows * row_len, (const uint32_t*)c->in_st_scalars.p, (const uint32_t*)c->in_st_index.p,
                    (const uint64_t*)(lb + o_ipa), pts));
-    { Launch l(c, "k_pv_ipa"); hipLaunchKernelGGL(k_pv_ipa, dim3(nb), dim3(64), 0, s, sh, B, round, (const uint32_t*)pts); }
+    { Launch l(c, "k_pv_ipa_lanes"); hipLaunchKernelGGL(k_pv_ipa_lanes, dim3(blocks_for(nb, 64)), dim3(64), 0, s, sh, B, round, (const uint32_t*)pts, nb); }
     len /= 2;
   }
   { Launch l(c, "k_pv_finish"); hipLaunchKernelGGL(k_pv_finish, dim3(blocks_for(batch, 256)), dim3(256), 0, s, sh, B, (const uint32_t*)c->pv_ab.p, nb, (uint32_t*)c->status.p); }
