@@ -320,11 +320,11 @@ ZK_HD_NOINLINE scm pv_invert_uniform(scm am) {
   const uint32_t e[8] = ZK_SC_LM2;
   const scl a = scl_from_scm(am);
   scl acc = a;                                     // bit 252 of l - 2
-  ZK_NOUNROLL for (int i = 251; i >= 0; --i) {
-    acc = pv_mul(acc, acc);
+  ZK_NOUNROLL for (int i = 251; i >= 0; --i) {      // (products inlined: two in a loop body, and a call costs a trip to scratch memory)
+    acc = scl_mul(acc, acc);
     uint32_t word = 0;
     ZK_UNROLL for (int k = 0; k < 8; ++k) word = (k == (i >> 5)) ? e[k] : word;
-    if ((word >> (i & 31)) & 1) acc = pv_mul(acc, a);
+    if ((word >> (i & 31)) & 1) acc = scl_mul(acc, a);
   }
   return scl_to_scm(acc);
 }
