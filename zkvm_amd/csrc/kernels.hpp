@@ -1216,7 +1216,7 @@ k_tbl_multiples(const uint32_t* __restrict__ base, uint32_t* __restrict__ tmp, u
 __global__ void __launch_bounds__(256)
 k_static_digits(const uint32_t* __restrict__ st_scalars, int16_t* __restrict__ digits, uint64_t n_static, int w,
                 int W, uint32_t* __restrict__ status, const uint32_t* __restrict__ row_map /*optional*/,
-                const uint32_t* __restrict__ n_active /*optional*/, uint32_t rows_per_msm) {
+                const uint32_t* __restrict__ n_active /*optional*/, uint32_t rows_per_msm, uint32_t fold_small_negatives) {
   uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_static) return;
   if (row_map) {   // only the terms of the MSMs queued in row_map (uniform rows of rows_per_msm terms)
@@ -1227,6 +1227,18 @@ k_static_digits(const uint32_t* __restrict__ st_scalars, int16_t* __restrict__ d
   const uint32_t* sc = st_scalars + 8 * k;
   if (sc[7] >> 31) atomicOr(&status[0], 2u);
   for (int t = 0; t < W; ++t) digits[(uint64_t)t * n_static + k] = 0;
+  // fold_small_negatives (the prover's commitment rows, whose results are ENCODED: a multiple of l added to a term changes
+  // nothing there): a scalar l - v with 0 < v < 2^14 -- the a_R = -1 of every bit multiplier -- is v on the negated point:
+  // one digit -v in window 0 instead of a non-zero digit in every window.
+  if (fold_small_negatives) {
+    const uint32_t l[8] = ZK_SC_L;
+    uint32_t v[8];
+    uint64_t br = 0;
+    for (int i = 0; i < 8; ++i) { const uint64_t d = (uint64_t)l[i] - sc[i] - br; v[i] = (uint32_t)d; br = (d >> 32) & 1; }
+    uint32_t high = v[0] >> 14;
+    for (int i = 1; i < 8; ++i) high |= v[i];
+    if (br == 0 && high == 0 && v[0] != 0 && w >= 15) { digits[k] = (int16_t)(-(int)v[0]); return; }
+  }
   for_each_digit(sc, w, W, [&](int t, int d) { digits[(uint64_t)t * n_static + k] = (int16_t)d; });
 }
 
@@ -1238,39 +1250,46 @@ k_static_accumulate(const int16_t* __restrict__ digits, const uint64_t* __restri
                     const uint32_t* __restrict__ st_index, const uint32_t* __restrict__ table, uint32_t n_set,
                     uint32_t H, int W, int P, uint32_t n_msm, uint64_t n_static, uint32_t* __restrict__ partials,
                     const uint32_t* __restrict__ row_map /*optional: slot -> MSM*/,
-                    const uint32_t* __restrict__ n_active /*optional: slots in use, device side*/) {
+                    const uint32_t* __restrict__ n_active /*optional: slots in use, device side*/,
+                    uint32_t interleave /*1, or the rows come in groups of this many kinds (the prover's A_I A_O S per proof)*/) {
   const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= (uint64_t)n_msm * W * P) return;
   // window-major lane order: the chip sweeps the table one window slice at a time
   const uint32_t part = (uint32_t)(lane % P);
-  const uint32_t slot = (uint32_t)((lane / P) % n_msm);
+  uint32_t slot = (uint32_t)((lane / P) % n_msm);
   const uint32_t t = (uint32_t)(lane / ((uint64_t)P * n_msm));
   if (n_active && slot >= *n_active) return;
+  // rows of one KIND side by side in a wavefront: their zero digits are in the same places (the a_O = 0 of every bit
+  // multiplier, the windows above the first of a_L = 0 / 1), and an addition that no lane needs is skipped below
+  if (interleave > 1) { const uint32_t per = n_msm / interleave; slot = (slot % per) * interleave + slot / per; }
   const uint32_t tx = row_map ? row_map[slot] : slot;
   const uint64_t k0 = st_offsets[tx], k1 = st_offsets[tx + 1];
   const int16_t* dig = digits + (uint64_t)t * n_static;
   const uint64_t tbase = (uint64_t)t * n_set;
   ge acc;
   ge_identity(acc);
-  auto fetch = [&](uint64_t k, ge_niels& q, bool& neg) {
+  auto fetch = [&](uint64_t k, ge_niels& q, bool& neg, bool& any) {
     int d = dig[k];
     d = (d == -32768) ? 32768 : d;   // w = 16: +2^15 is stored wrapped (the recoding never yields -2^15)
-    const uint32_t idx = st_index ? st_index[k] : (uint32_t)(k - k0);
-    const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-    const uint32_t* row = table + ((tbase + idx) * H + (mag ? mag - 1 : 0)) * TABLE_STRIDE;
-    load_table_row(q, row);
-    if (d == 0) niels_identity(q);
+    any = d != 0;
+    if (any) {
+      const uint32_t idx = st_index ? st_index[k] : (uint32_t)(k - k0);
+      const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+      load_table_row(q, table + ((tbase + idx) * H + (mag - 1)) * TABLE_STRIDE);
+    } else {
+      niels_identity(q);
+    }
     neg = d < 0;
   };
   uint64_t k = k0 + part;
   ge_niels cur, nxt;
-  bool cur_neg = false, nxt_neg = false;
-  if (k < k1) fetch(k, cur, cur_neg);
+  bool cur_neg = false, nxt_neg = false, cur_any = false, nxt_any = false;
+  if (k < k1) fetch(k, cur, cur_neg, cur_any);
   while (k < k1) {
     const uint64_t kn = k + P;
-    if (kn < k1) fetch(kn, nxt, nxt_neg);
-    ge_madd(acc, acc, cur, cur_neg);
-    cur = nxt; cur_neg = nxt_neg;
+    if (kn < k1) fetch(kn, nxt, nxt_neg, nxt_any);
+    if (__any(cur_any)) ge_madd(acc, acc, cur, cur_neg);      // (a lane whose digit is zero adds the identity)
+    cur = nxt; cur_neg = nxt_neg; cur_any = nxt_any;
     k = kn;
   }
   store_ext(partials + (((uint64_t)slot * W + t) * P + part) * EXT_WORDS, acc);

@@ -751,14 +751,14 @@ int batch_device_tables_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_points
     Launch l(c, "k_static_digits", s2);
     hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, s2, job.d_st_scalars,
                        (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p,
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0u);
   }
   {
     Launch l(c, "k_static_accumulate", s2);
     hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s2,
                        (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
                        (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)B, job.n_static, (uint32_t*)c->st_partials.p,
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u);
   }
   HIP_TRY(c, hipEventRecord(c->ev_join, s2));
   HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
@@ -979,7 +979,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
       hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)grp_rows * W * Pg, 256)), dim3(256), 0, H2,
                          (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
                          (uint32_t)ps->n, ps->tbl_H, W, Pg, grp_rows, (uint64_t)grp_rows * ns,
-                         (uint32_t*)c->grp_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                         (uint32_t*)c->grp_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u);
     }
     HIP_TRY(c, hipEventRecord(c->ev_sa, H2));
   } else {
@@ -987,14 +987,14 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
       Launch l(c, "k_static_digits", H2);
       hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, H2, job.d_st_scalars,
                          (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p,
-                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0u);
     }
     {
       Launch l(c, "k_static_accumulate", H2);
       hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, H2,
                          (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
                          (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)B, job.n_static, (uint32_t*)c->st_partials.p,
-                         (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u);
     }
     HIP_TRY(c, hipEventRecord(c->ev_sa, H2));
   }
@@ -1077,13 +1077,13 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
       hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)n_groups * W * Pl, 256)), dim3(256), 0, L,
                          (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
                          (uint32_t)ps->n, ps->tbl_H, W, Pl, n_groups, (uint64_t)n_groups * ns,
-                         (uint32_t*)c->grp_partials.p, (const uint32_t*)nullptr, (const uint32_t*)n_fail);
+                         (uint32_t*)c->grp_partials.p, (const uint32_t*)nullptr, (const uint32_t*)n_fail, 1u);
     }
     if (!locate) {
       Launch l(c, "k_static_digits", L);        // digits of the queued transactions only
       hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(job.n_static, 256)), dim3(256), 0, L, job.d_st_scalars,
                          (int16_t*)c->digits.p, job.n_static, ps->tbl_w, W, (uint32_t*)c->status.p,
-                         (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, ns);
+                         (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, ns, 0u);
     } else if (!spec && !fused_tail) {
       Launch l(c, "k_locate_combine", L);       // names the culprit (or queues the whole group) and writes the digits of the queued
       hipLaunchKernelGGL(k_locate_combine, dim3(n_groups), dim3(256), 0, L, (const uint32_t*)c->grp_partials.p,
@@ -1104,7 +1104,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
       hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)B * W * Pf, 256)), dim3(256), 0, L,
                          (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
                          (uint32_t)ps->n, ps->tbl_H, W, Pf, (uint32_t)B, job.n_static, (uint32_t*)c->st_partials.p,
-                         (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck);
+                         (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, 1u);
     }
     {
       Launch l(c, "k_static_combine", L);
@@ -1875,13 +1875,13 @@ int msm_ps_core(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, uint64_t n
     Launch l(c, "k_static_digits");
     hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_scalars,
                        (int16_t*)c->digits.p, n, ps->tbl_w, W, (uint32_t*)c->status.p, (const uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, 0u);
+                       (const uint32_t*)nullptr, 0u, 0u);
   }
   {
     Launch l(c, "k_static_accumulate");
     hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s, (const int16_t*)c->digits.p,
                        d_offsets, d_index, (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)batch, n,
-                       (uint32_t*)c->st_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                       (uint32_t*)c->st_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u);
   }
   {
     Launch l(c, "k_static_values");
@@ -1999,8 +1999,10 @@ int ipa_on_device(zkgpu_ctx* c, const zkgpu_pointset* ps, std::vector<std::uniqu
 
 // values of `rows` multiscalar multiplications over the tables, everything resident: queued on the context's stream,
 // encodings written to d_out (32 bytes per row)
+// kinds: 1, or the rows come in groups of `kinds` rows of different make per proof (A_I, A_O, S): k_static_accumulate then puts
+// rows of one make side by side in its wavefronts, where their zero digits coincide and the additions nobody needs are skipped
 int msm_ps_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t rows, uint64_t n, const uint32_t* d_scalars, const uint32_t* d_index,
-               const uint64_t* d_offsets, uint32_t* d_out) {
+               const uint64_t* d_offsets, uint32_t* d_out, uint32_t kinds = 1) {
   hipStream_t s = c->stream;
   const int W = ps->tbl_W;
   const int P = (int)std::max<uint64_t>(1, std::min<uint64_t>(64, (131072 + rows * W - 1) / (rows * W)));
@@ -2011,13 +2013,13 @@ int msm_ps_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t rows, uint64_t n, 
   if (n) {
     Launch l(c, "k_static_digits");
     hipLaunchKernelGGL(k_static_digits, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_scalars, (int16_t*)c->digits.p, n, ps->tbl_w, W,
-                       (uint32_t*)c->status.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
+                       (uint32_t*)c->status.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 1u);     // (results are encoded: small negatives folded)
   }
   {
     Launch l(c, "k_static_accumulate");
     hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s, (const int16_t*)c->digits.p, d_offsets,
                        d_index, (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)rows, n,
-                       (uint32_t*)c->st_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                       (uint32_t*)c->st_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, rows % kinds == 0 ? kinds : 1u);
   }
   TRY(ensure(c, c->rechk_pts, rows * EXT_WORDS * 4));       // (free while a prover runs: the verifier's re-check sums)
   {
@@ -2130,7 +2132,7 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
   uint32_t* pts = (uint32_t*)c->pv_pts.p;
   auto msm = [&](int which, const uint32_t* rows, uint32_t* out) {
     return msm_ps_dev(c, ps, lay_rows[which], lay_terms[which], rows, (const uint32_t*)(lb + o_idx[which]),
-                      (const uint64_t*)(lb + o_off[which]), out);
+                      (const uint64_t*)(lb + o_off[which]), out, which == 1 || which == 2 ? 3u : 1u);
   };
   const unsigned nb = (unsigned)batch;
   const double t_setup = now();
