@@ -1245,6 +1245,9 @@ k_static_digits(const uint32_t* __restrict__ st_scalars, int16_t* __restrict__ d
 // lane (tx, t, part): sum over its share of the tx's static terms of
 // sign(d) * table[t][idx][|d|-1]; the next row is fetched while the current
 // addition runs.  partials[((tx * W + t) * P + part)] (extended).
+// kSkipZeros (the prover's rows): a zero digit loads no table row, and an addition that no lane of the wavefront needs is
+// skipped; the verifier's scalars have no zeros to speak of and keep the plain loop.
+template <bool kSkipZeros>
 __global__ void __launch_bounds__(256)
 k_static_accumulate(const int16_t* __restrict__ digits, const uint64_t* __restrict__ st_offsets,
                     const uint32_t* __restrict__ st_index, const uint32_t* __restrict__ table, uint32_t n_set,
@@ -1272,13 +1275,10 @@ k_static_accumulate(const int16_t* __restrict__ digits, const uint64_t* __restri
     int d = dig[k];
     d = (d == -32768) ? 32768 : d;   // w = 16: +2^15 is stored wrapped (the recoding never yields -2^15)
     any = d != 0;
-    if (any) {
-      const uint32_t idx = st_index ? st_index[k] : (uint32_t)(k - k0);
-      const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-      load_table_row(q, table + ((tbase + idx) * H + (mag - 1)) * TABLE_STRIDE);
-    } else {
-      niels_identity(q);
-    }
+    const uint32_t idx = st_index ? st_index[k] : (uint32_t)(k - k0);
+    const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+    if (!kSkipZeros || any) load_table_row(q, table + ((tbase + idx) * H + (mag ? mag - 1 : 0)) * TABLE_STRIDE);
+    if (!any) niels_identity(q);
     neg = d < 0;
   };
   uint64_t k = k0 + part;
@@ -1288,7 +1288,7 @@ k_static_accumulate(const int16_t* __restrict__ digits, const uint64_t* __restri
   while (k < k1) {
     const uint64_t kn = k + P;
     if (kn < k1) fetch(kn, nxt, nxt_neg, nxt_any);
-    if (__any(cur_any)) ge_madd(acc, acc, cur, cur_neg);      // (a lane whose digit is zero adds the identity)
+    if (!kSkipZeros || __any(cur_any)) ge_madd(acc, acc, cur, cur_neg);      // (a lane whose digit is zero adds the identity)
     cur = nxt; cur_neg = nxt_neg; cur_any = nxt_any;
     k = kn;
   }

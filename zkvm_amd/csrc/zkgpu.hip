@@ -755,7 +755,7 @@ int batch_device_tables_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_points
   }
   {
     Launch l(c, "k_static_accumulate", s2);
-    hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s2,
+    hipLaunchKernelGGL(k_static_accumulate<false>, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s2,
                        (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
                        (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)B, job.n_static, (uint32_t*)c->st_partials.p,
                        (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u);
@@ -976,7 +976,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     }
     {
       Launch l(c, "k_static_accumulate", H2);
-      hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)grp_rows * W * Pg, 256)), dim3(256), 0, H2,
+      hipLaunchKernelGGL(k_static_accumulate<false>, dim3(blocks_for((uint64_t)grp_rows * W * Pg, 256)), dim3(256), 0, H2,
                          (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
                          (uint32_t)ps->n, ps->tbl_H, W, Pg, grp_rows, (uint64_t)grp_rows * ns,
                          (uint32_t*)c->grp_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u);
@@ -991,7 +991,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     }
     {
       Launch l(c, "k_static_accumulate", H2);
-      hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, H2,
+      hipLaunchKernelGGL(k_static_accumulate<false>, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, H2,
                          (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
                          (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)B, job.n_static, (uint32_t*)c->st_partials.p,
                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u);
@@ -1074,7 +1074,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     }
     if (locate && !spec && !fused_tail) {
       Launch l(c, "k_static_accumulate", L);
-      hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)n_groups * W * Pl, 256)), dim3(256), 0, L,
+      hipLaunchKernelGGL(k_static_accumulate<false>, dim3(blocks_for((uint64_t)n_groups * W * Pl, 256)), dim3(256), 0, L,
                          (const int16_t*)c->grp_digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
                          (uint32_t)ps->n, ps->tbl_H, W, Pl, n_groups, (uint64_t)n_groups * ns,
                          (uint32_t*)c->grp_partials.p, (const uint32_t*)nullptr, (const uint32_t*)n_fail, 1u);
@@ -1101,7 +1101,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     } else {
       {
       Launch l(c, "k_static_accumulate", L);
-      hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for((uint64_t)B * W * Pf, 256)), dim3(256), 0, L,
+      hipLaunchKernelGGL(k_static_accumulate<false>, dim3(blocks_for((uint64_t)B * W * Pf, 256)), dim3(256), 0, L,
                          (const int16_t*)c->digits.p, job.d_st_offsets, job.d_st_index, (const uint32_t*)ps->table,
                          (uint32_t)ps->n, ps->tbl_H, W, Pf, (uint32_t)B, job.n_static, (uint32_t*)c->st_partials.p,
                          (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, 1u);
@@ -1879,7 +1879,7 @@ int msm_ps_core(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t batch, uint64_t n
   }
   {
     Launch l(c, "k_static_accumulate");
-    hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s, (const int16_t*)c->digits.p,
+    hipLaunchKernelGGL(k_static_accumulate<false>, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s, (const int16_t*)c->digits.p,
                        d_offsets, d_index, (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)batch, n,
                        (uint32_t*)c->st_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u);
   }
@@ -2017,7 +2017,7 @@ int msm_ps_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t rows, uint64_t n, 
   }
   {
     Launch l(c, "k_static_accumulate");
-    hipLaunchKernelGGL(k_static_accumulate, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s, (const int16_t*)c->digits.p, d_offsets,
+    hipLaunchKernelGGL(k_static_accumulate<true>, dim3(blocks_for(n_lanes, 256)), dim3(256), 0, s, (const int16_t*)c->digits.p, d_offsets,
                        d_index, (const uint32_t*)ps->table, (uint32_t)ps->n, ps->tbl_H, W, P, (uint32_t)rows, n,
                        (uint32_t*)c->st_partials.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, rows % kinds == 0 ? kinds : 1u);
   }
