@@ -376,10 +376,11 @@ ZK_HD bool pv_solve(const PvView& V, const PvPlan& P, uint32_t con, uint32_t kin
 }
 
 // assignments of multipliers [first, last): the given ones by all threads, then the defined ones in index order by thread 0
+// (st: 1 the given ones, 2 the defined ones -- see the stages of a phase below)
 template <class Env>
-ZK_HD void pv_assign(Env& env, const PvView& V, const PvPlan& P, const PvBatch& B, uint32_t proof, uint32_t first, uint32_t last) {
+ZK_HD void pv_assign(Env& env, const PvView& V, const PvPlan& P, const PvBatch& B, uint32_t proof, uint32_t first, uint32_t last, uint32_t st = 3) {
   const PvShape& sh = V.sh;
-  for (uint32_t i = first + env.tid(); i < last; i += env.nt()) {
+  if (st & 1) for (uint32_t i = first + env.tid(); i < last; i += env.nt()) {
     const uint32_t slot = P.given_slot[i];
     if (slot == PV_GIVEN) continue;
     const uint32_t* g = B.given + ((uint64_t)proof * sh.n_given + slot) * 16;
@@ -389,7 +390,7 @@ ZK_HD void pv_assign(Env& env, const PvView& V, const PvPlan& P, const PvBatch& 
     pv_stl(V.at(sh.o_aO, i), pv_mul(l, r));
   }
   env.sync();
-  if (env.tid() == 0) {
+  if ((st & 2) && env.tid() == 0) {
     for (uint32_t i = first; i < last; ++i) {
       if (P.given_slot[i] != PV_GIVEN) continue;
       scl l = scl_zero(), r = scl_zero();
@@ -460,10 +461,19 @@ ZK_HD void pv_phase0(Env& env, const PvShape& sh, const PvBatch& B, uint32_t pro
 }
 
 // ---- phase 1: V_j in; first-phase witness, blinding vectors; rows of A_I1 A_O1 S1 ----------------------------
+// STAGES of a phase (st, a mask; PV_ALL = the whole phase in one go, as the host runs it): a phase alternates between work
+// of ONE thread per proof (transcript, challenges, the multipliers defined by constraints, the draws) and work of the whole
+// workgroup.  On the device every stage is a launch of its own: the one-thread stages with one LANE per proof (64 proofs to a
+// wavefront: k_pv_lanes), the others with a workgroup per proof (k_pv_wg) -- inside one kernel the one-thread stages kept one
+// lane of one wavefront busy while the rest of the workgroup waited: 6 % of a call's instructions on 1/64 of the lanes, and
+// the longest part of a workgroup's life.   phase 1, 2: 1 transcript | 2 given multipliers | 4 defined multipliers | 8 rows
+//                                            phase 3: 1 transcript, y z 1/y | 2 tables, flattening, t_i | 4 draws, rows
+//                                            phase 4: 1 transcript .. w | 2 l(x), r(x), generator coefficients
+constexpr uint32_t PV_ALL = 15;
 template <class Env>
-ZK_HD void pv_phase1(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch& B, uint32_t proof, const uint32_t* v_points /*m x 8*/) {
+ZK_HD void pv_phase1(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch& B, uint32_t proof, const uint32_t* v_points /*m x 8*/, uint32_t st = PV_ALL) {
   PvView V{sh, B.state + (uint64_t)proof * sh.state_words};
-  if (env.tid() == 0) {
+  if ((st & 1) && env.tid() == 0) {
     PvStrobe tr{env.strobe()};
     for (int i = 0; i < 52; ++i) tr.w[i] = P.init[i];
     for (uint32_t j = 0; j < sh.m; ++j) tr.append_words(PV_LBL("V"), v_points + 8 * j, 8);
@@ -476,16 +486,16 @@ ZK_HD void pv_phase1(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
     pv_st(V.at(sh.o_sym, 0), scm_one());
   }
   env.sync();
-  pv_assign(env, V, P, B, proof, 0, sh.n1);
-  pv_commit_rows(env, V, B.rows1 + (uint64_t)proof * sh.r1_terms * 8, 0, sh.n1);
+  pv_assign(env, V, P, B, proof, 0, sh.n1, (st >> 1) & 3);
+  if (st & 8) pv_commit_rows(env, V, B.rows1 + (uint64_t)proof * sh.r1_terms * 8, 0, sh.n1);
 }
 
 // ---- phase 2: A_I1 A_O1 S1 in; second-phase challenges and witness; rows of A_I2 A_O2 S2 ----------------------
 template <class Env>
-ZK_HD void pv_phase2(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch& B, uint32_t proof, const uint32_t* pts /*3 x 8*/) {
+ZK_HD void pv_phase2(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch& B, uint32_t proof, const uint32_t* pts /*3 x 8*/, uint32_t st = PV_ALL) {
   PvView V{sh, B.state + (uint64_t)proof * sh.state_words};
   uint8_t* proof_bytes = B.proofs + (uint64_t)proof * sh.proof_stride;
-  if (env.tid() == 0) {
+  if ((st & 1) && env.tid() == 0) {
     PvStrobe tr{env.strobe()};
     for (int i = 0; i < 52; ++i) tr.w[i] = V.s[sh.o_tr + i];
     tr.append_words(PV_LBL("A_I1"), pts, 8);
@@ -513,11 +523,11 @@ ZK_HD void pv_phase2(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
   env.sync();
   const uint32_t n2 = sh.n - sh.n1;
   if (n2 == 0) {                      // three empty rows (the identity), no second-phase blinding factors
-    if (env.tid() == 0) for (int k = PV_IBL2; k <= PV_SBL2; ++k) pv_st(V.at(sh.o_blind, k), scm_zero());
+    if ((st & 1) && env.tid() == 0) for (int k = PV_IBL2; k <= PV_SBL2; ++k) pv_st(V.at(sh.o_blind, k), scm_zero());
     return;
   }
-  pv_assign(env, V, P, B, proof, sh.n1, sh.n);
-  pv_commit_rows(env, V, B.rows2 + (uint64_t)proof * sh.r2_terms * 8, sh.n1, sh.n);   // the drawn part: pv_rng_draw
+  pv_assign(env, V, P, B, proof, sh.n1, sh.n, (st >> 1) & 3);
+  if (st & 8) pv_commit_rows(env, V, B.rows2 + (uint64_t)proof * sh.r2_terms * 8, sh.n1, sh.n);   // the drawn part: pv_rng_draw
 }
 
 // ---- phase 3: A_I2 A_O2 S2 in; y, z; flattening, t(x) coefficients; rows of T_1 T_3 T_4 T_5 T_6 ----------------
@@ -552,10 +562,10 @@ ZK_HD void pv_powers(Env& env, uint32_t* table, const scl& base, uint32_t count)
 }
 
 template <class Env>
-ZK_HD void pv_phase3(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch& B, uint32_t proof, const uint32_t* pts /*3 x 8*/) {
+ZK_HD void pv_phase3(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch& B, uint32_t proof, const uint32_t* pts /*3 x 8*/, uint32_t st = PV_ALL) {
   PvView V{sh, B.state + (uint64_t)proof * sh.state_words};
   uint8_t* proof_bytes = B.proofs + (uint64_t)proof * sh.proof_stride;
-  if (env.tid() == 0) {
+  if ((st & 1) && env.tid() == 0) {
     PvStrobe tr{env.strobe()};
     for (int i = 0; i < 52; ++i) tr.w[i] = V.s[sh.o_tr + i];
     tr.append_words(PV_LBL("A_I2"), pts, 8);
@@ -565,10 +575,11 @@ ZK_HD void pv_phase3(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
     const scm y = tr.challenge_scalar(PV_LBL("y")), z = tr.challenge_scalar(PV_LBL("z"));
     pv_st(V.at(sh.o_chal, PV_Y), y);
     pv_st(V.at(sh.o_chal, PV_Z), z);
-    pv_st(V.at(sh.o_chal, PV_YINV), pv_invert(y));
+    pv_st(V.at(sh.o_chal, PV_YINV), Env::kInvertInEveryLane ? pv_invert_uniform(y) : pv_invert(y));
     for (int i = 0; i < 52; ++i) V.s[sh.o_tr + i] = tr.w[i];
   }
   env.sync();
+  if (st & 2) {
   const scl y = pv_ldl(V.at(sh.o_chal, PV_Y)), z = pv_ldl(V.at(sh.o_chal, PV_Z)), yinv = pv_ldl(V.at(sh.o_chal, PV_YINV));
   // z^(q+1) for q < n_cons: table of z^i shifted by one
   pv_powers(env, V.at(sh.o_zpow), z, sh.n_cons + 1);
@@ -615,8 +626,9 @@ ZK_HD void pv_phase3(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
   }
   for (int k = 0; k < 6; ++k) t[k] = scl_weak(t[k]);
   env.sum(t, 6);                      // thread 0 holds the sums
-  if (env.tid() == 0) {
-    for (int k = 0; k < 6; ++k) pv_stl(V.at(sh.o_t, k + 1), t[k]);
+  if (env.tid() == 0) for (int k = 0; k < 6; ++k) pv_stl(V.at(sh.o_t, k + 1), t[k]);
+  }
+  if ((st & 4) && env.tid() == 0) {
     PvRng rng;
     rng.load(V.s + sh.o_rng);
     if (!rng.fast()) V.s[sh.o_flag] = 2;
@@ -634,11 +646,11 @@ ZK_HD void pv_phase3(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
 
 // ---- phase 4: T points in; u, x; t(x), blindings, l(x), r(x); the start of the inner-product argument ------------
 template <class Env>
-ZK_HD void pv_phase4(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch& B, uint32_t proof, const uint32_t* pts /*5 x 8*/) {
+ZK_HD void pv_phase4(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch& B, uint32_t proof, const uint32_t* pts /*5 x 8*/, uint32_t st = PV_ALL) {
   PvView V{sh, B.state + (uint64_t)proof * sh.state_words};
   uint8_t* proof_bytes = B.proofs + (uint64_t)proof * sh.proof_stride;
   (void)P;
-  if (env.tid() == 0) {
+  if ((st & 1) && env.tid() == 0) {
     PvStrobe tr{env.strobe()};
     for (int i = 0; i < 52; ++i) tr.w[i] = V.s[sh.o_tr + i];
     tr.append_words(PV_LBL("T_1"), pts, 8);
@@ -686,6 +698,7 @@ ZK_HD void pv_phase4(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch
     for (int i = 0; i < 52; ++i) V.s[sh.o_tr + i] = tr.w[i];
   }
   env.sync();
+  if (!(st & 2)) return;
   const scl x = pv_ldl(V.at(sh.o_chal, PV_X)), u = pv_ldl(V.at(sh.o_chal, PV_U));
   const scl x2 = pv_mul(x, x), x3 = pv_mul(x2, x);
   uint32_t* lv = B.ipa_lv + (uint64_t)proof * sh.pn * 8;

@@ -46,12 +46,6 @@ k_pv_phase0(PvShape sh, PvBatch B) {
   PvDevEnv env{lds};
   pv_phase0(env, sh, B, blockIdx.x);
 }
-__global__ void __launch_bounds__(256)
-k_pv_phase1(PvShape sh, PvPlan P, PvBatch B, const uint32_t* __restrict__ points) {
-  __shared__ uint32_t lds[PV_LDS_WORDS];
-  PvDevEnv env{lds};
-  pv_phase1(env, sh, P, B, blockIdx.x, points + (uint64_t)blockIdx.x * sh.m * 8);
-}
 // the TranscriptRng's draws of a commitment phase, one LANE per proof (state in registers, one Keccak-f per draw)
 __global__ void __launch_bounds__(64)
 k_pv_rng(PvShape sh, PvBatch B, uint32_t batch, uint32_t phase) {
@@ -113,24 +107,6 @@ k_pv_rng_coop(PvShape sh, PvBatch B, uint32_t batch, uint32_t phase) {
   if (k.primary) { state[sh.o_rng + 2 * k.q] = lo; state[sh.o_rng + 2 * k.q + 1] = hi; }
   if (lane == 0) { state[sh.o_rng + 50] = 64; state[sh.o_rng + 51] = 0; }
 }
-__global__ void __launch_bounds__(256)
-k_pv_phase2(PvShape sh, PvPlan P, PvBatch B, const uint32_t* __restrict__ points) {
-  __shared__ uint32_t lds[PV_LDS_WORDS];
-  PvDevEnv env{lds};
-  pv_phase2(env, sh, P, B, blockIdx.x, points + (uint64_t)blockIdx.x * 24);
-}
-__global__ void __launch_bounds__(256)
-k_pv_phase3(PvShape sh, PvPlan P, PvBatch B, const uint32_t* __restrict__ points) {
-  __shared__ uint32_t lds[PV_LDS_WORDS];
-  PvDevEnv env{lds};
-  pv_phase3(env, sh, P, B, blockIdx.x, points + (uint64_t)blockIdx.x * 24);
-}
-__global__ void __launch_bounds__(256)
-k_pv_phase4(PvShape sh, PvPlan P, PvBatch B, const uint32_t* __restrict__ points) {
-  __shared__ uint32_t lds[PV_LDS_WORDS];
-  PvDevEnv env{lds};
-  pv_phase4(env, sh, P, B, blockIdx.x, points + (uint64_t)blockIdx.x * 40);
-}
 // A round of the inner-product argument with one LANE per proof: the round is one thread's work (L_j, R_j into the transcript,
 // the challenge, its inverse), and with a workgroup per proof (k_pv_ipa, until round 5) 63 lanes of every wavefront idled
 // through ~50 000 instructions -- a fifth of all the wavefront instructions of a proving call (profiles/r05_proverprog_*).  STROBE states side by side in LDS (53 words apart:
@@ -151,6 +127,32 @@ k_pv_ipa_lanes(PvShape sh, PvBatch B, uint32_t round, const uint32_t* __restrict
   if (proof >= batch) return;
   PvLaneEnv env{lds + threadIdx.x * 53};
   pv_ipa_round(env, sh, B, proof, round, points + (uint64_t)proof * 16);
+}
+
+// The stages of phases 1 .. 4 (prover_dev.hpp, "STAGES of a phase"): PH the phase, ST the stage mask.  k_pv_lanes: a stage
+// that is one thread's work, one lane per proof; k_pv_wg: a stage of the whole workgroup, one workgroup per proof.
+template <int PH, uint32_t ST, class Env>
+__device__ __forceinline__ void pv_stage(Env& env, const PvShape& sh, const PvPlan& P, const PvBatch& B, uint32_t proof, const uint32_t* points) {
+  if (PH == 1) pv_phase1(env, sh, P, B, proof, points + (uint64_t)proof * sh.m * 8, ST);
+  else if (PH == 2) pv_phase2(env, sh, P, B, proof, points + (uint64_t)proof * 24, ST);
+  else if (PH == 3) pv_phase3(env, sh, P, B, proof, points + (uint64_t)proof * 24, ST);
+  else pv_phase4(env, sh, P, B, proof, points + (uint64_t)proof * 40, ST);
+}
+template <int PH, uint32_t ST>
+__global__ void __launch_bounds__(64)
+k_pv_lanes(PvShape sh, PvPlan P, PvBatch B, const uint32_t* __restrict__ points, uint32_t batch) {
+  __shared__ uint32_t lds[64 * 53];
+  const uint32_t proof = blockIdx.x * 64 + threadIdx.x;
+  if (proof >= batch) return;
+  PvLaneEnv env{lds + threadIdx.x * 53};
+  pv_stage<PH, ST>(env, sh, P, B, proof, points);
+}
+template <int PH, uint32_t ST>
+__global__ void __launch_bounds__(256)
+k_pv_wg(PvShape sh, PvPlan P, PvBatch B, const uint32_t* __restrict__ points) {
+  __shared__ uint32_t lds[PV_LDS_WORDS];
+  PvDevEnv env{lds};
+  pv_stage<PH, ST>(env, sh, P, B, blockIdx.x, points);
 }
 __global__ void __launch_bounds__(256)
 k_pv_finish(PvShape sh, PvBatch B, const uint32_t* __restrict__ ab, uint32_t batch, uint32_t* __restrict__ status) {

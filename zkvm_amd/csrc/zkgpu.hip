@@ -2138,7 +2138,11 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
   const double t_setup = now();
   { Launch l(c, "k_pv_phase0"); hipLaunchKernelGGL(k_pv_phase0, dim3(nb), dim3(64), 0, s, sh, B); }
   if (sh.m) TRY(msm(0, B.rows0, (uint32_t*)c->pv_com.p));
-  { Launch l(c, "k_pv_phase1"); hipLaunchKernelGGL(k_pv_phase1, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)c->pv_com.p); }
+  // a phase = its stages, each a launch: one lane per proof where a stage is one thread's work, a workgroup per proof elsewhere
+  const unsigned nbl = blocks_for(nb, 64);
+#define PV_LANES(PH, ST, pts_) { Launch l(c, "k_pv_lanes_" #PH "_" #ST); hipLaunchKernelGGL((k_pv_lanes<PH, ST>), dim3(nbl), dim3(64), 0, s, sh, P, B, (const uint32_t*)(pts_), nb); }
+#define PV_WG(PH, ST, pts_) { Launch l(c, "k_pv_wg_" #PH "_" #ST); hipLaunchKernelGGL((k_pv_wg<PH, ST>), dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)(pts_)); }
+  PV_LANES(1, 1, c->pv_com.p) PV_WG(1, 2, c->pv_com.p) PV_LANES(1, 4, c->pv_com.p) PV_WG(1, 8, c->pv_com.p)
   // the TranscriptRng's draws: one wavefront per proof on the spread Keccak state (k_pv_rng, one lane per proof, is the
   // form the host emulation and the first device version ran; kept for comparison)
   auto rng_launch = [&](uint32_t phase, uint32_t) {
@@ -2147,12 +2151,15 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
   };
   rng_launch(1u, sh.n1);
   TRY(msm(1, B.rows1, pts));
-  { Launch l(c, "k_pv_phase2"); hipLaunchKernelGGL(k_pv_phase2, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)pts); }
+  PV_LANES(2, 1, pts)
+  if (sh.n > sh.n1) { PV_WG(2, 2, pts) PV_LANES(2, 4, pts) PV_WG(2, 8, pts) }
   if (sh.n > sh.n1) rng_launch(2u, sh.n - sh.n1);
   TRY(msm(2, B.rows2, pts));
-  { Launch l(c, "k_pv_phase3"); hipLaunchKernelGGL(k_pv_phase3, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)pts); }
+  PV_LANES(3, 1, pts) PV_WG(3, 2, pts) PV_LANES(3, 4, pts)
   TRY(msm(3, B.rows3, pts));
-  { Launch l(c, "k_pv_phase4"); hipLaunchKernelGGL(k_pv_phase4, dim3(nb), dim3(256), 0, s, sh, P, B, (const uint32_t*)pts); }
+  PV_LANES(4, 1, pts) PV_WG(4, 2, pts)
+#undef PV_LANES
+#undef PV_WG
   size_t len = sh.pn;
   for (uint32_t round = 0; round <= sh.k; ++round) {
     const bool last = round == sh.k;
