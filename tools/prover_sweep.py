@@ -69,6 +69,11 @@ if __name__ == "__main__":
             for slices in (0, 3, 4, 6):
                 for kb in (0, 40, 64):
                     grid.append((kind, batch, 16, slices, {"ZKGPU_STATIC_LDS_KB": str(kb)}))
+    elif which == "stages":                    # after the phases became stages (round 5, last): the slice counts again
+        for kind, batch, sl in (("cloak", 8192, (1, 2, 3, 4, 6)), ("cloak", 4096, (1, 2, 4)), ("cloak", 2048, (1, 2, 3)),
+                                ("program", 4096, (1, 2, 3, 4, 6)), ("program", 2048, (1, 2, 4)), ("program", 1024, (1, 2))):
+            for slices in sl:
+                grid.append((kind, batch, 16, slices, {}))
     elif which == "big":                       # larger calls, more slices
         for kind, batch, sl in (("cloak", 8192, (4, 6, 8)), ("cloak", 6144, (4, 6)), ("program", 4096, (4, 6, 8)), ("program", 3072, (3, 6))):
             for slices in sl:
