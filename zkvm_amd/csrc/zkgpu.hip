@@ -2024,8 +2024,8 @@ int msm_ps_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t rows, uint64_t n, 
   TRY(ensure(c, c->rechk_pts, rows * EXT_WORDS * 4));       // (free while a prover runs: the verifier's re-check sums)
   {
     Launch l(c, "k_static_row_sums");
-    hipLaunchKernelGGL(k_static_row_sums, dim3((unsigned)rows), dim3(64), 0, s, (const uint32_t*)c->st_partials.p, (uint32_t)(W * P),
-                       (uint32_t*)c->rechk_pts.p);
+    hipLaunchKernelGGL(k_static_row_sums, dim3(blocks_for(rows * ROW_SUM_LANES, 64)), dim3(64), 0, s, (const uint32_t*)c->st_partials.p,
+                       (uint32_t)(W * P), (uint32_t)rows, (uint32_t*)c->rechk_pts.p);
   }
   {
     Launch l(c, "k_encode_rows");
