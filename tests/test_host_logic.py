@@ -213,11 +213,18 @@ def test_product_prover_equals_oracle_prover(host, oracle, shape, cap):
         com2 = C.create_string_buffer(64 * len(q))
         proof2 = C.create_string_buffer(4096)
         plen2 = C.c_size_t(0)
-        rc = host.zkhost_prove_dev_cloak(n_in, n_out, qa, b"".join(f), seed, gens, C.c_size_t(cap), com2, proof2,
-                                         C.c_size_t(4096), C.byref(plen2))
-        assert rc == 0
-        assert com2.raw == want_com
-        assert proof2.raw[: plen2.value] == want_proof
+        # ... in one call per phase, and stage by stage in the device's order (one-thread stages on the lane kernels' terms:
+        # the fixed-chain inverse), as k_pv_lanes / k_pv_wg run them
+        for staged in (0, 1):
+            host.zkhost_set_pv_staged(staged)
+            try:
+                rc = host.zkhost_prove_dev_cloak(n_in, n_out, qa, b"".join(f), seed, gens, C.c_size_t(cap), com2, proof2,
+                                                 C.c_size_t(4096), C.byref(plen2))
+            finally:
+                host.zkhost_set_pv_staged(0)
+            assert rc == 0
+            assert com2.raw == want_com
+            assert proof2.raw[: plen2.value] == want_proof, staged
 
 
 def test_lazy_scalar_form_equals_canonical(host):
@@ -379,13 +386,18 @@ def test_described_prover_equals_oracle_gadget_prover(host, oracle, kind, param)
     com2 = C.create_string_buffer(32 * m)
     proof2 = C.create_string_buffer(4096)
     plen2 = C.c_size_t(0)
-    rc = host.zkhost_prove_dev_r1cs(GADGET_LABEL, m, n1, n, len(labels), lab, len(cons), (C.c_uint64 * len(offs))(*offs),
-                                    (C.c_uint8 * nt)(*kinds), (C.c_uint32 * nt)(*idx), coeff, (C.c_int32 * nt)(*chal),
-                                    (C.c_uint32 * nt)(*power), (C.c_uint32 * max(len(mult_def), 1))(*mult_def),
-                                    b"".join(v.to_bytes(32, "little") for v in values), gv, C.c_size_t(len(given)), seed, gens,
-                                    C.c_size_t(cap), com2, proof2, C.c_size_t(4096), C.byref(plen2))
-    assert rc == 0
-    assert com2.raw == want_com and proof2.raw[: plen2.value] == want_proof
+    for staged in (0, 1):                                # (1: stage by stage, as the device runs a phase)
+        host.zkhost_set_pv_staged(staged)
+        try:
+            rc = host.zkhost_prove_dev_r1cs(GADGET_LABEL, m, n1, n, len(labels), lab, len(cons), (C.c_uint64 * len(offs))(*offs),
+                                            (C.c_uint8 * nt)(*kinds), (C.c_uint32 * nt)(*idx), coeff, (C.c_int32 * nt)(*chal),
+                                            (C.c_uint32 * nt)(*power), (C.c_uint32 * max(len(mult_def), 1))(*mult_def),
+                                            b"".join(v.to_bytes(32, "little") for v in values), gv, C.c_size_t(len(given)), seed, gens,
+                                            C.c_size_t(cap), com2, proof2, C.c_size_t(4096), C.byref(plen2))
+        finally:
+            host.zkhost_set_pv_staged(0)
+        assert rc == 0
+        assert com2.raw == want_com and proof2.raw[: plen2.value] == want_proof, staged
 
 
 @pytest.mark.parametrize("seed,shape", [(11, (1, 0, 0)), (12, (2, 1, 0)), (13, (3, 0, 2)), (14, (3, 6, 3)), (15, (2, 9, 2))])
@@ -413,15 +425,19 @@ def test_random_described_systems_device_prover_functions_equal_host_prover(host
     vb = b"".join(v.to_bytes(32, "little") for v in values)
     seed_b = hashlib.sha256(b"random system %d" % seed).digest()
     outs = []
-    for fn in (host.zkhost_r1cs_prove, host.zkhost_prove_dev_r1cs):
+    for fn, staged in ((host.zkhost_r1cs_prove, 0), (host.zkhost_prove_dev_r1cs, 0), (host.zkhost_prove_dev_r1cs, 1)):
         com, proof, plen = C.create_string_buffer(32 * m), C.create_string_buffer(4096), C.c_size_t(0)
-        rc = fn(b"random system", m, n1, n, len(labels), lab, len(cons), (C.c_uint64 * len(offs))(*offs), (C.c_uint8 * nt)(*kinds),
-                (C.c_uint32 * nt)(*idx), coeff, (C.c_int32 * nt)(*chal), (C.c_uint32 * nt)(*power),
-                (C.c_uint32 * max(len(mult_def), 1))(*mult_def), vb, gv, C.c_size_t(len(given)), seed_b, gens, C.c_size_t(cap), com, proof,
-                C.c_size_t(4096), C.byref(plen))
+        host.zkhost_set_pv_staged(staged)
+        try:
+            rc = fn(b"random system", m, n1, n, len(labels), lab, len(cons), (C.c_uint64 * len(offs))(*offs), (C.c_uint8 * nt)(*kinds),
+                    (C.c_uint32 * nt)(*idx), coeff, (C.c_int32 * nt)(*chal), (C.c_uint32 * nt)(*power),
+                    (C.c_uint32 * max(len(mult_def), 1))(*mult_def), vb, gv, C.c_size_t(len(given)), seed_b, gens, C.c_size_t(cap), com, proof,
+                    C.c_size_t(4096), C.byref(plen))
+        finally:
+            host.zkhost_set_pv_staged(0)
         assert rc == 0
         outs.append((com.raw, proof.raw[: plen.value]))
-    assert outs[0] == outs[1] and len(outs[0][1]) > 400
+    assert outs[0] == outs[1] == outs[2] and len(outs[0][1]) > 400
 
 
 def test_host_worker_pool(host):

@@ -434,8 +434,21 @@ int zkhost_r1cs_prove(const char* label, uint32_t m, uint32_t n1, uint32_t n, ui
 // kernels call, the reference multiscalar multiplication of this library between them.  CPU tests compare the bytes
 // with the host prover's and the oracle's.
 namespace {
+// pv_emulate's way through a phase: 0 the whole phase in one call (PV_ALL), 1 stage by stage in the device's order, the
+// one-thread stages on an environment that inverts as the lane kernels do (zkhost_set_pv_staged; the CPU tests run both)
+int g_pv_staged = 0;
 struct PvHostEnv {
   static constexpr bool kInvertInEveryLane = false;
+  uint32_t st[52];
+  uint32_t tid() const { return 0; }
+  uint32_t nt() const { return 1; }
+  void sync() {}
+  void sum(scl*, int) {}
+  uint32_t* strobe() { return st; }
+};
+
+struct PvHostLaneEnv {          // what k_pv_lanes / k_pv_ipa_lanes give a proof: one thread, the fixed-chain inverse
+  static constexpr bool kInvertInEveryLane = true;
   uint32_t st[52];
   uint32_t tid() const { return 0; }
   uint32_t nt() const { return 1; }
@@ -487,19 +500,33 @@ int pv_emulate(const R1csDesc& d, const std::vector<uint32_t>& mult_def, const s
   B.rng_seed = rng_seed.data(); B.proofs = pbytes.data(); B.rows0 = rows0.data(); B.rows1 = rows1.data(); B.rows2 = rows2.data(); B.rows3 = rows3.data();
   B.ipa_lv = lv.data(); B.ipa_rv = rv.data(); B.ipa_cg = cg.data(); B.ipa_ch = ch.data(); B.ipa_w = w.data(); B.ipa_u = uu.data();
   PvHostEnv env;
+  PvHostLaneEnv lane;
+  const bool staged = g_pv_staged != 0;
   std::vector<uint32_t> pts;
   pv_phase0(env, sh, B, 0);
   rows_points(gens, rows0.data(), pv_rows_pairs(sh.m), pts);
   for (size_t i = 0; i < 8 * (size_t)sh.m; ++i) for (int b = 0; b < 4; ++b) commitments[4 * i + b] = (uint8_t)(pts[i] >> (8 * b));
-  pv_phase1(env, sh, P, B, 0, pts.data());
+  if (staged) {
+    pv_phase1(lane, sh, P, B, 0, pts.data(), 1); pv_phase1(env, sh, P, B, 0, pts.data(), 2);
+    pv_phase1(lane, sh, P, B, 0, pts.data(), 4); pv_phase1(env, sh, P, B, 0, pts.data(), 8);
+  } else {
+    pv_phase1(env, sh, P, B, 0, pts.data());
+  }
   pv_rng_draw(sh, state.data(), rows1.data(), 0, sh.n1, PV_IBL1);
   rows_points(gens, rows1.data(), pv_rows_commit(1, 0, sh.n1, cap, false), pts);
-  pv_phase2(env, sh, P, B, 0, pts.data());
+  if (staged) {
+    pv_phase2(lane, sh, P, B, 0, pts.data(), 1);
+    if (sh.n > sh.n1) { pv_phase2(env, sh, P, B, 0, pts.data(), 2); pv_phase2(lane, sh, P, B, 0, pts.data(), 4); pv_phase2(env, sh, P, B, 0, pts.data(), 8); }
+  } else {
+    pv_phase2(env, sh, P, B, 0, pts.data());
+  }
   if (sh.n > sh.n1) pv_rng_draw(sh, state.data(), rows2.data(), sh.n1, sh.n, PV_IBL2);
   rows_points(gens, rows2.data(), pv_rows_commit(1, sh.n1, sh.n, cap, true), pts);
-  pv_phase3(env, sh, P, B, 0, pts.data());
+  if (staged) { pv_phase3(lane, sh, P, B, 0, pts.data(), 1); pv_phase3(env, sh, P, B, 0, pts.data(), 2); pv_phase3(lane, sh, P, B, 0, pts.data(), 4); }
+  else pv_phase3(env, sh, P, B, 0, pts.data());
   rows_points(gens, rows3.data(), pv_rows_pairs(5), pts);
-  pv_phase4(env, sh, P, B, 0, pts.data());
+  if (staged) { pv_phase4(lane, sh, P, B, 0, pts.data(), 1); pv_phase4(env, sh, P, B, 0, pts.data(), 2); }
+  else pv_phase4(env, sh, P, B, 0, pts.data());
   if (state[sh.o_flag]) return -2 - (int)state[sh.o_flag];
   // the inner-product rounds (on the device: k_ipa_round + the tables); here with the host's scalars
   std::vector<Scalar> L(sh.pn), R(sh.pn), G(sh.pn), H(sh.pn);
@@ -531,7 +558,7 @@ int pv_emulate(const R1csDesc& d, const std::vector<uint32_t>& mult_def, const s
     host_rows(gens, rows, lr);
     std::vector<uint32_t> lrw;
     words_of(lr.data(), 16, lrw);
-    pv_ipa_round(env, sh, B, 0, round, lrw.data());
+    if (staged) pv_ipa_round(lane, sh, B, 0, round, lrw.data()); else pv_ipa_round(env, sh, B, 0, round, lrw.data());
     const Scalar u = scalar_of_words(uu.data()), ui = scalar_of_words(uu.data() + 8);
     for (size_t j = 0; j < half; ++j) {
       L[j] = L[j] * u + L[half + j] * ui;
@@ -556,6 +583,7 @@ int pv_emulate(const R1csDesc& d, const std::vector<uint32_t>& mult_def, const s
 }  // namespace
 
 extern "C" {
+void zkhost_set_pv_staged(int on) { g_pv_staged = on; }
 int zkhost_prove_dev_cloak(uint32_t n_in, uint32_t n_out, const uint64_t* quantities, const uint8_t* flavors, const uint8_t seed[32],
                            const uint8_t* generators, size_t gens_capacity, uint8_t* commitments, uint8_t* proof, size_t proof_cap,
                            size_t* proof_len_out) {
