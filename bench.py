@@ -411,7 +411,7 @@ def msm_microbench(ctx, torch, dev):
     return out
 
 
-def prover_program_microbench(ctx, host_threads: int, batch: int = 4096):
+def prover_program_microbench(ctx, host_threads: int, batch: int = 8192):
     """BASELINE configs[4]: R1CS proving of a 1024-constraint program -- here 8 committed values, each shown to lie in
     [0, 2^64): 512 multipliers, 1032 constraints, handed over as DATA (zkgpu_r1cs_prove_batch); every proof verified
     by the device-side verifier through a plan made from the same description."""
@@ -447,7 +447,7 @@ def prover_program_microbench(ctx, host_threads: int, batch: int = 4096):
     counters = prover_leg_counters(ctx, lambda: pr.prove(vals, givens, seeds), dt, "pmc_valu_proverprog", batch, 1024)
     gens.close()
     return {"proofs_per_s": round(batch / dt, 1), "batch": batch, "ms_per_proof": round(dt / batch * 1e3, 4), "device": counters,
-            "slices": 4 if batch >= 4096 else 3 if batch >= 2048 else 2 if batch >= 1024 else 1,
+            "slices": 8 if batch >= 16384 else 4 if batch >= 4096 else 3 if batch >= 2048 else 2 if batch >= 1024 else 1,
             "constraints": len(cons), "multipliers": n, "commitments": m, "proof_bytes": len(proofs[0]), "host_threads": host_threads,
             "host_lockstep_proofs_per_s": round(256 / dt_host, 1),
             "note": "zkgpu_r1cs_prove_batch on a described constraint system (8 x 64-bit range proofs), best of 3 calls, cut by the "
@@ -551,7 +551,7 @@ def tx_verify_microbench(ctx, gens, host_threads: int, verifier=None):
                     "Python marshalling included; the format is an unpinned recollection (opt-in), never part of `value`"}
 
 
-def prover_microbench(ctx, gens, host_threads: int, batch: int = 8192, ctx2=None):
+def prover_microbench(ctx, gens, host_threads: int, batch: int = 16384, ctx2=None):
     """BASELINE configs[4] (prover side): `batch` 2-in/2-out cloak proofs per call; every proof verified by the device verifier."""
     import ctypes as C
     import random
@@ -611,7 +611,7 @@ def prover_microbench(ctx, gens, host_threads: int, batch: int = 8192, ctx2=None
     if own_gens is not None:
         own_gens.close()
     return {"proofs_per_s": round(batch / best, 1), "batch": batch, "ms_per_proof": round(best / batch * 1e3, 4), "device": counters,
-            "generator_table_bits": 16, "slices": 4 if batch >= 4096 else 3 if batch >= 2048 else 2 if batch >= 1024 else 1,
+            "generator_table_bits": 16, "slices": 8 if batch >= 16384 else 4 if batch >= 4096 else 3 if batch >= 2048 else 2 if batch >= 1024 else 1,
             "two_calls_in_flight_proofs_per_s": round(2 * rounds * batch / dt2, 1),
             "host_threads": host_threads, "host_lockstep_proofs_per_s": round(512 / dt_host, 1),
             "note": "zkgpu_cloak_prove_batch on contiguous inputs, time of the library call: the whole proof on the device "

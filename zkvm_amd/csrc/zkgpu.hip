@@ -2281,8 +2281,9 @@ int prover_slice_count(const zkgpu_ctx* c, size_t batch) {
   static const int env = [] { const char* e = getenv("ZKGPU_PROVER_SLICES"); return e ? std::max(1, std::min(8, atoi(e))) : 0; }();
   const int forced = c->prover_slices ? c->prover_slices : env;
   if (forced) return (int)std::min<size_t>((size_t)forced, std::max<size_t>(1, batch));
-  // the sweep (profiles/r05b_prover_sweep_*.jsonl): slices of about a thousand statements
-  return batch >= 4096 ? 4 : batch >= 2048 ? 3 : batch >= 1024 ? 2 : 1;
+  // the sweeps (profiles/r05b_prover_sweep_*.jsonl, r05z_prover_slices_after_stages.jsonl, r05z_prover_bigger_calls.jsonl; DESIGN.md
+  // sec 4.4): slices of one to two thousand statements, at most eight
+  return batch >= 16384 ? 8 : batch >= 4096 ? 4 : batch >= 2048 ? 3 : batch >= 1024 ? 2 : 1;
 }
 
 // one(ctx, lo, hi, host_threads) proves statements [lo, hi) on ctx; c->mu is held by the caller
