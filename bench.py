@@ -59,7 +59,16 @@ _HWQ_PRESET = "GPU_MAX_HW_QUEUES" in os.environ
 # per-kernel timing (zkgpu_profile_*), the HBM copy kernel and the mode switches of the sweeps are hooks of the library
 # (include/zkgpu_hooks.h), not exports: they answer only to a process that asks for them before it loads the library
 os.environ.setdefault("ZKGPU_TEST_HOOKS", "1")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8" if os.environ.get("ZKGPU_BENCH_SHARE_GPU") else "18")
+if os.environ.get("ZKGPU_BENCH_SHARE_GPU"):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+else:
+    # the library does not edit the environment: it recommends (zkgpu_runtime_hint), the host exports -- here, before torch or
+    # anything else in this process has made a HIP call
+    import sys as _sys
+    _sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from zkvm_amd import runtime_hint as _runtime_hint
+    _HWQ_HINT = _runtime_hint()
+    assert _HWQ_HINT[0] != 2, "bench.py: the HIP runtime started before the queue hint could be applied"
 # stdout carries exactly ONE line, the JSON record: whatever libraries print there (RCCL's version banner, gloo's
 # connection chatter) is sent to stderr instead
 _JSON_OUT = os.fdopen(os.dup(1), "w")
@@ -1070,7 +1079,7 @@ def run_config2(args, W):
                             "distinct_step_inputs": n_sets, "exchange": exchange_name, "steps_per_exchange": gather_every if world > 1 else None,
                             "ranks": ranks_info, "per_rank": per_rank, "rccl": roll_call,
                             "control_plane": "gloo (host)" if world > 1 else None, "bringup": W.bringup,
-                            "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "hw_queues_set_by": "caller" if _HWQ_PRESET else "bench.py, before the HIP runtime started",
+                            "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "hw_queues_set_by": "caller" if _HWQ_PRESET else "bench.py on zkgpu_runtime_hint's advice, before the HIP runtime started",
                             "parallelism": "tx-sharded x%d, RCCL all-gather of accept bitmaps" % world})
         line["roofline"] = roofline_object(solo, launches, in_flight_ms, alg_dev, dev_batch, ms_per_dev_batch, table_bytes,
                                            "algorithmic bytes per launch = %d B per transaction (64 B x %d proof-specific terms + 32 B x "

@@ -71,6 +71,22 @@ const char *zkgpu_strerror(int code);
 /* Human-readable detail of the last failing HIP call on this context. */
 const char *zkgpu_last_error(const zkgpu_ctx *ctx);
 
+/* The library never edits the process environment.  What it needs from it is ONE HIP runtime variable that the runtime
+ * reads when it starts: call this BEFORE the process's first HIP call (before zkgpu_init, before anything else that touches
+ * the GPU) and export what it writes into buf -- "NAME=value", NUL-terminated, today "GPU_MAX_HW_QUEUES=18" (why 18:
+ * DESIGN.md sec 5.1) -- with the host language's own setenv.  Returns
+ *   ZKGPU_HINT_APPLY   (0) the variable is unset and the runtime has not started: export it now, it will count;
+ *   ZKGPU_HINT_PRESENT (1) the caller has set the variable already: nothing to do (buf still holds the recommendation);
+ *   ZKGPU_HINT_LATE    (2) the runtime is up without it: exporting changes nothing now; the process runs on the runtime's
+ *                          default of 4 queues, verdicts are unaffected, batches in flight take turns; remembered and
+ *                          reported by zkgpu_ctx_queue_info / zkgpu_verifier_queue_info / zkgpu_verifier_last_error.
+ * A process that never calls it and never sets the variable is treated as LATE by its first zkgpu_init.
+ * (Replaces the setenv zkgpu_init used to do itself: an embedding application's environment is not the library's to edit.) */
+#define ZKGPU_HINT_APPLY 0
+#define ZKGPU_HINT_PRESENT 1
+#define ZKGPU_HINT_LATE 2
+int zkgpu_runtime_hint(char *buf, size_t cap);
+
 /* Create a context on HIP device `device`. */
 int zkgpu_init(int device, zkgpu_ctx **out);
 void zkgpu_destroy(zkgpu_ctx *ctx);
@@ -384,8 +400,7 @@ void zkgpu_verifier_destroy(zkgpu_verifier *v);
 int zkgpu_verifier_set_chunk(zkgpu_verifier *v, size_t transactions);
 int zkgpu_verifier_lanes(const zkgpu_verifier *v);
 /* Hardware queues.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES queues (default 4; read ONCE, when the runtime
- * starts: zkgpu_init sets it to 24 if unset, which only counts when no HIP call came before -- an embedding application
- * that touches HIP first must export it itself).  Measured on MI355X (profiles/r03_hw_queues.txt): on 4 - 8 queues every
+ * starts: the host exports what zkgpu_runtime_hint recommends BEFORE its first HIP call; the library itself never sets it).  Measured on MI355X (profiles/r03_hw_queues.txt): on 4 - 8 queues every
  * pair of streams still overlaps, but batches in flight that wait for each other's events take turns (a mixed block: 1.3
  * instead of 2.0 M tx/s); from 12 queues on that is gone, but the device runs fewer queues side by side than the runtime
  * hands out, and a lane whose light stream lands on a queue that is not co-scheduled with another lane's alternates with
@@ -547,8 +562,8 @@ int zkgpu_verifier_verify_sharded(zkgpu_verifier *v, zkgpu_comm *comm, size_t ba
  *   ZKGPU_TIMELINE=<file>     with profiling on, every launch as "ctx kernel start_ms end_ms"
  *   ZKGPU_PROVER_TIMING=1     the provers and zkgpu_tx_verify_batch print per-phase host / device times to stderr
  *   ZKGPU_PROVER_SLICES=n     slices of a prover call in flight together (default: 2 from 1024 statements on)
- * and GPU_MAX_HW_QUEUES (a HIP runtime variable): zkgpu_init sets it to 18 if it is unset and the
- * runtime has not started; batches in flight need a hardware queue per context. */
+ * and GPU_MAX_HW_QUEUES (a HIP runtime variable, READ only: the host exports it on zkgpu_runtime_hint's advice before its
+ * first HIP call; batches in flight need a hardware queue per context). */
 const void *zkgpu_hook(const char *name);
 
 #if defined(__GNUC__)

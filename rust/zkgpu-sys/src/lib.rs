@@ -18,6 +18,9 @@ pub const ZKGPU_ENODEVICE: c_int = -5;
 pub const ZKGPU_ENOCOMM: c_int = -6;
 pub const ZKGPU_EREMOTE: c_int = -7;
 pub const ZKGPU_WSECOND_VERIFIER: c_int = 1;
+pub const ZKGPU_HINT_APPLY: c_int = 0;
+pub const ZKGPU_HINT_PRESENT: c_int = 1;
+pub const ZKGPU_HINT_LATE: c_int = 2;
 pub const ZKGPU_TXFORMAT_RECOLLECTED_V1: c_int = 1;
 pub const ZKGPU_COMM_ID_BYTES: usize = 128;
 
@@ -71,6 +74,7 @@ extern "C" {
     pub fn zkgpu_abi_version() -> c_int;
     pub fn zkgpu_strerror(code: c_int) -> *const c_char;
     pub fn zkgpu_last_error(ctx: *const zkgpu_ctx) -> *const c_char;
+    pub fn zkgpu_runtime_hint(buf: *mut c_char, cap: usize) -> c_int;
     pub fn zkgpu_init(device: c_int, out: *mut *mut zkgpu_ctx) -> c_int;
     pub fn zkgpu_destroy(ctx: *mut zkgpu_ctx);
     pub fn zkgpu_msm(

@@ -162,6 +162,9 @@ impl GpuVerifier {
         if abi != 3 {
             return Err(Error::AbiMismatch(abi));
         }
+        // the library never edits the environment: it recommends, the host exports (a no-op once HIP has started or the
+        // application has set the variable itself; call `apply_runtime_hint()` earlier if the application touches HIP first)
+        apply_runtime_hint();
         let mut ctx: *mut sys::zkgpu_ctx = ptr::null_mut();
         check(unsafe { sys::zkgpu_init(device as c_int, &mut ctx) }, String::new)?;
         let ctx_err = |c: *mut sys::zkgpu_ctx| move || text(unsafe { sys::zkgpu_last_error(c) });
@@ -512,6 +515,24 @@ impl Drop for Comm {
 }
 
 /// Text of a status code (`zkgpu_strerror`).
+/// `zkgpu_runtime_hint`: exports what the library recommends ("GPU_MAX_HW_QUEUES=18") with `std::env::set_var` when the
+/// answer is `ZKGPU_HINT_APPLY` (variable unset, HIP runtime not started).  Returns the library's answer
+/// (0 applied, 1 already present, 2 too late: the process runs on the runtime's default, reported by `queue_info`).
+/// Call it before the process's first HIP call, on the main thread before other threads read the environment.
+pub fn apply_runtime_hint() -> i32 {
+    let mut buf = [0 as std::os::raw::c_char; 128];
+    let rc = unsafe { sys::zkgpu_runtime_hint(buf.as_mut_ptr(), buf.len()) };
+    if rc == sys::ZKGPU_HINT_APPLY as i32 {
+        let text = unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned();
+        for pair in text.split('\n') {
+            if let Some((name, value)) = pair.split_once('=') {
+                std::env::set_var(name, value);
+            }
+        }
+    }
+    rc
+}
+
 pub fn strerror(code: i32) -> String {
     text(unsafe { sys::zkgpu_strerror(code as c_int) })
 }

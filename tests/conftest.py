@@ -10,6 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("ZKGPU_TEST_HOOKS", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the library never edits the environment; the host exports what zkgpu_runtime_hint recommends before its first HIP call
+# (GPU_MAX_HW_QUEUES).  Here, before any test has touched the GPU.  (Not built yet: the tests that need it say so.)
+try:
+    from zkvm_amd import runtime_hint
+    runtime_hint()
+except Exception:
+    pass
 
 
 def pytest_configure(config):

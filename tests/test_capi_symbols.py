@@ -92,3 +92,39 @@ def test_hooks_are_not_exports_and_answer_only_to_a_process_that_asked_for_them(
         out[on] = r.stdout.strip().splitlines()[-3:]
     assert out[""] == ["0", "0", "raised -1"]                     # nothing answers; the binding raises ZKGPU_EINVAL
     assert out["1"] == [str(len(hooks)), "0", "0"]                # every hook answers (an export is not a hook); the mock switch works
+
+
+def test_the_library_never_edits_the_environment_it_only_recommends(lib):
+    """no setenv / putenv anywhere under zkvm_amd/csrc; zkgpu_runtime_hint writes its recommendation into
+    the caller's buffer, answers APPLY (unset, runtime not started) or PRESENT (the caller set it) without a GPU, and
+    leaves the environment exactly as it found it -- exporting is the host's act (zkvm_amd.runtime_hint, os.environ)."""
+    import ctypes
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "zkvm_amd", "csrc")
+    for f in os.listdir(csrc):
+        text = re.sub(r"//[^\n]*|/\*.*?\*/", "", open(os.path.join(csrc, f), errors="ignore").read(), flags=re.S)
+        assert not re.search(r"\b(setenv|putenv|unsetenv)\s*\(", text), f
+    child = r"""
+import ctypes, os, sys
+sys.path.insert(0, %r)
+os.environ.pop("GPU_MAX_HW_QUEUES", None)
+from zkvm_amd import native
+lib = native.load_library()
+buf = ctypes.create_string_buffer(64)
+before = dict(os.environ)
+rc = lib.zkgpu_runtime_hint(buf, 64)
+libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p
+assert rc == 0 and buf.value == b"GPU_MAX_HW_QUEUES=18" and libc.getenv(b"GPU_MAX_HW_QUEUES") is None, (rc, buf.value)
+small = ctypes.create_string_buffer(8)
+assert lib.zkgpu_runtime_hint(small, 8) == 0 and small.value == b"GPU_MAX"          # truncated, terminated
+assert lib.zkgpu_runtime_hint(None, 0) == 0
+rc2, text = native.runtime_hint()                                                     # the HOST applies it
+assert rc2 == 0 and os.environ["GPU_MAX_HW_QUEUES"] == "18" and libc.getenv(b"GPU_MAX_HW_QUEUES") == b"18"
+assert lib.zkgpu_runtime_hint(buf, 64) == 1                                          # present now
+os.environ["GPU_MAX_HW_QUEUES"] = "12"
+assert native.runtime_hint() == (1, "GPU_MAX_HW_QUEUES=18") and os.environ["GPU_MAX_HW_QUEUES"] == "12"   # the caller's choice stays
+print("HINT OK")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=120)
+    assert "HINT OK" in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])

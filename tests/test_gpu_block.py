@@ -438,7 +438,7 @@ def test_synchronous_calls_never_run_over_a_batch_in_flight(ctx, oracle):
 
 def test_lanes_are_probed_for_hardware_queues_and_a_late_environment_is_noticed(ctx, oracle):
     """zkgpu_verifier_create keeps only lanes whose streams really run side by side.  In this process (GPU_MAX_HW_QUEUES
-    set before HIP started: zkgpu_init did it) the context's stream pair overlaps and a ten-lane verifier keeps at least
+    set before HIP started: conftest.py did, on zkgpu_runtime_hint's advice) the context's stream pair overlaps and a ten-lane verifier keeps at least
     four lanes (the device runs fewer queues side by side than the runtime hands out: the rest are dropped, and counted);
     in a child process whose HIP runtime starts BEFORE the variable is set -- an embedding application that touched HIP
     first: the runtime's default of four queues, on which batches in flight take turns -- the library notices (the
@@ -470,7 +470,7 @@ sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
 from gpu_util import bits, load_cloak_fixture
 from zkvm_amd import Context
 from zkvm_amd.verifier import BlockVerifier, BulletproofGens, CloakTx
-ctx = Context(0)                                          # sets the variable -- too late
+ctx = Context(0)                                          # asks zkgpu_runtime_hint: too late, says the library
 gens = BulletproofGens(ctx, 256, table_bits=8)
 bv = BlockVerifier(ctx, gens, batches_in_flight=10)
 used, asked, dropped, late = bv.queue_info()

@@ -29,7 +29,7 @@ for _ in range(4):
     bm, st = bv.verify_txs_packed(blob, lens)
     dt = time.perf_counter() - t0
     print("%.2f ms, %.0f tx/s (%d transactions per call)" % (dt * 1e3, len(txs) / dt, len(txs)), file=sys.stderr)
-assert os.environ.get("ZKGPU_TEST_TX_FREE_HASHING") == "1" or not any(st)      # (the measurement hook makes every signature fail)
+assert os.environ.get("ZKGPU_TEST_TX_FREE_HASHING") == "1" or not any(st)      # (a -DZK_MEASURE_FREE_HASHING build with that variable set makes every signature fail)
 # the library call alone (offsets and output buffers made beforehand)
 offs = np.zeros(len(lens) + 1, dtype=np.uint64)
 np.cumsum(np.asarray(lens, dtype=np.uint64), out=offs[1:])

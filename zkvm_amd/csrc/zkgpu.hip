@@ -1240,7 +1240,7 @@ const char* zkgpu_strerror(int code) {
 const char* zkgpu_last_error(const zkgpu_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 namespace {
-bool g_hw_queues_late = false;     // GPU_MAX_HW_QUEUES was unset when the HIP runtime started, before the first zkgpu_init
+bool g_hw_queues_late = false;     // GPU_MAX_HW_QUEUES was unset when the HIP runtime started (seen by zkgpu_runtime_hint or the first zkgpu_init)
 
 // is the compute driver's device node open in this process (= has the HIP / HSA runtime started)?
 bool kfd_is_open() {
@@ -1357,30 +1357,32 @@ int ctx_create(int device, zkgpu_ctx* parent, zkgpu_ctx** out, int aux = 0) {
 }
 }  // namespace
 
+// What the host should have exported before its first HIP call.  18, not more: the runtime keeps that many queues PER
+// PRIORITY; a verifier's high-priority streams take all of them, its low-priority and default-priority streams (2 + 2) come on
+// top, and from 25 queues in all the device no longer runs them side by side -- which ones wait is a per-process lottery
+// (measured, profiles/archive/r04v_tx_hwq.txt, r04w_hwq_bench.txt: a 32 768-transaction call at 16.1-18.8 ms in every process
+// with 18; 16.5-18.5 OR 23-53 ms, one process in four, with 20 / 24; headline, steady state and config 4 equal at 16 / 18 / 24).
+// The variable is read ONCE, when the HIP runtime starts (the kernel driver's device node opened in this process): after
+// that, setting it changes nothing -- answer 2, remembered, and reported by zkgpu_ctx_queue_info and zkgpu_verifier_create.
+int zkgpu_runtime_hint(char* buf, size_t cap) {
+  static const char kHint[] = "GPU_MAX_HW_QUEUES=18";
+  if (buf && cap) { strncpy(buf, kHint, cap - 1); buf[cap - 1] = 0; }
+  if (getenv("GPU_MAX_HW_QUEUES")) return g_hw_queues_late ? ZKGPU_HINT_LATE : ZKGPU_HINT_PRESENT;
+  if (kfd_is_open()) { g_hw_queues_late = true; return ZKGPU_HINT_LATE; }
+  return ZKGPU_HINT_APPLY;
+}
+
 int zkgpu_init(int device, zkgpu_ctx** out) {
   if (!out) return ZKGPU_EINVAL;
   *out = nullptr;
-  // Batches in flight use a stream each plus six shared ones; the runtime maps streams onto 4
-  // hardware queues unless told otherwise, and streams that share a queue while waiting on each
-  // other's events crawl.  Only effective if the HIP runtime has not started yet in this process
-  // (otherwise the embedding application must export it itself); never overrides the caller.
-  // 18, not more: the runtime keeps that many queues PER PRIORITY; a verifier's high-priority streams take all of them, its
-  // low-priority and default-priority streams (2 + 2) come on top, and from 25 queues in all the device no longer runs them
-  // side by side -- which ones wait is a per-process lottery (measured, profiles/r04v_tx_hwq.txt, r04w_hwq_bench.txt: a
-  // 32 768-transaction call at 16.1-18.8 ms in every process with 18; 16.5-18.5 OR 23-53 ms, one process in four, with 20 / 24;
-  // headline, steady state and config 4 equal at 16 / 18 / 24).  DESIGN.md sec 5.1.
+  // Batches in flight use a stream each plus six shared ones; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
+  // queues (4 unless the process exported more BEFORE its first HIP call), and streams that share a queue while waiting on
+  // each other's events crawl.  The library does NOT edit the process environment: the host asks
+  // zkgpu_runtime_hint() what to export and exports it itself.  Here it is only noticed when nobody did: the process then runs
+  // on the runtime's default, reported by zkgpu_ctx_queue_info / zkgpu_verifier_create.  DESIGN.md sec 5.1.
   {
-    // The variable is read ONCE, when the HIP runtime starts.  Unset and the runtime not yet started (the kernel driver's
-    // device node not yet open in this process): set it, it will count.  Unset and the runtime already up -- an embedding
-    // application that touched HIP first: setting it changes nothing, the process runs on the runtime's default of 4
-    // queues, on which batches in flight that wait for each other's events take turns (measured: a mixed block at 1.3
-    // instead of 2.0 M tx/s) -- remembered, and reported by zkgpu_ctx_queue_info and zkgpu_verifier_create.
     static std::once_flag once;
-    std::call_once(once, [] {
-      if (getenv("GPU_MAX_HW_QUEUES")) return;
-      g_hw_queues_late = kfd_is_open();
-      setenv("GPU_MAX_HW_QUEUES", "18", 0);
-    });
+    std::call_once(once, [] { if (!getenv("GPU_MAX_HW_QUEUES")) g_hw_queues_late = true; });
   }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ZKGPU_ENODEVICE;

@@ -494,18 +494,22 @@ inline void tx_structure(const uint8_t* tx, size_t len, TxStatement& st, TxPlan&
 }
 
 // after the plan has run: the transaction ID and the MuSig coefficients move from the slots into the statement
-// MEASUREMENT hook (ZKGPU_TEST_HOOKS=1 and ZKGPU_TEST_TX_FREE_HASHING=1 in the environment): every Merlin hash of the host
-// side -- contract ids, anchors, the transaction-ID tree, the MuSig factors, the signature challenge -- is SKIPPED (slots read
-// zero, c = 1).  Verdicts are then wrong (signatures fail); the device does the same work.  It bounds from above what replaying
-// the hash plans on the device could ever give a call or the calls-in-flight leg: the host's hashing for free.
+// MEASUREMENT BUILDS ONLY (-DZK_MEASURE_FREE_HASHING, tools/build_variant.sh; like ZK_PREP_STAMPS): every Merlin hash of the
+// host side -- contract ids, anchors, the transaction-ID tree, the MuSig factors, the signature challenge -- is SKIPPED (slots
+// read zero, c = 1) when ZKGPU_TEST_TX_FREE_HASHING=1.  Verdicts are then wrong; the device does the same work.  It bounds from
+// above what replaying the hash plans on the device could give.  The shipped library has no such branch: nothing in the
+// environment can make it skip a hash (a verification bypass must not be one variable away).
+#ifdef ZK_MEASURE_FREE_HASHING
 inline bool tx_free_hashing_hook() {
   static const bool on = [] {
-    const char* h = std::getenv("ZKGPU_TEST_HOOKS");
     const char* f = std::getenv("ZKGPU_TEST_TX_FREE_HASHING");
-    return h && h[0] == '1' && f && f[0] == '1';
+    return f && f[0] == '1';
   }();
   return on;
 }
+#else
+constexpr bool tx_free_hashing_hook() { return false; }
+#endif
 
 inline void tx_finish_hashes(TxStatement& st, const TxSlots& out, const uint8_t* slots) {
   std::memcpy(st.txid, slots + 32 * (size_t)out.txid, 32);

@@ -199,9 +199,30 @@ def load_library():
     lib.zkgpu_r1cs_verify_batch.argtypes = [vp, vp, vp, sz, sz, u8p, u8p, sz, u8p, u8p, C.c_int]
     lib.zkgpu_r1cs_prove_batch.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), sz, sz, u8p, u8p, u8p, sz, u8p, C.c_int, u8p, u8p, sz,
                                            C.POINTER(sz)]
+    lib.zkgpu_runtime_hint.argtypes = [C.c_char_p, sz]
     _bind_hooks(lib)
     _LIB = lib
     return lib
+
+
+HINT_APPLY, HINT_PRESENT, HINT_LATE = 0, 1, 2
+
+
+def runtime_hint(apply: bool = True) -> Tuple[int, str]:
+    """zkgpu_runtime_hint: what the host should export before its first HIP call ("GPU_MAX_HW_QUEUES=18").  The library
+    never edits the environment; THIS is the host side doing it (os.environ, i.e. the host language's own setenv) when the
+    answer is HINT_APPLY.  Returns (answer, "NAME=value").  Context() calls it, so a Python host that creates its Context
+    before it touches torch.cuda / HIP needs nothing else; one that touches HIP first calls it first (bench.py does)."""
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    rc = lib.zkgpu_runtime_hint(buf, len(buf))
+    text = buf.value.decode()
+    if rc == HINT_APPLY and apply:
+        for pair in text.split("\n"):
+            name, _, value = pair.partition("=")
+            if name:
+                os.environ[name] = value
+    return rc, text
 
 
 def _ptr(x) -> int:
@@ -263,6 +284,7 @@ class Context:
         if _parent is not None:
             rc = self.lib.zkgpu_ctx_fork(_parent.h, C.byref(self.h))
         else:
+            runtime_hint()             # (the host's own setenv, before the first HIP call; a no-op afterwards)
             rc = self.lib.zkgpu_init(device, C.byref(self.h))
         if rc != OK:
             raise ZkGpuError(rc, self.lib.zkgpu_strerror(rc).decode() + " (libzkgpu needs a HIP device; no CPU fallback)")
