@@ -5,9 +5,10 @@
  * ZKGPU_TEST_HOOKS=1 was in the environment at the time the library was loaded and NULL otherwise.  tests/conftest.py and
  * bench.py set the variable; a deployed verifier never does, `rust/zkgpu-sys` does not bind them, and a C program cannot
  * link against them.  The declarations below are the signatures to cast the returned pointer to (zkvm_amd/native.py does).
- * No hook changes a result: every mode yields the same verdicts / proofs (the tests run every mode).
+ * No hook changes a result: every mode yields the same verdicts / proofs (the tests run every mode); the one hook that
+ * interferes at all, zkgpu_debug_fail_after, can only turn a call into an ERROR (all outputs zero), never into an accept.
  *
- * (Until round 4 these 24, and zkgpu_set_prover_mode among them, were exports of zkgpu.h; VERDICT r04 "ABI sprawl".)
+ * (Until round 4 the first 24 of these, and zkgpu_set_prover_mode among them, were exports of zkgpu.h; VERDICT r04 "ABI sprawl".)
  */
 #ifndef ZKGPU_HOOKS_H
 #define ZKGPU_HOOKS_H
@@ -85,11 +86,19 @@ int zkgpu_cloak_plan_layout(const zkgpu_cloak_plan *plan, uint32_t layout[8]);
 long long zkgpu_debug_force_regroup(zkgpu_ctx *ctx, int on);
 /* world > 0 replaces the collective function table by an in-process mock of a world of `world` ranks whose other ranks
  * contribute peer_slots (world x slot_bytes bytes), so that the exchange step can be exercised at world 2 .. 8 on one
- * GPU; world = 0 restores RCCL.  Returns the all-gathers the mock has served.  A communicator keeps the function table it
+ * GPU; world = 0 restores RCCL; world < 0 only asks.  Returns the all-gathers the mock has served.  A communicator keeps the function table it
  * was created with for its whole life, whatever the switch does afterwards.
  * (A second rehearsal aid lives in the environment: ZKGPU_TEST_COMM_STALL="init:<rank>|init:all|gather:<rank>|gather:all"
  * beside ZKGPU_TEST_HOOKS=1 makes ncclCommInitRank / the first ncclAllGather of the named rank never return.) */
 long long zkgpu_debug_comm_mock(zkgpu_ctx *ctx, int world, const uint8_t *peer_slots, size_t slot_bytes);
+/* Fault injection (csrc/fault_gate.hpp): the n-th HIP runtime call the library makes from now on -- allocation, copy, event,
+ * stream, synchronisation, the hipGetLastError that collects a launch -- reports hipErrorUnknown WITHOUT being made (the device
+ * is untouched); n < 0: the |n|-th call and every one after it (a lost device); n = 0: disarm.  Process-wide (ctx is ignored:
+ * lanes, slices and staging threads are contexts of their own).  Returns the number of calls that passed the gate since it was
+ * last armed; *fired (may be NULL) = how many of them were answered "failed".  The gate can only turn a success into an error:
+ * what the tests assert is that every such error ends in a nonzero status, outputs all zero, nothing hung, and a library that
+ * verifies the next clean batch correctly.  (Clean-up on an error path runs with the gate held open.) */
+long long zkgpu_debug_fail_after(zkgpu_ctx *ctx, long long n, long long *fired);
 
 #ifdef __cplusplus
 }

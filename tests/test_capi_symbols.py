@@ -62,7 +62,7 @@ def _hooks_declared():
 
 
 def test_hooks_are_not_exports_and_answer_only_to_a_process_that_asked_for_them():
-    """VERDICT r04 "ABI sprawl" / ADVICE r03: the 24 measurement, tuning and test hooks (include/zkgpu_hooks.h) are not in
+    """VERDICT r04 "ABI sprawl" / ADVICE r03: the 25 measurement, tuning and test hooks (include/zkgpu_hooks.h) are not in
     the library's symbol table and not in zkgpu.h; `zkgpu_hook(name)` answers NULL unless ZKGPU_TEST_HOOKS=1 was in the
     environment BEFORE the library was loaded (fresh interpreters: the answer is read once per process), and the Python
     binding's attribute then raises instead of calling anything."""
@@ -71,7 +71,7 @@ def test_hooks_are_not_exports_and_answer_only_to_a_process_that_asked_for_them(
     from zkvm_amd import build
     build.build()
     hooks = _hooks_declared()
-    assert len(hooks) == 24 and "zkgpu_debug_comm_mock" in hooks and "zkgpu_profile_get" in hooks
+    assert len(hooks) == 25 and "zkgpu_debug_fail_after" in hooks and "zkgpu_debug_comm_mock" in hooks and "zkgpu_profile_get" in hooks
     assert not set(hooks) & set(_declared())
     assert len(_declared()) <= 90
     nm = subprocess.run(["nm", "-D", "--defined-only", build.OUT], capture_output=True, text=True, check=True).stdout

@@ -215,6 +215,7 @@ ncclResult_t mock_all_gather(const void* send, void* recv, size_t bytes, ncclDat
   std::lock_guard<std::mutex> lk(g_comm_mock_mu);
   CommMock& m = g_comm_mock;
   ++m.gathers;
+  zk::fault::Suppress outside_the_product;
   if (bytes != m.slot) return ncclInvalidArgument;
   if (hipMemcpyAsync(recv, m.d_peers, bytes * (size_t)m.world, hipMemcpyDeviceToDevice, st) != hipSuccess) return ncclUnhandledCudaError;
   if (hipMemcpyAsync((char*)recv + bytes * (size_t)m.rank, send, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return ncclUnhandledCudaError;
@@ -609,7 +610,13 @@ int txblock_upload(zkgpu_verifier* v, zkgpu_txblock* b, zkgpu_verifier::TxArena*
     b->host_owned.reset();
     b->host_image = nullptr;
   }
-  if (e != hipSuccess) { v->last_error = hipGetErrorString(e); if (b->owns_dev && b->dev) (void)hipFree(b->dev); b->dev = nullptr; return ZKGPU_EHIP; }
+  if (e != hipSuccess) {
+    v->last_error = hipGetErrorString(e);
+    quiesce_after_fault(v->root);        // (an arena's copy may be half queued: the arena is handed out again after this)
+    if (b->owns_dev && b->dev) (void)hipFree(b->dev);
+    b->dev = nullptr;
+    return ZKGPU_EHIP;
+  }
   return ZKGPU_OK;
 }
 
@@ -857,7 +864,7 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
         // the back half could not be queued (a launch failed): what the front half queued is waited for, and the batch's
         // requests fail with the error -- nothing is left in flight on the lane
         v->last_error = zkgpu_last_error(L);
-        { DeviceGuard g(L->device); (void)hipDeviceSynchronize(); }
+        quiesce_after_fault(L);
         std::vector<zkgpu_request*> members;
         members.swap(v->running[(size_t)f.lane]);
         for (auto it = v->busy.begin(); it != v->busy.end(); ++it) if (*it == f.lane) { v->busy.erase(it); break; }
@@ -967,6 +974,7 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
     if (rc == ZKGPU_OK && plan) { v->running[(size_t)lane] = pick; v->busy.push_back(lane); }
     else {
       if (rc != ZKGPU_OK && plan) v->last_error = zkgpu_last_error(L);
+      if (rc != ZKGPU_OK) quiesce_after_fault(L);          // (merge copies, a front half: nothing of it stays in flight on a lane that reads as free)
       { std::lock_guard<std::recursive_mutex> lk(L->mu); L->dep_event = nullptr; }
       for (zkgpu_request* r : pick) if (r->run) block_request_done(v, r);     // (a block's batches answer to their run, at once)
     }
@@ -1028,7 +1036,7 @@ void host_batch_fail(zkgpu_verifier* v, zkgpu_host_batch* F, int rc) {      // e
   for (zkgpu_request* r : F->members) { r->state = 2; r->rc = rc; r->form = nullptr; r->bits.assign((r->batch + 7) / 8, 0); }
   if (F->stage >= 0) {
     zkgpu_verifier::HostStage& hs = v->host_stages[(size_t)F->stage];
-    if (hs.copied) { DeviceGuard g(v->root->device); (void)hipEventSynchronize(hs.copied); }    // (copies of staged tickets may still be queued)
+    quiesce_after_fault(v->root);      // (copies of staged tickets may still be queued, kernels of a half-queued batch may still read the twin)
     hs.taken = false;
   }
 }
@@ -1165,6 +1173,7 @@ int host_submit_one(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, size_t bat
     if (e == hipSuccess) e = hipEventRecord(hs.copied, v->copy_stream);
     if (e != hipSuccess) {
       v->last_error = std::string("ticket staging copy: ") + hipGetErrorString(e);
+      quiesce_after_fault(v->root);
       r->state = 2; r->rc = ZKGPU_EHIP; r->bits.assign((batch + 7) / 8, 0);
       return ZKGPU_OK;
     }
@@ -1325,7 +1334,9 @@ long long zkgpu_debug_comm_mock(zkgpu_ctx* ctx, int world, const uint8_t* peer_s
   if (!test_hooks_enabled()) return ZKGPU_EINVAL;        // (ZKGPU_TEST_HOOKS=1 in the environment when the library was loaded)
   std::lock_guard<std::mutex> lk(g_comm_mock_mu);
   CommMock& m = g_comm_mock;
-  if (world <= 0) { m.on = false; return (long long)m.gathers; }
+  if (world < 0) return (long long)m.gathers;            // (a query: nothing changes)
+  if (world == 0) { m.on = false; return (long long)m.gathers; }
+  zk::fault::Suppress outside_the_product;               // (the mock stands for RCCL and the peers: not what fault injection tests)
   if (!ctx || !peer_slots || slot_bytes == 0 || slot_bytes > COMM_MAX_SLOT) return ZKGPU_EINVAL;
   DeviceGuard g(ctx->device);
   if (m.d_peers) { (void)hipFree(m.d_peers); m.d_peers = nullptr; }
@@ -1428,7 +1439,7 @@ int zkgpu_comm_allgather(zkgpu_comm* cm, const uint8_t* local, size_t bytes, uin
     note(hipMemcpyAsync(cm->d_send, &poison, 4, hipMemcpyHostToDevice, cm->stream), "zkgpu_comm_allgather: poison");
   }
   note(hipStreamSynchronize(cm->stream), "zkgpu_comm_allgather: synchronize");
-  if (rc != ZKGPU_OK) { memset(all, 0, total); return rc; }
+  if (rc != ZKGPU_OK) { quiesce_after_fault(c); memset(all, 0, total); return rc; }     // (the pinned buffer is reused by the next call)
   memcpy(all, h + COMM_MAX_SLOT, total);
   return ZKGPU_OK;
 }
@@ -1967,6 +1978,24 @@ int zkgpu_tx_verify_stats(zkgpu_verifier* v, uint64_t out[2]) {
   return ZKGPU_OK;
 }
 
+// The n-th HIP runtime call of the process from now on reports hipErrorUnknown WITHOUT being made (fault_gate.hpp); n < 0: the
+// |n|-th and every call after it (a device that is gone); n = 0: disarm.  Process-wide -- the lanes of a verifier, the slices
+// of a prover call and the staging threads are contexts and threads of their own, and a fault belongs to whoever makes the
+// n-th call.  Returns the number of calls that passed the gate since it was last armed (so a test can count a clean run's
+// calls first and then fail every one of them in turn); *fired (may be NULL): how many were answered "failed".
+long long zkgpu_debug_fail_after(zkgpu_ctx* ctx, long long n, long long* fired) {
+  (void)ctx;
+  zk::fault::State& s = zk::fault::state();
+  const long long seen = s.seen.load();
+  if (fired) *fired = s.fired.load();
+  s.armed.store(0);
+  s.seen.store(0); s.fired.store(0);
+  s.sticky.store(n < 0 ? 1 : 0);
+  s.countdown.store(n < 0 ? -n : n);
+  if (n != 0) s.armed.store(1);
+  return seen;
+}
+
 // ---- hooks (include/zkgpu_hooks.h): by name, and only for a process that asked for them before it loaded the library --------
 const void* zkgpu_hook(const char* name) {
   if (!name || !test_hooks_enabled()) return nullptr;
@@ -1979,6 +2008,7 @@ const void* zkgpu_hook(const char* name) {
     ZKGPU_HOOK(zkgpu_profile_reset), ZKGPU_HOOK(zkgpu_profile_count), ZKGPU_HOOK(zkgpu_profile_get), ZKGPU_HOOK(zkgpu_last_window_bits),
     ZKGPU_HOOK(zkgpu_last_bucket_adds), ZKGPU_HOOK(zkgpu_verifier_lane), ZKGPU_HOOK(zkgpu_debug_arith), ZKGPU_HOOK(zkgpu_debug_coop_selftest),
     ZKGPU_HOOK(zkgpu_debug_read), ZKGPU_HOOK(zkgpu_cloak_plan_layout), ZKGPU_HOOK(zkgpu_debug_force_regroup), ZKGPU_HOOK(zkgpu_debug_comm_mock),
+    ZKGPU_HOOK(zkgpu_debug_fail_after),
   };
 #undef ZKGPU_HOOK
   for (const Entry& e : table) if (!strcmp(e.name, name)) return e.fn;

@@ -30,6 +30,8 @@
 #include <type_traits>
 #include <vector>
 
+#include "fault_gate.hpp"   // (every HIP runtime call below passes a gate a test can close: zkgpu_debug_fail_after)
+
 #include "r1cs_verifier.hpp"
 #include "cloak_plan.hpp"
 #include "prep_kernels.hpp"
@@ -88,6 +90,7 @@ struct zkgpu_ctx {
   hipEvent_t ev_t = nullptr, ev_p = nullptr, ev_sm = nullptr, ev_sa = nullptr, ev_done = nullptr;
   bool pending = false;            // a submitted batch has not been waited for yet
   size_t pending_batch = 0;
+  bool broken = false;             // a device fault could not even be drained (quiesce_after_fault): every later call fails
   // the general (non-pipelined) batch paths in two halves -- batch_device_enqueue / batch_device_tables_enqueue queue the
   // kernels and the copy of the results to the pinned buffer, batch_collect waits and reads them -- so that the key and
   // signature stages of zkgpu_tx_verify_batch can run beside the host's work on the next chunk (session.hpp)
@@ -160,14 +163,37 @@ struct zkgpu_ctx {
 };
 
 namespace {
+// A runtime call of a context's pipeline has failed.  What the pipeline had queued BEFORE it is still in flight -- on the
+// context's own streams and on the streams it shares with its family -- while the caller is about to treat the context as
+// idle: a lane of the verifier would be handed its next batch, whose first kernels (light stream) overwrite the workspace the
+// failed batch's last kernels (shared streams) still read; a staging area would be given to the next tickets.  Found by fault
+// injection (tests/test_gpu_faults.py: a failed wait on one device batch flipped a bit of the NEXT batch on that lane, status
+// OK).  So the error does not leave the library before the device is drained; if even that fails the context is broken for
+// good and every later call on it fails (an error is never an accept).  The sticky launch error is read off so that it is not
+// blamed on the next batch.  Error path only; the gate of fault_gate.hpp is held open (the fault under test has happened).
+void quiesce_after_fault(zkgpu_ctx* c) {
+  zk::fault::Suppress open;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (prev != c->device) (void)hipSetDevice(c->device);
+  if (hipDeviceSynchronize() != hipSuccess) c->broken = true;
+  (void)hipGetLastError();
+  if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
+}
+
 #define HIP_TRY(ctx, expr)                                                                  \
   do {                                                                                      \
+    if ((ctx)->broken) {                                                                    \
+      (ctx)->last_error = "an earlier device fault on this context could not be drained: the context is unusable"; \
+      return ZKGPU_EHIP;                                                                    \
+    }                                                                                       \
     hipError_t e__ = (expr);                                                                \
     if (e__ != hipSuccess) {                                                                \
       char buf__[256];                                                                      \
       snprintf(buf__, sizeof buf__, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
                __FILE__, __LINE__);                                                         \
       (ctx)->last_error = buf__;                                                            \
+      quiesce_after_fault(ctx);                                                             \
       return ZKGPU_EHIP;                                                                    \
     }                                                                                       \
   } while (0)
@@ -178,7 +204,7 @@ int ensure(zkgpu_ctx* c, Buffer& b, size_t bytes) {
   b.p = nullptr; b.cap = 0;
   size_t want = bytes + bytes / 8 + 256;
   hipError_t e = hipMalloc(&b.p, want);
-  if (e != hipSuccess) { c->last_error = std::string("hipMalloc: ") + hipGetErrorString(e); b.p = nullptr; return ZKGPU_ENOMEM; }
+  if (e != hipSuccess) { c->last_error = std::string("hipMalloc: ") + hipGetErrorString(e); b.p = nullptr; quiesce_after_fault(c); return ZKGPU_ENOMEM; }
   b.cap = want;
   return ZKGPU_OK;
 }
@@ -2306,11 +2332,15 @@ int run_sliced(zkgpu_ctx* c, size_t batch, int host_threads, const std::function
     zkgpu_ctx* t = c->pv_slices[(size_t)i - 1];
     t->prover_mode = c->prover_mode;
     t->profiling = c->profiling;
-    th.emplace_back([&, i, t] {
+    auto body = [&, i, t] {
       try { rc[(size_t)i] = one(t, cut(i), cut(i + 1), ht); }
       catch (const std::bad_alloc&) { t->last_error = "prover: out of host memory"; rc[(size_t)i] = ZKGPU_ENOMEM; }
       catch (const std::exception& e) { t->last_error = e.what(); rc[(size_t)i] = ZKGPU_EINVAL; }      // (never across a thread's top frame)
-    });
+    };
+    // a thread that cannot be started (std::system_error: the process is out of threads) must not unwind past the ones
+    // already running on the caller's buffers -- that would be std::terminate: its slice runs here instead
+    try { th.emplace_back(body); }
+    catch (const std::exception&) { body(); }
   }
   try { rc[0] = one(c, 0, cut(1), ht); }
   catch (const std::bad_alloc&) { c->last_error = "prover: out of host memory"; rc[0] = ZKGPU_ENOMEM; }

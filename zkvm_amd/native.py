@@ -69,6 +69,7 @@ def _bind_hooks(lib) -> None:
         "zkgpu_cloak_plan_layout": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
         "zkgpu_debug_force_regroup": (C.c_longlong, [vp, C.c_int]),
         "zkgpu_debug_comm_mock": (C.c_longlong, [vp, C.c_int, u8p, sz]),
+        "zkgpu_debug_fail_after": (C.c_longlong, [vp, C.c_longlong, C.POINTER(C.c_longlong)]),
     }
     for name, (restype, argtypes) in table.items():
         addr = lib.zkgpu_hook(name.encode())
