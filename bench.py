@@ -64,6 +64,10 @@ if os.environ.get("ZKGPU_BENCH_SHARE_GPU"):
 else:
     # the library does not edit the environment: it recommends (zkgpu_runtime_hint), the host exports -- here, before torch or
     # anything else in this process has made a HIP call
+    # (torch FIRST: it brings its own copy of the HIP runtime library, and the two must resolve to ONE runtime in the process --
+    # libzkgpu.so loaded before torch binds /opt/rocm's, torch then loads its own beside it, and the second one finds no
+    # device.  Importing torch does not start the runtime: the hint below still comes in time, and says so if it did not.)
+    import torch as _torch  # noqa: F401
     import sys as _sys
     _sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from zkvm_amd import runtime_hint as _runtime_hint
@@ -94,7 +98,8 @@ VALU_PEAK_GINST = 1024 * 2.4 / 4 * 64        # 1024 SIMDs x 2.4 GHz / 4 cycles p
 N_SIMD, CLOCK_GHZ = 1024, 2.4                  # 256 CUs x 4 SIMDs; the clock tools/ubench/valu_ops.hip prices its cycles at
 BAD_POINT = bytes.fromhex("01" + "00" * 31)
 SHAPE_TERMS = {}                             # (n_in, n_out) -> (n_dyn, n_static), filled from the library
-DEFAULT_MERGE = 10240                        # transactions per merged device batch (config 2), whatever --steps
+LIBRARY_MERGE = 10240                        # the LIBRARY's default merge target for tickets (session.hpp zkgpu_verifier::merge_target; tests/test_host_logic.py
+                                             # holds the two equal): bench.py does not set one unless --merge is given
 
 
 def emit(record) -> None:
@@ -859,12 +864,20 @@ def run_config2(args, W):
     # `--inflight M`: M device batches in flight.  Each has its own forked context (workspace + a light stream for its
     # latency-bound kernels); the chip-filling kernels of all of them go first-in first-out through the parent's
     # shared streams (zkgpu_ctx_fork).  Every step is one complete, independent verification of a whole batch.
-    ctx.set_group_size(args.group)               # forks inherit it
-    ctx.set_transcript_mode(args.transcript_mode)
-    ctx.set_locate_mode(args.locate_mode)
-    ctx.set_locate_parts(args.locate_parts)
-    ctx.set_tail_mode(args.tail_mode)
-    ctx.set_horner_mode(args.horner_mode)
+    # the modes of include/zkgpu_hooks.h are touched only when a flag asks for something else than the library's own choice:
+    # the timed path is the path a process without hooks runs
+    if args.group != 16:
+        ctx.set_group_size(args.group)           # forks inherit it
+    if args.transcript_mode:
+        ctx.set_transcript_mode(args.transcript_mode)
+    if args.locate_mode:
+        ctx.set_locate_mode(args.locate_mode)
+    if args.locate_parts:
+        ctx.set_locate_parts(args.locate_parts)
+    if args.tail_mode:
+        ctx.set_tail_mode(args.tail_mode)
+    if args.horner_mode:
+        ctx.set_horner_mode(args.horner_mode)
     # (with tickets the plain forks serve the single-rank side legs only: at N > 1 they would be four more streams beside the
     # verifier's lanes and the communicator's, on a device whose queue slots are limited -- DESIGN.md sec 5.1)
     ctxs = [ctx] + [ctx.fork() for _ in range((min(max(1, args.inflight), 10) if args.tickets <= 0 else (5 if world == 1 else 1)) - 1)]
@@ -930,9 +943,14 @@ def run_config2(args, W):
     bv = None
     if args.tickets > 0:
         bv = BlockVerifier(ctx, gens, batches_in_flight=args.inflight)
-        bv.set_merge(args.merge)
-        for i in range(bv.lanes()):
-            bv.lane(i).set_group_size(args.group)
+        if args.merge_given:
+            bv.set_merge(args.merge)
+        if args.group != 16:
+            for i in range(bv.lanes()):
+                bv.lane(i).set_group_size(args.group)
+        # setup, untimed, as the table build is: every lane's workspace for the largest device batch the merge policy can form
+        # (1.5 x the target: zkgpu.h "Tickets"), by the call the header recommends to an integrator for exactly this
+        bv.reserve(n_in, n_out, 3 * args.merge // 2)
 
     def run_tickets(n, base=0, depth=None, gather=True):
         # `--tickets D`: up to D batches in flight as tickets; the verifier merges them into device batches of --merge
@@ -1034,9 +1052,11 @@ def run_config2(args, W):
     n_prime = (bv.lanes() * rep if bv is not None else len(ctxs))
     timed(n_prime, base=args.steps, gather=False)
     timed(n_warm, base=args.steps)                            # warm-up on sets the timed steps do not use
-    # HIP events around every launch of the contexts in flight
+    # The timed region runs WITHOUT the per-launch HIP events (zkgpu_profile_*, a hook): it is the path an integrator's process
+    # runs.  The in-flight kernel durations come from a second, untimed pass over the same steps afterwards (rank 0).
+    # (ZKGPU_BENCH_INFLIGHT_EVENTS=1 puts the events back into the timed region, as until round 5.)
     prof_ctxs = [bv.lane(i) for i in range(bv.lanes())] if bv is not None else ctxs[:1]
-    inflight_events = os.environ.get("ZKGPU_BENCH_NO_INFLIGHT_EVENTS") != "1"      # (experiment: what the HIP events around every launch cost)
+    inflight_events = os.environ.get("ZKGPU_BENCH_INFLIGHT_EVENTS") == "1"
     for c in prof_ctxs:
         c.profile_reset()
         c.profile(inflight_events)
@@ -1056,6 +1076,13 @@ def run_config2(args, W):
     roll_call = rccl_roll_call(W, shared_comm[0])
 
     if rank == 0:
+        if not inflight_events and world == 1:
+            for c in prof_ctxs:
+                c.profile_reset()
+                c.profile(True)
+            timed(args.steps, base=0, gather=False)                # the same steps once more, untimed, with events around every launch
+            for c in prof_ctxs:
+                c.profile(False)
         prof = profile_lanes(prof_ctxs)
         in_flight_ms = {k: v[1] / v[0] for k, v in prof.items() if v[0]}
         solo, launches = solo_pass()
@@ -1075,7 +1102,10 @@ def run_config2(args, W):
                                         "test -> accept bitmap" % (batch, n_dyn + n_static, n_static),
                             "tx_per_gpu": batch, "terms_per_tx": n_dyn + n_static, "generator_table_bits": args.table_bits,
                             "calls_in_flight": min(args.tickets, args.steps) if bv is not None else len(ctxs), "group_size": args.group,
-                            "merged_device_batches": ({"transactions": args.merge, "lanes": bv.lanes()} if bv is not None else None),
+                            "merged_device_batches": ({"transactions": args.merge, "lanes": bv.lanes(), "source": "--merge" if args.merge_given else "library default",
+                                                       "policy": "what is queued of one shape leaves in round(queued / target) device batches of equal size"}
+                                                      if bv is not None else None),
+                            "events_in_timed_region": inflight_events,
                             "distinct_step_inputs": n_sets, "exchange": exchange_name, "steps_per_exchange": gather_every if world > 1 else None,
                             "ranks": ranks_info, "per_rank": per_rank, "rccl": roll_call,
                             "control_plane": "gloo (host)" if world > 1 else None, "bringup": W.bringup,
@@ -1106,6 +1136,22 @@ def run_config2(args, W):
                                          "tx_per_s": round(batch / lat[len(lat) // 2], 1),
                                          "note": "one %d-transaction batch, nothing else in flight: zkgpu_verifier_submit_dev + "
                                                  "zkgpu_verifier_wait, 12 distinct batches" % batch}
+        if bv is not None and not args.lean and world == 1:
+            # `value` against the step count (it used to peak where --steps was a multiple of merge / 1024):
+            # the same timed arrangement -- one submit_many of everything, then the waits -- for other run lengths, best of 3
+            by_steps = {}
+            for s_n in (16, 20, 24, 37):
+                best = None
+                for rep_i in range(3):
+                    t1 = time.perf_counter()
+                    run_tickets(s_n, base=(7 * rep_i) % n_sets, gather=False)
+                    dt = time.perf_counter() - t1
+                    best = dt if best is None or dt < best else best
+                by_steps[str(s_n)] = round(batch * s_n / best, 1)
+            line["value_by_steps"] = dict(by_steps, note="tx/s of a run of that many 1024-transaction steps, everything queued by one call "
+                                          "(best of 3): 16 / 20 / 24 / 37 steps leave as 2 x 8, 2 x 10, 2 x 12, 10 + 9 + 9 + 9 tickets per device "
+                                          "batch.  What still differs is the ~1.1 ms tail behind the LAST batch (Horner chains, verdicts), paid "
+                                          "once per run and amortised over more transactions in a longer one")
         if bv is not None and steady_steps:
             # the same arrangement under sustained load: 200 steps, up to 64 tickets in flight (never `value` unless the
             # run itself is that long)
@@ -1493,7 +1539,7 @@ def main():
     ap.add_argument("--bad-every", type=int, default=64, help="config 2: one transaction in this many is corrupted (0 = none)")
     ap.add_argument("--tickets", type=int, default=-1,
                     help="config 2: batches kept in flight as tickets of a zkgpu_verifier, which merges them into device batches of --merge tx (0 = plain contexts)")
-    ap.add_argument("--merge", type=int, default=0, help="config 2 with --tickets: transactions per merged device batch (0: %d)" % DEFAULT_MERGE)
+    ap.add_argument("--merge", type=int, default=0, help="config 2 with --tickets: zkgpu_verifier_set_merge (0: not called -- the library's default, %d)" % LIBRARY_MERGE)
     ap.add_argument("--locate-mode", type=int, default=0, choices=(0, 1, 2, 3), help="zkgpu_set_locate_mode")
     ap.add_argument("--locate-parts", type=int, default=0, help="zkgpu_set_locate_parts (0 = the library's default)")
     ap.add_argument("--tail-mode", type=int, default=0, choices=(0, 1), help="zkgpu_set_tail_mode")
@@ -1521,7 +1567,7 @@ def main():
         args.tickets = 64
     args.merge_given = args.merge > 0
     if args.merge <= 0:
-        args.merge = DEFAULT_MERGE
+        args.merge = LIBRARY_MERGE                    # (for the bench's own arithmetic: ring length, priming, the solo pass's device batch)
     if args.inflight <= 0:
         args.inflight = 5 if args.tickets > 0 else (10 if args.config == 4 and args.blocks_in_flight > 1 else 6)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -436,9 +436,12 @@ int zkgpu_verifier_block_start(zkgpu_verifier *v, const zkgpu_txblock *block, ui
 int zkgpu_verifier_block_finish(zkgpu_verifier *v, uint64_t run_id, uint8_t *accept_bitmap);
 /* Tickets: many small batches in flight, few large device batches.  zkgpu_verifier_submit_dev QUEUES one uniform batch
  * (inputs resident in HBM, as zkgpu_cloak_verify_submit_dev) and returns a ticket at once; queued batches of one shape
- * are merged, up to `merge` transactions (zkgpu_verifier_set_merge, default 4096), copied side by side into the
- * workspace of one of the verifier's contexts (device to device) and launched as ONE batch as soon as the target is
- * reached and a context is free -- or when a ticket among them is waited for.  zkgpu_verifier_wait blocks until that
+ * are merged into device batches of about `merge` transactions (default 10 240 for tickets, 4096 for the batches of
+ * blocks; zkgpu_verifier_set_merge sets both), copied side by side into the workspace of one of the verifier's contexts
+ * (device to device) and launched as ONE batch as soon as the target is reached and a context is free -- or when a ticket
+ * among them is waited for.  What is queued of one shape when a batch leaves is cut into round(queued / merge) batches of
+ * EQUAL size, so a burst of 16, 20, 24 or 37 tickets of 1024 leaves as 2 x 8, 2 x 10, 2 x 12, 10 + 9 + 9 + 9: no run pays
+ * for a short straggler batch (a device batch may therefore hold up to 1.5 x merge transactions).  zkgpu_verifier_wait blocks until that
  * ticket's batch is done and writes ITS accept bitmap (ceil(batch / 8) bytes; all zero on any error).  Verdicts are
  * those of separate batches; what changes is when a batch starts and how well it fills the chip: every kernel of a
  * 1024-transaction batch is a single round of workgroups, four merged batches run ~1.5x faster per transaction.

@@ -55,3 +55,17 @@ def test_committed_tables_cover_the_headline_kernels_and_bench_prices_them():
     v2 = bench.valu_roofline("k_small_accumulate", 1.9, valu, 2 * units)
     assert abs(v2["mix_bound_ms"] - 2 * v["mix_bound_ms"]) < 1e-3
     assert bench.valu_roofline("no_such_kernel", 1.0, valu, units) is None
+
+
+def test_bench_times_the_library_default_merge_target_not_one_of_its_own():
+    """the merge target the headline runs on must be the one an integrator gets.  bench.py calls
+    zkgpu_verifier_set_merge only when --merge is given; the constant it uses for its own arithmetic (ring length, priming,
+    the solo pass's device batch) is the library's default, held equal here."""
+    import re
+    src = open(os.path.join(ROOT, "zkvm_amd", "csrc", "session.hpp")).read()
+    m = re.search(r"size_t merge_target = (\d+);", src)
+    bench_src = open(os.path.join(ROOT, "bench.py")).read()
+    lib_merge = int(re.search(r"^LIBRARY_MERGE = (\d+)", bench_src, re.M).group(1))
+    assert m and int(m.group(1)) == lib_merge == 10240
+    assert re.search(r"if args\.merge_given:\s*\n\s*bv\.set_merge\(args\.merge\)", bench_src)
+    assert bench_src.count("bv.set_merge(") == 2          # (the other: --config 4, its own explicit 8192)

@@ -633,10 +633,17 @@ k_class_scan(const uint32_t* __restrict__ class_count, uint32_t* __restrict__ cl
 // they are listed in heavy[1..] (heavy[0] = count) and summed by a whole workgroup each.
 constexpr uint32_t HEAVY_BIN = 2048;
 constexpr uint32_t HEAVY_MAX = 65536;
+// Bins between FAT_BIN and HEAVY_BIN entries are summed by FAT_LANES lanes each (k_bucket_fat).  The case that matters is the
+// TOP window of a large multiscalar multiplication with uniform scalars: l < 2^253, so window 15 of sixteen 16-bit windows has 13
+// significant bits and its 2^20 terms land in ~4100 buckets of ~256 -- eight times the ~32 of every other bin.  One lane per
+// bin, those 64 wavefronts ran for the WHOLE kernel (started first, they still shared their SIMDs three ways for the first two
+// thirds and then finished alone: 0.84 - 0.89 ms against the 0.50 ms the kernel's instructions cost) -- round 6.
+constexpr uint32_t FAT_BIN = 96;
+constexpr int FAT_LANES = 16;
 
 __global__ void __launch_bounds__(256)
 k_bin_order(const uint32_t* __restrict__ cursor, uint64_t n_bins, uint32_t* __restrict__ class_cursor,
-            uint32_t* __restrict__ order, uint32_t* __restrict__ heavy) {
+            uint32_t* __restrict__ order, uint32_t* __restrict__ heavy, uint32_t* __restrict__ fat, uint32_t fat_cap) {
   __shared__ uint32_t h[SIZE_CLASSES], base[SIZE_CLASSES];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -645,9 +652,13 @@ k_bin_order(const uint32_t* __restrict__ cursor, uint64_t n_bins, uint32_t* __re
   if (bin < n_bins) {
     cls = bin_size_class(cursor, bin);
     rank = atomicAdd(&h[cls], 1u);
-    if (cls == 0 && cursor[bin] - (bin ? cursor[bin - 1] : 0u) > HEAVY_BIN) {
+    const uint32_t cnt = cursor[bin] - (bin ? cursor[bin - 1] : 0u);
+    if (cnt > HEAVY_BIN) {
       const uint32_t slot = atomicAdd(&heavy[0], 1u);
       if (slot < HEAVY_MAX) heavy[1 + slot] = (uint32_t)bin;
+    } else if (cnt > FAT_BIN) {
+      const uint32_t slot = atomicAdd(&fat[0], 1u);        // (cannot overflow: fat_cap >= entries / FAT_BIN)
+      if (slot < fat_cap) fat[1 + slot] = (uint32_t)bin;
     }
   }
   __syncthreads();
@@ -668,7 +679,7 @@ k_bucket_accumulate(const uint32_t* __restrict__ cursor, const uint32_t* __restr
   if (gid >= n_bins) return;
   const uint64_t bin = order ? order[gid] : gid;
   const uint32_t start = bin ? cursor[bin - 1] : 0u, end = cursor[bin];
-  if (start == end || end - start > HEAVY_BIN) return;   // heavy bins: k_bucket_heavy
+  if (start == end || end - start > FAT_BIN) return;     // fat bins: k_bucket_fat; heavy bins: k_bucket_heavy
   ge acc;
   ge_identity(acc);
   // two dependent gathers per term (entry -> row): entries run two terms ahead, rows one
@@ -689,6 +700,43 @@ k_bucket_accumulate(const uint32_t* __restrict__ cursor, const uint32_t* __restr
     cur = nxt; cur_neg = nxt_neg;
   }
   store_ext(buckets + bin * EXT_WORDS, acc);
+}
+
+// FAT_LANES lanes per fat bin (four bins per wavefront): strided partial sums, folded by four shuffle steps inside the group.
+// The grid is fixed; the lane groups walk the fat list.
+__global__ void __launch_bounds__(256)
+k_bucket_fat(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ entries,
+             const uint32_t* __restrict__ static_rows, const uint32_t* __restrict__ dyn_rows,
+             uint32_t* __restrict__ buckets, const uint32_t* __restrict__ fat, uint32_t fat_cap) {
+  const uint32_t n_fat = min(fat[0], fat_cap);
+  const uint32_t sub = threadIdx.x & (FAT_LANES - 1);
+  const uint32_t groups = gridDim.x * (256 / FAT_LANES);
+  for (uint32_t f = blockIdx.x * (256 / FAT_LANES) + threadIdx.x / FAT_LANES; ; f += groups) {
+    // (a wavefront leaves the loop together: its four groups hold consecutive list positions, and the shuffles below need all lanes)
+    if (__all((f & ~3u) >= n_fat)) break;
+    const bool live = f < n_fat;
+    const uint64_t bin = live ? fat[1 + f] : 0;
+    const uint32_t start = live ? (bin ? cursor[bin - 1] : 0u) : 0u, end = live ? cursor[bin] : 0u;
+    ge acc;
+    ge_identity(acc);
+    uint32_t k = start + sub;
+    uint32_t e_next = k < end ? entries[k] : 0u;
+    for (; k < end; k += FAT_LANES) {
+      const uint32_t e = e_next;
+      if (k + FAT_LANES < end) e_next = entries[k + FAT_LANES];
+      const uint32_t* row = ((e & ENTRY_DYN) ? dyn_rows : static_rows) + (uint64_t)(e & ENTRY_IDX) * NIELS_WORDS;
+      ge_niels q;
+      load_niels(q, row);
+      ge_madd(acc, acc, q, (e & ENTRY_NEG) != 0);
+    }
+#pragma unroll 1
+    for (int delta = FAT_LANES / 2; delta >= 1; delta >>= 1) {
+      ge other;
+      shfl_down_ge(other, acc, delta);
+      if (sub < (uint32_t)delta) ge_add(acc, acc, other);
+    }
+    if (live && sub == 0) store_ext(buckets + bin * EXT_WORDS, acc);
+  }
 }
 
 // One workgroup per heavy bin: 256 strided partial sums, folded by wavefront shuffles and

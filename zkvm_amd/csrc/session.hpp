@@ -57,7 +57,11 @@ struct zkgpu_verifier {
   std::map<uint64_t, zkgpu_request*> requests;          // every ticket not yet waited for
   std::vector<std::vector<zkgpu_request*>> running;     // per lane: the members of its merged batch in flight
   std::deque<int> busy;                                 // lanes in flight, oldest first
-  size_t merge_target = 4096;                           // transactions per merged device batch
+  size_t merge_target = 10240;                          // transactions per merged device batch of TICKETS: ten 1024-transaction batches,
+                                                        // the arrangement every sweep of DESIGN.md sec 6 ends at (8192 ... 12 288 differ by
+                                                        // 2 % in the steady state; below 8192 the chip-filling kernels lose their rounds)
+  size_t block_merge = 4096;                            // the same for the batches of BLOCKS (zkgpu_verifier_verify_block, _block_start and
+                                                        // the transaction calls): two lanes share a lone block of 8192 (measured, config 4)
   // host-memory tickets: pinned staging areas (2 * lanes + 2 of them, grow-only), each with a TWIN of the same size in HBM,
   // and the device batches being formed in them, oldest first; a batch that is full waits here for a free lane.  A ticket's
   // bytes travel to the twin as soon as they are staged (three hipMemcpyAsync per ticket on the copy stream), so that the copy
@@ -879,16 +883,26 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
   struct FlushAtExit { decltype(flush_backs)& f; ~FlushAtExit() { f(); } } flush_at_exit{flush_backs};
   while (!v->queue.empty()) {
     zkgpu_request* head = v->queue.front();
+    // Everything queued of the head's shape, T transactions, leaves in round(T / target) device batches of EQUAL size (to the
+    // ticket): 20 tickets of 1024 at a target of 10 240 are two batches of ten as before, but 16 are two of eight (not ten and
+    // six), 24 two of twelve, 37 four of ten, nine, nine, nine.  What a run of any length then pays is the one tail behind its
+    // last batch, not a short straggler batch as well (`value` used to peak where the step count was a
+    // multiple of the target).  Tickets that trickle in one by one leave at the target, as they always did.
+    const size_t target = head->run ? v->block_merge : v->merge_target;
+    size_t queued = 0;
+    for (zkgpu_request* r : v->queue)
+      if (r->n_in == head->n_in && r->n_out == head->n_out && r->proof_len == head->proof_len) queued += r->batch;
+    if (queued < target && !force) return ZKGPU_OK;
+    const size_t parts = std::max<size_t>(1, (queued + target / 2) / target);
+    const size_t quota = (queued + parts - 1) / parts;
     std::vector<zkgpu_request*> pick;
     size_t total = 0;
     for (zkgpu_request* r : v->queue) {
       if (r->n_in != head->n_in || r->n_out != head->n_out || r->proof_len != head->proof_len) continue;
-      if (!pick.empty() && total + r->batch > v->merge_target) break;
       pick.push_back(r);
       total += r->batch;
-      if (total >= v->merge_target) break;
+      if (total >= quota) break;
     }
-    if (total < v->merge_target && !force) return ZKGPU_OK;
     int lane = -1;
     for (size_t i = 0; i < v->lanes.size(); ++i) if (v->running[i].empty()) { lane = (int)i; break; }
     if (lane < 0) {
@@ -1242,7 +1256,7 @@ int zkgpu_verifier_reserve(zkgpu_verifier* v, uint32_t n_in, uint32_t n_out, siz
 int zkgpu_verifier_set_merge(zkgpu_verifier* v, size_t transactions) {
   if (!v || transactions == 0 || transactions >= (1u << 24)) return ZKGPU_EINVAL;
   std::lock_guard<std::mutex> lk(v->mu);
-  v->merge_target = transactions;
+  v->merge_target = v->block_merge = transactions;        // (one knob for a caller who turns it: tickets and blocks alike)
   return ZKGPU_OK;
 }
 

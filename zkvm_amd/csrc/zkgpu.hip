@@ -494,8 +494,13 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
     }
   }
   TRY(ensure(c, c->bin_order, n_bins * 4));
-  TRY(ensure(c, c->heavy, (HEAVY_MAX + 1) * 4));
-  HIP_TRY(c, hipMemsetAsync(c->heavy.p, 0, 4, s));
+  // heavy list | fat list (kernels.hpp: bins summed by a workgroup each / by FAT_LANES lanes each)
+  const uint32_t fat_cap = (uint32_t)(max_entries / FAT_BIN + 64);
+  TRY(ensure(c, c->heavy, ((size_t)HEAVY_MAX + 1 + fat_cap + 1) * 4));
+  uint32_t* heavy = (uint32_t*)c->heavy.p;
+  uint32_t* fat = heavy + HEAVY_MAX + 1;
+  HIP_TRY(c, hipMemsetAsync(heavy, 0, 4, s));
+  HIP_TRY(c, hipMemsetAsync(fat, 0, 4, s));
   {
     Launch l(c, "k_bin_order");
     if (!part_sort)                                      // (the partition sort counts the size classes of its bins itself)
@@ -503,9 +508,17 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
                          class_count);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(256), 0, s, (const uint32_t*)class_count, class_cursor);
     hipLaunchKernelGGL(k_bin_order, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p, n_bins,
-                       class_cursor, (uint32_t*)c->bin_order.p, (uint32_t*)c->heavy.p);
+                       class_cursor, (uint32_t*)c->bin_order.p, heavy, fat, fat_cap);
   }
   if (decompress_aside) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+  {
+    // the fat bins first: their lane groups carry the longest chains of the three kernels (FAT_BIN ... HEAVY_BIN / FAT_LANES
+    // additions and four folds); queued ahead, they run beside the first rounds of the one-lane-per-bin kernel
+    Launch l(c, "k_bucket_fat");
+    hipLaunchKernelGGL(k_bucket_fat, dim3(std::min<unsigned>(blocks_for((uint64_t)fat_cap * FAT_LANES, 256), 1024u)), dim3(256), 0, s,
+                       (const uint32_t*)c->bins.p, (const uint32_t*)c->entries.p, job.d_static_rows, (const uint32_t*)c->dyn_rows.p,
+                       (uint32_t*)c->buckets.p, (const uint32_t*)fat, fat_cap);
+  }
   {
     Launch l(c, "k_bucket_accumulate");
     hipLaunchKernelGGL(k_bucket_accumulate, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s,
@@ -517,7 +530,7 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
     Launch l(c, "k_bucket_heavy");
     hipLaunchKernelGGL(k_bucket_heavy, dim3(512), dim3(256), 0, s, (const uint32_t*)c->bins.p,
                        (const uint32_t*)c->entries.p, job.d_static_rows, (const uint32_t*)c->dyn_rows.p,
-                       (uint32_t*)c->buckets.p, (const uint32_t*)c->heavy.p);
+                       (uint32_t*)c->buckets.p, (const uint32_t*)heavy);
   }
   uint32_t* partials = chunks == 1 ? (uint32_t*)c->window_sums.p : (uint32_t*)c->partials.p;
   uint32_t* pflags = chunks == 1 ? (uint32_t*)c->window_flags.p : (uint32_t*)c->partial_flags.p;
