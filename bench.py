@@ -54,7 +54,7 @@ import os
 # was a second communicator per rank and the bench asked for 16 to leave it room.)
 # (18 = what zkgpu_init itself asks for when it is the process's first HIP user -- here torch may be: the runtime keeps that
 # many queues per stream priority, the verifier's low- and default-priority streams come on top, and from 25 in all the
-# device stops running them side by side in one process out of four: DESIGN.md sec 5.1, profiles/r04v / r04w)
+# device stops running them side by side in one process out of four: DESIGN.md sec 5.1, profiles/archive/r04v / r04w)
 _HWQ_PRESET = "GPU_MAX_HW_QUEUES" in os.environ
 # per-kernel timing (zkgpu_profile_*), the HBM copy kernel and the mode switches of the sweeps are hooks of the library
 # (include/zkgpu_hooks.h), not exports: they answer only to a process that asks for them before it loads the library
@@ -461,7 +461,7 @@ def prover_program_microbench(ctx, host_threads: int, batch: int = 8192):
     counters = prover_leg_counters(ctx, lambda: pr.prove(vals, givens, seeds), dt, "pmc_valu_proverprog", batch, 1024)
     gens.close()
     return {"proofs_per_s": round(batch / dt, 1), "batch": batch, "ms_per_proof": round(dt / batch * 1e3, 4), "device": counters,
-            "slices": 8 if batch >= 16384 else 4 if batch >= 4096 else 3 if batch >= 2048 else 2 if batch >= 1024 else 1,
+            "slices": int.from_bytes(ctx.debug_read("prover_slices", 4), "little"),      # (what the library did in the last call)
             "constraints": len(cons), "multipliers": n, "commitments": m, "proof_bytes": len(proofs[0]), "host_threads": host_threads,
             "host_lockstep_proofs_per_s": round(256 / dt_host, 1),
             "note": "zkgpu_r1cs_prove_batch on a described constraint system (8 x 64-bit range proofs), best of 3 calls, cut by the "
@@ -625,7 +625,7 @@ def prover_microbench(ctx, gens, host_threads: int, batch: int = 16384, ctx2=Non
     if own_gens is not None:
         own_gens.close()
     return {"proofs_per_s": round(batch / best, 1), "batch": batch, "ms_per_proof": round(best / batch * 1e3, 4), "device": counters,
-            "generator_table_bits": 16, "slices": 8 if batch >= 16384 else 4 if batch >= 4096 else 3 if batch >= 2048 else 2 if batch >= 1024 else 1,
+            "generator_table_bits": 16, "slices": int.from_bytes(ctx.debug_read("prover_slices", 4), "little"),
             "two_calls_in_flight_proofs_per_s": round(2 * rounds * batch / dt2, 1),
             "host_threads": host_threads, "host_lockstep_proofs_per_s": round(512 / dt_host, 1),
             "note": "zkgpu_cloak_prove_batch on contiguous inputs, time of the library call: the whole proof on the device "
@@ -1399,7 +1399,7 @@ def run_config4(args, W):
     # (zkgpu_verifier_block_finish) and exchanged.  --blocks-in-flight D (default 4) queues blocks k+1 .. k+D-1 before block k is
     # waited for, as a node verifying a stream of blocks does: since round 4 the batches of one shape from the blocks in flight
     # are MERGED (they are tickets of the verifier's queue) instead of competing for lanes.  Measured on one MI355X, 8192 mixed
-    # transactions per block (profiles/r04p_*, r04q_*): one block at a time 2.0 M tx/s (five batches of ~1640 transactions, a
+    # transactions per block (profiles/archive/r04p_*, r04q_*): one block at a time 2.0 M tx/s (five batches of ~1640 transactions, a
     # burst with its own head and tail every step); 2 / 3 / 4 / 6 / 8 in flight at merge 8192: 2.6 / 2.8 / 2.93 / 3.0 / 3.09 M.
     # Until round 3 a second block in flight bought nothing (1.96 vs 1.97 M: it waited for lanes).
     depth = max(1, args.blocks_in_flight)

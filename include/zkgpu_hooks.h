@@ -77,6 +77,7 @@ int zkgpu_debug_coop_selftest(zkgpu_ctx *ctx, const uint32_t *in, uint32_t *out,
  *        (layout[3]: A_I1 A_O1 S1 A_I2 A_O2 S2 | V | T_1 T_3..T_6 | L | R): canonical 32-byte scalars of
  *        the verification equation MULTIPLIED THROUGH by c' = rho * y^(padded_n - 1) * prod u_j^2 (the
  *        device evaluates the equation in this inversion-free form).
+  * ("prover_slices": 4 bytes, the slices the last prover call on the context ran in.)
  * Returns bytes copied.  zkgpu_cloak_plan_layout fills layout[0..7] = slots per transaction, challenge
  * slots proper, second-phase challenges, dynamic terms, static terms, k, m, monomials. */
 long long zkgpu_debug_read(zkgpu_ctx *ctx, const char *what, void *out, size_t bytes);

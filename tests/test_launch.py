@@ -136,6 +136,11 @@ elif mode == "stall-1":
     print("ok", flush=True)
 elif mode == "refuse":
     print("ZkGpuError: ncclCommInitRank: invalid usage", flush=True); sys.exit(1)
+elif mode == "slow-exit":
+    # the id and the answer leave in ONE write on rank 0, then a teardown that never ends (ncclCommDestroy hanging)
+    sys.stdout.write("ok\n"); sys.stdout.flush(); time.sleep(600)
+elif mode == "not-ok":
+    print("the collective gave back a book", flush=True); sys.exit(0)        # ends in the letters "ok", is not the answer
 """
 
 PROBE_RANK = r"""
@@ -201,6 +206,16 @@ def test_probe_child_that_refuses_or_never_makes_an_id():
     assert "did not produce a unique id" in rec["errs"][0] and "no unique id" in rec["errs"][1] and rec["s"] < 60
 
 
+def test_probe_answer_is_a_whole_line_and_a_slow_teardown_after_it_is_not_a_stall():
+    """(1) a child that has answered "ok" and then hangs in its teardown is a success on every rank, rank 0
+    included -- whose first read may hold the id and the answer together -- and the probe is back long before the timeout;
+    (2) text that merely ENDS in the letters "ok" is not the answer."""
+    rec = _probe_world("slow-exit", 20, world=2)
+    assert rec["errs"] == [None, None] and rec["s"] < 15, rec
+    rec = _probe_world("not-ok", 20, world=2)
+    assert all(e and "exited with code 0" in e for e in rec["errs"]), rec
+
+
 def test_watchdog_ends_a_rank_that_stalls_and_the_launcher_ends_the_others():
     """The in-process bound: rank 1 'stalls in ncclCommInitRank' (sleeps) under a 1.5 s watchdog -> it says why and leaves
     with code 3; the launcher gives the waiting ranks their grace, ends them, returns 3; nobody is left.  A watchdog that is
@@ -252,6 +267,11 @@ def test_a_terminated_launcher_takes_its_ranks_and_their_children_with_it():
                 pids += [int(x) for x in l.split("pid")[1].split()]
     assert len(pids) == 4, lines
     p.terminate()
+    time.sleep(0.3)
+    try:
+        p.terminate()                     # a second SIGTERM, as `timeout` and drivers send: it must not abort the clean-up
+    except ProcessLookupError:
+        pass
     assert p.wait(timeout=30) == 143
     time.sleep(0.5)
     for pid in pids:

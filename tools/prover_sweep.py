@@ -56,7 +56,7 @@ if __name__ == "__main__":
         sys.exit(0)
     which = sys.argv[1] if len(sys.argv) > 1 else "slices"
     grid = []                                  # (kind, batch, table bits, slices, extra environment)
-    if which == "slices":                      # round 5, first sweep (profiles/r05b_*)
+    if which == "slices":                      # round 5, first sweep (profiles/archive/r05b_*)
         for kind, batches in (("cloak", (2048, 4096)), ("program", (1024, 2048))):
             for batch in batches:
                 for slices in (1, 2, 3, 4):

@@ -130,24 +130,30 @@ def probe(rank: int, world: int, device: int, timeout: float, broadcast: Callabl
             child = subprocess.Popen(command(device, rank, world, uid.hex()), stdout=subprocess.PIPE, stdin=subprocess.DEVNULL, env=penv)
         except Exception as e:       # noqa: BLE001
             err = "%s: %s" % (type(e).__name__, str(e)[:300])
+    def answered(text: str) -> bool:
+        # a whole line "ok" (not any text that happens to END in those letters: ADVICE r05)
+        return any(l.strip() == "ok" for l in text.splitlines())
+
     if child is not None and err is None:
         while True:
+            # checked BEFORE the next read: rank 0's first read may have brought "uid ...\nok\n" together, and waiting for more
+            # output then means waiting for the child to exit -- a slow teardown would read as a stall
+            if answered(tail):
+                err = None
+                try:
+                    child.wait(timeout=max(1.0, min(3.0, deadline - time.monotonic())))
+                except subprocess.TimeoutExpired:
+                    pass             # (it answered; whatever it still does at exit is not the bench's problem: ended below)
+                break
             line = _read_line(child.stdout, deadline)
             if line is None:
                 err = "stalled: no answer from zkgpu_comm_create + the first all-gather within %.0f s (child killed)" % timeout
                 break
             if line == "":
                 code = child.wait()
-                err = None if (code == 0 and tail.strip().endswith("ok")) else "probe child exited with code %d: %s" % (code, tail.strip()[-300:] or "no output")
+                err = "probe child exited with code %d: %s" % (code, tail.strip()[-300:] or "no output")
                 break
             tail += line
-            if tail.strip().endswith("ok"):
-                err = None
-                try:
-                    child.wait(timeout=max(1.0, deadline - time.monotonic()))
-                except subprocess.TimeoutExpired:
-                    pass             # (it answered; whatever it still does at exit is not the bench's problem)
-                break
     elif err is None and not have_uid:
         err = "no unique id (rank 0's probe failed)"
     if child is not None:

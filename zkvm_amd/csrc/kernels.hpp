@@ -35,7 +35,10 @@ constexpr uint32_t ENTRY_IDX = (1u << 30) - 1;
 constexpr int NIELS_WORDS = 32;
 constexpr int EXT_WORDS = 40;
 constexpr int REDUCE_CHUNK = 64;   // buckets per lane in k_bucket_reduce when a window has at most this many
-constexpr int REDUCE_CHUNK_BIG = 16;  // ... and when it has more (more lanes, shorter serial chains)
+#ifndef ZK_REDUCE_CHUNK_BIG
+#define ZK_REDUCE_CHUNK_BIG 16
+#endif
+constexpr int REDUCE_CHUNK_BIG = ZK_REDUCE_CHUNK_BIG;  // ... and when it has more (more lanes, shorter serial chains)
 constexpr int TABLE_WORDS = 24;    // fixed-base table row: three canonical 255-bit values, 96 B
 constexpr int TABLE_STRIDE = 32;   // ... one row per 128-byte line (96-byte rows at a 96-byte stride straddle lines: 2.07x the bytes addressed)
 
@@ -220,7 +223,15 @@ k_decompress_pre(const uint32_t* __restrict__ pts, uint32_t* __restrict__ scratc
 }
 
 // row[50..59] <- row[50..59]^((p-5)/8)
-__global__ void __launch_bounds__(256, 4)
+// ZK_POW_WAVES wavefronts per SIMD: at 4 (until round 6) the kernel is held to 128 registers -- 84 bytes of it in scratch -- and
+// takes EVERY register of every SIMD, so that the digit sort "beside" it (k_part_*: 20 - 52 registers a lane) only ran as its
+// workgroups retired, a quarter of the chip every 226 us (profiles/r06b_msm_timeline.txt: k_part_offsets, 4 MB of counters,
+// 207 us).  One wavefront alone issues every 4.6 cycles, two every 4.3: a chain of dependent squarings
+// does not need the fourth.
+#ifndef ZK_POW_WAVES
+#define ZK_POW_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, ZK_POW_WAVES)
 k_pow22523(uint32_t* __restrict__ scratch, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -671,49 +682,17 @@ k_bin_order(const uint32_t* __restrict__ cursor, uint64_t n_bins, uint32_t* __re
 // After the scatter, cursor[bin] is the END offset of bin; its start is the end
 // of the previous bin.  One lane per bin, bins taken in `order` (fullest first);
 // the row of the next entry is fetched while the current addition runs.
-__global__ void __launch_bounds__(256)
-k_bucket_accumulate(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ entries,
-                    const uint32_t* __restrict__ static_rows, const uint32_t* __restrict__ dyn_rows,
-                    uint32_t* __restrict__ buckets, uint64_t n_bins, const uint32_t* __restrict__ order) {
-  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= n_bins) return;
-  const uint64_t bin = order ? order[gid] : gid;
-  const uint32_t start = bin ? cursor[bin - 1] : 0u, end = cursor[bin];
-  if (start == end || end - start > FAT_BIN) return;     // fat bins: k_bucket_fat; heavy bins: k_bucket_heavy
-  ge acc;
-  ge_identity(acc);
-  // two dependent gathers per term (entry -> row): entries run two terms ahead, rows one
-  auto fetch_row = [&](uint32_t e, ge_niels& q, bool& neg) {
-    const uint32_t* row = ((e & ENTRY_DYN) ? dyn_rows : static_rows) + (uint64_t)(e & ENTRY_IDX) * NIELS_WORDS;
-    load_niels(q, row);
-    neg = (e & ENTRY_NEG) != 0;
-  };
-  ge_niels cur, nxt;
-  bool cur_neg = false, nxt_neg = false;
-  fetch_row(entries[start], cur, cur_neg);
-  uint32_t e_next = start + 1 < end ? entries[start + 1] : 0u;
-  for (uint32_t k = start; k < end; ++k) {
-    const uint32_t e_cur = e_next;
-    if (k + 2 < end) e_next = entries[k + 2];
-    if (k + 1 < end) fetch_row(e_cur, nxt, nxt_neg);
-    ge_madd(acc, acc, cur, cur_neg);
-    cur = nxt; cur_neg = nxt_neg;
-  }
-  store_ext(buckets + bin * EXT_WORDS, acc);
-}
-
 // FAT_LANES lanes per fat bin (four bins per wavefront): strided partial sums, folded by four shuffle steps inside the group.
-// The grid is fixed; the lane groups walk the fat list.
-__global__ void __launch_bounds__(256)
-k_bucket_fat(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ entries,
-             const uint32_t* __restrict__ static_rows, const uint32_t* __restrict__ dyn_rows,
-             uint32_t* __restrict__ buckets, const uint32_t* __restrict__ fat, uint32_t fat_cap) {
+// The lane groups walk the fat list (n_groups of them in all).
+__device__ __forceinline__ void bucket_fat_role(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ entries,
+                                                const uint32_t* __restrict__ static_rows, const uint32_t* __restrict__ dyn_rows,
+                                                uint32_t* __restrict__ buckets, const uint32_t* __restrict__ fat, uint32_t fat_cap,
+                                                uint32_t first_group, uint32_t n_groups) {
   const uint32_t n_fat = min(fat[0], fat_cap);
   const uint32_t sub = threadIdx.x & (FAT_LANES - 1);
-  const uint32_t groups = gridDim.x * (256 / FAT_LANES);
-  for (uint32_t f = blockIdx.x * (256 / FAT_LANES) + threadIdx.x / FAT_LANES; ; f += groups) {
+  for (uint32_t f = first_group + threadIdx.x / FAT_LANES; ; f += n_groups) {
     // (a wavefront leaves the loop together: its four groups hold consecutive list positions, and the shuffles below need all lanes)
-    if (__all((f & ~3u) >= n_fat)) break;
+    if ((f & ~3u) >= n_fat) break;
     const bool live = f < n_fat;
     const uint64_t bin = live ? fat[1 + f] : 0;
     const uint32_t start = live ? (bin ? cursor[bin - 1] : 0u) : 0u, end = live ? cursor[bin] : 0u;
@@ -737,6 +716,46 @@ k_bucket_fat(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ e
     }
     if (live && sub == 0) store_ext(buckets + bin * EXT_WORDS, acc);
   }
+}
+
+// The first `fat_blocks` workgroups of the grid sum the fat bins (bucket_fat_role), the others one bin per lane.  ONE launch:
+// the fat groups carry the longest chains (up to HEAVY_BIN / FAT_LANES additions and four folds) and must START first -- as a
+// kernel of their own on a second stream they got their slots only as the one-lane-per-bin workgroups retired and ended when
+// those did (profiles/r06b_msm_timeline.txt), queued ahead on the same stream they cost their 84 us on an idle chip.
+__global__ void __launch_bounds__(256)
+k_bucket_accumulate(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ entries,
+                    const uint32_t* __restrict__ static_rows, const uint32_t* __restrict__ dyn_rows,
+                    uint32_t* __restrict__ buckets, uint64_t n_bins, const uint32_t* __restrict__ order,
+                    const uint32_t* __restrict__ fat, uint32_t fat_cap, uint32_t fat_blocks) {
+  if (blockIdx.x < fat_blocks) {
+    bucket_fat_role(cursor, entries, static_rows, dyn_rows, buckets, fat, fat_cap, blockIdx.x * (256 / FAT_LANES), fat_blocks * (256 / FAT_LANES));
+    return;
+  }
+  const uint64_t gid = (uint64_t)(blockIdx.x - fat_blocks) * blockDim.x + threadIdx.x;
+  if (gid >= n_bins) return;
+  const uint64_t bin = order ? order[gid] : gid;
+  const uint32_t start = bin ? cursor[bin - 1] : 0u, end = cursor[bin];
+  if (start == end || end - start > FAT_BIN) return;     // fat bins: the first workgroups; heavy bins: k_bucket_heavy
+  ge acc;
+  ge_identity(acc);
+  // two dependent gathers per term (entry -> row): entries run two terms ahead, rows one
+  auto fetch_row = [&](uint32_t e, ge_niels& q, bool& neg) {
+    const uint32_t* row = ((e & ENTRY_DYN) ? dyn_rows : static_rows) + (uint64_t)(e & ENTRY_IDX) * NIELS_WORDS;
+    load_niels(q, row);
+    neg = (e & ENTRY_NEG) != 0;
+  };
+  ge_niels cur, nxt;
+  bool cur_neg = false, nxt_neg = false;
+  fetch_row(entries[start], cur, cur_neg);
+  uint32_t e_next = start + 1 < end ? entries[start + 1] : 0u;
+  for (uint32_t k = start; k < end; ++k) {
+    const uint32_t e_cur = e_next;
+    if (k + 2 < end) e_next = entries[k + 2];
+    if (k + 1 < end) fetch_row(e_cur, nxt, nxt_neg);
+    ge_madd(acc, acc, cur, cur_neg);
+    cur = nxt; cur_neg = nxt_neg;
+  }
+  store_ext(buckets + bin * EXT_WORDS, acc);
 }
 
 // One workgroup per heavy bin: 256 strided partial sums, folded by wavefront shuffles and
@@ -826,6 +845,51 @@ k_bucket_reduce(const uint32_t* __restrict__ cursor, const uint32_t* __restrict_
   }
   partial_nonempty[task] = sum_set ? 1u : 0u;
   if (sum_set) store_ext(partials + task * EXT_WORDS, sum);
+}
+
+// The same with a QUAD of lanes per task (quad.hpp: an addition is 3 multiplications deep instead of 9, a doubling 2 instead of
+// 8): for a single large multiscalar multiplication the reduction is 32 768 chains of ~54 dependent point operations on a chip
+// that is otherwise idle -- latency, 0.17 ms of a 2.2 ms call.  Four lanes hold copies of the task's points and split every
+// field operation; the four loads of a bucket are one address.  (Round 6.)
+__global__ void __launch_bounds__(256)
+k_bucket_reduce_quad(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ buckets,
+                     uint32_t* __restrict__ partials, uint32_t* __restrict__ partial_nonempty,
+                     uint64_t n_tasks, uint32_t n_buckets, uint32_t chunks_per_window, uint32_t chunk_size) {
+  const uint64_t task = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const int r = threadIdx.x & 3;
+  if (task >= n_tasks) return;                             // (whole quads leave together)
+  const uint64_t win = task / chunks_per_window;
+  const uint32_t chunk = (uint32_t)(task % chunks_per_window);
+  const uint32_t lo = chunk * chunk_size;
+  const uint32_t hi = min(lo + chunk_size, n_buckets);
+  const uint64_t bin0 = win * n_buckets;
+  ge run, sum;
+  bool run_set = false, sum_set = false;
+  for (uint32_t b = hi; b-- > lo;) {
+    const uint64_t bin = bin0 + b;
+    const uint32_t s = bin ? cursor[bin - 1] : 0u, e = cursor[bin];
+    if (s != e) {
+      ge p;
+      load_ext(p, buckets + bin * EXT_WORDS);
+      if (run_set) quad_add(run, p, r); else { run = p; run_set = true; }
+    }
+    if (run_set) {
+      if (sum_set) quad_add(sum, run, r); else { sum = run; sum_set = true; }
+    }
+  }
+  if (sum_set && lo != 0) {
+    ge acc = run;
+    const int top = 31 - __clz(lo);
+    for (int bit = top - 1; bit >= 0; --bit) {
+      quad_double(acc, r);
+      if ((lo >> bit) & 1) quad_add(acc, run, r);
+    }
+    quad_add(sum, acc, r);
+  }
+  if (r == 0) {
+    partial_nonempty[task] = sum_set ? 1u : 0u;
+    if (sum_set) store_ext(partials + task * EXT_WORDS, sum);
+  }
 }
 
 // ---- k_window_partials ------------------------------------------------------------
@@ -1078,16 +1142,27 @@ k_msm_finish_quad(const uint32_t* __restrict__ window_sums, const uint32_t* __re
   ge acc;
   ge_identity(acc);
   bool have = false;
+  // The sum of window t - 1 (and its flag) is fetched BEFORE the doublings of step t, unconditionally: in the chain of a lone
+  // batch the two dependent loads of every step (flag, then 160 bytes) were ~1.5 us of its ~7 -- a quarter of the 0.46 ms the
+  // Horner chain is of a 1024-transaction batch's 1.1 ms (round 6).  A window that is empty is loaded and not used.
+  const uint64_t win0 = (uint64_t)m * n_windows;
+  ge p;
+  uint32_t ne = window_nonempty[win0 + n_windows - 1];
+  load_ext(p, window_sums + (win0 + n_windows - 1) * EXT_WORDS);
   for (int t = n_windows - 1; t >= 0; --t) {
+    ge pn;
+    uint32_t nen = 0;
+    if (t > 0) {
+      nen = window_nonempty[win0 + t - 1];
+      load_ext(pn, window_sums + (win0 + t - 1) * EXT_WORDS);
+    }
     if (have) {
       for (int k = 0; k < w; ++k) quad_double(acc, r);
     }
-    const uint64_t win = (uint64_t)m * n_windows + t;
-    if (window_nonempty[win]) {
-      ge p;
-      load_ext(p, window_sums + win * EXT_WORDS);
+    if (ne) {
       if (have) quad_add(acc, p, r); else { acc = p; have = true; }
     }
+    if (t > 0) { p = pn; ne = nen; }
   }
   if (!live || r != 0) return;
   const bool failed = msm_fail && msm_fail[m];
@@ -1144,7 +1219,7 @@ k_spin(unsigned long long cycles, uint32_t* __restrict__ sink) {
 // The achievable-HBM yardstick of SURVEY.md sec 8(d) ("measure achievable HBM with a copy kernel and report both"): ONE
 // 16-byte vector per lane, one workgroup per 4 KiB, no loop -- the shape that reaches the 6.2-6.3 TB/s the microarchitecture
 // guide quotes for a float4 copy.  Measured on an MI355X, 2 GiB, read + write bytes (tools/ubench/hbm_copy.hip,
-// profiles/r04_hbm_copy_variants.txt): this form 6.24 TB/s; the grid-stride loop with four loads in flight that was here
+// profiles/archive/r04_hbm_copy_variants.txt): this form 6.24 TB/s; the grid-stride loop with four loads in flight that was here
 // until round 3: 4.7-4.95 TB/s whatever the grid; block-contiguous tiles of 4 / 8 vectors per lane 5.4-5.7, non-temporal
 // 5.6-6.0; hipMemcpyDtoD 5.45.
 __global__ void __launch_bounds__(256)
@@ -1375,14 +1450,44 @@ __device__ inline void static_combine_slot(const uint32_t* __restrict__ partials
   }
 }
 
+// COMBINE_LANES lanes per slot, eight slots per wavefront: a slot's W x P partial sums (19 for a payment over 14-bit tables) are
+// three additions per lane and three folds.  (Until round 6 a wavefront per slot: 19 of 64 lanes with a partial sum to load, then
+// six folds at 32, 16, .. 1 live lanes -- 0.17 of its lanes at work, 7 % of a transaction call's instructions:
+// profiles/archive/r05z_lane_utilization_per_kernel.txt; the rework k_static_row_sums got in round 5.)
+constexpr uint32_t COMBINE_LANES = 8;
+
 __global__ void __launch_bounds__(64)
 k_static_combine(const uint32_t* __restrict__ partials, uint32_t n_partials, const uint32_t* __restrict__ dyn_sum,
                  const uint8_t* __restrict__ dyn_ok, const uint32_t* __restrict__ row_map,
-                 const uint32_t* __restrict__ n_active, uint8_t* __restrict__ accept,
+                 const uint32_t* __restrict__ n_active, uint32_t n_slots, uint8_t* __restrict__ accept,
                  uint32_t* __restrict__ out_points /*optional: the sum of slot b, extended, for k_locate_finish*/) {
-  if (n_active && blockIdx.x >= *n_active) return;
-  const uint32_t slot = blockIdx.x;
-  static_combine_slot(partials, n_partials, dyn_sum, dyn_ok, slot, row_map ? row_map[slot] : slot, (int)threadIdx.x, accept, out_points);
+  const uint32_t n = n_active ? min(*n_active, n_slots) : n_slots;
+  const uint32_t g = blockIdx.x * 64 + threadIdx.x, sub = g % COMBINE_LANES, first = (blockIdx.x * 64) / COMBINE_LANES;
+  if (first >= n) return;                                  // (the whole wavefront: its slots are first .. first + 7)
+  const uint32_t mine = g / COMBINE_LANES, slot = mine < n ? mine : n - 1;      // (whole wavefronts stay active for the shuffles)
+  const uint32_t tx = row_map ? row_map[slot] : slot;
+  ge acc;
+  ge_identity(acc);
+  for (uint32_t c = sub; c < n_partials; c += COMBINE_LANES) {
+    ge p;
+    load_ext(p, partials + ((uint64_t)slot * n_partials + c) * EXT_WORDS);
+    ge_add(acc, acc, p);
+  }
+  if (sub == 0 && dyn_sum) {
+    ge p;
+    load_ext(p, dyn_sum + (uint64_t)tx * EXT_WORDS);
+    ge_add(acc, acc, p);
+  }
+#pragma unroll 1
+  for (int delta = COMBINE_LANES / 2; delta >= 1; delta >>= 1) {
+    ge other;
+    shfl_down_ge(other, acc, delta);
+    if (sub < (uint32_t)delta) ge_add(acc, acc, other);
+  }
+  if (sub == 0 && mine < n) {
+    accept[tx] = (ge_is_identity(acc) && (!dyn_ok || dyn_ok[tx])) ? 1 : 0;
+    if (out_points) store_ext(out_points + (uint64_t)slot * EXT_WORDS, acc);
+  }
 }
 
 // One thread's share of ONE row's fixed-base sum: the (window, term) pairs i = tid, tid + n_threads, .. of the W x ns

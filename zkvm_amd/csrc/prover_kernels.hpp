@@ -109,7 +109,7 @@ k_pv_rng_coop(PvShape sh, PvBatch B, uint32_t batch, uint32_t phase) {
 }
 // A round of the inner-product argument with one LANE per proof: the round is one thread's work (L_j, R_j into the transcript,
 // the challenge, its inverse), and with a workgroup per proof (k_pv_ipa, until round 5) 63 lanes of every wavefront idled
-// through ~50 000 instructions -- a fifth of all the wavefront instructions of a proving call (profiles/r05_proverprog_*).  STROBE states side by side in LDS (53 words apart:
+// through ~50 000 instructions -- a fifth of all the wavefront instructions of a proving call (profiles/archive/r05_proverprog_*).  STROBE states side by side in LDS (53 words apart:
 // no bank conflicts), the inverse by the fixed chain pv_invert_uniform.  Byte-identical proofs.
 struct PvLaneEnv {
   static constexpr bool kInvertInEveryLane = true;

@@ -881,6 +881,8 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
     fronts.clear();
   };
   struct FlushAtExit { decltype(flush_backs)& f; ~FlushAtExit() { f(); } } flush_at_exit{flush_backs};
+  size_t owed = 0;                                      // device batches still to leave of the cut decided for the head's shape
+  uint64_t owed_shape[3] = {0, 0, 0};
   while (!v->queue.empty()) {
     zkgpu_request* head = v->queue.front();
     // Everything queued of the head's shape, T transactions, leaves in round(T / target) device batches of EQUAL size (to the
@@ -892,9 +894,15 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
     size_t queued = 0;
     for (zkgpu_request* r : v->queue)
       if (r->n_in == head->n_in && r->n_out == head->n_out && r->proof_len == head->proof_len) queued += r->batch;
-    if (queued < target && !force) return ZKGPU_OK;
-    const size_t parts = std::max<size_t>(1, (queued + target / 2) / target);
-    const size_t quota = (queued + parts - 1) / parts;
+    // the cut is decided ONCE for what is queued, and every part of it leaves in this call (`owed`): two parts of 8192 must not
+    // turn into one now and one when somebody waits (the second would start after the first had finished -- measured, 16 steps)
+    const bool same_cut = owed > 0 && owed_shape[0] == head->n_in && owed_shape[1] == head->n_out && owed_shape[2] == head->proof_len;
+    if (!same_cut) {
+      if (queued < target && !force) return ZKGPU_OK;
+      owed = std::max<size_t>(1, (queued + target / 2) / target);
+      owed_shape[0] = head->n_in; owed_shape[1] = head->n_out; owed_shape[2] = head->proof_len;
+    }
+    const size_t quota = (queued + owed - 1) / owed;
     std::vector<zkgpu_request*> pick;
     size_t total = 0;
     for (zkgpu_request* r : v->queue) {
@@ -911,6 +919,7 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
       collect_oldest(v);
       continue;
     }
+    --owed;
     zkgpu_ctx* L = v->lanes[(size_t)lane];
     int rc = ZKGPU_OK;
     std::string plan_err;
@@ -1837,9 +1846,9 @@ void tx_engine_main(zkgpu_verifier* v) {
   std::unique_ptr<TxRound> active[2];
   // Two rounds in flight while the process's hardware queues are few enough for the device to run them all side by side
   // (GPU_MAX_HW_QUEUES <= 19: DESIGN.md sec 5.1), else one.  Measured on MI355X, three processes per setting
-  // (profiles/r04y_rounds_hwq.txt), at 18 queues: 4 calls of 4096 in flight 1.72 - 1.76 M tx/s with two rounds against
+  // (profiles/archive/r04y_rounds_hwq.txt), at 18 queues: 4 calls of 4096 in flight 1.72 - 1.76 M tx/s with two rounds against
   // 0.98 - 1.41 M with one, 8 calls of 1024 1.15 - 1.30 M against 1.00 - 1.12 M; at 24 queues (28 in all priorities) two
-  // rounds LOST -- 0.56 - 0.60 M against 0.92 - 0.96 M, single stages stalling 5 - 20 ms (profiles/r04e_inflight.txt,
+  // rounds LOST -- 0.56 - 0.60 M against 0.92 - 0.96 M, single stages stalling 5 - 20 ms (profiles/archive/r04e_inflight.txt,
   // r04f_inflight_timing.txt): both key contexts, both signature contexts and the lanes busy at once were more queues than
   // the device runs side by side.  ZKGPU_TX_ROUNDS=1 / 2 overrides.
   int max_rounds = 1;

@@ -90,6 +90,7 @@ struct zkgpu_ctx {
   hipEvent_t ev_t = nullptr, ev_p = nullptr, ev_sm = nullptr, ev_sa = nullptr, ev_done = nullptr;
   bool pending = false;            // a submitted batch has not been waited for yet
   size_t pending_batch = 0;
+  int last_prover_slices = 0;      // slices the last prover call ran in (what the library did, not what a caller computes: ADVICE r05)
   bool broken = false;             // a device fault could not even be drained (quiesce_after_fault): every later call fails
   // the general (non-pipelined) batch paths in two halves -- batch_device_enqueue / batch_device_tables_enqueue queue the
   // kernels and the copy of the results to the pinned buffer, batch_collect waits and reads them -- so that the key and
@@ -103,7 +104,7 @@ struct zkgpu_ctx {
   // tables (chip-filling); BACK = everything that waits for the transcript.  The verifier queues the FRONT of every batch,
   // then the MID of every batch, then the BACKs, so that the second batch's transcript and decoding run beside the first's
   // instead of 0.6 ms later, when the host has finished queueing the first batch's ~45 launches
-  // (profiles/r04am_timeline.txt).  The same call is made once per piece with the same arguments.
+  // (profiles/archive/r04am_timeline.txt).  The same call is made once per piece with the same arguments.
   enum { ENQ_ALL = 0, ENQ_FRONT = 1, ENQ_MID = 2, ENQ_BACK = 3 };
   int enqueue_phase = ENQ_ALL;
   bool awaiting_back = false;      // an ENQ_FRONT call really queued a front half (shapes outside the pipeline run whole, at once)
@@ -395,7 +396,19 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
   TRY(ensure(c, c->msm_fail, (size_t)job.n_msm * 4));
   TRY(ensure(c, c->status, 64));
 
+  // heavy list | fat list (kernels.hpp: bins summed by a workgroup each / by FAT_LANES lanes each)
+  const uint32_t fat_cap = (uint32_t)(max_entries / FAT_BIN + 64);
+  TRY(ensure(c, c->heavy, ((size_t)HEAVY_MAX + 1 + fat_cap + 1) * 4));
+  uint32_t* heavy = (uint32_t*)c->heavy.p;
+  uint32_t* fat = heavy + HEAVY_MAX + 1;
+  TRY(ensure(c, c->class_count, 2 * SIZE_CLASSES * 4));
+
   hipStream_t s = c->stream;
+  // (every counter the sort and the bin order start from is cleared HERE, before anything runs: a memset between two kernels is
+  // a launch of its own, ~10 us of an otherwise empty queue each -- four of them stood between the sort and the accumulation)
+  HIP_TRY(c, hipMemsetAsync(heavy, 0, 4, s));
+  HIP_TRY(c, hipMemsetAsync(fat, 0, 4, s));
+  HIP_TRY(c, hipMemsetAsync(c->class_count.p, 0, SIZE_CLASSES * 4, s));
   const bool part_sort = job.n_msm == 1 && job.n_static == 0 && w - 1 >= PART_LO_BITS && n_terms >= 32768 && n_terms <= (1ull << PART_IDX_BITS);
   if (!part_sort) HIP_TRY(c, hipMemsetAsync(c->bins.p, 0, (n_bins + 1) * 4, s));     // (the partition sort writes every bin's end offset itself)
   HIP_TRY(c, hipMemsetAsync(c->msm_fail.p, 0, (size_t)job.n_msm * 4, s));
@@ -435,10 +448,8 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
                        (uint32_t*)c->dyn_rows.p, job.n_dyn, job.d_dyn_offsets, job.n_msm,
                        (uint32_t*)c->msm_fail.p, bad_index, (uint8_t*)nullptr);
   }
-  TRY(ensure(c, c->class_count, 2 * SIZE_CLASSES * 4));
   uint32_t* class_count = (uint32_t*)c->class_count.p;
   uint32_t* class_cursor = class_count + SIZE_CLASSES;
-  HIP_TRY(c, hipMemsetAsync(class_count, 0, SIZE_CLASSES * 4, s));
   if (part_sort) {
     // single large MSM: two-level sort with LDS atomics only
     PartShape ps;
@@ -494,13 +505,6 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
     }
   }
   TRY(ensure(c, c->bin_order, n_bins * 4));
-  // heavy list | fat list (kernels.hpp: bins summed by a workgroup each / by FAT_LANES lanes each)
-  const uint32_t fat_cap = (uint32_t)(max_entries / FAT_BIN + 64);
-  TRY(ensure(c, c->heavy, ((size_t)HEAVY_MAX + 1 + fat_cap + 1) * 4));
-  uint32_t* heavy = (uint32_t*)c->heavy.p;
-  uint32_t* fat = heavy + HEAVY_MAX + 1;
-  HIP_TRY(c, hipMemsetAsync(heavy, 0, 4, s));
-  HIP_TRY(c, hipMemsetAsync(fat, 0, 4, s));
   {
     Launch l(c, "k_bin_order");
     if (!part_sort)                                      // (the partition sort counts the size classes of its bins itself)
@@ -512,19 +516,14 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
   }
   if (decompress_aside) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
   {
-    // the fat bins first: their lane groups carry the longest chains of the three kernels (FAT_BIN ... HEAVY_BIN / FAT_LANES
-    // additions and four folds); queued ahead, they run beside the first rounds of the one-lane-per-bin kernel
-    Launch l(c, "k_bucket_fat");
-    hipLaunchKernelGGL(k_bucket_fat, dim3(std::min<unsigned>(blocks_for((uint64_t)fat_cap * FAT_LANES, 256), 1024u)), dim3(256), 0, s,
-                       (const uint32_t*)c->bins.p, (const uint32_t*)c->entries.p, job.d_static_rows, (const uint32_t*)c->dyn_rows.p,
-                       (uint32_t*)c->buckets.p, (const uint32_t*)fat, fat_cap);
-  }
-  {
+    // one launch: its first workgroups sum the fat bins with FAT_LANES lanes each (they hold the longest chains and must start
+    // first), the others one bin per lane
+    const unsigned fat_blocks = std::min<unsigned>(blocks_for((uint64_t)fat_cap * FAT_LANES, 256), 320u);
     Launch l(c, "k_bucket_accumulate");
-    hipLaunchKernelGGL(k_bucket_accumulate, dim3(blocks_for(n_bins, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_bucket_accumulate, dim3(fat_blocks + blocks_for(n_bins, 256)), dim3(256), 0, s,
                        (const uint32_t*)c->bins.p, (const uint32_t*)c->entries.p, job.d_static_rows,
                        (const uint32_t*)c->dyn_rows.p, (uint32_t*)c->buckets.p, n_bins,
-                       (const uint32_t*)c->bin_order.p);
+                       (const uint32_t*)c->bin_order.p, (const uint32_t*)fat, fat_cap, fat_blocks);
   }
   {
     Launch l(c, "k_bucket_heavy");
@@ -535,9 +534,15 @@ int run_to_windows(zkgpu_ctx* c, const Job& job, JobDesc& jd, bool reset_status 
   uint32_t* partials = chunks == 1 ? (uint32_t*)c->window_sums.p : (uint32_t*)c->partials.p;
   uint32_t* pflags = chunks == 1 ? (uint32_t*)c->window_flags.p : (uint32_t*)c->partial_flags.p;
   {
+    // few tasks (one large multiscalar multiplication: 32 768): a quad of lanes per task, a third of the chain's depth; many
+    // tasks (a batch of small ones): one lane each, a quarter of the instructions
     Launch l(c, "k_bucket_reduce");
-    hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_for(n_tasks, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p,
-                       (const uint32_t*)c->buckets.p, partials, pflags, n_tasks, jd.n_buckets, chunks, chunk_size);
+    if (n_tasks <= 65536)
+      hipLaunchKernelGGL(k_bucket_reduce_quad, dim3(blocks_for(4 * n_tasks, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p,
+                         (const uint32_t*)c->buckets.p, partials, pflags, n_tasks, jd.n_buckets, chunks, chunk_size);
+    else
+      hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_for(n_tasks, 256)), dim3(256), 0, s, (const uint32_t*)c->bins.p,
+                         (const uint32_t*)c->buckets.p, partials, pflags, n_tasks, jd.n_buckets, chunks, chunk_size);
   }
   if (chunks > 1) {
     Launch l(c, "k_window_partials");
@@ -803,10 +808,10 @@ int batch_device_tables_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_points
   HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
   {
     Launch l(c, "k_static_combine");
-    hipLaunchKernelGGL(k_static_combine, dim3((unsigned)B), dim3(64), 0, s, (const uint32_t*)c->st_partials.p,
+    hipLaunchKernelGGL(k_static_combine, dim3(blocks_for((uint64_t)B * COMBINE_LANES, 64)), dim3(64), 0, s, (const uint32_t*)c->st_partials.p,
                        (uint32_t)(W * P), has_dyn ? (const uint32_t*)c->dynsum.p : (const uint32_t*)nullptr,
                        has_dyn ? (const uint8_t*)c->accept.p : (const uint8_t*)nullptr, (const uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, (uint8_t*)c->accept2.p, (uint32_t*)nullptr);
+                       (const uint32_t*)nullptr, (uint32_t)B, (uint8_t*)c->accept2.p, (uint32_t*)nullptr);
   }
   {
     Launch l(c, "k_pack_bitmap");
@@ -979,7 +984,7 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     // the proof-specific points need the proof bytes only: gather, decompress and build their small tables on the shared
     // stream while the transcript is replayed.  Queued AFTER the transcript: k_points_tables takes every register of the chip
     // (255 per lane, two wavefronts per SIMD), and a light kernel queued behind it waits for one of its wavefronts to retire
-    // -- ~0.6 ms (measured: the next batch's 30 us merge copy took 0.59 ms there, profiles/r04an_timeline.txt)
+    // -- ~0.6 ms (measured: the next batch's 30 us merge copy took 0.59 ms there, profiles/archive/r04an_timeline.txt)
     const PrepShape& sh = prep->sh;
     HIP_TRY(c, hipStreamWaitEvent(H1, c->ev_u, 0));
     {
@@ -1147,9 +1152,9 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     }
     {
       Launch l(c, "k_static_combine", L);
-      hipLaunchKernelGGL(k_static_combine, dim3((unsigned)B), dim3(64), 0, L, (const uint32_t*)c->st_partials.p,
+      hipLaunchKernelGGL(k_static_combine, dim3(blocks_for((uint64_t)B * COMBINE_LANES, 64)), dim3(64), 0, L, (const uint32_t*)c->st_partials.p,
                          (uint32_t)(W * Pf), (const uint32_t*)c->dynsum.p, (const uint8_t*)c->accept.p,
-                         (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, (uint8_t*)c->accept2.p,
+                         (const uint32_t*)c->row_map.p, (const uint32_t*)n_recheck, (uint32_t)B, (uint8_t*)c->accept2.p,
                          (uint32_t*)c->rechk_pts.p);
     }
     }
@@ -1163,9 +1168,9 @@ int pipe_enqueue(zkgpu_ctx* c, const Job& job, const zkgpu_pointset* ps, const P
     }
   } else {
     Launch l(c, "k_static_combine", L);
-    hipLaunchKernelGGL(k_static_combine, dim3((unsigned)B), dim3(64), 0, L, (const uint32_t*)c->st_partials.p,
+    hipLaunchKernelGGL(k_static_combine, dim3(blocks_for((uint64_t)B * COMBINE_LANES, 64)), dim3(64), 0, L, (const uint32_t*)c->st_partials.p,
                        (uint32_t)(W * P), (const uint32_t*)c->dynsum.p, (const uint8_t*)c->accept.p,
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)c->accept2.p, (uint32_t*)nullptr);
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)B, (uint8_t*)c->accept2.p, (uint32_t*)nullptr);
   }
   if (group <= 1) {
     Launch l(c, "k_pack_bitmap", L);
@@ -1710,6 +1715,12 @@ long long zkgpu_debug_read(zkgpu_ctx* c, const char* what, void* out, size_t byt
     return (long long)n;
   }
 #endif
+  if (w == "prover_slices") {          // slices the LAST prover call on this context really ran in (run_sliced): 4 bytes
+    if (bytes < 4) return ZKGPU_EINVAL;
+    const uint32_t n = (uint32_t)c->last_prover_slices;
+    memcpy(out, &n, 4);
+    return 4;
+  }
   const Buffer* b = w == "challenges" ? &c->prep_ch : w == "static_scalars" ? &c->prep_st_sc :
                     w == "dyn_scalars" ? &c->prep_dyn_sc : w == "dyn_points" ? &c->prep_dyn_pt : nullptr;
   if (!b || !b->p) return ZKGPU_EINVAL;
@@ -2037,6 +2048,9 @@ int ipa_on_device(zkgpu_ctx* c, const zkgpu_pointset* ps, std::vector<std::uniqu
 
 // ---- the device prover ------------------------------------------------------------------------------------
 // (host_parallel: host_pool.hpp)
+#ifndef PV_RNG_LANES_FROM
+#define PV_RNG_LANES_FROM ((size_t)1 << 40)      // (never, until the A/B of round 6 says otherwise)
+#endif
 
 // values of `rows` multiscalar multiplications over the tables, everything resident: queued on the context's stream,
 // encodings written to d_out (32 bytes per row)
@@ -2074,6 +2088,15 @@ int msm_ps_dev(zkgpu_ctx* c, const zkgpu_pointset* ps, size_t rows, uint64_t n, 
   }
   HIP_TRY(c, hipGetLastError());
   return ZKGPU_OK;
+}
+
+// The TranscriptRng's draws -- one Keccak-f each, 3 + 2n of them per proof, a third of a proof's instructions in the wavefront
+// form (k_pv_rng_coop: 25 of 64 lanes at work, ~1500 wave-instructions per draw) -- in the LANE form (k_pv_rng: 64 proofs per
+// wavefront, ~70 wave-instructions per draw and proof, but 8 us of one lane's latency per draw) when the call is large enough
+// for other slices to fill the chip meanwhile.  Same draws, same proofs.  (ZKGPU_PV_RNG=lanes|coop overrides: A/B.)
+bool pv_rng_lanes_pay(const zkgpu_ctx* c, size_t batch_of_this_slice) {
+  (void)c;
+  return batch_of_this_slice >= PV_RNG_LANES_FROM;
 }
 
 // Proves `batch` statements of one described system.  Host: the constant tables (once per call), the inputs' upload,
@@ -2186,9 +2209,16 @@ int prove_device(zkgpu_ctx* c, const zkgpu_pointset* ps, const PvHostPlan& hp, s
   PV_LANES(1, 1, c->pv_com.p) PV_WG(1, 2, c->pv_com.p) PV_LANES(1, 4, c->pv_com.p) PV_WG(1, 8, c->pv_com.p)
   // the TranscriptRng's draws: one wavefront per proof on the spread Keccak state (k_pv_rng, one lane per proof, is the
   // form the host emulation and the first device version ran; kept for comparison)
+  static const int rng_env = [] { const char* e = getenv("ZKGPU_PV_RNG"); return e ? (e[0] == 'l' ? 1 : e[0] == 'c' ? 2 : 0) : 0; }();
+  const bool rng_lanes = rng_env == 1 || (rng_env == 0 && pv_rng_lanes_pay(c, batch));
   auto rng_launch = [&](uint32_t phase, uint32_t) {
-    Launch l(c, "k_pv_rng_coop");
-    hipLaunchKernelGGL(k_pv_rng_coop, dim3(nb), dim3(64), 0, s, sh, B, nb, phase);
+    if (rng_lanes) {
+      Launch l(c, "k_pv_rng");
+      hipLaunchKernelGGL(k_pv_rng, dim3(blocks_for(nb, 64)), dim3(64), 0, s, sh, B, nb, phase);
+    } else {
+      Launch l(c, "k_pv_rng_coop");
+      hipLaunchKernelGGL(k_pv_rng_coop, dim3(nb), dim3(64), 0, s, sh, B, nb, phase);
+    }
   };
   rng_launch(1u, sh.n1);
   TRY(msm(1, B.rows1, pts));
@@ -2322,7 +2352,7 @@ int prover_slice_count(const zkgpu_ctx* c, size_t batch) {
   static const int env = [] { const char* e = getenv("ZKGPU_PROVER_SLICES"); return e ? std::max(1, std::min(8, atoi(e))) : 0; }();
   const int forced = c->prover_slices ? c->prover_slices : env;
   if (forced) return (int)std::min<size_t>((size_t)forced, std::max<size_t>(1, batch));
-  // the sweeps (profiles/r05b_prover_sweep_*.jsonl, r05z_prover_slices_after_stages.jsonl, r05z_prover_bigger_calls.jsonl; DESIGN.md
+  // the sweeps (profiles/archive/r05b_prover_sweep_*.jsonl, r05z_prover_slices_after_stages.jsonl, r05z_prover_bigger_calls.jsonl; DESIGN.md
   // sec 4.4): slices of one to two thousand statements, at most eight
   return batch >= 16384 ? 8 : batch >= 4096 ? 4 : batch >= 2048 ? 3 : batch >= 1024 ? 2 : 1;
 }
@@ -2336,6 +2366,7 @@ int run_sliced(zkgpu_ctx* c, size_t batch, int host_threads, const std::function
     if (ctx_create(c->device, nullptr, &t, 2) != ZKGPU_OK) { S = (int)c->pv_slices.size() + 1; break; }   // (fewer slices: still correct)
     c->pv_slices.push_back(t);
   }
+  c->last_prover_slices = std::max(S, 1);
   if (S <= 1) return one(c, 0, batch, host_threads);
   const int ht = std::max(1, (host_threads > 0 ? host_threads : usable_cpus()) / S);
   std::vector<int> rc((size_t)S, ZKGPU_OK);

@@ -82,11 +82,16 @@ def spawn_ranks(command: Sequence[str], world: int, env: Optional[Dict[str, str]
     first_bad: Optional[int] = None
     # a SIGTERM to the parent (`timeout 600 python bench.py --gpus 8`, the driver's limit) must not leave the ranks behind,
     # holding the GPUs and waiting in a collective: it becomes an exception here and the `finally` below ends them
+    # (the handler only SETS A FLAG that the poll loop reads -- an exception raised from a signal handler lands at
+    # whatever bytecode is running, and a second SIGTERM, which `timeout` and drivers do send, used to land inside the clean-up
+    # and abort it with the ranks still alive; during the clean-up further SIGTERMs are ignored)
     class _Terminated(BaseException):
         pass
 
+    term_seen = threading.Event()
+
     def on_term(signum, frame):
-        raise _Terminated()
+        term_seen.set()
 
     old_term = None
     if threading.current_thread() is threading.main_thread():
@@ -96,6 +101,8 @@ def spawn_ranks(command: Sequence[str], world: int, env: Optional[Dict[str, str]
             old_term = None
     try:
         for r in range(world):
+            if term_seen.is_set():
+                raise _Terminated()
             p = subprocess.Popen(list(command), env=rank_environment(base, r, world, port), stdout=subprocess.PIPE,
                                  stdin=subprocess.DEVNULL, text=True, bufsize=1, start_new_session=True)
             procs.append(p)
@@ -107,6 +114,8 @@ def spawn_ranks(command: Sequence[str], world: int, env: Optional[Dict[str, str]
         t_bad: Optional[float] = None
         sent_term = False
         while True:
+            if term_seen.is_set():
+                raise _Terminated()
             running = 0
             for r, p in enumerate(procs):
                 if codes[r] is None:
@@ -141,6 +150,11 @@ def spawn_ranks(command: Sequence[str], world: int, env: Optional[Dict[str, str]
         first_bad = first_bad or 143
     finally:
         # whatever way this is left (an exception above, KeyboardInterrupt, SIGTERM, a failed Popen): nobody stays behind
+        if old_term is not None:
+            try:
+                signal.signal(signal.SIGTERM, signal.SIG_IGN)           # (a second SIGTERM must not interrupt the clean-up)
+            except (ValueError, OSError):
+                pass
         if any(p.poll() is None for p in procs):
             end_all(signal.SIGTERM)
             t_end = time.monotonic() + 2.0
