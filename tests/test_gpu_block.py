@@ -1203,3 +1203,68 @@ def test_tickets_of_drawn_sizes_from_host_and_device_memory_waited_for_in_a_draw
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "ticket_soak.py"), "250", str(seed), str(merge), str(lanes)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ticket soak ok: 250 tickets" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_ticket_bursts_leave_in_equal_device_batches_and_the_default_target_is_the_tuned_one(ctx, oracle):
+    """Round 6: what is queued of one shape leaves in round(queued / target) device batches of EQUAL
+    size, all of them in the call that decided the cut -- bursts of 16, 20, 24, 37 tickets at a target of ten tickets are
+    2, 2, 2, 4 device batches (8 + 8, 10 + 10, 12 + 12, 10 + 9 + 9 + 9), counted by the k_batch_init launches on the lanes;
+    half a target beyond a multiple makes one batch more (24 -> 2, 25 -> 3); every bit of every ticket against the
+    oracle.  And a verifier nobody called set_merge on cuts at 10 240 transactions: 21 tickets of 1024 -> two batches."""
+    from gpu_util import benched_randomness, benched_step
+    from zkvm_amd.verifier import BlockVerifier, BulletproofGens
+    small, merge = 48, 480                                       # tickets of 48 transactions, ten to a target
+    gens = BulletproofGens(ctx, 256, table_bits=10)
+    sets = []
+    for s in range(37):
+        txs, expected = benched_step(small, 0, 16, s)
+        r = benched_randomness(0, s, small)
+        n_in, n_out, plen = txs[0][0], txs[0][1], len(txs[0][3])
+        com, proofs = b"".join(t[2] for t in txs), b"".join(t[3] for t in txs)
+        assert list(oracle.cloak_verify_batch(com, n_in, n_out, proofs, plen, r, threads=16)) == expected, s
+        sets.append(([ctx.to_device(b) for b in (com, proofs, r)], expected))
+
+    def device_batches(bv, run):
+        lanes = [bv.lane(i) for i in range(bv.lanes())]
+        for c in lanes:
+            c.profile_reset()
+            c.profile(True)
+        run()
+        n = 0
+        for c in lanes:
+            c.profile(False)
+            n += int(c.profile_read().get("k_batch_init", (0, 0.0))[0])
+        return n
+
+    bv = BlockVerifier(ctx, gens, batches_in_flight=5)
+    bv.set_merge(merge)
+    try:
+        for burst, want_batches in ((16, 2), (20, 2), (24, 2), (37, 4), (25, 3), (4, 1)):
+            def run():
+                tickets = bv.submit_many_dev(n_in, n_out, small, [t[0] for t, _ in sets[:burst]], [t[1] for t, _ in sets[:burst]], plen,
+                                             [t[2] for t, _ in sets[:burst]])
+                for k, tk in enumerate(tickets):
+                    assert bits(bv.wait(tk), small) == sets[k][1], (burst, k)
+            assert device_batches(bv, run) == want_batches, burst
+    finally:
+        bv.close()
+    # the library's own target, 1024-transaction tickets (one step's inputs repeated: the verdicts repeat with them)
+    big = 1024
+    txs, expected = benched_step(big, 0, 64, 0)
+    r = benched_randomness(0, 0, big)
+    d = [ctx.to_device(b) for b in (b"".join(t[2] for t in txs), b"".join(t[3] for t in txs), r)]
+    bv = BlockVerifier(ctx, gens, batches_in_flight=5)           # (no set_merge)
+    try:
+        def run21():
+            tickets = bv.submit_many_dev(n_in, n_out, big, [d[0]] * 21, [d[1]] * 21, plen, [d[2]] * 21)
+            for tk in tickets:
+                assert bits(bv.wait(tk), big) == expected
+        assert device_batches(bv, run21) == 2                    # 21 504 transactions: round(2.1) = 2 batches (11 + 10 tickets)
+    finally:
+        bv.close()
+        for x in d:
+            ctx.free_device(x)
+        for t, _ in sets:
+            for x in t:
+                ctx.free_device(x)
+        gens.close()

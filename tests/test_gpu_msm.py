@@ -334,6 +334,43 @@ def test_msm_adversarial_bin_loads(ctx, oracle):
     assert got == ctx.msm(((n * k) % L).to_bytes(32, "little"), one_pt)
 
 
+def test_msm_fat_bins_between_the_one_lane_and_the_workgroup_path(ctx, oracle):
+    """Round 6: bins of 97 .. 2048 entries are summed by 16 lanes each inside the accumulation launch (kernels.hpp
+    FAT_BIN / bucket_fat_role) -- in a uniform 2^20-term multiplication that is the whole top window.  Here every size class
+    around both thresholds on purpose: scalars drawn from few distinct values so that a window's bins hold 90 .. 2100
+    entries, mixed with uniform ones (one-lane bins) and one value shared by 5000 terms (a heavy bin); and the top window of
+    uniform scalars at 2^17 terms (32 entries a bin in window 15)."""
+    n = 40000
+    pts = points(oracle, "fat", n, distinct=509)
+    rng = random.Random(606)
+    few = [rng.randrange(L) for _ in range(60)]
+    sizes = [90, 96, 97, 98, 128, 255, 256, 257, 700, 2047, 2048, 2049, 2100]
+    vals = []
+    for i, c in enumerate(sizes):
+        vals += [few[i]] * c
+    vals += [few[40]] * 5000
+    vals += [rng.randrange(L) for _ in range(n - len(vals))]
+    rng.shuffle(vals)
+    sc = b"".join(v.to_bytes(32, "little") for v in vals)
+    for w in (0, 16, 13, 9):                                  # (0: the library's choice for this size)
+        ctx.set_window_bits(w)
+        try:
+            got = ctx.msm(sc, pts)
+        finally:
+            ctx.set_window_bits(0)
+        rc, want, _ = oracle.msm(sc, pts)
+        assert rc == 0 and got == want, w
+    n = 1 << 17
+    sc, pts = scalars("fat top window", n), points(oracle, "fat2", n, distinct=977)
+    ctx.set_window_bits(16)
+    try:
+        got = ctx.msm(sc, pts)
+    finally:
+        ctx.set_window_bits(0)
+    rc, want, _ = oracle.msm(sc, pts)
+    assert rc == 0 and got == want
+
+
 @pytest.mark.parametrize("w", [5, 12])
 def test_msm_values_over_resident_set(ctx, oracle, w):
     """zkgpu_msm_ps_batch (the prover-side primitive: Pedersen vector commitments out of the fixed-base
