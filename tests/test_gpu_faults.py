@@ -338,3 +338,123 @@ def test_sliced_prover_call_fails_closed_in_every_slice(ctx, oracle):
     finally:
         _disarm(ctx)
         gens.close()
+
+
+@pytest.mark.timeout(1500, method="thread")
+def test_the_four_entry_points_of_the_survey_fail_closed(ctx, oracle):
+    """(e) SURVEY.md sec 8(b): zkgpu_msm (out = 32 zero bytes and a nonzero status on a device error: the partition sort, the
+    decompression beside it on the second stream, the fat / heavy bins) and zkgpu_verify_batch (bitmap zeroed) on a context of
+    their own; zkgpu_init / zkgpu_destroy are what every fresh set of objects of the sweep goes through."""
+    from gpu_util import points, scalars
+    from zkvm_amd import Context
+    lib = ctx.lib
+    n = 40000                                              # (the partition-sort path: >= 32 768 terms)
+    sc, pt = scalars("fault msm", n), points(oracle, "fault msm", n, distinct=211)
+    rc, want, _ = oracle.msm(sc, pt)
+    assert rc == 0
+    m = 300
+    bsc, bpt, offs, expect = b"", b"", [0], []
+    for i in range(m):
+        k = int.from_bytes(sc[32 * i: 32 * i + 32], "little")
+        p = pt[32 * i: 32 * i + 32]
+        good = i % 7 != 3
+        bsc += k.to_bytes(32, "little") + ((L_ORDER - k + (0 if good else 1)) % L_ORDER).to_bytes(32, "little")
+        bpt += p + p
+        offs.append(offs[-1] + 2)
+        expect.append(1 if good else 0)
+    want_bm = bytearray((m + 7) // 8)
+    for i, b in enumerate(expect):
+        want_bm[i // 8] |= b << (i % 8)
+    assert oracle.verify_batch(bsc, bpt, offs) == bytes(want_bm)
+    c_offs = (C.c_uint64 * (m + 1))(*offs)
+
+    def make():
+        c2 = Context(0)
+
+        def scenario():
+            out = C.create_string_buffer(b"\xff" * 32, 32)
+            bad = C.c_size_t(0)
+            st = lib.zkgpu_msm(c2.h, sc, pt, n, out, C.byref(bad))
+            bm = C.create_string_buffer(b"\xff" * len(want_bm), len(want_bm))
+            st2 = lib.zkgpu_verify_batch(c2.h, bsc, bpt, c_offs, m, bm)
+            return [(st, out.raw, want), (st2, bm.raw, bytes(want_bm))]
+        return scenario, c2.close
+
+    _sweep(ctx, make, _check_outputs("msm + verify_batch"), "msm + verify_batch", cold_samples=12)
+
+
+L_ORDER = 2**252 + 27742317777372353535851937790883648493
+
+
+@pytest.mark.timeout(1500, method="thread")
+def test_serialized_transaction_calls_fail_closed_synchronous_and_in_flight(ctx, oracle):
+    """(f) zkgpu_tx_verify_batch and two zkgpu_tx_verify_submit calls in flight on one verifier (the engine thread's rounds):
+    staging arenas, the key and signature stages on their own contexts, the proofs as blocks over the ticket queue.  Both
+    outputs fail closed: a nonzero status leaves every accept bit 0 and NO status byte 0 ("accepted"); with status OK bits and
+    status bytes are the oracle's (the transactions' expected verdicts are held against the oracle's Tx::verify here)."""
+    from gpu_util import built_transactions
+    from zkvm_amd.verifier import BlockVerifier, BulletproofGens
+    lib = ctx.lib
+    n = 96
+    txs, expected = built_transactions(n, call=7, bad_every=8)
+    r = hashlib.shake_256(b"faulty tx").digest(64)
+    assert [1 if oracle.tx_verify(t, r) == 0 else 0 for t in txs[:24]] == list(expected[:24]) and 0 in expected and 1 in expected
+    want_bm = bytearray((n + 7) // 8)
+    for i, b in enumerate(expected):
+        want_bm[i // 8] |= b << (i % 8)
+    want_st = bytes(0 if b else 1 for b in expected)
+    blob = b"".join(txs)
+    offs = (C.c_uint64 * (n + 1))(*([0] + [sum(len(t) for t in txs[:i + 1]) for i in range(n)]))
+    half = n // 2
+    blob_a, blob_b = b"".join(txs[:half]), b"".join(txs[half:])
+    offs_a = (C.c_uint64 * (half + 1))(*([0] + [sum(len(t) for t in txs[:i + 1]) for i in range(half)]))
+    offs_b = (C.c_uint64 * (n - half + 1))(*([0] + [sum(len(t) for t in txs[half:half + i + 1]) for i in range(n - half)]))
+    gens = BulletproofGens(ctx, 256, table_bits=8)
+
+    def bm_of(bits_):
+        out = bytearray((len(bits_) + 7) // 8)
+        for i, b in enumerate(bits_):
+            out[i // 8] |= b << (i % 8)
+        return bytes(out)
+
+    def make():
+        bv = BlockVerifier(ctx, gens, batches_in_flight=3)
+        bv.set_tx_format(BlockVerifier.TXFORMAT_RECOLLECTED_V1)
+
+        def scenario():
+            bm = C.create_string_buffer(b"\xff" * len(want_bm), len(want_bm))
+            st = C.create_string_buffer(b"\x00" * n, n)               # (0 = "accepted": the value that must never survive an error)
+            rc = lib.zkgpu_tx_verify_batch(bv.h, n, blob, offs, 4, bm, st)
+            outs = [(rc, bm.raw, bytes(want_bm))]
+            if rc == OK:
+                assert st.raw == want_st
+            else:
+                assert 0 not in st.raw, "a status of 'accepted' beside an error"
+            ids = []
+            for b_, o_, cnt in ((blob_a, offs_a, half), (blob_b, offs_b, n - half)):
+                cid = C.c_uint64(0)
+                rc = lib.zkgpu_tx_verify_submit(bv.h, cnt, b_, o_, 2, C.byref(cid))
+                ids.append((rc, cid.value, cnt))
+            for k, (rc, cid, cnt) in enumerate(ids):
+                lo = 0 if k == 0 else half
+                wbm = bm_of(list(expected[lo: lo + cnt]))
+                if rc != OK:
+                    outs.append((rc, bytes(len(wbm)), wbm))
+                    continue
+                bm2 = C.create_string_buffer(b"\xff" * len(wbm), len(wbm))
+                st2 = C.create_string_buffer(b"\x00" * cnt, cnt)
+                rc2 = lib.zkgpu_tx_verify_wait(bv.h, cid, bm2, st2)
+                outs.append((rc2, bm2.raw, wbm))
+                if rc2 == OK:
+                    assert st2.raw == want_st[lo: lo + cnt]
+                else:
+                    assert 0 not in st2.raw
+            return outs
+        scenario.verifier = bv
+        return scenario, bv.close
+
+    try:
+        _sweep(ctx, make, _check_outputs("serialized transactions"), "serialized transactions", cold_samples=16)
+    finally:
+        _disarm(ctx)
+        gens.close()
