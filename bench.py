@@ -425,6 +425,22 @@ def msm_microbench(ctx, torch, dev):
                     tot += valu_tbl.get(name, 0) * (launches.get(k, 1.0) if name == k else 1.0)
             out["valu_wave_instructions"] = int(tot)
             out["valu_issue_frac"] = round(tot * 64 / dt / 1e9 / VALU_PEAK_GINST, 4)
+            # the roofline that binds, per chip-filling kernel of the call: instructions x their mix-weighted issue cost against the
+            # measured duration (VERDICT r05 weak 2 read k_bucket_accumulate at 0.56 of it)
+            try:
+                mix = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
+            except Exception:                                   # noqa: BLE001
+                mix = {}
+            by = {}
+            for k, ms in (("k_pow22523", None), ("k_bucket_accumulate", kern.get("k_bucket_accumulate")), ("k_bucket_reduce_quad", kern.get("k_bucket_reduce"))):
+                if k in mix and k in valu_tbl:
+                    bound = valu_tbl[k] * mix[k]["cpi_mix"] / (N_SIMD * CLOCK_GHZ * 1e9) * 1e3
+                    by[k] = {"valu_wave_instructions": int(valu_tbl[k]), "cpi_mix": mix[k]["cpi_mix"], "mix_bound_ms": round(bound, 4),
+                             "launch_ms": ms, "mix_frac": round(bound / ms, 4) if ms else None}
+            out["roofline"]["valu_by_kernel"] = by
+            out["roofline"]["valu_note"] = ("mix_bound_ms = SQ_INSTS_VALU (profiles/pmc_valu.json, this pipeline) x mix-weighted cycles per instruction "
+                                            "(profiles/valu_mix.json) / (1024 SIMDs x 2.4 GHz); k_pow22523 runs inside the k_decompress events "
+                                            "(its own duration: the rocprofv3 summary, profiles/r06_msm_kernel_trace_summary.txt)")
     return out
 
 
