@@ -49,6 +49,9 @@ inline hipError_t gate() {
 }}  // namespace zk::fault
 
 // (GNU `a ?: b`: a when it is non-zero, else b -- the real call is evaluated only when the gate answers hipSuccess)
+// hipEventQuery / hipStreamQuery are NOT gated: they are polls in spin loops (how many are made depends on timing, which would make
+// the n-th call of a run mean something else every time), they change nothing, and whatever they answer the collecting call that
+// follows synchronises for real -- that one is gated.
 #define hipMalloc(...) ((hipError_t)(zk::fault::gate() ?: hipMalloc(__VA_ARGS__)))
 #define hipHostMalloc(...) ((hipError_t)(zk::fault::gate() ?: hipHostMalloc(__VA_ARGS__)))
 #define hipMemcpy(...) ((hipError_t)(zk::fault::gate() ?: hipMemcpy(__VA_ARGS__)))
@@ -58,12 +61,10 @@ inline hipError_t gate() {
 #define hipEventCreateWithFlags(...) ((hipError_t)(zk::fault::gate() ?: hipEventCreateWithFlags(__VA_ARGS__)))
 #define hipEventRecord(...) ((hipError_t)(zk::fault::gate() ?: hipEventRecord(__VA_ARGS__)))
 #define hipEventSynchronize(...) ((hipError_t)(zk::fault::gate() ?: hipEventSynchronize(__VA_ARGS__)))
-#define hipEventQuery(...) ((hipError_t)(zk::fault::gate() ?: hipEventQuery(__VA_ARGS__)))
 #define hipStreamCreate(...) ((hipError_t)(zk::fault::gate() ?: hipStreamCreate(__VA_ARGS__)))
 #define hipStreamCreateWithFlags(...) ((hipError_t)(zk::fault::gate() ?: hipStreamCreateWithFlags(__VA_ARGS__)))
 #define hipStreamCreateWithPriority(...) ((hipError_t)(zk::fault::gate() ?: hipStreamCreateWithPriority(__VA_ARGS__)))
 #define hipStreamSynchronize(...) ((hipError_t)(zk::fault::gate() ?: hipStreamSynchronize(__VA_ARGS__)))
 #define hipStreamWaitEvent(...) ((hipError_t)(zk::fault::gate() ?: hipStreamWaitEvent(__VA_ARGS__)))
-#define hipStreamQuery(...) ((hipError_t)(zk::fault::gate() ?: hipStreamQuery(__VA_ARGS__)))
 #define hipDeviceSynchronize(...) ((hipError_t)(zk::fault::gate() ?: hipDeviceSynchronize(__VA_ARGS__)))
 #define hipGetLastError(...) ((hipError_t)(zk::fault::gate() ?: hipGetLastError(__VA_ARGS__)))
