@@ -52,7 +52,7 @@ import os
 # the host, so the ONLY RCCL communicator of a rank is the library's own (zkgpu_comm): the process holds the streams of one
 # verifier and one communicator, as at N = 1, and asks for the same number of queues.  Until round 3 torch's "nccl" group
 # was a second communicator per rank and the bench asked for 16 to leave it room.)
-# (18 = what zkgpu_init itself asks for when it is the process's first HIP user -- here torch may be: the runtime keeps that
+# (18 = what zkgpu_runtime_hint recommends -- the library never exports it itself; here torch may be the first HIP user: the runtime keeps that
 # many queues per stream priority, the verifier's low- and default-priority streams come on top, and from 25 in all the
 # device stops running them side by side in one process out of four: DESIGN.md sec 5.1, profiles/archive/r04v / r04w)
 _HWQ_PRESET = "GPU_MAX_HW_QUEUES" in os.environ

@@ -368,8 +368,8 @@ int zkgpu_verifier_create(zkgpu_ctx* ctx, const zkgpu_pointset* ps, size_t gens_
   v->lanes_requested = batches_in_flight;
   // A lane is worth having only if its light stream -- the latency-bound kernels of its batch: transcript, Horner chains,
   // verdicts -- really runs beside the other lanes'.  The runtime hands out a limited number of hardware queues
-  // (GPU_MAX_HW_QUEUES, read once when HIP starts: 4 unless the process exported more BEFORE its first HIP call; zkgpu_init
-  // sets 24 when it is the first), and streams beyond that share queues: two lanes on one queue take turns, and when they
+  // (GPU_MAX_HW_QUEUES, read once when HIP starts: 4 unless the process exported more BEFORE its first HIP call -- the host does,
+  // on zkgpu_runtime_hint's advice), and streams beyond that share queues: two lanes on one queue take turns, and when they
   // also wait for each other's events they crawl (measured in round 2: 3x - 10x slower with 8 and 10 lanes than with 7 and
   // 9).  So every new lane is probed against the lanes kept so far (two spinning wavefronts, ~0.2 ms per pair, idle
   // device assumed) and not kept if it serialises with one of them; a stream made next lands on the runtime's next queue, so

@@ -3345,11 +3345,11 @@ int zkgpu_bulletproof_gens(zkgpu_ctx* c, size_t capacity, uint32_t party, uint8_
 
 // Diagnostics of the stream -> hardware-queue mapping (idle device assumed).  out[0]: do this context's two pipeline
 // streams run side by side (1 / 0; -1: the probe failed) -- probed afresh; out[1]: GPU_MAX_HW_QUEUES as the process sees
-// it (0: unset); out[2]: 1 when that value came too late -- the HIP runtime had started, with the variable unset, before
-// the first zkgpu_init of the process.  The variable is read by the HIP runtime ONCE, when it starts: zkgpu_init sets it to 24 if it is unset,
-// which only helps when no HIP call came before -- an embedding application that touched HIP first gets the runtime's
-// default of 4 queues unless it exported the variable itself.  The library does not trust the variable: it probes what it
-// got (here, and per lane in zkgpu_verifier_create).
+// it (0: unset); out[2]: 1 when that value came too late -- the HIP runtime had started with the variable unset (seen by
+// zkgpu_runtime_hint or by the first zkgpu_init of the process).  The variable is read by the HIP runtime ONCE, when it
+// starts; the HOST exports it on zkgpu_runtime_hint's advice before its first HIP call -- the library never sets it -- and an
+// application that touched HIP first runs on the runtime's default of 4 queues.  The library does not trust the variable: it
+// probes what it got (here, and per lane in zkgpu_verifier_create).
 int zkgpu_ctx_queue_info(zkgpu_ctx* c, int out[3]) {
   if (!c || !out) return ZKGPU_EINVAL;
   std::lock_guard<std::recursive_mutex> lk(c->mu);
