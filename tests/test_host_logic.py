@@ -459,3 +459,39 @@ def test_host_worker_pool(host):
     except (OSError, ValueError):
         pass
     assert host.zkhost_pool_selftest(1, 1) == 0
+
+
+def test_ticket_bursts_are_cut_into_equal_device_batches(host):
+    """csrc/ticket_cut.hpp, the policy of session.hpp's ticket_dispatch (round 6): what is queued of one
+    shape leaves in round(queued / target) device batches, every ticket in exactly one, in queue order, sizes equal to within
+    one ticket; uniform bursts of 16 / 20 / 24 / 37 at a target of ten tickets are 8 + 8, 10 + 10, 12 + 12, 10 + 9 + 9 + 9;
+    a batch never exceeds 1.5 targets + one ticket; drawn ticket sizes obey the same invariants."""
+    import random
+    host.zkhost_ticket_cut.restype = C.c_size_t
+
+    def cut(sizes, target):
+        arr = (C.c_uint64 * len(sizes))(*sizes)
+        out = (C.c_uint64 * (len(sizes) + 1))()
+        n = host.zkhost_ticket_cut(arr, C.c_size_t(len(sizes)), C.c_uint64(target), out, C.c_size_t(len(sizes) + 1))
+        return [int(out[i]) for i in range(n)]
+
+    for burst, want in ((16, [8, 8]), (20, [10, 10]), (24, [12, 12]), (37, [10, 9, 9, 9]), (25, [9, 8, 8]), (4, [4]), (1, [1]), (14, [14]), (15, [8, 7])):
+        assert cut([1024] * burst, 10240) == want, burst
+    assert cut([], 10240) == []
+    assert cut([11 * 1024], 10240) == [1]                                # a ticket larger than the target is a batch of its own
+    rng = random.Random(66)
+    for _ in range(300):
+        target = rng.choice([480, 4096, 10240])
+        sizes = [rng.choice([1, 7, 48, 64, 1024, 3000]) for _ in range(rng.randrange(1, 60))]
+        got = cut(sizes, target)
+        total = sum(sizes)
+        assert sum(got) == len(sizes) and all(g >= 1 for g in got)
+        parts = max(1, (total + target // 2) // target)
+        assert len(got) <= parts                                             # (a big ticket may finish a later part's share early)
+        at, batch_tx = 0, []
+        for g in got:
+            batch_tx.append(sum(sizes[at: at + g]))
+            at += g
+        assert max(batch_tx) <= (3 * target) // 2 + max(sizes) + target // max(parts, 1)
+        if len(set(sizes)) == 1 and len(got) == parts:                       # uniform tickets: equal to within one ticket
+            assert max(got) - min(got) <= 1

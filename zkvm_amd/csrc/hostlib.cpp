@@ -759,6 +759,15 @@ extern "C" uint64_t zkhost_pool_selftest(uint32_t rounds, uint32_t callers) {
 
 // ---- the framing of the sharded verification's one exchange (comm_frame.hpp), for the CPU tests: a world of any size is
 // ---- the test concatenating the slots its "ranks" packed
+#include "ticket_cut.hpp"
+// the device batches a burst of tickets leaves in (tickets per batch) under the equal-parts policy; returns their number
+extern "C" size_t zkhost_ticket_cut(const uint64_t* sizes, size_t n, uint64_t target, uint64_t* out_counts, size_t cap) {
+  std::vector<size_t> v(sizes, sizes + n);
+  const std::vector<size_t> cut = zk::ticket_cut(v, (size_t)target);
+  for (size_t i = 0; i < cut.size() && i < cap; ++i) out_counts[i] = cut[i];
+  return cut.size();
+}
+
 #include "comm_frame.hpp"
 extern "C" size_t zkhost_comm_slot_bytes(const uint64_t* cuts, int world) { return commframe::slot_bytes(cuts, world); }
 extern "C" void zkhost_comm_pack(uint8_t* out, size_t slot, const uint64_t* cuts, int rank, const uint8_t* local_bitmap, int local_status) {

@@ -899,10 +899,10 @@ int ticket_dispatch(zkgpu_verifier* v, bool force) {       // v->mu held
     const bool same_cut = owed > 0 && owed_shape[0] == head->n_in && owed_shape[1] == head->n_out && owed_shape[2] == head->proof_len;
     if (!same_cut) {
       if (queued < target && !force) return ZKGPU_OK;
-      owed = std::max<size_t>(1, (queued + target / 2) / target);
+      owed = zk::ticket_parts(queued, target);            // (ticket_cut.hpp: the policy, also driven by the CPU tests)
       owed_shape[0] = head->n_in; owed_shape[1] = head->n_out; owed_shape[2] = head->proof_len;
     }
-    const size_t quota = (queued + owed - 1) / owed;
+    const size_t quota = zk::ticket_quota(queued, owed);
     std::vector<zkgpu_request*> pick;
     size_t total = 0;
     for (zkgpu_request* r : v->queue) {

@@ -41,6 +41,7 @@
 #include "prover_kernels.hpp"
 #include "zkvm_tx.hpp"
 #include "host_pool.hpp"
+#include "ticket_cut.hpp"
 
 using namespace zk;
 
