@@ -225,7 +225,7 @@ k_decompress_pre(const uint32_t* __restrict__ pts, uint32_t* __restrict__ scratc
 // row[50..59] <- row[50..59]^((p-5)/8)
 // ZK_POW_WAVES wavefronts per SIMD: at 4 (until round 6) the kernel is held to 128 registers -- 84 bytes of it in scratch -- and
 // takes EVERY register of every SIMD, so that the digit sort "beside" it (k_part_*: 20 - 52 registers a lane) only ran as its
-// workgroups retired, a quarter of the chip every 226 us (profiles/r06b_*: k_part_offsets, 4 MB of counters,
+// workgroups retired, a quarter of the chip every 226 us (profiles/r06c_*: k_part_offsets, 4 MB of counters,
 // 207 us).  One wavefront alone issues every 4.6 cycles, two every 4.3: a chain of dependent squarings
 // does not need the fourth.
 #ifndef ZK_POW_WAVES
@@ -721,7 +721,7 @@ __device__ __forceinline__ void bucket_fat_role(const uint32_t* __restrict__ cur
 // The first `fat_blocks` workgroups of the grid sum the fat bins (bucket_fat_role), the others one bin per lane.  ONE launch:
 // the fat groups carry the longest chains (up to HEAVY_BIN / FAT_LANES additions and four folds) and must START first -- as a
 // kernel of their own on a second stream they got their slots only as the one-lane-per-bin workgroups retired and ended when
-// those did (profiles/r06b_*), queued ahead on the same stream they cost their 84 us on an idle chip.
+// those did (profiles/r06c_*), queued ahead on the same stream they cost their 84 us on an idle chip.
 __global__ void __launch_bounds__(256)
 k_bucket_accumulate(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ entries,
                     const uint32_t* __restrict__ static_rows, const uint32_t* __restrict__ dyn_rows,
